@@ -1,0 +1,368 @@
+#!/usr/bin/env node
+/*
+ * gen_golden.js — TEST INFRASTRUCTURE ONLY (never imported by the product path).
+ *
+ * Runs the REAL reference modules (KORandi/bullet-js, mounted read-only at
+ * $BULLET_REF or /root/reference) under Node on seeded synthetic inputs and
+ * writes input-spec / expected-output pairs into tests/golden/*.json.
+ * Only *data* is written: no reference source text is copied anywhere.
+ *
+ * What is exercised (reference file:line):
+ *   - BulletCRT.processUpdate / resolve            src/bullet-crt.js:164-318   (oracle level L0)
+ *   - Bullet.setData -> crt.handleUpdate -> apply  src/bullet.js:139-220, src/bullet-crt.js:329-385 (L1)
+ *   - BulletQuery.index/equals/range/count/filter  src/bullet-query.js:30-313
+ *
+ * The stream generator below is mirrored bit-for-bit by oracle/streams.py; a
+ * mismatch between the two shows up as a digest mismatch in tests/test_oracle_golden.py.
+ *
+ * Usage: node oracle/gen_golden.js [outdir]      (default: tests/golden)
+ */
+"use strict";
+const fs = require("fs");
+const path = require("path");
+
+const REF = process.env.BULLET_REF || "/root/reference";
+const OUT = process.argv[2] || path.join(__dirname, "..", "tests", "golden");
+const BulletCRT = require(path.join(REF, "src", "bullet-crt.js"));
+
+/* ------------------------------------------------------------------ PRNG / hashes */
+const M64 = (1n << 64n) - 1n;
+function xorshift32(seed) {
+  let s = seed >>> 0;
+  if (s === 0) s = 0x9e3779b9;
+  return function next() {
+    s ^= s << 13; s >>>= 0;
+    s ^= s >>> 17;
+    s ^= s << 5; s >>>= 0;
+    return s;
+  };
+}
+function splitmix64(x) {
+  let z = (BigInt.asUintN(64, x) + 0x9e3779b97f4a7c15n) & M64;
+  z = ((z ^ (z >> 30n)) * 0xbf58476d1ce4e5b9n) & M64;
+  z = ((z ^ (z >> 27n)) * 0x94d049bb133111ebn) & M64;
+  return z ^ (z >> 31n);
+}
+function fnv1a32(str) {
+  let h = 0x811c9dc5;
+  for (let i = 0; i < str.length; i++) {
+    h ^= str.charCodeAt(i) & 0xff;
+    h = Math.imul(h, 0x01000193) >>> 0;
+  }
+  return h >>> 0;
+}
+function fieldHash(fi) { return fnv1a32("f" + fi); }
+function rowId(row, F) { return splitmix64(BigInt(Math.floor(row / F)) + 1n); }
+function rowField(row, F) { return fieldHash(row % F); }
+
+/* order-independent digest of a (id, field, ts, val) row set */
+function rowDigest(id, field, ts, val) {
+  let h = splitmix64(BigInt.asUintN(64, BigInt(val)));
+  h = splitmix64(h ^ BigInt.asUintN(64, BigInt(ts)));
+  h = splitmix64(h ^ BigInt(field));
+  h = splitmix64(h ^ id);
+  return h;
+}
+
+/* ------------------------------------------------------------------ stream spec -> rows */
+const PERM_PRIME = 1000003;
+function genStream(spec) {
+  const rng = xorshift32(spec.seed);
+  const F = spec.F || 1;
+  const resident = [];
+  for (let r = 0; r < spec.R; r++) {
+    const ts = spec.T0 + (rng() % spec.DT);
+    const val = (rng() % spec.VR) - spec.VOFF;
+    resident.push({ row: r, ts, val });
+  }
+  const deltas = [];
+  const insSpace = spec.ins_space || Math.max(1, Math.floor(spec.R / 10));
+  for (let j = 0; j < spec.D; j++) {
+    const u = rng() % 100;
+    let row;
+    if (u < spec.insert_pct) {
+      row = spec.unique ? spec.R + j : spec.R + (rng() % insSpace);
+    } else if (u < spec.insert_pct + spec.hot_pct) {
+      row = rng() % spec.H;
+    } else if (spec.unique) {
+      row = (j * PERM_PRIME + 7) % spec.R;
+    } else {
+      row = rng() % spec.R;
+    }
+    const ts = spec.T0 + (rng() % (2 * spec.DT));
+    const val = (rng() % spec.VR) - spec.VOFF;
+    deltas.push({ row, ts, val });
+  }
+  return { resident, deltas, F };
+}
+
+/* ------------------------------------------------------------------ L0 harness around the real BulletCRT */
+const WID = "w";
+function newCrt() { return new BulletCRT({ id: WID, meta: {}, _getData() { return undefined; } }); }
+function flagsOf(d) {
+  return (d.incoming ? 1 : 0) | (d.current ? 2 : 0) | (d.historical ? 4 : 0) | (d.concurrent ? 8 : 0);
+}
+function clockTs(clock) {
+  const ks = Object.keys(clock);
+  if (ks.length !== 1 || ks[0] !== WID) throw new Error("off-contract clock " + JSON.stringify(clock));
+  return clock[WID];
+}
+/* state: Map key -> {value, clock}; returns decision */
+function applyDelta(crt, state, key, ts, val) {
+  const cur = state.get(key);
+  const r = crt.processUpdate(key, val, { [WID]: ts }, cur ? cur.value : undefined, cur ? cur.clock : undefined);
+  const d = r.decision;
+  /* store rule of the caller: src/bullet-crt.js:383 + src/bullet.js:144-148 */
+  if (d.incoming || !cur || d.concurrent) state.set(key, { value: r.value, clock: r.vectorClock });
+  return d;
+}
+
+function runStream(spec) {
+  const { resident, deltas, F } = genStream(spec);
+  const crt = newCrt();
+  const state = new Map();
+  const keyOf = (row) => rowId(row, F).toString(16) + ":" + rowField(row, F);
+  for (const r of resident) state.set(keyOf(r.row), { value: r.val, clock: { [WID]: r.ts }, row: r.row });
+  const flags = Buffer.alloc(deltas.length);
+  const lastApplied = new Map();
+  let nApplied = 0, nHist = 0;
+  deltas.forEach((d, j) => {
+    const key = keyOf(d.row);
+    const dec = applyDelta(crt, state, key, d.ts, d.val);
+    flags[j] = flagsOf(dec);
+    if (dec.concurrent) throw new Error("concurrent branch hit: off-contract");
+    if (dec.incoming) { lastApplied.set(key, j); nApplied++; state.get(key).row = d.row; }
+    if (dec.historical) nHist++;
+  });
+  const winners = Array.from(lastApplied.values()).sort((a, b) => a - b);
+  let digest = 0n;
+  const finalRows = [];
+  for (const [, st] of state) {
+    const ts = clockTs(st.clock);
+    digest = (digest + rowDigest(rowId(st.row, F), rowField(st.row, F), ts, st.value)) & M64;
+    finalRows.push([st.row, ts, st.value]);
+  }
+  finalRows.sort((a, b) => a[0] - b[0]);
+  const out = {
+    kind: "stream",
+    source: "reference BulletCRT.processUpdate (src/bullet-crt.js:304-318), single-component clocks {w:ts}",
+    spec,
+    n_rows_final: state.size,
+    n_incoming: nApplied,
+    n_historical: nHist,
+    flags_b64: flags.toString("base64"),
+    winners,
+    digest: digest.toString(16),
+  };
+  if (spec.store_final) out.final_rows = finalRows; /* [row ordinal, ts, val] */
+  else out.final_sample = finalRows.filter((_, i) => i % Math.ceil(finalRows.length / 200) === 0);
+  return out;
+}
+
+/* ------------------------------------------------------------------ G1/G3: decision table + ts edge cases */
+function genDecisionTable() {
+  const TS = [0, 1, 2, 3, 2147483647, 2147483648, 2147483649, Number.MAX_SAFE_INTEGER];
+  const VALS = [-5, 0, 7];
+  const VEDGE = [-(2 ** 53 - 1), 2 ** 53 - 1, -1, 1];
+  const cases = [];
+  const one = (cur, a, v) => {
+    const crt = newCrt();
+    const r = crt.processUpdate("k", v, { [WID]: a }, cur ? cur.val : undefined, cur ? { [WID]: cur.ts } : undefined);
+    const d = r.decision;
+    cases.push({
+      cur: cur ? [cur.ts, cur.val] : null, inc: [a, v], flags: flagsOf(d),
+      out: [clockTs(r.vectorClock), r.value], reason: d.reason,
+    });
+  };
+  for (const a of TS) for (const v of VALS) one(null, a, v);
+  for (const b of TS) for (const c of VALS) for (const a of TS) for (const v of VALS) one({ ts: b, val: c }, a, v);
+  for (const c of VEDGE) for (const v of VEDGE) { one({ ts: 5, val: c }, 5, v); one({ ts: 5, val: c }, 6, v); one({ ts: 6, val: c }, 5, v); }
+  return { kind: "decision_table", source: "reference BulletCRT.processUpdate, fresh resolver per case", cases };
+}
+
+/* G3: short scripted sequences on one key over tiny domains: exercises the insert quirk ({w:2}) */
+function genSequences() {
+  const rng = xorshift32(424242);
+  const seqs = [];
+  for (let s = 0; s < 300; s++) {
+    const crt = newCrt();
+    const state = new Map();
+    const startResident = (rng() % 3) === 0;
+    let start = null;
+    if (startResident) { start = [rng() % 5, (rng() % 3) - 1]; state.set("k", { value: start[1], clock: { [WID]: start[0] } }); }
+    const n = 2 + (rng() % 7);
+    const deltas = [], flags = [];
+    let winner = -1;
+    for (let j = 0; j < n; j++) {
+      const ts = rng() % 5, val = (rng() % 3) - 1;
+      const d = applyDelta(crt, state, "k", ts, val);
+      deltas.push([ts, val]); flags.push(flagsOf(d));
+      if (d.incoming) winner = j;
+    }
+    const st = state.get("k");
+    seqs.push({ start, deltas, flags, final: [clockTs(st.clock), st.value], winner });
+  }
+  return { kind: "sequences", source: "reference BulletCRT.processUpdate, one key, ts in 0..4, val in -1..1", seqs };
+}
+
+/* ------------------------------------------------------------------ L1 / query fixtures through the real Bullet facade */
+function quiet(fn) { const l = console.log; console.log = () => {}; try { return fn(); } finally { console.log = l; } }
+function newBullet(extra) {
+  const Bullet = require(path.join(REF, "src", "bullet.js"));
+  return quiet(() => {
+    const b = new Bullet(Object.assign({ disableNetwork: true, storage: false, server: false, enableMiddleware: false,
+      enableValidation: false, enableSerializer: false }, extra || {}));
+    b.id = WID;
+    return b;
+  });
+}
+function genL1() {
+  /* scripted node-level ops; expected store/meta after each op. enableIndexing:false so setData returns the value */
+  const b = newBullet({ enableIndexing: false });
+  const ops = [
+    { path: "users/bob", data: { name: "Bob", age: 30, __fromNetwork: true, __vectorClock: { w: 5 } } },
+    { path: "users/bob", data: { name: "Bobby", __fromNetwork: true, __vectorClock: { w: 7 } } },          /* dominate -> whole-object replace */
+    { path: "users/bob", data: { name: "Old", age: 1, __fromNetwork: true, __vectorClock: { w: 6 } } },     /* historical */
+    { path: "users/bob", data: { name: "Aaa", __fromNetwork: true, __vectorClock: { w: 7 } } },             /* tie: objects compare +1 -> incoming */
+    { path: "users/bob", data: { name: "Aaa", __fromNetwork: true, __vectorClock: { w: 7 } } },             /* tie again, still incoming (objects never ===) */
+    { path: "users/amy", data: { city: "X", __fromNetwork: true, __vectorClock: { w: 3 } } },               /* insert quirk: stored clock {w:2} */
+    { path: "users/amy", data: { city: "Y", __fromNetwork: true, __vectorClock: { w: 1 } } },               /* 1 < 2 -> historical */
+    { path: "users/amy", data: { city: "Z", __fromNetwork: true, __vectorClock: { w: 2 } } },               /* 2 == 2 -> tie -> incoming */
+    { path: "users/cat", data: { a: 1, n: { x: 1 }, __fromNetwork: true, __vectorClock: { w: 4, p: 1 } } },
+    { path: "users/cat", data: { b: 2, n: { y: 2 }, __fromNetwork: true, __vectorClock: { w: 3, q: 9 } } }, /* after insert clock is {w:2}: concurrent -> deep merge */
+    { path: "users/cat", data: { b: 5, c: 3, n: { y: 1, z: 3 }, __fromNetwork: true, __vectorClock: { w: 1, p: 50 } } }, /* truly concurrent vs {w:3,q:9}: deep merge, per-leaf compare */
+    { path: "cfg/theme", data: "dark" },                                                                     /* local primitive writes */
+    { path: "cfg/theme", data: "light" },
+    { path: "cfg/theme", data: "light" },
+    { path: "cfg/n", data: 41 },
+    { path: "cfg/n", data: 40 },
+  ];
+  const steps = [];
+  for (const op of ops) {
+    const hu = JSON.parse(JSON.stringify(op.data));
+    const ret = quiet(() => b.setData(op.path, op.data, false));
+    steps.push({
+      path: op.path, data: hu, ret: ret === undefined ? null : JSON.parse(JSON.stringify(ret)),
+      store: JSON.parse(JSON.stringify(b.store)),
+      clock: b.meta[op.path] ? JSON.parse(JSON.stringify(b.meta[op.path].vectorClock)) : null,
+      source: b.meta[op.path] ? b.meta[op.path].source : null,
+      log_len: b.log.length,
+    });
+  }
+  return { kind: "l1_ops", source: "reference Bullet.setData -> BulletCRT.handleUpdate (src/bullet.js:139-220, src/bullet-crt.js:329-385), bullet.id='w'", steps };
+}
+
+function childKeys(nodes) { return nodes.map((n) => n.path.split("/").pop()); }
+
+function genQueryExample() {
+  /* known-answer dataset (values only) of examples/bullet-query-example.js:17-47 */
+  const users = {
+    user1: { name: "Alice Johnson", age: 28, active: true, role: "admin" }, user2: { name: "Bob Smith", age: 35, active: true, role: "user" },
+    user3: { name: "Carol Davis", age: 42, active: false, role: "user" }, user4: { name: "Dave Wilson", age: 23, active: true, role: "editor" },
+    user5: { name: "Eve Brown", age: 31, active: true, role: "user" }, user6: { name: "Frank Miller", age: 47, active: false, role: "admin" },
+    user7: { name: "Grace Lee", age: 29, active: true, role: "editor" }, user8: { name: "Harry Taylor", age: 39, active: true, role: "user" },
+    user9: { name: "Irene Clark", age: 26, active: false, role: "user" }, user10: { name: "Jack Roberts", age: 33, active: true, role: "admin" },
+  };
+  const products = {
+    prod1: { name: "Laptop", price: 1200, stock: 15, category: "electronics" }, prod2: { name: "Smartphone", price: 800, stock: 25, category: "electronics" },
+    prod3: { name: "Headphones", price: 150, stock: 50, category: "accessories" }, prod4: { name: "Mouse", price: 30, stock: 100, category: "accessories" },
+    prod5: { name: "Keyboard", price: 80, stock: 40, category: "accessories" }, prod6: { name: "Monitor", price: 300, stock: 20, category: "electronics" },
+    prod7: { name: "Desk Chair", price: 250, stock: 10, category: "furniture" }, prod8: { name: "Desk", price: 400, stock: 5, category: "furniture" },
+    prod9: { name: "Printer", price: 200, stock: 8, category: "electronics" }, prod10: { name: "Camera", price: 600, stock: 12, category: "electronics" },
+  };
+  const b = newBullet({ enableIndexing: true });
+  quiet(() => {
+    for (const [k, v] of Object.entries(users)) b.get("users/" + k).put(v);
+    for (const [k, v] of Object.entries(products)) b.get("products/" + k).put(v);
+  });
+  const q = [];
+  const rec = (name, args, nodes) => q.push({ op: name, args, keys: childKeys(nodes) });
+  quiet(() => {
+    rec("range", ["users", "age", 30, 40], b.range("users", "age", 30, 40));
+    rec("range", ["users", "age", 0, 1000], b.range("users", "age", 0, 1000));
+    rec("range", ["users", "age", 40, 30], b.range("users", "age", 40, 30));
+    rec("equals", ["users", "age", 42], b.equals("users", "age", 42));
+    rec("equals", ["users", "age", "42"], b.equals("users", "age", "42"));
+    rec("equals", ["users", "age", 99], b.equals("users", "age", 99));
+    rec("range", ["products", "price", 100, 500], b.range("products", "price", 100, 500));
+    rec("range", ["products", "price", 600, Infinity], b.range("products", "price", 600, "Infinity"));
+    rec("range", ["products", "stock", 10, 25], b.range("products", "stock", 10, 25));
+    rec("equals", ["products", "stock", 50], b.equals("products", "stock", 50));
+    rec("filter", ["products", "price>=200&&stock<=12"], b.filter("products", (p) => p.price >= 200 && p.stock <= 12));
+    q.push({ op: "count", args: ["users", "age", 35], n: b.query.count("users", "age", 35) });
+    q.push({ op: "count", args: ["products", "price", 30], n: b.query.count("products", "price", 30) });
+    q.push({ op: "range_undefined_max", args: ["users", "age", 30], keys: childKeys(b.range("users", "age", 30, undefined)) });
+  });
+  /* the Infinity query above used the string form to survive JSON; redo with a real Infinity */
+  q[7] = { op: "range", args: ["products", "price", 600, "Infinity"], keys: quiet(() => childKeys(b.range("products", "price", 600, Infinity))) };
+  return { kind: "query_example", source: "reference BulletQuery via Bullet facade (src/bullet-query.js:186-313), dataset values of examples/bullet-query-example.js:17-47",
+    users, products, queries: q, indices: Object.keys(b.query.indices) };
+}
+
+function genQuerySeeded(N, seed, full) {
+  const rng = xorshift32(seed);
+  const b = newBullet({ enableIndexing: true });
+  const ages = new Array(N), scores = new Array(N);
+  quiet(() => {
+    for (let i = 0; i < N; i++) {
+      ages[i] = rng() % 100; scores[i] = (rng() % 200001) - 100000;
+      /* network-tagged object write with scalar clock, as sync entries arrive (src/bullet-network-sync.js:551-569) */
+      b.setData("n/k" + i, { age: ages[i], score: scores[i], __fromNetwork: true, __vectorClock: { w: 10 + (i % 7) } }, false);
+    }
+  });
+  const ord = (nodes) => nodes.map((n) => parseInt(n.path.split("/").pop().slice(1), 10));
+  const sum = (a) => a.reduce((x, y) => x + y, 0);
+  const queries = [];
+  const rec = (op, field, args, nodes) => {
+    const o = ord(nodes);
+    const e = { op, field, args, count: o.length, ordinal_sum: sum(o) };
+    if (full) e.ordinals = o; /* reference order */
+    queries.push(e);
+  };
+  quiet(() => {
+    rec("equals", "age", [42], b.equals("n", "age", 42));
+    rec("equals", "age", [0], b.equals("n", "age", 0));
+    rec("equals", "age", [100], b.equals("n", "age", 100));
+    rec("range", "age", [20, 30], b.range("n", "age", 20, 30));
+    rec("range", "age", [0, 99], b.range("n", "age", 0, 99));
+    rec("range", "age", [50, 49], b.range("n", "age", 50, 49));
+    rec("range", "age", [99, 1e9], b.range("n", "age", 99, 1e9));
+    rec("range", "score", [-100, 100], b.range("n", "score", -100, 100));
+    rec("range", "score", [-100000, -99000], b.range("n", "score", -100000, -99000));
+    rec("range", "score", [0, 100000], b.range("n", "score", 0, 100000));
+    rec("equals", "score", [scores[3]], b.equals("n", "score", scores[3]));
+    queries.push({ op: "count", field: "age", args: [7], count: b.query.count("n", "age", 7) });
+    rec("filter_and", "age,score", [[25, 35], [0, 50000]], b.filter("n", (v) => v.age >= 25 && v.age <= 35 && v.score >= 0 && v.score <= 50000));
+  });
+  return { kind: "query_seeded", source: "reference BulletQuery (fresh index: queries issued after all writes)", N, seed,
+    gen: "for i<N: age=rng()%100; score=rng()%200001-100000 (xorshift32, interleaved per node)", queries };
+}
+
+/* ------------------------------------------------------------------ main */
+function write(name, obj) {
+  const p = path.join(OUT, name);
+  fs.writeFileSync(p, JSON.stringify(obj));
+  console.log("wrote", p, fs.statSync(p).size, "bytes");
+}
+const BASE = { T0: 1000, DT: 1000, VR: 1000, VOFF: 0, F: 1, H: 16, hot_pct: 0, insert_pct: 0, unique: false, store_final: false };
+const STREAMS = {
+  /* config-1 shape of BASELINE.md: R=100k, D=10k, ts~U[1000,2000) / U[1000,3000), val~U[0,1000) */
+  "g2_stream_cfg1_100k_10k.json": Object.assign({}, BASE, { seed: 12345, R: 100000, D: 10000 }),
+  "g2_stream_unique_10k_10k.json": Object.assign({}, BASE, { seed: 777, R: 10000, D: 10000, unique: true, store_final: true }),
+  "g2_stream_unique_insert_10k_4k.json": Object.assign({}, BASE, { seed: 778, R: 10000, D: 4000, unique: true, insert_pct: 10, store_final: true }),
+  "g2_stream_hot30_10k_10k.json": Object.assign({}, BASE, { seed: 31337, R: 10000, D: 10000, hot_pct: 30, H: 10, store_final: true }),
+  "g2_stream_insert10_1k_10k.json": Object.assign({}, BASE, { seed: 99, R: 1000, D: 10000, insert_pct: 10, store_final: true }),
+  "g2_stream_ties_1k_10k.json": Object.assign({}, BASE, { seed: 5, R: 1000, D: 10000, T0: 0, DT: 2, VR: 3, VOFF: 1, insert_pct: 15, hot_pct: 20, H: 5, store_final: true }),
+  "g2_stream_multifield_1k_1k.json": Object.assign({}, BASE, { seed: 2024, R: 4000, D: 4000, F: 4, insert_pct: 5, store_final: true }),
+  "g2_stream_mixed_100k_10k.json": Object.assign({}, BASE, { seed: 8086, R: 100000, D: 10000, insert_pct: 10, hot_pct: 30, H: 100, VR: 2000, VOFF: 1000 }),
+  "g2_stream_empty_start_0_1k.json": Object.assign({}, BASE, { seed: 3, R: 0, D: 1000, insert_pct: 100, ins_space: 300, store_final: true }),
+};
+
+fs.mkdirSync(OUT, { recursive: true });
+write("g1_decision_table.json", genDecisionTable());
+write("g3_sequences.json", genSequences());
+for (const [name, spec] of Object.entries(STREAMS)) write(name, runStream(spec));
+write("g4_l1_ops.json", genL1());
+write("g5_query_example.json", genQueryExample());
+write("g5_query_seeded_2k.json", genQuerySeeded(2000, 4711, true));
+write("g5_query_seeded_100k.json", genQuerySeeded(100000, 4712, false));

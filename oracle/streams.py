@@ -1,0 +1,131 @@
+"""Seeded synthetic delta streams — TEST INFRASTRUCTURE ONLY.
+
+gen_stream() mirrors genStream() of oracle/gen_golden.js bit for bit (xorshift32, same draw order), so
+the golden fixtures only need to store the spec, not the inputs. big_stream() is the vectorised
+counter-based generator used for bench-sized inputs (SURVEY §8(d) config 2/5 shapes).
+"""
+import numpy as np
+
+PERM_PRIME = 1000003
+M64 = (1 << 64) - 1
+
+
+def splitmix64(x):
+    z = (x + 0x9e3779b97f4a7c15) & M64
+    z = ((z ^ (z >> 30)) * 0xbf58476d1ce4e5b9) & M64
+    z = ((z ^ (z >> 27)) * 0x94d049bb133111eb) & M64
+    return z ^ (z >> 31)
+
+
+def splitmix64_np(x):
+    with np.errstate(over="ignore"):
+        z = x.astype(np.uint64) + np.uint64(0x9e3779b97f4a7c15)
+        z = (z ^ (z >> np.uint64(30))) * np.uint64(0xbf58476d1ce4e5b9)
+        z = (z ^ (z >> np.uint64(27))) * np.uint64(0x94d049bb133111eb)
+        return z ^ (z >> np.uint64(31))
+
+
+def fnv1a32(s):
+    h = 0x811c9dc5
+    for ch in s.encode("utf-8"):
+        h ^= ch
+        h = (h * 0x01000193) & 0xffffffff
+    return h
+
+
+def field_hash(fi):
+    return fnv1a32("f%d" % fi)
+
+
+class XorShift32:
+    def __init__(self, seed):
+        self.s = (seed & 0xffffffff) or 0x9e3779b9
+
+    def __call__(self):
+        s = self.s
+        s ^= (s << 13) & 0xffffffff
+        s ^= s >> 17
+        s ^= (s << 5) & 0xffffffff
+        self.s = s
+        return s
+
+
+def row_id(row, F):
+    return splitmix64(row // F + 1)
+
+
+def rows_to_keys(rows, F):
+    rows = np.asarray(rows, dtype=np.int64)
+    ids = splitmix64_np((rows // F + 1).astype(np.uint64))
+    fh = np.array([field_hash(i) for i in range(F)], dtype=np.uint32)
+    return ids, fh[rows % F]
+
+
+def gen_stream(spec):
+    """Returns dict(resident=(rows, id, field, ts, val), deltas=(rows, id, field, ts, val))."""
+    rng = XorShift32(spec["seed"])
+    F = spec.get("F", 1) or 1
+    R, D = spec["R"], spec["D"]
+    T0, DT, VR, VOFF = spec["T0"], spec["DT"], spec["VR"], spec["VOFF"]
+    rts = np.zeros(R, np.int64); rval = np.zeros(R, np.int64)
+    for r in range(R):
+        rts[r] = T0 + rng() % DT
+        rval[r] = rng() % VR - VOFF
+    ins_space = spec.get("ins_space") or max(1, R // 10)
+    drow = np.zeros(D, np.int64); dts = np.zeros(D, np.int64); dval = np.zeros(D, np.int64)
+    for j in range(D):
+        u = rng() % 100
+        if u < spec["insert_pct"]:
+            row = R + j if spec["unique"] else R + rng() % ins_space
+        elif u < spec["insert_pct"] + spec["hot_pct"]:
+            row = rng() % spec["H"]
+        elif spec["unique"]:
+            row = (j * PERM_PRIME + 7) % R
+        else:
+            row = rng() % R
+        drow[j] = row
+        dts[j] = T0 + rng() % (2 * DT)
+        dval[j] = rng() % VR - VOFF
+    rrow = np.arange(R, dtype=np.int64)
+    rid, rf = rows_to_keys(rrow, F)
+    did, df = rows_to_keys(drow, F)
+    return dict(F=F, resident=(rrow, rid, rf, rts, rval), deltas=(drow, did, df, dts, dval))
+
+
+def _u(seed, n, salt):
+    """n uniform uint64 draws, counter-based (vectorised)."""
+    with np.errstate(over="ignore"):
+        i = np.arange(n, dtype=np.uint64)
+        return splitmix64_np(i * np.uint64(0x9E3779B97F4A7C15) + np.uint64((seed * 0x632BE59BD9B4E019 + salt * 0xD1342543DE82EF95) & M64))
+
+
+def big_resident(R, seed=1, T0=1_000_000, DT=1_000_000, F=1, row0=0):
+    """Resident rows row0..row0+R-1: id = splitmix64(node+1), ts~U[T0,T0+DT), val in ±2^31."""
+    rows = np.arange(row0, row0 + R, dtype=np.int64)
+    ids, fld = rows_to_keys(rows, F)
+    ts = (T0 + (_u(seed, R, 1) % np.uint64(DT))).astype(np.int64)
+    val = (_u(seed, R, 2) % np.uint64(1 << 32)).astype(np.int64) - (1 << 31)
+    return ids, fld, ts, val
+
+
+def big_deltas(D, R, seed=2, T0=1_000_000, DT=1_000_000, F=1, insert_pct=10, hot_pct=0, hot_keys=0, unique=True, batch=0):
+    """Config-2/5 shaped delta batch over a resident graph of R rows.
+
+    unique=True: hit rows are a stride permutation (no duplicate keys inside the batch), inserts get fresh rows.
+    ts ~ U[T0 + batch*DT/2, T0 + batch*DT/2 + 2*DT)."""
+    u = _u(seed + 7919 * batch, D, 3) % np.uint64(100)
+    j = np.arange(D, dtype=np.int64)
+    if unique:
+        hit_rows = (j * PERM_PRIME + 7 + batch * 7717) % R
+        ins_rows = R + batch * D + j
+    else:
+        hit_rows = (_u(seed + 7919 * batch, D, 4) % np.uint64(R)).astype(np.int64)
+        ins_rows = R + (_u(seed + 7919 * batch, D, 5) % np.uint64(max(1, R // 10))).astype(np.int64)
+    rows = np.where(u < insert_pct, ins_rows, hit_rows)
+    if hot_pct:
+        hot_rows = (_u(seed + 7919 * batch, D, 6) % np.uint64(max(1, hot_keys))).astype(np.int64)
+        rows = np.where((u >= insert_pct) & (u < insert_pct + hot_pct), hot_rows, rows)
+    ids, fld = rows_to_keys(rows, F)
+    ts = (T0 + batch * (DT // 2) + (_u(seed + 7919 * batch, D, 8) % np.uint64(2 * DT))).astype(np.int64)
+    val = (_u(seed + 7919 * batch, D, 9) % np.uint64(1 << 32)).astype(np.int64) - (1 << 31)
+    return ids, fld, ts, val
