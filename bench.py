@@ -1,0 +1,201 @@
+#!/usr/bin/env python3
+"""bench.py — CRDT field-merges/s on MI355X (BASELINE.json metric), one JSON line on rank 0.
+
+A "step" is one pass of the merge hot path over one 1M-delta batch:
+  resident graph R = 10M rows per GPU (id = splitmix64(node), 1 field, ts ~ U[T0,T0+DT), val in +-2^31),
+  batch D = 1M deltas: 90 % hit resident rows (unique keys inside the batch), 10 % absent keys (inserts),
+  ts ~ U[T0 + b*DT/16, T0 + b*DT/16 + 2*DT)  (~75-78 % of hits win in steady state; batches walk disjoint rows).
+Inputs and outputs are device-resident when the timed region starts; the timed region is exactly K
+bmx_merge_batch calls (BMX_MEM_DEVICE: probe+apply, conflict resolve, winner compaction) per rank.
+
+N > 1 (one process per GPU, launched by torch.distributed.run): the graph is sharded by node-id hash,
+every rank originates 1M mixed-owner deltas per step; a step = partition by owner + all-to-all (RCCL)
++ local merge of what arrived. Weak scaling: R and D per GPU are fixed.
+
+Besides the contract fields the line carries
+  roofline     — dominant kernel (k_probe_apply): algorithmic bytes per launch / its average duration,
+                 measured live with HIP events on the engine's stream in a second pass over the same batches;
+  cpu_baseline — the CPU oracle (oracle/bmx_oracle.c, a C port proven equal to the reference on golden
+                 vectors) timed on one host core on a bounded sample of the same workload (rank 0, N=1 only).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+for p in (ROOT, os.path.join(ROOT, "bullet-js_amd")):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+import numpy as np
+import torch
+
+R_PER_GPU = 10_000_000
+D_PER_STEP = 1_000_000
+T0, DT = 1_000_000, 1_000_000
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec
+
+
+def gen_resident(R, row0=0):
+    from oracle import streams
+    return streams.big_resident(R, seed=1, T0=T0, DT=DT, row0=row0)
+
+
+def gen_batch(b, R, D=D_PER_STEP, seed=2):
+    from oracle import streams
+    return streams.big_deltas(D, R, seed=seed, T0=T0, DT=DT, insert_pct=10, unique=True, batch=b, drift=DT // 16)
+
+
+def to_dev(cols, dev):
+    id, field, ts, val = cols
+    return (torch.from_numpy(id.view(np.int64)).to(dev), torch.from_numpy(field.view(np.int32)).to(dev),
+            torch.from_numpy(ts).to(dev), torch.from_numpy(val).to(dev))
+
+
+def cpu_baseline(n_batches=3):
+    """Oracle (C port of the reference merge rule) on ONE host core, same workload shape."""
+    from oracle.oracle import Oracle
+    o = Oracle()
+    o.load_rows(*gen_resident(R_PER_GPU))
+    batches = [gen_batch(b, R_PER_GPU) for b in range(n_batches)]
+    t0 = time.perf_counter()
+    for b in batches:
+        o.merge_batch(*b)
+    dt = time.perf_counter() - t0
+    o.close()
+    return {"value": n_batches * D_PER_STEP / dt, "unit": "merges/s", "cores": 1, "kind": "port",
+            "sample": "%d x 1M-delta batches against the 10M-row resident graph (load excluded), oracle/bmx_oracle.c, 1 thread" % n_batches}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if args.gpus > 1 and world != args.gpus:
+        raise SystemExit("--gpus %d needs WORLD_SIZE=%d (launch with torch.distributed.run)" % (args.gpus, args.gpus))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the engine has no CPU path")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+
+    import bmx
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group(backend="nccl", device_id=dev)
+
+    K, W = args.steps, args.warmup
+    nb = K + W
+    # every step inserts 10 % new rows: size the table for all of them (load factor stays <= 0.5)
+    eng = bmx.Engine(capacity_rows=R_PER_GPU + (2 * nb + 8) * D_PER_STEP // 5 + D_PER_STEP, device=local_rank)
+
+    if world == 1:
+        rid = gen_resident(R_PER_GPU)
+        eng.load_rows(*rid)
+        del rid
+        batches = [to_dev(gen_batch(b, R_PER_GPU), dev) for b in range(nb)]
+        applied = torch.zeros(D_PER_STEP, dtype=torch.int32, device=dev)
+        n_applied = torch.zeros(nb, dtype=torch.int64, device=dev)
+        torch.cuda.synchronize()
+
+        def step(b):
+            i, f, t, v = batches[b]
+            eng.merge_batch_dev(D_PER_STEP, i, f, t, v, bmx.INSERT_REFERENCE, applied=applied, n_applied=n_applied[b:b + 1])
+
+        for b in range(W):
+            step(b)
+        eng.sync(); torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        eng.timer_start()
+        for b in range(W, nb):
+            step(b)
+        ev_ms = eng.timer_stop()
+        eng.sync(); torch.cuda.synchronize()
+        wall = time.perf_counter() - t0
+        elapsed = wall
+        winners = n_applied[W:].cpu().numpy()
+
+        # second pass over fresh batches of the same shape: per-kernel HIP-event timing (live roofline figure)
+        pbatches = [to_dev(gen_batch(nb + b, R_PER_GPU), dev) for b in range(min(K, 32))]
+        torch.cuda.synchronize()
+        eng.profile_enable(True)
+        for (i, f, t, v) in pbatches:
+            eng.merge_batch_dev(D_PER_STEP, i, f, t, v, bmx.INSERT_REFERENCE, applied=applied, n_applied=n_applied[0:1])
+        stage_ms, ncalls = eng.profile_read()
+        eng.profile_enable(False)
+        wavg = float(winners.mean()) if len(winners) else 0.0
+        # algorithmic bytes of one k_probe_apply launch: delta read 28*D + resident row read 28*D
+        # + (ts,val) store of the winners 16*W. (The 4*W index write belongs to the compaction launches.)
+        alg_bytes = 56.0 * D_PER_STEP + 16.0 * wavg
+        probe_s = stage_ms["probe_apply"] * 1e-3
+        achieved = alg_bytes / probe_s / 1e9 if probe_s > 0 else 0.0
+        traffic = None
+        tpath = os.path.join(ROOT, "profiles", "traffic_probe_apply.json")
+        if os.path.exists(tpath):  # HBM bytes per launch from a committed rocprofv3 --pmc run of this same command
+            try:
+                traffic = json.load(open(tpath)).get("bytes_per_launch")
+            except Exception:
+                traffic = None
+        roofline = {"bound": "hbm", "kernel": "k_probe_apply", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                    "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "algorithmic_bytes_per_launch": alg_bytes,
+                    "kernel_ms": {k: round(v, 5) for k, v in stage_ms.items()}, "launches_averaged": ncalls,
+                    "whole_merge_achieved_GBs": round((56.0 * D_PER_STEP + 20.0 * wavg) / (elapsed / K) / 1e9, 1)}
+        total_units = K * D_PER_STEP
+        extra = {"event_ms_per_step": round(ev_ms / K, 5), "winners_per_step": round(wavg, 1)}
+        cfg = {"workload": "config 2: 10M-row resident graph on 1 MI355X, 1M-delta batch merge (90% hits / 10% inserts, unique keys in batch)",
+               "resident_rows_per_gpu": R_PER_GPU, "deltas_per_step_per_gpu": D_PER_STEP, "insert_mode": "reference", "sharding": "none"}
+    else:
+        from bmx.sharded import ShardedGraph, EngineOps
+        sg = ShardedGraph(EngineOps(eng, dev), dist, rank, world)
+        sg.load_owned_resident(R_PER_GPU, T0=T0, DT=DT)
+        R_global = R_PER_GPU * world
+        batches = [to_dev(gen_batch(b, R_global, seed=2 + 1000 * rank), dev) for b in range(nb)]
+        torch.cuda.synchronize()
+        for b in range(W):
+            sg.merge_step(D_PER_STEP, *batches[b])
+        eng.sync(); torch.cuda.synchronize(); dist.barrier()
+        t0 = time.perf_counter()
+        for b in range(W, nb):
+            sg.merge_step(D_PER_STEP, *batches[b])
+        eng.sync(); torch.cuda.synchronize(); dist.barrier()
+        wall = time.perf_counter() - t0
+        tmax = torch.tensor([wall], dtype=torch.float64, device=dev)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        elapsed = float(tmax.item())
+        total_units = K * D_PER_STEP * world
+        roofline = {"bound": "hbm", "kernel": "k_probe_apply", "achieved": None, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": None, "traffic": None,
+                    "note": "per-kernel figure is reported by the N=1 run"}
+        extra = {"exchange": sg.stats()}
+        cfg = {"workload": "config 4 shape: %dM-row graph id-hash sharded over %d MI355X, %dM mixed-owner deltas per step routed by RCCL all-to-all" %
+               (R_global // 1_000_000, world, world * D_PER_STEP // 1_000_000),
+               "resident_rows_per_gpu": R_PER_GPU, "deltas_per_step_per_gpu": D_PER_STEP, "insert_mode": "reference", "sharding": "owner = hash(node id) mod N"}
+
+    out = None
+    if rank == 0:
+        out = {"metric": "CRDT field-merges/s", "value": total_units / elapsed, "unit": "merges/s", "n_gpus": world, "steps": K, "warmup": W,
+               "ms_per_step": elapsed / K * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "int64",
+               "data": "synthetic", "config": cfg, "roofline": roofline}
+        out.update(extra)
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline()
+        else:
+            out["cpu_baseline"] = None
+    eng.close()
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+    if out is not None:
+        print(json.dumps(out))
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,270 @@
+"""bmx — ctypes binding of libbmx.so (include/bmx.h), the MI355X CRDT-merge / index-scan engine.
+
+This is the Python-side driver used by tests and bench.py. The product surface is the C ABI and the
+N-API/JS host (bullet-js_amd/js); nothing here computes anything on the CPU: every call goes to the
+HIP library and raises BmxError if it (or a GPU) is missing.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+_PKG = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+LIB_PATH = os.path.join(_PKG, "libbmx.so")
+
+OK = 0
+ERR_INVALID, ERR_HIP, ERR_FULL, ERR_NOMEM, ERR_RANGE, ERR_INTERNAL, ERR_NO_DEVICE, ERR_NO_INDEX = -1, -2, -3, -4, -5, -6, -7, -8
+MEM_HOST, MEM_DEVICE = 0, 1
+INSERT_REFERENCE, INSERT_DELTA = 0, 1
+FLAG_INCOMING, FLAG_CURRENT, FLAG_HISTORICAL = 1, 2, 4
+MAX_BATCH = 1 << 24
+
+EXPORTS = [
+    "bmx_create", "bmx_destroy", "bmx_last_error", "bmx_abi_version", "bmx_get_info", "bmx_sync", "bmx_set_stream", "bmx_get_stream",
+    "bmx_load_rows", "bmx_merge_batch", "bmx_merge_records", "bmx_get_rows", "bmx_get_row", "bmx_dump_rows", "bmx_row_count",
+    "bmx_index_build", "bmx_index_drop", "bmx_index_size", "bmx_scan_range", "bmx_scan_equals", "bmx_scan_count", "bmx_scan_filter",
+    "bmx_owner_of", "bmx_partition_by_owner", "bmx_timer_start", "bmx_timer_stop", "bmx_profile_enable", "bmx_profile_read",
+]
+
+
+class BmxError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__("bmx error %d: %s" % (code, msg))
+        self.code = code
+
+
+class MergeStats(C.Structure):
+    _fields_ = [("n_applied", C.c_uint64), ("n_conflicts", C.c_uint64), ("n_rows", C.c_uint64), ("reserved", C.c_uint64)]
+
+
+class Term(C.Structure):
+    _fields_ = [("field", C.c_uint32), ("reserved", C.c_uint32), ("lo", C.c_int64), ("hi", C.c_int64)]
+
+
+class Info(C.Structure):
+    _fields_ = [("capacity_rows", C.c_uint64), ("n_slots", C.c_uint64), ("table_bytes", C.c_uint64), ("n_rows", C.c_uint64),
+                ("device", C.c_uint32), ("abi_version", C.c_uint32), ("n_indexes", C.c_uint32), ("epoch", C.c_uint32)]
+
+
+DELTA_REC_DTYPE = np.dtype([("id", "<u8"), ("field", "<u4"), ("aux", "<u4"), ("ts", "<i8"), ("val", "<i8")])
+
+_lib = None
+
+
+def load_library():
+    """dlopen libbmx.so and declare its signatures. No GPU is touched."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise BmxError(ERR_NO_DEVICE, "libbmx.so not built (run __graft_entry__.build() or make -C bullet-js_amd): the engine has no CPU fallback")
+    L = C.CDLL(LIB_PATH)
+    vp, u64, u32, i64, i32 = C.c_void_p, C.c_uint64, C.c_uint32, C.c_int64, C.c_int
+    L.bmx_create.argtypes = [i32, u64, u32, C.POINTER(vp)]; L.bmx_create.restype = i32
+    L.bmx_destroy.argtypes = [vp]; L.bmx_destroy.restype = None
+    L.bmx_last_error.argtypes = [vp]; L.bmx_last_error.restype = C.c_char_p
+    L.bmx_abi_version.argtypes = []; L.bmx_abi_version.restype = i32
+    L.bmx_get_info.argtypes = [vp, C.POINTER(Info)]; L.bmx_get_info.restype = i32
+    L.bmx_sync.argtypes = [vp]; L.bmx_sync.restype = i32
+    L.bmx_set_stream.argtypes = [vp, vp]; L.bmx_set_stream.restype = i32
+    L.bmx_get_stream.argtypes = [vp]; L.bmx_get_stream.restype = vp
+    L.bmx_load_rows.argtypes = [vp, u64, vp, vp, vp, vp, i32]; L.bmx_load_rows.restype = i32
+    L.bmx_merge_batch.argtypes = [vp, u64, vp, vp, vp, vp, i32, i32, vp, vp, vp, vp]; L.bmx_merge_batch.restype = i32
+    L.bmx_merge_records.argtypes = [vp, u64, vp, i32, vp, vp, vp, vp]; L.bmx_merge_records.restype = i32
+    L.bmx_get_rows.argtypes = [vp, u64, vp, vp, vp, vp, vp, i32]; L.bmx_get_rows.restype = i32
+    L.bmx_get_row.argtypes = [vp, u64, u32, C.POINTER(i64), C.POINTER(i64)]; L.bmx_get_row.restype = i32
+    L.bmx_dump_rows.argtypes = [vp, u64, vp, vp, vp, vp, vp, i32]; L.bmx_dump_rows.restype = i32
+    L.bmx_row_count.argtypes = [vp, C.POINTER(u64)]; L.bmx_row_count.restype = i32
+    L.bmx_index_build.argtypes = [vp, u32]; L.bmx_index_build.restype = i32
+    L.bmx_index_drop.argtypes = [vp, u32]; L.bmx_index_drop.restype = i32
+    L.bmx_index_size.argtypes = [vp, u32, C.POINTER(u64)]; L.bmx_index_size.restype = i32
+    L.bmx_scan_range.argtypes = [vp, u32, i64, i64, vp, u64, vp, i32]; L.bmx_scan_range.restype = i32
+    L.bmx_scan_equals.argtypes = [vp, u32, i64, vp, u64, vp, i32]; L.bmx_scan_equals.restype = i32
+    L.bmx_scan_count.argtypes = [vp, u32, i64, i64, vp, i32]; L.bmx_scan_count.restype = i32
+    L.bmx_scan_filter.argtypes = [vp, u32, C.POINTER(Term), vp, u64, vp, i32]; L.bmx_scan_filter.restype = i32
+    L.bmx_owner_of.argtypes = [u64, u32]; L.bmx_owner_of.restype = u32
+    L.bmx_partition_by_owner.argtypes = [vp, u64, vp, vp, vp, vp, u32, vp, vp]; L.bmx_partition_by_owner.restype = i32
+    L.bmx_timer_start.argtypes = [vp]; L.bmx_timer_start.restype = i32
+    L.bmx_timer_stop.argtypes = [vp, C.POINTER(C.c_float)]; L.bmx_timer_stop.restype = i32
+    L.bmx_profile_enable.argtypes = [vp, i32]; L.bmx_profile_enable.restype = i32
+    L.bmx_profile_read.argtypes = [vp, C.POINTER(C.c_float), C.POINTER(u32)]; L.bmx_profile_read.restype = i32
+    _lib = L
+    return L
+
+
+def _np(a, dt):
+    return np.ascontiguousarray(a, dtype=dt)
+
+
+def _ptr(a):
+    """numpy array -> void*, torch tensor -> data_ptr, int passes through, None -> NULL."""
+    if a is None:
+        return None
+    if isinstance(a, int):
+        return C.c_void_p(a)
+    if isinstance(a, np.ndarray):
+        return C.c_void_p(a.ctypes.data)
+    return C.c_void_p(a.data_ptr())
+
+
+class Engine:
+    """One GPU-resident graph shard (a bmx_ctx). Host-array methods are synchronous; *_dev methods take
+    device tensors/pointers and only enqueue work on the engine's stream."""
+
+    def __init__(self, capacity_rows, device=0):
+        self.L = load_library()
+        h = C.c_void_p()
+        rc = self.L.bmx_create(int(device), int(capacity_rows), 0, C.byref(h))
+        if rc != OK:
+            raise BmxError(rc, (self.L.bmx_last_error(None) or b"").decode())
+        self.h = h
+        self.device = device
+
+    def _chk(self, rc):
+        if rc < 0:
+            raise BmxError(rc, (self.L.bmx_last_error(self.h) or b"").decode())
+        return rc
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.L.bmx_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
+
+    # ---- host-array (synchronous) API ----
+    def load_rows(self, id, field, ts, val):
+        id, field, ts, val = _np(id, np.uint64), _np(field, np.uint32), _np(ts, np.int64), _np(val, np.int64)
+        self._chk(self.L.bmx_load_rows(self.h, len(id), _ptr(id), _ptr(field), _ptr(ts), _ptr(val), MEM_HOST))
+
+    def merge_batch(self, id, field, ts, val, insert_mode=INSERT_REFERENCE, want_flags=True):
+        """Returns (applied_idx u32[w] ascending, flags u8[n] or None, MergeStats)."""
+        id, field, ts, val = _np(id, np.uint64), _np(field, np.uint32), _np(ts, np.int64), _np(val, np.int64)
+        n = len(id)
+        applied = np.zeros(max(n, 1), np.uint32)
+        flags = np.zeros(max(n, 1), np.uint8) if want_flags else None
+        na = C.c_uint64(0)
+        st = MergeStats()
+        self._chk(self.L.bmx_merge_batch(self.h, n, _ptr(id), _ptr(field), _ptr(ts), _ptr(val), int(insert_mode), MEM_HOST,
+                                         _ptr(applied), C.cast(C.byref(na), C.c_void_p), _ptr(flags), C.cast(C.byref(st), C.c_void_p)))
+        return applied[:na.value].copy(), (flags[:n] if want_flags else None), st
+
+    def get_rows(self, id, field):
+        id, field = _np(id, np.uint64), _np(field, np.uint32)
+        n = len(id)
+        ts = np.zeros(n, np.int64); val = np.zeros(n, np.int64); found = np.zeros(n, np.uint8)
+        self._chk(self.L.bmx_get_rows(self.h, n, _ptr(id), _ptr(field), _ptr(ts), _ptr(val), _ptr(found), MEM_HOST))
+        return ts, val, found.astype(bool)
+
+    def get_row(self, id, field):
+        ts, val = C.c_int64(), C.c_int64()
+        rc = self._chk(self.L.bmx_get_row(self.h, int(id), int(field), C.byref(ts), C.byref(val)))
+        return (ts.value, val.value) if rc == 1 else None
+
+    def row_count(self):
+        n = C.c_uint64()
+        self._chk(self.L.bmx_row_count(self.h, C.byref(n)))
+        return n.value
+
+    def dump_rows(self):
+        n = self.row_count()
+        id = np.zeros(n, np.uint64); field = np.zeros(n, np.uint32); ts = np.zeros(n, np.int64); val = np.zeros(n, np.int64)
+        m = C.c_uint64()
+        self._chk(self.L.bmx_dump_rows(self.h, n, _ptr(id), _ptr(field), _ptr(ts), _ptr(val), C.cast(C.byref(m), C.c_void_p), MEM_HOST))
+        assert m.value == n
+        return id, field, ts, val
+
+    def index_build(self, field):
+        self._chk(self.L.bmx_index_build(self.h, int(field)))
+
+    def index_drop(self, field):
+        self._chk(self.L.bmx_index_drop(self.h, int(field)))
+
+    def index_size(self, field):
+        n = C.c_uint64()
+        self._chk(self.L.bmx_index_size(self.h, int(field), C.byref(n)))
+        return n.value
+
+    def scan_range(self, field, lo, hi, cap=None):
+        cap = self.index_size(field) if cap is None else cap
+        out = np.zeros(max(cap, 1), np.uint64)
+        m = C.c_uint64()
+        self._chk(self.L.bmx_scan_range(self.h, int(field), int(lo), int(hi), _ptr(out), cap, C.cast(C.byref(m), C.c_void_p), MEM_HOST))
+        return out[:min(m.value, cap)].copy()
+
+    def scan_equals(self, field, value):
+        return self.scan_range(field, value, value)
+
+    def scan_count(self, field, lo, hi):
+        m = C.c_uint64()
+        self._chk(self.L.bmx_scan_count(self.h, int(field), int(lo), int(hi), C.cast(C.byref(m), C.c_void_p), MEM_HOST))
+        return m.value
+
+    def scan_filter(self, terms, cap=None):
+        arr = (Term * len(terms))(*[Term(int(f), 0, int(lo), int(hi)) for f, lo, hi in terms])
+        cap = self.index_size(terms[0][0]) if cap is None else cap
+        out = np.zeros(max(cap, 1), np.uint64)
+        m = C.c_uint64()
+        self._chk(self.L.bmx_scan_filter(self.h, len(terms), arr, _ptr(out), cap, C.cast(C.byref(m), C.c_void_p), MEM_HOST))
+        return out[:min(m.value, cap)].copy()
+
+    def info(self):
+        i = Info()
+        self._chk(self.L.bmx_get_info(self.h, C.byref(i)))
+        return i
+
+    # ---- device-pointer (asynchronous) API: arguments are torch CUDA tensors or raw device addresses ----
+    def sync(self):
+        self._chk(self.L.bmx_sync(self.h))
+
+    def set_stream(self, stream_ptr):
+        self._chk(self.L.bmx_set_stream(self.h, C.c_void_p(stream_ptr) if stream_ptr else None))
+
+    def load_rows_dev(self, n, id, field, ts, val):
+        self._chk(self.L.bmx_load_rows(self.h, int(n), _ptr(id), _ptr(field), _ptr(ts), _ptr(val), MEM_DEVICE))
+
+    def merge_batch_dev(self, n, id, field, ts, val, insert_mode=INSERT_REFERENCE, applied=None, n_applied=None, flags=None, stats=None):
+        self._chk(self.L.bmx_merge_batch(self.h, int(n), _ptr(id), _ptr(field), _ptr(ts), _ptr(val), int(insert_mode), MEM_DEVICE,
+                                         _ptr(applied), _ptr(n_applied), _ptr(flags), _ptr(stats)))
+
+    def merge_records_dev(self, n, recs, insert_mode=INSERT_REFERENCE, applied=None, n_applied=None, flags=None, stats=None):
+        self._chk(self.L.bmx_merge_records(self.h, int(n), _ptr(recs), int(insert_mode), _ptr(applied), _ptr(n_applied), _ptr(flags), _ptr(stats)))
+
+    def partition_by_owner_dev(self, n, id, field, ts, val, nshards, recs_out, counts_out):
+        self._chk(self.L.bmx_partition_by_owner(self.h, int(n), _ptr(id), _ptr(field), _ptr(ts), _ptr(val), int(nshards), _ptr(recs_out), _ptr(counts_out)))
+
+    def scan_range_dev(self, field, lo, hi, out_ids, cap, n_out):
+        self._chk(self.L.bmx_scan_range(self.h, int(field), int(lo), int(hi), _ptr(out_ids), int(cap), _ptr(n_out), MEM_DEVICE))
+
+    def profile_enable(self, on=True):
+        self._chk(self.L.bmx_profile_enable(self.h, 1 if on else 0))
+
+    def profile_read(self):
+        """-> (dict stage -> average ms per merge call, number of calls)"""
+        ms = (C.c_float * 3)()
+        n = C.c_uint32()
+        self._chk(self.L.bmx_profile_read(self.h, ms, C.byref(n)))
+        return {"probe_apply": ms[0], "resolve_lists": ms[1], "compact": ms[2]}, n.value
+
+    def timer_start(self):
+        self._chk(self.L.bmx_timer_start(self.h))
+
+    def timer_stop(self):
+        ms = C.c_float()
+        self._chk(self.L.bmx_timer_stop(self.h, C.byref(ms)))
+        return ms.value
+
+
+def owner_of(ids, nshards):
+    L = load_library()
+    return np.array([L.bmx_owner_of(int(i), int(nshards)) for i in np.asarray(ids, dtype=np.uint64)], dtype=np.uint32)

@@ -1,0 +1,722 @@
+// bmx.hip — C ABI (include/bmx.h) over the gfx950 kernels. One context = one GPU + one HIP stream.
+// No CPU fallback exists: every entry point fails with BMX_ERR_NO_DEVICE / BMX_ERR_HIP when there is no GPU.
+#include <hip/hip_runtime.h>
+#include <algorithm>
+#include <climits>
+#include <cstdio>
+#include <cstring>
+#include <new>
+#include <string>
+#include <vector>
+
+#include "../../include/bmx.h"
+#include "merge_kernels.h"
+#include "scan_kernels.h"
+#include "select.h"
+#include "slot.h"
+
+using namespace bmx;
+
+namespace {
+
+struct DevScalars {  // one small device allocation; zeroed at create
+  unsigned long long row_count;
+  unsigned long long n_out;        // scratch count for host-mode calls
+  unsigned long long part_totals[PART_MAX_SHARDS];
+  bmx_merge_stats stats;           // scratch stats for host-mode calls
+  uint32_t status;
+  uint32_t wide;
+};
+
+struct Index {
+  uint32_t field = 0;
+  uint64_t n = 0, cap = 0;
+  uint64_t* ids = nullptr;
+  int64_t* v64 = nullptr;
+  int32_t* v32 = nullptr;
+  bool fits32 = false;
+  uint64_t version = ~0ull;  // table version it was built from
+};
+
+thread_local std::string g_err;
+constexpr uint32_t PROF_MAX_CALLS = 64;
+
+}  // namespace
+
+struct bmx_ctx {
+  int device = 0;
+  hipStream_t own_stream = nullptr, stream = nullptr;
+  Slot* slots = nullptr;
+  uint64_t nslots = 0, capacity_rows = 0;
+  DevScalars* ds = nullptr;
+  // per-batch workspace (grown on demand)
+  uint32_t ws_cap = 0;
+  uint32_t* next = nullptr;
+  uint8_t* wflag = nullptr;
+  uint32_t* slot_of = nullptr;
+  unsigned long long* shard_ctr = nullptr;  // CTR_SHARDS * CTR_STRIDE
+  // staging for BMX_MEM_HOST calls
+  uint32_t st_cap = 0;
+  uint64_t* st_id = nullptr; uint32_t* st_field = nullptr; int64_t* st_ts = nullptr; int64_t* st_val = nullptr;
+  uint32_t* st_applied = nullptr; uint8_t* st_flags = nullptr;
+  uint64_t scan_cap = 0; uint64_t* scan_out = nullptr;
+  uint32_t* block_counts = nullptr;   // SEL_MAX_BLOCKS
+  unsigned long long* granules = nullptr;  // SEL_MAX_BLOCKS look-back granules {seq, count}
+  uint32_t sel_seq = 0;               // sequence number of the last k_select call (never 0 in a granule)
+  uint32_t* part_counts = nullptr;    // PART_MAX_SHARDS * PART_BLOCKS
+  uint32_t epoch = 0;
+  uint64_t version = 0;
+  uint64_t rows_ub = 0;               // host-side upper bound of resident rows
+  std::vector<Index> indexes;
+  hipEvent_t ev0 = nullptr, ev1 = nullptr;
+  // optional per-kernel profiling (bmx_profile_enable)
+  bool prof_on = false;
+  uint32_t prof_n = 0;
+  std::vector<hipEvent_t> prof_ev;    // 4 events per profiled call
+  std::string err;
+};
+
+namespace {
+
+int fail(bmx_ctx* c, int code, const std::string& msg) {
+  if (c) c->err = msg;
+  g_err = msg;
+  return code;
+}
+int fail_hip(bmx_ctx* c, hipError_t e, const char* what) {
+  return fail(c, BMX_ERR_HIP, std::string(what) + ": " + hipGetErrorString(e));
+}
+#define HIPCHK(call)                                                  \
+  do {                                                                \
+    hipError_t e__ = (call);                                          \
+    if (e__ != hipSuccess) return fail_hip(ctx, e__, #call);          \
+  } while (0)
+#define LAUNCHCHK(name)                                               \
+  do {                                                                \
+    hipError_t e__ = hipGetLastError();                               \
+    if (e__ != hipSuccess) return fail_hip(ctx, e__, "launch " name); \
+  } while (0)
+
+template <class T>
+int dev_alloc(bmx_ctx* ctx, T** p, uint64_t count) {
+  *p = nullptr;
+  if (count == 0) count = 1;
+  hipError_t e = hipMalloc(reinterpret_cast<void**>(p), count * sizeof(T));
+  if (e != hipSuccess) return fail(ctx, e == hipErrorOutOfMemory ? BMX_ERR_NOMEM : BMX_ERR_HIP, std::string("hipMalloc: ") + hipGetErrorString(e));
+  return BMX_OK;
+}
+template <class T>
+void dev_free(T*& p) {
+  if (p) (void)hipFree(p);
+  p = nullptr;
+}
+
+// Pull the sticky device status; translate to an error code.
+int check_status(bmx_ctx* ctx) {
+  uint32_t st = 0;
+  HIPCHK(hipMemcpyAsync(&st, &ctx->ds->status, sizeof(st), hipMemcpyDeviceToHost, ctx->stream));
+  HIPCHK(hipStreamSynchronize(ctx->stream));
+  if (!st) return BMX_OK;
+  HIPCHK(hipMemsetAsync(&ctx->ds->status, 0, sizeof(uint32_t), ctx->stream));
+  if (st & ST_SPIN) return fail(ctx, BMX_ERR_INTERNAL, "device protocol fault: bounded spin expired");
+  if (st & ST_FULL) return fail(ctx, BMX_ERR_FULL, "resident table is full");
+  return fail(ctx, BMX_ERR_RANGE, "delta out of domain: reserved key, ts outside [0, 2^53-1] or |val| > 2^53-1");
+}
+
+int refresh_rows(bmx_ctx* ctx) {
+  unsigned long long r = 0;
+  HIPCHK(hipMemcpyAsync(&r, &ctx->ds->row_count, sizeof(r), hipMemcpyDeviceToHost, ctx->stream));
+  HIPCHK(hipStreamSynchronize(ctx->stream));
+  ctx->rows_ub = r;
+  return BMX_OK;
+}
+
+int ensure_workspace(bmx_ctx* ctx, uint64_t n) {
+  if (n <= ctx->ws_cap) return BMX_OK;
+  HIPCHK(hipStreamSynchronize(ctx->stream));
+  uint64_t cap = std::max<uint64_t>(n, std::min<uint64_t>((uint64_t)ctx->ws_cap * 2, MAX_BATCH));
+  cap = std::max<uint64_t>(cap, 1u << 16);
+  cap = (cap + 255) & ~255ull;
+  dev_free(ctx->next); dev_free(ctx->wflag); dev_free(ctx->slot_of);
+  ctx->ws_cap = 0;
+  int rc;
+  if ((rc = dev_alloc(ctx, &ctx->next, cap)) || (rc = dev_alloc(ctx, &ctx->wflag, cap + 16)) || (rc = dev_alloc(ctx, &ctx->slot_of, cap))) return rc;
+  HIPCHK(hipMemsetAsync(ctx->next, 0, cap * sizeof(uint32_t), ctx->stream));
+  ctx->ws_cap = (uint32_t)cap;
+  return BMX_OK;
+}
+
+int ensure_staging(bmx_ctx* ctx, uint64_t n) {
+  if (n <= ctx->st_cap) return BMX_OK;
+  HIPCHK(hipStreamSynchronize(ctx->stream));
+  uint64_t cap = std::max<uint64_t>(n, 1u << 16);
+  cap = (cap + 255) & ~255ull;
+  dev_free(ctx->st_id); dev_free(ctx->st_field); dev_free(ctx->st_ts); dev_free(ctx->st_val); dev_free(ctx->st_applied); dev_free(ctx->st_flags);
+  ctx->st_cap = 0;
+  int rc;
+  if ((rc = dev_alloc(ctx, &ctx->st_id, cap)) || (rc = dev_alloc(ctx, &ctx->st_field, cap)) || (rc = dev_alloc(ctx, &ctx->st_ts, cap)) ||
+      (rc = dev_alloc(ctx, &ctx->st_val, cap)) || (rc = dev_alloc(ctx, &ctx->st_applied, cap)) || (rc = dev_alloc(ctx, &ctx->st_flags, cap)))
+    return rc;
+  ctx->st_cap = (uint32_t)cap;
+  return BMX_OK;
+}
+
+// Sequence number for the next k_select call; granules are re-zeroed when it wraps.
+int next_seq(bmx_ctx* ctx, uint32_t* seq) {
+  if (++ctx->sel_seq == 0) {
+    HIPCHK(hipMemsetAsync(ctx->granules, 0, SEL_MAX_BLOCKS * sizeof(unsigned long long), ctx->stream));
+    ctx->sel_seq = 1;
+  }
+  *seq = ctx->sel_seq;
+  return BMX_OK;
+}
+
+// The merge proper: all pointers are device pointers; only enqueues work.
+template <bool AOS>
+int merge_core(bmx_ctx* ctx, uint64_t n, const uint64_t* id, const uint32_t* field, const int64_t* ts, const int64_t* val,
+               const bmx_delta_rec* recs, int insert_mode, uint32_t* applied_idx, uint64_t* n_applied, uint8_t* flags,
+               bmx_merge_stats* stats) {
+  if (n > MAX_BATCH) return fail(ctx, BMX_ERR_INVALID, "batch larger than 2^24 deltas: split it (sequential semantics are preserved)");
+  if (insert_mode != BMX_INSERT_REFERENCE && insert_mode != BMX_INSERT_DELTA) return fail(ctx, BMX_ERR_INVALID, "bad insert_mode");
+  if (n == 0) {
+    if (n_applied) HIPCHK(hipMemsetAsync(n_applied, 0, sizeof(uint64_t), ctx->stream));
+    if (stats) HIPCHK(hipMemsetAsync(stats, 0, sizeof(bmx_merge_stats), ctx->stream));
+    return BMX_OK;
+  }
+  // capacity guards: physical (never let probing run out of empty slots) and logical (capacity_rows)
+  if (ctx->rows_ub + n >= ctx->nslots || ctx->rows_ub > ctx->capacity_rows) {
+    int rc = refresh_rows(ctx);
+    if (rc) return rc;
+    if (ctx->rows_ub + n >= ctx->nslots || ctx->rows_ub > ctx->capacity_rows) return fail(ctx, BMX_ERR_FULL, "resident table is full (capacity_rows exceeded)");
+  }
+  int rc = ensure_workspace(ctx, n);
+  if (rc) return rc;
+  if (++ctx->epoch > EPOCH_MAX) {  // tags wrap: forget every claim
+    hipLaunchKernelGGL(k_sweep_heads, dim3(2048), dim3(256), 0, ctx->stream, ctx->slots, ctx->nslots);
+    LAUNCHCHK("k_sweep_heads");
+    HIPCHK(hipMemsetAsync(ctx->next, 0, (size_t)ctx->ws_cap * sizeof(uint32_t), ctx->stream));
+    ctx->epoch = 1;
+  }
+  MergeArgs A;
+  A.slots = ctx->slots; A.nslots = ctx->nslots;
+  A.id = id; A.field = field; A.ts = ts; A.val = val; A.recs = recs;
+  A.n = (uint32_t)n; A.epoch = ctx->epoch;
+  A.next = ctx->next; A.wflag = ctx->wflag; A.flags = flags;
+  A.slot_of = ctx->slot_of; A.shard_ctr = ctx->shard_ctr; A.status = &ctx->ds->status;
+  const uint32_t blocks = (uint32_t)((n + 255) / 256);
+  const uint32_t rblocks = std::min<uint32_t>(blocks, 1024);
+  hipEvent_t* pe = (ctx->prof_on && ctx->prof_n < PROF_MAX_CALLS) ? &ctx->prof_ev[4 * ctx->prof_n] : nullptr;
+  if (pe) HIPCHK(hipEventRecord(pe[0], ctx->stream));
+  if (insert_mode == BMX_INSERT_REFERENCE) {
+    hipLaunchKernelGGL((k_probe_apply<AOS, BMX_INSERT_REFERENCE>), dim3(blocks), dim3(256), 0, ctx->stream, A);
+    LAUNCHCHK("k_probe_apply");
+    if (pe) HIPCHK(hipEventRecord(pe[1], ctx->stream));
+    hipLaunchKernelGGL((k_resolve_lists<AOS, BMX_INSERT_REFERENCE>), dim3(rblocks), dim3(256), 0, ctx->stream, A);
+  } else {
+    hipLaunchKernelGGL((k_probe_apply<AOS, BMX_INSERT_DELTA>), dim3(blocks), dim3(256), 0, ctx->stream, A);
+    LAUNCHCHK("k_probe_apply");
+    if (pe) HIPCHK(hipEventRecord(pe[1], ctx->stream));
+    hipLaunchKernelGGL((k_resolve_lists<AOS, BMX_INSERT_DELTA>), dim3(rblocks), dim3(256), 0, ctx->stream, A);
+  }
+  LAUNCHCHK("k_resolve_lists");
+  if (pe) HIPCHK(hipEventRecord(pe[2], ctx->stream));
+  // K3: ordered compaction of the winner bytes
+  PredWinner P{ctx->wflag};
+  EmitApplied Em{applied_idx};
+  FinishMerge Fin{reinterpret_cast<unsigned long long*>(n_applied), stats, ctx->shard_ctr, &ctx->ds->row_count};
+  SelGeom g = sel_geom<PredWinner::E>(n);
+  uint32_t seq;
+  if ((rc = next_seq(ctx, &seq))) return rc;
+  hipLaunchKernelGGL((k_select<PredWinner, EmitApplied, FinishMerge>), dim3(g.blocks), dim3(SEL_THREADS), 0, ctx->stream, P, Em, Fin, n,
+                     g.tiles_per_block, ctx->granules, seq, &ctx->ds->status);
+  LAUNCHCHK("k_select");
+  if (pe) { HIPCHK(hipEventRecord(pe[3], ctx->stream)); ctx->prof_n++; }
+  ctx->rows_ub += n;
+  ctx->version++;
+  return BMX_OK;
+}
+
+int merge_host(bmx_ctx* ctx, uint64_t n, const uint64_t* id, const uint32_t* field, const int64_t* ts, const int64_t* val,
+               int insert_mode, uint32_t* applied_idx, uint64_t* n_applied, uint8_t* flags, bmx_merge_stats* stats) {
+  int rc = ensure_staging(ctx, n);
+  if (rc) return rc;
+  if (n) {
+    HIPCHK(hipMemcpyAsync(ctx->st_id, id, n * 8, hipMemcpyHostToDevice, ctx->stream));
+    HIPCHK(hipMemcpyAsync(ctx->st_field, field, n * 4, hipMemcpyHostToDevice, ctx->stream));
+    HIPCHK(hipMemcpyAsync(ctx->st_ts, ts, n * 8, hipMemcpyHostToDevice, ctx->stream));
+    HIPCHK(hipMemcpyAsync(ctx->st_val, val, n * 8, hipMemcpyHostToDevice, ctx->stream));
+  }
+  rc = merge_core<false>(ctx, n, ctx->st_id, ctx->st_field, ctx->st_ts, ctx->st_val, nullptr, insert_mode, ctx->st_applied,
+                         reinterpret_cast<uint64_t*>(&ctx->ds->n_out), flags ? ctx->st_flags : nullptr, &ctx->ds->stats);
+  if (rc) return rc;
+  bmx_merge_stats hs;
+  HIPCHK(hipMemcpyAsync(&hs, &ctx->ds->stats, sizeof(hs), hipMemcpyDeviceToHost, ctx->stream));
+  HIPCHK(hipStreamSynchronize(ctx->stream));
+  if (n == 0) std::memset(&hs, 0, sizeof(hs));
+  rc = check_status(ctx);
+  if (rc) return rc;
+  if (n) ctx->rows_ub = hs.n_rows;
+  if (applied_idx && hs.n_applied) HIPCHK(hipMemcpyAsync(applied_idx, ctx->st_applied, hs.n_applied * 4, hipMemcpyDeviceToHost, ctx->stream));
+  if (flags && n) HIPCHK(hipMemcpyAsync(flags, ctx->st_flags, n, hipMemcpyDeviceToHost, ctx->stream));
+  HIPCHK(hipStreamSynchronize(ctx->stream));
+  if (n_applied) *n_applied = hs.n_applied;
+  if (stats) *stats = hs;
+  return BMX_OK;
+}
+
+Index* find_index(bmx_ctx* ctx, uint32_t field) {
+  for (auto& ix : ctx->indexes)
+    if (ix.field == field) return &ix;
+  return nullptr;
+}
+
+// (Re)build the dense columns of `field` from the table, in slot order. Synchronous.
+int build_index(bmx_ctx* ctx, Index* ix) {
+  PredSlotField P{ctx->slots, ix->field};
+  SelGeom g = sel_geom<PredSlotField::E>(ctx->nslots);
+  hipLaunchKernelGGL((k_sel_count<PredSlotField>), dim3(g.blocks), dim3(SEL_THREADS), 0, ctx->stream, P, ctx->nslots, g.tiles_per_block, ctx->block_counts);
+  LAUNCHCHK("k_sel_count(index)");
+  hipLaunchKernelGGL(k_sum_counts, dim3(1), dim3(SEL_THREADS), 0, ctx->stream, ctx->block_counts, g.blocks, &ctx->ds->n_out);
+  LAUNCHCHK("k_sum_counts");
+  unsigned long long n = 0;
+  HIPCHK(hipMemcpyAsync(&n, &ctx->ds->n_out, sizeof(n), hipMemcpyDeviceToHost, ctx->stream));
+  HIPCHK(hipStreamSynchronize(ctx->stream));
+  if (n > ix->cap) {
+    dev_free(ix->ids); dev_free(ix->v64); dev_free(ix->v32);
+    ix->cap = 0;
+    uint64_t cap = (n + n / 8 + 1023) & ~1023ull;
+    int rc;
+    if ((rc = dev_alloc(ctx, &ix->ids, cap)) || (rc = dev_alloc(ctx, &ix->v64, cap)) || (rc = dev_alloc(ctx, &ix->v32, cap + 4))) return rc;
+    ix->cap = cap;
+  }
+  HIPCHK(hipMemsetAsync(&ctx->ds->wide, 0, sizeof(uint32_t), ctx->stream));
+  EmitIndex Em{ctx->slots, ix->ids, ix->v64, ix->v32, &ctx->ds->wide};
+  FinishCount Fin{nullptr};
+  hipLaunchKernelGGL((k_sel_write<PredSlotField, EmitIndex, FinishCount>), dim3(g.blocks), dim3(SEL_THREADS), 0, ctx->stream, P, Em, Fin, ctx->nslots,
+                     g.tiles_per_block, ctx->block_counts);
+  LAUNCHCHK("k_sel_write(index)");
+  uint32_t wide = 0;
+  HIPCHK(hipMemcpyAsync(&wide, &ctx->ds->wide, sizeof(wide), hipMemcpyDeviceToHost, ctx->stream));
+  HIPCHK(hipStreamSynchronize(ctx->stream));
+  ix->n = n;
+  ix->fits32 = wide == 0;
+  ix->version = ctx->version;
+  return BMX_OK;
+}
+
+int fresh_index(bmx_ctx* ctx, uint32_t field, Index** out) {
+  Index* ix = find_index(ctx, field);
+  if (!ix) {  // equals()/range() auto-create a missing index: src/bullet-query.js:194-196, 230-232
+    ctx->indexes.emplace_back();
+    ix = &ctx->indexes.back();
+    ix->field = field;
+  }
+  if (ix->version != ctx->version) {
+    int rc = build_index(ctx, ix);
+    if (rc) return rc;
+  }
+  *out = ix;
+  return BMX_OK;
+}
+
+int ensure_scan_out(bmx_ctx* ctx, uint64_t n) {
+  if (n <= ctx->scan_cap) return BMX_OK;
+  HIPCHK(hipStreamSynchronize(ctx->stream));
+  dev_free(ctx->scan_out);
+  ctx->scan_cap = 0;
+  int rc = dev_alloc(ctx, &ctx->scan_out, n);
+  if (rc) return rc;
+  ctx->scan_cap = n;
+  return BMX_OK;
+}
+
+// Run one predicate over an index and deliver ids / count according to `mem`.
+template <class Pred>
+int run_scan(bmx_ctx* ctx, const Pred& P, const Index* ix, uint64_t* out_ids, uint64_t cap, uint64_t* n_out, int mem) {
+  SelGeom g = sel_geom<Pred::E>(ix->n);
+  const bool host = mem == BMX_MEM_HOST;
+  uint64_t* d_out = out_ids;
+  uint64_t d_cap = cap;
+  if (host && out_ids) {
+    d_cap = std::min<uint64_t>(cap, ix->n);
+    int rc = ensure_scan_out(ctx, std::max<uint64_t>(d_cap, 1));
+    if (rc) return rc;
+    d_out = ctx->scan_out;
+  }
+  unsigned long long* d_n = host ? &ctx->ds->n_out : reinterpret_cast<unsigned long long*>(n_out);
+  if (d_out) {
+    EmitIds Em{ix->ids, d_out, d_cap};
+    FinishCount Fin{d_n};
+    uint32_t seq;
+    int rc = next_seq(ctx, &seq);
+    if (rc) return rc;
+    hipLaunchKernelGGL((k_select<Pred, EmitIds, FinishCount>), dim3(g.blocks), dim3(SEL_THREADS), 0, ctx->stream, P, Em, Fin, ix->n, g.tiles_per_block,
+                       ctx->granules, seq, &ctx->ds->status);
+    LAUNCHCHK("k_select(scan)");
+  } else if (d_n) {
+    hipLaunchKernelGGL((k_sel_count<Pred>), dim3(g.blocks), dim3(SEL_THREADS), 0, ctx->stream, P, ix->n, g.tiles_per_block, ctx->block_counts);
+    LAUNCHCHK("k_sel_count(scan)");
+    hipLaunchKernelGGL(k_sum_counts, dim3(1), dim3(SEL_THREADS), 0, ctx->stream, ctx->block_counts, g.blocks, d_n);
+    LAUNCHCHK("k_sum_counts");
+  }
+  if (host) {
+    unsigned long long m = 0;
+    HIPCHK(hipMemcpyAsync(&m, &ctx->ds->n_out, sizeof(m), hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    if (out_ids && m) HIPCHK(hipMemcpy(out_ids, ctx->scan_out, std::min<uint64_t>(m, d_cap) * 8, hipMemcpyDeviceToHost));
+    if (n_out) *n_out = m;
+  }
+  return BMX_OK;
+}
+
+int scan_range_impl(bmx_ctx* ctx, uint32_t field, int64_t lo, int64_t hi, uint64_t* out_ids, uint64_t cap, uint64_t* n_out, int mem) {
+  if (mem != BMX_MEM_HOST && mem != BMX_MEM_DEVICE) return fail(ctx, BMX_ERR_INVALID, "bad mem kind");
+  Index* ix;
+  int rc = fresh_index(ctx, field, &ix);
+  if (rc) return rc;
+  if (ix->fits32) {
+    // every value fits int32: scan the 4-byte column with bounds clamped into int32 (an empty range stays empty)
+    int64_t l = std::max<int64_t>(lo, INT32_MIN), h = std::min<int64_t>(hi, INT32_MAX);
+    if (lo > INT32_MAX || hi < INT32_MIN) { l = 1; h = 0; }
+    PredRange32 P{ix->v32, (int32_t)l, (int32_t)h};
+    return run_scan(ctx, P, ix, out_ids, cap, n_out, mem);
+  }
+  PredRange64 P{ix->v64, lo, hi};
+  return run_scan(ctx, P, ix, out_ids, cap, n_out, mem);
+}
+
+}  // namespace
+
+extern "C" {
+
+int bmx_abi_version(void) { return BMX_ABI_VERSION; }
+
+const char* bmx_last_error(const bmx_ctx* ctx) { return ctx ? ctx->err.c_str() : g_err.c_str(); }
+
+uint32_t bmx_owner_of(uint64_t id, uint32_t nshards) { return (uint32_t)(((unsigned __int128)owner_hash(id) * nshards) >> 64); }
+
+int bmx_create(int device, uint64_t capacity_rows, uint32_t flags, bmx_ctx** out) {
+  (void)flags;
+  if (!out || capacity_rows == 0) return fail(nullptr, BMX_ERR_INVALID, "bmx_create: bad arguments");
+  *out = nullptr;
+  int ndev = 0;
+  hipError_t e = hipGetDeviceCount(&ndev);
+  if (e != hipSuccess || ndev == 0) return fail(nullptr, BMX_ERR_NO_DEVICE, "no HIP device: this library has no CPU path");
+  if (device < 0 || device >= ndev) return fail(nullptr, BMX_ERR_INVALID, "bmx_create: device index out of range");
+  bmx_ctx* ctx = new (std::nothrow) bmx_ctx();
+  if (!ctx) return fail(nullptr, BMX_ERR_NOMEM, "out of host memory");
+  ctx->device = device;
+  ctx->capacity_rows = capacity_rows;
+  auto bail = [&](int rc) { std::string m = ctx->err; bmx_destroy(ctx); g_err = m; return rc; };
+#define CR(call) do { hipError_t e2 = (call); if (e2 != hipSuccess) { fail_hip(ctx, e2, #call); return bail(BMX_ERR_HIP); } } while (0)
+  CR(hipSetDevice(device));
+  CR(hipStreamCreateWithFlags(&ctx->own_stream, hipStreamNonBlocking));
+  ctx->stream = ctx->own_stream;
+  CR(hipEventCreate(&ctx->ev0));
+  CR(hipEventCreate(&ctx->ev1));
+  // load factor <= 0.5 at capacity_rows: expected 1.5 slots per hit, 2.5 per miss, almost always inside one 128-B line
+  uint64_t nslots = std::max<uint64_t>(4096, capacity_rows * 2);
+  nslots = (nslots + 3) & ~3ull;
+  ctx->nslots = nslots;
+  int rc;
+  if ((rc = dev_alloc(ctx, &ctx->slots, nslots))) return bail(rc);
+  if ((rc = dev_alloc(ctx, &ctx->ds, 1))) return bail(rc);
+  if ((rc = dev_alloc(ctx, &ctx->block_counts, SEL_MAX_BLOCKS))) return bail(rc);
+  if ((rc = dev_alloc(ctx, &ctx->part_counts, PART_MAX_SHARDS * PART_BLOCKS))) return bail(rc);
+  if ((rc = dev_alloc(ctx, &ctx->granules, SEL_MAX_BLOCKS))) return bail(rc);
+  CR(hipMemsetAsync(ctx->granules, 0, SEL_MAX_BLOCKS * sizeof(unsigned long long), ctx->stream));
+  if ((rc = dev_alloc(ctx, &ctx->shard_ctr, CTR_SHARDS * CTR_STRIDE))) return bail(rc);
+  CR(hipMemsetAsync(ctx->shard_ctr, 0, CTR_SHARDS * CTR_STRIDE * sizeof(unsigned long long), ctx->stream));
+  CR(hipMemsetAsync(ctx->ds, 0, sizeof(DevScalars), ctx->stream));
+  hipLaunchKernelGGL(k_init_slots, dim3(2048), dim3(256), 0, ctx->stream, ctx->slots, nslots);
+  CR(hipGetLastError());
+  CR(hipStreamSynchronize(ctx->stream));
+#undef CR
+  *out = ctx;
+  return BMX_OK;
+}
+
+void bmx_destroy(bmx_ctx* ctx) {
+  if (!ctx) return;
+  (void)hipSetDevice(ctx->device);
+  if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
+  for (auto& ix : ctx->indexes) { dev_free(ix.ids); dev_free(ix.v64); dev_free(ix.v32); }
+  dev_free(ctx->slots); dev_free(ctx->ds); dev_free(ctx->next); dev_free(ctx->wflag); dev_free(ctx->slot_of); dev_free(ctx->shard_ctr);
+  dev_free(ctx->st_id); dev_free(ctx->st_field); dev_free(ctx->st_ts); dev_free(ctx->st_val); dev_free(ctx->st_applied); dev_free(ctx->st_flags);
+  dev_free(ctx->scan_out); dev_free(ctx->block_counts); dev_free(ctx->part_counts); dev_free(ctx->granules);
+  for (auto ev : ctx->prof_ev) (void)hipEventDestroy(ev);
+  if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
+  if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);
+  if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
+  delete ctx;
+}
+
+int bmx_sync(bmx_ctx* ctx) {
+  if (!ctx) return fail(nullptr, BMX_ERR_INVALID, "null context");
+  HIPCHK(hipSetDevice(ctx->device));
+  return check_status(ctx);
+}
+
+int bmx_set_stream(bmx_ctx* ctx, void* s) {
+  if (!ctx) return fail(nullptr, BMX_ERR_INVALID, "null context");
+  HIPCHK(hipStreamSynchronize(ctx->stream));
+  ctx->stream = s ? reinterpret_cast<hipStream_t>(s) : ctx->own_stream;
+  return BMX_OK;
+}
+void* bmx_get_stream(bmx_ctx* ctx) { return ctx ? reinterpret_cast<void*>(ctx->stream) : nullptr; }
+
+int bmx_get_info(bmx_ctx* ctx, bmx_info* out) {
+  if (!ctx || !out) return fail(ctx, BMX_ERR_INVALID, "bad arguments");
+  HIPCHK(hipSetDevice(ctx->device));
+  int rc = refresh_rows(ctx);
+  if (rc) return rc;
+  out->capacity_rows = ctx->capacity_rows; out->n_slots = ctx->nslots; out->table_bytes = ctx->nslots * sizeof(Slot); out->n_rows = ctx->rows_ub;
+  out->device = (uint32_t)ctx->device; out->abi_version = BMX_ABI_VERSION; out->n_indexes = (uint32_t)ctx->indexes.size(); out->epoch = ctx->epoch;
+  return BMX_OK;
+}
+
+int bmx_row_count(bmx_ctx* ctx, uint64_t* n_out) {
+  if (!ctx || !n_out) return fail(ctx, BMX_ERR_INVALID, "bad arguments");
+  HIPCHK(hipSetDevice(ctx->device));
+  int rc = refresh_rows(ctx);
+  if (rc) return rc;
+  *n_out = ctx->rows_ub;
+  return BMX_OK;
+}
+
+int bmx_merge_batch(bmx_ctx* ctx, uint64_t n, const uint64_t* id, const uint32_t* field, const int64_t* ts, const int64_t* val,
+                    int insert_mode, int mem, uint32_t* applied_idx, uint64_t* n_applied, uint8_t* flags, bmx_merge_stats* stats) {
+  if (!ctx) return fail(nullptr, BMX_ERR_INVALID, "null context");
+  if (n && (!id || !field || !ts || !val)) return fail(ctx, BMX_ERR_INVALID, "null input column");
+  HIPCHK(hipSetDevice(ctx->device));
+  if (mem == BMX_MEM_DEVICE) return merge_core<false>(ctx, n, id, field, ts, val, nullptr, insert_mode, applied_idx, n_applied, flags, stats);
+  if (mem != BMX_MEM_HOST) return fail(ctx, BMX_ERR_INVALID, "bad mem kind");
+  if (n > MAX_BATCH) return fail(ctx, BMX_ERR_INVALID, "batch larger than 2^24 deltas: split it (sequential semantics are preserved)");
+  return merge_host(ctx, n, id, field, ts, val, insert_mode, applied_idx, n_applied, flags, stats);
+}
+
+int bmx_merge_records(bmx_ctx* ctx, uint64_t n, const bmx_delta_rec* recs, int insert_mode, uint32_t* applied_idx, uint64_t* n_applied,
+                      uint8_t* flags, bmx_merge_stats* stats) {
+  if (!ctx) return fail(nullptr, BMX_ERR_INVALID, "null context");
+  if (n && !recs) return fail(ctx, BMX_ERR_INVALID, "null records");
+  HIPCHK(hipSetDevice(ctx->device));
+  return merge_core<true>(ctx, n, nullptr, nullptr, nullptr, nullptr, recs, insert_mode, applied_idx, n_applied, flags, stats);
+}
+
+int bmx_load_rows(bmx_ctx* ctx, uint64_t n, const uint64_t* id, const uint32_t* field, const int64_t* ts, const int64_t* val, int mem) {
+  if (!ctx) return fail(nullptr, BMX_ERR_INVALID, "null context");
+  if (n && (!id || !field || !ts || !val)) return fail(ctx, BMX_ERR_INVALID, "null input column");
+  if (mem != BMX_MEM_HOST && mem != BMX_MEM_DEVICE) return fail(ctx, BMX_ERR_INVALID, "bad mem kind");
+  HIPCHK(hipSetDevice(ctx->device));
+  const uint64_t chunk = 1u << 22;
+  for (uint64_t off = 0; off < n; off += chunk) {
+    uint64_t m = std::min<uint64_t>(chunk, n - off);
+    int rc;
+    if (mem == BMX_MEM_DEVICE)
+      rc = merge_core<false>(ctx, m, id + off, field + off, ts + off, val + off, nullptr, BMX_INSERT_DELTA, nullptr, nullptr, nullptr, nullptr);
+    else
+      rc = merge_host(ctx, m, id + off, field + off, ts + off, val + off, BMX_INSERT_DELTA, nullptr, nullptr, nullptr, nullptr);
+    if (rc) return rc;
+  }
+  return mem == BMX_MEM_DEVICE ? BMX_OK : check_status(ctx);
+}
+
+int bmx_get_rows(bmx_ctx* ctx, uint64_t n, const uint64_t* id, const uint32_t* field, int64_t* ts, int64_t* val, uint8_t* found, int mem) {
+  if (!ctx) return fail(nullptr, BMX_ERR_INVALID, "null context");
+  if (n == 0) return BMX_OK;
+  if (!id || !field || !ts || !val || !found || n > 0xFFFFFFFFull) return fail(ctx, BMX_ERR_INVALID, "bad arguments");
+  HIPCHK(hipSetDevice(ctx->device));
+  const uint32_t blocks = (uint32_t)((n + 255) / 256);
+  if (mem == BMX_MEM_DEVICE) {
+    hipLaunchKernelGGL(k_get_rows, dim3(blocks), dim3(256), 0, ctx->stream, ctx->slots, ctx->nslots, (uint32_t)n, id, field, ts, val, found);
+    LAUNCHCHK("k_get_rows");
+    return BMX_OK;
+  }
+  if (mem != BMX_MEM_HOST) return fail(ctx, BMX_ERR_INVALID, "bad mem kind");
+  uint64_t* d_id = nullptr; uint32_t* d_f = nullptr; int64_t* d_ts = nullptr; int64_t* d_val = nullptr; uint8_t* d_found = nullptr;
+  int rc;
+  if ((rc = dev_alloc(ctx, &d_id, n)) || (rc = dev_alloc(ctx, &d_f, n)) || (rc = dev_alloc(ctx, &d_ts, n)) || (rc = dev_alloc(ctx, &d_val, n)) ||
+      (rc = dev_alloc(ctx, &d_found, n))) {
+    dev_free(d_id); dev_free(d_f); dev_free(d_ts); dev_free(d_val); dev_free(d_found);
+    return rc;
+  }
+  hipError_t e = hipMemcpyAsync(d_id, id, n * 8, hipMemcpyHostToDevice, ctx->stream);
+  if (e == hipSuccess) e = hipMemcpyAsync(d_f, field, n * 4, hipMemcpyHostToDevice, ctx->stream);
+  if (e == hipSuccess) {
+    hipLaunchKernelGGL(k_get_rows, dim3(blocks), dim3(256), 0, ctx->stream, ctx->slots, ctx->nslots, (uint32_t)n, d_id, d_f, d_ts, d_val, d_found);
+    e = hipGetLastError();
+  }
+  if (e == hipSuccess) e = hipMemcpyAsync(ts, d_ts, n * 8, hipMemcpyDeviceToHost, ctx->stream);
+  if (e == hipSuccess) e = hipMemcpyAsync(val, d_val, n * 8, hipMemcpyDeviceToHost, ctx->stream);
+  if (e == hipSuccess) e = hipMemcpyAsync(found, d_found, n, hipMemcpyDeviceToHost, ctx->stream);
+  if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+  dev_free(d_id); dev_free(d_f); dev_free(d_ts); dev_free(d_val); dev_free(d_found);
+  if (e != hipSuccess) return fail_hip(ctx, e, "bmx_get_rows");
+  return BMX_OK;
+}
+
+int bmx_get_row(bmx_ctx* ctx, uint64_t id, uint32_t field, int64_t* ts, int64_t* val) {
+  uint8_t found = 0;
+  int64_t t = 0, v = 0;
+  int rc = bmx_get_rows(ctx, 1, &id, &field, &t, &v, &found, BMX_MEM_HOST);
+  if (rc) return rc;
+  if (found) { if (ts) *ts = t; if (val) *val = v; }
+  return found ? 1 : 0;
+}
+
+int bmx_dump_rows(bmx_ctx* ctx, uint64_t cap, uint64_t* id, uint32_t* field, int64_t* ts, int64_t* val, uint64_t* n_out, int mem) {
+  if (!ctx) return fail(nullptr, BMX_ERR_INVALID, "null context");
+  if (cap && (!id || !field || !ts || !val)) return fail(ctx, BMX_ERR_INVALID, "null output column");
+  if (mem != BMX_MEM_HOST && mem != BMX_MEM_DEVICE) return fail(ctx, BMX_ERR_INVALID, "bad mem kind");
+  HIPCHK(hipSetDevice(ctx->device));
+  const bool host = mem == BMX_MEM_HOST;
+  uint64_t* d_id = id; uint32_t* d_f = field; int64_t* d_ts = ts; int64_t* d_val = val;
+  int rc = BMX_OK;
+  if (host && cap) {
+    d_id = nullptr; d_f = nullptr; d_ts = nullptr; d_val = nullptr;
+    if ((rc = dev_alloc(ctx, &d_id, cap)) || (rc = dev_alloc(ctx, &d_f, cap)) || (rc = dev_alloc(ctx, &d_ts, cap)) || (rc = dev_alloc(ctx, &d_val, cap))) {
+      dev_free(d_id); dev_free(d_f); dev_free(d_ts); dev_free(d_val);
+      return rc;
+    }
+  }
+  PredSlotAny P{ctx->slots};
+  EmitRows Em{ctx->slots, cap, d_id, d_f, d_ts, d_val};
+  FinishCount Fin{host ? &ctx->ds->n_out : reinterpret_cast<unsigned long long*>(n_out)};
+  SelGeom g = sel_geom<PredSlotAny::E>(ctx->nslots);
+  hipLaunchKernelGGL((k_sel_count<PredSlotAny>), dim3(g.blocks), dim3(SEL_THREADS), 0, ctx->stream, P, ctx->nslots, g.tiles_per_block, ctx->block_counts);
+  hipLaunchKernelGGL((k_sel_write<PredSlotAny, EmitRows, FinishCount>), dim3(g.blocks), dim3(SEL_THREADS), 0, ctx->stream, P, Em, Fin, ctx->nslots,
+                     g.tiles_per_block, ctx->block_counts);
+  hipError_t e = hipGetLastError();
+  if (host) {
+    unsigned long long m = 0;
+    if (e == hipSuccess) e = hipMemcpyAsync(&m, &ctx->ds->n_out, sizeof(m), hipMemcpyDeviceToHost, ctx->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+    uint64_t k = std::min<uint64_t>(m, cap);
+    if (e == hipSuccess && k) {
+      e = hipMemcpy(id, d_id, k * 8, hipMemcpyDeviceToHost);
+      if (e == hipSuccess) e = hipMemcpy(field, d_f, k * 4, hipMemcpyDeviceToHost);
+      if (e == hipSuccess) e = hipMemcpy(ts, d_ts, k * 8, hipMemcpyDeviceToHost);
+      if (e == hipSuccess) e = hipMemcpy(val, d_val, k * 8, hipMemcpyDeviceToHost);
+    }
+    if (cap) { dev_free(d_id); dev_free(d_f); dev_free(d_ts); dev_free(d_val); }
+    if (n_out) *n_out = m;
+  }
+  if (e != hipSuccess) return fail_hip(ctx, e, "bmx_dump_rows");
+  return BMX_OK;
+}
+
+int bmx_index_build(bmx_ctx* ctx, uint32_t field) {
+  if (!ctx) return fail(nullptr, BMX_ERR_INVALID, "null context");
+  HIPCHK(hipSetDevice(ctx->device));
+  Index* ix;
+  return fresh_index(ctx, field, &ix);
+}
+
+int bmx_index_drop(bmx_ctx* ctx, uint32_t field) {
+  if (!ctx) return fail(nullptr, BMX_ERR_INVALID, "null context");
+  HIPCHK(hipSetDevice(ctx->device));
+  HIPCHK(hipStreamSynchronize(ctx->stream));
+  for (size_t i = 0; i < ctx->indexes.size(); i++)
+    if (ctx->indexes[i].field == field) {
+      dev_free(ctx->indexes[i].ids); dev_free(ctx->indexes[i].v64); dev_free(ctx->indexes[i].v32);
+      ctx->indexes.erase(ctx->indexes.begin() + (long)i);
+      return BMX_OK;
+    }
+  return fail(ctx, BMX_ERR_NO_INDEX, "no index on that field");
+}
+
+int bmx_index_size(bmx_ctx* ctx, uint32_t field, uint64_t* n_out) {
+  if (!ctx || !n_out) return fail(ctx, BMX_ERR_INVALID, "bad arguments");
+  HIPCHK(hipSetDevice(ctx->device));
+  Index* ix;
+  int rc = fresh_index(ctx, field, &ix);
+  if (rc) return rc;
+  *n_out = ix->n;
+  return BMX_OK;
+}
+
+int bmx_scan_range(bmx_ctx* ctx, uint32_t field, int64_t lo, int64_t hi, uint64_t* out_ids, uint64_t cap, uint64_t* n_out, int mem) {
+  if (!ctx) return fail(nullptr, BMX_ERR_INVALID, "null context");
+  HIPCHK(hipSetDevice(ctx->device));
+  return scan_range_impl(ctx, field, lo, hi, out_ids, cap, n_out, mem);
+}
+int bmx_scan_equals(bmx_ctx* ctx, uint32_t field, int64_t value, uint64_t* out_ids, uint64_t cap, uint64_t* n_out, int mem) {
+  return bmx_scan_range(ctx, field, value, value, out_ids, cap, n_out, mem);
+}
+int bmx_scan_count(bmx_ctx* ctx, uint32_t field, int64_t lo, int64_t hi, uint64_t* n_out, int mem) {
+  return bmx_scan_range(ctx, field, lo, hi, nullptr, 0, n_out, mem);
+}
+
+int bmx_scan_filter(bmx_ctx* ctx, uint32_t nterms, const bmx_term* terms, uint64_t* out_ids, uint64_t cap, uint64_t* n_out, int mem) {
+  if (!ctx) return fail(nullptr, BMX_ERR_INVALID, "null context");
+  if (nterms == 0 || nterms > MAX_TERMS || !terms) return fail(ctx, BMX_ERR_INVALID, "filter needs 1..8 terms");
+  if (mem != BMX_MEM_HOST && mem != BMX_MEM_DEVICE) return fail(ctx, BMX_ERR_INVALID, "bad mem kind");
+  HIPCHK(hipSetDevice(ctx->device));
+  Index* ix;
+  int rc = fresh_index(ctx, terms[0].field, &ix);
+  if (rc) return rc;
+  PredFilter P;
+  P.v = ix->v64; P.ids = ix->ids; P.slots = ctx->slots; P.nslots = ctx->nslots; P.nterms = nterms;
+  for (uint32_t k = 0; k < nterms; k++) P.t[k] = terms[k];
+  return run_scan(ctx, P, ix, out_ids, cap, n_out, mem);
+}
+
+int bmx_partition_by_owner(bmx_ctx* ctx, uint64_t n, const uint64_t* id, const uint32_t* field, const int64_t* ts, const int64_t* val,
+                           uint32_t nshards, bmx_delta_rec* recs_out, uint64_t* counts_out_dev) {
+  if (!ctx) return fail(nullptr, BMX_ERR_INVALID, "null context");
+  if (nshards == 0 || nshards > PART_MAX_SHARDS || n > 0xFFFFFFFFull || !counts_out_dev) return fail(ctx, BMX_ERR_INVALID, "bad arguments (1..16 shards)");
+  if (n && (!id || !field || !ts || !val || !recs_out)) return fail(ctx, BMX_ERR_INVALID, "null pointer");
+  HIPCHK(hipSetDevice(ctx->device));
+  uint32_t per_block = (uint32_t)((n + PART_BLOCKS - 1) / PART_BLOCKS);
+  per_block = std::max<uint32_t>(256, (per_block + 255) & ~255u);
+  hipLaunchKernelGGL(k_part_count, dim3(PART_BLOCKS), dim3(256), 0, ctx->stream, id, (uint32_t)n, nshards, per_block, ctx->part_counts);
+  LAUNCHCHK("k_part_count");
+  hipLaunchKernelGGL(k_part_scatter, dim3(PART_BLOCKS), dim3(256), 0, ctx->stream, id, field, ts, val, (uint32_t)n, nshards, per_block, ctx->part_counts,
+                     recs_out, reinterpret_cast<unsigned long long*>(counts_out_dev));
+  LAUNCHCHK("k_part_scatter");
+  return BMX_OK;
+}
+
+int bmx_timer_start(bmx_ctx* ctx) {
+  if (!ctx) return fail(nullptr, BMX_ERR_INVALID, "null context");
+  HIPCHK(hipEventRecord(ctx->ev0, ctx->stream));
+  return BMX_OK;
+}
+int bmx_timer_stop(bmx_ctx* ctx, float* ms_out) {
+  if (!ctx || !ms_out) return fail(ctx, BMX_ERR_INVALID, "bad arguments");
+  HIPCHK(hipEventRecord(ctx->ev1, ctx->stream));
+  HIPCHK(hipEventSynchronize(ctx->ev1));
+  HIPCHK(hipEventElapsedTime(ms_out, ctx->ev0, ctx->ev1));
+  return BMX_OK;
+}
+
+int bmx_profile_enable(bmx_ctx* ctx, int on) {
+  if (!ctx) return fail(nullptr, BMX_ERR_INVALID, "null context");
+  HIPCHK(hipSetDevice(ctx->device));
+  HIPCHK(hipStreamSynchronize(ctx->stream));
+  if (on && ctx->prof_ev.empty()) {
+    ctx->prof_ev.resize(4 * PROF_MAX_CALLS, nullptr);
+    for (auto& ev : ctx->prof_ev) HIPCHK(hipEventCreate(&ev));
+  }
+  ctx->prof_on = on != 0;
+  ctx->prof_n = 0;
+  return BMX_OK;
+}
+
+int bmx_profile_read(bmx_ctx* ctx, float ms_out[3], uint32_t* n_calls) {
+  if (!ctx || !ms_out || !n_calls) return fail(ctx, BMX_ERR_INVALID, "bad arguments");
+  HIPCHK(hipSetDevice(ctx->device));
+  HIPCHK(hipStreamSynchronize(ctx->stream));
+  double acc[3] = {0, 0, 0};
+  for (uint32_t i = 0; i < ctx->prof_n; i++)
+    for (int k = 0; k < 3; k++) {
+      float ms = 0;
+      HIPCHK(hipEventElapsedTime(&ms, ctx->prof_ev[4 * i + k], ctx->prof_ev[4 * i + k + 1]));
+      acc[k] += ms;
+    }
+  for (int k = 0; k < 3; k++) ms_out[k] = ctx->prof_n ? (float)(acc[k] / ctx->prof_n) : 0.f;
+  *n_calls = ctx->prof_n;
+  return BMX_OK;
+}
+
+}  // extern "C"

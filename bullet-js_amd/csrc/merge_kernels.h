@@ -1,0 +1,373 @@
+// merge_kernels.h — delta-vs-resident join and conflict resolution (K1/K2/K4 of SURVEY §2.1), gfx950.
+//
+// Replaces, for scalar clocks {w: ts}, the per-entry loop
+//     for (entry of entries) bullet.setData(...)  ->  crt.handleUpdate -> crt.resolve
+// (reference src/bullet-network-sync.js:551-569, src/bullet-crt.js:329-385, :164-279) by three launches
+// whose joint effect on the resident rows and on the reported winners equals that loop's:
+//
+//   k_probe_apply    one lane per delta: probe the row's slot (ONE 128-B line), decide against the
+//                    snapshot it saw, claim the row with ONE atomicExch on slot.head, and — if it is the
+//                    first claimer of the batch — store (ts,val) right away (one aligned 16-B store).
+//                    An absent key is created with a CAS on slot.id plus one 64-bit exchange that publishes
+//                    the field and claims the head together.
+//                    Later claimers of the same row (duplicate keys) link themselves into a per-row
+//                    list (next[]) and mark themselves pending instead of writing.
+//   k_resolve_lists  pending deltas only (none for unique-key batches without inserts): the LAST claimer of
+//                    each row walks the row's list and applies the reference's sequential outcome (lexmax of
+//                    (ts,val), ties to the smaller index, first write of an absent key stored with ts := 2).
+//   select (select.h) ordered compaction of the per-delta winner bytes -> applied_idx.
+//
+// Why this shape (measured, profiles/r01_micro_probe_v2.log): a random probe costs one 128-B line
+// (~50 G lines/s), a dirty line costs its write-back, and global atomics run at ~25 G/s whatever the
+// table size — so each delta gets exactly one line read, at most one atomic, at most one 16-B store,
+// and nothing ever revisits the table unless two deltas of one batch share a key.
+#pragma once
+#include "slot.h"
+#include "../../include/bmx.h"
+
+namespace bmx {
+
+struct MergeArgs {
+  Slot* slots;
+  uint64_t nslots;
+  const uint64_t* id;
+  const uint32_t* field;
+  const int64_t* ts;
+  const int64_t* val;
+  const bmx_delta_rec* recs;  // AoS input (id/field/ts/val unused then)
+  uint32_t n;
+  uint32_t epoch;             // 1..EPOCH_MAX
+  uint32_t* next;             // per delta: (epoch<<24)|previous claimer; stale epoch = end of list
+  uint8_t* wflag;             // per delta: W_WINNER = this delta's value is the row's final value,
+                              //            W_PENDING = needs k_resolve_lists (duplicate key / reference-mode insert)
+  uint8_t* flags;             // optional decision flags
+  uint32_t* slot_of;          // per delta, written for W_PENDING deltas only: the row's slot
+  unsigned long long* shard_ctr;  // CTR_SHARDS x CTR_STRIDE counters: [s][0] rows created, [s][1] conflicts
+  uint32_t* status;
+};
+
+constexpr uint8_t W_NONE = 0, W_WINNER = 1, W_PENDING = 2;
+// A single hot word takes only ~88 atomics/us (MI355X_MICROARCH.md "dequeue"), so per-batch counters are
+// spread over 256 words on separate 128-B lines and folded once per batch by the last compaction block.
+constexpr uint32_t CTR_SHARDS = 256, CTR_STRIDE = 16;
+
+template <bool AOS>
+__device__ __forceinline__ void load_delta(const MergeArgs& A, uint32_t j, uint64_t& id, uint32_t& field, int64_t& ts, int64_t& val) {
+  if (AOS) {
+    const uint4* p = reinterpret_cast<const uint4*>(A.recs + j);
+    uint4 lo = p[0], hi = p[1];
+    id = (uint64_t)lo.x | ((uint64_t)lo.y << 32);
+    field = lo.z;
+    ts = (int64_t)((uint64_t)hi.x | ((uint64_t)hi.y << 32));
+    val = (int64_t)((uint64_t)hi.z | ((uint64_t)hi.w << 32));
+  } else {
+    id = A.id[j]; field = A.field[j]; ts = A.ts[j]; val = A.val[j];
+  }
+}
+template <bool AOS>
+__device__ __forceinline__ void load_delta_tv(const MergeArgs& A, uint32_t j, int64_t& ts, int64_t& val) {
+  if (AOS) {
+    uint4 hi = reinterpret_cast<const uint4*>(A.recs + j)[1];
+    ts = (int64_t)((uint64_t)hi.x | ((uint64_t)hi.y << 32));
+    val = (int64_t)((uint64_t)hi.z | ((uint64_t)hi.w << 32));
+  } else {
+    ts = A.ts[j]; val = A.val[j];
+  }
+}
+
+__device__ __forceinline__ void store_tv(Slot* sl, int64_t ts, int64_t val) {
+  uint4 v = make_uint4((uint32_t)(uint64_t)ts, (uint32_t)((uint64_t)ts >> 32), (uint32_t)(uint64_t)val, (uint32_t)((uint64_t)val >> 32));
+  reinterpret_cast<uint4*>(sl)[1] = v;  // one aligned global_store_dwordx4: (ts,val) never tears
+}
+
+// Locate (or create) the slot of key (id, field). Returns false if the table is full / protocol fault.
+// is_new: the row has no resident value visible to this lane (created in this batch, by anyone).
+// created: this lane created the row AND (with the same 64-bit exchange that publishes the field) claimed it;
+// prev_head is then the old head word.
+__device__ __forceinline__ bool probe_or_insert(const MergeArgs& A, uint32_t tag, uint64_t id, uint32_t field, uint64_t& slot_out,
+                                                bool& is_new, bool& created, uint32_t& prev_head, int64_t& cts, int64_t& cval) {
+  created = false;
+  uint64_t s = home_slot(key_hash(id, field), A.nslots);
+  for (uint64_t p = 0; p < A.nslots; ++p) {
+    Slot* sl = A.slots + s;
+    const uint4* q = reinterpret_cast<const uint4*>(sl);
+    uint4 lo = q[0], hi = q[1];
+    uint64_t sid = (uint64_t)lo.x | ((uint64_t)lo.y << 32);
+    uint32_t sf = lo.z;
+    bool fresh = false;
+    if (sid == EMPTY_ID) {
+      unsigned long long old = atomicCAS(reinterpret_cast<unsigned long long*>(&sl->id), (unsigned long long)EMPTY_ID, (unsigned long long)id);
+      if (old == EMPTY_ID) {  // this lane created the row: ONE 64-bit exchange publishes the field and claims the head
+        unsigned long long w1 = atomicExch(reinterpret_cast<unsigned long long*>(&sl->field), (unsigned long long)field | ((unsigned long long)tag << 32));
+        prev_head = (uint32_t)(w1 >> 32);
+        created = true;
+        slot_out = s; is_new = true; cts = TS_NEW; cval = 0;
+        return true;
+      }
+      sid = old;            // somebody claimed it while we looked (or our L1 copy was stale)
+      sf = FIELD_PENDING;   // read the field through L2
+      fresh = true;         // whatever (ts,val) we loaded is not a resident value
+    }
+    if (sid == id) {
+      if (sf == FIELD_PENDING) {
+        uint32_t spins = 0;
+        do {
+          sf = __hip_atomic_load(&sl->field, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          if (sf != FIELD_PENDING) break;
+          __builtin_amdgcn_s_sleep(1);
+        } while (++spins < (1u << 22));
+        if (sf == FIELD_PENDING) { atomicOr(A.status, ST_SPIN); return false; }
+      }
+      if (sf == field) {
+        int64_t t = (int64_t)((uint64_t)hi.x | ((uint64_t)hi.y << 32));
+        slot_out = s;
+        // no pre-batch state: slot just claimed, still unwritten, or created earlier in this very batch
+        is_new = fresh || t == TS_NEW || ts_mark(t) == (tag >> IDX_BITS);
+        cts = is_new ? TS_NEW : ts_value(t);
+        cval = (int64_t)((uint64_t)hi.z | ((uint64_t)hi.w << 32));
+        return true;
+      }
+    }
+    s = (s + 1 == A.nslots) ? 0 : s + 1;
+  }
+  atomicOr(A.status, ST_FULL);
+  return false;
+}
+
+template <bool AOS, int MODE>
+__global__ __launch_bounds__(256) void k_probe_apply(MergeArgs A) {
+  const uint32_t j = blockIdx.x * 256u + threadIdx.x;
+  const bool active = j < A.n;
+  uint64_t id = EMPTY_ID; uint32_t field = 0; int64_t a = 0, v = 0;
+  if (active) load_delta<AOS>(A, j, id, field, a, v);
+  const bool pad = AOS && id == EMPTY_ID;  // padding record of a fixed-size exchange slab
+  const bool valid = active && id != EMPTY_ID && field != FIELD_PENDING && a >= 0 && a <= TS_MAX && v >= -VAL_MAX && v <= VAL_MAX;
+  if (active && !valid && !pad) atomicOr(A.status, ST_RANGE);
+
+  uint32_t fl = 0, wf = W_NONE;
+  bool conflict = false, created = false;
+  if (valid) {
+    bool is_new; int64_t cts, cval; uint64_t s; uint32_t prev = 0;
+    const uint32_t tag = (A.epoch << IDX_BITS) | j;
+    if (probe_or_insert(A, tag, id, field, s, is_new, created, prev, cts, cval)) {
+      // decision against the snapshot this lane saw (resolve(): src/bullet-crt.js:164-279, scalar clocks)
+      int c = is_new ? 1 : lexcmp(a, v, cts, cval);
+      if (c < 0) {
+        // strictly below a pre-batch value or a value stored in this batch by a delta of a resident row:
+        // it can never be the final value
+        fl = BMX_FLAG_CURRENT | (a < cts ? BMX_FLAG_HISTORICAL : 0u);
+      } else {
+        Slot* sl = A.slots + s;
+        if (!created) prev = atomicExch(&sl->head, tag);
+        if ((prev >> IDX_BITS) != A.epoch) {
+          // first claimer of this row in this batch: its snapshot is the pre-batch row
+          if (is_new) {
+            // first write of an absent key: the reference stores clock {id:2} (src/bullet-crt.js:172-185);
+            // the creation mark keeps later deltas of this key from comparing against this provisional value
+            const int64_t t0 = (MODE == BMX_INSERT_REFERENCE) ? 2 : a;
+            store_tv(sl, t0 | ((int64_t)A.epoch << TS_MARK_SHIFT), v);
+            wf = W_WINNER; fl = BMX_FLAG_INCOMING;
+          } else if (c > 0) {
+            store_tv(sl, a, v); wf = W_WINNER; fl = BMX_FLAG_INCOMING;
+          }  // c == 0: identical clock and value: no-op, all flags false
+        } else {
+          // duplicate key inside the batch: link behind the previous claimer, resolve in k_resolve_lists
+          A.next[j] = (A.epoch << IDX_BITS) | (prev & IDX_MASK);
+          A.slot_of[j] = (uint32_t)s;
+          wf = W_PENDING; conflict = true;
+          fl = c > 0 ? BMX_FLAG_INCOMING : 0u;
+        }
+      }
+    }
+  }
+  // per-wave counts into sharded counters (no return value: the wave does not wait for them)
+  {
+    unsigned long long mc = __ballot(created), mx = __ballot(conflict);
+    if (lane_id() == 0 && (mc | mx)) {
+      unsigned long long* ctr = A.shard_ctr + (size_t)((blockIdx.x * 4u + (threadIdx.x >> 6)) & (CTR_SHARDS - 1)) * CTR_STRIDE;
+      if (mc) atomicAdd(ctr + 0, (unsigned long long)__popcll(mc));
+      if (mx) atomicAdd(ctr + 1, (unsigned long long)__popcll(mx));
+    }
+  }
+  if (active) {
+    A.wflag[j] = (uint8_t)wf;
+    if (A.flags) A.flags[j] = (uint8_t)fl;
+  }
+}
+
+// Pending pass (duplicate keys only). 16 winner bytes per lane are scanned; only the LAST claimer of a row
+// (slot.head names it) does anything: it walks next[] back to the first claimer and applies the sequential
+// outcome for that key.
+template <bool AOS, int MODE>
+__device__ __forceinline__ void resolve_one(const MergeArgs& A, uint32_t j) {
+  Slot* sl = A.slots + A.slot_of[j];
+  if ((sl->head & IDX_MASK) != j) return;
+  const int64_t tsw = sl->ts;
+  const bool is_new = tsw == TS_NEW || ts_mark(tsw) == A.epoch;  // row created in this batch: no pre-batch state
+  // pass 1: find the first claimer (end of list) and the smallest index (creates an absent row: src/bullet-crt.js:172-185)
+  uint32_t j0 = j, first = j;
+  {
+    uint32_t idx = j, steps = 0;
+    for (;;) {
+      if (idx < j0) j0 = idx;
+      uint32_t nx = A.next[idx];
+      if ((nx >> IDX_BITS) != A.epoch) { first = idx; break; }
+      idx = nx & IDX_MASK;
+      if (++steps > A.n) { atomicOr(A.status, ST_SPIN); return; }
+    }
+  }
+  int64_t bt, bv;      // best (ts,val) so far
+  uint32_t owner;      // delta that owns `best`, or ~0u if it is the resident row
+  const uint32_t base_owner = A.wflag[first] == W_WINNER ? first : ~0u;  // the first claimer stored iff it beat the pre-batch row
+  if (is_new) {
+    int64_t t0, v0; load_delta_tv<AOS>(A, j0, t0, v0);
+    bt = (MODE == BMX_INSERT_REFERENCE) ? 2 : t0; bv = v0; owner = j0;
+  } else {
+    bt = ts_value(tsw); bv = sl->val; owner = base_owner;
+  }
+  // pass 2: lexmax over the list, ties to the smaller index ("identical clocks and values" is a no-op, :207-219)
+  {
+    uint32_t idx = j, steps = 0;
+    for (;;) {
+      if (!(is_new && idx == j0)) {
+        int64_t t, v; load_delta_tv<AOS>(A, idx, t, v);
+        int c = lexcmp(t, v, bt, bv);
+        if (c > 0) { bt = t; bv = v; owner = idx; }
+        else if (c == 0 && owner != ~0u && idx < owner) owner = idx;
+      }
+      uint32_t nx = A.next[idx];
+      if ((nx >> IDX_BITS) != A.epoch) break;
+      idx = nx & IDX_MASK;
+      if (++steps > A.n) break;
+    }
+  }
+  store_tv(sl, is_new ? (bt | ((int64_t)A.epoch << TS_MARK_SHIFT)) : bt, bv);
+  if (base_owner != ~0u && base_owner != owner) A.wflag[base_owner] = W_NONE;
+  if (owner != ~0u) A.wflag[owner] = W_WINNER;
+}
+
+template <bool AOS, int MODE>
+__global__ __launch_bounds__(256) void k_resolve_lists(MergeArgs A) {
+  const uint32_t ngroups = (A.n + 15u) / 16u;
+  for (uint32_t g = blockIdx.x * 256u + threadIdx.x; g < ngroups; g += gridDim.x * 256u) {
+    const uint32_t base = g * 16u;
+    uint4 x = *reinterpret_cast<const uint4*>(A.wflag + base);   // wflag is padded to a multiple of 16
+    uint32_t q[4] = {x.x, x.y, x.z, x.w};
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+      uint32_t pend = q[k] & 0x02020202u;                          // W_PENDING bytes
+      while (pend) {
+        int b = (__ffs((int)pend) - 1) >> 3;
+        pend &= ~(0xFFu << (8 * b));
+        uint32_t j = base + 4u * k + (uint32_t)b;
+        if (j < A.n) resolve_one<AOS, MODE>(A, j);
+      }
+    }
+  }
+}
+
+// epoch wrap: forget every claim tag and every creation mark
+__global__ __launch_bounds__(256) void k_sweep_heads(Slot* slots, uint64_t nslots) {
+  for (uint64_t s = (uint64_t)blockIdx.x * 256u + threadIdx.x; s < nslots; s += (uint64_t)gridDim.x * 256u) {
+    slots[s].head = 0;
+    int64_t t = slots[s].ts;
+    if (t != TS_NEW && ts_mark(t)) slots[s].ts = ts_value(t);
+  }
+}
+
+__global__ __launch_bounds__(256) void k_init_slots(Slot* slots, uint64_t nslots) {
+  const uint4 lo = make_uint4(0xFFFFFFFFu, 0xFFFFFFFFu, FIELD_PENDING, 0u);
+  const uint4 hi = make_uint4(0u, 0x80000000u, 0u, 0u);  // ts = INT64_MIN, val = 0
+  for (uint64_t s = (uint64_t)blockIdx.x * 256u + threadIdx.x; s < nslots; s += (uint64_t)gridDim.x * 256u) {
+    uint4* q = reinterpret_cast<uint4*>(slots + s);
+    q[0] = lo; q[1] = hi;
+  }
+}
+
+// read-only lookup of n keys
+__global__ __launch_bounds__(256) void k_get_rows(const Slot* slots, uint64_t nslots, uint32_t n, const uint64_t* id,
+                                                  const uint32_t* field, int64_t* ts, int64_t* val, uint8_t* found) {
+  uint32_t j = blockIdx.x * 256u + threadIdx.x;
+  if (j >= n) return;
+  uint64_t kid = id[j]; uint32_t kf = field[j];
+  uint64_t s = home_slot(key_hash(kid, kf), nslots);
+  uint8_t f = 0; int64_t t = 0, v = 0;
+  for (uint64_t p = 0; p < nslots; ++p) {
+    const uint4* q = reinterpret_cast<const uint4*>(slots + s);
+    uint4 lo = q[0];
+    uint64_t sid = (uint64_t)lo.x | ((uint64_t)lo.y << 32);
+    if (sid == EMPTY_ID) break;
+    if (sid == kid && lo.z == kf) {
+      uint4 hi = q[1];
+      t = (int64_t)((uint64_t)hi.x | ((uint64_t)hi.y << 32));
+      v = (int64_t)((uint64_t)hi.z | ((uint64_t)hi.w << 32));
+      f = t != TS_NEW;
+      t = ts_value(t);
+      break;
+    }
+    s = (s + 1 == nslots) ? 0 : s + 1;
+  }
+  ts[j] = t; val[j] = v; found[j] = f;
+}
+
+// K7: stable partition of a delta batch by owner shard into 32-byte records.
+constexpr int PART_MAX_SHARDS = 16;
+constexpr int PART_BLOCKS = 256;
+
+__device__ __forceinline__ uint32_t owner_of_dev(uint64_t id, uint32_t nshards) { return (uint32_t)__umul64hi(owner_hash(id), (uint64_t)nshards); }
+
+__global__ __launch_bounds__(256) void k_part_count(const uint64_t* id, uint32_t n, uint32_t nshards, uint32_t per_block,
+                                                    uint32_t* counts /*[nshards][PART_BLOCKS]*/) {
+  __shared__ uint32_t hist[PART_MAX_SHARDS];
+  if (threadIdx.x < PART_MAX_SHARDS) hist[threadIdx.x] = 0;
+  __syncthreads();
+  uint32_t lo = blockIdx.x * per_block, hi = min(n, lo + per_block);
+  for (uint32_t j = lo + threadIdx.x; j < hi; j += 256) atomicAdd(&hist[owner_of_dev(id[j], nshards)], 1u);
+  __syncthreads();
+  if (threadIdx.x < nshards) counts[threadIdx.x * PART_BLOCKS + blockIdx.x] = hist[threadIdx.x];
+}
+
+__global__ __launch_bounds__(256) void k_part_scatter(const uint64_t* id, const uint32_t* field, const int64_t* ts, const int64_t* val,
+                                                      uint32_t n, uint32_t nshards, uint32_t per_block, const uint32_t* counts,
+                                                      bmx_delta_rec* out, unsigned long long* totals) {
+  __shared__ uint32_t base[PART_MAX_SHARDS];   // running output cursor of this block per shard
+  __shared__ uint32_t wcnt[4][PART_MAX_SHARDS];
+  // cursor[g] = sum of all counts of shards < g + counts of shard g in blocks < this one
+  if (threadIdx.x < nshards) {
+    uint32_t g = threadIdx.x, acc = 0;
+    for (uint32_t gg = 0; gg < g; gg++) for (uint32_t b = 0; b < PART_BLOCKS; b++) acc += counts[gg * PART_BLOCKS + b];
+    uint32_t tot = 0;
+    for (uint32_t b = 0; b < PART_BLOCKS; b++) { uint32_t c = counts[g * PART_BLOCKS + b]; if (b < blockIdx.x) acc += c; tot += c; }
+    base[g] = acc;
+    if (blockIdx.x == 0) totals[g] = tot;
+  }
+  __syncthreads();
+  const uint32_t lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  uint32_t lo = blockIdx.x * per_block, hi = min(n, lo + per_block);
+  for (uint32_t t0 = lo; t0 < hi; t0 += 256) {
+    uint32_t j = t0 + threadIdx.x;
+    bool act = j < hi;
+    uint64_t kid = 0; uint32_t g = 0xFFFFFFFFu;
+    if (act) { kid = id[j]; g = owner_of_dev(kid, nshards); }
+    uint32_t rank_in_wave = 0;
+    for (uint32_t gg = 0; gg < nshards; gg++) {
+      unsigned long long m = __ballot(act && g == gg);
+      if (g == gg) rank_in_wave = (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
+      if (lane == 0) wcnt[w][gg] = (uint32_t)__popcll(m);
+    }
+    __syncthreads();
+    if (act) {
+      uint32_t pos = base[g] + rank_in_wave;
+      for (uint32_t ww = 0; ww < w; ww++) pos += wcnt[ww][g];
+      uint4* q = reinterpret_cast<uint4*>(out + pos);
+      uint64_t t = (uint64_t)ts[j], v = (uint64_t)val[j];
+      q[0] = make_uint4((uint32_t)kid, (uint32_t)(kid >> 32), field[j], j);
+      q[1] = make_uint4((uint32_t)t, (uint32_t)(t >> 32), (uint32_t)v, (uint32_t)(v >> 32));
+    }
+    __syncthreads();
+    if (threadIdx.x < nshards) { uint32_t g2 = threadIdx.x; base[g2] += wcnt[0][g2] + wcnt[1][g2] + wcnt[2][g2] + wcnt[3][g2]; }
+    __syncthreads();
+  }
+}
+
+}  // namespace bmx

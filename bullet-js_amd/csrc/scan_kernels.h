@@ -1,0 +1,200 @@
+// scan_kernels.h — index build and index scans (K5/K6 of SURVEY §2.1), gfx950.
+//
+// An index (reference: BulletQuery.index/_buildIndex, src/bullet-query.js:30-73) is a pair of dense,
+// coalesced columns (node id u64, value i32 or i64) of the rows carrying one field, compacted from the
+// table in slot order. range()/equals()/count() (src/bullet-query.js:186-261, 293-313) stream the value
+// column once (16 B per lane per load), and compact the matching node ids with select.h. The scan is
+// HBM-stream bound: w*R bytes in + 8*M bytes out.
+#pragma once
+#include "select.h"
+#include "merge_kernels.h"
+#include "../../include/bmx.h"
+
+namespace bmx {
+
+// ---- predicates over the resident table (index build, dump) ----
+struct PredSlotField {  // slots holding a row of `field`
+  static constexpr int E = 2;
+  const Slot* slots; uint32_t field;
+  __device__ uint32_t mask(uint64_t first, uint64_t n) const {
+    uint32_t m = 0;
+#pragma unroll
+    for (int e = 0; e < E; e++) {
+      uint64_t s = first + e;
+      if (s < n) {
+        uint4 lo = reinterpret_cast<const uint4*>(slots + s)[0];
+        bool occ = !(lo.x == 0xFFFFFFFFu && lo.y == 0xFFFFFFFFu);
+        if (occ && lo.z == field) m |= 1u << e;
+      }
+    }
+    return m;
+  }
+};
+struct PredSlotAny {  // every occupied slot
+  static constexpr int E = 2;
+  const Slot* slots;
+  __device__ uint32_t mask(uint64_t first, uint64_t n) const {
+    uint32_t m = 0;
+#pragma unroll
+    for (int e = 0; e < E; e++) {
+      uint64_t s = first + e;
+      if (s < n) {
+        uint4 lo = reinterpret_cast<const uint4*>(slots + s)[0];
+        if (!(lo.x == 0xFFFFFFFFu && lo.y == 0xFFFFFFFFu)) m |= 1u << e;
+      }
+    }
+    return m;
+  }
+};
+struct EmitIndex {  // slot -> index columns
+  const Slot* slots; uint64_t* ids; int64_t* v64; int32_t* v32; uint32_t* wide;  // *wide set if a value does not fit i32
+  __device__ void operator()(uint64_t pos, uint64_t s) const {
+    const Slot& sl = slots[s];
+    int64_t v = sl.val;
+    ids[pos] = sl.id; v64[pos] = v; v32[pos] = (int32_t)v;
+    if (v != (int64_t)(int32_t)v) *wide = 1u;
+  }
+};
+struct EmitRows {  // slot -> dumped row columns (bounded by cap)
+  const Slot* slots; uint64_t cap; uint64_t* id; uint32_t* field; int64_t* ts; int64_t* val;
+  __device__ void operator()(uint64_t pos, uint64_t s) const {
+    if (pos >= cap) return;
+    const Slot& sl = slots[s];
+    id[pos] = sl.id; field[pos] = sl.field; ts[pos] = ts_value(sl.ts); val[pos] = sl.val;
+  }
+};
+
+// ---- predicates over an index value column ----
+struct PredRange32 {  // lo <= v <= hi on an int32 column, 4 values (16 B) per lane
+  static constexpr int E = 4;
+  const int32_t* v; int32_t lo, hi;
+  __device__ uint32_t mask(uint64_t first, uint64_t n) const {
+    uint32_t m = 0;
+    if (first + 4 <= n) {
+      int4 x = *reinterpret_cast<const int4*>(v + first);
+      m = (uint32_t)(x.x >= lo && x.x <= hi) | ((uint32_t)(x.y >= lo && x.y <= hi) << 1) |
+          ((uint32_t)(x.z >= lo && x.z <= hi) << 2) | ((uint32_t)(x.w >= lo && x.w <= hi) << 3);
+    } else {
+      for (int e = 0; e < 4 && first + e < n; e++) { int32_t x = v[first + e]; m |= (uint32_t)(x >= lo && x <= hi) << e; }
+    }
+    return m;
+  }
+};
+struct PredRange64 {  // int64 column, 2 values (16 B) per lane
+  static constexpr int E = 2;
+  const int64_t* v; int64_t lo, hi;
+  __device__ uint32_t mask(uint64_t first, uint64_t n) const {
+    uint32_t m = 0;
+    if (first + 2 <= n) {
+      longlong2 x = *reinterpret_cast<const longlong2*>(v + first);
+      m = (uint32_t)(x.x >= lo && x.x <= hi) | ((uint32_t)(x.y >= lo && x.y <= hi) << 1);
+    } else if (first < n) {
+      int64_t x = v[first]; m = (uint32_t)(x >= lo && x <= hi);
+    }
+    return m;
+  }
+};
+
+// Declarative filter (subset of filter(path, fn), src/bullet-query.js:270-283): term 0 on the index column,
+// the remaining terms by probing the node's other field rows in the table.
+constexpr int MAX_TERMS = 8;
+struct PredFilter {
+  static constexpr int E = 2;
+  const int64_t* v; const uint64_t* ids; const Slot* slots; uint64_t nslots;
+  uint32_t nterms; bmx_term t[MAX_TERMS];
+  __device__ bool rest(uint64_t id) const {
+    for (uint32_t k = 1; k < nterms; k++) {
+      uint64_t s = home_slot(key_hash(id, t[k].field), nslots);
+      bool ok = false;
+      for (uint64_t p = 0; p < nslots; ++p) {
+        const uint4* q = reinterpret_cast<const uint4*>(slots + s);
+        uint4 lo = q[0];
+        uint64_t sid = (uint64_t)lo.x | ((uint64_t)lo.y << 32);
+        if (sid == EMPTY_ID) break;
+        if (sid == id && lo.z == t[k].field) {
+          uint4 hi = q[1];
+          int64_t x = (int64_t)((uint64_t)hi.z | ((uint64_t)hi.w << 32));
+          ok = x >= t[k].lo && x <= t[k].hi;
+          break;
+        }
+        s = (s + 1 == nslots) ? 0 : s + 1;
+      }
+      if (!ok) return false;
+    }
+    return true;
+  }
+  __device__ uint32_t mask(uint64_t first, uint64_t n) const {
+    uint32_t m = 0;
+#pragma unroll
+    for (int e = 0; e < E; e++) {
+      uint64_t i = first + e;
+      if (i < n) { int64_t x = v[i]; if (x >= t[0].lo && x <= t[0].hi && rest(ids[i])) m |= 1u << e; }
+    }
+    return m;
+  }
+};
+
+struct EmitIds {  // index position -> node id (bounded by cap)
+  const uint64_t* ids; uint64_t* out; uint64_t cap;
+  __device__ void operator()(uint64_t pos, uint64_t i) const { if (out && pos < cap) out[pos] = ids[i]; }
+};
+struct FinishCount {  // total -> *n_out (device), optional
+  unsigned long long* n_out;
+  __device__ void operator()(uint64_t total, uint32_t*) const { if (n_out && threadIdx.x == 0) *n_out = total; }
+};
+
+// K3 winner compaction over the per-delta winner bytes: 16 flags (16 B) per lane
+struct PredWinner {
+  static constexpr int E = 16;
+  const uint8_t* w;
+  __device__ uint32_t mask(uint64_t first, uint64_t n) const {
+    uint32_t m = 0;
+    if (first + 16 <= n) {
+      uint4 x = *reinterpret_cast<const uint4*>(w + first);
+      uint32_t q[4] = {x.x, x.y, x.z, x.w};
+#pragma unroll
+      for (int k = 0; k < 4; k++) {
+        // bytes are 0/1: gather bit 0 of each byte
+        uint32_t b = q[k] & 0x01010101u;
+        m |= (((b * 0x10204080u) >> 28) & 0xFu) << (4 * k);
+      }
+    } else {
+      for (int e = 0; e < 16 && first + e < n; e++) m |= (uint32_t)(w[first + e] & 1u) << e;
+    }
+    return m;
+  }
+};
+struct EmitApplied {
+  uint32_t* out;
+  __device__ void operator()(uint64_t pos, uint64_t j) const { if (out) out[pos] = (uint32_t)j; }
+};
+struct FinishMerge {  // totals -> caller; fold and clear the sharded per-batch counters
+  unsigned long long* n_applied; bmx_merge_stats* stats;
+  unsigned long long* shard_ctr; unsigned long long* row_count;
+  __device__ void operator()(uint64_t total, uint32_t* lds4) const {
+    static_assert(CTR_SHARDS == SEL_THREADS, "one counter shard per thread");
+    unsigned long long* c = shard_ctr + (size_t)threadIdx.x * CTR_STRIDE;
+    uint32_t rows = (uint32_t)c[0], conf = (uint32_t)c[1];
+    c[0] = 0; c[1] = 0;
+    uint32_t trows, tconf;
+    block_excl_scan(rows, trows, lds4);
+    block_excl_scan(conf, tconf, lds4);
+    if (threadIdx.x == 0) {
+      unsigned long long r = *row_count + trows;
+      *row_count = r;
+      if (n_applied) *n_applied = total;
+      if (stats) { stats->n_applied = total; stats->n_conflicts = tconf; stats->n_rows = r; stats->reserved = 0; }
+    }
+  }
+};
+
+__global__ void k_sum_counts(const uint32_t* block_counts, uint32_t nblocks, unsigned long long* n_out) {
+  __shared__ uint32_t wsum[4];
+  uint32_t part = 0;
+  for (uint32_t b = threadIdx.x; b < nblocks; b += SEL_THREADS) part += block_counts[b];
+  uint32_t tot;
+  block_excl_scan(part, tot, wsum);
+  if (threadIdx.x == 0) *n_out = tot;
+}
+
+}  // namespace bmx

@@ -1,0 +1,66 @@
+// slot.h — resident-table slot layout, hashing and device status bits (gfx950 only).
+//
+// The resident graph is ONE open-addressed hash table of 32-byte AoS slots in HBM:
+//     { id u64 | field u32 | head u32 | ts i64 | val i64 }
+// A probe touches exactly one 128-byte L2 line whatever it reads (measured: profiles/r01_micro_probe_*.log:
+// 16 B, 32 B or a whole line per probe all cost ~20 us per 1M probes; four SoA columns cost 3.4x), so the
+// row's key, clock and value share a 32-byte sector and the (ts,val) pair is one aligned 16-byte access.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace bmx {
+
+constexpr uint64_t EMPTY_ID = ~0ull;            // reserved node id: empty slot
+constexpr uint32_t FIELD_PENDING = 0xFFFFFFFFu; // reserved field: slot claimed, field not yet published
+constexpr int64_t TS_NEW = INT64_MIN;           // ts of an empty slot / of a row created in the running batch
+constexpr int64_t TS_MAX = (1ll << 53) - 1;     // JS safe-integer range
+constexpr int64_t VAL_MAX = (1ll << 53) - 1;
+constexpr uint32_t IDX_BITS = 24;               // batch index bits in a head / next tag
+constexpr uint32_t IDX_MASK = (1u << IDX_BITS) - 1;
+constexpr uint32_t MAX_BATCH = 1u << IDX_BITS;
+constexpr uint32_t EPOCH_MAX = 255;             // 8-bit batch epoch in the tag; heads are swept when it wraps
+// A row created in batch `epoch` stores ts | (epoch << 53) until the next epoch sweep: bits 53..60 of the stored
+// clock are free because ts <= 2^53-1. A later delta of the same key in the same batch sees, in ONE aligned
+// 16-byte load, both the value and the fact that the row has no pre-batch state.
+constexpr int TS_MARK_SHIFT = 53;
+constexpr int64_t TS_VALUE_MASK = (1ll << 53) - 1;
+__host__ __device__ inline int64_t ts_value(int64_t w) { return w & TS_VALUE_MASK; }
+__host__ __device__ inline uint32_t ts_mark(int64_t w) { return (uint32_t)((uint64_t)w >> TS_MARK_SHIFT) & 0xFFu; }
+
+// device status word bits (sticky until read by the host)
+constexpr uint32_t ST_RANGE = 1, ST_FULL = 2, ST_SPIN = 4;
+
+struct alignas(32) Slot {
+  uint64_t id;
+  uint32_t field;
+  uint32_t head;  // (epoch << 24) | index of the last delta that claimed this row in batch `epoch`
+  int64_t ts;
+  int64_t val;
+};
+static_assert(sizeof(Slot) == 32, "slot must be one 32-byte sector");
+
+__host__ __device__ inline uint64_t mix64(uint64_t x) {
+  x ^= x >> 33; x *= 0xff51afd7ed558ccdULL; x ^= x >> 33; x *= 0xc4ceb9fe1a85ec53ULL; x ^= x >> 33;
+  return x;
+}
+__host__ __device__ inline uint64_t key_hash(uint64_t id, uint32_t field) {
+  return mix64(id ^ ((uint64_t)field * 0x9E3779B97F4A7C15ULL));
+}
+// owner shard of a node id; independent of key_hash so shards see uniformly hashed slots
+__host__ __device__ inline uint64_t owner_hash(uint64_t id) { return mix64(id * 0xD6E8FEB86659FD93ULL + 0x2545F4914F6CDD1DULL); }
+
+__device__ __forceinline__ uint64_t home_slot(uint64_t h, uint64_t nslots) { return __umul64hi(h, nslots); }
+
+// all kernels here use 1-D blocks whose size is a multiple of 64, so the lane is the low 6 bits of threadIdx.x
+__device__ __forceinline__ uint32_t lane_id() { return threadIdx.x & 63u; }
+
+// lexicographic compare of (ts,val) pairs: -1, 0, +1   (reference: clock compare then default value compare,
+// src/bullet-crt.js:68-95 scalar form, :11-15)
+__device__ __forceinline__ int lexcmp(int64_t ta, int64_t va, int64_t tb, int64_t vb) {
+  if (ta != tb) return ta < tb ? -1 : 1;
+  if (va != vb) return va < vb ? -1 : 1;
+  return 0;
+}
+
+}  // namespace bmx

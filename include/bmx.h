@@ -1,0 +1,186 @@
+/*
+ * bmx.h — C ABI of libbmx.so: the MI355X (gfx950) CRDT-merge and index-scan engine that sits
+ * behind Bullet's `crt` and `query` plug points.
+ *
+ * This is the drop-in boundary. The reference (KORandi/bullet-js) is pure JavaScript with no FFI;
+ * the entry points below are what an N-API addon binds (bullet-js_amd/napi/bmx_napi.cc) so that
+ *   bullet.crt   = new GpuCRT(bullet)     replaces src/bullet-crt.js    (called at src/bullet.js:141-142)
+ *   bullet.query = new GpuQuery(bullet)   replaces src/bullet-query.js  (called at src/bullet.js:313-389)
+ * Each function cites the reference interface it replaces. Plain pointers and sizes only; no C++,
+ * torch or HIP types cross this boundary. Little-endian, 64-bit sizes.
+ *
+ * Data model: one resident row per (node-id hash u64, field hash u32) holding a
+ * scalar clock `ts` (int64, 0 <= ts <= 2^53-1: a single-component vector clock {w: ts}) and an integer
+ * value `val` (int64, |val| <= 2^53-1: exact in a JS number). Strings, objects and multi-writer clocks
+ * stay on the host (GpuCRT's single-op path).
+ *
+ * Reserved key values (never produced by the host hash functions): id 0xFFFFFFFFFFFFFFFF, field 0xFFFFFFFF.
+ *
+ * Threading: a context is bound to one GPU and one HIP stream and is not re-entrant.
+ * Errors: every call returns BMX_OK (0) or a negative code; bmx_last_error() gives the text. The
+ * library never aborts the process (reference error policy: src/bullet.js:230-234).
+ */
+#ifndef BMX_H
+#define BMX_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define BMX_ABI_VERSION 1
+
+/* status codes */
+#define BMX_OK             0
+#define BMX_ERR_INVALID   -1  /* bad argument */
+#define BMX_ERR_HIP       -2  /* HIP runtime failure (text in bmx_last_error) */
+#define BMX_ERR_FULL      -3  /* resident table cannot take the batch (capacity_rows exceeded) */
+#define BMX_ERR_NOMEM     -4
+#define BMX_ERR_RANGE     -5  /* a delta carried a reserved key, ts < 0 or > 2^53-1, or |val| > 2^53-1 */
+#define BMX_ERR_INTERNAL  -6  /* device-side protocol fault (bounded spin expired) */
+#define BMX_ERR_NO_DEVICE -7
+#define BMX_ERR_NO_INDEX  -8  /* scan on a field with no index and auto-build disabled */
+
+/* where the caller's buffers live */
+#define BMX_MEM_HOST   0      /* host pointers: the call copies in/out and is synchronous */
+#define BMX_MEM_DEVICE 1      /* device pointers (same GPU): the call only enqueues work on the context's
+                                 stream; outputs (including counts) are valid after bmx_sync() */
+
+/* what an absent key's first write stores as its clock */
+#define BMX_INSERT_REFERENCE 0 /* ts := 2, exactly as src/bullet-crt.js:172-185 (+ :33-60) does */
+#define BMX_INSERT_DELTA     1 /* ts := incoming ts (true last-writer-wins); used by bmx_load_rows */
+
+/* per-delta decision flags (bits of `flags[j]`), the booleans of resolve()'s decision record
+ * src/bullet-crt.js:174-184. Exact for batches without duplicate keys (stats.n_conflicts == 0);
+ * with duplicates they are relative to the state each delta observed. */
+#define BMX_FLAG_INCOMING   1u
+#define BMX_FLAG_CURRENT    2u
+#define BMX_FLAG_HISTORICAL 4u
+
+typedef struct bmx_ctx bmx_ctx;
+
+/* 32-byte delta record: the wire format of the sharded exchange and an alternative input layout */
+typedef struct bmx_delta_rec {
+  uint64_t id;
+  uint32_t field;
+  uint32_t aux;     /* carried through untouched */
+  int64_t ts;
+  int64_t val;
+} bmx_delta_rec;
+
+typedef struct bmx_merge_stats {
+  uint64_t n_applied;    /* final winners: keys whose stored (ts,val) changed */
+  uint64_t n_conflicts;  /* deltas that met another delta of the same key inside the batch */
+  uint64_t n_rows;       /* resident rows after the batch */
+  uint64_t reserved;
+} bmx_merge_stats;
+
+/* one term of a declarative filter: lo <= value(field) <= hi */
+typedef struct bmx_term {
+  uint32_t field;
+  uint32_t reserved;
+  int64_t lo, hi;
+} bmx_term;
+
+typedef struct bmx_info {
+  uint64_t capacity_rows, n_slots, table_bytes, n_rows;
+  uint32_t device, abi_version, n_indexes, epoch;
+} bmx_info;
+
+/* ---- lifetime -------------------------------------------------------------------------------
+ * Replaces `new BulletCRT(bullet)` src/bullet-crt.js:6-16 / `new BulletQuery(bullet)`
+ * src/bullet-query.js:2-7 for the device-resident part of the state (reference state:
+ * bullet.store/meta src/bullet.js:28-31). capacity_rows bounds the resident rows. */
+int bmx_create(int device, uint64_t capacity_rows, uint32_t flags, bmx_ctx** out);
+void bmx_destroy(bmx_ctx* ctx);                     /* reference: Bullet.close() src/bullet.js:288-304 */
+const char* bmx_last_error(const bmx_ctx* ctx);     /* ctx may be NULL for bmx_create failures */
+int bmx_abi_version(void);
+int bmx_get_info(bmx_ctx* ctx, bmx_info* out);
+int bmx_sync(bmx_ctx* ctx);                         /* wait for the stream; returns a sticky device error if any */
+int bmx_set_stream(bmx_ctx* ctx, void* hip_stream); /* run on the caller's hipStream_t (NULL = context's own) */
+void* bmx_get_stream(bmx_ctx* ctx);
+
+/* ---- merge ----------------------------------------------------------------------------------
+ * bmx_load_rows: bulk preload of resident rows with their clocks (what storage load / initial sync
+ * does through setData: src/bullet-file-storage.js:96-163). True LWW against anything already there.
+ *
+ * bmx_merge_batch: one batch of deltas through conflict resolution. Replaces calling
+ * crt.handleUpdate()/resolve() once per entry (src/bullet-crt.js:164-279, 329-385) in the
+ * sequential loop of src/bullet-network-sync.js:551-569, with the same final state and the same
+ * final winner per key as that loop (deltas taken in index order):
+ *   - final (ts,val) of a key = lexicographic max over its resident row and its deltas,
+ *   - applied_idx = ascending indices j of the deltas whose value is finally stored, one per changed
+ *     key (the smallest index attaining the key's maximum; nothing if the key did not change),
+ *   - an absent key is created by its smallest-index delta with ts := 2 (BMX_INSERT_REFERENCE).
+ * n <= 2^24 per call. applied_idx (capacity n), n_applied, flags (capacity n) and stats may be NULL.
+ * With BMX_MEM_DEVICE, n_applied and stats are device pointers too. */
+int bmx_load_rows(bmx_ctx* ctx, uint64_t n, const uint64_t* id, const uint32_t* field, const int64_t* ts,
+                  const int64_t* val, int mem);
+int bmx_merge_batch(bmx_ctx* ctx, uint64_t n, const uint64_t* id, const uint32_t* field, const int64_t* ts,
+                    const int64_t* val, int insert_mode, int mem, uint32_t* applied_idx, uint64_t* n_applied,
+                    uint8_t* flags, bmx_merge_stats* stats);
+/* same, deltas as 32-byte records (device pointers only): the receive side of the sharded exchange */
+int bmx_merge_records(bmx_ctx* ctx, uint64_t n, const bmx_delta_rec* recs, int insert_mode, uint32_t* applied_idx,
+                      uint64_t* n_applied, uint8_t* flags, bmx_merge_stats* stats);
+
+/* ---- point reads ----------------------------------------------------------------------------
+ * Replaces bullet._getData(path) + bullet.meta[path].vectorClock (src/bullet.js:115-129,
+ * src/bullet-crt.js:331-333) for device-resident rows. found[i] = 1/0. */
+int bmx_get_rows(bmx_ctx* ctx, uint64_t n, const uint64_t* id, const uint32_t* field, int64_t* ts, int64_t* val,
+                 uint8_t* found, int mem);
+int bmx_get_row(bmx_ctx* ctx, uint64_t id, uint32_t field, int64_t* ts, int64_t* val); /* 1 found, 0 absent, <0 error */
+/* all resident rows, unordered; *n_out = row count even if cap is smaller (checkpoint hook:
+ * src/bullet-network-sync.js:592-664 _collectFullSyncData) */
+int bmx_dump_rows(bmx_ctx* ctx, uint64_t cap, uint64_t* id, uint32_t* field, int64_t* ts, int64_t* val,
+                  uint64_t* n_out, int mem);
+int bmx_row_count(bmx_ctx* ctx, uint64_t* n_out);
+
+/* ---- index + scans --------------------------------------------------------------------------
+ * bmx_index_build replaces BulletQuery.index(path, field) / _buildIndex (src/bullet-query.js:30-73):
+ * it materialises dense columns (node id, value) of the rows carrying `field`. Scans always see the
+ * FRESH index state (a stale index is rebuilt before the scan), which is the state in which the
+ * reference's range()/equals() equal a ground-truth scan (SURVEY §8(a) "Scan parity target").
+ *
+ * bmx_scan_range replaces range(path, field, min, max) src/bullet-query.js:221-261: lo <= val <= hi,
+ * both inclusive. bmx_scan_equals replaces equals() :186-210, bmx_scan_count replaces count() :293-313.
+ * Results are node ids in index-column order (deterministic for a given table state); the host mirror
+ * maps ids back to paths and can reproduce the reference's first-seen-value order.
+ * out_ids may be NULL (count only). *n_out = number of matches even if cap is smaller. */
+int bmx_index_build(bmx_ctx* ctx, uint32_t field);
+int bmx_index_drop(bmx_ctx* ctx, uint32_t field);
+int bmx_index_size(bmx_ctx* ctx, uint32_t field, uint64_t* n_out);
+int bmx_scan_range(bmx_ctx* ctx, uint32_t field, int64_t lo, int64_t hi, uint64_t* out_ids, uint64_t cap,
+                   uint64_t* n_out, int mem);
+int bmx_scan_equals(bmx_ctx* ctx, uint32_t field, int64_t value, uint64_t* out_ids, uint64_t cap, uint64_t* n_out,
+                    int mem);
+int bmx_scan_count(bmx_ctx* ctx, uint32_t field, int64_t lo, int64_t hi, uint64_t* n_out, int mem);
+/* Declarative subset of filter(path, fn) src/bullet-query.js:270-283: fn = AND of range terms over
+ * fields of the same node. Arbitrary JS predicates stay on the host. */
+int bmx_scan_filter(bmx_ctx* ctx, uint32_t nterms, const bmx_term* terms, uint64_t* out_ids, uint64_t cap,
+                    uint64_t* n_out, int mem);
+
+/* ---- sharding (one context per GPU; rows owned by bmx_owner_of(id, nshards)) -----------------
+ * Replaces the gossip fan-out of src/bullet-network.js:378-418 inside one node: instead of every
+ * peer merging every delta, each delta is routed to the shard that owns its node id.
+ * bmx_partition_by_owner: stable partition of a delta batch into `nshards` contiguous runs of
+ * 32-byte records in recs_out (device, capacity n), counts[nshards] (device or host per `mem`
+ * of the counts pointer: always device here; copy it yourself or use bmx_copy_counts). */
+uint32_t bmx_owner_of(uint64_t id, uint32_t nshards);
+int bmx_partition_by_owner(bmx_ctx* ctx, uint64_t n, const uint64_t* id, const uint32_t* field, const int64_t* ts,
+                           const int64_t* val, uint32_t nshards, bmx_delta_rec* recs_out, uint64_t* counts_out_dev);
+
+/* ---- timing helpers (HIP events on the context's stream; used by bench.py) ------------------- */
+int bmx_timer_start(bmx_ctx* ctx);
+int bmx_timer_stop(bmx_ctx* ctx, float* ms_out);    /* synchronises on the stop event */
+/* Per-kernel timing of the merge: while enabled, every merge call brackets its three stages with HIP
+ * events (up to 64 calls are kept). bmx_profile_read synchronises and returns the AVERAGE milliseconds
+ * per call of: [0] k_probe_apply, [1] k_resolve_lists, [2] winner compaction (2 launches), and the
+ * number of calls averaged. */
+int bmx_profile_enable(bmx_ctx* ctx, int on);
+int bmx_profile_read(bmx_ctx* ctx, float ms_out[3], uint32_t* n_calls);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* BMX_H */

@@ -108,15 +108,19 @@ def big_resident(R, seed=1, T0=1_000_000, DT=1_000_000, F=1, row0=0):
     return ids, fld, ts, val
 
 
-def big_deltas(D, R, seed=2, T0=1_000_000, DT=1_000_000, F=1, insert_pct=10, hot_pct=0, hot_keys=0, unique=True, batch=0):
+def big_deltas(D, R, seed=2, T0=1_000_000, DT=1_000_000, F=1, insert_pct=10, hot_pct=0, hot_keys=0, unique=True, batch=0, drift=None):
     """Config-2/5 shaped delta batch over a resident graph of R rows.
 
     unique=True: hit rows are a stride permutation (no duplicate keys inside the batch), inserts get fresh rows.
-    ts ~ U[T0 + batch*DT/2, T0 + batch*DT/2 + 2*DT)."""
+    ts ~ U[T0 + batch*drift, T0 + batch*drift + 2*DT); drift defaults to DT/2 per batch (streaming, config 5).
+    Config 2 uses drift = DT/16: consecutive unique batches walk disjoint rows (a row is revisited every R/D batches),
+    and the slow drift keeps ~75-78 % of hits winning in steady state, as SURVEY §8(d) specifies."""
+    if drift is None:
+        drift = DT // 2
     u = _u(seed + 7919 * batch, D, 3) % np.uint64(100)
     j = np.arange(D, dtype=np.int64)
     if unique:
-        hit_rows = (j * PERM_PRIME + 7 + batch * 7717) % R
+        hit_rows = ((j + batch * D) * PERM_PRIME + 7) % R
         ins_rows = R + batch * D + j
     else:
         hit_rows = (_u(seed + 7919 * batch, D, 4) % np.uint64(R)).astype(np.int64)
@@ -126,6 +130,6 @@ def big_deltas(D, R, seed=2, T0=1_000_000, DT=1_000_000, F=1, insert_pct=10, hot
         hot_rows = (_u(seed + 7919 * batch, D, 6) % np.uint64(max(1, hot_keys))).astype(np.int64)
         rows = np.where((u >= insert_pct) & (u < insert_pct + hot_pct), hot_rows, rows)
     ids, fld = rows_to_keys(rows, F)
-    ts = (T0 + batch * (DT // 2) + (_u(seed + 7919 * batch, D, 8) % np.uint64(2 * DT))).astype(np.int64)
+    ts = (T0 + batch * drift + (_u(seed + 7919 * batch, D, 8) % np.uint64(2 * DT))).astype(np.int64)
     val = (_u(seed + 7919 * batch, D, 9) % np.uint64(1 << 32)).astype(np.int64) - (1 << 31)
     return ids, fld, ts, val

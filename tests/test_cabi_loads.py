@@ -1,0 +1,52 @@
+"""CPU-only checks of the drop-in boundary: libbmx.so builds, loads, exports every symbol that
+include/bmx.h declares, and refuses to run without a GPU (no CPU fallback)."""
+import os
+import re
+
+import pytest
+
+import bmx
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def lib():
+    import __graft_entry__ as g
+    g.build()
+    return bmx.load_library()
+
+
+def test_every_declared_symbol_is_exported(lib):
+    hdr = open(os.path.join(ROOT, "include", "bmx.h")).read()
+    hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
+    declared = set(re.findall(r"\b(bmx_[a-z_0-9]+)\s*\(", hdr))
+    assert len(declared) >= 20
+    for name in sorted(declared):
+        assert hasattr(lib, name), "libbmx.so does not export " + name
+    assert declared == set(bmx.EXPORTS)
+
+
+def test_abi_version(lib):
+    assert lib.bmx_abi_version() == 1
+
+
+def test_owner_of_matches_oracle(lib):
+    from oracle.oracle import owner_of as o_owner
+    from oracle import streams
+    import numpy as np
+    ids = streams.splitmix64_np(np.arange(1, 2000, dtype=np.uint64))
+    for g in (1, 2, 3, 8, 16):
+        a = bmx.owner_of(ids, g); b = o_owner(ids, g)
+        assert (a == b).all() and a.max() < g
+        if g == 8:
+            assert np.bincount(a, minlength=8).min() > 150
+
+
+def test_no_cpu_fallback_without_gpu(lib):
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    with pytest.raises(bmx.BmxError) as ei:
+        bmx.Engine(1000)
+    assert ei.value.code == bmx.ERR_NO_DEVICE
