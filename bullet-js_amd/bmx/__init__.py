@@ -16,6 +16,7 @@ OK = 0
 ERR_INVALID, ERR_HIP, ERR_FULL, ERR_NOMEM, ERR_RANGE, ERR_INTERNAL, ERR_NO_DEVICE, ERR_NO_INDEX = -1, -2, -3, -4, -5, -6, -7, -8
 MEM_HOST, MEM_DEVICE = 0, 1
 INSERT_REFERENCE, INSERT_DELTA = 0, 1
+MERGE_UNIQUE_KEYS = 0x100
 FLAG_INCOMING, FLAG_CURRENT, FLAG_HISTORICAL = 1, 2, 4
 MAX_BATCH = 1 << 24
 

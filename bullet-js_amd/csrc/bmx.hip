@@ -177,6 +177,8 @@ int merge_core(bmx_ctx* ctx, uint64_t n, const uint64_t* id, const uint32_t* fie
                const bmx_delta_rec* recs, int insert_mode, uint32_t* applied_idx, uint64_t* n_applied, uint8_t* flags,
                bmx_merge_stats* stats) {
   if (n > MAX_BATCH) return fail(ctx, BMX_ERR_INVALID, "batch larger than 2^24 deltas: split it (sequential semantics are preserved)");
+  const bool unique = (insert_mode & BMX_MERGE_UNIQUE_KEYS) != 0;
+  insert_mode &= ~BMX_MERGE_UNIQUE_KEYS;
   if (insert_mode != BMX_INSERT_REFERENCE && insert_mode != BMX_INSERT_DELTA) return fail(ctx, BMX_ERR_INVALID, "bad insert_mode");
   if (n == 0) {
     if (n_applied) HIPCHK(hipMemsetAsync(n_applied, 0, sizeof(uint64_t), ctx->stream));
@@ -204,19 +206,21 @@ int merge_core(bmx_ctx* ctx, uint64_t n, const uint64_t* id, const uint32_t* fie
   A.next = ctx->next; A.wflag = ctx->wflag; A.flags = flags;
   A.slot_of = ctx->slot_of; A.shard_ctr = ctx->shard_ctr; A.status = &ctx->ds->status;
   const uint32_t blocks = (uint32_t)((n + 255) / 256);
-  const uint32_t rblocks = std::min<uint32_t>(blocks, 1024);
+  const uint32_t rblocks = std::min<uint32_t>((uint32_t)((n + 4095) / 4096), 1024);
   hipEvent_t* pe = (ctx->prof_on && ctx->prof_n < PROF_MAX_CALLS) ? &ctx->prof_ev[4 * ctx->prof_n] : nullptr;
   if (pe) HIPCHK(hipEventRecord(pe[0], ctx->stream));
   if (insert_mode == BMX_INSERT_REFERENCE) {
-    hipLaunchKernelGGL((k_probe_apply<AOS, BMX_INSERT_REFERENCE>), dim3(blocks), dim3(256), 0, ctx->stream, A);
-    LAUNCHCHK("k_probe_apply");
-    if (pe) HIPCHK(hipEventRecord(pe[1], ctx->stream));
-    hipLaunchKernelGGL((k_resolve_lists<AOS, BMX_INSERT_REFERENCE>), dim3(rblocks), dim3(256), 0, ctx->stream, A);
+    if (unique) hipLaunchKernelGGL((k_probe_apply<AOS, BMX_INSERT_REFERENCE, true>), dim3(blocks), dim3(256), 0, ctx->stream, A);
+    else hipLaunchKernelGGL((k_probe_apply<AOS, BMX_INSERT_REFERENCE, false>), dim3(blocks), dim3(256), 0, ctx->stream, A);
   } else {
-    hipLaunchKernelGGL((k_probe_apply<AOS, BMX_INSERT_DELTA>), dim3(blocks), dim3(256), 0, ctx->stream, A);
-    LAUNCHCHK("k_probe_apply");
-    if (pe) HIPCHK(hipEventRecord(pe[1], ctx->stream));
-    hipLaunchKernelGGL((k_resolve_lists<AOS, BMX_INSERT_DELTA>), dim3(rblocks), dim3(256), 0, ctx->stream, A);
+    if (unique) hipLaunchKernelGGL((k_probe_apply<AOS, BMX_INSERT_DELTA, true>), dim3(blocks), dim3(256), 0, ctx->stream, A);
+    else hipLaunchKernelGGL((k_probe_apply<AOS, BMX_INSERT_DELTA, false>), dim3(blocks), dim3(256), 0, ctx->stream, A);
+  }
+  LAUNCHCHK("k_probe_apply");
+  if (pe) HIPCHK(hipEventRecord(pe[1], ctx->stream));
+  if (!unique) {  // duplicate keys can only exist without the caller's guarantee
+    if (insert_mode == BMX_INSERT_REFERENCE) hipLaunchKernelGGL((k_resolve_lists<AOS, BMX_INSERT_REFERENCE>), dim3(rblocks), dim3(256), 0, ctx->stream, A);
+    else hipLaunchKernelGGL((k_resolve_lists<AOS, BMX_INSERT_DELTA>), dim3(rblocks), dim3(256), 0, ctx->stream, A);
   }
   LAUNCHCHK("k_resolve_lists");
   if (pe) HIPCHK(hipEventRecord(pe[2], ctx->stream));

@@ -84,6 +84,7 @@ __device__ __forceinline__ void store_tv(Slot* sl, int64_t ts, int64_t val) {
 // is_new: the row has no resident value visible to this lane (created in this batch, by anyone).
 // created: this lane created the row AND (with the same 64-bit exchange that publishes the field) claimed it;
 // prev_head is then the old head word.
+template <bool UNIQUE>
 __device__ __forceinline__ bool probe_or_insert(const MergeArgs& A, uint32_t tag, uint64_t id, uint32_t field, uint64_t& slot_out,
                                                 bool& is_new, bool& created, uint32_t& prev_head, int64_t& cts, int64_t& cval) {
   created = false;
@@ -98,8 +99,13 @@ __device__ __forceinline__ bool probe_or_insert(const MergeArgs& A, uint32_t tag
     if (sid == EMPTY_ID) {
       unsigned long long old = atomicCAS(reinterpret_cast<unsigned long long*>(&sl->id), (unsigned long long)EMPTY_ID, (unsigned long long)id);
       if (old == EMPTY_ID) {  // this lane created the row: ONE 64-bit exchange publishes the field and claims the head
-        unsigned long long w1 = atomicExch(reinterpret_cast<unsigned long long*>(&sl->field), (unsigned long long)field | ((unsigned long long)tag << 32));
-        prev_head = (uint32_t)(w1 >> 32);
+        if (UNIQUE) {  // nobody else claims this key: publishing the field is enough
+          __hip_atomic_store(&sl->field, field, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          prev_head = 0;
+        } else {
+          unsigned long long w1 = atomicExch(reinterpret_cast<unsigned long long*>(&sl->field), (unsigned long long)field | ((unsigned long long)tag << 32));
+          prev_head = (uint32_t)(w1 >> 32);
+        }
         created = true;
         slot_out = s; is_new = true; cts = TS_NEW; cval = 0;
         return true;
@@ -134,7 +140,7 @@ __device__ __forceinline__ bool probe_or_insert(const MergeArgs& A, uint32_t tag
   return false;
 }
 
-template <bool AOS, int MODE>
+template <bool AOS, int MODE, bool UNIQUE>
 __global__ __launch_bounds__(256) void k_probe_apply(MergeArgs A) {
   const uint32_t j = blockIdx.x * 256u + threadIdx.x;
   const bool active = j < A.n;
@@ -149,7 +155,7 @@ __global__ __launch_bounds__(256) void k_probe_apply(MergeArgs A) {
   if (valid) {
     bool is_new; int64_t cts, cval; uint64_t s; uint32_t prev = 0;
     const uint32_t tag = (A.epoch << IDX_BITS) | j;
-    if (probe_or_insert(A, tag, id, field, s, is_new, created, prev, cts, cval)) {
+    if (probe_or_insert<UNIQUE>(A, tag, id, field, s, is_new, created, prev, cts, cval)) {
       // decision against the snapshot this lane saw (resolve(): src/bullet-crt.js:164-279, scalar clocks)
       int c = is_new ? 1 : lexcmp(a, v, cts, cval);
       if (c < 0) {
@@ -158,7 +164,7 @@ __global__ __launch_bounds__(256) void k_probe_apply(MergeArgs A) {
         fl = BMX_FLAG_CURRENT | (a < cts ? BMX_FLAG_HISTORICAL : 0u);
       } else {
         Slot* sl = A.slots + s;
-        if (!created) prev = atomicExch(&sl->head, tag);
+        if (!created && !UNIQUE) prev = atomicExch(&sl->head, tag);   // UNIQUE: caller-guaranteed single claimer (prev stays 0)
         if ((prev >> IDX_BITS) != A.epoch) {
           // first claimer of this row in this batch: its snapshot is the pre-batch row
           if (is_new) {

@@ -51,6 +51,12 @@ extern "C" {
 #define BMX_INSERT_REFERENCE 0 /* ts := 2, exactly as src/bullet-crt.js:172-185 (+ :33-60) does */
 #define BMX_INSERT_DELTA     1 /* ts := incoming ts (true last-writer-wins); used by bmx_load_rows */
 
+/* Optional bit OR-ed into `insert_mode`: the caller guarantees that no two deltas of the batch share a key
+ * (e.g. the JS host de-duplicated the batch while hashing paths). The per-row claim atomic is then skipped.
+ * With duplicate keys in such a batch the result is unspecified (never unsafe): use it only when the
+ * guarantee holds. The default path makes no assumption and is exact for any batch. */
+#define BMX_MERGE_UNIQUE_KEYS 0x100
+
 /* per-delta decision flags (bits of `flags[j]`), the booleans of resolve()'s decision record
  * src/bullet-crt.js:174-184. Exact for batches without duplicate keys (stats.n_conflicts == 0);
  * with duplicates they are relative to the state each delta observed. */

@@ -1,0 +1,120 @@
+"""GPU: the asynchronous device-pointer side of the C ABI (torch tensors only carry the memory),
+32-byte record input, owner partition, the caller-guaranteed unique-keys mode, per-kernel profiling."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+import bmx
+from oracle import streams
+from oracle.oracle import Oracle, INSERT_REFERENCE, INSERT_DELTA, rows_digest, owner_of as o_owner
+
+F0 = streams.field_hash(0)
+
+
+def _dev(cols, dev):
+    id, f, ts, val = cols
+    return (torch.from_numpy(np.ascontiguousarray(id).view(np.int64)).to(dev), torch.from_numpy(np.ascontiguousarray(f).view(np.int32)).to(dev),
+            torch.from_numpy(np.ascontiguousarray(ts)).to(dev), torch.from_numpy(np.ascontiguousarray(val)).to(dev))
+
+
+def test_device_pointer_merge_matches_oracle():
+    dev = torch.device("cuda", 0)
+    R, D = 200_000, 50_000
+    res = streams.big_resident(R, seed=31)
+    o = Oracle(); o.load_rows(*res)
+    with bmx.Engine(2 * (R + 4 * D)) as e:
+        e.load_rows_dev(R, *_dev(res, dev))
+        applied = torch.zeros(D, dtype=torch.int32, device=dev)
+        n_applied = torch.zeros(1, dtype=torch.int64, device=dev)
+        stats = torch.zeros(4, dtype=torch.int64, device=dev)
+        flags = torch.zeros(D, dtype=torch.uint8, device=dev)
+        for b in range(4):
+            d = streams.big_deltas(D, R, seed=32, insert_pct=10, hot_pct=25, hot_keys=64, unique=False, batch=b)
+            dd = _dev(d, dev)
+            e.merge_batch_dev(D, *dd, INSERT_REFERENCE, applied=applied, n_applied=n_applied, flags=flags, stats=stats)
+            e.sync()
+            _, ow = o.merge_batch(*d)
+            na = int(n_applied.item())
+            assert na == len(ow) == int(stats[0].item())
+            assert np.array_equal(applied[:na].cpu().numpy().view(np.uint32), ow)
+            assert int(stats[2].item()) == len(o)
+        assert rows_digest(*e.dump_rows()) == o.digest()
+
+
+def test_unique_keys_mode_equals_default_on_unique_batches():
+    dev = torch.device("cuda", 0)
+    R, D = 300_000, 100_000
+    res = streams.big_resident(R, seed=41)
+    o = Oracle(); o.load_rows(*res)
+    with bmx.Engine(2 * (R + 3 * D)) as e:
+        e.load_rows(*res)
+        for b in range(3):
+            d = streams.big_deltas(D, R, seed=42, insert_pct=10, unique=True, batch=b, drift=60_000)
+            assert len(np.unique(d[0])) == D
+            applied, flags, st = e.merge_batch(*d, insert_mode=INSERT_REFERENCE | bmx.MERGE_UNIQUE_KEYS)
+            of, ow = o.merge_batch(*d)
+            assert np.array_equal(applied, ow) and np.array_equal(flags, of) and st.n_conflicts == 0
+        assert rows_digest(*e.dump_rows()) == o.digest()
+
+
+def test_partition_by_owner_is_stable_and_complete_then_merge_records():
+    dev = torch.device("cuda", 0)
+    n, G = 100_000, 8
+    d = streams.big_deltas(n, 500_000, seed=51, insert_pct=20, hot_pct=20, hot_keys=100, unique=False)
+    dd = _dev(d, dev)
+    recs = torch.zeros((n, 4), dtype=torch.int64, device=dev)
+    counts = torch.zeros(G, dtype=torch.int64, device=dev)
+    with bmx.Engine(1_000_000) as e:
+        e.partition_by_owner_dev(n, *dd, G, recs, counts)
+        e.sync()
+        c = counts.cpu().numpy()
+        r = recs.cpu().numpy().view(bmx.DELTA_REC_DTYPE).reshape(-1)
+        own = o_owner(d[0], G)
+        assert c.tolist() == np.bincount(own, minlength=G).tolist() and c.sum() == n
+        off = 0
+        for g in range(G):
+            seg = r[off:off + c[g]]
+            src = np.nonzero(own == g)[0]                     # stable: original order inside each shard
+            assert np.array_equal(seg["aux"], src.astype(np.uint32))
+            assert np.array_equal(seg["id"], d[0][src]) and np.array_equal(seg["field"], d[1][src])
+            assert np.array_equal(seg["ts"], d[2][src]) and np.array_equal(seg["val"], d[3][src])
+            off += c[g]
+        # records as merge input: same result as the column input
+        o = Oracle()
+        _, ow = o.merge_batch(r["id"], r["field"], r["ts"], r["val"])
+        applied = torch.zeros(n, dtype=torch.int32, device=dev)
+        n_applied = torch.zeros(1, dtype=torch.int64, device=dev)
+        e.merge_records_dev(n, recs, INSERT_REFERENCE, applied=applied, n_applied=n_applied)
+        e.sync()
+        na = int(n_applied.item())
+        assert np.array_equal(applied[:na].cpu().numpy().view(np.uint32), ow)
+        assert rows_digest(*e.dump_rows()) == o.digest()
+
+
+def test_padding_records_are_skipped():
+    dev = torch.device("cuda", 0)
+    r = np.zeros(6, dtype=bmx.DELTA_REC_DTYPE)
+    r["id"] = [11, 2**64 - 1, 12, 2**64 - 1, 11, 2**64 - 1]
+    r["field"] = F0; r["ts"] = [5, 0, 6, 0, 7, 0]; r["val"] = [1, 0, 2, 0, 3, 0]
+    recs = torch.from_numpy(r.view(np.int64).reshape(6, 4)).to(dev)
+    n_applied = torch.zeros(1, dtype=torch.int64, device=dev)
+    applied = torch.zeros(6, dtype=torch.int32, device=dev)
+    with bmx.Engine(100) as e:
+        e.merge_records_dev(6, recs, INSERT_DELTA, applied=applied, n_applied=n_applied)
+        e.sync()
+        assert applied[:int(n_applied.item())].cpu().tolist() == [2, 4]
+        assert e.row_count() == 2 and e.get_row(11, F0) == (7, 3)
+
+
+def test_profile_hooks_report_three_stages():
+    R, D = 100_000, 50_000
+    with bmx.Engine(4 * R) as e:
+        e.load_rows(*streams.big_resident(R, seed=61))
+        e.profile_enable(True)
+        for b in range(3):
+            e.merge_batch(*streams.big_deltas(D, R, seed=62, batch=b), want_flags=False)
+        ms, n = e.profile_read()
+        assert n == 3 and all(v > 0 for v in ms.values())
+        e.profile_enable(False)
