@@ -39,13 +39,13 @@ HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec
 
 
 def gen_resident(R, row0=0):
-    from oracle import streams
-    return streams.big_resident(R, seed=1, T0=T0, DT=DT, row0=row0)
+    from bmx import synth
+    return synth.big_resident(R, seed=1, T0=T0, DT=DT, row0=row0)
 
 
 def gen_batch(b, R, D=D_PER_STEP, seed=2):
-    from oracle import streams
-    return streams.big_deltas(D, R, seed=seed, T0=T0, DT=DT, insert_pct=10, unique=True, batch=b, drift=DT // 16)
+    from bmx import synth
+    return synth.big_deltas(D, R, seed=seed, T0=T0, DT=DT, insert_pct=10, unique=True, batch=b, drift=DT // 16)
 
 
 def to_dev(cols, dev):

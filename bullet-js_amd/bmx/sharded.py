@@ -1,0 +1,119 @@
+"""sharded.py — one graph sharded by node-id hash over the GPUs of a node.
+
+The reference replicates every delta to every peer over WebSocket gossip and lets every peer merge it
+(src/bullet-network.js:378-418). Inside one node this module routes instead: rows live on exactly one shard
+(owner = bmx_owner_of(id, N)), each rank partitions the deltas it originates by owner (K7, stable), the
+32-byte records are exchanged with ONE all-to-all(v) (RCCL over xGMI when the backend is nccl), and each
+shard merges what it received with the normal merge kernels. No other collective is on the data path.
+
+Order: a shard receives the runs of rank 0, 1, ..., N-1 concatenated, each run in its origin's index order, so
+the global batch order (rank-major, then index) restricted to the shard is preserved and the sequential
+semantics of the merge (smallest index wins ties / creates absent rows) stay well defined.
+
+`ops` hides where the bytes live: EngineOps = the HIP engine + torch CUDA tensors (product);
+tests inject a CPU implementation to exercise the routing with the gloo backend.
+"""
+import numpy as np
+import torch
+
+from . import INSERT_REFERENCE
+from . import synth
+
+
+class EngineOps:
+    """GPU side: bmx.Engine does the work; torch only owns buffers and the stream shared with RCCL."""
+
+    def __init__(self, engine, device):
+        self.e = engine
+        self.device = device
+        # same stream as torch's collectives: partition -> all_to_all -> merge are ordered without extra events
+        engine.set_stream(torch.cuda.current_stream(device).cuda_stream)
+
+    def empty_records(self, n):
+        return torch.empty((max(int(n), 1), 4), dtype=torch.int64, device=self.device)
+
+    def zeros_i64(self, n):
+        return torch.zeros(int(n), dtype=torch.int64, device=self.device)
+
+    def partition(self, n, id, field, ts, val, nshards, recs_out, counts_out):
+        self.e.partition_by_owner_dev(n, id, field, ts, val, nshards, recs_out, counts_out)
+
+    def merge_records(self, n, recs, insert_mode, applied, n_applied):
+        self.e.merge_records_dev(n, recs, insert_mode, applied=applied, n_applied=n_applied)
+
+    def load_rows(self, id, field, ts, val):
+        self.e.load_rows(id, field, ts, val)
+
+    def sync(self):
+        self.e.sync()
+
+
+class ShardedGraph:
+    def __init__(self, ops, dist, rank, world, insert_mode=INSERT_REFERENCE):
+        self.ops, self.dist, self.rank, self.world = ops, dist, rank, world
+        self.insert_mode = insert_mode
+        self._recs = None
+        self._recv = None
+        self._applied = None
+        self._n_applied = ops.zeros_i64(1)
+        self._counts = ops.zeros_i64(world)
+        self._rcounts = ops.zeros_i64(world)
+        self.n_steps = 0
+        self.sent_remote = 0
+        self.received = 0
+
+    def owned_rows(self, R_global, chunk=4_000_000):
+        """row ordinals in [0, R_global) whose node this rank owns."""
+        out = []
+        for r0 in range(0, R_global, chunk):
+            rows = np.arange(r0, min(R_global, r0 + chunk), dtype=np.int64)
+            ids, _ = synth.rows_to_keys(rows)
+            out.append(rows[synth.owner_of_np(ids, self.world) == self.rank])
+        return np.concatenate(out) if out else np.zeros(0, np.int64)
+
+    def load_owned_resident(self, R_per_gpu, T0=1_000_000, DT=1_000_000, seed=1):
+        """Load this rank's part of a global graph of R_per_gpu * world rows (same rows as synth.big_resident)."""
+        R_global = R_per_gpu * self.world
+        rows = self.owned_rows(R_global)
+        ids, fld = synth.rows_to_keys(rows)
+        # same per-row values as big_resident(R_global): draws are indexed by the row ordinal
+        with np.errstate(over="ignore"):
+            i = rows.astype(np.uint64)
+            base1 = np.uint64((seed * 0x632BE59BD9B4E019 + 1 * 0xD1342543DE82EF95) & synth.M64)
+            base2 = np.uint64((seed * 0x632BE59BD9B4E019 + 2 * 0xD1342543DE82EF95) & synth.M64)
+            u1 = synth.splitmix64_np(i * np.uint64(0x9E3779B97F4A7C15) + base1)
+            u2 = synth.splitmix64_np(i * np.uint64(0x9E3779B97F4A7C15) + base2)
+        ts = (T0 + (u1 % np.uint64(DT))).astype(np.int64)
+        val = (u2 % np.uint64(1 << 32)).astype(np.int64) - (1 << 31)
+        self.ops.load_rows(ids, fld, ts, val)
+        return len(rows)
+
+    def merge_step(self, n, id, field, ts, val):
+        """Route this rank's n deltas to their owners and merge what arrives here. Returns the number received."""
+        ops, dist, W = self.ops, self.dist, self.world
+        if self._recs is None or self._recs.shape[0] < n:
+            self._recs = ops.empty_records(n)
+        ops.partition(n, id, field, ts, val, W, self._recs, self._counts)
+        send = self._counts.cpu().tolist()               # host needs the split sizes (one sync)
+        dist.all_to_all_single(self._rcounts, self._counts)
+        recv = self._rcounts.cpu().tolist()
+        nrecv = int(sum(recv))
+        if self._recv is None or self._recv.shape[0] < nrecv:
+            self._recv = ops.empty_records(int(nrecv * 1.25) + 1024)
+            self._applied = torch.zeros(self._recv.shape[0], dtype=torch.int32, device=self._recv.device)
+        dist.all_to_all_single(self._recv[:nrecv], self._recs[:n], output_split_sizes=recv, input_split_sizes=send)
+        ops.merge_records(nrecv, self._recv, self.insert_mode, self._applied, self._n_applied)
+        self.n_steps += 1
+        self.sent_remote += n - send[self.rank]
+        self.received += nrecv
+        return nrecv
+
+    def last_applied(self):
+        """(indices into the received batch, received records) of the last step's winners."""
+        self.ops.sync()
+        na = int(self._n_applied.cpu().item())
+        return self._applied[:na], self._recv
+
+    def stats(self):
+        return {"steps": self.n_steps, "records_sent_to_other_shards": self.sent_remote, "records_received": self.received,
+                "bytes_per_record": 32}

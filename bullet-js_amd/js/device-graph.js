@@ -1,0 +1,38 @@
+"use strict";
+/*
+ * device-graph.js — one GPU-resident graph shard (a bmx_ctx) plus the host dictionary that maps the
+ * device's hashed keys back to Bullet paths. Shared by GpuCRT (merge) and GpuQuery (index scans).
+ */
+const { requireNative } = require("./native");
+const { KeyDictionary } = require("./hash");
+
+class DeviceGraph {
+  constructor(opts = {}) {
+    this.native = requireNative();                 // throws if the addon is missing: no CPU fallback
+    this.device = opts.device || 0;
+    this.capacityRows = opts.capacityRows || (1 << 22);
+    this.handle = this.native.create(this.device, this.capacityRows);
+    this.keys = new KeyDictionary();
+    this.batches = 0;
+  }
+  mergeBatch(cols, mode) {
+    this.batches++;
+    return this.native.mergeBatch(this.handle, cols.id, cols.field, cols.ts, cols.val, mode | 0);
+  }
+  loadRows(cols) { this.native.loadRows(this.handle, cols.id, cols.field, cols.ts, cols.val); }
+  getRows(id, field) { return this.native.getRows(this.handle, id, field); }
+  rowCount() { return this.native.rowCount(this.handle); }
+  dumpRows() { return this.native.dumpRows(this.handle); }
+  indexBuild(f) { this.native.indexBuild(this.handle, f); }
+  indexDrop(f) { this.native.indexDrop(this.handle, f); }
+  indexSize(f) { return this.native.indexSize(this.handle, f); }
+  scanRange(f, lo, hi) { return this.native.scanRange(this.handle, f, lo, hi); }
+  scanCount(f, lo, hi) { return this.native.scanCount(this.handle, f, lo, hi); }
+  scanFilter(terms) { return this.native.scanFilter(this.handle, terms); }
+  info() { return this.native.info(this.handle); }
+  close() {
+    if (this.handle) { this.native.destroy(this.handle); this.handle = null; }
+  }
+}
+
+module.exports = DeviceGraph;

@@ -1,0 +1,263 @@
+"use strict";
+/*
+ * gpu-crt.js — GpuCRT: drop-in for the reference's conflict resolver behind `bullet.crt`
+ * (plug point: `new Bullet({disableCRT: true}); bullet.crt = new GpuCRT(bullet)`, SURVEY §8(b)).
+ *
+ * Interface mirrored (same names, arguments, return shapes and error behaviour as the reference's class in
+ * src/bullet-crt.js): setCompare :23, createVectorClock :33, getVectorClock :44, incrementVectorClock :56,
+ * compareVectorClocks :68, mergeVectorClocks :103, mergeValues :122, resolve :164, createUpdate :287,
+ * processUpdate :304, handleUpdate :329 (the only method Bullet.setData calls, src/bullet.js:141-142), formatClock :392.
+ *
+ * Two paths:
+ *   - single operations (one put / one network message, arbitrary JS values, general vector clocks) are decided
+ *     here on the host: a PCIe round trip per put would be pointless, and strings/objects cannot live on the GPU;
+ *   - batches (sync chunks, bulk loads: src/bullet-network-sync.js:551-569) go to the MI355X through
+ *     mergeBatch()/mergeEntries(): typed columns -> bmx_merge_batch. That path has no host implementation.
+ */
+const { Columns, fieldId, isDeviceInt, scalarClock } = require("./hash");
+
+const REASON = {
+  fresh: "no current state",
+  same: "identical clocks and values",
+  byValue: "identical clocks, decided by value comparison",
+  newer: "incoming vector clock dominates",
+  older: "current vector clock dominates (incoming is historical)",
+  forked: "concurrent modifications, merged objects",
+};
+
+function threeWay(a, b) {
+  if (a === b) return 0;
+  return a < b ? -1 : 1;          // anything unordered (objects, NaN, null vs object) falls through to +1
+}
+
+function isMergeable(v) { return typeof v === "object" && v !== null && !Array.isArray(v); }
+
+function verdict(winner, clock, value, reason, extra) {
+  /* decision record; field set of the reference's resolve() results */
+  return Object.assign({
+    defer: false, historical: false, converge: true,
+    incoming: winner === "in", current: winner === "cur", concurrent: false,
+    vectorClock: clock, reason, value,
+  }, extra || {});
+}
+
+class GpuCRT {
+  /**
+   * @param {object} bullet  the Bullet instance (needs .id, .meta, ._getData)
+   * @param {object} [opts]  { graph: DeviceGraph (shared with GpuQuery), device, capacityRows, writer }
+   */
+  constructor(bullet, opts = {}) {
+    this.bullet = bullet;
+    this.vectorClocks = new Map();
+    this.compare = threeWay;
+    this._opts = opts;
+    this._graph = opts.graph || null;
+  }
+
+  /* ---------------------------------------------------------------- clock bookkeeping (host) */
+  setCompare(fn) { this.compare = fn; return this; }
+
+  createVectorClock(key) {
+    const c = {};
+    c[this.bullet.id] = 1;
+    this.vectorClocks.set(key, c);
+    return c;
+  }
+
+  getVectorClock(key) {
+    const c = this.vectorClocks.get(key);
+    return c === undefined ? this.createVectorClock(key) : c;
+  }
+
+  incrementVectorClock(key) {
+    const c = this.getVectorClock(key);
+    const me = this.bullet.id;
+    c[me] = (c[me] || 0) + 1;
+    return c;                       // the live object, as the reference hands out (meta aliases it)
+  }
+
+  compareVectorClocks(a, b) {
+    if (!a) return -1;
+    if (!b) return 1;
+    let aAhead = false, bAhead = false;
+    const seen = new Set();
+    for (const list of [Object.keys(a), Object.keys(b)]) {
+      for (const node of list) {
+        if (seen.has(node)) continue;
+        seen.add(node);
+        const x = a[node] || 0, y = b[node] || 0;
+        if (x > y) aAhead = true; else if (y > x) bAhead = true;
+        if (aAhead && bAhead) return 0;
+      }
+    }
+    return aAhead ? 1 : (bAhead ? -1 : 0);
+  }
+
+  mergeVectorClocks(a, b) {
+    if (!a) return Object.assign({}, b);
+    if (!b) return Object.assign({}, a);
+    const out = Object.assign({}, a);
+    for (const node of Object.keys(b)) out[node] = Math.max(out[node] || 0, b[node]);
+    return out;
+  }
+
+  mergeValues(incoming, current) {
+    if (!isMergeable(incoming) || !isMergeable(current)) {
+      return this.compare(incoming, current) >= 0 ? incoming : current;
+    }
+    const out = Object.assign({}, current);
+    for (const k of Object.keys(incoming)) {
+      out[k] = (k in out) ? this.mergeValues(incoming[k], out[k]) : incoming[k];
+    }
+    return out;
+  }
+
+  /* ---------------------------------------------------------------- one decision (host) */
+  resolve(key, incomingClock, currentClock, incomingValue, currentValue) {
+    if (!currentClock) {
+      return verdict("in", this.incrementVectorClock(key), incomingValue, REASON.fresh);
+    }
+    const order = this.compareVectorClocks(incomingClock, currentClock);
+    const merged = this.mergeVectorClocks(incomingClock, currentClock);
+    this.vectorClocks.set(key, merged);
+
+    if (order > 0) return verdict("in", merged, incomingValue, REASON.newer);
+    if (order < 0) return verdict("cur", merged, currentValue, REASON.older, { historical: true });
+
+    if (JSON.stringify(incomingClock) === JSON.stringify(currentClock)) {
+      const c = this.compare(incomingValue, currentValue);
+      if (c === 0) return verdict("none", merged, currentValue, REASON.same);
+      return verdict(c > 0 ? "in" : "cur", merged, c > 0 ? incomingValue : currentValue, REASON.byValue);
+    }
+    return verdict("none", merged, this.mergeValues(incomingValue, currentValue), REASON.forked, { concurrent: true });
+  }
+
+  createUpdate(key, value) {
+    return { value, vectorClock: Object.assign({}, this.incrementVectorClock(key)) };
+  }
+
+  processUpdate(key, incomingValue, incomingClock, currentValue, currentClock) {
+    const decision = this.resolve(key, incomingClock, currentClock, incomingValue, currentValue);
+    return { value: decision.value, vectorClock: decision.vectorClock, decision };
+  }
+
+  handleUpdate(path, incomingData, isFromNetwork = false) {
+    const currentData = this.bullet._getData(path);
+    const currentClock = (this.bullet.meta[path] || {}).vectorClock;
+
+    let clock, payload = incomingData;
+    const tagged = isFromNetwork && incomingData && typeof incomingData === "object" && incomingData.__vectorClock;
+    if (tagged) {
+      clock = incomingData.__vectorClock;
+      if (Array.isArray(incomingData)) {
+        payload = incomingData.slice();
+      } else {
+        payload = {};
+        for (const k of Object.keys(incomingData)) if (k !== "__vectorClock") payload[k] = incomingData[k];
+      }
+    } else {
+      clock = this.incrementVectorClock(path);      // local write (or untagged network primitive)
+    }
+
+    const d = this.resolve(path, clock, currentClock, payload, currentData);
+
+    let broadcastData = d.value;
+    if (typeof broadcastData === "object" && broadcastData !== null) {
+      broadcastData = Array.isArray(broadcastData)
+        ? broadcastData.concat([{ __vectorClock: d.vectorClock }])
+        : Object.assign({}, broadcastData, { __vectorClock: d.vectorClock });
+    }
+    return {
+      value: d.value,
+      vectorClock: d.vectorClock,
+      broadcastData,
+      decision: d,
+      doUpdate: d.incoming || !currentClock || d.concurrent,
+    };
+  }
+
+  formatClock(clock) {
+    if (!clock) return "null";
+    return Object.keys(clock).map((n) => n + ":" + clock[n]).join(", ");
+  }
+
+  /* ---------------------------------------------------------------- batch path (MI355X) */
+  get graph() {
+    if (!this._graph) {
+      const DeviceGraph = require("./device-graph");
+      this._graph = new DeviceGraph(this._opts);    // throws without the addon / a GPU
+      this._ownsGraph = true;
+    }
+    return this._graph;
+  }
+
+  /**
+   * Merge typed columns on the GPU.
+   * cols: {id: BigUint64Array, field: Uint32Array, ts: BigInt64Array, val: BigInt64Array}
+   * opts: {insertMode: 'reference'|'delta', uniqueKeys: bool}
+   * -> {applied: Uint32Array (ascending delta indices whose value is now stored), flags, nApplied, nConflicts, nRows}
+   */
+  mergeBatch(cols, opts = {}) {
+    const g = this.graph;
+    let mode = opts.insertMode === "delta" ? g.native.INSERT_DELTA : g.native.INSERT_REFERENCE;
+    if (opts.uniqueKeys) mode |= g.native.MERGE_UNIQUE_KEYS;
+    return g.mergeBatch(cols, mode);
+  }
+
+  /**
+   * Batch adapter for sync chunks (reference loop: src/bullet-network-sync.js:551-569).
+   * entries: [{path, data, vectorClock}] where data is an integer or an object of integer fields and
+   * vectorClock is {<writer>: ts}. Each (node, field) becomes one device row. Entries outside that contract
+   * (strings, nested objects, multi-writer clocks) are returned in `host` for the caller to pass to setData().
+   * -> {applied: [{entry, field}], nConflicts, host: [entry indices]}
+   */
+  mergeEntries(entries, opts = {}) {
+    const writer = opts.writer || this.bullet.id;
+    const g = this.graph;
+    let rows = 0;
+    const plan = [];                      // per entry: list of [fieldName|null, value] or null (host)
+    for (const e of entries) {
+      const ts = scalarClock(e.vectorClock, writer);
+      let fields = null;
+      if (ts >= 0) {
+        if (isDeviceInt(e.data)) fields = [[null, e.data]];
+        else if (e.data && typeof e.data === "object" && !Array.isArray(e.data)) {
+          fields = [];
+          for (const k of Object.keys(e.data)) {
+            if (k === "__vectorClock" || k === "__fromNetwork") continue;
+            if (!isDeviceInt(e.data[k])) { fields = null; break; }
+            fields.push([k, e.data[k]]);
+          }
+        }
+      }
+      plan.push(fields && fields.length ? { ts, fields } : null);
+      if (fields) rows += fields.length;
+    }
+    const cols = new Columns(rows);
+    const back = new Array(rows);
+    let i = 0;
+    const host = [];
+    entries.forEach((e, ei) => {
+      const p = plan[ei];
+      if (!p) { host.push(ei); return; }
+      const cut = e.path.lastIndexOf("/");
+      const parent = cut < 0 ? "" : e.path.slice(0, cut);
+      const id = g.keys.idOf(e.path);
+      for (const [fname, v] of p.fields) {
+        cols.set(i, id, fieldId(parent, fname), p.ts, v);
+        back[i] = { entry: ei, field: fname };
+        i++;
+      }
+    });
+    const r = this.mergeBatch(cols, opts);
+    const applied = Array.from(r.applied, (j) => back[j]);
+    return { applied, nApplied: r.nApplied, nConflicts: r.nConflicts, nRows: r.nRows, host };
+  }
+
+  close() {
+    if (this._ownsGraph && this._graph) this._graph.close();
+    this._graph = null;
+  }
+}
+
+module.exports = GpuCRT;

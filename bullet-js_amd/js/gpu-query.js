@@ -1,0 +1,257 @@
+"use strict";
+/*
+ * gpu-query.js — GpuQuery: drop-in for the reference's query engine behind `bullet.query`
+ * (plug point: `new Bullet({enableIndexing: false}); bullet.query = new GpuQuery(bullet)`, SURVEY §8(b)).
+ *
+ * Interface mirrored (src/bullet-query.js): index :30, equals :186, range :221, filter :270, count :293,
+ * map :322, find :342, the `indices` object keyed "path:field" (read by src/bullet-serializer.js:655-665),
+ * and the setData hook of :13-21. Results are arrays of bullet.get(path) nodes, in the reference's order.
+ *
+ * Where the work happens:
+ *   - an index whose values are all safe integers lives on the MI355X: index() loads the children's
+ *     (node id, value) rows and bmx_index_build() compacts them into dense columns; equals/range/count and
+ *     filterWhere() stream those columns (bmx_scan_*). Nothing on the host re-implements those scans.
+ *   - an index over strings/booleans/objects (e.g. role === "admin") cannot be expressed in the device's
+ *     integer domain and is kept as a host Map, like the reference does for everything.
+ *   - filter/map/find take arbitrary JS callbacks and run on the host, as in the reference.
+ *
+ * Freshness: the reference maintains its indices incrementally and drifts (SURVEY §8(a) Q4); parity is defined
+ * on the FRESH state. Here a write under an indexed path marks the index stale and the next query rebuilds it.
+ */
+const { Columns, fieldId, isDeviceInt } = require("./hash");
+
+function bucketKey(v) { return (typeof v === "object" && v !== null) ? JSON.stringify(v) : String(v); }
+
+class GpuQuery {
+  /** @param {object} bullet @param {object} [opts] { graph: DeviceGraph shared with GpuCRT, device, capacityRows } */
+  constructor(bullet, opts = {}) {
+    this.bullet = bullet;
+    this.indices = {};
+    this.indexedPaths = new Set();
+    this.lastPath = null;           // 'device' | 'host': which side answered the last indexed query (for tests/ops)
+    this._opts = opts;
+    this._graph = opts.graph || null;
+    this._gen = 0;
+    this._hookWrites();
+  }
+
+  get graph() {
+    if (!this._graph) {
+      const DeviceGraph = require("./device-graph");
+      this._graph = new DeviceGraph(this._opts);
+      this._ownsGraph = true;
+    }
+    return this._graph;
+  }
+
+  _hookWrites() {
+    const inner = this.bullet.setData.bind(this.bullet);
+    this.bullet.setData = (path, data, broadcast = true) => {
+      inner(path, data, broadcast);            // like the reference's hook, the return value is dropped
+      this._touch(path);
+    };
+  }
+
+  _touch(path) {
+    for (const base of this.indexedPaths) {
+      if (path === base || path.startsWith(base + "/") || base.startsWith(path + "/")) {
+        for (const k of Object.keys(this.indices)) if (this.indices[k].path === base) this.indices[k].stale = true;
+      }
+    }
+  }
+
+  static keyOf(path, field) { return field ? `${path}:${field}` : path; }
+
+  index(path, field = null) {
+    const key = GpuQuery.keyOf(path, field);
+    if (this.indices[key]) return this;
+    this.indices[key] = { path, field, stale: true, kind: null };
+    this.indexedPaths.add(path);
+    this._build(this.indices[key]);
+    return this;
+  }
+
+  /* scan the direct children of `path` (one level, as _buildIndex does) and materialise the index */
+  _build(ix) {
+    const base = this.bullet._getData(ix.path);
+    const paths = [], values = [];
+    if (typeof base === "object" && base !== null) {
+      for (const [child, v] of Object.entries(base)) {
+        let x;
+        if (ix.field) {
+          if (typeof v !== "object" || v === null || !(ix.field in v)) continue;
+          x = v[ix.field];
+        } else {
+          x = v;
+        }
+        if (x === null || x === undefined) continue;
+        paths.push(`${ix.path}/${child}`);
+        values.push(x);
+      }
+    }
+    ix.paths = paths;
+    ix.values = values;
+    ix.stale = false;
+    ix.rank = null;
+    ix._posByPath = null;
+    if (values.length > 0 && values.every(isDeviceInt)) this._buildDevice(ix);
+    else this._buildHost(ix);
+  }
+
+  _buildHost(ix) {
+    ix.kind = "host";
+    const buckets = new Map();
+    ix.values.forEach((v, i) => {
+      const k = bucketKey(v);
+      if (!buckets.has(k)) buckets.set(k, []);
+      buckets.get(k).push(i);
+    });
+    ix.buckets = buckets;
+  }
+
+  _buildDevice(ix) {
+    const g = this.graph;                       // throws when the addon / GPU is missing: no host scan for integer indices
+    ix.kind = "device";
+    if (ix.deviceField !== undefined) g.indexDrop(ix.deviceField);
+    // rows of an older build of this index stay behind under their own field hash and are never scanned again
+    ix.deviceField = fieldId(ix.path + "#" + (++this._gen), ix.field);
+    const n = ix.paths.length;
+    const cols = new Columns(n);
+    for (let i = 0; i < n; i++) cols.set(i, g.keys.idOf(ix.paths[i]), ix.deviceField, 1, ix.values[i]);
+    g.loadRows(cols);
+    g.indexBuild(ix.deviceField);
+  }
+
+  _fresh(path, field) {
+    const key = GpuQuery.keyOf(path, field);
+    if (!this.indices[key]) this.index(path, field);
+    const ix = this.indices[key];
+    if (ix.stale) this._build(ix);
+    return ix;
+  }
+
+  /* device ids -> child ordinals of the build scan */
+  _ordinals(ix, ids) {
+    const u32 = new Uint32Array(ids.buffer, ids.byteOffset, ids.length * 2);
+    const out = new Array(ids.length);
+    const pos = ix._posByPath || (ix._posByPath = new Map(ix.paths.map((p, i) => [p, i])));
+    for (let i = 0; i < ids.length; i++) {
+      const p = this.graph.keys.pathOf(u32[2 * i], u32[2 * i + 1]);
+      out[i] = pos.get(p);
+    }
+    return out;
+  }
+
+  /* reference order of a result set: distinct values in first-seen order of the build scan, children of one value in scan order */
+  _inReferenceOrder(ix, ordinals) {
+    if (!ix.rank) {
+      const seen = new Map();
+      ix.rank = ix.values.map((v) => { const k = bucketKey(v); if (!seen.has(k)) seen.set(k, seen.size); return seen.get(k); });
+    }
+    return ordinals.sort((a, b) => (ix.rank[a] - ix.rank[b]) || (a - b));
+  }
+
+  _nodes(ix, ordinals) { return ordinals.map((i) => this.bullet.get(ix.paths[i])); }
+
+  equals(path, field, value) {
+    if (arguments.length === 2) { value = field; field = null; }
+    const ix = this._fresh(path, field);
+    this.lastPath = ix.kind;
+    if (ix.kind === "host") {
+      const hit = ix.buckets.get(bucketKey(value));
+      return hit ? this._nodes(ix, hit) : [];
+    }
+    // the reference compares String(value): 30 and "30" are the same bucket
+    const n = typeof value === "string" && value.trim() !== "" ? Number(value) : value;
+    if (!isDeviceInt(n) || String(n) !== String(value)) return [];
+    const ids = this.graph.scanRange(ix.deviceField, n, n);
+    return this._nodes(ix, this._ordinals(ix, ids).sort((a, b) => a - b));
+  }
+
+  range(path, field, min, max) {
+    if (arguments.length === 3) { max = min; min = field; field = null; }
+    const ix = this._fresh(path, field);
+    this.lastPath = ix.kind;
+    if (typeof min === "undefined" || typeof max === "undefined") return [];
+    if (ix.kind === "device" && typeof min === "number" && typeof max === "number" && !Number.isNaN(min) && !Number.isNaN(max)) {
+      // integer column: lo = ceil(min), hi = floor(max) select exactly the values with min <= v <= max
+      const ids = this.graph.scanRange(ix.deviceField, Math.ceil(min), Math.floor(max));
+      return this._nodes(ix, this._inReferenceOrder(ix, this._ordinals(ix, ids)));
+    }
+    // host index, or bounds the device cannot express (strings): JS comparison semantics on the host
+    this.lastPath = "host";
+    const out = [];
+    const groups = new Map();
+    ix.values.forEach((v, i) => { const k = bucketKey(v); if (!groups.has(k)) groups.set(k, []); groups.get(k).push(i); });
+    for (const [k, members] of groups) {
+      let v = Number(k);
+      if (Number.isNaN(v)) v = k;
+      if (v >= min && v <= max) out.push(...members);
+    }
+    return this._nodes(ix, out);
+  }
+
+  count(path, field, value) {
+    if (arguments.length === 2) { value = field; field = null; }
+    const ix = this._fresh(path, field);
+    this.lastPath = ix.kind;
+    if (ix.kind === "host") {
+      const hit = ix.buckets.get(bucketKey(value));
+      return hit ? hit.length : 0;
+    }
+    const n = typeof value === "string" && value.trim() !== "" ? Number(value) : value;
+    if (!isDeviceInt(n) || String(n) !== String(value)) return 0;
+    return this.graph.scanCount(ix.deviceField, n, n);
+  }
+
+  /**
+   * Declarative filter on the device: AND of range terms over integer fields of the same child node.
+   * terms: [{field, min, max}]  (equality: min === max). The arbitrary-callback form stays in filter().
+   */
+  filterWhere(path, terms) {
+    if (!terms || terms.length === 0) return [];
+    const ixs = terms.map((t) => this._fresh(path, t.field));
+    if (!ixs.every((ix) => ix.kind === "device")) {
+      const err = new Error("bmx: filterWhere needs integer-valued fields on every term");
+      err.code = "BMX_NOT_DEVICE_INDEX";
+      throw err;
+    }
+    this.lastPath = "device";
+    const native = terms.map((t, k) => [ixs[k].deviceField, Math.ceil(t.min), Math.floor(t.max)]);
+    const ids = this.graph.scanFilter(native);
+    return this._nodes(ixs[0], this._ordinals(ixs[0], ids).sort((a, b) => a - b));
+  }
+
+  filter(path, fn) {
+    const base = this.bullet._getData(path);
+    const out = [];
+    if (typeof base === "object" && base !== null) {
+      for (const [k, v] of Object.entries(base)) if (fn(v, k)) out.push(this.bullet.get(`${path}/${k}`));
+    }
+    return out;
+  }
+
+  map(path, fn) {
+    const base = this.bullet._getData(path);
+    const out = [];
+    if (typeof base === "object" && base !== null) {
+      for (const [k, v] of Object.entries(base)) out.push(fn(v, k));
+    }
+    return out;
+  }
+
+  find(path, fn) {
+    const base = this.bullet._getData(path);
+    if (typeof base === "object" && base !== null) {
+      for (const [k, v] of Object.entries(base)) if (fn(v, k)) return this.bullet.get(`${path}/${k}`);
+    }
+    return null;
+  }
+
+  close() {
+    if (this._ownsGraph && this._graph) this._graph.close();
+    this._graph = null;
+  }
+}
+
+module.exports = GpuQuery;

@@ -1,0 +1,104 @@
+"use strict";
+/*
+ * hash.js — host-side hashing of Bullet's string keys to the fixed-width device keys (SURVEY H5).
+ *   node path  -> 64-bit id, kept as two uint32 halves [lo, hi] (no BigInt on the hot path)
+ *   field name -> 32-bit field hash (scoped by the parent collection, like the reference's "path:field" index key
+ *                 src/bullet-query.js:31)
+ * The device never sees strings; KeyDictionary remembers id -> path and detects collisions.
+ */
+
+function fnv1a32(str, seed) {
+  let h = seed >>> 0;
+  for (let i = 0; i < str.length; i++) {
+    let c = str.charCodeAt(i);
+    if (c < 0x80) {
+      h = Math.imul(h ^ c, 0x01000193);
+    } else {                       // UTF-16 code unit as two bytes: deterministic, no encoder allocation
+      h = Math.imul(h ^ (c & 0xff), 0x01000193);
+      h = Math.imul(h ^ (c >>> 8), 0x01000193);
+    }
+  }
+  return h >>> 0;
+}
+function fmix32(h) {
+  h ^= h >>> 16; h = Math.imul(h, 0x85ebca6b);
+  h ^= h >>> 13; h = Math.imul(h, 0xc2b2ae35);
+  h ^= h >>> 16;
+  return h >>> 0;
+}
+
+/* 64-bit id of a node path as [lo, hi]; 0xFFFFFFFF:FFFFFFFF is reserved by the device */
+function pathId(p) {
+  const lo = fmix32(fnv1a32(p, 0x811c9dc5));
+  let hi = fmix32(fnv1a32(p, 0x9747b28c) ^ lo);
+  if (lo === 0xffffffff && hi === 0xffffffff) hi = 0xfffffffe;
+  return [lo, hi];
+}
+
+/* 32-bit hash of (collection path, field name); 0xFFFFFFFF is reserved by the device */
+function fieldId(collection, field) {
+  const h = fmix32(fnv1a32(collection + ":" + (field === null || field === undefined ? "" : field), 0x811c9dc5));
+  return h === 0xffffffff ? 0xfffffffe : h;
+}
+
+function idKey(lo, hi) { return hi * 4294967296 + lo <= Number.MAX_SAFE_INTEGER ? String(hi * 4294967296 + lo) : hi.toString(16) + ":" + lo.toString(16); }
+
+class KeyDictionary {
+  constructor() {
+    this.byPath = new Map();   // path -> [lo, hi]
+    this.byId = new Map();     // idKey -> path
+  }
+  idOf(p) {
+    let id = this.byPath.get(p);
+    if (id) return id;
+    id = pathId(p);
+    const k = idKey(id[0], id[1]);
+    const other = this.byId.get(k);
+    if (other !== undefined && other !== p) {
+      const err = new Error(`bmx: 64-bit id collision between paths '${other}' and '${p}'`);
+      err.code = "BMX_ID_COLLISION";
+      throw err;
+    }
+    this.byId.set(k, p);
+    this.byPath.set(p, id);
+    return id;
+  }
+  pathOf(lo, hi) { return this.byId.get(idKey(lo, hi)); }
+}
+
+/* typed-column builder: id as BigUint64Array written through a Uint32Array view */
+class Columns {
+  constructor(n) {
+    this.n = n;
+    this.id = new BigUint64Array(n);
+    this._id32 = new Uint32Array(this.id.buffer);
+    this.field = new Uint32Array(n);
+    this.ts = new BigInt64Array(n);
+    this.val = new BigInt64Array(n);
+  }
+  set(i, idPair, field, ts, val) {
+    this._id32[2 * i] = idPair[0]; this._id32[2 * i + 1] = idPair[1];
+    this.field[i] = field;
+    this.ts[i] = BigInt(ts); this.val[i] = BigInt(val);
+  }
+  slice(n) {
+    if (n === this.n) return this;
+    const c = Object.create(Columns.prototype);
+    c.n = n; c.id = this.id.subarray(0, n); c._id32 = this._id32.subarray(0, 2 * n);
+    c.field = this.field.subarray(0, n); c.ts = this.ts.subarray(0, n); c.val = this.val.subarray(0, n);
+    return c;
+  }
+}
+
+const MAX_SAFE = Number.MAX_SAFE_INTEGER;
+function isDeviceInt(v) { return typeof v === "number" && Number.isInteger(v) && v <= MAX_SAFE && v >= -MAX_SAFE; }
+/* a clock the device understands: exactly one component, owned by `writer`, a non-negative safe integer */
+function scalarClock(clock, writer) {
+  if (!clock || typeof clock !== "object") return -1;
+  const ks = Object.keys(clock);
+  if (ks.length !== 1 || ks[0] !== writer) return -1;
+  const t = clock[writer];
+  return isDeviceInt(t) && t >= 0 ? t : -1;
+}
+
+module.exports = { pathId, fieldId, idKey, KeyDictionary, Columns, isDeviceInt, scalarClock, fnv1a32 };

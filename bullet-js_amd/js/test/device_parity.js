@@ -1,0 +1,122 @@
+"use strict";
+/*
+ * device_parity.js — GPU test of the JS host over the N-API addon: GpuCRT.mergeBatch/mergeEntries and GpuQuery's
+ * device indices against golden vectors produced by the real reference (tests/golden). Needs an MI355X.
+ * Usage: node device_parity.js <golden dir>
+ */
+const fs = require("fs");
+const path = require("path");
+const assert = require("assert");
+const { GpuCRT, GpuQuery, attach, hash } = require("..");
+const MiniBullet = require("./mini-bullet");
+const gen = require(path.join(__dirname, "..", "..", "..", "oracle", "gen_golden.js"));   // test infrastructure: stream generator only
+
+const GOLD = process.argv[2] || path.join(__dirname, "..", "..", "..", "tests", "golden");
+const load = (n) => JSON.parse(fs.readFileSync(path.join(GOLD, n), "utf8"));
+let checks = 0;
+
+function columns(rows, F) {
+  const n = rows.length;
+  const c = { id: new BigUint64Array(n), field: new Uint32Array(n), ts: new BigInt64Array(n), val: new BigInt64Array(n) };
+  rows.forEach((r, i) => { c.id[i] = gen.rowId(r.row, F); c.field[i] = gen.rowField(r.row, F); c.ts[i] = BigInt(r.ts); c.val[i] = BigInt(r.val); });
+  return c;
+}
+
+/* G2 streams through GpuCRT.mergeBatch */
+for (const name of fs.readdirSync(GOLD).filter((f) => f.startsWith("g2_stream_")).sort()) {
+  const g = load(name);
+  const { resident, deltas, F } = gen.genStream(g.spec);
+  const crt = new GpuCRT({ id: "w", meta: {}, _getData() {} }, { capacityRows: Math.max(4096, 2 * (g.spec.R + g.spec.D)) });
+  const rc = columns(resident, F);
+  crt.graph.loadRows(rc);
+  const r = crt.mergeBatch(columns(deltas, F));
+  assert.deepStrictEqual(Array.from(r.applied), g.winners, name + " winners");
+  assert.strictEqual(r.nRows, g.n_rows_final, name + " rows");
+  if (r.nConflicts === 0) assert.strictEqual(Buffer.from(r.flags).toString("base64"), g.flags_b64, name + " flags");
+  const d = crt.graph.dumpRows();
+  let digest = 0n;
+  for (let i = 0; i < d.id.length; i++) digest = (digest + gen.rowDigest(d.id[i], d.field[i], d.ts[i], d.val[i])) & ((1n << 64n) - 1n);
+  assert.strictEqual(digest.toString(16), g.digest, name + " state digest");
+  crt.close();
+  checks += 4;
+}
+
+/* G5: integer indices on the device, reference order included */
+{
+  const g = load("g5_query_seeded_2k.json");
+  const rng = gen.xorshift32(g.seed);
+  const b = new MiniBullet("w");
+  const { query } = attach(b, { capacityRows: 1 << 16 });
+  for (let i = 0; i < g.N; i++) {
+    const age = rng() % 100, score = (rng() % 200001) - 100000;
+    b.setData("n/k" + i, { age, score, __fromNetwork: true, __vectorClock: { w: 10 + (i % 7) } }, false);
+  }
+  const ord = (nodes) => nodes.map((n) => parseInt(n.path.split("/").pop().slice(1), 10));
+  for (const q of g.queries) {
+    let got;
+    if (q.op === "equals") got = ord(query.equals("n", q.field, q.args[0]));
+    else if (q.op === "range") got = ord(query.range("n", q.field, q.args[0], q.args[1]));
+    else if (q.op === "count") { assert.strictEqual(query.count("n", q.field, q.args[0]), q.count); assert.strictEqual(query.lastPath, "device"); checks++; continue; }
+    else if (q.op === "filter_and") got = ord(query.filterWhere("n", [{ field: "age", min: q.args[0][0], max: q.args[0][1] }, { field: "score", min: q.args[1][0], max: q.args[1][1] }]));
+    assert.strictEqual(query.lastPath, "device", JSON.stringify(q));
+    if (q.op === "filter_and") assert.deepStrictEqual(got.slice().sort((a, b) => a - b), q.ordinals.slice().sort((a, b) => a - b));
+    else assert.deepStrictEqual(got, q.ordinals, "reference order " + JSON.stringify(q.args));   // exact order of the reference
+    checks++;
+  }
+  // a write makes the index stale; the next query sees it (fresh-index semantics)
+  b.setData("n/k5", { age: 42, score: 1, __fromNetwork: true, __vectorClock: { w: 999 } }, false);
+  assert.ok(ord(query.equals("n", "age", 42)).includes(5));
+  assert.strictEqual(query.equals("n", "age", "42").length, query.equals("n", "age", 42).length);   // "42" and 42 share a bucket
+  assert.deepStrictEqual(query.range("n", "age", 30, undefined), []);
+  b.close();
+  checks += 3;
+}
+
+/* G5 example dataset: ints on the device, strings on the host, through the same facade */
+{
+  const g = load("g5_query_example.json");
+  const b = new MiniBullet("w");
+  const { query } = attach(b, { capacityRows: 4096 });
+  for (const [k, v] of Object.entries(g.users)) b.get("users/" + k).put(v);
+  for (const [k, v] of Object.entries(g.products)) b.get("products/" + k).put(v);
+  const keys = (nodes) => nodes.map((n) => n.path.split("/").pop());
+  for (const q of g.queries) {
+    if (q.op === "range") {
+      const hi = q.args[3] === "Infinity" ? Infinity : q.args[3];
+      assert.deepStrictEqual(keys(query.range(q.args[0], q.args[1], q.args[2], hi)), q.keys, JSON.stringify(q.args));
+      assert.strictEqual(query.lastPath, "device");
+    } else if (q.op === "equals") {
+      assert.deepStrictEqual(keys(query.equals(q.args[0], q.args[1], q.args[2])), q.keys, JSON.stringify(q.args));
+    } else if (q.op === "count") {
+      assert.strictEqual(query.count(q.args[0], q.args[1], q.args[2]), q.n);
+    } else if (q.op === "range_undefined_max") {
+      assert.deepStrictEqual(query.range(q.args[0], q.args[1], q.args[2], undefined), []);
+    }
+    checks++;
+  }
+  assert.deepStrictEqual(keys(query.equals("users", "role", "admin")), ["user1", "user6", "user10"]);
+  assert.strictEqual(query.lastPath, "host");
+  b.close();
+}
+
+/* sync-chunk adapter: entries -> device rows; off-contract entries are handed back */
+{
+  const b = new MiniBullet("w");
+  const { crt } = attach(b, { capacityRows: 4096 });
+  const entries = [
+    { path: "s/a", data: { n: 1, m: 5 }, vectorClock: { w: 10 } },
+    { path: "s/b", data: 7, vectorClock: { w: 3 } },
+    { path: "s/a", data: { n: 2 }, vectorClock: { w: 9 } },          // older than the first: loses against it
+    { path: "s/c", data: { name: "x" }, vectorClock: { w: 4 } },     // string: host path
+    { path: "s/d", data: { n: 1 }, vectorClock: { w: 4, q: 1 } },    // multi-writer clock: host path
+    { path: "s/a", data: { n: 3 }, vectorClock: { w: 11 } },
+  ];
+  const r = crt.mergeEntries(entries, { insertMode: "delta" });
+  assert.deepStrictEqual(r.host, [3, 4]);
+  assert.deepStrictEqual(r.applied, [{ entry: 0, field: "m" }, { entry: 1, field: null }, { entry: 5, field: "n" }]);
+  assert.strictEqual(r.nRows, 3);
+  b.close();
+  checks += 3;
+}
+
+console.log("device_parity ok:", checks, "checks");

@@ -1,0 +1,302 @@
+// bmx_napi.cc — thin N-API shim over the C ABI (include/bmx.h). No logic lives here: it converts typed
+// arrays to pointers, calls libbmx.so and throws a JS Error carrying bmx_last_error() on failure
+// (reference error policy: the hot path reports, never aborts — src/bullet.js:230-234).
+// Built by bullet-js_amd/Makefile into bullet-js_amd/bmx.node and loaded by js/native.js.
+#include <node_api.h>
+#include <stdint.h>
+#include <math.h>
+#include <string.h>
+#include <string>
+#include <vector>
+
+#include "bmx.h"
+
+namespace {
+
+#define NAPI_OK(call)                                           \
+  do {                                                          \
+    if ((call) != napi_ok) {                                    \
+      napi_throw_error(env, nullptr, "N-API call failed: " #call); \
+      return nullptr;                                           \
+    }                                                           \
+  } while (0)
+
+napi_value throw_bmx(napi_env env, bmx_ctx* ctx, int rc) {
+  std::string msg = "bmx error " + std::to_string(rc) + ": " + bmx_last_error(ctx);
+  napi_value code, err, m;
+  napi_create_string_utf8(env, msg.c_str(), NAPI_AUTO_LENGTH, &m);
+  napi_create_error(env, nullptr, m, &err);
+  napi_create_int32(env, rc, &code);
+  napi_set_named_property(env, err, "code", code);
+  napi_throw(env, err);
+  return nullptr;
+}
+
+struct Handle { bmx_ctx* ctx; };
+
+void finalize_handle(napi_env, void* data, void*) {
+  Handle* h = static_cast<Handle*>(data);
+  if (h->ctx) bmx_destroy(h->ctx);
+  delete h;
+}
+
+bool get_handle(napi_env env, napi_value v, Handle** out) {
+  void* p = nullptr;
+  if (napi_get_value_external(env, v, &p) != napi_ok || !p || !static_cast<Handle*>(p)->ctx) {
+    napi_throw_error(env, nullptr, "bmx: invalid or closed engine handle");
+    return false;
+  }
+  *out = static_cast<Handle*>(p);
+  return true;
+}
+
+// typed array -> (pointer, element count); checks the element type
+bool get_ta(napi_env env, napi_value v, napi_typedarray_type want, void** data, size_t* len) {
+  napi_typedarray_type t; napi_value ab; size_t off;
+  if (napi_get_typedarray_info(env, v, &t, len, data, &ab, &off) != napi_ok || t != want) {
+    napi_throw_type_error(env, nullptr, "bmx: wrong typed-array type (id BigUint64Array, field Uint32Array, ts/val BigInt64Array)");
+    return false;
+  }
+  return true;
+}
+
+napi_value make_ta(napi_env env, napi_typedarray_type t, size_t elem, size_t n, void** data) {
+  napi_value ab, ta;
+  if (napi_create_arraybuffer(env, n * elem, data, &ab) != napi_ok) return nullptr;
+  if (napi_create_typedarray(env, t, n, ab, 0, &ta) != napi_ok) return nullptr;
+  return ta;
+}
+
+// number | bigint -> int64 (saturating; +-Infinity allowed, as range() accepts them: src/bullet-query.js:248-253)
+bool get_i64(napi_env env, napi_value v, int64_t* out) {
+  napi_valuetype t;
+  napi_typeof(env, v, &t);
+  if (t == napi_bigint) {
+    bool lossless;
+    return napi_get_value_bigint_int64(env, v, out, &lossless) == napi_ok;
+  }
+  double d;
+  if (napi_get_value_double(env, v, &d) != napi_ok || isnan(d)) { napi_throw_type_error(env, nullptr, "bmx: expected a number or bigint"); return false; }
+  if (d >= 9.2e18) *out = INT64_MAX; else if (d <= -9.2e18) *out = INT64_MIN; else *out = (int64_t)d;
+  return true;
+}
+
+void set_num(napi_env env, napi_value obj, const char* k, double v) { napi_value n; napi_create_double(env, v, &n); napi_set_named_property(env, obj, k, n); }
+
+#define ARGS(N)                                              \
+  size_t argc = N; napi_value argv[N];                       \
+  NAPI_OK(napi_get_cb_info(env, info, &argc, argv, nullptr, nullptr)); \
+  if (argc < N) { napi_throw_type_error(env, nullptr, "bmx: missing arguments"); return nullptr; }
+
+napi_value AbiVersion(napi_env env, napi_callback_info) { napi_value v; napi_create_int32(env, bmx_abi_version(), &v); return v; }
+
+napi_value Create(napi_env env, napi_callback_info info) {
+  ARGS(2);
+  int32_t device; double cap;
+  NAPI_OK(napi_get_value_int32(env, argv[0], &device));
+  NAPI_OK(napi_get_value_double(env, argv[1], &cap));
+  bmx_ctx* ctx = nullptr;
+  int rc = bmx_create(device, (uint64_t)cap, 0, &ctx);
+  if (rc) return throw_bmx(env, nullptr, rc);
+  Handle* h = new Handle{ctx};
+  napi_value ext;
+  NAPI_OK(napi_create_external(env, h, finalize_handle, nullptr, &ext));
+  return ext;
+}
+
+napi_value Destroy(napi_env env, napi_callback_info info) {
+  ARGS(1);
+  void* p = nullptr;
+  if (napi_get_value_external(env, argv[0], &p) == napi_ok && p) {
+    Handle* h = static_cast<Handle*>(p);
+    if (h->ctx) { bmx_destroy(h->ctx); h->ctx = nullptr; }
+  }
+  return nullptr;
+}
+
+bool get_cols(napi_env env, napi_value* a, const uint64_t** id, const uint32_t** field, const int64_t** ts, const int64_t** val, size_t* n) {
+  void *p0, *p1, *p2, *p3; size_t n0, n1, n2, n3;
+  if (!get_ta(env, a[0], napi_biguint64_array, &p0, &n0) || !get_ta(env, a[1], napi_uint32_array, &p1, &n1) ||
+      !get_ta(env, a[2], napi_bigint64_array, &p2, &n2) || !get_ta(env, a[3], napi_bigint64_array, &p3, &n3)) return false;
+  if (n0 != n1 || n0 != n2 || n0 != n3) { napi_throw_range_error(env, nullptr, "bmx: column lengths differ"); return false; }
+  *id = (const uint64_t*)p0; *field = (const uint32_t*)p1; *ts = (const int64_t*)p2; *val = (const int64_t*)p3; *n = n0;
+  return true;
+}
+
+// mergeBatch(h, id, field, ts, val, mode) -> {applied: Uint32Array, flags: Uint8Array, nApplied, nConflicts, nRows}
+napi_value MergeBatch(napi_env env, napi_callback_info info) {
+  ARGS(6);
+  Handle* h; if (!get_handle(env, argv[0], &h)) return nullptr;
+  const uint64_t* id; const uint32_t* field; const int64_t *ts, *val; size_t n;
+  if (!get_cols(env, argv + 1, &id, &field, &ts, &val, &n)) return nullptr;
+  int32_t mode; NAPI_OK(napi_get_value_int32(env, argv[5], &mode));
+  std::vector<uint32_t> applied(n ? n : 1);
+  void* fl = nullptr;
+  napi_value flags = make_ta(env, napi_uint8_array, 1, n, &fl);
+  uint64_t na = 0; bmx_merge_stats st; memset(&st, 0, sizeof(st));
+  int rc = bmx_merge_batch(h->ctx, n, id, field, ts, val, mode, BMX_MEM_HOST, applied.data(), &na, (uint8_t*)fl, &st);
+  if (rc) return throw_bmx(env, h->ctx, rc);
+  void* ap = nullptr;
+  napi_value ta = make_ta(env, napi_uint32_array, 4, (size_t)na, &ap);
+  if (na) memcpy(ap, applied.data(), (size_t)na * 4);
+  napi_value out; NAPI_OK(napi_create_object(env, &out));
+  napi_set_named_property(env, out, "applied", ta);
+  napi_set_named_property(env, out, "flags", flags);
+  set_num(env, out, "nApplied", (double)st.n_applied); set_num(env, out, "nConflicts", (double)st.n_conflicts); set_num(env, out, "nRows", (double)st.n_rows);
+  return out;
+}
+
+napi_value LoadRows(napi_env env, napi_callback_info info) {
+  ARGS(5);
+  Handle* h; if (!get_handle(env, argv[0], &h)) return nullptr;
+  const uint64_t* id; const uint32_t* field; const int64_t *ts, *val; size_t n;
+  if (!get_cols(env, argv + 1, &id, &field, &ts, &val, &n)) return nullptr;
+  int rc = bmx_load_rows(h->ctx, n, id, field, ts, val, BMX_MEM_HOST);
+  if (rc) return throw_bmx(env, h->ctx, rc);
+  return nullptr;
+}
+
+// getRows(h, id, field) -> {ts, val, found}
+napi_value GetRows(napi_env env, napi_callback_info info) {
+  ARGS(3);
+  Handle* h; if (!get_handle(env, argv[0], &h)) return nullptr;
+  void *p0, *p1; size_t n0, n1;
+  if (!get_ta(env, argv[1], napi_biguint64_array, &p0, &n0) || !get_ta(env, argv[2], napi_uint32_array, &p1, &n1)) return nullptr;
+  if (n0 != n1) { napi_throw_range_error(env, nullptr, "bmx: column lengths differ"); return nullptr; }
+  void *ts, *val, *found;
+  napi_value a = make_ta(env, napi_bigint64_array, 8, n0, &ts), b = make_ta(env, napi_bigint64_array, 8, n0, &val), c = make_ta(env, napi_uint8_array, 1, n0, &found);
+  int rc = bmx_get_rows(h->ctx, n0, (const uint64_t*)p0, (const uint32_t*)p1, (int64_t*)ts, (int64_t*)val, (uint8_t*)found, BMX_MEM_HOST);
+  if (rc) return throw_bmx(env, h->ctx, rc);
+  napi_value out; NAPI_OK(napi_create_object(env, &out));
+  napi_set_named_property(env, out, "ts", a); napi_set_named_property(env, out, "val", b); napi_set_named_property(env, out, "found", c);
+  return out;
+}
+
+napi_value RowCount(napi_env env, napi_callback_info info) {
+  ARGS(1);
+  Handle* h; if (!get_handle(env, argv[0], &h)) return nullptr;
+  uint64_t n = 0; int rc = bmx_row_count(h->ctx, &n);
+  if (rc) return throw_bmx(env, h->ctx, rc);
+  napi_value v; napi_create_double(env, (double)n, &v); return v;
+}
+
+napi_value DumpRows(napi_env env, napi_callback_info info) {
+  ARGS(1);
+  Handle* h; if (!get_handle(env, argv[0], &h)) return nullptr;
+  uint64_t n = 0; int rc = bmx_row_count(h->ctx, &n);
+  if (rc) return throw_bmx(env, h->ctx, rc);
+  void *id, *f, *ts, *val;
+  napi_value a = make_ta(env, napi_biguint64_array, 8, n, &id), b = make_ta(env, napi_uint32_array, 4, n, &f),
+             c = make_ta(env, napi_bigint64_array, 8, n, &ts), d = make_ta(env, napi_bigint64_array, 8, n, &val);
+  uint64_t m = 0;
+  rc = bmx_dump_rows(h->ctx, n, (uint64_t*)id, (uint32_t*)f, (int64_t*)ts, (int64_t*)val, &m, BMX_MEM_HOST);
+  if (rc) return throw_bmx(env, h->ctx, rc);
+  napi_value out; NAPI_OK(napi_create_object(env, &out));
+  napi_set_named_property(env, out, "id", a); napi_set_named_property(env, out, "field", b);
+  napi_set_named_property(env, out, "ts", c); napi_set_named_property(env, out, "val", d);
+  return out;
+}
+
+napi_value IndexBuild(napi_env env, napi_callback_info info) {
+  ARGS(2);
+  Handle* h; if (!get_handle(env, argv[0], &h)) return nullptr;
+  uint32_t f; NAPI_OK(napi_get_value_uint32(env, argv[1], &f));
+  int rc = bmx_index_build(h->ctx, f);
+  if (rc) return throw_bmx(env, h->ctx, rc);
+  return nullptr;
+}
+napi_value IndexDrop(napi_env env, napi_callback_info info) {
+  ARGS(2);
+  Handle* h; if (!get_handle(env, argv[0], &h)) return nullptr;
+  uint32_t f; NAPI_OK(napi_get_value_uint32(env, argv[1], &f));
+  int rc = bmx_index_drop(h->ctx, f);
+  if (rc && rc != BMX_ERR_NO_INDEX) return throw_bmx(env, h->ctx, rc);
+  return nullptr;
+}
+napi_value IndexSize(napi_env env, napi_callback_info info) {
+  ARGS(2);
+  Handle* h; if (!get_handle(env, argv[0], &h)) return nullptr;
+  uint32_t f; NAPI_OK(napi_get_value_uint32(env, argv[1], &f));
+  uint64_t n = 0; int rc = bmx_index_size(h->ctx, f, &n);
+  if (rc) return throw_bmx(env, h->ctx, rc);
+  napi_value v; napi_create_double(env, (double)n, &v); return v;
+}
+
+// scanRange(h, field, lo, hi) -> BigUint64Array of node ids
+napi_value ScanRange(napi_env env, napi_callback_info info) {
+  ARGS(4);
+  Handle* h; if (!get_handle(env, argv[0], &h)) return nullptr;
+  uint32_t f; NAPI_OK(napi_get_value_uint32(env, argv[1], &f));
+  int64_t lo, hi; if (!get_i64(env, argv[2], &lo) || !get_i64(env, argv[3], &hi)) return nullptr;
+  uint64_t m = 0; int rc = bmx_scan_count(h->ctx, f, lo, hi, &m, BMX_MEM_HOST);
+  if (rc) return throw_bmx(env, h->ctx, rc);
+  void* out; napi_value ta = make_ta(env, napi_biguint64_array, 8, m, &out);
+  if (m) { uint64_t m2 = 0; rc = bmx_scan_range(h->ctx, f, lo, hi, (uint64_t*)out, m, &m2, BMX_MEM_HOST); if (rc) return throw_bmx(env, h->ctx, rc); }
+  return ta;
+}
+napi_value ScanCount(napi_env env, napi_callback_info info) {
+  ARGS(4);
+  Handle* h; if (!get_handle(env, argv[0], &h)) return nullptr;
+  uint32_t f; NAPI_OK(napi_get_value_uint32(env, argv[1], &f));
+  int64_t lo, hi; if (!get_i64(env, argv[2], &lo) || !get_i64(env, argv[3], &hi)) return nullptr;
+  uint64_t m = 0; int rc = bmx_scan_count(h->ctx, f, lo, hi, &m, BMX_MEM_HOST);
+  if (rc) return throw_bmx(env, h->ctx, rc);
+  napi_value v; napi_create_double(env, (double)m, &v); return v;
+}
+// scanFilter(h, [[field, lo, hi], ...]) -> BigUint64Array
+napi_value ScanFilter(napi_env env, napi_callback_info info) {
+  ARGS(2);
+  Handle* h; if (!get_handle(env, argv[0], &h)) return nullptr;
+  uint32_t nt = 0; NAPI_OK(napi_get_array_length(env, argv[1], &nt));
+  if (nt == 0 || nt > 8) { napi_throw_range_error(env, nullptr, "bmx: filter needs 1..8 terms"); return nullptr; }
+  bmx_term terms[8];
+  for (uint32_t k = 0; k < nt; k++) {
+    napi_value t, e0, e1, e2;
+    NAPI_OK(napi_get_element(env, argv[1], k, &t));
+    NAPI_OK(napi_get_element(env, t, 0, &e0)); NAPI_OK(napi_get_element(env, t, 1, &e1)); NAPI_OK(napi_get_element(env, t, 2, &e2));
+    NAPI_OK(napi_get_value_uint32(env, e0, &terms[k].field));
+    terms[k].reserved = 0;
+    if (!get_i64(env, e1, &terms[k].lo) || !get_i64(env, e2, &terms[k].hi)) return nullptr;
+  }
+  uint64_t cap = 0; int rc = bmx_index_size(h->ctx, terms[0].field, &cap);
+  if (rc) return throw_bmx(env, h->ctx, rc);
+  std::vector<uint64_t> tmp(cap ? cap : 1);
+  uint64_t m = 0; rc = bmx_scan_filter(h->ctx, nt, terms, tmp.data(), cap, &m, BMX_MEM_HOST);
+  if (rc) return throw_bmx(env, h->ctx, rc);
+  void* out; napi_value ta = make_ta(env, napi_biguint64_array, 8, m, &out);
+  if (m) memcpy(out, tmp.data(), m * 8);
+  return ta;
+}
+
+napi_value Info(napi_env env, napi_callback_info info) {
+  ARGS(1);
+  Handle* h; if (!get_handle(env, argv[0], &h)) return nullptr;
+  bmx_info i; int rc = bmx_get_info(h->ctx, &i);
+  if (rc) return throw_bmx(env, h->ctx, rc);
+  napi_value out; NAPI_OK(napi_create_object(env, &out));
+  set_num(env, out, "capacityRows", (double)i.capacity_rows); set_num(env, out, "nSlots", (double)i.n_slots);
+  set_num(env, out, "tableBytes", (double)i.table_bytes); set_num(env, out, "nRows", (double)i.n_rows);
+  set_num(env, out, "device", i.device); set_num(env, out, "abiVersion", i.abi_version); set_num(env, out, "nIndexes", i.n_indexes);
+  return out;
+}
+
+napi_value Init(napi_env env, napi_value exports) {
+  struct { const char* name; napi_callback fn; } fns[] = {
+      {"abiVersion", AbiVersion}, {"create", Create}, {"destroy", Destroy}, {"mergeBatch", MergeBatch}, {"loadRows", LoadRows},
+      {"getRows", GetRows}, {"rowCount", RowCount}, {"dumpRows", DumpRows}, {"indexBuild", IndexBuild}, {"indexDrop", IndexDrop},
+      {"indexSize", IndexSize}, {"scanRange", ScanRange}, {"scanCount", ScanCount}, {"scanFilter", ScanFilter}, {"info", Info}};
+  for (auto& f : fns) {
+    napi_value v;
+    if (napi_create_function(env, f.name, NAPI_AUTO_LENGTH, f.fn, nullptr, &v) != napi_ok) return nullptr;
+    napi_set_named_property(env, exports, f.name, v);
+  }
+  struct { const char* name; int v; } consts[] = {{"INSERT_REFERENCE", BMX_INSERT_REFERENCE}, {"INSERT_DELTA", BMX_INSERT_DELTA},
+                                                  {"MERGE_UNIQUE_KEYS", BMX_MERGE_UNIQUE_KEYS}, {"FLAG_INCOMING", BMX_FLAG_INCOMING},
+                                                  {"FLAG_CURRENT", BMX_FLAG_CURRENT}, {"FLAG_HISTORICAL", BMX_FLAG_HISTORICAL}};
+  for (auto& c : consts) { napi_value v; napi_create_int32(env, c.v, &v); napi_set_named_property(env, exports, c.name, v); }
+  return exports;
+}
+
+}  // namespace
+
+NAPI_MODULE(NODE_GYP_MODULE_NAME, Init)

@@ -23,7 +23,7 @@ const path = require("path");
 
 const REF = process.env.BULLET_REF || "/root/reference";
 const OUT = process.argv[2] || path.join(__dirname, "..", "tests", "golden");
-const BulletCRT = require(path.join(REF, "src", "bullet-crt.js"));
+let BulletCRT = null;   /* loaded lazily: importing this file for genStream() must not need the reference */
 
 /* ------------------------------------------------------------------ PRNG / hashes */
 const M64 = (1n << 64n) - 1n;
@@ -98,7 +98,7 @@ function genStream(spec) {
 
 /* ------------------------------------------------------------------ L0 harness around the real BulletCRT */
 const WID = "w";
-function newCrt() { return new BulletCRT({ id: WID, meta: {}, _getData() { return undefined; } }); }
+function newCrt() { if (!BulletCRT) BulletCRT = require(path.join(REF, "src", "bullet-crt.js")); return new BulletCRT({ id: WID, meta: {}, _getData() { return undefined; } }); }
 function flagsOf(d) {
   return (d.incoming ? 1 : 0) | (d.current ? 2 : 0) | (d.historical ? 4 : 0) | (d.concurrent ? 8 : 0);
 }
@@ -358,11 +358,16 @@ const STREAMS = {
   "g2_stream_empty_start_0_1k.json": Object.assign({}, BASE, { seed: 3, R: 0, D: 1000, insert_pct: 100, ins_space: 300, store_final: true }),
 };
 
-fs.mkdirSync(OUT, { recursive: true });
-write("g1_decision_table.json", genDecisionTable());
-write("g3_sequences.json", genSequences());
-for (const [name, spec] of Object.entries(STREAMS)) write(name, runStream(spec));
-write("g4_l1_ops.json", genL1());
-write("g5_query_example.json", genQueryExample());
-write("g5_query_seeded_2k.json", genQuerySeeded(2000, 4711, true));
-write("g5_query_seeded_100k.json", genQuerySeeded(100000, 4712, false));
+function main() {
+  fs.mkdirSync(OUT, { recursive: true });
+  write("g1_decision_table.json", genDecisionTable());
+  write("g3_sequences.json", genSequences());
+  for (const [name, spec] of Object.entries(STREAMS)) write(name, runStream(spec));
+  write("g4_l1_ops.json", genL1());
+  write("g5_query_example.json", genQueryExample());
+  write("g5_query_seeded_2k.json", genQuerySeeded(2000, 4711, true));
+  write("g5_query_seeded_100k.json", genQuerySeeded(100000, 4712, false));
+}
+
+module.exports = { genStream, rowId, rowField, xorshift32, splitmix64, fnv1a32, rowDigest };
+if (require.main === module) main();

@@ -1,8 +1,8 @@
 """Seeded synthetic delta streams — TEST INFRASTRUCTURE ONLY.
 
 gen_stream() mirrors genStream() of oracle/gen_golden.js bit for bit (xorshift32, same draw order), so
-the golden fixtures only need to store the spec, not the inputs. big_stream() is the vectorised
-counter-based generator used for bench-sized inputs (SURVEY §8(d) config 2/5 shapes).
+the golden fixtures only need to store the spec, not the inputs. (Bench-sized synthetic inputs come from
+the product-side generator bmx/synth.py, which is plain data generation and not part of the oracle.)
 """
 import numpy as np
 
@@ -90,46 +90,3 @@ def gen_stream(spec):
     rid, rf = rows_to_keys(rrow, F)
     did, df = rows_to_keys(drow, F)
     return dict(F=F, resident=(rrow, rid, rf, rts, rval), deltas=(drow, did, df, dts, dval))
-
-
-def _u(seed, n, salt):
-    """n uniform uint64 draws, counter-based (vectorised)."""
-    with np.errstate(over="ignore"):
-        i = np.arange(n, dtype=np.uint64)
-        return splitmix64_np(i * np.uint64(0x9E3779B97F4A7C15) + np.uint64((seed * 0x632BE59BD9B4E019 + salt * 0xD1342543DE82EF95) & M64))
-
-
-def big_resident(R, seed=1, T0=1_000_000, DT=1_000_000, F=1, row0=0):
-    """Resident rows row0..row0+R-1: id = splitmix64(node+1), ts~U[T0,T0+DT), val in ±2^31."""
-    rows = np.arange(row0, row0 + R, dtype=np.int64)
-    ids, fld = rows_to_keys(rows, F)
-    ts = (T0 + (_u(seed, R, 1) % np.uint64(DT))).astype(np.int64)
-    val = (_u(seed, R, 2) % np.uint64(1 << 32)).astype(np.int64) - (1 << 31)
-    return ids, fld, ts, val
-
-
-def big_deltas(D, R, seed=2, T0=1_000_000, DT=1_000_000, F=1, insert_pct=10, hot_pct=0, hot_keys=0, unique=True, batch=0, drift=None):
-    """Config-2/5 shaped delta batch over a resident graph of R rows.
-
-    unique=True: hit rows are a stride permutation (no duplicate keys inside the batch), inserts get fresh rows.
-    ts ~ U[T0 + batch*drift, T0 + batch*drift + 2*DT); drift defaults to DT/2 per batch (streaming, config 5).
-    Config 2 uses drift = DT/16: consecutive unique batches walk disjoint rows (a row is revisited every R/D batches),
-    and the slow drift keeps ~75-78 % of hits winning in steady state, as SURVEY §8(d) specifies."""
-    if drift is None:
-        drift = DT // 2
-    u = _u(seed + 7919 * batch, D, 3) % np.uint64(100)
-    j = np.arange(D, dtype=np.int64)
-    if unique:
-        hit_rows = ((j + batch * D) * PERM_PRIME + 7) % R
-        ins_rows = R + batch * D + j
-    else:
-        hit_rows = (_u(seed + 7919 * batch, D, 4) % np.uint64(R)).astype(np.int64)
-        ins_rows = R + (_u(seed + 7919 * batch, D, 5) % np.uint64(max(1, R // 10))).astype(np.int64)
-    rows = np.where(u < insert_pct, ins_rows, hit_rows)
-    if hot_pct:
-        hot_rows = (_u(seed + 7919 * batch, D, 6) % np.uint64(max(1, hot_keys))).astype(np.int64)
-        rows = np.where((u >= insert_pct) & (u < insert_pct + hot_pct), hot_rows, rows)
-    ids, fld = rows_to_keys(rows, F)
-    ts = (T0 + batch * drift + (_u(seed + 7919 * batch, D, 8) % np.uint64(2 * DT))).astype(np.int64)
-    val = (_u(seed + 7919 * batch, D, 9) % np.uint64(1 << 32)).astype(np.int64) - (1 << 31)
-    return ids, fld, ts, val

@@ -8,6 +8,7 @@ pytestmark = pytest.mark.gpu
 
 import bmx
 from oracle import streams
+from bmx import synth
 from oracle.oracle import Oracle, INSERT_REFERENCE, INSERT_DELTA, rows_digest, owner_of as o_owner
 
 F0 = streams.field_hash(0)
@@ -22,7 +23,7 @@ def _dev(cols, dev):
 def test_device_pointer_merge_matches_oracle():
     dev = torch.device("cuda", 0)
     R, D = 200_000, 50_000
-    res = streams.big_resident(R, seed=31)
+    res = synth.big_resident(R, seed=31)
     o = Oracle(); o.load_rows(*res)
     with bmx.Engine(2 * (R + 4 * D)) as e:
         e.load_rows_dev(R, *_dev(res, dev))
@@ -31,7 +32,7 @@ def test_device_pointer_merge_matches_oracle():
         stats = torch.zeros(4, dtype=torch.int64, device=dev)
         flags = torch.zeros(D, dtype=torch.uint8, device=dev)
         for b in range(4):
-            d = streams.big_deltas(D, R, seed=32, insert_pct=10, hot_pct=25, hot_keys=64, unique=False, batch=b)
+            d = synth.big_deltas(D, R, seed=32, insert_pct=10, hot_pct=25, hot_keys=64, unique=False, batch=b)
             dd = _dev(d, dev)
             e.merge_batch_dev(D, *dd, INSERT_REFERENCE, applied=applied, n_applied=n_applied, flags=flags, stats=stats)
             e.sync()
@@ -46,12 +47,12 @@ def test_device_pointer_merge_matches_oracle():
 def test_unique_keys_mode_equals_default_on_unique_batches():
     dev = torch.device("cuda", 0)
     R, D = 300_000, 100_000
-    res = streams.big_resident(R, seed=41)
+    res = synth.big_resident(R, seed=41)
     o = Oracle(); o.load_rows(*res)
     with bmx.Engine(2 * (R + 3 * D)) as e:
         e.load_rows(*res)
         for b in range(3):
-            d = streams.big_deltas(D, R, seed=42, insert_pct=10, unique=True, batch=b, drift=60_000)
+            d = synth.big_deltas(D, R, seed=42, insert_pct=10, unique=True, batch=b, drift=60_000)
             assert len(np.unique(d[0])) == D
             applied, flags, st = e.merge_batch(*d, insert_mode=INSERT_REFERENCE | bmx.MERGE_UNIQUE_KEYS)
             of, ow = o.merge_batch(*d)
@@ -62,7 +63,7 @@ def test_unique_keys_mode_equals_default_on_unique_batches():
 def test_partition_by_owner_is_stable_and_complete_then_merge_records():
     dev = torch.device("cuda", 0)
     n, G = 100_000, 8
-    d = streams.big_deltas(n, 500_000, seed=51, insert_pct=20, hot_pct=20, hot_keys=100, unique=False)
+    d = synth.big_deltas(n, 500_000, seed=51, insert_pct=20, hot_pct=20, hot_keys=100, unique=False)
     dd = _dev(d, dev)
     recs = torch.zeros((n, 4), dtype=torch.int64, device=dev)
     counts = torch.zeros(G, dtype=torch.int64, device=dev)
@@ -111,10 +112,10 @@ def test_padding_records_are_skipped():
 def test_profile_hooks_report_three_stages():
     R, D = 100_000, 50_000
     with bmx.Engine(4 * R) as e:
-        e.load_rows(*streams.big_resident(R, seed=61))
+        e.load_rows(*synth.big_resident(R, seed=61))
         e.profile_enable(True)
         for b in range(3):
-            e.merge_batch(*streams.big_deltas(D, R, seed=62, batch=b), want_flags=False)
+            e.merge_batch(*synth.big_deltas(D, R, seed=62, batch=b), want_flags=False)
         ms, n = e.profile_read()
         assert n == 3 and all(v > 0 for v in ms.values())
         e.profile_enable(False)

@@ -7,6 +7,7 @@ pytestmark = pytest.mark.gpu
 
 import bmx
 from oracle import streams
+from bmx import synth
 from oracle.oracle import Oracle, INSERT_REFERENCE, INSERT_DELTA, rows_digest
 from helpers import load_golden, stream_fixtures, golden_flags, run_oracle_stream
 
@@ -179,9 +180,9 @@ def test_idempotent_and_commutative_properties_at_scale():
     """1M-row table, 200k-delta batches with hot keys: re-applying a batch changes nothing;
     applying two batches in either order gives the same state when no inserts are involved (true LWW on hits)."""
     R, D = 1_000_000, 200_000
-    rid, rf, rts, rval = streams.big_resident(R, seed=3)
-    b1 = streams.big_deltas(D, R, seed=4, insert_pct=0, hot_pct=30, hot_keys=R // 1000, unique=False, batch=0)
-    b2 = streams.big_deltas(D, R, seed=5, insert_pct=0, hot_pct=30, hot_keys=R // 1000, unique=False, batch=1)
+    rid, rf, rts, rval = synth.big_resident(R, seed=3)
+    b1 = synth.big_deltas(D, R, seed=4, insert_pct=0, hot_pct=30, hot_keys=R // 1000, unique=False, batch=0)
+    b2 = synth.big_deltas(D, R, seed=5, insert_pct=0, hot_pct=30, hot_keys=R // 1000, unique=False, batch=1)
     with bmx.Engine(2 * R) as e1, bmx.Engine(2 * R) as e2:
         e1.load_rows(rid, rf, rts, rval); e2.load_rows(rid, rf, rts, rval)
         a1, _, s1 = e1.merge_batch(*b1); e1.merge_batch(*b2)
@@ -202,12 +203,12 @@ def test_idempotent_and_commutative_properties_at_scale():
 def test_epoch_wrap_many_small_batches():
     """More than 255 batches: the 8-bit claim epoch wraps and heads are swept."""
     R = 2000
-    rid, rf, rts, rval = streams.big_resident(R, seed=21)
+    rid, rf, rts, rval = synth.big_resident(R, seed=21)
     o = Oracle(); o.load_rows(rid, rf, rts, rval)
     with bmx.Engine(3 * R) as e:
         e.load_rows(rid, rf, rts, rval)
         for b in range(300):
-            d = streams.big_deltas(64, R, seed=22, insert_pct=5, hot_pct=50, hot_keys=8, unique=False, batch=b, DT=40, T0=1_000_000)
+            d = synth.big_deltas(64, R, seed=22, insert_pct=5, hot_pct=50, hot_keys=8, unique=False, batch=b, DT=40, T0=1_000_000)
             applied, _, _ = e.merge_batch(*d)
             _, ow = o.merge_batch(*d)
             assert np.array_equal(applied, ow), b

@@ -1,0 +1,107 @@
+"""N>1 routing on CPU: world_size-2 gloo. The exchange logic (stable owner partition -> all_to_all(v) ->
+per-shard merge) is the product's bmx/sharded.py; the per-shard engine is replaced by the CPU oracle here
+because this container has no GPU. The sharded result must equal ONE oracle fed the concatenated batch."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+class OracleOps:
+    """CPU stand-in for EngineOps (tests only)."""
+
+    def __init__(self):
+        from oracle.oracle import Oracle
+        self.o = Oracle()
+        self.winners = None
+
+    def empty_records(self, n):
+        return torch.empty((max(int(n), 1), 4), dtype=torch.int64)
+
+    def zeros_i64(self, n):
+        return torch.zeros(int(n), dtype=torch.int64)
+
+    def partition(self, n, id, field, ts, val, nshards, recs_out, counts_out):
+        import bmx
+        from oracle.oracle import owner_of
+        idn = id.numpy().view(np.uint64)[:n]
+        own = owner_of(idn, nshards)
+        order = np.argsort(own, kind="stable")
+        r = np.zeros(n, dtype=bmx.DELTA_REC_DTYPE)
+        r["id"] = idn[order]; r["field"] = field.numpy().view(np.uint32)[:n][order]; r["aux"] = order.astype(np.uint32)
+        r["ts"] = ts.numpy()[:n][order]; r["val"] = val.numpy()[:n][order]
+        recs_out[:n] = torch.from_numpy(r.view(np.int64).reshape(n, 4))
+        counts_out[:] = torch.from_numpy(np.bincount(own, minlength=nshards).astype(np.int64))
+
+    def merge_records(self, n, recs, insert_mode, applied, n_applied):
+        import bmx
+        r = recs[:n].numpy().view(bmx.DELTA_REC_DTYPE).reshape(-1)
+        _, w = self.o.merge_batch(r["id"], r["field"], r["ts"], r["val"], insert_mode)
+        applied[:len(w)] = torch.from_numpy(w.astype(np.int32))
+        n_applied[0] = len(w)
+
+    def load_rows(self, id, field, ts, val):
+        self.o.load_rows(id, field, ts, val)
+
+    def sync(self):
+        pass
+
+
+def _worker(rank, world, port, tmp):
+    sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "bullet-js_amd"))
+    os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from bmx import synth
+    from bmx.sharded import ShardedGraph
+    ops = OracleOps()
+    sg = ShardedGraph(ops, dist, rank, world)
+    R = 20000
+    nloaded = sg.load_owned_resident(R // world * world // world, T0=1000, DT=1000)   # R/world per rank
+    digests = []
+    for b in range(3):
+        d = synth.big_deltas(3000, R, seed=5 + 100 * rank, T0=1000, DT=1000, insert_pct=15, hot_pct=30, hot_keys=40, unique=False, batch=b)
+        t = [torch.from_numpy(np.ascontiguousarray(x).view(np.int64 if x.dtype.itemsize == 8 else np.int32)) for x in d]
+        sg.merge_step(3000, *t)
+        applied, recv = sg.last_applied()
+        digests.append(len(applied))
+    id, f, ts, val = ops.o.dump_rows()
+    np.savez(os.path.join(tmp, "rank%d.npz" % rank), id=id, f=f, ts=ts, val=val, nloaded=nloaded, winners=np.array(digests),
+             sent=sg.sent_remote, recv=sg.received)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def _free_port():
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); p = s.getsockname()[1]; s.close()
+    return p
+
+
+def test_two_rank_routing_equals_single_merge(tmp_path):
+    world = 2
+    mp.spawn(_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    from bmx import synth
+    from oracle.oracle import Oracle, rows_digest, owner_of
+    R = 20000
+    # single-oracle truth: the whole graph, batches applied in global order (rank-major inside each step)
+    o = Oracle()
+    o.load_rows(*synth.big_resident(R, seed=1, T0=1000, DT=1000))
+    for b in range(3):
+        for rank in range(world):
+            o.merge_batch(*synth.big_deltas(3000, R, seed=5 + 100 * rank, T0=1000, DT=1000, insert_pct=15, hot_pct=30, hot_keys=40, unique=False, batch=b))
+    parts = [np.load(os.path.join(str(tmp_path), "rank%d.npz" % r)) for r in range(world)]
+    assert sum(int(p["nloaded"]) for p in parts) == R
+    for r, p in enumerate(parts):
+        assert (owner_of(p["id"], world) == r).all()          # every row sits on its owner
+        assert int(p["recv"]) > 0 and int(p["sent"]) > 0
+    ids = np.concatenate([p["id"] for p in parts]); f = np.concatenate([p["f"] for p in parts])
+    ts = np.concatenate([p["ts"] for p in parts]); val = np.concatenate([p["val"] for p in parts])
+    assert len(ids) == len(o)
+    assert rows_digest(ids, f, ts, val) == o.digest()          # union of shards == single merge, bit for bit
+    assert sum(int(p["sent"]) for p in parts) + sum(int(p["recv"]) for p in parts) > 0
