@@ -70,11 +70,17 @@ def cpu_baseline(n_batches=3):
 
 
 def main():
+    # stdout carries exactly ONE JSON line: native libraries (RCCL's version banner) print to fd 1, so fd 1 is pointed
+    # at stderr for the whole run and the JSON goes to a private duplicate of the real stdout.
+    sys.stdout.flush()
+    real_stdout = os.fdopen(os.dup(1), "w")
+    os.dup2(2, 1)
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--force-sharded", action="store_true", help="run the N>1 code path (partition + all-to-all + merge) even with one rank: rehearsal only")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -89,16 +95,18 @@ def main():
 
     import bmx
     dist = None
-    if world > 1:
+    sharded = world > 1 or args.force_sharded
+    if sharded:
         import torch.distributed as dist
-        dist.init_process_group(backend="nccl", device_id=dev)
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1"); os.environ.setdefault("MASTER_PORT", "29544")
+        dist.init_process_group(backend="nccl", rank=rank, world_size=world, device_id=dev)
 
     K, W = args.steps, args.warmup
     nb = K + W
     # every step inserts 10 % new rows: size the table for all of them (load factor stays <= 0.5)
     eng = bmx.Engine(capacity_rows=R_PER_GPU + (2 * nb + 8) * D_PER_STEP // 5 + D_PER_STEP, device=local_rank)
 
-    if world == 1:
+    if not sharded:
         rid = gen_resident(R_PER_GPU)
         eng.load_rows(*rid)
         del rid
@@ -159,22 +167,34 @@ def main():
         sg.load_owned_resident(R_PER_GPU, T0=T0, DT=DT)
         R_global = R_PER_GPU * world
         batches = [to_dev(gen_batch(b, R_global, seed=2 + 1000 * rank), dev) for b in range(nb)]
+        sg.setup_pipeline(D_PER_STEP)
         torch.cuda.synchronize()
-        for b in range(W):
-            sg.merge_step(D_PER_STEP, *batches[b])
-        eng.sync(); torch.cuda.synchronize(); dist.barrier()
+
+        def run(lo, hi):
+            # exactly (hi-lo) routes and (hi-lo) merges; route b+1 (partition + all-to-all, comm stream) overlaps merge b:
+            # merge(b) is enqueued first so the GPU never waits for the host, route(b+1) follows on the other stream
+            tk = sg.route(D_PER_STEP, *batches[lo])
+            for b in range(lo, hi):
+                sg.merge(tk)
+                tk = sg.route(D_PER_STEP, *batches[b + 1]) if b + 1 < hi else None
+
+        if W:
+            run(0, W)
+        sg.ops.sync(); torch.cuda.synchronize(); dist.barrier()
         t0 = time.perf_counter()
-        for b in range(W, nb):
-            sg.merge_step(D_PER_STEP, *batches[b])
-        eng.sync(); torch.cuda.synchronize(); dist.barrier()
+        run(W, nb)
+        t_enq = time.perf_counter() - t0
+        sg.ops.sync(); torch.cuda.synchronize(); dist.barrier()
         wall = time.perf_counter() - t0
+        if sg.overflowed():
+            raise SystemExit("exchange slab overflow: run invalid (raise ShardedGraph.setup_pipeline slack)")
         tmax = torch.tensor([wall], dtype=torch.float64, device=dev)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed = float(tmax.item())
         total_units = K * D_PER_STEP * world
         roofline = {"bound": "hbm", "kernel": "k_probe_apply", "achieved": None, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": None, "traffic": None,
                     "note": "per-kernel figure is reported by the N=1 run"}
-        extra = {"exchange": sg.stats()}
+        extra = {"host_enqueue_ms_per_step": round(t_enq / K * 1e3, 4), "exchange": dict(sg.stats(), mode="fixed slabs of %d records per ordered pair, partition+all-to-all of batch b+1 overlapped with merge of batch b" % sg.slab)}
         cfg = {"workload": "config 4 shape: %dM-row graph id-hash sharded over %d MI355X, %dM mixed-owner deltas per step routed by RCCL all-to-all" %
                (R_global // 1_000_000, world, world * D_PER_STEP // 1_000_000),
                "resident_rows_per_gpu": R_PER_GPU, "deltas_per_step_per_gpu": D_PER_STEP, "insert_mode": "reference", "sharding": "owner = hash(node id) mod N"}
@@ -185,16 +205,19 @@ def main():
                "ms_per_step": elapsed / K * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "int64",
                "data": "synthetic", "config": cfg, "roofline": roofline}
         out.update(extra)
-        if world == 1 and not args.no_cpu_baseline:
+        if not sharded and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline()
         else:
             out["cpu_baseline"] = None
+    if sharded:
+        sg.ops.close()
     eng.close()
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
     if out is not None:
-        print(json.dumps(out))
+        real_stdout.write(json.dumps(out) + "\n")
+        real_stdout.flush()
 
 
 if __name__ == "__main__":

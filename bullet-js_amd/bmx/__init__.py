@@ -24,7 +24,7 @@ EXPORTS = [
     "bmx_create", "bmx_destroy", "bmx_last_error", "bmx_abi_version", "bmx_get_info", "bmx_sync", "bmx_set_stream", "bmx_get_stream",
     "bmx_load_rows", "bmx_merge_batch", "bmx_merge_records", "bmx_get_rows", "bmx_get_row", "bmx_dump_rows", "bmx_row_count",
     "bmx_index_build", "bmx_index_drop", "bmx_index_size", "bmx_scan_range", "bmx_scan_equals", "bmx_scan_count", "bmx_scan_filter",
-    "bmx_owner_of", "bmx_partition_by_owner", "bmx_timer_start", "bmx_timer_stop", "bmx_profile_enable", "bmx_profile_read",
+    "bmx_owner_of", "bmx_partition_by_owner", "bmx_partition_by_owner_slabs", "bmx_timer_start", "bmx_timer_stop", "bmx_profile_enable", "bmx_profile_read",
 ]
 
 
@@ -85,6 +85,7 @@ def load_library():
     L.bmx_scan_filter.argtypes = [vp, u32, C.POINTER(Term), vp, u64, vp, i32]; L.bmx_scan_filter.restype = i32
     L.bmx_owner_of.argtypes = [u64, u32]; L.bmx_owner_of.restype = u32
     L.bmx_partition_by_owner.argtypes = [vp, u64, vp, vp, vp, vp, u32, vp, vp]; L.bmx_partition_by_owner.restype = i32
+    L.bmx_partition_by_owner_slabs.argtypes = [vp, u64, vp, vp, vp, vp, u32, u64, vp, vp]; L.bmx_partition_by_owner_slabs.restype = i32
     L.bmx_timer_start.argtypes = [vp]; L.bmx_timer_start.restype = i32
     L.bmx_timer_stop.argtypes = [vp, C.POINTER(C.c_float)]; L.bmx_timer_stop.restype = i32
     L.bmx_profile_enable.argtypes = [vp, i32]; L.bmx_profile_enable.restype = i32
@@ -243,6 +244,10 @@ class Engine:
 
     def partition_by_owner_dev(self, n, id, field, ts, val, nshards, recs_out, counts_out):
         self._chk(self.L.bmx_partition_by_owner(self.h, int(n), _ptr(id), _ptr(field), _ptr(ts), _ptr(val), int(nshards), _ptr(recs_out), _ptr(counts_out)))
+
+    def partition_by_owner_slabs_dev(self, n, id, field, ts, val, nshards, slab_records, recs_out, counts_out):
+        self._chk(self.L.bmx_partition_by_owner_slabs(self.h, int(n), _ptr(id), _ptr(field), _ptr(ts), _ptr(val), int(nshards), int(slab_records),
+                                                      _ptr(recs_out), _ptr(counts_out)))
 
     def scan_range_dev(self, field, lo, hi, out_ids, cap, n_out):
         self._chk(self.L.bmx_scan_range(self.h, int(field), int(lo), int(hi), _ptr(out_ids), int(cap), _ptr(n_out), MEM_DEVICE))

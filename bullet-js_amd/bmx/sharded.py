@@ -10,9 +10,18 @@ Order: a shard receives the runs of rank 0, 1, ..., N-1 concatenated, each run i
 the global batch order (rank-major, then index) restricted to the shard is preserved and the sequential
 semantics of the merge (smallest index wins ties / creates absent rows) stay well defined.
 
+Two ways to run a step:
+  merge_step()        exact split sizes: the counts go through the host (two small syncs per step). Always safe.
+  route() + merge()   pipelined: fixed-size slabs padded with reserved-id records (skipped by the merge), equal
+                      splits, no host round trip; partition + all-to-all of batch b+1 run on a second stream while
+                      batch b merges, so the exchange leaves the critical path. A slab overflow (one
+                      shard receiving > slab records from one origin) is reported by overflowed(); the caller then
+                      re-sends that batch with merge_step() — merging is idempotent.
+
 `ops` hides where the bytes live: EngineOps = the HIP engine + torch CUDA tensors (product);
 tests inject a CPU implementation to exercise the routing with the gloo backend.
 """
+import contextlib
 import numpy as np
 import torch
 
@@ -21,13 +30,23 @@ from . import synth
 
 
 class EngineOps:
-    """GPU side: bmx.Engine does the work; torch only owns buffers and the stream shared with RCCL."""
+    """GPU side: bmx.Engine does the work; torch only owns buffers, streams and events shared with RCCL."""
 
     def __init__(self, engine, device):
         self.e = engine
         self.device = device
-        # same stream as torch's collectives: partition -> all_to_all -> merge are ordered without extra events
-        engine.set_stream(torch.cuda.current_stream(device).cuda_stream)
+        # merge stream = torch's current stream: all_to_all -> merge are ordered without extra events in merge_step()
+        self.main = torch.cuda.current_stream(device)
+        engine.set_stream(self.main.cuda_stream)
+        self.comm = None
+        self.pe = None
+
+    def _pipeline(self):
+        if self.comm is None:
+            from . import Engine
+            self.comm = torch.cuda.Stream(device=self.device)
+            self.pe = Engine(capacity_rows=1024, device=self.device.index or 0)   # owns only the partition scratch
+            self.pe.set_stream(self.comm.cuda_stream)
 
     def empty_records(self, n):
         return torch.empty((max(int(n), 1), 4), dtype=torch.int64, device=self.device)
@@ -35,8 +54,15 @@ class EngineOps:
     def zeros_i64(self, n):
         return torch.zeros(int(n), dtype=torch.int64, device=self.device)
 
+    def zeros_i32(self, n):
+        return torch.zeros(int(n), dtype=torch.int32, device=self.device)
+
     def partition(self, n, id, field, ts, val, nshards, recs_out, counts_out):
         self.e.partition_by_owner_dev(n, id, field, ts, val, nshards, recs_out, counts_out)
+
+    def partition_slabs(self, n, id, field, ts, val, nshards, slab, recs_out, counts_out):
+        self._pipeline()
+        self.pe.partition_by_owner_slabs_dev(n, id, field, ts, val, nshards, slab, recs_out, counts_out)
 
     def merge_records(self, n, recs, insert_mode, applied, n_applied):
         self.e.merge_records_dev(n, recs, insert_mode, applied=applied, n_applied=n_applied)
@@ -46,6 +72,27 @@ class EngineOps:
 
     def sync(self):
         self.e.sync()
+        if self.comm is not None:
+            self.comm.synchronize()
+
+    # stream plumbing for the pipelined mode
+    def comm_ctx(self):
+        self._pipeline()
+        return torch.cuda.stream(self.comm)
+
+    def new_event(self):
+        return torch.cuda.Event()
+
+    def record(self, ev, on_comm):
+        ev.record(self.comm if on_comm else self.main)
+
+    def wait(self, ev, on_comm):
+        (self.comm if on_comm else self.main).wait_event(ev)
+
+    def close(self):
+        if self.pe is not None:
+            self.pe.close()
+            self.pe = None
 
 
 class ShardedGraph:
@@ -107,6 +154,50 @@ class ShardedGraph:
         self.sent_remote += n - send[self.rank]
         self.received += nrecv
         return nrecv
+
+    # ---- pipelined mode ----------------------------------------------------------------------
+    def setup_pipeline(self, max_deltas, slack=1.03, depth=2):
+        """Allocate `depth` send/receive slab sets for batches of up to max_deltas deltas per rank."""
+        W = self.world
+        self.slab = int(max_deltas / W * slack) + 64
+        self._pipe = []
+        for _ in range(depth):
+            self._pipe.append(dict(send=self.ops.empty_records(W * self.slab), recv=self.ops.empty_records(W * self.slab),
+                                   counts=self.ops.zeros_i64(W), applied=self.ops.zeros_i32(W * self.slab), n_applied=self.ops.zeros_i64(1),
+                                   ready=self.ops.new_event(), free=self.ops.new_event(), used=False))
+        self._routed = 0
+        self._merged = 0
+
+    def route(self, n, id, field, ts, val):
+        """Enqueue partition + all-to-all of one batch on the communication stream; returns a ticket for merge()."""
+        p = self._pipe[self._routed % len(self._pipe)]
+        self._routed += 1
+        with self.ops.comm_ctx():
+            if p["used"]:
+                self.ops.wait(p["free"], on_comm=True)        # the merge that last read these slabs is done
+            self.ops.partition_slabs(n, id, field, ts, val, self.world, self.slab, p["send"], p["counts"])
+            self.dist.all_to_all_single(p["recv"], p["send"])  # equal splits: world slabs of `slab` records
+            self.ops.record(p["ready"], on_comm=True)
+        p["used"] = True
+        self.sent_remote += n - n // self.world
+        return p
+
+    def merge(self, ticket):
+        """Merge a routed batch on the merge stream (waits for its exchange on the device, not on the host)."""
+        p = ticket
+        self.ops.wait(p["ready"], on_comm=False)
+        nrecv = self.world * self.slab                         # padding records are skipped by the kernel
+        self.ops.merge_records(nrecv, p["recv"], self.insert_mode, p["applied"], p["n_applied"])
+        self.ops.record(p["free"], on_comm=False)
+        self._merged += 1
+        self.n_steps += 1
+        self.received += nrecv
+        return p
+
+    def overflowed(self):
+        """True if any slab of any in-flight buffer was too small for what its origin had to send (host sync)."""
+        self.ops.sync()
+        return any(int(p["counts"].max().item()) > self.slab for p in self._pipe if p["used"])
 
     def last_applied(self):
         """(indices into the received batch, received records) of the last step's winners."""

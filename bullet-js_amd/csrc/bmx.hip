@@ -463,7 +463,7 @@ int bmx_sync(bmx_ctx* ctx) {
 
 int bmx_set_stream(bmx_ctx* ctx, void* s) {
   if (!ctx) return fail(nullptr, BMX_ERR_INVALID, "null context");
-  HIPCHK(hipStreamSynchronize(ctx->stream));
+  HIPCHK(hipStreamSynchronize(ctx->stream));   // work already enqueued on the old stream finishes first
   ctx->stream = s ? reinterpret_cast<hipStream_t>(s) : ctx->own_stream;
   return BMX_OK;
 }
@@ -665,10 +665,11 @@ int bmx_scan_filter(bmx_ctx* ctx, uint32_t nterms, const bmx_term* terms, uint64
   return run_scan(ctx, P, ix, out_ids, cap, n_out, mem);
 }
 
-int bmx_partition_by_owner(bmx_ctx* ctx, uint64_t n, const uint64_t* id, const uint32_t* field, const int64_t* ts, const int64_t* val,
-                           uint32_t nshards, bmx_delta_rec* recs_out, uint64_t* counts_out_dev) {
+static int partition_impl(bmx_ctx* ctx, uint64_t n, const uint64_t* id, const uint32_t* field, const int64_t* ts, const int64_t* val,
+                          uint32_t nshards, uint64_t slab, bmx_delta_rec* recs_out, uint64_t* counts_out_dev) {
   if (!ctx) return fail(nullptr, BMX_ERR_INVALID, "null context");
-  if (nshards == 0 || nshards > PART_MAX_SHARDS || n > 0xFFFFFFFFull || !counts_out_dev) return fail(ctx, BMX_ERR_INVALID, "bad arguments (1..16 shards)");
+  if (nshards == 0 || nshards > PART_MAX_SHARDS || n > 0xFFFFFFFFull || !counts_out_dev || slab * nshards > 0xFFFFFFFFull)
+    return fail(ctx, BMX_ERR_INVALID, "bad arguments (1..16 shards)");
   if (n && (!id || !field || !ts || !val || !recs_out)) return fail(ctx, BMX_ERR_INVALID, "null pointer");
   HIPCHK(hipSetDevice(ctx->device));
   uint32_t per_block = (uint32_t)((n + PART_BLOCKS - 1) / PART_BLOCKS);
@@ -676,9 +677,20 @@ int bmx_partition_by_owner(bmx_ctx* ctx, uint64_t n, const uint64_t* id, const u
   hipLaunchKernelGGL(k_part_count, dim3(PART_BLOCKS), dim3(256), 0, ctx->stream, id, (uint32_t)n, nshards, per_block, ctx->part_counts);
   LAUNCHCHK("k_part_count");
   hipLaunchKernelGGL(k_part_scatter, dim3(PART_BLOCKS), dim3(256), 0, ctx->stream, id, field, ts, val, (uint32_t)n, nshards, per_block, ctx->part_counts,
-                     recs_out, reinterpret_cast<unsigned long long*>(counts_out_dev));
+                     recs_out, reinterpret_cast<unsigned long long*>(counts_out_dev), (uint32_t)slab);
   LAUNCHCHK("k_part_scatter");
   return BMX_OK;
+}
+
+int bmx_partition_by_owner(bmx_ctx* ctx, uint64_t n, const uint64_t* id, const uint32_t* field, const int64_t* ts, const int64_t* val,
+                           uint32_t nshards, bmx_delta_rec* recs_out, uint64_t* counts_out_dev) {
+  return partition_impl(ctx, n, id, field, ts, val, nshards, 0, recs_out, counts_out_dev);
+}
+
+int bmx_partition_by_owner_slabs(bmx_ctx* ctx, uint64_t n, const uint64_t* id, const uint32_t* field, const int64_t* ts, const int64_t* val,
+                                 uint32_t nshards, uint64_t slab_records, bmx_delta_rec* recs_out, uint64_t* counts_out_dev) {
+  if (slab_records == 0) return fail(ctx, BMX_ERR_INVALID, "slab_records must be > 0");
+  return partition_impl(ctx, n, id, field, ts, val, nshards, slab_records, recs_out, counts_out_dev);
 }
 
 int bmx_timer_start(bmx_ctx* ctx) {

@@ -316,39 +316,67 @@ __global__ __launch_bounds__(256) void k_get_rows(const Slot* slots, uint64_t ns
   ts[j] = t; val[j] = v; found[j] = f;
 }
 
-// K7: stable partition of a delta batch by owner shard into 32-byte records.
+// K7: stable partition of a delta batch by owner shard into 32-byte records (two launches: count, scatter).
+// Counting and ranking are wave-ballot based (one __ballot per shard per 64 deltas): no LDS or global atomics.
 constexpr int PART_MAX_SHARDS = 16;
-constexpr int PART_BLOCKS = 256;
+constexpr int PART_BLOCKS = 1024;
 
 __device__ __forceinline__ uint32_t owner_of_dev(uint64_t id, uint32_t nshards) { return (uint32_t)__umul64hi(owner_hash(id), (uint64_t)nshards); }
 
 __global__ __launch_bounds__(256) void k_part_count(const uint64_t* id, uint32_t n, uint32_t nshards, uint32_t per_block,
                                                     uint32_t* counts /*[nshards][PART_BLOCKS]*/) {
-  __shared__ uint32_t hist[PART_MAX_SHARDS];
-  if (threadIdx.x < PART_MAX_SHARDS) hist[threadIdx.x] = 0;
-  __syncthreads();
+  __shared__ uint32_t wtot[4][PART_MAX_SHARDS];
+  const uint32_t lane = threadIdx.x & 63, w = threadIdx.x >> 6;
   uint32_t lo = blockIdx.x * per_block, hi = min(n, lo + per_block);
-  for (uint32_t j = lo + threadIdx.x; j < hi; j += 256) atomicAdd(&hist[owner_of_dev(id[j], nshards)], 1u);
+  uint32_t mine = 0;  // lane g (< nshards) of each wave accumulates shard g's count
+  for (uint32_t t0 = lo; t0 < hi; t0 += 256) {
+    uint32_t j = t0 + threadIdx.x;
+    uint32_t g = j < hi ? owner_of_dev(id[j], nshards) : 0xFFFFFFFFu;
+    for (uint32_t gg = 0; gg < nshards; gg++) {
+      uint32_t c = (uint32_t)__popcll(__ballot(g == gg));
+      if (lane == gg) mine += c;
+    }
+  }
+  if (lane < PART_MAX_SHARDS) wtot[w][lane] = mine;
   __syncthreads();
-  if (threadIdx.x < nshards) counts[threadIdx.x * PART_BLOCKS + blockIdx.x] = hist[threadIdx.x];
+  if (threadIdx.x < nshards) counts[threadIdx.x * PART_BLOCKS + blockIdx.x] = wtot[0][threadIdx.x] + wtot[1][threadIdx.x] + wtot[2][threadIdx.x] + wtot[3][threadIdx.x];
 }
 
 __global__ __launch_bounds__(256) void k_part_scatter(const uint64_t* id, const uint32_t* field, const int64_t* ts, const int64_t* val,
                                                       uint32_t n, uint32_t nshards, uint32_t per_block, const uint32_t* counts,
-                                                      bmx_delta_rec* out, unsigned long long* totals) {
+                                                      bmx_delta_rec* out, unsigned long long* totals, uint32_t slab) {
   __shared__ uint32_t base[PART_MAX_SHARDS];   // running output cursor of this block per shard
+  __shared__ uint32_t tot[PART_MAX_SHARDS];    // shard totals over the whole batch
   __shared__ uint32_t wcnt[4][PART_MAX_SHARDS];
-  // cursor[g] = sum of all counts of shards < g + counts of shard g in blocks < this one
-  if (threadIdx.x < nshards) {
-    uint32_t g = threadIdx.x, acc = 0;
-    for (uint32_t gg = 0; gg < g; gg++) for (uint32_t b = 0; b < PART_BLOCKS; b++) acc += counts[gg * PART_BLOCKS + b];
-    uint32_t tot = 0;
-    for (uint32_t b = 0; b < PART_BLOCKS; b++) { uint32_t c = counts[g * PART_BLOCKS + b]; if (b < blockIdx.x) acc += c; tot += c; }
-    base[g] = acc;
-    if (blockIdx.x == 0) totals[g] = tot;
+  __shared__ uint32_t red[PART_MAX_SHARDS][4][2];
+  const uint32_t lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  // per shard g: before = sum of counts[g][b] for b < this block, total = sum over all blocks (coalesced reads, wave reduce)
+  for (uint32_t g = 0; g < nshards; g++) {
+    uint32_t before = 0, all = 0;
+    for (uint32_t b = threadIdx.x; b < PART_BLOCKS; b += 256) {
+      uint32_t c = counts[g * PART_BLOCKS + b];
+      all += c;
+      if (b < blockIdx.x) before += c;
+    }
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) { before += __shfl_xor(before, d); all += __shfl_xor(all, d); }
+    if (lane == 0) { red[g][w][0] = before; red[g][w][1] = all; }
   }
   __syncthreads();
-  const uint32_t lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  if (threadIdx.x < nshards) {
+    uint32_t g = threadIdx.x;
+    uint32_t all = red[g][0][1] + red[g][1][1] + red[g][2][1] + red[g][3][1];
+    tot[g] = all;
+    if (blockIdx.x == 0) totals[g] = all;
+  }
+  __syncthreads();
+  if (threadIdx.x < nshards) {
+    uint32_t g = threadIdx.x, start = 0;
+    if (slab) start = g * slab;                              // fixed-size slabs: shard g starts at g*slab
+    else for (uint32_t gg = 0; gg < g; gg++) start += tot[gg];
+    base[g] = start + red[g][0][0] + red[g][1][0] + red[g][2][0] + red[g][3][0];
+  }
+  __syncthreads();
   uint32_t lo = blockIdx.x * per_block, hi = min(n, lo + per_block);
   for (uint32_t t0 = lo; t0 < hi; t0 += 256) {
     uint32_t j = t0 + threadIdx.x;
@@ -357,7 +385,7 @@ __global__ __launch_bounds__(256) void k_part_scatter(const uint64_t* id, const 
     if (act) { kid = id[j]; g = owner_of_dev(kid, nshards); }
     uint32_t rank_in_wave = 0;
     for (uint32_t gg = 0; gg < nshards; gg++) {
-      unsigned long long m = __ballot(act && g == gg);
+      unsigned long long m = __ballot(g == gg);
       if (g == gg) rank_in_wave = (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
       if (lane == 0) wcnt[w][gg] = (uint32_t)__popcll(m);
     }
@@ -365,14 +393,27 @@ __global__ __launch_bounds__(256) void k_part_scatter(const uint64_t* id, const 
     if (act) {
       uint32_t pos = base[g] + rank_in_wave;
       for (uint32_t ww = 0; ww < w; ww++) pos += wcnt[ww][g];
-      uint4* q = reinterpret_cast<uint4*>(out + pos);
-      uint64_t t = (uint64_t)ts[j], v = (uint64_t)val[j];
-      q[0] = make_uint4((uint32_t)kid, (uint32_t)(kid >> 32), field[j], j);
-      q[1] = make_uint4((uint32_t)t, (uint32_t)(t >> 32), (uint32_t)v, (uint32_t)(v >> 32));
+      if (!slab || pos - g * slab < slab) {  // a slab overflow drops the record; totals[] tells the caller
+        uint4* q = reinterpret_cast<uint4*>(out + pos);
+        uint64_t t = (uint64_t)ts[j], v = (uint64_t)val[j];
+        q[0] = make_uint4((uint32_t)kid, (uint32_t)(kid >> 32), field[j], j);
+        q[1] = make_uint4((uint32_t)t, (uint32_t)(t >> 32), (uint32_t)v, (uint32_t)(v >> 32));
+      }
     }
     __syncthreads();
     if (threadIdx.x < nshards) { uint32_t g2 = threadIdx.x; base[g2] += wcnt[0][g2] + wcnt[1][g2] + wcnt[2][g2] + wcnt[3][g2]; }
     __syncthreads();
+  }
+  // fixed-size slabs: the unused tail of every slab becomes padding (reserved id), striped over all blocks
+  if (slab) {
+    const uint4 padlo = make_uint4(0xFFFFFFFFu, 0xFFFFFFFFu, FIELD_PENDING, 0u), padhi = make_uint4(0u, 0u, 0u, 0u);
+    for (uint32_t g = 0; g < nshards; g++) {
+      uint32_t used = min(tot[g], slab);
+      for (uint32_t p = used + blockIdx.x * 256u + threadIdx.x; p < slab; p += PART_BLOCKS * 256u) {
+        uint4* q = reinterpret_cast<uint4*>(out + (size_t)g * slab + p);
+        q[0] = padlo; q[1] = padhi;
+      }
+    }
   }
 }
 

@@ -175,6 +175,14 @@ int bmx_scan_filter(bmx_ctx* ctx, uint32_t nterms, const bmx_term* terms, uint64
 uint32_t bmx_owner_of(uint64_t id, uint32_t nshards);
 int bmx_partition_by_owner(bmx_ctx* ctx, uint64_t n, const uint64_t* id, const uint32_t* field, const int64_t* ts,
                            const int64_t* val, uint32_t nshards, bmx_delta_rec* recs_out, uint64_t* counts_out_dev);
+/* Same, into fixed-size slabs: shard g's records go to recs_out[g*slab_records ...] and the rest of each slab
+ * is padding (id = 0xFFFFFFFFFFFFFFFF, skipped by bmx_merge_records), so the exchange can use equal splits and
+ * needs no host round trip for counts. recs_out has nshards*slab_records records. counts_out_dev[g] is the TRUE
+ * count: if it exceeds slab_records the surplus records of that shard were NOT written and the caller must
+ * re-route the batch with bmx_partition_by_owner (merging is idempotent, so re-sending is safe). */
+int bmx_partition_by_owner_slabs(bmx_ctx* ctx, uint64_t n, const uint64_t* id, const uint32_t* field, const int64_t* ts,
+                                 const int64_t* val, uint32_t nshards, uint64_t slab_records, bmx_delta_rec* recs_out,
+                                 uint64_t* counts_out_dev);
 
 /* ---- timing helpers (HIP events on the context's stream; used by bench.py) ------------------- */
 int bmx_timer_start(bmx_ctx* ctx);

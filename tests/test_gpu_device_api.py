@@ -119,3 +119,53 @@ def test_profile_hooks_report_three_stages():
         ms, n = e.profile_read()
         assert n == 3 and all(v > 0 for v in ms.values())
         e.profile_enable(False)
+
+
+def test_sharded_step_over_rccl_world1():
+    """The product's sharded step (K7 partition -> all_to_all over RCCL -> merge_records) with a one-rank group:
+    every code path of the N>1 bench except the cross-GPU links. Must equal the plain merge."""
+    import os
+    import torch.distributed as dist
+    from bmx.sharded import ShardedGraph, EngineOps
+    dev = torch.device("cuda", 0)
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1"); os.environ.setdefault("MASTER_PORT", "29533")
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+    try:
+        R, D = 200_000, 60_000
+        o = Oracle(); o.load_rows(*synth.big_resident(R, seed=1, T0=1000, DT=1000))
+        with bmx.Engine(2 * (R + 3 * D)) as e:
+            sg = ShardedGraph(EngineOps(e, dev), dist, 0, 1)
+            assert sg.load_owned_resident(R, T0=1000, DT=1000) == R
+            for b in range(3):
+                d = synth.big_deltas(D, R, seed=71, T0=1000, DT=1000, insert_pct=10, hot_pct=20, hot_keys=100, unique=False, batch=b)
+                assert sg.merge_step(D, *_dev(d, dev)) == D
+                applied, recv = sg.last_applied()
+                _, ow = o.merge_batch(*d)
+                # records keep their origin index in `aux`; with one shard the partition is the identity
+                assert np.array_equal(applied.cpu().numpy().view(np.uint32), ow)
+            assert rows_digest(*e.dump_rows()) == o.digest()
+            # pipelined mode: slabs + second stream, two batches in flight
+            sg.setup_pipeline(D, slack=1.05)
+            ds = [synth.big_deltas(D, R, seed=72, T0=1000, DT=1000, insert_pct=10, hot_pct=20, hot_keys=100, unique=False, batch=b) for b in range(4)]
+            dd = [_dev(d, dev) for d in ds]
+            tk = sg.route(D, *dd[0])
+            outs = []
+            for b in range(4):
+                nxt = sg.route(D, *dd[b + 1]) if b + 1 < 4 else None
+                p = sg.merge(tk)
+                sg.ops.sync()
+                na = int(p["n_applied"].item())
+                outs.append(p["applied"][:na].cpu().numpy().view(np.uint32).copy())
+                tk = nxt
+            assert not sg.overflowed()
+            for b in range(4):
+                _, ow = o.merge_batch(*ds[b])
+                assert np.array_equal(outs[b], ow), b     # one shard: slab 0 holds the batch in order, indices match
+            assert rows_digest(*e.dump_rows()) == o.digest()
+            sg.setup_pipeline(D, slack=0.5)               # too small on purpose: overflow must be reported
+            sg.merge(sg.route(D, *dd[0]))
+            assert sg.overflowed()
+            sg.ops.close()
+            e.set_stream(None)
+    finally:
+        dist.destroy_process_group()

@@ -40,9 +40,36 @@ class OracleOps:
         recs_out[:n] = torch.from_numpy(r.view(np.int64).reshape(n, 4))
         counts_out[:] = torch.from_numpy(np.bincount(own, minlength=nshards).astype(np.int64))
 
+    def zeros_i32(self, n):
+        return torch.zeros(int(n), dtype=torch.int32)
+
+    def partition_slabs(self, n, id, field, ts, val, nshards, slab, recs_out, counts_out):
+        tmp = torch.empty((n, 4), dtype=torch.int64)
+        self.partition(n, id, field, ts, val, nshards, tmp, counts_out)
+        recs_out.view(torch.uint8).fill_(0xFF)
+        off = 0
+        for g, c in enumerate(counts_out.tolist()):
+            k = min(c, slab)
+            recs_out[g * slab:g * slab + k] = tmp[off:off + k]
+            off += c
+
+    def comm_ctx(self):
+        import contextlib
+        return contextlib.nullcontext()
+
+    def new_event(self):
+        return None
+
+    def record(self, ev, on_comm):
+        pass
+
+    def wait(self, ev, on_comm):
+        pass
+
     def merge_records(self, n, recs, insert_mode, applied, n_applied):
         import bmx
         r = recs[:n].numpy().view(bmx.DELTA_REC_DTYPE).reshape(-1)
+        r = r[r["id"] != np.uint64(2**64 - 1)]            # padding records are skipped, as k_probe_apply does
         _, w = self.o.merge_batch(r["id"], r["field"], r["ts"], r["val"], insert_mode)
         applied[:len(w)] = torch.from_numpy(w.astype(np.int32))
         n_applied[0] = len(w)
@@ -54,7 +81,7 @@ class OracleOps:
         pass
 
 
-def _worker(rank, world, port, tmp):
+def _worker(rank, world, port, tmp, pipelined=False):
     sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "bullet-js_amd"))
     os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
@@ -68,9 +95,16 @@ def _worker(rank, world, port, tmp):
     for b in range(3):
         d = synth.big_deltas(3000, R, seed=5 + 100 * rank, T0=1000, DT=1000, insert_pct=15, hot_pct=30, hot_keys=40, unique=False, batch=b)
         t = [torch.from_numpy(np.ascontiguousarray(x).view(np.int64 if x.dtype.itemsize == 8 else np.int32)) for x in d]
-        sg.merge_step(3000, *t)
-        applied, recv = sg.last_applied()
-        digests.append(len(applied))
+        if pipelined:
+            if b == 0:
+                sg.setup_pipeline(3000, slack=1.2)
+            p = sg.merge(sg.route(3000, *t))
+            assert not sg.overflowed()
+            digests.append(int(p["n_applied"][0]))
+        else:
+            sg.merge_step(3000, *t)
+            applied, recv = sg.last_applied()
+            digests.append(len(applied))
     id, f, ts, val = ops.o.dump_rows()
     np.savez(os.path.join(tmp, "rank%d.npz" % rank), id=id, f=f, ts=ts, val=val, nloaded=nloaded, winners=np.array(digests),
              sent=sg.sent_remote, recv=sg.received)
@@ -83,9 +117,10 @@ def _free_port():
     return p
 
 
-def test_two_rank_routing_equals_single_merge(tmp_path):
+@pytest.mark.parametrize("pipelined", [False, True])
+def test_two_rank_routing_equals_single_merge(tmp_path, pipelined):
     world = 2
-    mp.spawn(_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    mp.spawn(_worker, args=(world, _free_port(), str(tmp_path), pipelined), nprocs=world, join=True)
     from bmx import synth
     from oracle.oracle import Oracle, rows_digest, owner_of
     R = 20000
