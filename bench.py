@@ -69,6 +69,34 @@ def cpu_baseline(n_batches=3):
             "sample": "%d x 1M-delta batches against the 10M-row resident graph (load excluded), oracle/bmx_oracle.c, 1 thread" % n_batches}
 
 
+def scan_bench(bmx, dev, R=10_000_000, reps=20):
+    """Config 3 (extra fields, not the headline): range/equals scans over an indexed int32 field of R nodes.
+    Algorithmic bytes = 4*R (value column) + 8*M (ids out); time = HIP events around `reps` back-to-back scans."""
+    from bmx import synth
+    ids = synth.splitmix64_np(np.arange(1, R + 1, dtype=np.uint64))
+    with np.errstate(over="ignore"):
+        ages = (synth.splitmix64_np(ids ^ np.uint64(0xABCDEF)) % np.uint64(1000)).astype(np.int64)
+    fa = synth.fnv1a32("n:age")
+    out = {}
+    with bmx.Engine(capacity_rows=R + 1024, device=dev.index or 0) as e:
+        e.load_rows(ids, np.full(R, fa, np.uint32), np.full(R, 5, np.int64), ages)
+        t0 = time.perf_counter(); e.index_build(fa); out["index_build_ms"] = round((time.perf_counter() - t0) * 1e3, 3)
+        out_ids = torch.zeros(R, dtype=torch.int64, device=dev)
+        n_out = torch.zeros(1, dtype=torch.int64, device=dev)
+        for name, lo, hi in [("equals_0.1pct", 42, 42), ("range_1pct", 100, 109), ("range_10pct", 100, 199), ("range_50pct", 0, 499)]:
+            for _ in range(3):
+                e.scan_range_dev(fa, lo, hi, out_ids, R, n_out)
+            e.sync(); e.timer_start()
+            for _ in range(reps):
+                e.scan_range_dev(fa, lo, hi, out_ids, R, n_out)
+            ms = e.timer_stop() / reps
+            m = int(n_out.item())
+            alg = 4.0 * R + 8.0 * m
+            out[name] = {"matches": m, "us": round(ms * 1e3, 2), "achieved_GBs": round(alg / (ms * 1e-3) / 1e9, 1), "frac_of_8TBs": round(alg / (ms * 1e-3) / 8e12, 4),
+                         "rows_per_s": round(R / (ms * 1e-3))}
+    return out
+
+
 def main():
     # stdout carries exactly ONE JSON line: native libraries (RCCL's version banner) print to fd 1, so fd 1 is pointed
     # at stderr for the whole run and the JSON goes to a private duplicate of the real stdout.
@@ -80,6 +108,7 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--scan", action="store_true", help="also measure the config-3 index scans (extra fields)")
     ap.add_argument("--force-sharded", action="store_true", help="run the N>1 code path (partition + all-to-all + merge) even with one rank: rehearsal only")
     args = ap.parse_args()
 
@@ -205,6 +234,8 @@ def main():
                "ms_per_step": elapsed / K * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "int64",
                "data": "synthetic", "config": cfg, "roofline": roofline}
         out.update(extra)
+        if not sharded and args.scan:
+            out["scan_config3"] = scan_bench(bmx, dev)
         if not sharded and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline()
         else:
@@ -212,6 +243,7 @@ def main():
     if sharded:
         sg.ops.close()
     eng.close()
+    eng = None
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()

@@ -163,7 +163,7 @@ int ensure_staging(bmx_ctx* ctx, uint64_t n) {
 
 // Sequence number for the next k_select call; granules are re-zeroed when it wraps.
 int next_seq(bmx_ctx* ctx, uint32_t* seq) {
-  if (++ctx->sel_seq == 0) {
+  if (++ctx->sel_seq >= (1u << 30)) {
     HIPCHK(hipMemsetAsync(ctx->granules, 0, SEL_MAX_BLOCKS * sizeof(unsigned long long), ctx->stream));
     ctx->sel_seq = 1;
   }
@@ -231,8 +231,12 @@ int merge_core(bmx_ctx* ctx, uint64_t n, const uint64_t* id, const uint32_t* fie
   SelGeom g = sel_geom<PredWinner::E>(n);
   uint32_t seq;
   if ((rc = next_seq(ctx, &seq))) return rc;
-  hipLaunchKernelGGL((k_select<PredWinner, EmitApplied, FinishMerge>), dim3(g.blocks), dim3(SEL_THREADS), 0, ctx->stream, P, Em, Fin, n,
-                     g.tiles_per_block, ctx->granules, seq, &ctx->ds->status);
+  if (g.tiles_per_block <= (uint32_t)SEL_STAGE)
+    hipLaunchKernelGGL((k_select_staged<PredWinner, EmitApplied, FinishMerge>), dim3(g.blocks), dim3(SEL_THREADS), 0, ctx->stream, P, Em, Fin, n,
+                       g.tiles_per_block, ctx->granules, seq, &ctx->ds->status);
+  else
+    hipLaunchKernelGGL((k_select<PredWinner, EmitApplied, FinishMerge>), dim3(g.blocks), dim3(SEL_THREADS), 0, ctx->stream, P, Em, Fin, n,
+                       g.tiles_per_block, ctx->granules, seq, &ctx->ds->status);
   LAUNCHCHK("k_select");
   if (pe) { HIPCHK(hipEventRecord(pe[3], ctx->stream)); ctx->prof_n++; }
   ctx->rows_ub += n;
@@ -354,8 +358,12 @@ int run_scan(bmx_ctx* ctx, const Pred& P, const Index* ix, uint64_t* out_ids, ui
     uint32_t seq;
     int rc = next_seq(ctx, &seq);
     if (rc) return rc;
-    hipLaunchKernelGGL((k_select<Pred, EmitIds, FinishCount>), dim3(g.blocks), dim3(SEL_THREADS), 0, ctx->stream, P, Em, Fin, ix->n, g.tiles_per_block,
-                       ctx->granules, seq, &ctx->ds->status);
+    if (g.tiles_per_block <= (uint32_t)SEL_STAGE)
+      hipLaunchKernelGGL((k_select_staged<Pred, EmitIds, FinishCount>), dim3(g.blocks), dim3(SEL_THREADS), 0, ctx->stream, P, Em, Fin, ix->n,
+                         g.tiles_per_block, ctx->granules, seq, &ctx->ds->status);
+    else
+      hipLaunchKernelGGL((k_select<Pred, EmitIds, FinishCount>), dim3(g.blocks), dim3(SEL_THREADS), 0, ctx->stream, P, Em, Fin, ix->n,
+                         g.tiles_per_block, ctx->granules, seq, &ctx->ds->status);
     LAUNCHCHK("k_select(scan)");
   } else if (d_n) {
     hipLaunchKernelGGL((k_sel_count<Pred>), dim3(g.blocks), dim3(SEL_THREADS), 0, ctx->stream, P, ix->n, g.tiles_per_block, ctx->block_counts);

@@ -8,8 +8,8 @@
 //   k_probe_apply    one lane per delta: probe the row's slot (ONE 128-B line), decide against the
 //                    snapshot it saw, claim the row with ONE atomicExch on slot.head, and — if it is the
 //                    first claimer of the batch — store (ts,val) right away (one aligned 16-B store).
-//                    An absent key is created with a CAS on slot.id plus one 64-bit exchange that publishes
-//                    the field and claims the head together.
+//                    An absent key is created with a CAS on slot.id plus one 8-byte store that publishes the
+//                    field and claims the head together.
 //                    Later claimers of the same row (duplicate keys) link themselves into a per-row
 //                    list (next[]) and mark themselves pending instead of writing.
 //   k_resolve_lists  pending deltas only (none for unique-key batches without inserts): the LAST claimer of
@@ -98,14 +98,13 @@ __device__ __forceinline__ bool probe_or_insert(const MergeArgs& A, uint32_t tag
     bool fresh = false;
     if (sid == EMPTY_ID) {
       unsigned long long old = atomicCAS(reinterpret_cast<unsigned long long*>(&sl->id), (unsigned long long)EMPTY_ID, (unsigned long long)id);
-      if (old == EMPTY_ID) {  // this lane created the row: ONE 64-bit exchange publishes the field and claims the head
-        if (UNIQUE) {  // nobody else claims this key: publishing the field is enough
-          __hip_atomic_store(&sl->field, field, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-          prev_head = 0;
-        } else {
-          unsigned long long w1 = atomicExch(reinterpret_cast<unsigned long long*>(&sl->field), (unsigned long long)field | ((unsigned long long)tag << 32));
-          prev_head = (uint32_t)(w1 >> 32);
-        }
+      if (old == EMPTY_ID) {  // this lane created the row
+        // ONE aligned 8-byte agent-scope store publishes the field and claims the head together. A store (not an
+        // exchange) is enough: other lanes of this key wait for the field before they touch the head, so nobody
+        // can have claimed it earlier and every later claimer's exchange returns this tag.
+        __hip_atomic_store(reinterpret_cast<unsigned long long*>(&sl->field), (unsigned long long)field | ((unsigned long long)(UNIQUE ? 0u : tag) << 32),
+                           __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        prev_head = 0;
         created = true;
         slot_out = s; is_new = true; cts = TS_NEW; cval = 0;
         return true;
