@@ -74,11 +74,31 @@ class EngineOps:
         self.e.sync()
         if self.comm is not None:
             self.comm.synchronize()
+        self.main.synchronize()
 
-    # stream plumbing for the pipelined mode
-    def comm_ctx(self):
+    # stream plumbing for the pipelined mode: the communication stream becomes torch's CURRENT stream once
+    # (RCCL collectives are enqueued on the current stream), the merge engine keeps its own stream; no per-step
+    # context managers on the host path.
+    def enter_pipeline(self):
         self._pipeline()
-        return torch.cuda.stream(self.comm)
+        if not getattr(self, "_entered", False):
+            self._prev_stream = torch.cuda.current_stream(self.device)
+            self.main = torch.cuda.Stream(device=self.device)
+            self.e.set_stream(self.main.cuda_stream)
+            torch.cuda.set_stream(self.comm)
+            self._entered = True
+
+    def leave_pipeline(self):
+        if getattr(self, "_entered", False):
+            self.sync()
+            torch.cuda.set_stream(self._prev_stream)
+            self.main = self._prev_stream
+            self.e.set_stream(self.main.cuda_stream)
+            self._entered = False
+
+    def comm_ctx(self):
+        self.enter_pipeline()
+        return contextlib.nullcontext()
 
     def new_event(self):
         return torch.cuda.Event()
@@ -90,6 +110,7 @@ class EngineOps:
         (self.comm if on_comm else self.main).wait_event(ev)
 
     def close(self):
+        self.leave_pipeline()
         if self.pe is not None:
             self.pe.close()
             self.pe = None
@@ -172,7 +193,7 @@ class ShardedGraph:
         """Enqueue partition + all-to-all of one batch on the communication stream; returns a ticket for merge()."""
         p = self._pipe[self._routed % len(self._pipe)]
         self._routed += 1
-        with self.ops.comm_ctx():
+        with self.ops.comm_ctx():                             # GPU: a no-op after the first call (streams are set once)
             if p["used"]:
                 self.ops.wait(p["free"], on_comm=True)        # the merge that last read these slabs is done
             self.ops.partition_slabs(n, id, field, ts, val, self.world, self.slab, p["send"], p["counts"])

@@ -244,14 +244,70 @@ class GpuCRT {
       const parent = cut < 0 ? "" : e.path.slice(0, cut);
       const id = g.keys.idOf(e.path);
       for (const [fname, v] of p.fields) {
-        cols.set(i, id, fieldId(parent, fname), p.ts, v);
+        cols.set(i, id, g.keys.fieldOf(parent, fname), p.ts, v);
         back[i] = { entry: ei, field: fname };
         i++;
       }
     });
     const r = this.mergeBatch(cols, opts);
     const applied = Array.from(r.applied, (j) => back[j]);
+    if (opts.apply) this._applyWinners(entries, cols, r.applied, applied);
     return { applied, nApplied: r.nApplied, nConflicts: r.nConflicts, nRows: r.nRows, host };
+  }
+
+  /*
+   * N1 (SURVEY §8(f)): hand the batch's final winners to the facade in ONE pass. Each winning row is the leaf
+   * `<entry.path>[/<field>]`; its stored clock and value are read back from the device (an inserted row's clock is
+   * {writer: 2}, not the incoming one) and applied through the facade's own _applyUpdate (store, meta, op log,
+   * listeners: src/bullet.js:184-266) when it has one.
+   */
+  _applyWinners(entries, cols, appliedIdx, applied) {
+    const n = appliedIdx.length;
+    if (n === 0) return;
+    const ids = new BigUint64Array(n), fields = new Uint32Array(n);
+    for (let k = 0; k < n; k++) { ids[k] = cols.id[appliedIdx[k]]; fields[k] = cols.field[appliedIdx[k]]; }
+    const rows = this.graph.getRows(ids, fields);
+    const writer = this._opts.writer || this.bullet.id;
+    for (let k = 0; k < n; k++) {
+      const a = applied[k];
+      const e = entries[a.entry];
+      const leaf = a.field === null ? e.path : e.path + "/" + a.field;
+      const clock = {};
+      clock[writer] = Number(rows.ts[k]);
+      const value = Number(rows.val[k]);
+      if (typeof this.bullet._applyUpdate === "function") this.bullet._applyUpdate(leaf, value, clock, true);
+      this.vectorClocks.set(leaf, clock);
+    }
+  }
+
+  /*
+   * N3 (SURVEY §8(f)): checkpoint of the device rows in host terms — [{path, collection, field, ts, val}] — and its
+   * inverse. The shape matches what the reference persists per path (value + vectorClock: src/bullet-file-storage.js:170-210).
+   */
+  checkpoint() {
+    const g = this.graph;
+    const d = g.dumpRows();
+    const id32 = new Uint32Array(d.id.buffer, d.id.byteOffset, d.id.length * 2);
+    const out = [];
+    for (let i = 0; i < d.id.length; i++) {
+      const path = g.keys.pathOf(id32[2 * i], id32[2 * i + 1]);
+      const f = g.keys.fields.get(d.field[i]);
+      out.push({ path: path === undefined ? null : path, id: d.id[i].toString(16), fieldHash: d.field[i],
+        collection: f ? f[0] : null, field: f ? f[1] : null, ts: Number(d.ts[i]), val: Number(d.val[i]) });
+    }
+    return out;
+  }
+
+  restore(rows) {
+    const g = this.graph;
+    const cols = new Columns(rows.length);
+    rows.forEach((r, i) => {
+      const id = r.path !== null && r.path !== undefined ? g.keys.idOf(r.path) : [Number(BigInt("0x" + r.id) & 0xffffffffn), Number(BigInt("0x" + r.id) >> 32n)];
+      const f = r.collection !== null && r.collection !== undefined ? g.keys.fieldOf(r.collection, r.field) : r.fieldHash;
+      cols.set(i, id, f, r.ts, r.val);
+    });
+    g.loadRows(cols);
+    return rows.length;
   }
 
   close() {

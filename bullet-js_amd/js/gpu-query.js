@@ -114,7 +114,7 @@ class GpuQuery {
     ix.kind = "device";
     if (ix.deviceField !== undefined) g.indexDrop(ix.deviceField);
     // rows of an older build of this index stay behind under their own field hash and are never scanned again
-    ix.deviceField = fieldId(ix.path + "#" + (++this._gen), ix.field);
+    ix.deviceField = g.keys.fieldOf(ix.path + "#" + (++this._gen), ix.field);
     const n = ix.paths.length;
     const cols = new Columns(n);
     for (let i = 0; i < n; i++) cols.set(i, g.keys.idOf(ix.paths[i]), ix.deviceField, 1, ix.values[i]);

@@ -47,6 +47,18 @@ class KeyDictionary {
   constructor() {
     this.byPath = new Map();   // path -> [lo, hi]
     this.byId = new Map();     // idKey -> path
+    this.fields = new Map();   // field hash -> [collection, field name]
+  }
+  fieldOf(collection, field) {
+    const h = fieldId(collection, field);
+    const known = this.fields.get(h);
+    if (known === undefined) this.fields.set(h, [collection, field === undefined ? null : field]);
+    else if (known[0] !== collection || known[1] !== (field === undefined ? null : field)) {
+      const err = new Error(`bmx: 32-bit field hash collision between '${known[0]}:${known[1]}' and '${collection}:${field}'`);
+      err.code = "BMX_FIELD_COLLISION";
+      throw err;
+    }
+    return h;
   }
   idOf(p) {
     let id = this.byPath.get(p);

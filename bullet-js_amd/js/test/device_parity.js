@@ -119,4 +119,38 @@ for (const name of fs.readdirSync(GOLD).filter((f) => f.startsWith("g2_stream_")
   checks += 3;
 }
 
+/* N1 + N3: winners applied to the store in one pass; checkpoint / restore of the device rows */
+{
+  const b = new MiniBullet("w");
+  const applied = [];
+  b._applyUpdate = (path, value, clock, fromNetwork) => {    // the facade hook the reference exposes (src/bullet.js:184)
+    applied.push([path, value, clock.w, fromNetwork]);
+    const segs = path.split("/"); let node = b.store;
+    for (const s of segs.slice(0, -1)) { if (!node[s]) node[s] = {}; node = node[s]; }
+    node[segs[segs.length - 1]] = value; b.meta[path] = { source: "network", vectorClock: clock };
+  };
+  const { crt } = attach(b, { capacityRows: 4096 });
+  const entries = [
+    { path: "acct/a", data: { bal: 10, seq: 1 }, vectorClock: { w: 100 } },
+    { path: "acct/b", data: { bal: 20 }, vectorClock: { w: 100 } },
+    { path: "acct/a", data: { bal: 15 }, vectorClock: { w: 101 } },
+  ];
+  const r1 = crt.mergeEntries(entries, { apply: true });
+  // reference insert rule: a first write stores clock {w:2}; the later delta (101 > 2) then wins acct/a/bal
+  assert.deepStrictEqual(applied, [["acct/a/seq", 1, 2, true], ["acct/b/bal", 20, 2, true], ["acct/a/bal", 15, 101, true]]);
+  assert.deepStrictEqual(b.store, { acct: { a: { seq: 1, bal: 15 }, b: { bal: 20 } } });
+  assert.strictEqual(r1.nRows, 3);
+  const snap = crt.checkpoint().sort((x, y) => (x.path + x.field < y.path + y.field ? -1 : 1));
+  assert.deepStrictEqual(snap.map((x) => [x.path, x.collection, x.field, x.ts, x.val]),
+    [["acct/a", "acct", "bal", 101, 15], ["acct/a", "acct", "seq", 2, 1], ["acct/b", "acct", "bal", 2, 20]]);
+  b.close();
+  const b2 = new MiniBullet("w");
+  const h2 = attach(b2, { capacityRows: 4096 });
+  assert.strictEqual(h2.crt.restore(snap), 3);
+  const again = h2.crt.mergeEntries([{ path: "acct/a", data: { bal: 1 }, vectorClock: { w: 50 } }, { path: "acct/b", data: { bal: 21 }, vectorClock: { w: 2 } }]);
+  assert.deepStrictEqual(again.applied, [{ entry: 1, field: "bal" }]);      // 50 < 101 loses; (2,21) > (2,20) wins the tie by value
+  b2.close();
+  checks += 6;
+}
+
 console.log("device_parity ok:", checks, "checks");
