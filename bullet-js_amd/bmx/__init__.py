@@ -17,6 +17,7 @@ ERR_INVALID, ERR_HIP, ERR_FULL, ERR_NOMEM, ERR_RANGE, ERR_INTERNAL, ERR_NO_DEVIC
 MEM_HOST, MEM_DEVICE = 0, 1
 INSERT_REFERENCE, INSERT_DELTA = 0, 1
 MERGE_UNIQUE_KEYS = 0x100
+CTX_ASYNC_COMPACT = 1
 FLAG_INCOMING, FLAG_CURRENT, FLAG_HISTORICAL = 1, 2, 4
 MAX_BATCH = 1 << 24
 
@@ -113,10 +114,10 @@ class Engine:
     """One GPU-resident graph shard (a bmx_ctx). Host-array methods are synchronous; *_dev methods take
     device tensors/pointers and only enqueue work on the engine's stream."""
 
-    def __init__(self, capacity_rows, device=0):
+    def __init__(self, capacity_rows, device=0, flags=0):
         self.L = load_library()
         h = C.c_void_p()
-        rc = self.L.bmx_create(int(device), int(capacity_rows), 0, C.byref(h))
+        rc = self.L.bmx_create(int(device), int(capacity_rows), int(flags), C.byref(h))
         if rc != OK:
             raise BmxError(rc, (self.L.bmx_last_error(None) or b"").decode())
         self.h = h

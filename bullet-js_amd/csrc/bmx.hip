@@ -63,6 +63,17 @@ struct bmx_ctx {
   uint32_t* block_counts = nullptr;   // SEL_MAX_BLOCKS
   unsigned long long* granules = nullptr;  // SEL_MAX_BLOCKS look-back granules {seq, count}
   uint32_t sel_seq = 0;               // sequence number of the last k_select call (never 0 in a granule)
+  // BMX_CTX_ASYNC_COMPACT: K3 of batch b runs on `side` while K1 of batch b+1 runs on `stream`
+  bool async_compact = false;
+  hipStream_t side = nullptr;
+  uint8_t* wflag2 = nullptr;                  // second winner-byte buffer
+  unsigned long long* shard_ctr2 = nullptr;   // second counter set
+  unsigned long long* granules2 = nullptr;    // granules of the side stream's selects
+  uint32_t sel_seq2 = 0;
+  hipEvent_t ev_k2[2] = {nullptr, nullptr};   // main: K2 of the batch using buffer i is done
+  hipEvent_t ev_k3[2] = {nullptr, nullptr};   // side: K3 of the batch using buffer i is done
+  bool k3_pending[2] = {false, false};
+  uint64_t nbatch = 0;
   uint32_t* part_counts = nullptr;    // PART_MAX_SHARDS * PART_BLOCKS
   uint32_t epoch = 0;
   uint64_t version = 0;
@@ -111,8 +122,21 @@ void dev_free(T*& p) {
   p = nullptr;
 }
 
+// Make the main stream (and the host, if asked) see everything the side stream has produced.
+int join_side(bmx_ctx* ctx, bool host_sync) {
+  if (!ctx->async_compact) return BMX_OK;
+  for (int i = 0; i < 2; i++)
+    if (ctx->k3_pending[i]) {
+      HIPCHK(hipStreamWaitEvent(ctx->stream, ctx->ev_k3[i], 0));
+      ctx->k3_pending[i] = false;
+    }
+  if (host_sync) HIPCHK(hipStreamSynchronize(ctx->side));
+  return BMX_OK;
+}
+
 // Pull the sticky device status; translate to an error code.
 int check_status(bmx_ctx* ctx) {
+  { int rcj = join_side(ctx, true); if (rcj) return rcj; }
   uint32_t st = 0;
   HIPCHK(hipMemcpyAsync(&st, &ctx->ds->status, sizeof(st), hipMemcpyDeviceToHost, ctx->stream));
   HIPCHK(hipStreamSynchronize(ctx->stream));
@@ -124,6 +148,7 @@ int check_status(bmx_ctx* ctx) {
 }
 
 int refresh_rows(bmx_ctx* ctx) {
+  { int rcj = join_side(ctx, true); if (rcj) return rcj; }
   unsigned long long r = 0;
   HIPCHK(hipMemcpyAsync(&r, &ctx->ds->row_count, sizeof(r), hipMemcpyDeviceToHost, ctx->stream));
   HIPCHK(hipStreamSynchronize(ctx->stream));
@@ -137,10 +162,12 @@ int ensure_workspace(bmx_ctx* ctx, uint64_t n) {
   uint64_t cap = std::max<uint64_t>(n, std::min<uint64_t>((uint64_t)ctx->ws_cap * 2, MAX_BATCH));
   cap = std::max<uint64_t>(cap, 1u << 16);
   cap = (cap + 255) & ~255ull;
-  dev_free(ctx->next); dev_free(ctx->wflag); dev_free(ctx->slot_of);
+  { int rcj = join_side(ctx, true); if (rcj) return rcj; }
+  dev_free(ctx->next); dev_free(ctx->wflag); dev_free(ctx->wflag2); dev_free(ctx->slot_of);
   ctx->ws_cap = 0;
   int rc;
   if ((rc = dev_alloc(ctx, &ctx->next, cap)) || (rc = dev_alloc(ctx, &ctx->wflag, cap + 16)) || (rc = dev_alloc(ctx, &ctx->slot_of, cap))) return rc;
+  if (ctx->async_compact && (rc = dev_alloc(ctx, &ctx->wflag2, cap + 16))) return rc;
   HIPCHK(hipMemsetAsync(ctx->next, 0, cap * sizeof(uint32_t), ctx->stream));
   ctx->ws_cap = (uint32_t)cap;
   return BMX_OK;
@@ -199,12 +226,20 @@ int merge_core(bmx_ctx* ctx, uint64_t n, const uint64_t* id, const uint32_t* fie
     HIPCHK(hipMemsetAsync(ctx->next, 0, (size_t)ctx->ws_cap * sizeof(uint32_t), ctx->stream));
     ctx->epoch = 1;
   }
+  // double buffering for the asynchronous compaction: batch b uses buffer b&1
+  const int bi = ctx->async_compact ? (int)(ctx->nbatch & 1) : 0;
+  uint8_t* wflag = bi ? ctx->wflag2 : ctx->wflag;
+  unsigned long long* ctr = bi ? ctx->shard_ctr2 : ctx->shard_ctr;
+  if (ctx->async_compact && ctx->k3_pending[bi]) {   // the compaction that last read this buffer must be done
+    HIPCHK(hipStreamWaitEvent(ctx->stream, ctx->ev_k3[bi], 0));
+    ctx->k3_pending[bi] = false;
+  }
   MergeArgs A;
   A.slots = ctx->slots; A.nslots = ctx->nslots;
   A.id = id; A.field = field; A.ts = ts; A.val = val; A.recs = recs;
   A.n = (uint32_t)n; A.epoch = ctx->epoch;
-  A.next = ctx->next; A.wflag = ctx->wflag; A.flags = flags;
-  A.slot_of = ctx->slot_of; A.shard_ctr = ctx->shard_ctr; A.status = &ctx->ds->status;
+  A.next = ctx->next; A.wflag = wflag; A.flags = flags;
+  A.slot_of = ctx->slot_of; A.shard_ctr = ctr; A.status = &ctx->ds->status;
   const uint32_t blocks = (uint32_t)((n + 255) / 256);
   const uint32_t rblocks = std::min<uint32_t>((uint32_t)((n + 4095) / 4096), 1024);
   hipEvent_t* pe = (ctx->prof_on && ctx->prof_n < PROF_MAX_CALLS) ? &ctx->prof_ev[4 * ctx->prof_n] : nullptr;
@@ -224,21 +259,40 @@ int merge_core(bmx_ctx* ctx, uint64_t n, const uint64_t* id, const uint32_t* fie
   }
   LAUNCHCHK("k_resolve_lists");
   if (pe) HIPCHK(hipEventRecord(pe[2], ctx->stream));
-  // K3: ordered compaction of the winner bytes
-  PredWinner P{ctx->wflag};
-  EmitApplied Em{applied_idx};
-  FinishMerge Fin{reinterpret_cast<unsigned long long*>(n_applied), stats, ctx->shard_ctr, &ctx->ds->row_count};
-  SelGeom g = sel_geom<PredWinner::E>(n);
+  // K3: ordered compaction of the winner bytes (on the side stream when asynchronous compaction is on)
+  hipStream_t ks = ctx->stream;
+  unsigned long long* gran = ctx->granules;
   uint32_t seq;
-  if ((rc = next_seq(ctx, &seq))) return rc;
+  if (ctx->async_compact) {
+    HIPCHK(hipEventRecord(ctx->ev_k2[bi], ctx->stream));
+    HIPCHK(hipStreamWaitEvent(ctx->side, ctx->ev_k2[bi], 0));
+    ks = ctx->side;
+    gran = ctx->granules2;
+    if (++ctx->sel_seq2 >= (1u << 30)) {
+      HIPCHK(hipMemsetAsync(ctx->granules2, 0, SEL_MAX_BLOCKS * sizeof(unsigned long long), ctx->side));
+      ctx->sel_seq2 = 1;
+    }
+    seq = ctx->sel_seq2;
+  } else if ((rc = next_seq(ctx, &seq))) {
+    return rc;
+  }
+  PredWinner P{wflag};
+  EmitApplied Em{applied_idx};
+  FinishMerge Fin{reinterpret_cast<unsigned long long*>(n_applied), stats, ctr, &ctx->ds->row_count};
+  SelGeom g = sel_geom<PredWinner::E>(n);
   if (g.tiles_per_block <= (uint32_t)SEL_STAGE)
-    hipLaunchKernelGGL((k_select_staged<PredWinner, EmitApplied, FinishMerge>), dim3(g.blocks), dim3(SEL_THREADS), 0, ctx->stream, P, Em, Fin, n,
-                       g.tiles_per_block, ctx->granules, seq, &ctx->ds->status);
+    hipLaunchKernelGGL((k_select_staged<PredWinner, EmitApplied, FinishMerge>), dim3(g.blocks), dim3(SEL_THREADS), 0, ks, P, Em, Fin, n,
+                       g.tiles_per_block, gran, seq, &ctx->ds->status);
   else
-    hipLaunchKernelGGL((k_select<PredWinner, EmitApplied, FinishMerge>), dim3(g.blocks), dim3(SEL_THREADS), 0, ctx->stream, P, Em, Fin, n,
-                       g.tiles_per_block, ctx->granules, seq, &ctx->ds->status);
+    hipLaunchKernelGGL((k_select<PredWinner, EmitApplied, FinishMerge>), dim3(g.blocks), dim3(SEL_THREADS), 0, ks, P, Em, Fin, n,
+                       g.tiles_per_block, gran, seq, &ctx->ds->status);
   LAUNCHCHK("k_select");
-  if (pe) { HIPCHK(hipEventRecord(pe[3], ctx->stream)); ctx->prof_n++; }
+  if (ctx->async_compact) {
+    HIPCHK(hipEventRecord(ctx->ev_k3[bi], ctx->side));
+    ctx->k3_pending[bi] = true;
+  }
+  if (pe) { HIPCHK(hipEventRecord(pe[3], ks)); ctx->prof_n++; }
+  ctx->nbatch++;
   ctx->rows_ub += n;
   ctx->version++;
   return BMX_OK;
@@ -257,6 +311,7 @@ int merge_host(bmx_ctx* ctx, uint64_t n, const uint64_t* id, const uint32_t* fie
   rc = merge_core<false>(ctx, n, ctx->st_id, ctx->st_field, ctx->st_ts, ctx->st_val, nullptr, insert_mode, ctx->st_applied,
                          reinterpret_cast<uint64_t*>(&ctx->ds->n_out), flags ? ctx->st_flags : nullptr, &ctx->ds->stats);
   if (rc) return rc;
+  if ((rc = join_side(ctx, false))) return rc;
   bmx_merge_stats hs;
   HIPCHK(hipMemcpyAsync(&hs, &ctx->ds->stats, sizeof(hs), hipMemcpyDeviceToHost, ctx->stream));
   HIPCHK(hipStreamSynchronize(ctx->stream));
@@ -408,7 +463,6 @@ const char* bmx_last_error(const bmx_ctx* ctx) { return ctx ? ctx->err.c_str() :
 uint32_t bmx_owner_of(uint64_t id, uint32_t nshards) { return (uint32_t)(((unsigned __int128)owner_hash(id) * nshards) >> 64); }
 
 int bmx_create(int device, uint64_t capacity_rows, uint32_t flags, bmx_ctx** out) {
-  (void)flags;
   if (!out || capacity_rows == 0) return fail(nullptr, BMX_ERR_INVALID, "bmx_create: bad arguments");
   *out = nullptr;
   int ndev = 0;
@@ -439,6 +493,15 @@ int bmx_create(int device, uint64_t capacity_rows, uint32_t flags, bmx_ctx** out
   CR(hipMemsetAsync(ctx->granules, 0, SEL_MAX_BLOCKS * sizeof(unsigned long long), ctx->stream));
   if ((rc = dev_alloc(ctx, &ctx->shard_ctr, CTR_SHARDS * CTR_STRIDE))) return bail(rc);
   CR(hipMemsetAsync(ctx->shard_ctr, 0, CTR_SHARDS * CTR_STRIDE * sizeof(unsigned long long), ctx->stream));
+  if (flags & BMX_CTX_ASYNC_COMPACT) {
+    ctx->async_compact = true;
+    CR(hipStreamCreateWithFlags(&ctx->side, hipStreamNonBlocking));
+    for (int i = 0; i < 2; i++) { CR(hipEventCreateWithFlags(&ctx->ev_k2[i], hipEventDisableTiming)); CR(hipEventCreateWithFlags(&ctx->ev_k3[i], hipEventDisableTiming)); }
+    if ((rc = dev_alloc(ctx, &ctx->shard_ctr2, CTR_SHARDS * CTR_STRIDE))) return bail(rc);
+    CR(hipMemsetAsync(ctx->shard_ctr2, 0, CTR_SHARDS * CTR_STRIDE * sizeof(unsigned long long), ctx->stream));
+    if ((rc = dev_alloc(ctx, &ctx->granules2, SEL_MAX_BLOCKS))) return bail(rc);
+    CR(hipMemsetAsync(ctx->granules2, 0, SEL_MAX_BLOCKS * sizeof(unsigned long long), ctx->stream));
+  }
   CR(hipMemsetAsync(ctx->ds, 0, sizeof(DevScalars), ctx->stream));
   hipLaunchKernelGGL(k_init_slots, dim3(2048), dim3(256), 0, ctx->stream, ctx->slots, nslots);
   CR(hipGetLastError());
@@ -452,6 +515,10 @@ void bmx_destroy(bmx_ctx* ctx) {
   if (!ctx) return;
   (void)hipSetDevice(ctx->device);
   if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
+  if (ctx->side) (void)hipStreamSynchronize(ctx->side);
+  dev_free(ctx->wflag2); dev_free(ctx->shard_ctr2); dev_free(ctx->granules2);
+  for (int i = 0; i < 2; i++) { if (ctx->ev_k2[i]) (void)hipEventDestroy(ctx->ev_k2[i]); if (ctx->ev_k3[i]) (void)hipEventDestroy(ctx->ev_k3[i]); }
+  if (ctx->side) (void)hipStreamDestroy(ctx->side);
   for (auto& ix : ctx->indexes) { dev_free(ix.ids); dev_free(ix.v64); dev_free(ix.v32); }
   dev_free(ctx->slots); dev_free(ctx->ds); dev_free(ctx->next); dev_free(ctx->wflag); dev_free(ctx->slot_of); dev_free(ctx->shard_ctr);
   dev_free(ctx->st_id); dev_free(ctx->st_field); dev_free(ctx->st_ts); dev_free(ctx->st_val); dev_free(ctx->st_applied); dev_free(ctx->st_flags);
@@ -708,6 +775,7 @@ int bmx_timer_start(bmx_ctx* ctx) {
 }
 int bmx_timer_stop(bmx_ctx* ctx, float* ms_out) {
   if (!ctx || !ms_out) return fail(ctx, BMX_ERR_INVALID, "bad arguments");
+  { int rcj = join_side(ctx, false); if (rcj) return rcj; }   // the stop event also covers compactions still running on the side stream
   HIPCHK(hipEventRecord(ctx->ev1, ctx->stream));
   HIPCHK(hipEventSynchronize(ctx->ev1));
   HIPCHK(hipEventElapsedTime(ms_out, ctx->ev0, ctx->ev1));
@@ -730,6 +798,7 @@ int bmx_profile_enable(bmx_ctx* ctx, int on) {
 int bmx_profile_read(bmx_ctx* ctx, float ms_out[3], uint32_t* n_calls) {
   if (!ctx || !ms_out || !n_calls) return fail(ctx, BMX_ERR_INVALID, "bad arguments");
   HIPCHK(hipSetDevice(ctx->device));
+  { int rcj = join_side(ctx, true); if (rcj) return rcj; }
   HIPCHK(hipStreamSynchronize(ctx->stream));
   double acc[3] = {0, 0, 0};
   for (uint32_t i = 0; i < ctx->prof_n; i++)

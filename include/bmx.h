@@ -94,6 +94,11 @@ typedef struct bmx_info {
   uint32_t device, abi_version, n_indexes, epoch;
 } bmx_info;
 
+/* bmx_create flags */
+#define BMX_CTX_ASYNC_COMPACT 1u  /* run the winner compaction of batch b on a second stream, under the probe kernel of
+                                     batch b+1 (double-buffered winner bytes). Outputs of a merge call (applied_idx,
+                                     n_applied, stats) are then valid only after bmx_sync(), not in stream order. */
+
 /* ---- lifetime -------------------------------------------------------------------------------
  * Replaces `new BulletCRT(bullet)` src/bullet-crt.js:6-16 / `new BulletQuery(bullet)`
  * src/bullet-query.js:2-7 for the device-resident part of the state (reference state:
