@@ -241,7 +241,7 @@ int merge_core(bmx_ctx* ctx, uint64_t n, const uint64_t* id, const uint32_t* fie
   A.next = ctx->next; A.wflag = wflag; A.flags = flags;
   A.slot_of = ctx->slot_of; A.shard_ctr = ctr; A.status = &ctx->ds->status;
   const uint32_t blocks = (uint32_t)((n + 255) / 256);
-  const uint32_t rblocks = std::min<uint32_t>((uint32_t)((n + 4095) / 4096), 1024);
+  const uint32_t rblocks = blocks;   // one lane per delta
   hipEvent_t* pe = (ctx->prof_on && ctx->prof_n < PROF_MAX_CALLS) ? &ctx->prof_ev[4 * ctx->prof_n] : nullptr;
   if (pe) HIPCHK(hipEventRecord(pe[0], ctx->stream));
   if (insert_mode == BMX_INSERT_REFERENCE) {

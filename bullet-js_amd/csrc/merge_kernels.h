@@ -200,75 +200,123 @@ __global__ __launch_bounds__(256) void k_probe_apply(MergeArgs A) {
   }
 }
 
-// Pending pass (duplicate keys only). 16 winner bytes per lane are scanned; only the LAST claimer of a row
-// (slot.head names it) does anything: it walks next[] back to the first claimer and applies the sequential
-// outcome for that key.
+// Pending pass (duplicate keys only): one lane per delta, so every walker starts at once (the pass is latency bound:
+// few walkers, each a chain of dependent reads). Only the LAST claimer of a row (slot.head names it) does anything:
+// it walks next[] back to the first claimer and applies the sequential outcome for that key.
+
+// generic single-pass walk for long lists (a key hit more than RES_CAP times in one batch): tracks the smallest index,
+// the best (ts,val) with its smallest index, and the best among the other deltas, so that the creating delta of an absent
+// row (smallest index, stored with ts := 2) can be excluded afterwards without a second walk.
 template <bool AOS, int MODE>
-__device__ __forceinline__ void resolve_one(const MergeArgs& A, uint32_t j) {
-  Slot* sl = A.slots + A.slot_of[j];
-  if ((sl->head & IDX_MASK) != j) return;
-  const int64_t tsw = sl->ts;
-  const bool is_new = tsw == TS_NEW || ts_mark(tsw) == A.epoch;  // row created in this batch: no pre-batch state
-  // pass 1: find the first claimer (end of list) and the smallest index (creates an absent row: src/bullet-crt.js:172-185)
+__device__ __forceinline__ void resolve_long(const MergeArgs& A, uint32_t j, Slot* sl, int64_t tsw, int64_t cval) {
+  const bool is_new = tsw == TS_NEW || ts_mark(tsw) == A.epoch;
   uint32_t j0 = j, first = j;
+  int64_t v_j0 = 0, t_j0 = 0;
+  int64_t t1 = INT64_MIN, v1 = INT64_MIN, t2 = INT64_MIN, v2 = INT64_MIN;   // best and best-of-the-rest
+  uint32_t o1 = ~0u, o2 = ~0u;
   {
     uint32_t idx = j, steps = 0;
     for (;;) {
-      if (idx < j0) j0 = idx;
+      int64_t t, v; load_delta_tv<AOS>(A, idx, t, v);
       uint32_t nx = A.next[idx];
+      if (idx <= j0) { j0 = idx; t_j0 = t; v_j0 = v; }
+      int c1 = o1 == ~0u ? 1 : lexcmp(t, v, t1, v1);
+      if (c1 > 0 || (c1 == 0 && idx < o1)) {
+        // new best; the old best becomes a candidate for second place (unless it ties the new best: same value, larger index)
+        if (o1 != ~0u && c1 > 0) { int c2 = o2 == ~0u ? 1 : lexcmp(t1, v1, t2, v2); if (c2 > 0 || (c2 == 0 && o1 < o2)) { t2 = t1; v2 = v1; o2 = o1; } }
+        else if (o1 != ~0u && c1 == 0) { int c2 = o2 == ~0u ? 1 : lexcmp(t1, v1, t2, v2); if (c2 > 0 || (c2 == 0 && o1 < o2)) { t2 = t1; v2 = v1; o2 = o1; } }
+        t1 = t; v1 = v; o1 = idx;
+      } else {
+        int c2 = o2 == ~0u ? 1 : lexcmp(t, v, t2, v2);
+        if (c2 > 0 || (c2 == 0 && idx < o2)) { t2 = t; v2 = v; o2 = idx; }
+      }
       if ((nx >> IDX_BITS) != A.epoch) { first = idx; break; }
       idx = nx & IDX_MASK;
       if (++steps > A.n) { atomicOr(A.status, ST_SPIN); return; }
     }
   }
-  int64_t bt, bv;      // best (ts,val) so far
-  uint32_t owner;      // delta that owns `best`, or ~0u if it is the resident row
-  const uint32_t base_owner = A.wflag[first] == W_WINNER ? first : ~0u;  // the first claimer stored iff it beat the pre-batch row
+  const uint32_t base_owner = A.wflag[first] == W_WINNER ? first : ~0u;
+  int64_t bt, bv;
+  uint32_t owner;
   if (is_new) {
-    int64_t t0, v0; load_delta_tv<AOS>(A, j0, t0, v0);
+    // the row starts as (2 or t_j0, v_j0) owned by j0; the other deltas then compete against it
+    bt = (MODE == BMX_INSERT_REFERENCE) ? 2 : t_j0; bv = v_j0; owner = j0;
+    const bool use2 = o1 == j0;                      // best of the deltas other than j0
+    const uint32_t om = use2 ? o2 : o1;
+    if (om != ~0u) {
+      const int64_t tm = use2 ? t2 : t1, vm = use2 ? v2 : v1;
+      int c = lexcmp(tm, vm, bt, bv);
+      if (c > 0) { bt = tm; bv = vm; owner = om; }   // a tie keeps j0 (it has the smaller index)
+    }
+  } else {
+    bt = ts_value(tsw); bv = cval; owner = base_owner;
+    int c = lexcmp(t1, v1, bt, bv);
+    if (c > 0) { bt = t1; bv = v1; owner = o1; }
+    else if (c == 0 && owner != ~0u && o1 < owner) owner = o1;
+  }
+  store_tv(sl, is_new ? (bt | ((int64_t)A.epoch << TS_MARK_SHIFT)) : bt, bv);
+  if (base_owner != ~0u && base_owner != owner) A.wflag[base_owner] = W_NONE;
+  if (owner != ~0u) { A.wflag[owner] = W_WINNER; if (A.flags) A.flags[owner] = (uint8_t)BMX_FLAG_INCOMING; }
+}
+
+constexpr int RES_CAP = 8;  // list nodes kept in registers by the single-walk fast path
+
+template <bool AOS, int MODE>
+__global__ __launch_bounds__(256) void k_resolve_lists(MergeArgs A) {
+  const uint32_t j = blockIdx.x * 256u + threadIdx.x;
+  if (j >= A.n || A.wflag[j] != W_PENDING) return;
+  // independent loads first: this delta's value, its link, and the row (one line)
+  int64_t t, v; load_delta_tv<AOS>(A, j, t, v);
+  uint32_t nx = A.next[j];
+  Slot* sl = A.slots + A.slot_of[j];
+  const uint4* q = reinterpret_cast<const uint4*>(sl);
+  const uint4 lo = q[0], hi = q[1];
+  if ((lo.w & IDX_MASK) != j) return;   // not the last claimer of its row
+  const int64_t tsw = (int64_t)((uint64_t)hi.x | ((uint64_t)hi.y << 32));
+  const int64_t cval = (int64_t)((uint64_t)hi.z | ((uint64_t)hi.w << 32));
+  const bool is_new = tsw == TS_NEW || ts_mark(tsw) == A.epoch;  // row created in this batch: no pre-batch state
+
+  // single walk, nodes in registers (static indices only: a runtime-indexed array would go to scratch)
+  uint32_t ni[RES_CAP]; int64_t nt[RES_CAP], nv[RES_CAP];
+  int L = 0;
+  bool alive = true;
+  uint32_t idx = j, first = j;
+#pragma unroll
+  for (int k = 0; k < RES_CAP; k++) {
+    if (alive) {
+      ni[k] = idx; nt[k] = t; nv[k] = v; L = k + 1;
+      if ((nx >> IDX_BITS) != A.epoch) { first = idx; alive = false; }
+      else { idx = nx & IDX_MASK; nx = A.next[idx]; load_delta_tv<AOS>(A, idx, t, v); }   // two independent loads per hop
+    }
+  }
+  if (alive) { resolve_long<AOS, MODE>(A, j, sl, tsw, cval); return; }
+
+  // smallest index creates an absent row with ts := 2 (src/bullet-crt.js:172-185)
+  uint32_t j0 = j; int k0 = 0;
+#pragma unroll
+  for (int k = 0; k < RES_CAP; k++) if (k < L && ni[k] < j0) { j0 = ni[k]; k0 = k; }
+  const uint32_t base_owner = A.wflag[first] == W_WINNER ? first : ~0u;   // the first claimer stored iff it beat the pre-batch row
+  int64_t bt, bv; uint32_t owner;
+  if (is_new) {
+    int64_t t0 = 0, v0 = 0;
+#pragma unroll
+    for (int k = 0; k < RES_CAP; k++) if (k == k0) { t0 = nt[k]; v0 = nv[k]; }
     bt = (MODE == BMX_INSERT_REFERENCE) ? 2 : t0; bv = v0; owner = j0;
   } else {
-    bt = ts_value(tsw); bv = sl->val; owner = base_owner;
+    bt = ts_value(tsw); bv = cval; owner = base_owner;
   }
-  // pass 2: lexmax over the list, ties to the smaller index ("identical clocks and values" is a no-op, :207-219)
-  {
-    uint32_t idx = j, steps = 0;
-    for (;;) {
-      if (!(is_new && idx == j0)) {
-        int64_t t, v; load_delta_tv<AOS>(A, idx, t, v);
-        int c = lexcmp(t, v, bt, bv);
-        if (c > 0) { bt = t; bv = v; owner = idx; }
-        else if (c == 0 && owner != ~0u && idx < owner) owner = idx;
-      }
-      uint32_t nx = A.next[idx];
-      if ((nx >> IDX_BITS) != A.epoch) break;
-      idx = nx & IDX_MASK;
-      if (++steps > A.n) break;
+  // lexmax over the list, ties to the smaller index ("identical clocks and values" is a no-op, :207-219)
+#pragma unroll
+  for (int k = 0; k < RES_CAP; k++) {
+    if (k < L && !(is_new && ni[k] == j0)) {
+      int c = lexcmp(nt[k], nv[k], bt, bv);
+      if (c > 0) { bt = nt[k]; bv = nv[k]; owner = ni[k]; }
+      else if (c == 0 && owner != ~0u && ni[k] < owner) owner = ni[k];
     }
   }
   store_tv(sl, is_new ? (bt | ((int64_t)A.epoch << TS_MARK_SHIFT)) : bt, bv);
   if (base_owner != ~0u && base_owner != owner) A.wflag[base_owner] = W_NONE;
-  if (owner != ~0u) A.wflag[owner] = W_WINNER;
-}
-
-template <bool AOS, int MODE>
-__global__ __launch_bounds__(256) void k_resolve_lists(MergeArgs A) {
-  const uint32_t ngroups = (A.n + 15u) / 16u;
-  for (uint32_t g = blockIdx.x * 256u + threadIdx.x; g < ngroups; g += gridDim.x * 256u) {
-    const uint32_t base = g * 16u;
-    uint4 x = *reinterpret_cast<const uint4*>(A.wflag + base);   // wflag is padded to a multiple of 16
-    uint32_t q[4] = {x.x, x.y, x.z, x.w};
-#pragma unroll
-    for (int k = 0; k < 4; k++) {
-      uint32_t pend = q[k] & 0x02020202u;                          // W_PENDING bytes
-      while (pend) {
-        int b = (__ffs((int)pend) - 1) >> 3;
-        pend &= ~(0xFFu << (8 * b));
-        uint32_t j = base + 4u * k + (uint32_t)b;
-        if (j < A.n) resolve_one<AOS, MODE>(A, j);
-      }
-    }
-  }
+  if (owner != ~0u) { A.wflag[owner] = W_WINNER; if (A.flags) A.flags[owner] = (uint8_t)BMX_FLAG_INCOMING; }
 }
 
 // epoch wrap: forget every claim tag and every creation mark

@@ -227,3 +227,31 @@ def test_all_deltas_one_key_worst_case_contention():
         assert np.array_equal(applied, ow) and len(applied) == 1
         assert e.get_row(42, F0) == o.get_row(42, F0)
         assert st.n_conflicts == n - 1
+
+
+@pytest.mark.parametrize("mode", [INSERT_REFERENCE, INSERT_DELTA])
+@pytest.mark.parametrize("seed", [1, 2, 3])
+def test_duplicate_heavy_random_vs_oracle(seed, mode):
+    """Lists of 1..60 same-key deltas (short and long resolve paths), ts in 0..4 and val in -1..1 so ties and the
+    ts := 2 insert rule are hit constantly; half the keys resident, half absent; three consecutive batches."""
+    rng = np.random.default_rng(seed)
+    K = 3000
+    keys = synth.splitmix64_np(np.arange(10_000 * seed, 10_000 * seed + K, dtype=np.uint64))
+    res = keys[: K // 2]
+    o = Oracle()
+    with bmx.Engine(4 * K) as e:
+        rts = rng.integers(0, 5, len(res)); rval = rng.integers(-1, 2, len(res))
+        e.load_rows(res, np.full(len(res), F0), rts, rval); o.load_rows(res, np.full(len(res), F0), rts, rval)
+        for b in range(3):
+            mult = np.minimum(rng.geometric(0.25, K), 60)
+            mult[rng.integers(0, K, 20)] = 60                      # a few long lists for sure
+            idx = np.repeat(np.arange(K), mult)
+            rng.shuffle(idx)
+            n = len(idx)
+            ts = rng.integers(0, 5, n); val = rng.integers(-1, 2, n)
+            applied, flags, st = e.merge_batch(keys[idx], np.full(n, F0), ts, val, mode)
+            of, ow = o.merge_batch(keys[idx], np.full(n, F0), ts, val, mode)
+            assert np.array_equal(applied, ow), (seed, mode, b)
+            assert (flags[applied] & 1).all()
+            assert st.n_conflicts > 0 and st.n_rows == len(o)
+            _assert_same_state(e, o)
