@@ -18,12 +18,13 @@ MEM_HOST, MEM_DEVICE = 0, 1
 INSERT_REFERENCE, INSERT_DELTA = 0, 1
 MERGE_UNIQUE_KEYS = 0x100
 CTX_ASYNC_COMPACT = 1
+CTX_FIXED_CAPACITY = 2
 FLAG_INCOMING, FLAG_CURRENT, FLAG_HISTORICAL = 1, 2, 4
 MAX_BATCH = 1 << 24
 
 EXPORTS = [
     "bmx_create", "bmx_destroy", "bmx_last_error", "bmx_abi_version", "bmx_get_info", "bmx_sync", "bmx_set_stream", "bmx_get_stream",
-    "bmx_load_rows", "bmx_merge_batch", "bmx_merge_records", "bmx_get_rows", "bmx_get_row", "bmx_dump_rows", "bmx_row_count",
+    "bmx_load_rows", "bmx_merge_batch", "bmx_merge_records", "bmx_get_rows", "bmx_get_row", "bmx_dump_rows", "bmx_row_count", "bmx_reserve",
     "bmx_index_build", "bmx_index_drop", "bmx_index_size", "bmx_scan_range", "bmx_scan_equals", "bmx_scan_count", "bmx_scan_filter",
     "bmx_owner_of", "bmx_partition_by_owner", "bmx_partition_by_owner_slabs", "bmx_timer_start", "bmx_timer_stop", "bmx_profile_enable", "bmx_profile_read",
 ]
@@ -77,6 +78,7 @@ def load_library():
     L.bmx_get_row.argtypes = [vp, u64, u32, C.POINTER(i64), C.POINTER(i64)]; L.bmx_get_row.restype = i32
     L.bmx_dump_rows.argtypes = [vp, u64, vp, vp, vp, vp, vp, i32]; L.bmx_dump_rows.restype = i32
     L.bmx_row_count.argtypes = [vp, C.POINTER(u64)]; L.bmx_row_count.restype = i32
+    L.bmx_reserve.argtypes = [vp, u64]; L.bmx_reserve.restype = i32
     L.bmx_index_build.argtypes = [vp, u32]; L.bmx_index_build.restype = i32
     L.bmx_index_drop.argtypes = [vp, u32]; L.bmx_index_drop.restype = i32
     L.bmx_index_size.argtypes = [vp, u32, C.POINTER(u64)]; L.bmx_index_size.restype = i32
@@ -178,6 +180,9 @@ class Engine:
         n = C.c_uint64()
         self._chk(self.L.bmx_row_count(self.h, C.byref(n)))
         return n.value
+
+    def reserve(self, capacity_rows):
+        self._chk(self.L.bmx_reserve(self.h, int(capacity_rows)))
 
     def dump_rows(self):
         n = self.row_count()

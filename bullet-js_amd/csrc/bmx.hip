@@ -64,6 +64,7 @@ struct bmx_ctx {
   unsigned long long* granules = nullptr;  // SEL_MAX_BLOCKS look-back granules {seq, count}
   uint32_t sel_seq = 0;               // sequence number of the last k_select call (never 0 in a granule)
   // BMX_CTX_ASYNC_COMPACT: K3 of batch b runs on `side` while K1 of batch b+1 runs on `stream`
+  bool fixed_capacity = false;
   bool async_compact = false;
   hipStream_t side = nullptr;
   uint8_t* wflag2 = nullptr;                  // second winner-byte buffer
@@ -188,6 +189,28 @@ int ensure_staging(bmx_ctx* ctx, uint64_t n) {
   return BMX_OK;
 }
 
+// Rehash into a table for `capacity_rows` rows. Synchronous.
+int grow_table(bmx_ctx* ctx, uint64_t capacity_rows) {
+  if (capacity_rows <= ctx->capacity_rows) return BMX_OK;
+  int rc = join_side(ctx, true);
+  if (rc) return rc;
+  HIPCHK(hipStreamSynchronize(ctx->stream));
+  uint64_t nslots = std::max<uint64_t>(4096, capacity_rows * 2);
+  nslots = (nslots + 3) & ~3ull;
+  Slot* fresh = nullptr;
+  if ((rc = dev_alloc(ctx, &fresh, nslots))) return rc;
+  hipLaunchKernelGGL(k_init_slots, dim3(2048), dim3(256), 0, ctx->stream, fresh, nslots);
+  hipLaunchKernelGGL(k_rehash, dim3(2048), dim3(256), 0, ctx->stream, ctx->slots, ctx->nslots, fresh, nslots, &ctx->ds->status);
+  hipError_t e = hipGetLastError();
+  if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+  if (e != hipSuccess) { dev_free(fresh); return fail_hip(ctx, e, "grow_table"); }
+  dev_free(ctx->slots);
+  ctx->slots = fresh; ctx->nslots = nslots; ctx->capacity_rows = capacity_rows;
+  // the batch epoch keeps counting: next[] still holds links tagged with earlier epochs; the new heads are all 0
+  ctx->version++;          // indices are rebuilt on their next use
+  return check_status(ctx);
+}
+
 // Sequence number for the next k_select call; granules are re-zeroed when it wraps.
 int next_seq(bmx_ctx* ctx, uint32_t* seq) {
   if (++ctx->sel_seq >= (1u << 30)) {
@@ -213,12 +236,17 @@ int merge_core(bmx_ctx* ctx, uint64_t n, const uint64_t* id, const uint32_t* fie
     return BMX_OK;
   }
   // capacity guards: physical (never let probing run out of empty slots) and logical (capacity_rows)
+  int rc;
   if (ctx->rows_ub + n >= ctx->nslots || ctx->rows_ub > ctx->capacity_rows) {
-    int rc = refresh_rows(ctx);
+    rc = refresh_rows(ctx);
     if (rc) return rc;
-    if (ctx->rows_ub + n >= ctx->nslots || ctx->rows_ub > ctx->capacity_rows) return fail(ctx, BMX_ERR_FULL, "resident table is full (capacity_rows exceeded)");
+    if (ctx->rows_ub + n >= ctx->nslots || ctx->rows_ub > ctx->capacity_rows) {
+      if (ctx->fixed_capacity) return fail(ctx, BMX_ERR_FULL, "resident table is full (capacity_rows exceeded)");
+      uint64_t want = std::max<uint64_t>(ctx->capacity_rows * 2, ctx->rows_ub + n + n / 2);   // amortised doubling
+      if ((rc = grow_table(ctx, want))) return rc;
+    }
   }
-  int rc = ensure_workspace(ctx, n);
+  rc = ensure_workspace(ctx, n);
   if (rc) return rc;
   if (++ctx->epoch > EPOCH_MAX) {  // tags wrap: forget every claim
     hipLaunchKernelGGL(k_sweep_heads, dim3(2048), dim3(256), 0, ctx->stream, ctx->slots, ctx->nslots);
@@ -493,6 +521,7 @@ int bmx_create(int device, uint64_t capacity_rows, uint32_t flags, bmx_ctx** out
   CR(hipMemsetAsync(ctx->granules, 0, SEL_MAX_BLOCKS * sizeof(unsigned long long), ctx->stream));
   if ((rc = dev_alloc(ctx, &ctx->shard_ctr, CTR_SHARDS * CTR_STRIDE))) return bail(rc);
   CR(hipMemsetAsync(ctx->shard_ctr, 0, CTR_SHARDS * CTR_STRIDE * sizeof(unsigned long long), ctx->stream));
+  ctx->fixed_capacity = (flags & BMX_CTX_FIXED_CAPACITY) != 0;
   if (flags & BMX_CTX_ASYNC_COMPACT) {
     ctx->async_compact = true;
     CR(hipStreamCreateWithFlags(&ctx->side, hipStreamNonBlocking));
@@ -561,6 +590,12 @@ int bmx_row_count(bmx_ctx* ctx, uint64_t* n_out) {
   if (rc) return rc;
   *n_out = ctx->rows_ub;
   return BMX_OK;
+}
+
+int bmx_reserve(bmx_ctx* ctx, uint64_t capacity_rows) {
+  if (!ctx || capacity_rows == 0) return fail(ctx, BMX_ERR_INVALID, "bad arguments");
+  HIPCHK(hipSetDevice(ctx->device));
+  return grow_table(ctx, capacity_rows);
 }
 
 int bmx_merge_batch(bmx_ctx* ctx, uint64_t n, const uint64_t* id, const uint32_t* field, const int64_t* ts, const int64_t* val,

@@ -337,6 +337,34 @@ __global__ __launch_bounds__(256) void k_init_slots(Slot* slots, uint64_t nslots
   }
 }
 
+// growth: re-insert every row of the old table into the new (empty) one. Keys are unique, so a lane only competes
+// with lanes of OTHER keys for an empty slot: CAS on id, then plain stores of the rest (nobody reads it in this launch).
+__global__ __launch_bounds__(256) void k_rehash(const Slot* old_slots, uint64_t old_n, Slot* slots, uint64_t nslots, uint32_t* status) {
+  for (uint64_t i = (uint64_t)blockIdx.x * 256u + threadIdx.x; i < old_n; i += (uint64_t)gridDim.x * 256u) {
+    const uint4* q = reinterpret_cast<const uint4*>(old_slots + i);
+    uint4 lo = q[0];
+    uint64_t id = (uint64_t)lo.x | ((uint64_t)lo.y << 32);
+    if (id == EMPTY_ID) continue;
+    uint4 hi = q[1];
+    int64_t t = (int64_t)((uint64_t)hi.x | ((uint64_t)hi.y << 32));
+    if (t != TS_NEW) t = ts_value(t);          // creation marks do not survive a rehash
+    uint64_t s = home_slot(key_hash(id, lo.z), nslots);
+    bool done = false;
+    for (uint64_t p = 0; p < nslots && !done; ++p) {
+      Slot* sl = slots + s;
+      unsigned long long old = atomicCAS(reinterpret_cast<unsigned long long*>(&sl->id), (unsigned long long)EMPTY_ID, (unsigned long long)id);
+      if (old == EMPTY_ID) {
+        sl->field = lo.z; sl->head = 0;
+        reinterpret_cast<uint4*>(sl)[1] = make_uint4((uint32_t)(uint64_t)t, (uint32_t)((uint64_t)t >> 32), hi.z, hi.w);
+        done = true;
+      } else {
+        s = (s + 1 == nslots) ? 0 : s + 1;
+      }
+    }
+    if (!done) atomicOr(status, ST_FULL);
+  }
+}
+
 // read-only lookup of n keys
 __global__ __launch_bounds__(256) void k_get_rows(const Slot* slots, uint64_t nslots, uint32_t n, const uint64_t* id,
                                                   const uint32_t* field, int64_t* ts, int64_t* val, uint8_t* found) {

@@ -95,6 +95,8 @@ typedef struct bmx_info {
 } bmx_info;
 
 /* bmx_create flags */
+#define BMX_CTX_FIXED_CAPACITY 2u /* never grow: a batch that would exceed capacity_rows fails with BMX_ERR_FULL.
+                                     Default: the table is rehashed into one twice as large (synchronous, on device). */
 #define BMX_CTX_ASYNC_COMPACT 1u  /* run the winner compaction of batch b on a second stream, under the probe kernel of
                                      batch b+1 (double-buffered winner bytes). Outputs of a merge call (applied_idx,
                                      n_applied, stats) are then valid only after bmx_sync(), not in stream order. */
@@ -146,6 +148,10 @@ int bmx_get_row(bmx_ctx* ctx, uint64_t id, uint32_t field, int64_t* ts, int64_t*
 int bmx_dump_rows(bmx_ctx* ctx, uint64_t cap, uint64_t* id, uint32_t* field, int64_t* ts, int64_t* val,
                   uint64_t* n_out, int mem);
 int bmx_row_count(bmx_ctx* ctx, uint64_t* n_out);
+/* Make room for at least capacity_rows resident rows (no-op if already there): allocates a new table, re-inserts every
+ * row on the device, frees the old one. Synchronous. The reference's store is a JS object that simply grows
+ * (src/bullet.js:28); this is the device-side equivalent. */
+int bmx_reserve(bmx_ctx* ctx, uint64_t capacity_rows);
 
 /* ---- index + scans --------------------------------------------------------------------------
  * bmx_index_build replaces BulletQuery.index(path, field) / _buildIndex (src/bullet-query.js:30-73):

@@ -157,8 +157,27 @@ def test_domain_errors_are_reported_not_fatal():
         assert e.get_row(8, F0) == (0, 2**53 - 1)
 
 
-def test_table_full_is_an_error():
+def test_table_grows_by_rehash_and_keeps_every_row():
+    """Default contexts grow (device-side rehash) instead of failing; scans and merges keep working across the growth."""
+    o = Oracle()
     with bmx.Engine(1000) as e:
+        n0 = e.info().n_slots
+        for b in range(12):
+            d = synth.big_deltas(3000, 1000, seed=77, insert_pct=70, hot_pct=10, hot_keys=20, unique=False, batch=b)
+            applied, _, st = e.merge_batch(*d)
+            _, ow = o.merge_batch(*d)
+            assert np.array_equal(applied, ow), b
+        assert e.row_count() == len(o) > 1000 and e.info().n_slots > n0
+        _assert_same_state(e, o)
+        f0 = int(d[1][0])
+        assert np.array_equal(np.sort(e.scan_range(f0, -(1 << 40), 1 << 40)), np.sort(o.scan_range(f0, -(1 << 40), 1 << 40)))
+        e.reserve(200_000)                       # explicit reservation: same rows afterwards
+        assert e.info().capacity_rows == 200_000
+        _assert_same_state(e, o)
+
+
+def test_table_full_is_an_error_with_fixed_capacity():
+    with bmx.Engine(1000, flags=bmx.CTX_FIXED_CAPACITY) as e:
         ids = streams.splitmix64_np(np.arange(1, 9001, dtype=np.uint64))
         with pytest.raises(bmx.BmxError) as ei:
             for k in range(0, 9000, 1000):
