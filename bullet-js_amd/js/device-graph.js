@@ -19,6 +19,11 @@ class DeviceGraph {
     this.batches++;
     return this.native.mergeBatch(this.handle, cols.id, cols.field, cols.ts, cols.val, mode | 0);
   }
+  mergeBatchAsync(cols, mode) {
+    this.batches++;
+    return this.native.mergeBatchAsync(this.handle, cols.id, cols.field, cols.ts, cols.val, mode | 0);
+  }
+  reserve(capacityRows) { this.native.reserve(this.handle, capacityRows); }
   loadRows(cols) { this.native.loadRows(this.handle, cols.id, cols.field, cols.ts, cols.val); }
   getRows(id, field) { return this.native.getRows(this.handle, id, field); }
   rowCount() { return this.native.rowCount(this.handle); }

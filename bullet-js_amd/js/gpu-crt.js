@@ -204,6 +204,15 @@ class GpuCRT {
     return g.mergeBatch(cols, mode);
   }
 
+  /** Same as mergeBatch but off the event loop: resolves to the same result object (the reference API is synchronous;
+   *  this is the Promise variant SURVEY §8(b) calls for). The columns must not be mutated until it settles. */
+  mergeBatchAsync(cols, opts = {}) {
+    const g = this.graph;
+    let mode = opts.insertMode === "delta" ? g.native.INSERT_DELTA : g.native.INSERT_REFERENCE;
+    if (opts.uniqueKeys) mode |= g.native.MERGE_UNIQUE_KEYS;
+    return g.mergeBatchAsync(cols, mode);
+  }
+
   /**
    * Batch adapter for sync chunks (reference loop: src/bullet-network-sync.js:551-569).
    * entries: [{path, data, vectorClock}] where data is an integer or an object of integer fields and

@@ -153,4 +153,27 @@ for (const name of fs.readdirSync(GOLD).filter((f) => f.startsWith("g2_stream_")
   checks += 6;
 }
 
-console.log("device_parity ok:", checks, "checks");
+/* Promise variant: two batches in flight from the event loop's point of view, serialised inside the addon */
+(async () => {
+  const g = load("g2_stream_hot30_10k_10k.json");
+  const { resident, deltas, F } = gen.genStream(g.spec);
+  const crt = new GpuCRT({ id: "w", meta: {}, _getData() {} }, { capacityRows: 1024 });   // small on purpose: the table grows
+  crt.graph.loadRows(columns(resident, F));
+  const half = deltas.length >> 1;
+  let ticks = 0;
+  const timer = setInterval(() => { ticks++; }, 0);
+  const p1 = crt.mergeBatchAsync(columns(deltas.slice(0, half), F));
+  const p2 = crt.mergeBatchAsync(columns(deltas.slice(half), F));
+  const [r1, r2] = await Promise.all([p1, p2]);
+  clearInterval(timer);
+  assert.strictEqual(r2.nRows, g.n_rows_final);
+  const d = crt.graph.dumpRows();
+  let digest = 0n;
+  for (let i = 0; i < d.id.length; i++) digest = (digest + gen.rowDigest(d.id[i], d.field[i], d.ts[i], d.val[i])) & ((1n << 64n) - 1n);
+  assert.strictEqual(digest.toString(16), g.digest, "two sequential async halves == the whole batch");
+  await assert.rejects(crt.mergeBatchAsync({ id: new BigUint64Array([2n ** 64n - 1n]), field: new Uint32Array([1]), ts: new BigInt64Array([1n]), val: new BigInt64Array([1n]) }),
+    (e) => e.code === -5);
+  crt.close();
+  checks += 3;
+  console.log("device_parity ok:", checks, "checks");
+})().catch((e) => { console.error(e); process.exit(1); });

@@ -6,6 +6,7 @@
 #include <stdint.h>
 #include <math.h>
 #include <string.h>
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -32,7 +33,7 @@ napi_value throw_bmx(napi_env env, bmx_ctx* ctx, int rc) {
   return nullptr;
 }
 
-struct Handle { bmx_ctx* ctx; };
+struct Handle { bmx_ctx* ctx; std::mutex mu; };   // a context is not re-entrant: async work serialises on mu
 
 void finalize_handle(napi_env, void* data, void*) {
   Handle* h = static_cast<Handle*>(data);
@@ -98,7 +99,8 @@ napi_value Create(napi_env env, napi_callback_info info) {
   bmx_ctx* ctx = nullptr;
   int rc = bmx_create(device, (uint64_t)cap, 0, &ctx);
   if (rc) return throw_bmx(env, nullptr, rc);
-  Handle* h = new Handle{ctx};
+  Handle* h = new Handle();
+  h->ctx = ctx;
   napi_value ext;
   NAPI_OK(napi_create_external(env, h, finalize_handle, nullptr, &ext));
   return ext;
@@ -109,6 +111,7 @@ napi_value Destroy(napi_env env, napi_callback_info info) {
   void* p = nullptr;
   if (napi_get_value_external(env, argv[0], &p) == napi_ok && p) {
     Handle* h = static_cast<Handle*>(p);
+    std::lock_guard<std::mutex> g(h->mu);
     if (h->ctx) { bmx_destroy(h->ctx); h->ctx = nullptr; }
   }
   return nullptr;
@@ -134,6 +137,7 @@ napi_value MergeBatch(napi_env env, napi_callback_info info) {
   void* fl = nullptr;
   napi_value flags = make_ta(env, napi_uint8_array, 1, n, &fl);
   uint64_t na = 0; bmx_merge_stats st; memset(&st, 0, sizeof(st));
+  std::lock_guard<std::mutex> g(h->mu);
   int rc = bmx_merge_batch(h->ctx, n, id, field, ts, val, mode, BMX_MEM_HOST, applied.data(), &na, (uint8_t*)fl, &st);
   if (rc) return throw_bmx(env, h->ctx, rc);
   void* ap = nullptr;
@@ -144,6 +148,85 @@ napi_value MergeBatch(napi_env env, napi_callback_info info) {
   napi_set_named_property(env, out, "flags", flags);
   set_num(env, out, "nApplied", (double)st.n_applied); set_num(env, out, "nConflicts", (double)st.n_conflicts); set_num(env, out, "nRows", (double)st.n_rows);
   return out;
+}
+
+// ---- asynchronous merge: the H2D copy, kernels and D2H copy run on a libuv worker thread; resolves to the same object
+// as mergeBatch. The input typed arrays are referenced until completion (they must not be mutated meanwhile).
+struct MergeJob {
+  napi_async_work work = nullptr;
+  napi_deferred deferred = nullptr;
+  napi_ref refs[4] = {nullptr, nullptr, nullptr, nullptr};
+  Handle* h = nullptr;
+  const uint64_t* id = nullptr; const uint32_t* field = nullptr; const int64_t* ts = nullptr; const int64_t* val = nullptr;
+  size_t n = 0; int mode = 0;
+  std::vector<uint32_t> applied; std::vector<uint8_t> flags;
+  uint64_t na = 0; bmx_merge_stats st; int rc = 0; std::string err;
+};
+
+void merge_execute(napi_env, void* data) {
+  MergeJob* j = static_cast<MergeJob*>(data);
+  std::lock_guard<std::mutex> g(j->h->mu);
+  if (!j->h->ctx) { j->rc = BMX_ERR_INVALID; j->err = "engine closed"; return; }
+  j->rc = bmx_merge_batch(j->h->ctx, j->n, j->id, j->field, j->ts, j->val, j->mode, BMX_MEM_HOST, j->applied.data(), &j->na, j->flags.data(), &j->st);
+  if (j->rc) j->err = bmx_last_error(j->h->ctx);
+}
+
+void merge_complete(napi_env env, napi_status, void* data) {
+  MergeJob* j = static_cast<MergeJob*>(data);
+  for (auto& r : j->refs) if (r) napi_delete_reference(env, r);
+  if (j->rc) {
+    napi_value msg, err, code;
+    std::string m = "bmx error " + std::to_string(j->rc) + ": " + j->err;
+    napi_create_string_utf8(env, m.c_str(), NAPI_AUTO_LENGTH, &msg);
+    napi_create_error(env, nullptr, msg, &err);
+    napi_create_int32(env, j->rc, &code);
+    napi_set_named_property(env, err, "code", code);
+    napi_reject_deferred(env, j->deferred, err);
+  } else {
+    void *ap = nullptr, *fl = nullptr;
+    napi_value ta = make_ta(env, napi_uint32_array, 4, (size_t)j->na, &ap);
+    if (j->na) memcpy(ap, j->applied.data(), (size_t)j->na * 4);
+    napi_value fa = make_ta(env, napi_uint8_array, 1, j->n, &fl);
+    if (j->n) memcpy(fl, j->flags.data(), j->n);
+    napi_value out;
+    napi_create_object(env, &out);
+    napi_set_named_property(env, out, "applied", ta);
+    napi_set_named_property(env, out, "flags", fa);
+    set_num(env, out, "nApplied", (double)j->st.n_applied); set_num(env, out, "nConflicts", (double)j->st.n_conflicts); set_num(env, out, "nRows", (double)j->st.n_rows);
+    napi_resolve_deferred(env, j->deferred, out);
+  }
+  napi_delete_async_work(env, j->work);
+  delete j;
+}
+
+// mergeBatchAsync(h, id, field, ts, val, mode) -> Promise<{applied, flags, nApplied, nConflicts, nRows}>
+napi_value MergeBatchAsync(napi_env env, napi_callback_info info) {
+  ARGS(6);
+  Handle* h; if (!get_handle(env, argv[0], &h)) return nullptr;
+  MergeJob* j = new MergeJob();
+  j->h = h;
+  if (!get_cols(env, argv + 1, &j->id, &j->field, &j->ts, &j->val, &j->n)) { delete j; return nullptr; }
+  int32_t mode; if (napi_get_value_int32(env, argv[5], &mode) != napi_ok) { delete j; napi_throw_type_error(env, nullptr, "bmx: bad mode"); return nullptr; }
+  j->mode = mode;
+  j->applied.resize(j->n ? j->n : 1); j->flags.resize(j->n ? j->n : 1);
+  memset(&j->st, 0, sizeof(j->st));
+  for (int k = 0; k < 4; k++) napi_create_reference(env, argv[1 + k], 1, &j->refs[k]);
+  napi_value promise, name;
+  NAPI_OK(napi_create_promise(env, &j->deferred, &promise));
+  NAPI_OK(napi_create_string_utf8(env, "bmx.mergeBatchAsync", NAPI_AUTO_LENGTH, &name));
+  NAPI_OK(napi_create_async_work(env, nullptr, name, merge_execute, merge_complete, j, &j->work));
+  NAPI_OK(napi_queue_async_work(env, j->work));
+  return promise;
+}
+
+napi_value Reserve(napi_env env, napi_callback_info info) {
+  ARGS(2);
+  Handle* h; if (!get_handle(env, argv[0], &h)) return nullptr;
+  double cap; NAPI_OK(napi_get_value_double(env, argv[1], &cap));
+  std::lock_guard<std::mutex> g(h->mu);
+  int rc = bmx_reserve(h->ctx, (uint64_t)cap);
+  if (rc) return throw_bmx(env, h->ctx, rc);
+  return nullptr;
 }
 
 napi_value LoadRows(napi_env env, napi_callback_info info) {
@@ -282,7 +365,7 @@ napi_value Info(napi_env env, napi_callback_info info) {
 
 napi_value Init(napi_env env, napi_value exports) {
   struct { const char* name; napi_callback fn; } fns[] = {
-      {"abiVersion", AbiVersion}, {"create", Create}, {"destroy", Destroy}, {"mergeBatch", MergeBatch}, {"loadRows", LoadRows},
+      {"abiVersion", AbiVersion}, {"create", Create}, {"destroy", Destroy}, {"mergeBatch", MergeBatch}, {"mergeBatchAsync", MergeBatchAsync}, {"reserve", Reserve}, {"loadRows", LoadRows},
       {"getRows", GetRows}, {"rowCount", RowCount}, {"dumpRows", DumpRows}, {"indexBuild", IndexBuild}, {"indexDrop", IndexDrop},
       {"indexSize", IndexSize}, {"scanRange", ScanRange}, {"scanCount", ScanCount}, {"scanFilter", ScanFilter}, {"info", Info}};
   for (auto& f : fns) {
