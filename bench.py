@@ -215,12 +215,13 @@ def main():
         torch.cuda.synchronize()
 
         def run(lo, hi):
-            # exactly (hi-lo) routes and (hi-lo) merges; route b+1 (partition + all-to-all, comm stream) overlaps merge b:
-            # merge(b) is enqueued first so the GPU never waits for the host, route(b+1) follows on the other stream
+            # exactly (hi-lo) routes and (hi-lo) merges. route(b+1) is enqueued before merge(b): its partition runs on the merge
+            # stream ahead of merge(b), its all-to-all on the communication stream underneath merge(b)
             tk = sg.route(D_PER_STEP, *batches[lo])
             for b in range(lo, hi):
+                nxt = sg.route(D_PER_STEP, *batches[b + 1]) if b + 1 < hi else None
                 sg.merge(tk)
-                tk = sg.route(D_PER_STEP, *batches[b + 1]) if b + 1 < hi else None
+                tk = nxt
 
         if W:
             run(0, W)

@@ -13,8 +13,9 @@ semantics of the merge (smallest index wins ties / creates absent rows) stay wel
 Two ways to run a step:
   merge_step()        exact split sizes: the counts go through the host (two small syncs per step). Always safe.
   route() + merge()   pipelined: fixed-size slabs padded with reserved-id records (skipped by the merge), equal
-                      splits, no host round trip; partition + all-to-all of batch b+1 run on a second stream while
-                      batch b merges, so the exchange leaves the critical path. A slab overflow (one
+                      splits, no host round trip; call route(b+1) BEFORE merge(b): the partition of b+1 runs on the
+                      merge stream ahead of merge(b), its all-to-all on a second stream under merge(b), so the exchange
+                      leaves the critical path. A slab overflow (one
                       shard receiving > slab records from one origin) is reported by overflowed(); the caller then
                       re-sends that batch with merge_step() — merging is idempotent.
 
@@ -61,8 +62,9 @@ class EngineOps:
         self.e.partition_by_owner_dev(n, id, field, ts, val, nshards, recs_out, counts_out)
 
     def partition_slabs(self, n, id, field, ts, val, nshards, slab, recs_out, counts_out):
-        self._pipeline()
-        self.pe.partition_by_owner_slabs_dev(n, id, field, ts, val, nshards, slab, recs_out, counts_out)
+        # on the MERGE stream: the partition is short (~20 us alone) but slows to 60 us when it competes with the probe
+        # kernel for memory bandwidth, so it runs between two merges and only the all-to-all overlaps the merge
+        self.e.partition_by_owner_slabs_dev(n, id, field, ts, val, nshards, slab, recs_out, counts_out)
 
     def merge_records(self, n, recs, insert_mode, applied, n_applied):
         self.e.merge_records_dev(n, recs, insert_mode, applied=applied, n_applied=n_applied)
@@ -178,38 +180,60 @@ class ShardedGraph:
 
     # ---- pipelined mode ----------------------------------------------------------------------
     def setup_pipeline(self, max_deltas, slack=1.03, depth=2):
-        """Allocate `depth` send/receive slab sets for batches of up to max_deltas deltas per rank."""
+        """Allocate `depth` (>= 2) send/receive slab sets for batches of up to max_deltas deltas per rank. Protocol: call
+        route(b+1) before merge(b) and merge in route order; at most `depth` routed-but-unmerged batches may exist."""
+        assert depth >= 2
         W = self.world
         self.slab = int(max_deltas / W * slack) + 64
         self._pipe = []
         for _ in range(depth):
             self._pipe.append(dict(send=self.ops.empty_records(W * self.slab), recv=self.ops.empty_records(W * self.slab),
                                    counts=self.ops.zeros_i64(W), applied=self.ops.zeros_i32(W * self.slab), n_applied=self.ops.zeros_i64(1),
-                                   ready=self.ops.new_event(), free=self.ops.new_event(), used=False))
+                                   ready=self.ops.new_event(), free=self.ops.new_event(), parted=self.ops.new_event(), used=False))
         self._routed = 0
         self._merged = 0
+        self._due = []
 
     def route(self, n, id, field, ts, val):
-        """Enqueue partition + all-to-all of one batch on the communication stream; returns a ticket for merge()."""
+        """Enqueue the owner partition of one batch (merge stream) and remember that its exchange is due; returns a ticket
+        for merge(). The all-to-all itself is issued by the next merge() call AFTER that merge's kernels are enqueued, so
+        the (slow, host-side) collective call never delays kernels the GPU could already be running."""
+        assert self._routed - self._merged < len(self._pipe), "merge() the oldest routed batch before routing another"
         p = self._pipe[self._routed % len(self._pipe)]
         self._routed += 1
         with self.ops.comm_ctx():                             # GPU: a no-op after the first call (streams are set once)
-            if p["used"]:
-                self.ops.wait(p["free"], on_comm=True)        # the merge that last read these slabs is done
+            # merge stream: partition into the send slabs (the all-to-all that last read them finished before the merge
+            # that preceded this call on the same stream)
             self.ops.partition_slabs(n, id, field, ts, val, self.world, self.slab, p["send"], p["counts"])
-            self.dist.all_to_all_single(p["recv"], p["send"])  # equal splits: world slabs of `slab` records
-            self.ops.record(p["ready"], on_comm=True)
+            self.ops.record(p["parted"], on_comm=False)
         p["used"] = True
+        p["exchanged"] = False
+        self._due.append(p)
         self.sent_remote += n - n // self.world
         return p
 
+    def _exchange(self, p):
+        # communication stream: exchange once the slabs are written. `parted` was recorded on the merge stream AFTER the
+        # merge that last read these receive slabs (order on that stream: ... merge(b-2), partition(b), merge(b-1) ...
+        # with two slab sets), so waiting for it also protects recv: no separate "free" event is needed.
+        with self.ops.comm_ctx():
+            self.ops.wait(p["parted"], on_comm=True)
+            self.dist.all_to_all_single(p["recv"], p["send"])  # equal splits: world slabs of `slab` records
+            self.ops.record(p["ready"], on_comm=True)
+        p["exchanged"] = True
+
     def merge(self, ticket):
-        """Merge a routed batch on the merge stream (waits for its exchange on the device, not on the host)."""
+        """Merge a routed batch on the merge stream (waits for its exchange on the device, not on the host), then issue
+        the exchanges of the batches routed meanwhile."""
         p = ticket
+        if not p["exchanged"]:                                 # first batch of a pipeline: nothing to hide it behind
+            self._due.remove(p)
+            self._exchange(p)
         self.ops.wait(p["ready"], on_comm=False)
         nrecv = self.world * self.slab                         # padding records are skipped by the kernel
         self.ops.merge_records(nrecv, p["recv"], self.insert_mode, p["applied"], p["n_applied"])
-        self.ops.record(p["free"], on_comm=False)
+        while self._due:
+            self._exchange(self._due.pop(0))
         self._merged += 1
         self.n_steps += 1
         self.received += nrecv

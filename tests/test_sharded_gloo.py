@@ -61,7 +61,7 @@ class OracleOps:
         return None
 
     def record(self, ev, on_comm):
-        pass
+        pass   # CPU stand-in: everything is synchronous
 
     def wait(self, ev, on_comm):
         pass
