@@ -54,6 +54,7 @@ struct bmx_ctx {
   uint32_t* next = nullptr;
   uint8_t* wflag = nullptr;
   uint32_t* slot_of = nullptr;
+  uint32_t* blk_info = nullptr;       // ws_cap/256 block summaries (second set right behind the first for async compaction)
   unsigned long long* shard_ctr = nullptr;  // CTR_SHARDS * CTR_STRIDE
   // staging for BMX_MEM_HOST calls
   uint32_t st_cap = 0;
@@ -69,8 +70,6 @@ struct bmx_ctx {
   hipStream_t side = nullptr;
   uint8_t* wflag2 = nullptr;                  // second winner-byte buffer
   unsigned long long* shard_ctr2 = nullptr;   // second counter set
-  unsigned long long* granules2 = nullptr;    // granules of the side stream's selects
-  uint32_t sel_seq2 = 0;
   hipEvent_t ev_k2[2] = {nullptr, nullptr};   // main: K2 of the batch using buffer i is done
   hipEvent_t ev_k3[2] = {nullptr, nullptr};   // side: K3 of the batch using buffer i is done
   bool k3_pending[2] = {false, false};
@@ -164,11 +163,12 @@ int ensure_workspace(bmx_ctx* ctx, uint64_t n) {
   cap = std::max<uint64_t>(cap, 1u << 16);
   cap = (cap + 255) & ~255ull;
   { int rcj = join_side(ctx, true); if (rcj) return rcj; }
-  dev_free(ctx->next); dev_free(ctx->wflag); dev_free(ctx->wflag2); dev_free(ctx->slot_of);
+  dev_free(ctx->next); dev_free(ctx->wflag); dev_free(ctx->wflag2); dev_free(ctx->slot_of); dev_free(ctx->blk_info);
   ctx->ws_cap = 0;
   int rc;
   if ((rc = dev_alloc(ctx, &ctx->next, cap)) || (rc = dev_alloc(ctx, &ctx->wflag, cap + 16)) || (rc = dev_alloc(ctx, &ctx->slot_of, cap))) return rc;
   if (ctx->async_compact && (rc = dev_alloc(ctx, &ctx->wflag2, cap + 16))) return rc;
+  if ((rc = dev_alloc(ctx, &ctx->blk_info, 2 * (cap / 256 + 16)))) return rc;
   HIPCHK(hipMemsetAsync(ctx->next, 0, cap * sizeof(uint32_t), ctx->stream));
   ctx->ws_cap = (uint32_t)cap;
   return BMX_OK;
@@ -268,6 +268,7 @@ int merge_core(bmx_ctx* ctx, uint64_t n, const uint64_t* id, const uint32_t* fie
   A.n = (uint32_t)n; A.epoch = ctx->epoch;
   A.next = ctx->next; A.wflag = wflag; A.flags = flags;
   A.slot_of = ctx->slot_of; A.shard_ctr = ctr; A.status = &ctx->ds->status;
+  A.blk_info = ctx->blk_info + (bi ? (ctx->ws_cap / 256 + 16) : 0);
   const uint32_t blocks = (uint32_t)((n + 255) / 256);
   const uint32_t rblocks = blocks;   // one lane per delta
   hipEvent_t* pe = (ctx->prof_on && ctx->prof_n < PROF_MAX_CALLS) ? &ctx->prof_ev[4 * ctx->prof_n] : nullptr;
@@ -289,32 +290,15 @@ int merge_core(bmx_ctx* ctx, uint64_t n, const uint64_t* id, const uint32_t* fie
   if (pe) HIPCHK(hipEventRecord(pe[2], ctx->stream));
   // K3: ordered compaction of the winner bytes (on the side stream when asynchronous compaction is on)
   hipStream_t ks = ctx->stream;
-  unsigned long long* gran = ctx->granules;
-  uint32_t seq;
   if (ctx->async_compact) {
     HIPCHK(hipEventRecord(ctx->ev_k2[bi], ctx->stream));
     HIPCHK(hipStreamWaitEvent(ctx->side, ctx->ev_k2[bi], 0));
     ks = ctx->side;
-    gran = ctx->granules2;
-    if (++ctx->sel_seq2 >= (1u << 30)) {
-      HIPCHK(hipMemsetAsync(ctx->granules2, 0, SEL_MAX_BLOCKS * sizeof(unsigned long long), ctx->side));
-      ctx->sel_seq2 = 1;
-    }
-    seq = ctx->sel_seq2;
-  } else if ((rc = next_seq(ctx, &seq))) {
-    return rc;
   }
-  PredWinner P{wflag};
-  EmitApplied Em{applied_idx};
   FinishMerge Fin{reinterpret_cast<unsigned long long*>(n_applied), stats, ctr, &ctx->ds->row_count};
-  SelGeom g = sel_geom<PredWinner::E>(n);
-  if (g.tiles_per_block <= (uint32_t)SEL_STAGE)
-    hipLaunchKernelGGL((k_select_staged<PredWinner, EmitApplied, FinishMerge>), dim3(g.blocks), dim3(SEL_THREADS), 0, ks, P, Em, Fin, n,
-                       g.tiles_per_block, gran, seq, &ctx->ds->status);
-  else
-    hipLaunchKernelGGL((k_select<PredWinner, EmitApplied, FinishMerge>), dim3(g.blocks), dim3(SEL_THREADS), 0, ks, P, Em, Fin, n,
-                       g.tiles_per_block, gran, seq, &ctx->ds->status);
-  LAUNCHCHK("k_select");
+  hipLaunchKernelGGL((k_compact_winners<FinishMerge>), dim3((uint32_t)((n + 4095) / 4096)), dim3(SEL_THREADS), 0, ks, wflag, A.blk_info, (uint32_t)n,
+                     applied_idx, Fin);
+  LAUNCHCHK("k_compact_winners");
   if (ctx->async_compact) {
     HIPCHK(hipEventRecord(ctx->ev_k3[bi], ctx->side));
     ctx->k3_pending[bi] = true;
@@ -528,8 +512,6 @@ int bmx_create(int device, uint64_t capacity_rows, uint32_t flags, bmx_ctx** out
     for (int i = 0; i < 2; i++) { CR(hipEventCreateWithFlags(&ctx->ev_k2[i], hipEventDisableTiming)); CR(hipEventCreateWithFlags(&ctx->ev_k3[i], hipEventDisableTiming)); }
     if ((rc = dev_alloc(ctx, &ctx->shard_ctr2, CTR_SHARDS * CTR_STRIDE))) return bail(rc);
     CR(hipMemsetAsync(ctx->shard_ctr2, 0, CTR_SHARDS * CTR_STRIDE * sizeof(unsigned long long), ctx->stream));
-    if ((rc = dev_alloc(ctx, &ctx->granules2, SEL_MAX_BLOCKS))) return bail(rc);
-    CR(hipMemsetAsync(ctx->granules2, 0, SEL_MAX_BLOCKS * sizeof(unsigned long long), ctx->stream));
   }
   CR(hipMemsetAsync(ctx->ds, 0, sizeof(DevScalars), ctx->stream));
   hipLaunchKernelGGL(k_init_slots, dim3(2048), dim3(256), 0, ctx->stream, ctx->slots, nslots);
@@ -545,11 +527,11 @@ void bmx_destroy(bmx_ctx* ctx) {
   (void)hipSetDevice(ctx->device);
   if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
   if (ctx->side) (void)hipStreamSynchronize(ctx->side);
-  dev_free(ctx->wflag2); dev_free(ctx->shard_ctr2); dev_free(ctx->granules2);
+  dev_free(ctx->wflag2); dev_free(ctx->shard_ctr2);
   for (int i = 0; i < 2; i++) { if (ctx->ev_k2[i]) (void)hipEventDestroy(ctx->ev_k2[i]); if (ctx->ev_k3[i]) (void)hipEventDestroy(ctx->ev_k3[i]); }
   if (ctx->side) (void)hipStreamDestroy(ctx->side);
   for (auto& ix : ctx->indexes) { dev_free(ix.ids); dev_free(ix.v64); dev_free(ix.v32); }
-  dev_free(ctx->slots); dev_free(ctx->ds); dev_free(ctx->next); dev_free(ctx->wflag); dev_free(ctx->slot_of); dev_free(ctx->shard_ctr);
+  dev_free(ctx->slots); dev_free(ctx->ds); dev_free(ctx->next); dev_free(ctx->wflag); dev_free(ctx->slot_of); dev_free(ctx->blk_info); dev_free(ctx->shard_ctr);
   dev_free(ctx->st_id); dev_free(ctx->st_field); dev_free(ctx->st_ts); dev_free(ctx->st_val); dev_free(ctx->st_applied); dev_free(ctx->st_flags);
   dev_free(ctx->scan_out); dev_free(ctx->block_counts); dev_free(ctx->part_counts); dev_free(ctx->granules);
   for (auto ev : ctx->prof_ev) (void)hipEventDestroy(ev);

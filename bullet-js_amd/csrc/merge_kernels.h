@@ -42,11 +42,13 @@ struct MergeArgs {
                               //            W_PENDING = needs k_resolve_lists (duplicate key / reference-mode insert)
   uint8_t* flags;             // optional decision flags
   uint32_t* slot_of;          // per delta, written for W_PENDING deltas only: the row's slot
+  uint32_t* blk_info;         // per 256-delta block: bit 31 = block has pending deltas, bits 0..30 = winners in the block
   unsigned long long* shard_ctr;  // CTR_SHARDS x CTR_STRIDE counters: [s][0] rows created, [s][1] conflicts
   uint32_t* status;
 };
 
 constexpr uint8_t W_NONE = 0, W_WINNER = 1, W_PENDING = 2;
+constexpr uint32_t BLK_PENDING = 0x80000000u, BLK_COUNT = 0x7FFFFFFFu;
 // A single hot word takes only ~88 atomics/us (MI355X_MICROARCH.md "dequeue"), so per-batch counters are
 // spread over 256 words on separate 128-B lines and folded once per batch by the last compaction block.
 constexpr uint32_t CTR_SHARDS = 256, CTR_STRIDE = 16;
@@ -198,6 +200,15 @@ __global__ __launch_bounds__(256) void k_probe_apply(MergeArgs A) {
     A.wflag[j] = (uint8_t)wf;
     if (A.flags) A.flags[j] = (uint8_t)fl;
   }
+  // block summary for the two passes that follow: they skip blocks without pending deltas and need no counting phase
+  {
+    __shared__ uint32_t s_w[4], s_p[4];
+    unsigned long long mw = __ballot(wf == W_WINNER), mp = __ballot(wf == W_PENDING);
+    if (lane_id() == 0) { s_w[threadIdx.x >> 6] = (uint32_t)__popcll(mw); s_p[threadIdx.x >> 6] = mp != 0ull; }
+    __syncthreads();
+    if (threadIdx.x == 0)
+      A.blk_info[blockIdx.x] = (s_w[0] + s_w[1] + s_w[2] + s_w[3]) | ((s_p[0] | s_p[1] | s_p[2] | s_p[3]) ? BLK_PENDING : 0u);
+  }
 }
 
 // Pending pass (duplicate keys only): one lane per delta, so every walker starts at once (the pass is latency bound:
@@ -255,14 +266,19 @@ __device__ __forceinline__ void resolve_long(const MergeArgs& A, uint32_t j, Slo
     else if (c == 0 && owner != ~0u && o1 < owner) owner = o1;
   }
   store_tv(sl, is_new ? (bt | ((int64_t)A.epoch << TS_MARK_SHIFT)) : bt, bv);
-  if (base_owner != ~0u && base_owner != owner) A.wflag[base_owner] = W_NONE;
-  if (owner != ~0u) { A.wflag[owner] = W_WINNER; if (A.flags) A.flags[owner] = (uint8_t)BMX_FLAG_INCOMING; }
+  // move the winner mark (and the per-block winner counts the compaction relies on) from the first claimer to the owner
+  if (base_owner != owner) {
+    if (base_owner != ~0u) { A.wflag[base_owner] = W_NONE; atomicSub(&A.blk_info[base_owner >> 8], 1u); }
+    if (owner != ~0u) { A.wflag[owner] = W_WINNER; atomicAdd(&A.blk_info[owner >> 8], 1u); }
+  }
+  if (owner != ~0u && A.flags) A.flags[owner] = (uint8_t)BMX_FLAG_INCOMING;
 }
 
 constexpr int RES_CAP = 8;  // list nodes kept in registers by the single-walk fast path
 
 template <bool AOS, int MODE>
 __global__ __launch_bounds__(256) void k_resolve_lists(MergeArgs A) {
+  if (!(A.blk_info[blockIdx.x] & BLK_PENDING)) return;      // whole block: nothing pending (same 256-delta blocks as k_probe_apply)
   const uint32_t j = blockIdx.x * 256u + threadIdx.x;
   if (j >= A.n || A.wflag[j] != W_PENDING) return;
   // independent loads first: this delta's value, its link, and the row (one line)
@@ -315,8 +331,12 @@ __global__ __launch_bounds__(256) void k_resolve_lists(MergeArgs A) {
     }
   }
   store_tv(sl, is_new ? (bt | ((int64_t)A.epoch << TS_MARK_SHIFT)) : bt, bv);
-  if (base_owner != ~0u && base_owner != owner) A.wflag[base_owner] = W_NONE;
-  if (owner != ~0u) { A.wflag[owner] = W_WINNER; if (A.flags) A.flags[owner] = (uint8_t)BMX_FLAG_INCOMING; }
+  // move the winner mark (and the per-block winner counts the compaction relies on) from the first claimer to the owner
+  if (base_owner != owner) {
+    if (base_owner != ~0u) { A.wflag[base_owner] = W_NONE; atomicSub(&A.blk_info[base_owner >> 8], 1u); }
+    if (owner != ~0u) { A.wflag[owner] = W_WINNER; atomicAdd(&A.blk_info[owner >> 8], 1u); }
+  }
+  if (owner != ~0u && A.flags) A.flags[owner] = (uint8_t)BMX_FLAG_INCOMING;
 }
 
 // epoch wrap: forget every claim tag and every creation mark

@@ -188,6 +188,34 @@ struct FinishMerge {  // totals -> caller; fold and clear the sharded per-batch 
   }
 };
 
+// K3 proper: ordered compaction of the winner bytes into applied_idx. The per-256-delta winner counts were left by
+// k_probe_apply (and adjusted by k_resolve_lists), so a block gets its global rank from a prefix over counts written by
+// EARLIER launches: no counting phase, no in-launch hand-off. One block = 4096 deltas = 16 count entries.
+template <class Finish>
+__global__ __launch_bounds__(SEL_THREADS) void k_compact_winners(const uint8_t* __restrict__ wflag, const uint32_t* __restrict__ blk_info, uint32_t n,
+                                                                  uint32_t* __restrict__ applied, Finish Fin) {
+  __shared__ uint32_t wsum[4];
+  // both loads are issued before the first wait: this block's 16 winner bytes per lane and its share of the count prefix
+  PredWinner P{wflag};
+  const uint64_t first = (uint64_t)blockIdx.x * 4096u + (uint64_t)threadIdx.x * 16u;
+  uint32_t m = first < n ? P.mask(first, n) : 0u;
+  const uint32_t first_kb = blockIdx.x * 16u;
+  uint32_t part = 0;
+  for (uint32_t k = threadIdx.x; k < first_kb; k += SEL_THREADS) part += blk_info[k] & BLK_COUNT;
+  uint32_t offset;
+  block_excl_scan(part, offset, wsum);
+  uint32_t tot;
+  uint32_t pos = offset + block_excl_scan((uint32_t)__popc(m), tot, wsum);
+  if (applied) {
+    while (m) {
+      int e = __ffs((int)m) - 1;
+      m &= m - 1;
+      applied[pos++] = (uint32_t)first + (uint32_t)e;
+    }
+  }
+  if (blockIdx.x == gridDim.x - 1) Fin((uint64_t)offset + tot, wsum);
+}
+
 __global__ void k_sum_counts(const uint32_t* block_counts, uint32_t nblocks, unsigned long long* n_out) {
   __shared__ uint32_t wsum[4];
   uint32_t part = 0;
