@@ -73,13 +73,16 @@ def scan_bench(bmx, dev, R=10_000_000, reps=20):
     """Config 3 (extra fields, not the headline): range/equals scans over an indexed int32 field of R nodes.
     Algorithmic bytes = 4*R (value column) + 8*M (ids out); time = HIP events around `reps` back-to-back scans."""
     from bmx import synth
-    ids = synth.splitmix64_np(np.arange(1, R + 1, dtype=np.uint64))
-    with np.errstate(over="ignore"):
-        ages = (synth.splitmix64_np(ids ^ np.uint64(0xABCDEF)) % np.uint64(1000)).astype(np.int64)
     fa = synth.fnv1a32("n:age")
     out = {}
     with bmx.Engine(capacity_rows=R + 1024, device=dev.index or 0) as e:
-        e.load_rows(ids, np.full(R, fa, np.uint32), np.full(R, 5, np.int64), ages)
+        for r0 in range(0, R, 10_000_000):          # load in 10M-row pieces: bounded host memory
+            m = min(10_000_000, R - r0)
+            ids = synth.splitmix64_np(np.arange(r0 + 1, r0 + m + 1, dtype=np.uint64))
+            with np.errstate(over="ignore"):
+                ages = (synth.splitmix64_np(ids ^ np.uint64(0xABCDEF)) % np.uint64(1000)).astype(np.int64)
+            e.load_rows(ids, np.full(m, fa, np.uint32), np.full(m, 5, np.int64), ages)
+        del ids, ages
         t0 = time.perf_counter(); e.index_build(fa); out["index_build_ms"] = round((time.perf_counter() - t0) * 1e3, 3)
         out_ids = torch.zeros(R, dtype=torch.int64, device=dev)
         n_out = torch.zeros(1, dtype=torch.int64, device=dev)
@@ -109,6 +112,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--scan", action="store_true", help="also measure the config-3 index scans (extra fields)")
+    ap.add_argument("--scan-rows", type=int, default=10_000_000, help="rows of the scanned index (100000000 puts the int32 column beyond the 256 MiB Infinity Cache)")
     ap.add_argument("--force-sharded", action="store_true", help="run the N>1 code path (partition + all-to-all + merge) even with one rank: rehearsal only")
     args = ap.parse_args()
 
@@ -251,7 +255,8 @@ def main():
                "data": "synthetic", "config": cfg, "roofline": roofline}
         out.update(extra)
         if not sharded and args.scan:
-            out["scan_config3"] = scan_bench(bmx, dev)
+            out["scan_config3"] = scan_bench(bmx, dev, R=args.scan_rows)
+            out["scan_config3"]["rows"] = args.scan_rows
         if not sharded and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline()
         else:

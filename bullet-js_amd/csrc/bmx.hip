@@ -62,8 +62,9 @@ struct bmx_ctx {
   uint32_t* st_applied = nullptr; uint8_t* st_flags = nullptr;
   uint64_t scan_cap = 0; uint64_t* scan_out = nullptr;
   uint32_t* block_counts = nullptr;   // SEL_MAX_BLOCKS
-  unsigned long long* granules = nullptr;  // SEL_MAX_BLOCKS look-back granules {seq, count}
-  uint32_t sel_seq = 0;               // sequence number of the last k_select call (never 0 in a granule)
+  uint32_t* scan_mask = nullptr;      // scan scratch: one match bit per index row
+  uint32_t* scan_counts = nullptr;    // scan scratch: matches per 8192-row block (+ total)
+  uint64_t scan_blocks_cap = 0;
   // BMX_CTX_ASYNC_COMPACT: K3 of batch b runs on `side` while K1 of batch b+1 runs on `stream`
   bool fixed_capacity = false;
   bool async_compact = false;
@@ -209,16 +210,6 @@ int grow_table(bmx_ctx* ctx, uint64_t capacity_rows) {
   // the batch epoch keeps counting: next[] still holds links tagged with earlier epochs; the new heads are all 0
   ctx->version++;          // indices are rebuilt on their next use
   return check_status(ctx);
-}
-
-// Sequence number for the next k_select call; granules are re-zeroed when it wraps.
-int next_seq(bmx_ctx* ctx, uint32_t* seq) {
-  if (++ctx->sel_seq >= (1u << 30)) {
-    HIPCHK(hipMemsetAsync(ctx->granules, 0, SEL_MAX_BLOCKS * sizeof(unsigned long long), ctx->stream));
-    ctx->sel_seq = 1;
-  }
-  *seq = ctx->sel_seq;
-  return BMX_OK;
 }
 
 // The merge proper: all pointers are device pointers; only enqueues work.
@@ -405,37 +396,52 @@ int ensure_scan_out(bmx_ctx* ctx, uint64_t n) {
   return BMX_OK;
 }
 
+// scratch of the scans: one match bit per index row + one count per 8192-row block (+1 for the total)
+int ensure_scan_scratch(bmx_ctx* ctx, uint64_t n) {
+  uint64_t nb = (n + SCAN_BLOCK_ELEMS - 1) / SCAN_BLOCK_ELEMS;
+  if (nb <= ctx->scan_blocks_cap) return BMX_OK;
+  HIPCHK(hipStreamSynchronize(ctx->stream));
+  dev_free(ctx->scan_mask); dev_free(ctx->scan_counts);
+  ctx->scan_blocks_cap = 0;
+  uint64_t cap = nb + nb / 4 + 16;
+  int rc;
+  if ((rc = dev_alloc(ctx, &ctx->scan_mask, cap * (SCAN_BLOCK_ELEMS / 32))) || (rc = dev_alloc(ctx, &ctx->scan_counts, cap + 1))) return rc;
+  ctx->scan_blocks_cap = cap;
+  return BMX_OK;
+}
+
 // Run one predicate over an index and deliver ids / count according to `mem`.
 template <class Pred>
 int run_scan(bmx_ctx* ctx, const Pred& P, const Index* ix, uint64_t* out_ids, uint64_t cap, uint64_t* n_out, int mem) {
-  SelGeom g = sel_geom<Pred::E>(ix->n);
   const bool host = mem == BMX_MEM_HOST;
   uint64_t* d_out = out_ids;
   uint64_t d_cap = cap;
+  int rc;
   if (host && out_ids) {
     d_cap = std::min<uint64_t>(cap, ix->n);
-    int rc = ensure_scan_out(ctx, std::max<uint64_t>(d_cap, 1));
-    if (rc) return rc;
+    if ((rc = ensure_scan_out(ctx, std::max<uint64_t>(d_cap, 1)))) return rc;
     d_out = ctx->scan_out;
   }
+  if ((rc = ensure_scan_scratch(ctx, std::max<uint64_t>(ix->n, 1)))) return rc;
   unsigned long long* d_n = host ? &ctx->ds->n_out : reinterpret_cast<unsigned long long*>(n_out);
+  const uint32_t nb = (uint32_t)((std::max<uint64_t>(ix->n, 1) + SCAN_BLOCK_ELEMS - 1) / SCAN_BLOCK_ELEMS);
   if (d_out) {
+    // pass 1: one read of the column -> match mask + block counts; pass 2: ids from the mask
+    hipLaunchKernelGGL((k_scan_mask<Pred, true>), dim3(nb), dim3(SEL_THREADS), 0, ctx->stream, P, ix->n, ctx->scan_mask, ctx->scan_counts);
+    LAUNCHCHK("k_scan_mask");
+    const bool scanned = nb > 2048;   // many blocks: one small launch turns the counts into offsets
+    if (scanned) {
+      hipLaunchKernelGGL(k_scan_offsets, dim3(1), dim3(SEL_THREADS), 0, ctx->stream, ctx->scan_counts, nb);
+      LAUNCHCHK("k_scan_offsets");
+    }
     EmitIds Em{ix->ids, d_out, d_cap};
     FinishCount Fin{d_n};
-    uint32_t seq;
-    int rc = next_seq(ctx, &seq);
-    if (rc) return rc;
-    if (g.tiles_per_block <= (uint32_t)SEL_STAGE)
-      hipLaunchKernelGGL((k_select_staged<Pred, EmitIds, FinishCount>), dim3(g.blocks), dim3(SEL_THREADS), 0, ctx->stream, P, Em, Fin, ix->n,
-                         g.tiles_per_block, ctx->granules, seq, &ctx->ds->status);
-    else
-      hipLaunchKernelGGL((k_select<Pred, EmitIds, FinishCount>), dim3(g.blocks), dim3(SEL_THREADS), 0, ctx->stream, P, Em, Fin, ix->n,
-                         g.tiles_per_block, ctx->granules, seq, &ctx->ds->status);
-    LAUNCHCHK("k_select(scan)");
+    hipLaunchKernelGGL((k_scan_emit<EmitIds, FinishCount>), dim3(nb), dim3(SEL_THREADS), 0, ctx->stream, ctx->scan_mask, ctx->scan_counts, scanned, ix->n, Em, Fin);
+    LAUNCHCHK("k_scan_emit");
   } else if (d_n) {
-    hipLaunchKernelGGL((k_sel_count<Pred>), dim3(g.blocks), dim3(SEL_THREADS), 0, ctx->stream, P, ix->n, g.tiles_per_block, ctx->block_counts);
-    LAUNCHCHK("k_sel_count(scan)");
-    hipLaunchKernelGGL(k_sum_counts, dim3(1), dim3(SEL_THREADS), 0, ctx->stream, ctx->block_counts, g.blocks, d_n);
+    hipLaunchKernelGGL((k_scan_mask<Pred, false>), dim3(nb), dim3(SEL_THREADS), 0, ctx->stream, P, ix->n, ctx->scan_mask, ctx->scan_counts);
+    LAUNCHCHK("k_scan_mask(count)");
+    hipLaunchKernelGGL(k_sum_counts, dim3(1), dim3(SEL_THREADS), 0, ctx->stream, ctx->scan_counts, nb, d_n);
     LAUNCHCHK("k_sum_counts");
   }
   if (host) {
@@ -501,8 +507,6 @@ int bmx_create(int device, uint64_t capacity_rows, uint32_t flags, bmx_ctx** out
   if ((rc = dev_alloc(ctx, &ctx->ds, 1))) return bail(rc);
   if ((rc = dev_alloc(ctx, &ctx->block_counts, SEL_MAX_BLOCKS))) return bail(rc);
   if ((rc = dev_alloc(ctx, &ctx->part_counts, PART_MAX_SHARDS * PART_BLOCKS))) return bail(rc);
-  if ((rc = dev_alloc(ctx, &ctx->granules, SEL_MAX_BLOCKS))) return bail(rc);
-  CR(hipMemsetAsync(ctx->granules, 0, SEL_MAX_BLOCKS * sizeof(unsigned long long), ctx->stream));
   if ((rc = dev_alloc(ctx, &ctx->shard_ctr, CTR_SHARDS * CTR_STRIDE))) return bail(rc);
   CR(hipMemsetAsync(ctx->shard_ctr, 0, CTR_SHARDS * CTR_STRIDE * sizeof(unsigned long long), ctx->stream));
   ctx->fixed_capacity = (flags & BMX_CTX_FIXED_CAPACITY) != 0;
@@ -533,7 +537,7 @@ void bmx_destroy(bmx_ctx* ctx) {
   for (auto& ix : ctx->indexes) { dev_free(ix.ids); dev_free(ix.v64); dev_free(ix.v32); }
   dev_free(ctx->slots); dev_free(ctx->ds); dev_free(ctx->next); dev_free(ctx->wflag); dev_free(ctx->slot_of); dev_free(ctx->blk_info); dev_free(ctx->shard_ctr);
   dev_free(ctx->st_id); dev_free(ctx->st_field); dev_free(ctx->st_ts); dev_free(ctx->st_val); dev_free(ctx->st_applied); dev_free(ctx->st_flags);
-  dev_free(ctx->scan_out); dev_free(ctx->block_counts); dev_free(ctx->part_counts); dev_free(ctx->granules);
+  dev_free(ctx->scan_out); dev_free(ctx->block_counts); dev_free(ctx->part_counts); dev_free(ctx->scan_mask); dev_free(ctx->scan_counts);
   for (auto ev : ctx->prof_ev) (void)hipEventDestroy(ev);
   if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
   if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);

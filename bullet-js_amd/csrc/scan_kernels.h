@@ -143,7 +143,7 @@ struct FinishCount {  // total -> *n_out (device), optional
   __device__ void operator()(uint64_t total, uint32_t*) const { if (n_out && threadIdx.x == 0) *n_out = total; }
 };
 
-// K3 winner compaction over the per-delta winner bytes: 16 flags (16 B) per lane
+// winner bytes -> bit mask: 16 flags (16 B) per lane (used by k_compact_winners)
 struct PredWinner {
   static constexpr int E = 16;
   const uint8_t* w;

@@ -1,15 +1,11 @@
-// select.h — ordered (stable) stream compaction: the prefix-sum winner compaction K3 and the match
-// compaction of the index scans K5/K6 share these skeletons. Output order = element order (deterministic).
+// select.h — ordered (stable) stream compaction skeletons. Output order = element order (deterministic). Workgroups never
+// talk to each other inside a launch: ranks always come from counts an EARLIER launch left behind (a single-launch
+// look-back variant was built and measured: its cross-CU hand-off costs ~4 us per launch and forces a second read of
+// large columns).
 //
-// ONE launch (k_select / k_select_staged): block b counts the selected elements of its contiguous chunk, publishes
-//   the count as an 8-byte {call sequence number, count} granule with ONE agent-scope atomic store
-//   sums the granules of blocks 0..b-1 (relaxed agent-scope loads, all of a thread's polls in flight together),
-//   then writes its chunk at the global rank. Every block publishes BEFORE it waits and the grid (<= 1024 blocks of
-//   256 threads) is fully resident, so the waits terminate; spins are bounded anyway. This is the "data is the
-//   flag" hand-off of cdna_hip_programming.md G16 (R2): no fence, no plain loads of handed-off bytes; the sequence
-//   number makes re-initialisation unnecessary (granules are re-zeroed when the sequence wraps).
-// TWO launches (k_sel_count + k_sel_write): used where the host needs the total before the output exists
-//   (index build sizes its columns from it).
+// k_sel_count + k_sel_write : generic two-launch select over any predicate (index build, row dump); the predicate is
+//                              evaluated twice.
+// k_scan_mask + k_scan_emit  : index scans; the column is read once, pass 2 works from a 1-bit-per-row mask.
 //
 // Pred  : struct { static constexpr int E; __device__ uint32_t mask(uint64_t first, uint64_t n) const; }
 //         thread owns E consecutive elements [first, first+E); bit e set <=> element first+e selected (and < n)
@@ -21,8 +17,7 @@
 namespace bmx {
 
 constexpr int SEL_THREADS = 256;
-constexpr int SEL_MAX_BLOCKS = 1024;   // <= 4 blocks of 256 threads per CU: the whole grid is resident
-constexpr int SEL_STAGE = 12;          // tiles whose masks a block keeps in registers between counting and writing
+constexpr int SEL_MAX_BLOCKS = 1024;          // tiles whose masks a block keeps in registers between counting and writing
 
 struct SelGeom {
   uint32_t blocks;
@@ -109,112 +104,86 @@ __global__ __launch_bounds__(SEL_THREADS) void k_sel_write(Pred P, Emit Em, Fini
 }
 
 
-// ---- look-back over per-block aggregates ----
-// granule = call sequence number << 32 | this block's count, published with ONE agent-scope atomic store before the
-// block waits for anything. Block b sums granules 0..b-1: each thread owns at most SEL_MAX_BLOCKS/256 of them and
-// issues all its loads together, re-polling only those not yet published. There is no block-to-block chain (a
-// chained inclusive-prefix look-back measured slower here: ~0.8 us per cross-CU hop x 32 hops).
-__device__ __forceinline__ uint32_t lookback_exclusive(unsigned long long* granules, uint32_t seq, uint32_t mine, uint32_t* status,
-                                                       uint32_t* wsum /* 4 LDS words */) {
-  if (threadIdx.x == 0)
-    __hip_atomic_store(granules + blockIdx.x, ((unsigned long long)seq << 32) | mine, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  constexpr int NP = SEL_MAX_BLOCKS / SEL_THREADS;
-  uint32_t part = 0, pending = 0;
+// ---- index scans: match mask + counts (pass 1), emit from the mask (pass 2) ----
+// Pass 1 streams the value column ONCE (every lane has 32/E x 16 B in flight), packs the per-lane match bits into one
+// bit per element with wave shuffles and leaves one count per 8192-element block. Pass 2 reads only the mask (1/32 of an
+// int32 column) and writes the matching ids at ranks derived from the counts of the PREVIOUS launch: no in-launch
+// communication between workgroups, any column size, deterministic element order.
+constexpr uint32_t SCAN_BLOCK_ELEMS = 8192;   // elements per block in both passes = 256 mask words
+
+template <class Pred, bool WRITE_MASK>
+__global__ __launch_bounds__(SEL_THREADS) void k_scan_mask(Pred P, uint64_t n, uint32_t* __restrict__ mask_words, uint32_t* __restrict__ block_counts) {
+  constexpr int E = Pred::E;
+  constexpr int TILES = 32 / E;   // tiles of 256*E elements per block
+  constexpr int LPW = 32 / E;     // lanes that share one 32-bit mask word
+  __shared__ uint32_t wsum[4];
+  const uint64_t base = (uint64_t)blockIdx.x * SCAN_BLOCK_ELEMS;
+  uint32_t m[TILES];
 #pragma unroll
-  for (int k = 0; k < NP; k++) if (threadIdx.x + k * SEL_THREADS < blockIdx.x) pending |= 1u << k;
-  uint32_t spins = 0;
-  while (pending) {
-    unsigned long long g[NP];
+  for (int k = 0; k < TILES; k++) {
+    uint64_t first = base + (uint64_t)k * SEL_THREADS * E + (uint64_t)threadIdx.x * E;
+    m[k] = first < n ? P.mask(first, n) : 0u;
+  }
+  uint32_t cnt = 0;
 #pragma unroll
-    for (int k = 0; k < NP; k++)
-      g[k] = (pending >> k & 1u) ? __hip_atomic_load(granules + threadIdx.x + k * SEL_THREADS, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0ull;
+  for (int k = 0; k < TILES; k++) {
+    cnt += __popc(m[k]);
+    if (WRITE_MASK) {
+      uint32_t v = m[k] << (E * (threadIdx.x & (LPW - 1)));
 #pragma unroll
-    for (int k = 0; k < NP; k++)
-      if ((pending >> k & 1u) && (uint32_t)(g[k] >> 32) == seq) { part += (uint32_t)g[k]; pending &= ~(1u << k); }
-    if (pending) {
-      if (++spins > (1u << 22)) { atomicOr(status, ST_SPIN); break; }
-      __builtin_amdgcn_s_sleep(1);
+      for (int d = 1; d < LPW; d <<= 1) v |= __shfl_xor(v, d);
+      if ((threadIdx.x & (LPW - 1)) == 0)
+        mask_words[(base + (uint64_t)k * SEL_THREADS * E + (uint64_t)threadIdx.x * E) >> 5] = v;
     }
   }
   uint32_t total;
-  block_excl_scan(part, total, wsum);
-  return total;
+  block_excl_scan(cnt, total, wsum);
+  if (threadIdx.x == 0) block_counts[blockIdx.x] = total;
 }
 
-// ---- single-launch variant with look-back granules ----
-template <class Pred, class Emit, class Finish>
-__global__ __launch_bounds__(SEL_THREADS) void k_select(Pred P, Emit Em, Finish Fin, uint64_t n, uint32_t tiles_per_block,
-                                                         unsigned long long* granules, uint32_t seq, uint32_t* status) {
+// exclusive scan of the block counts in place (one workgroup; used when there are too many blocks for each emitting
+// block to sum its predecessors itself); total -> counts[nb]
+__global__ __launch_bounds__(SEL_THREADS) void k_scan_offsets(uint32_t* counts, uint32_t nb) {
   __shared__ uint32_t wsum[4];
-  constexpr int E = Pred::E;
-  const uint64_t tile = (uint64_t)SEL_THREADS * E;
-  const uint64_t t0 = (uint64_t)blockIdx.x * tiles_per_block;
-  // 1. count this block's chunk and publish it
-  uint32_t cnt = 0;
-  for (uint32_t k = 0; k < tiles_per_block; k++) {
-    uint64_t first = (t0 + k) * tile + (uint64_t)threadIdx.x * E;
-    if (first < n) cnt += __popc(P.mask(first, n));
-  }
-  uint32_t mine;
-  block_excl_scan(cnt, mine, wsum);
-  // 2. rank of the chunk's first selected element = sum of the predecessors' counts (decoupled look-back)
-  const uint32_t offset = lookback_exclusive(granules, seq, mine, status, wsum);
-  // 3. re-evaluate (the chunk is L2-hot) and write in order
-  uint64_t running = offset;
-  for (uint32_t k = 0; k < tiles_per_block; k++) {
-    uint64_t first = (t0 + k) * tile + (uint64_t)threadIdx.x * E;
-    uint32_t m = first < n ? P.mask(first, n) : 0u;
+  uint32_t carry = 0;
+  for (uint32_t b0 = 0; b0 < nb; b0 += SEL_THREADS) {
+    uint32_t i = b0 + threadIdx.x;
+    uint32_t c = i < nb ? counts[i] : 0u;
     uint32_t tot;
-    uint32_t ex = block_excl_scan((uint32_t)__popc(m), tot, wsum);
-    uint64_t pos = running + ex;
-    while (m) {
-      int e = __ffs((int)m) - 1;
-      m &= m - 1;
-      Em(pos++, first + (uint64_t)e);
-    }
-    running += tot;
+    uint32_t ex = block_excl_scan(c, tot, wsum);
+    if (i < nb) counts[i] = carry + ex;
+    carry += tot;
   }
-  if (blockIdx.x == gridDim.x - 1) Fin(running, wsum);
+  if (threadIdx.x == 0) counts[nb] = carry;
 }
 
-// Register-staged variant for tiles_per_block <= SEL_STAGE: every load of the chunk is issued before the first
-// wait (SEL_STAGE x 16 B in flight per lane), the predicate masks stay in registers, the input is read ONCE.
-template <class Pred, class Emit, class Finish>
-__global__ __launch_bounds__(SEL_THREADS) void k_select_staged(Pred P, Emit Em, Finish Fin, uint64_t n, uint32_t tiles_per_block,
-                                                                unsigned long long* granules, uint32_t seq, uint32_t* status) {
+template <class Emit, class Finish>
+__global__ __launch_bounds__(SEL_THREADS) void k_scan_emit(const uint32_t* __restrict__ mask_words, const uint32_t* __restrict__ counts, bool scanned,
+                                                            uint64_t n, Emit Em, Finish Fin) {
   __shared__ uint32_t wsum[4];
-  constexpr int E = Pred::E;
-  const uint64_t tile = (uint64_t)SEL_THREADS * E;
-  const uint64_t t0 = (uint64_t)blockIdx.x * tiles_per_block;
-  uint32_t m[SEL_STAGE];
-  uint32_t cnt = 0;
-#pragma unroll
-  for (int k = 0; k < SEL_STAGE; k++) {
-    uint64_t first = (t0 + k) * tile + (uint64_t)threadIdx.x * E;
-    m[k] = ((uint32_t)k < tiles_per_block && first < n) ? P.mask(first, n) : 0u;
+  __shared__ uint16_t loc[SCAN_BLOCK_ELEMS];   // block-local row offsets of the matches, in rank order (16 KB)
+  const uint64_t w = (uint64_t)blockIdx.x * SEL_THREADS + threadIdx.x;
+  uint32_t mk = (w << 5) < n ? mask_words[w] : 0u;
+  uint32_t offset;
+  if (scanned) {
+    offset = counts[blockIdx.x];
+  } else {
+    uint32_t part = 0;
+    for (uint32_t b = threadIdx.x; b < blockIdx.x; b += SEL_THREADS) part += counts[b];
+    block_excl_scan(part, offset, wsum);
   }
-#pragma unroll
-  for (int k = 0; k < SEL_STAGE; k++) cnt += __popc(m[k]);
-  uint32_t mine;
-  block_excl_scan(cnt, mine, wsum);
-  const uint32_t offset = lookback_exclusive(granules, seq, mine, status, wsum);
-  uint64_t running = offset;
-#pragma unroll
-  for (int k = 0; k < SEL_STAGE; k++) {
-    if ((uint32_t)k < tiles_per_block) {   // uniform across the block
-      uint64_t first = (t0 + k) * tile + (uint64_t)threadIdx.x * E;
-      uint32_t mk = m[k], tot;
-      uint32_t ex = block_excl_scan((uint32_t)__popc(mk), tot, wsum);
-      uint64_t pos = running + ex;
-      while (mk) {
-        int e = __ffs((int)mk) - 1;
-        mk &= mk - 1;
-        Em(pos++, first + (uint64_t)e);
-      }
-      running += tot;
-    }
+  uint32_t tot;
+  uint32_t r = block_excl_scan((uint32_t)__popc(mk), tot, wsum);
+  // transpose through LDS: a lane owns 32 consecutive rows, but the output wants consecutive lanes on consecutive ranks
+  while (mk) {
+    int e = __ffs((int)mk) - 1;
+    mk &= mk - 1;
+    loc[r++] = (uint16_t)(threadIdx.x * 32u + (uint32_t)e);
   }
-  if (blockIdx.x == gridDim.x - 1) Fin(running, wsum);
+  __syncthreads();
+  const uint64_t base = (uint64_t)blockIdx.x * SCAN_BLOCK_ELEMS;
+  for (uint32_t k = threadIdx.x; k < tot; k += SEL_THREADS) Em((uint64_t)offset + k, base + loc[k]);   // coalesced stores, near-sequential gathers
+  if (blockIdx.x == gridDim.x - 1) Fin((uint64_t)offset + tot, wsum);
 }
 
 }  // namespace bmx
