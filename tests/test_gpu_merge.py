@@ -274,3 +274,23 @@ def test_duplicate_heavy_random_vs_oracle(seed, mode):
             assert (flags[applied] & 1).all()
             assert st.n_conflicts > 0 and st.n_rows == len(o)
             _assert_same_state(e, o)
+
+
+def test_maximum_batch_size_boundary():
+    """2^24 deltas in one call is the documented maximum (24-bit batch index in the claim tag); one more is rejected
+    without touching the table. Checked against the oracle on the full batch."""
+    n = 1 << 24
+    R = 4_000_000
+    rng = np.random.default_rng(11)
+    rows = rng.integers(0, R, n)
+    ids = synth.splitmix64_np((rows + 1).astype(np.uint64))
+    ts = rng.integers(0, 1 << 40, n); val = rng.integers(-(1 << 30), 1 << 30, n)
+    o = Oracle()
+    _, ow = o.merge_batch(ids, np.full(n, F0, np.uint32), ts, val)
+    with bmx.Engine(2 * R) as e:
+        with pytest.raises(bmx.BmxError) as ei:
+            e.merge_batch(np.concatenate([ids, ids[:1]]), np.full(n + 1, F0, np.uint32), np.concatenate([ts, ts[:1]]), np.concatenate([val, val[:1]]), want_flags=False)
+        assert ei.value.code == bmx.ERR_INVALID and e.row_count() == 0
+        applied, _, st = e.merge_batch(ids, np.full(n, F0, np.uint32), ts, val, want_flags=False)
+        assert np.array_equal(applied, ow)
+        assert st.n_rows == len(o) and rows_digest(*e.dump_rows()) == o.digest()
