@@ -236,6 +236,20 @@ function genL1() {
     { path: "cfg/theme", data: "light" },
     { path: "cfg/n", data: 41 },
     { path: "cfg/n", data: 40 },
+    /* nulls and falsy leaves: delete-vs-update is order dependent (docs/conflict-resolution.md:512-523), and reading a falsy
+       leaf through _getData replaces it with {} (src/bullet.js:122-124) */
+    { path: "tmp/x", data: { a: 1, __fromNetwork: true, __vectorClock: { w: 5 } } },
+    { path: "tmp/x", data: null },                                                                          /* local delete: null vs object */
+    { path: "tmp/x", data: { a: 2, __fromNetwork: true, __vectorClock: { w: 5 } } },                        /* object vs the autovivified {} */
+    { path: "tmp/z", data: 0 },                                                                              /* falsy leaf */
+    { path: "tmp/z", data: 7 },
+    { path: "tmp/z", data: "" },
+    { path: "tmp/z", data: false },
+    { path: "tmp/arr", data: [1, 2, 3] },
+    { path: "tmp/arr", data: [1, 2] },
+    { path: "tmp/s", data: "b" },
+    { path: "tmp/s", data: "a" },
+    { path: "tmp/s", data: "c" },
   ];
   const steps = [];
   for (const op of ops) {
