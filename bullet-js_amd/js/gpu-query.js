@@ -62,17 +62,32 @@ class GpuQuery {
 
   static keyOf(path, field) { return field ? `${path}:${field}` : path; }
 
-  index(path, field = null) {
+  /**
+   * index(path, field) as in the reference. opts.source === 'device' indexes the rows that already live on the GPU
+   * (ingested through GpuCRT.mergeEntries / mergeBatch under the same (collection, field) hash) instead of uploading the
+   * children found in the JS store: the sync -> device -> query flow then never re-sends values.
+   */
+  index(path, field = null, opts = {}) {
     const key = GpuQuery.keyOf(path, field);
     if (this.indices[key]) return this;
-    this.indices[key] = { path, field, stale: true, kind: null };
+    this.indices[key] = { path, field, stale: true, kind: null, source: opts.source === "device" ? "device" : "store" };
     this.indexedPaths.add(path);
     this._build(this.indices[key]);
     return this;
   }
 
+  /* device-sourced index: nothing to upload; rows are the ones merge batches put there */
+  _buildFromDevice(ix) {
+    const g = this.graph;
+    ix.kind = "device";
+    ix.deviceField = g.keys.fieldOf(ix.path, ix.field);
+    g.indexBuild(ix.deviceField);
+    ix.paths = null; ix.values = null; ix.stale = false; ix.rank = null; ix._posByPath = null;
+  }
+
   /* scan the direct children of `path` (one level, as _buildIndex does) and materialise the index */
   _build(ix) {
+    if (ix.source === "device") { this._buildFromDevice(ix); return; }
     const base = this.bullet._getData(ix.path);
     const paths = [], values = [];
     if (typeof base === "object" && base !== null) {
@@ -130,6 +145,18 @@ class GpuQuery {
     return ix;
   }
 
+  /* device-sourced index: ids -> nodes, ordered by path (the store holds no scan order for them) */
+  _nodesFromIds(ids) {
+    const u32 = new Uint32Array(ids.buffer, ids.byteOffset, ids.length * 2);
+    const paths = [];
+    for (let i = 0; i < ids.length; i++) {
+      const p = this.graph.keys.pathOf(u32[2 * i], u32[2 * i + 1]);
+      if (p !== undefined) paths.push(p);
+    }
+    paths.sort();
+    return paths.map((p) => this.bullet.get(p));
+  }
+
   /* device ids -> child ordinals of the build scan */
   _ordinals(ix, ids) {
     const u32 = new Uint32Array(ids.buffer, ids.byteOffset, ids.length * 2);
@@ -165,6 +192,7 @@ class GpuQuery {
     const n = typeof value === "string" && value.trim() !== "" ? Number(value) : value;
     if (!isDeviceInt(n) || String(n) !== String(value)) return [];
     const ids = this.graph.scanRange(ix.deviceField, n, n);
+    if (ix.source === "device") return this._nodesFromIds(ids);
     return this._nodes(ix, this._ordinals(ix, ids).sort((a, b) => a - b));
   }
 
@@ -176,8 +204,10 @@ class GpuQuery {
     if (ix.kind === "device" && typeof min === "number" && typeof max === "number" && !Number.isNaN(min) && !Number.isNaN(max)) {
       // integer column: lo = ceil(min), hi = floor(max) select exactly the values with min <= v <= max
       const ids = this.graph.scanRange(ix.deviceField, Math.ceil(min), Math.floor(max));
+      if (ix.source === "device") return this._nodesFromIds(ids);
       return this._nodes(ix, this._inReferenceOrder(ix, this._ordinals(ix, ids)));
     }
+    if (ix.source === "device") return [];   // non-numeric bounds cannot match integer rows
     // host index, or bounds the device cannot express (strings): JS comparison semantics on the host
     this.lastPath = "host";
     const out = [];

@@ -153,6 +153,27 @@ for (const name of fs.readdirSync(GOLD).filter((f) => f.startsWith("g2_stream_")
   checks += 6;
 }
 
+/* device-sourced index: rows ingested by mergeEntries are queried without re-uploading anything from the JS store */
+{
+  const b = new MiniBullet("w");
+  const { crt, query } = attach(b, { capacityRows: 4096 });
+  const entries = [];
+  for (let i = 0; i < 500; i++) entries.push({ path: "dev/n" + i, data: { age: i % 50, score: 1000 - i }, vectorClock: { w: 10 } });
+  entries.push({ path: "dev/n7", data: { age: 49 }, vectorClock: { w: 11 } });     // newer clock: n7 moves from 7 to 49
+  crt.mergeEntries(entries, { insertMode: "delta" });
+  query.index("dev", "age", { source: "device" });
+  const keys = (nodes) => nodes.map((n) => n.path.split("/").pop());
+  const want49 = []; for (let i = 0; i < 500; i++) if (i % 50 === 49 || i === 7) want49.push("n" + i);
+  assert.deepStrictEqual(keys(query.equals("dev", "age", 49)), want49.sort());
+  assert.strictEqual(query.lastPath, "device");
+  assert.strictEqual(query.range("dev", "age", 0, 4).length, 50);
+  assert.strictEqual(query.count("dev", "age", 7), 9);                              // n7 moved away from 7
+  crt.mergeEntries([{ path: "dev/n1", data: { age: 49 }, vectorClock: { w: 12 } }], { insertMode: "delta" });
+  assert.ok(keys(query.equals("dev", "age", 49)).includes("n1"));                   // bmx rebuilds the device index when the table changed
+  b.close();
+  checks += 5;
+}
+
 /* Promise variant: two batches in flight from the event loop's point of view, serialised inside the addon */
 (async () => {
   const g = load("g2_stream_hot30_10k_10k.json");

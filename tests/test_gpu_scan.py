@@ -7,7 +7,6 @@ pytestmark = pytest.mark.gpu
 
 import bmx
 from oracle import streams
-from bmx import synth
 from oracle.oracle import Oracle, INSERT_REFERENCE
 from helpers import load_golden
 
