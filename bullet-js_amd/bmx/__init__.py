@@ -17,6 +17,7 @@ ERR_INVALID, ERR_HIP, ERR_FULL, ERR_NOMEM, ERR_RANGE, ERR_INTERNAL, ERR_NO_DEVIC
 MEM_HOST, MEM_DEVICE = 0, 1
 INSERT_REFERENCE, INSERT_DELTA = 0, 1
 MERGE_UNIQUE_KEYS = 0x100
+MERGE_STRICT_FLAGS = 0x200
 CTX_ASYNC_COMPACT = 1
 CTX_FIXED_CAPACITY = 2
 FLAG_INCOMING, FLAG_CURRENT, FLAG_HISTORICAL = 1, 2, 4

@@ -219,7 +219,9 @@ int merge_core(bmx_ctx* ctx, uint64_t n, const uint64_t* id, const uint32_t* fie
                bmx_merge_stats* stats) {
   if (n > MAX_BATCH) return fail(ctx, BMX_ERR_INVALID, "batch larger than 2^24 deltas: split it (sequential semantics are preserved)");
   const bool unique = (insert_mode & BMX_MERGE_UNIQUE_KEYS) != 0;
-  insert_mode &= ~BMX_MERGE_UNIQUE_KEYS;
+  const bool strict = (insert_mode & BMX_MERGE_STRICT_FLAGS) != 0;
+  insert_mode &= ~(BMX_MERGE_UNIQUE_KEYS | BMX_MERGE_STRICT_FLAGS);
+  if (unique && strict) return fail(ctx, BMX_ERR_INVALID, "BMX_MERGE_STRICT_FLAGS cannot be combined with BMX_MERGE_UNIQUE_KEYS");
   if (insert_mode != BMX_INSERT_REFERENCE && insert_mode != BMX_INSERT_DELTA) return fail(ctx, BMX_ERR_INVALID, "bad insert_mode");
   if (n == 0) {
     if (n_applied) HIPCHK(hipMemsetAsync(n_applied, 0, sizeof(uint64_t), ctx->stream));
@@ -264,7 +266,9 @@ int merge_core(bmx_ctx* ctx, uint64_t n, const uint64_t* id, const uint32_t* fie
   const uint32_t rblocks = blocks;   // one lane per delta
   hipEvent_t* pe = (ctx->prof_on && ctx->prof_n < PROF_MAX_CALLS) ? &ctx->prof_ev[4 * ctx->prof_n] : nullptr;
   if (pe) HIPCHK(hipEventRecord(pe[0], ctx->stream));
-  if (insert_mode == BMX_INSERT_REFERENCE) {
+  if (strict) {
+    hipLaunchKernelGGL((k_probe_link_strict<AOS>), dim3(blocks), dim3(256), 0, ctx->stream, A);
+  } else if (insert_mode == BMX_INSERT_REFERENCE) {
     if (unique) hipLaunchKernelGGL((k_probe_apply<AOS, BMX_INSERT_REFERENCE, true>), dim3(blocks), dim3(256), 0, ctx->stream, A);
     else hipLaunchKernelGGL((k_probe_apply<AOS, BMX_INSERT_REFERENCE, false>), dim3(blocks), dim3(256), 0, ctx->stream, A);
   } else {
@@ -273,7 +277,15 @@ int merge_core(bmx_ctx* ctx, uint64_t n, const uint64_t* id, const uint32_t* fie
   }
   LAUNCHCHK("k_probe_apply");
   if (pe) HIPCHK(hipEventRecord(pe[1], ctx->stream));
-  if (!unique) {  // duplicate keys can only exist without the caller's guarantee
+  if (strict) {   // flags for every delta against the untouched rows, then the final state by the last claimers
+    if (insert_mode == BMX_INSERT_REFERENCE) {
+      if (flags) hipLaunchKernelGGL((k_resolve_strict<AOS, BMX_INSERT_REFERENCE, false>), dim3(rblocks), dim3(256), 0, ctx->stream, A);
+      hipLaunchKernelGGL((k_resolve_strict<AOS, BMX_INSERT_REFERENCE, true>), dim3(rblocks), dim3(256), 0, ctx->stream, A);
+    } else {
+      if (flags) hipLaunchKernelGGL((k_resolve_strict<AOS, BMX_INSERT_DELTA, false>), dim3(rblocks), dim3(256), 0, ctx->stream, A);
+      hipLaunchKernelGGL((k_resolve_strict<AOS, BMX_INSERT_DELTA, true>), dim3(rblocks), dim3(256), 0, ctx->stream, A);
+    }
+  } else if (!unique) {  // duplicate keys can only exist without the caller's guarantee
     if (insert_mode == BMX_INSERT_REFERENCE) hipLaunchKernelGGL((k_resolve_lists<AOS, BMX_INSERT_REFERENCE>), dim3(rblocks), dim3(256), 0, ctx->stream, A);
     else hipLaunchKernelGGL((k_resolve_lists<AOS, BMX_INSERT_DELTA>), dim3(rblocks), dim3(256), 0, ctx->stream, A);
   }

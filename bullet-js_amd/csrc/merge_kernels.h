@@ -339,6 +339,134 @@ __global__ __launch_bounds__(256) void k_resolve_lists(MergeArgs A) {
   if (owner != ~0u && A.flags) A.flags[owner] = (uint8_t)BMX_FLAG_INCOMING;
 }
 
+// ---- strict mode (BMX_MERGE_STRICT_FLAGS): exact sequential per-delta flags for any batch ----
+// k_probe_link_strict: every valid delta finds/creates its row, claims it and links into the row's list; nobody compares,
+// drops or writes. k_resolve_strict: every delta walks its row's whole list once. Because the state after applying any SET
+// of deltas in index order is order independent — lexmax of the resident row and the deltas, an absent row starting as
+// (2, value of its smallest-index delta) — the state delta j meets is computed from the members with a smaller index,
+// which gives resolve()'s flags for j exactly (src/bullet-crt.js:164-279). The last claimer also writes the final state.
+constexpr uint32_t STRICT_NO_ROW = 0xFFFFFFFFu;
+
+template <bool AOS>
+__global__ __launch_bounds__(256) void k_probe_link_strict(MergeArgs A) {
+  const uint32_t j = blockIdx.x * 256u + threadIdx.x;
+  const bool active = j < A.n;
+  uint64_t id = EMPTY_ID; uint32_t field = 0; int64_t a = 0, v = 0;
+  if (active) load_delta<AOS>(A, j, id, field, a, v);
+  const bool pad = AOS && id == EMPTY_ID;
+  const bool valid = active && id != EMPTY_ID && field != FIELD_PENDING && a >= 0 && a <= TS_MAX && v >= -VAL_MAX && v <= VAL_MAX;
+  if (active && !valid && !pad) atomicOr(A.status, ST_RANGE);
+  uint32_t slot = STRICT_NO_ROW;
+  bool conflict = false, created = false;
+  if (valid) {
+    bool is_new; int64_t cts, cval; uint64_t s; uint32_t prev = 0;
+    const uint32_t tag = (A.epoch << IDX_BITS) | j;
+    if (probe_or_insert<false>(A, tag, id, field, s, is_new, created, prev, cts, cval)) {
+      if (!created) prev = atomicExch(&(A.slots + s)->head, tag);
+      if ((prev >> IDX_BITS) == A.epoch) { A.next[j] = (A.epoch << IDX_BITS) | (prev & IDX_MASK); conflict = true; }
+      slot = (uint32_t)s;
+    }
+  }
+  {
+    unsigned long long mc = __ballot(created), mx = __ballot(conflict);
+    if (lane_id() == 0 && (mc | mx)) {
+      unsigned long long* ctr = A.shard_ctr + (size_t)((blockIdx.x * 4u + (threadIdx.x >> 6)) & (CTR_SHARDS - 1)) * CTR_STRIDE;
+      if (mc) atomicAdd(ctr + 0, (unsigned long long)__popcll(mc));
+      if (mx) atomicAdd(ctr + 1, (unsigned long long)__popcll(mx));
+    }
+  }
+  if (active) {
+    A.slot_of[j] = slot;            // STRICT_NO_ROW for deltas that take no part (invalid, padding)
+    A.wflag[j] = W_NONE;            // only the last claimer of a row ever writes W_WINNER (in k_resolve_strict)
+    if (A.flags) A.flags[j] = 0;
+  }
+  if (threadIdx.x == 0) A.blk_info[blockIdx.x] = 0;   // winners are counted by k_resolve_strict
+}
+
+// top-2 tracker: best (ts,val) with its smallest index, and the best among the rest
+struct Top2 {
+  int64_t t1 = INT64_MIN, v1 = INT64_MIN, t2 = INT64_MIN, v2 = INT64_MIN;
+  uint32_t o1 = ~0u, o2 = ~0u;
+  __device__ __forceinline__ void add(uint32_t idx, int64_t t, int64_t v) {
+    int c1 = o1 == ~0u ? 1 : lexcmp(t, v, t1, v1);
+    if (c1 > 0 || (c1 == 0 && idx < o1)) {
+      if (o1 != ~0u) { int c2 = o2 == ~0u ? 1 : lexcmp(t1, v1, t2, v2); if (c2 > 0 || (c2 == 0 && o1 < o2)) { t2 = t1; v2 = v1; o2 = o1; } }
+      t1 = t; v1 = v; o1 = idx;
+    } else {
+      int c2 = o2 == ~0u ? 1 : lexcmp(t, v, t2, v2);
+      if (c2 > 0 || (c2 == 0 && idx < o2)) { t2 = t; v2 = v; o2 = idx; }
+    }
+  }
+  // best entry whose index is not `skip`
+  __device__ __forceinline__ bool best_except(uint32_t skip, int64_t& t, int64_t& v, uint32_t& o) const {
+    const bool use2 = o1 == skip;
+    o = use2 ? o2 : o1;
+    if (o == ~0u) return false;
+    t = use2 ? t2 : t1; v = use2 ? v2 : v1;
+    return true;
+  }
+};
+
+// APPLY = false: every delta computes its own sequential flags (rows are only READ: they still hold the pre-batch state).
+// APPLY = true : launched afterwards; only the last claimer of each row proceeds, writes the final state, names the winner.
+template <bool AOS, int MODE, bool APPLY>
+__global__ __launch_bounds__(256) void k_resolve_strict(MergeArgs A) {
+  const uint32_t j = blockIdx.x * 256u + threadIdx.x;
+  if (j >= A.n) return;
+  const uint32_t slot = A.slot_of[j];
+  if (slot == STRICT_NO_ROW) return;
+  Slot* sl = A.slots + slot;
+  const uint4* q = reinterpret_cast<const uint4*>(sl);
+  const uint4 lo = q[0], hi = q[1];
+  const uint32_t head = lo.w & IDX_MASK;
+  if (APPLY && head != j) return;
+  int64_t aj, vj; load_delta_tv<AOS>(A, j, aj, vj);
+  const int64_t tsw = (int64_t)((uint64_t)hi.x | ((uint64_t)hi.y << 32));
+  const int64_t rval = (int64_t)((uint64_t)hi.z | ((uint64_t)hi.w << 32));
+  const bool is_new = tsw == TS_NEW;            // unwritten = absent before the batch (strict mode writes rows only in the APPLY launch)
+  // one walk over the whole list, from the last claimer to the first
+  uint32_t j0 = ~0u; int64_t t_j0 = 0, v_j0 = 0;   // smallest index of the list and its delta
+  Top2 top;                                       // APPLY: over all members; else: over the members with index < j
+  {
+    uint32_t idx = head, steps = 0;
+    for (;;) {
+      int64_t t, v; load_delta_tv<AOS>(A, idx, t, v);
+      uint32_t nx = A.next[idx];
+      if (idx < j0) { j0 = idx; t_j0 = t; v_j0 = v; }
+      if (APPLY || idx < j) top.add(idx, t, v);
+      if ((nx >> IDX_BITS) != A.epoch) break;
+      idx = nx & IDX_MASK;
+      if (++steps > A.n) { atomicOr(A.status, ST_SPIN); return; }
+    }
+  }
+  // state that (APPLY) the whole list leaves / (else) delta j meets: the resident row or the row created by j0, raised by `top`
+  int64_t bt, bv; uint32_t owner;
+  if (is_new) {
+    bt = (MODE == BMX_INSERT_REFERENCE) ? 2 : t_j0; bv = v_j0; owner = j0;
+    int64_t tm, vm; uint32_t om;
+    if (top.best_except(j0, tm, vm, om) && lexcmp(tm, vm, bt, bv) > 0) { bt = tm; bv = vm; owner = om; }   // a tie keeps j0 (smaller index)
+  } else {
+    bt = ts_value(tsw); bv = rval; owner = ~0u;
+    if (top.o1 != ~0u && lexcmp(top.t1, top.v1, bt, bv) > 0) { bt = top.t1; bv = top.v1; owner = top.o1; }
+  }
+  if (APPLY) {
+    if (owner != ~0u) {
+      store_tv(sl, is_new ? (bt | ((int64_t)A.epoch << TS_MARK_SHIFT)) : bt, bv);
+      A.wflag[owner] = W_WINNER;
+      atomicAdd(&A.blk_info[owner >> 8], 1u);
+    }
+  } else if (A.flags) {
+    uint32_t fl;
+    if (is_new && j == j0) {
+      fl = BMX_FLAG_INCOMING;                       // "no current state": src/bullet-crt.js:172-185
+    } else {
+      int c = lexcmp(aj, vj, bt, bv);
+      fl = c > 0 ? BMX_FLAG_INCOMING : (c == 0 ? 0u : (BMX_FLAG_CURRENT | (aj < bt ? BMX_FLAG_HISTORICAL : 0u)));
+    }
+    A.flags[j] = (uint8_t)fl;
+  }
+}
+
 // epoch wrap: forget every claim tag and every creation mark
 __global__ __launch_bounds__(256) void k_sweep_heads(Slot* slots, uint64_t nslots) {
   for (uint64_t s = (uint64_t)blockIdx.x * 256u + threadIdx.x; s < nslots; s += (uint64_t)gridDim.x * 256u) {

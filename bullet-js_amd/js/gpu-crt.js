@@ -194,13 +194,15 @@ class GpuCRT {
   /**
    * Merge typed columns on the GPU.
    * cols: {id: BigUint64Array, field: Uint32Array, ts: BigInt64Array, val: BigInt64Array}
-   * opts: {insertMode: 'reference'|'delta', uniqueKeys: bool}
+   * opts: {insertMode: 'reference'|'delta', uniqueKeys: bool, strictFlags: bool (exact sequential per-delta flags even with
+   *        duplicate keys in the batch; about twice as slow)}
    * -> {applied: Uint32Array (ascending delta indices whose value is now stored), flags, nApplied, nConflicts, nRows}
    */
   mergeBatch(cols, opts = {}) {
     const g = this.graph;
     let mode = opts.insertMode === "delta" ? g.native.INSERT_DELTA : g.native.INSERT_REFERENCE;
     if (opts.uniqueKeys) mode |= g.native.MERGE_UNIQUE_KEYS;
+    if (opts.strictFlags) mode |= g.native.MERGE_STRICT_FLAGS;
     return g.mergeBatch(cols, mode);
   }
 
@@ -210,6 +212,7 @@ class GpuCRT {
     const g = this.graph;
     let mode = opts.insertMode === "delta" ? g.native.INSERT_DELTA : g.native.INSERT_REFERENCE;
     if (opts.uniqueKeys) mode |= g.native.MERGE_UNIQUE_KEYS;
+    if (opts.strictFlags) mode |= g.native.MERGE_STRICT_FLAGS;
     return g.mergeBatchAsync(cols, mode);
   }
 

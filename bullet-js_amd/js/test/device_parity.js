@@ -33,6 +33,15 @@ for (const name of fs.readdirSync(GOLD).filter((f) => f.startsWith("g2_stream_")
   assert.deepStrictEqual(Array.from(r.applied), g.winners, name + " winners");
   assert.strictEqual(r.nRows, g.n_rows_final, name + " rows");
   if (r.nConflicts === 0) assert.strictEqual(Buffer.from(r.flags).toString("base64"), g.flags_b64, name + " flags");
+  else {   // duplicates in the batch: the strict mode reproduces the reference's per-delta flags exactly
+    const crt2 = new GpuCRT({ id: "w", meta: {}, _getData() {} }, { capacityRows: Math.max(4096, 2 * (g.spec.R + g.spec.D)) });
+    crt2.graph.loadRows(rc);
+    const r2 = crt2.mergeBatch(columns(deltas, F), { strictFlags: true });
+    assert.strictEqual(Buffer.from(r2.flags).toString("base64"), g.flags_b64, name + " strict flags");
+    assert.deepStrictEqual(Array.from(r2.applied), g.winners, name + " strict winners");
+    crt2.close();
+    checks += 2;
+  }
   const d = crt.graph.dumpRows();
   let digest = 0n;
   for (let i = 0; i < d.id.length; i++) digest = (digest + gen.rowDigest(d.id[i], d.field[i], d.ts[i], d.val[i])) & ((1n << 64n) - 1n);

@@ -374,7 +374,7 @@ napi_value Init(napi_env env, napi_value exports) {
     napi_set_named_property(env, exports, f.name, v);
   }
   struct { const char* name; int v; } consts[] = {{"INSERT_REFERENCE", BMX_INSERT_REFERENCE}, {"INSERT_DELTA", BMX_INSERT_DELTA},
-                                                  {"MERGE_UNIQUE_KEYS", BMX_MERGE_UNIQUE_KEYS}, {"FLAG_INCOMING", BMX_FLAG_INCOMING},
+                                                  {"MERGE_UNIQUE_KEYS", BMX_MERGE_UNIQUE_KEYS}, {"MERGE_STRICT_FLAGS", BMX_MERGE_STRICT_FLAGS}, {"FLAG_INCOMING", BMX_FLAG_INCOMING},
                                                   {"FLAG_CURRENT", BMX_FLAG_CURRENT}, {"FLAG_HISTORICAL", BMX_FLAG_HISTORICAL}};
   for (auto& c : consts) { napi_value v; napi_create_int32(env, c.v, &v); napi_set_named_property(env, exports, c.name, v); }
   return exports;

@@ -57,9 +57,15 @@ extern "C" {
  * guarantee holds. The default path makes no assumption and is exact for any batch. */
 #define BMX_MERGE_UNIQUE_KEYS 0x100
 
+/* Optional bit OR-ed into `insert_mode`: exact SEQUENTIAL decision flags for every delta even when keys repeat inside the
+ * batch (SURVEY §8(a) batch semantics (C)): flags[j] is what resolve() would have returned for delta j in the reference's
+ * one-by-one loop. Final state and applied_idx are the same as without it; the batch takes roughly twice as long because
+ * no delta is applied optimistically. Cannot be combined with BMX_MERGE_UNIQUE_KEYS. */
+#define BMX_MERGE_STRICT_FLAGS 0x200
+
 /* per-delta decision flags (bits of `flags[j]`), the booleans of resolve()'s decision record
- * src/bullet-crt.js:174-184. Exact for batches without duplicate keys (stats.n_conflicts == 0);
- * with duplicates they are relative to the state each delta observed. */
+ * src/bullet-crt.js:174-184. Exact for batches without duplicate keys (stats.n_conflicts == 0); with duplicates they are
+ * relative to the state each delta observed, unless BMX_MERGE_STRICT_FLAGS is set (then always exact). */
 #define BMX_FLAG_INCOMING   1u
 #define BMX_FLAG_CURRENT    2u
 #define BMX_FLAG_HISTORICAL 4u

@@ -294,3 +294,51 @@ def test_maximum_batch_size_boundary():
         applied, _, st = e.merge_batch(ids, np.full(n, F0, np.uint32), ts, val, want_flags=False)
         assert np.array_equal(applied, ow)
         assert st.n_rows == len(o) and rows_digest(*e.dump_rows()) == o.digest()
+
+
+@pytest.mark.parametrize("name", stream_fixtures())
+def test_strict_flags_equal_reference_on_every_stream(name):
+    """BMX_MERGE_STRICT_FLAGS: flags[j] is exactly what resolve() returned for delta j in the reference's sequential loop,
+    duplicates or not (SURVEY §8(a) batch semantics (C)); state and winners as in the default mode."""
+    g = load_golden(name)
+    spec = g["spec"]
+    st, o, oflags, owinners = run_oracle_stream(spec)
+    _, rid, rf, rts, rval = st["resident"]
+    _, did, df, dts, dval = st["deltas"]
+    with bmx.Engine(max(1024, 2 * (spec["R"] + spec["D"]))) as e:
+        e.load_rows(rid, rf, rts, rval)
+        applied, flags, stats = e.merge_batch(did, df, dts, dval, INSERT_REFERENCE | bmx.MERGE_STRICT_FLAGS)
+        assert np.array_equal(flags, golden_flags(g))
+        assert applied.tolist() == g["winners"]
+        id, f, ts, val = e.dump_rows()
+        assert "%x" % rows_digest(id, f, ts, val) == g["digest"]
+        assert stats.n_rows == g["n_rows_final"] and stats.n_applied == len(g["winners"])
+        # a second, default-mode batch on the same table still behaves (marks, heads and counters are consistent)
+        applied2, _, _ = e.merge_batch(did, df, dts, dval, INSERT_REFERENCE)
+        _, ow2 = o.merge_batch(did, df, dts, dval, INSERT_REFERENCE)     # rows created with ts := 2 are beaten again on replay
+        assert np.array_equal(applied2, ow2)
+        _assert_same_state(e, o)
+
+
+@pytest.mark.parametrize("mode", [INSERT_REFERENCE, INSERT_DELTA])
+def test_strict_flags_on_duplicate_heavy_batches(mode):
+    rng = np.random.default_rng(5)
+    K = 2000
+    keys = synth.splitmix64_np(np.arange(777, 777 + K, dtype=np.uint64))
+    o = Oracle()
+    with bmx.Engine(4 * K) as e:
+        rts = rng.integers(0, 5, K // 2); rval = rng.integers(-1, 2, K // 2)
+        e.load_rows(keys[: K // 2], np.full(K // 2, F0), rts, rval); o.load_rows(keys[: K // 2], np.full(K // 2, F0), rts, rval)
+        for b in range(3):
+            mult = np.minimum(rng.geometric(0.2, K), 80)
+            idx = np.repeat(np.arange(K), mult); rng.shuffle(idx)
+            n = len(idx)
+            ts = rng.integers(0, 5, n); val = rng.integers(-1, 2, n)
+            applied, flags, st = e.merge_batch(keys[idx], np.full(n, F0), ts, val, mode | bmx.MERGE_STRICT_FLAGS)
+            of, ow = o.merge_batch(keys[idx], np.full(n, F0), ts, val, mode)
+            assert np.array_equal(flags, of), (mode, b)
+            assert np.array_equal(applied, ow), (mode, b)
+            _assert_same_state(e, o)
+    with bmx.Engine(100) as e:
+        with pytest.raises(bmx.BmxError):
+            e.merge_batch([1], [F0], [1], [1], INSERT_REFERENCE | bmx.MERGE_STRICT_FLAGS | bmx.MERGE_UNIQUE_KEYS)
