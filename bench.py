@@ -65,8 +65,23 @@ def cpu_baseline(n_batches=3):
         o.merge_batch(*b)
     dt = time.perf_counter() - t0
     o.close()
-    return {"value": n_batches * D_PER_STEP / dt, "unit": "merges/s", "cores": 1, "kind": "port",
-            "sample": "%d x 1M-delta batches against the 10M-row resident graph (load excluded), oracle/bmx_oracle.c, 1 thread" % n_batches}
+    out = {"value": n_batches * D_PER_STEP / dt, "unit": "merges/s", "cores": 1, "kind": "port",
+           "sample": "%d x 1M-delta batches against the 10M-row resident graph (load excluded), oracle/bmx_oracle.c, 1 thread" % n_batches}
+    # the Node.js path on the same box: the per-delta processUpdate loop over a Map (the reference harness shape of BASELINE.md §2),
+    # run by the golden-pinned JS twin of BulletCRT (bullet-js_amd/js/gpu-crt.js); bounded sample, one thread
+    import shutil
+    import subprocess
+    node = shutil.which("node")
+    if node:
+        try:
+            r = subprocess.run([node, os.path.join(ROOT, "bullet-js_amd", "js", "test", "cpu_baseline.js"), "1000000", "300000"],
+                               capture_output=True, text=True, timeout=180)
+            j = json.loads(r.stdout.strip().splitlines()[-1])
+            out["js_twin"] = {"value": j["value"], "unit": "merges/s", "cores": 1, "node": j["node"],
+                              "sample": "%d deltas (10 %% inserts) against %d resident keys, processUpdate loop over a Map, 1 thread" % (j["deltas"], j["resident_keys"])}
+        except Exception as e:  # the JS figure is an extra; never fail the bench for it
+            out["js_twin"] = {"error": str(e)[:200]}
+    return out
 
 
 def scan_bench(bmx, dev, R=10_000_000, reps=20):
