@@ -10,7 +10,7 @@ class DeviceGraph {
   constructor(opts = {}) {
     this.native = requireNative();                 // throws if the addon is missing: no CPU fallback
     this.device = opts.device || 0;
-    this.capacityRows = opts.capacityRows || (1 << 22);
+    this.capacityRows = opts.capacityRows || (1 << 16);   // grows on demand (bmx_reserve / automatic rehash)
     this.handle = this.native.create(this.device, this.capacityRows);
     this.keys = new KeyDictionary();
     this.batches = 0;

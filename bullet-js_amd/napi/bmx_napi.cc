@@ -232,6 +232,7 @@ napi_value Reserve(napi_env env, napi_callback_info info) {
 napi_value LoadRows(napi_env env, napi_callback_info info) {
   ARGS(5);
   Handle* h; if (!get_handle(env, argv[0], &h)) return nullptr;
+  std::lock_guard<std::mutex> lock(h->mu);   // a context is not re-entrant; async merges run on worker threads
   const uint64_t* id; const uint32_t* field; const int64_t *ts, *val; size_t n;
   if (!get_cols(env, argv + 1, &id, &field, &ts, &val, &n)) return nullptr;
   int rc = bmx_load_rows(h->ctx, n, id, field, ts, val, BMX_MEM_HOST);
@@ -243,6 +244,7 @@ napi_value LoadRows(napi_env env, napi_callback_info info) {
 napi_value GetRows(napi_env env, napi_callback_info info) {
   ARGS(3);
   Handle* h; if (!get_handle(env, argv[0], &h)) return nullptr;
+  std::lock_guard<std::mutex> lock(h->mu);   // a context is not re-entrant; async merges run on worker threads
   void *p0, *p1; size_t n0, n1;
   if (!get_ta(env, argv[1], napi_biguint64_array, &p0, &n0) || !get_ta(env, argv[2], napi_uint32_array, &p1, &n1)) return nullptr;
   if (n0 != n1) { napi_throw_range_error(env, nullptr, "bmx: column lengths differ"); return nullptr; }
@@ -258,6 +260,7 @@ napi_value GetRows(napi_env env, napi_callback_info info) {
 napi_value RowCount(napi_env env, napi_callback_info info) {
   ARGS(1);
   Handle* h; if (!get_handle(env, argv[0], &h)) return nullptr;
+  std::lock_guard<std::mutex> lock(h->mu);   // a context is not re-entrant; async merges run on worker threads
   uint64_t n = 0; int rc = bmx_row_count(h->ctx, &n);
   if (rc) return throw_bmx(env, h->ctx, rc);
   napi_value v; napi_create_double(env, (double)n, &v); return v;
@@ -266,6 +269,7 @@ napi_value RowCount(napi_env env, napi_callback_info info) {
 napi_value DumpRows(napi_env env, napi_callback_info info) {
   ARGS(1);
   Handle* h; if (!get_handle(env, argv[0], &h)) return nullptr;
+  std::lock_guard<std::mutex> lock(h->mu);   // a context is not re-entrant; async merges run on worker threads
   uint64_t n = 0; int rc = bmx_row_count(h->ctx, &n);
   if (rc) return throw_bmx(env, h->ctx, rc);
   void *id, *f, *ts, *val;
@@ -283,6 +287,7 @@ napi_value DumpRows(napi_env env, napi_callback_info info) {
 napi_value IndexBuild(napi_env env, napi_callback_info info) {
   ARGS(2);
   Handle* h; if (!get_handle(env, argv[0], &h)) return nullptr;
+  std::lock_guard<std::mutex> lock(h->mu);   // a context is not re-entrant; async merges run on worker threads
   uint32_t f; NAPI_OK(napi_get_value_uint32(env, argv[1], &f));
   int rc = bmx_index_build(h->ctx, f);
   if (rc) return throw_bmx(env, h->ctx, rc);
@@ -291,6 +296,7 @@ napi_value IndexBuild(napi_env env, napi_callback_info info) {
 napi_value IndexDrop(napi_env env, napi_callback_info info) {
   ARGS(2);
   Handle* h; if (!get_handle(env, argv[0], &h)) return nullptr;
+  std::lock_guard<std::mutex> lock(h->mu);   // a context is not re-entrant; async merges run on worker threads
   uint32_t f; NAPI_OK(napi_get_value_uint32(env, argv[1], &f));
   int rc = bmx_index_drop(h->ctx, f);
   if (rc && rc != BMX_ERR_NO_INDEX) return throw_bmx(env, h->ctx, rc);
@@ -299,6 +305,7 @@ napi_value IndexDrop(napi_env env, napi_callback_info info) {
 napi_value IndexSize(napi_env env, napi_callback_info info) {
   ARGS(2);
   Handle* h; if (!get_handle(env, argv[0], &h)) return nullptr;
+  std::lock_guard<std::mutex> lock(h->mu);   // a context is not re-entrant; async merges run on worker threads
   uint32_t f; NAPI_OK(napi_get_value_uint32(env, argv[1], &f));
   uint64_t n = 0; int rc = bmx_index_size(h->ctx, f, &n);
   if (rc) return throw_bmx(env, h->ctx, rc);
@@ -309,6 +316,7 @@ napi_value IndexSize(napi_env env, napi_callback_info info) {
 napi_value ScanRange(napi_env env, napi_callback_info info) {
   ARGS(4);
   Handle* h; if (!get_handle(env, argv[0], &h)) return nullptr;
+  std::lock_guard<std::mutex> lock(h->mu);   // a context is not re-entrant; async merges run on worker threads
   uint32_t f; NAPI_OK(napi_get_value_uint32(env, argv[1], &f));
   int64_t lo, hi; if (!get_i64(env, argv[2], &lo) || !get_i64(env, argv[3], &hi)) return nullptr;
   uint64_t m = 0; int rc = bmx_scan_count(h->ctx, f, lo, hi, &m, BMX_MEM_HOST);
@@ -320,6 +328,7 @@ napi_value ScanRange(napi_env env, napi_callback_info info) {
 napi_value ScanCount(napi_env env, napi_callback_info info) {
   ARGS(4);
   Handle* h; if (!get_handle(env, argv[0], &h)) return nullptr;
+  std::lock_guard<std::mutex> lock(h->mu);   // a context is not re-entrant; async merges run on worker threads
   uint32_t f; NAPI_OK(napi_get_value_uint32(env, argv[1], &f));
   int64_t lo, hi; if (!get_i64(env, argv[2], &lo) || !get_i64(env, argv[3], &hi)) return nullptr;
   uint64_t m = 0; int rc = bmx_scan_count(h->ctx, f, lo, hi, &m, BMX_MEM_HOST);
@@ -330,6 +339,7 @@ napi_value ScanCount(napi_env env, napi_callback_info info) {
 napi_value ScanFilter(napi_env env, napi_callback_info info) {
   ARGS(2);
   Handle* h; if (!get_handle(env, argv[0], &h)) return nullptr;
+  std::lock_guard<std::mutex> lock(h->mu);   // a context is not re-entrant; async merges run on worker threads
   uint32_t nt = 0; NAPI_OK(napi_get_array_length(env, argv[1], &nt));
   if (nt == 0 || nt > 8) { napi_throw_range_error(env, nullptr, "bmx: filter needs 1..8 terms"); return nullptr; }
   bmx_term terms[8];
@@ -354,6 +364,7 @@ napi_value ScanFilter(napi_env env, napi_callback_info info) {
 napi_value Info(napi_env env, napi_callback_info info) {
   ARGS(1);
   Handle* h; if (!get_handle(env, argv[0], &h)) return nullptr;
+  std::lock_guard<std::mutex> lock(h->mu);   // a context is not re-entrant; async merges run on worker threads
   bmx_info i; int rc = bmx_get_info(h->ctx, &i);
   if (rc) return throw_bmx(env, h->ctx, rc);
   napi_value out; NAPI_OK(napi_create_object(env, &out));
