@@ -238,3 +238,135 @@ uint32_t orc_owner_of(uint64_t id, uint32_t nshards) {
   uint64_t h = mix64(id * 0xD6E8FEB86659FD93ULL + 0x2545F4914F6CDD1DULL);
   return (uint32_t)(((unsigned __int128)h * nshards) >> 64);
 }
+
+/* ======================================================================================================================
+ * N4: fixed-K multi-writer vector clocks, integer values. Restates resolve() for general clocks
+ * (src/bullet-crt.js:164-279) with compareVectorClocks :68-95 (missing component = 0), mergeVectorClocks :103-114
+ * (component-wise max) and mergeValues :122-153 for non-objects (compare(in,cur) >= 0 ? in : cur).
+ * Contract: every incoming clock is "dense" (lists the same K writers in the same order), so JSON equality of two clocks is
+ * component equality — except against the ONE-key clock {local: 2} stored by a first write (:172-185), tracked as `sparse`.
+ * Pinned by the g6 vc fixtures under tests/golden (real reference, 3 writers).
+ * ====================================================================================================================== */
+#define ORC_VC_MAXK 8
+#define ORC_FLAG_CONCURRENT 8u
+
+typedef struct {
+  uint64_t id; uint32_t field; uint32_t stamp; int64_t val; uint32_t clock[ORC_VC_MAXK]; uint32_t last_j; uint8_t sparse;
+} orc_vrow;
+typedef struct orc_vc {
+  orc_vrow* rows; uint64_t n, cap; uint32_t* slots; uint64_t nslots; uint32_t K, local, stamp;
+} orc_vc_t;
+
+static void vc_rehash(orc_vc_t* t, uint64_t nslots) {
+  free(t->slots);
+  t->slots = (uint32_t*)calloc(nslots, sizeof(uint32_t));
+  t->nslots = nslots;
+  for (uint64_t i = 0; i < t->n; i++) {
+    uint64_t s = key_hash(t->rows[i].id, t->rows[i].field) & (nslots - 1);
+    while (t->slots[s]) s = (s + 1) & (nslots - 1);
+    t->slots[s] = (uint32_t)(i + 1);
+  }
+}
+orc_vc_t* orc_vc_create(uint32_t K, uint32_t local) {
+  if (K == 0 || K > ORC_VC_MAXK || local >= K) return NULL;
+  orc_vc_t* t = (orc_vc_t*)calloc(1, sizeof(orc_vc_t));
+  t->K = K; t->local = local; t->cap = 1024;
+  t->rows = (orc_vrow*)malloc(t->cap * sizeof(orc_vrow));
+  vc_rehash(t, 4096);
+  return t;
+}
+void orc_vc_destroy(orc_vc_t* t) { if (t) { free(t->rows); free(t->slots); free(t); } }
+uint64_t orc_vc_size(const orc_vc_t* t) { return t->n; }
+static orc_vrow* vc_find(orc_vc_t* t, uint64_t id, uint32_t field) {
+  uint64_t s = key_hash(id, field) & (t->nslots - 1);
+  while (t->slots[s]) {
+    orc_vrow* r = &t->rows[t->slots[s] - 1];
+    if (r->id == id && r->field == field) return r;
+    s = (s + 1) & (t->nslots - 1);
+  }
+  return NULL;
+}
+static orc_vrow* vc_append(orc_vc_t* t, uint64_t id, uint32_t field) {
+  if (t->n == t->cap) { t->cap *= 2; t->rows = (orc_vrow*)realloc(t->rows, t->cap * sizeof(orc_vrow)); }
+  if ((t->n + 1) * 2 > t->nslots) vc_rehash(t, t->nslots * 2);
+  orc_vrow* r = &t->rows[t->n];
+  memset(r, 0, sizeof(*r));
+  r->id = id; r->field = field;
+  uint64_t s = key_hash(id, field) & (t->nslots - 1);
+  while (t->slots[s]) s = (s + 1) & (t->nslots - 1);
+  t->slots[s] = (uint32_t)(++t->n);
+  return r;
+}
+/* dense preload (harness sets state directly) */
+void orc_vc_load_rows(orc_vc_t* t, uint64_t n, const uint64_t* id, const uint32_t* field, const uint32_t* clocks, const int64_t* val) {
+  for (uint64_t i = 0; i < n; i++) {
+    orc_vrow* r = vc_find(t, id[i], field[i]);
+    if (!r) r = vc_append(t, id[i], field[i]);
+    for (uint32_t k = 0; k < t->K; k++) r->clock[k] = clocks[i * t->K + k];
+    r->val = val[i]; r->sparse = 0;
+  }
+}
+static unsigned vc_resolve(orc_vc_t* t, uint64_t id, uint32_t field, const uint32_t* c, int64_t v, orc_vrow** out) {
+  orc_vrow* r = vc_find(t, id, field);
+  if (!r) {                                  /* "no current state": stored clock is {local: 2}, the incoming clock is dropped */
+    r = vc_append(t, id, field);
+    r->clock[t->local] = 2; r->sparse = 1; r->val = v;
+    *out = r;
+    return ORC_FLAG_INCOMING;
+  }
+  *out = r;
+  int in_ahead = 0, cur_ahead = 0, equal = 1;
+  for (uint32_t k = 0; k < t->K; k++) {
+    if (c[k] > r->clock[k]) in_ahead = 1; else if (r->clock[k] > c[k]) cur_ahead = 1;
+    if (c[k] != r->clock[k]) equal = 0;
+  }
+  const int cmp = (in_ahead && cur_ahead) ? 0 : (in_ahead ? 1 : (cur_ahead ? -1 : 0));
+  const int json_equal = equal && (!r->sparse || t->K == 1);   /* {local:2} has one key, a dense clock K keys */
+  if (cmp == 0 && json_equal) {                                /* identical clocks: value comparison  :200-233 */
+    int vc = cmp3(v, r->val);
+    if (vc == 0) return 0;
+    if (vc > 0) { r->val = v; return ORC_FLAG_INCOMING; }
+    return ORC_FLAG_CURRENT;
+  }
+  if (cmp < 0) return ORC_FLAG_CURRENT | ORC_FLAG_HISTORICAL;  /* :251-263 (the row keeps its clock) */
+  for (uint32_t k = 0; k < t->K; k++) if (c[k] > r->clock[k]) r->clock[k] = c[k];   /* merged clock is stored with the update */
+  r->sparse = 0;
+  if (cmp > 0) { r->val = v; return ORC_FLAG_INCOMING; }       /* :236-248 */
+  if (cmp3(v, r->val) >= 0) r->val = v;                        /* concurrent: mergeValues on non-objects  :266-278, :133-135 */
+  return ORC_FLAG_CONCURRENT;
+}
+/* sequential batch; updated (optional, capacity n) = ascending indices of the last delta per key that caused a store
+ * (doUpdate = incoming || no current || concurrent: src/bullet-crt.js:383). Returns their number. */
+uint64_t orc_vc_merge_batch(orc_vc_t* t, uint64_t n, const uint64_t* id, const uint32_t* field, const uint32_t* clocks, const int64_t* val,
+                            uint8_t* flags, uint32_t* updated) {
+  t->stamp++;
+  uint8_t* mark = (uint8_t*)calloc(n ? n : 1, 1);
+  for (uint64_t j = 0; j < n; j++) {
+    orc_vrow* r;
+    unsigned f = vc_resolve(t, id[j], field[j], clocks + j * t->K, val[j], &r);
+    if (flags) flags[j] = (uint8_t)f;
+    if (f & (ORC_FLAG_INCOMING | ORC_FLAG_CONCURRENT)) {
+      if (r->stamp == t->stamp) mark[r->last_j] = 0;
+      r->stamp = t->stamp; r->last_j = (uint32_t)j; mark[j] = 1;
+    }
+  }
+  uint64_t w = 0;
+  for (uint64_t j = 0; j < n; j++) if (mark[j]) { if (updated) updated[w] = (uint32_t)j; w++; }
+  free(mark);
+  return w;
+}
+int orc_vc_get_row(orc_vc_t* t, uint64_t id, uint32_t field, uint32_t* clock_out, int64_t* val, int* sparse) {
+  orc_vrow* r = vc_find(t, id, field);
+  if (!r) return 0;
+  for (uint32_t k = 0; k < t->K; k++) clock_out[k] = r->clock[k];
+  *val = r->val; if (sparse) *sparse = r->sparse;
+  return 1;
+}
+uint64_t orc_vc_dump_rows(const orc_vc_t* t, uint64_t cap, uint64_t* id, uint32_t* field, uint32_t* clocks, int64_t* val) {
+  uint64_t m = t->n < cap ? t->n : cap;
+  for (uint64_t i = 0; i < m; i++) {
+    id[i] = t->rows[i].id; field[i] = t->rows[i].field; val[i] = t->rows[i].val;
+    for (uint32_t k = 0; k < t->K; k++) clocks[i * t->K + k] = t->rows[i].clock[k];
+  }
+  return t->n;
+}

@@ -205,6 +205,53 @@ function genSequences() {
   return { kind: "sequences", source: "reference BulletCRT.processUpdate, one key, ts in 0..4, val in -1..1", seqs };
 }
 
+/* ------------------------------------------------------------------ N4: multi-writer ("dense") vector clocks, integer values
+ * Contract of the device path: every incoming clock lists the same K writers in the same key order (WRITERS below, the local
+ * id last), components are small non-negative integers. Then JSON-equality of two clocks is component equality, except
+ * against the one-key clock {local: 2} that a first write stores (src/bullet-crt.js:172-185) — fixtures cover that too. */
+const WRITERS = ["a", "b", "w"];
+function denseClock(c) { const o = {}; WRITERS.forEach((k, i) => { o[k] = c[i]; }); return o; }
+function compsOf(clock) { return WRITERS.map((k) => clock[k] || 0); }
+function runVcStream(spec) {
+  const rng = xorshift32(spec.seed);
+  const crt = newCrt();
+  const state = new Map();
+  const K = WRITERS.length;
+  const rc = () => { const c = []; for (let k = 0; k < K; k++) c.push(rng() % spec.CMAX); return c; };
+  const resident = [];
+  for (let r = 0; r < spec.R; r++) {
+    const c = rc(); if (c.every((x) => x === 0)) c[K - 1] = 1;
+    const val = (rng() % spec.VR) - spec.VOFF;
+    resident.push({ row: r, clock: c, val });
+    state.set("k" + r, { value: val, clock: denseClock(c), row: r });
+  }
+  const deltas = [];
+  const flags = Buffer.alloc(spec.D);
+  const last = new Map();
+  for (let j = 0; j < spec.D; j++) {
+    const u = rng() % 100;
+    let row;
+    if (u < spec.insert_pct) row = spec.R + (rng() % spec.ins_space);
+    else if (u < spec.insert_pct + spec.hot_pct) row = rng() % spec.H;
+    else row = rng() % spec.R;
+    const c = rc();
+    const val = (rng() % spec.VR) - spec.VOFF;
+    deltas.push({ row, clock: c, val });
+    const key = "k" + row;
+    const cur = state.get(key);
+    const r = crt.processUpdate(key, val, denseClock(c), cur ? cur.value : undefined, cur ? cur.clock : undefined);
+    const d = r.decision;
+    flags[j] = flagsOf(d);
+    if (d.incoming || !cur || d.concurrent) { state.set(key, { value: r.value, clock: r.vectorClock, row }); last.set(key, j); }
+  }
+  const finalRows = [];
+  for (const [, st] of state) finalRows.push([st.row, compsOf(st.clock), st.value, Object.keys(st.clock).length]);
+  finalRows.sort((x, y) => x[0] - y[0]);
+  return { kind: "vc_stream", source: "reference BulletCRT.processUpdate with dense 3-writer clocks {a,b,w}, bullet.id = 'w'", writers: WRITERS, spec,
+    resident: resident.map((r) => [r.row, r.clock, r.val]), deltas: deltas.map((d) => [d.row, d.clock, d.val]),
+    flags_b64: flags.toString("base64"), updated: Array.from(last.values()).sort((x, y) => x - y), final_rows: finalRows };
+}
+
 /* ------------------------------------------------------------------ L1 / query fixtures through the real Bullet facade */
 function quiet(fn) { const l = console.log; console.log = () => {}; try { return fn(); } finally { console.log = l; } }
 function newBullet(extra) {
@@ -377,6 +424,9 @@ function main() {
   write("g1_decision_table.json", genDecisionTable());
   write("g3_sequences.json", genSequences());
   for (const [name, spec] of Object.entries(STREAMS)) write(name, runStream(spec));
+  write("g6_vc_unique_2k.json", runVcStream({ seed: 61, R: 2000, D: 1500, CMAX: 4, VR: 5, VOFF: 2, insert_pct: 10, hot_pct: 0, H: 1, ins_space: 100000 }));
+  write("g6_vc_dups_500.json", runVcStream({ seed: 62, R: 500, D: 4000, CMAX: 3, VR: 3, VOFF: 1, insert_pct: 15, hot_pct: 30, H: 8, ins_space: 60 }));
+  write("g6_vc_empty_start.json", runVcStream({ seed: 63, R: 0, D: 1500, CMAX: 3, VR: 3, VOFF: 1, insert_pct: 100, hot_pct: 0, H: 1, ins_space: 200 }));
   write("g4_l1_ops.json", genL1());
   write("g5_query_example.json", genQueryExample());
   write("g5_query_seeded_2k.json", genQuerySeeded(2000, 4711, true));

@@ -147,3 +147,63 @@ def rows_digest(id, field, ts, val):
         h = sm(h ^ np.asarray(field, np.uint32).astype(np.uint64))
         h = sm(h ^ np.asarray(id, np.uint64))
         return int(h.sum(dtype=np.uint64))
+
+
+FLAG_CONCURRENT = 8
+
+
+class OracleVC:
+    """N4: sequential CPU table with the reference's general (K-writer, dense) vector-clock merge semantics."""
+
+    def __init__(self, K, local):
+        L = lib()
+        u64p, u32p, i64p, u8p = (C.POINTER(C.c_uint64), C.POINTER(C.c_uint32), C.POINTER(C.c_int64), C.POINTER(C.c_uint8))
+        L.orc_vc_create.restype = C.c_void_p; L.orc_vc_create.argtypes = [C.c_uint32, C.c_uint32]
+        L.orc_vc_destroy.argtypes = [C.c_void_p]
+        L.orc_vc_size.argtypes = [C.c_void_p]; L.orc_vc_size.restype = C.c_uint64
+        L.orc_vc_load_rows.argtypes = [C.c_void_p, C.c_uint64, u64p, u32p, u32p, i64p]
+        L.orc_vc_merge_batch.argtypes = [C.c_void_p, C.c_uint64, u64p, u32p, u32p, i64p, u8p, u32p]; L.orc_vc_merge_batch.restype = C.c_uint64
+        L.orc_vc_get_row.argtypes = [C.c_void_p, C.c_uint64, C.c_uint32, u32p, C.POINTER(C.c_int64), C.POINTER(C.c_int)]; L.orc_vc_get_row.restype = C.c_int
+        L.orc_vc_dump_rows.argtypes = [C.c_void_p, C.c_uint64, u64p, u32p, u32p, i64p]; L.orc_vc_dump_rows.restype = C.c_uint64
+        self._L, self.K = L, K
+        self._h = C.c_void_p(L.orc_vc_create(K, local))
+        assert self._h
+
+    def __del__(self):
+        try:
+            if self._h:
+                self._L.orc_vc_destroy(self._h); self._h = None
+        except Exception:
+            pass
+
+    def __len__(self):
+        return int(self._L.orc_vc_size(self._h))
+
+    def _args(self, id, field, clocks, val):
+        id = np.ascontiguousarray(id, np.uint64); field = np.ascontiguousarray(field, np.uint32)
+        clocks = np.ascontiguousarray(clocks, np.uint32).reshape(len(id), self.K); val = np.ascontiguousarray(val, np.int64)
+        return id, field, clocks, val
+
+    def load_rows(self, id, field, clocks, val):
+        id, field, clocks, val = self._args(id, field, clocks, val)
+        self._L.orc_vc_load_rows(self._h, len(id), _p(id, C.c_uint64), _p(field, C.c_uint32), _p(clocks, C.c_uint32), _p(val, C.c_int64))
+
+    def merge_batch(self, id, field, clocks, val):
+        """-> (flags u8[n] with bit 8 = concurrent, updated u32[w] ascending)"""
+        id, field, clocks, val = self._args(id, field, clocks, val)
+        n = len(id)
+        flags = np.zeros(max(n, 1), np.uint8); upd = np.zeros(max(n, 1), np.uint32)
+        w = self._L.orc_vc_merge_batch(self._h, n, _p(id, C.c_uint64), _p(field, C.c_uint32), _p(clocks, C.c_uint32), _p(val, C.c_int64),
+                                       _p(flags, C.c_uint8), _p(upd, C.c_uint32))
+        return flags[:n], upd[:w].copy()
+
+    def get_row(self, id, field):
+        c = np.zeros(self.K, np.uint32); v = C.c_int64(); sp = C.c_int()
+        ok = self._L.orc_vc_get_row(self._h, int(id), int(field), _p(c, C.c_uint32), C.byref(v), C.byref(sp))
+        return (c.tolist(), v.value, bool(sp.value)) if ok else None
+
+    def dump_rows(self):
+        n = len(self)
+        id = np.zeros(n, np.uint64); field = np.zeros(n, np.uint32); clocks = np.zeros((n, self.K), np.uint32); val = np.zeros(n, np.int64)
+        self._L.orc_vc_dump_rows(self._h, n, _p(id, C.c_uint64), _p(field, C.c_uint32), _p(clocks, C.c_uint32), _p(val, C.c_int64))
+        return id, field, clocks, val
