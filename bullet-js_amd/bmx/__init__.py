@@ -28,6 +28,7 @@ EXPORTS = [
     "bmx_load_rows", "bmx_merge_batch", "bmx_merge_records", "bmx_get_rows", "bmx_get_row", "bmx_dump_rows", "bmx_row_count", "bmx_reserve",
     "bmx_index_build", "bmx_index_drop", "bmx_index_size", "bmx_scan_range", "bmx_scan_equals", "bmx_scan_count", "bmx_scan_filter",
     "bmx_owner_of", "bmx_partition_by_owner", "bmx_partition_by_owner_slabs", "bmx_timer_start", "bmx_timer_stop", "bmx_profile_enable", "bmx_profile_read",
+    "bmx_vc_create", "bmx_vc_destroy", "bmx_vc_last_error", "bmx_vc_load_rows", "bmx_vc_merge_batch", "bmx_vc_get_rows", "bmx_vc_row_count",
 ]
 
 
@@ -94,6 +95,13 @@ def load_library():
     L.bmx_timer_stop.argtypes = [vp, C.POINTER(C.c_float)]; L.bmx_timer_stop.restype = i32
     L.bmx_profile_enable.argtypes = [vp, i32]; L.bmx_profile_enable.restype = i32
     L.bmx_profile_read.argtypes = [vp, C.POINTER(C.c_float), C.POINTER(u32)]; L.bmx_profile_read.restype = i32
+    L.bmx_vc_create.argtypes = [i32, u64, u32, u32, C.POINTER(vp)]; L.bmx_vc_create.restype = i32
+    L.bmx_vc_destroy.argtypes = [vp]; L.bmx_vc_destroy.restype = None
+    L.bmx_vc_last_error.argtypes = [vp]; L.bmx_vc_last_error.restype = C.c_char_p
+    L.bmx_vc_load_rows.argtypes = [vp, u64, vp, vp, vp, vp]; L.bmx_vc_load_rows.restype = i32
+    L.bmx_vc_merge_batch.argtypes = [vp, u64, vp, vp, vp, vp, vp, vp, vp]; L.bmx_vc_merge_batch.restype = i32
+    L.bmx_vc_get_rows.argtypes = [vp, u64, vp, vp, vp, vp, vp]; L.bmx_vc_get_rows.restype = i32
+    L.bmx_vc_row_count.argtypes = [vp, C.POINTER(u64)]; L.bmx_vc_row_count.restype = i32
     _lib = L
     return L
 
@@ -276,6 +284,73 @@ class Engine:
         ms = C.c_float()
         self._chk(self.L.bmx_timer_stop(self.h, C.byref(ms)))
         return ms.value
+
+
+FLAG_CONCURRENT = 8
+VC_ABSENT, VC_DENSE, VC_SPARSE = 0, 1, 2
+
+
+class EngineVC:
+    """N4 table (a bmx_vc): rows carry a K-writer vector clock instead of one timestamp. Host arrays only, synchronous.
+    clocks are (n, K) uint32, component k = writer k's counter (0 = absent from the reference's clock object)."""
+
+    def __init__(self, capacity_rows, k_writers, local_writer, device=0):
+        self.L = load_library()
+        h = C.c_void_p()
+        rc = self.L.bmx_vc_create(int(device), int(capacity_rows), int(k_writers), int(local_writer), C.byref(h))
+        if rc != OK:
+            raise BmxError(rc, (self.L.bmx_vc_last_error(None) or b"").decode())
+        self.h = h
+        self.K = int(k_writers)
+
+    def _chk(self, rc):
+        if rc < 0:
+            raise BmxError(rc, (self.L.bmx_vc_last_error(self.h) or b"").decode())
+        return rc
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.L.bmx_vc_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _cols(self, id, field, clocks, val):
+        id = _np(id, np.uint64); field = _np(field, np.uint32); val = _np(val, np.int64)
+        clocks = _np(clocks, np.uint32).reshape(len(id), self.K) if len(id) else np.zeros((0, self.K), np.uint32)
+        if not (len(id) == len(field) == len(val)):
+            raise ValueError("column lengths differ")
+        return id, field, clocks, val
+
+    def load_rows(self, id, field, clocks, val):
+        id, field, clocks, val = self._cols(id, field, clocks, val)
+        self._chk(self.L.bmx_vc_load_rows(self.h, len(id), _ptr(id), _ptr(field), _ptr(clocks), _ptr(val)))
+
+    def merge_batch(self, id, field, clocks, val):
+        """-> (flags uint8[n], updated uint32[]): per-delta resolve() flags; for each touched row that changed, the index of the
+        last delta that updated it, ascending."""
+        id, field, clocks, val = self._cols(id, field, clocks, val)
+        n = len(id)
+        flags = np.zeros(n, np.uint8); upd = np.zeros(max(n, 1), np.uint32); nu = C.c_uint64()
+        self._chk(self.L.bmx_vc_merge_batch(self.h, n, _ptr(id), _ptr(field), _ptr(clocks), _ptr(val), _ptr(upd), C.byref(nu), _ptr(flags)))
+        return flags, upd[: nu.value].copy()
+
+    def get_rows(self, id, field):
+        """-> (clocks (n,K) uint32, val int64[n], state uint8[n]) with state VC_ABSENT / VC_DENSE / VC_SPARSE."""
+        id = _np(id, np.uint64); field = _np(field, np.uint32)
+        n = len(id)
+        clocks = np.zeros((n, self.K), np.uint32); val = np.zeros(n, np.int64); st = np.zeros(n, np.uint8)
+        self._chk(self.L.bmx_vc_get_rows(self.h, n, _ptr(id), _ptr(field), _ptr(clocks), _ptr(val), _ptr(st)))
+        return clocks, val, st
+
+    def row_count(self):
+        n = C.c_uint64()
+        self._chk(self.L.bmx_vc_row_count(self.h, C.byref(n)))
+        return n.value
 
 
 def owner_of(ids, nshards):

@@ -846,3 +846,5 @@ int bmx_profile_read(bmx_ctx* ctx, float ms_out[3], uint32_t* n_calls) {
 }
 
 }  // extern "C"
+
+#include "bmx_vc.inc"

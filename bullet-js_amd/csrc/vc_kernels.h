@@ -1,0 +1,233 @@
+// vc_kernels.h — N4: K-writer vector-clock rows, gfx950. 64-byte slots:
+//   { id u64 | field u32 | head u32 | val i64 | state u32 | pad u32 | clock u32[8] }
+// Two launches per batch, no optimistic writes (the outcome for concurrent clocks depends on the order of the deltas):
+//   k_vc_link    every delta finds/creates its row, claims it (one atomicExch) and links into the row's list
+//   k_vc_resolve the LAST claimer of a row applies the row's deltas in index order with the reference's resolve()
+//                (src/bullet-crt.js:164-279, general clocks), writes every delta's flags, the row's final state and the
+//                last updating delta; rows are written by exactly one lane, after every read of the launch pair
+#pragma once
+#include "slot.h"
+#include "merge_kernels.h"
+
+namespace bmx {
+
+constexpr int VC_MAXK = 8;
+constexpr uint32_t VC_ABSENT = 0, VC_DENSE = 1, VC_SPARSE = 2;
+
+struct alignas(64) VSlot {
+  uint64_t id; uint32_t field; uint32_t head;
+  int64_t val; uint32_t state; uint32_t pad;
+  uint32_t clock[VC_MAXK];
+};
+static_assert(sizeof(VSlot) == 64, "vc slot is 64 bytes");
+
+struct VcArgs {
+  VSlot* slots; uint64_t nslots;
+  const uint64_t* id; const uint32_t* field; const uint32_t* clocks; const int64_t* val;
+  uint32_t n, K, local, epoch;
+  uint32_t* next; uint32_t* slot_of; uint8_t* wflag; uint8_t* flags; uint32_t* blk_info;
+  unsigned long long* row_count; uint32_t* status;
+  int load;   // 1: bulk preload (the highest-index delta of a key overwrites the row, dense)
+};
+
+__global__ __launch_bounds__(256) void k_vc_init(VSlot* slots, uint64_t nslots) {
+  for (uint64_t s = (uint64_t)blockIdx.x * 256u + threadIdx.x; s < nslots; s += (uint64_t)gridDim.x * 256u) {
+    uint4* q = reinterpret_cast<uint4*>(slots + s);
+    q[0] = make_uint4(0xFFFFFFFFu, 0xFFFFFFFFu, FIELD_PENDING, 0u);
+    q[1] = make_uint4(0u, 0u, VC_ABSENT, 0u);
+    q[2] = make_uint4(0u, 0u, 0u, 0u); q[3] = make_uint4(0u, 0u, 0u, 0u);
+  }
+}
+
+// epoch wrap: forget every claim tag (a stale head of the same epoch value would splice an old index into a new list)
+__global__ __launch_bounds__(256) void k_vc_sweep_heads(VSlot* slots, uint64_t nslots) {
+  for (uint64_t s = (uint64_t)blockIdx.x * 256u + threadIdx.x; s < nslots; s += (uint64_t)gridDim.x * 256u) slots[s].head = 0u;
+}
+
+__global__ __launch_bounds__(256) void k_vc_link(VcArgs A) {
+  const uint32_t j = blockIdx.x * 256u + threadIdx.x;
+  const bool active = j < A.n;
+  uint32_t slot = 0xFFFFFFFFu;
+  bool created = false;
+  if (active) {
+    const uint64_t id = A.id[j]; const uint32_t field = A.field[j]; const int64_t v = A.val[j];
+    bool valid = id != EMPTY_ID && field != FIELD_PENDING && v >= -VAL_MAX && v <= VAL_MAX;
+    if (!valid) atomicOr(A.status, ST_RANGE);
+    if (valid) {
+      const uint32_t tag = (A.epoch << IDX_BITS) | j;
+      uint64_t s = home_slot(key_hash(id, field), A.nslots);
+      bool found = false;
+      for (uint64_t p = 0; p < A.nslots && !found; ++p) {
+        VSlot* sl = A.slots + s;
+        uint4 lo = reinterpret_cast<const uint4*>(sl)[0];
+        uint64_t sid = (uint64_t)lo.x | ((uint64_t)lo.y << 32);
+        uint32_t sf = lo.z;
+        if (sid == EMPTY_ID) {
+          unsigned long long old = atomicCAS(reinterpret_cast<unsigned long long*>(&sl->id), (unsigned long long)EMPTY_ID, (unsigned long long)id);
+          if (old == EMPTY_ID) {   // created: one 8-byte store publishes the field and claims the head (see merge_kernels.h)
+            __hip_atomic_store(reinterpret_cast<unsigned long long*>(&sl->field), (unsigned long long)field | ((unsigned long long)tag << 32),
+                               __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            created = true; found = true; slot = (uint32_t)s;
+            break;
+          }
+          sid = old; sf = FIELD_PENDING;
+        }
+        if (sid == id) {
+          if (sf == FIELD_PENDING) {
+            uint32_t spins = 0;
+            do { sf = __hip_atomic_load(&sl->field, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); if (sf != FIELD_PENDING) break; __builtin_amdgcn_s_sleep(1); } while (++spins < (1u << 22));
+            if (sf == FIELD_PENDING) { atomicOr(A.status, ST_SPIN); break; }
+          }
+          if (sf == field) {
+            uint32_t prev = atomicExch(&sl->head, tag);
+            if ((prev >> IDX_BITS) == A.epoch) A.next[j] = (A.epoch << IDX_BITS) | (prev & IDX_MASK);
+            found = true; slot = (uint32_t)s;
+            break;
+          }
+        }
+        s = (s + 1 == A.nslots) ? 0 : s + 1;
+      }
+      if (!found && slot == 0xFFFFFFFFu) atomicOr(A.status, ST_FULL);
+    }
+    A.slot_of[j] = slot;
+    A.wflag[j] = W_NONE;
+    if (A.flags) A.flags[j] = 0;
+  }
+  // rows created by this block: one (non-returning) add per block, not per lane or wave (a single hot word is slow)
+  __shared__ uint32_t s_c[4];
+  unsigned long long mc = __ballot(created);
+  if (lane_id() == 0) s_c[threadIdx.x >> 6] = (uint32_t)__popcll(mc);
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    uint32_t c = s_c[0] + s_c[1] + s_c[2] + s_c[3];
+    if (c) atomicAdd(A.row_count, (unsigned long long)c);
+    A.blk_info[blockIdx.x] = 0;
+  }
+}
+
+// resolve() for one delta against the running row state held in registers (static indices only)
+struct VcState { uint32_t c[VC_MAXK]; int64_t val; uint32_t state; };
+__device__ __forceinline__ uint32_t vc_apply(VcState& R, const uint32_t* in, int64_t v, uint32_t K, uint32_t local) {
+  if (R.state == VC_ABSENT) {                    // "no current state": clock {local: 2}, incoming clock dropped (:172-185)
+#pragma unroll
+    for (int k = 0; k < VC_MAXK; k++) R.c[k] = ((uint32_t)k == local) ? 2u : 0u;
+    R.val = v; R.state = VC_SPARSE;
+    return BMX_FLAG_INCOMING;
+  }
+  bool in_ahead = false, cur_ahead = false, equal = true;
+#pragma unroll
+  for (int k = 0; k < VC_MAXK; k++) if ((uint32_t)k < K) {
+    if (in[k] > R.c[k]) in_ahead = true; else if (R.c[k] > in[k]) cur_ahead = true;
+    if (in[k] != R.c[k]) equal = false;
+  }
+  const int cmp = (in_ahead && cur_ahead) ? 0 : (in_ahead ? 1 : (cur_ahead ? -1 : 0));
+  const bool json_equal = equal && (R.state != VC_SPARSE || K == 1);
+  if (cmp == 0 && json_equal) {                  // identical clocks: value comparison (:200-233)
+    if (v == R.val) return 0u;
+    if (v > R.val) { R.val = v; return BMX_FLAG_INCOMING; }
+    return BMX_FLAG_CURRENT;
+  }
+  if (cmp < 0) return BMX_FLAG_CURRENT | BMX_FLAG_HISTORICAL;    // :251-263
+#pragma unroll
+  for (int k = 0; k < VC_MAXK; k++) if ((uint32_t)k < K && in[k] > R.c[k]) R.c[k] = in[k];   // merged clock stored with the update
+  R.state = VC_DENSE;
+  if (cmp > 0) { R.val = v; return BMX_FLAG_INCOMING; }          // :236-248
+  if (v >= R.val) R.val = v;                                      // concurrent: mergeValues on non-objects (:266-278, :133-135)
+  return BMX_FLAG_CONCURRENT;
+}
+
+// one row's work for its last claimer; returns the index of the last delta that updated the row (or ~0u)
+__device__ __forceinline__ uint32_t vc_resolve_row(const VcArgs& A, VSlot* sl, uint32_t head) {
+  const uint4* q = reinterpret_cast<const uint4*>(sl);
+  VcState R;
+  {
+    const uint4 mid = q[1], c0 = q[2], c1 = q[3];
+    R.val = (int64_t)((uint64_t)mid.x | ((uint64_t)mid.y << 32)); R.state = mid.z;
+    R.c[0] = c0.x; R.c[1] = c0.y; R.c[2] = c0.z; R.c[3] = c0.w; R.c[4] = c1.x; R.c[5] = c1.y; R.c[6] = c1.z; R.c[7] = c1.w;
+  }
+  uint32_t last_upd = ~0u;
+  if (A.load) {
+    // bulk preload: the highest-index delta of the key overwrites the row (dense)
+    uint32_t best = head, idx = head, steps = 0;
+    for (;;) { if (idx > best) best = idx; uint32_t nx = A.next[idx]; if ((nx >> IDX_BITS) != A.epoch) break; idx = nx & IDX_MASK; if (++steps > A.n) break; }
+#pragma unroll
+    for (int k = 0; k < VC_MAXK; k++) R.c[k] = ((uint32_t)k < A.K) ? A.clocks[(size_t)best * A.K + k] : 0u;
+    R.val = A.val[best]; R.state = VC_DENSE; last_upd = best;
+  } else {
+    // apply the row's deltas in index order: each round walks the list for the smallest index above the last one applied
+    uint32_t done = 0, prev_idx = 0; bool first_round = true;
+    for (uint32_t guard = 0; guard <= A.n; guard++) {
+      uint32_t pick = ~0u, idx = head, steps = 0, members = 0;
+      for (;;) {
+        members++;
+        if ((first_round || idx > prev_idx) && idx < pick) pick = idx;
+        uint32_t nx = A.next[idx];
+        if ((nx >> IDX_BITS) != A.epoch) break;
+        idx = nx & IDX_MASK;
+        if (++steps > A.n) { atomicOr(A.status, ST_SPIN); return ~0u; }
+      }
+      if (pick == ~0u) break;
+      uint32_t in[VC_MAXK];
+#pragma unroll
+      for (int k = 0; k < VC_MAXK; k++) in[k] = ((uint32_t)k < A.K) ? A.clocks[(size_t)pick * A.K + k] : 0u;
+      const uint32_t fl = vc_apply(R, in, A.val[pick], A.K, A.local);
+      if (A.flags) A.flags[pick] = (uint8_t)fl;
+      if (fl & (BMX_FLAG_INCOMING | BMX_FLAG_CONCURRENT)) last_upd = pick;
+      prev_idx = pick; first_round = false;
+      if (++done >= members) break;
+    }
+  }
+  // one writer per row, after all reads of this launch pair
+  uint4* w = reinterpret_cast<uint4*>(sl);
+  w[1] = make_uint4((uint32_t)(uint64_t)R.val, (uint32_t)((uint64_t)R.val >> 32), R.state, 0u);
+  w[2] = make_uint4(R.c[0], R.c[1], R.c[2], R.c[3]);
+  w[3] = make_uint4(R.c[4], R.c[5], R.c[6], R.c[7]);
+  return last_upd;
+}
+
+__global__ __launch_bounds__(256) void k_vc_resolve(VcArgs A) {
+  const uint32_t j = blockIdx.x * 256u + threadIdx.x;
+  uint32_t last_upd = ~0u;
+  if (j < A.n) {
+    const uint32_t slot = A.slot_of[j];
+    if (slot != 0xFFFFFFFFu) {
+      VSlot* sl = A.slots + slot;
+      const uint32_t head = __builtin_nontemporal_load(&sl->head) & IDX_MASK;
+      if (head == j) last_upd = vc_resolve_row(A, sl, head);     // only the last claimer of a row works
+    }
+  }
+  // winner marks + the per-256-delta counts k_compact_winners ranks with. Winners inside this block's own 256 deltas
+  // (every singleton row) are counted with one add per wave; only a winner that sits in another block pays its own atomic.
+  if (last_upd != ~0u) A.wflag[last_upd] = W_WINNER;
+  const bool own = last_upd != ~0u && (last_upd >> 8) == blockIdx.x;
+  if (last_upd != ~0u && !own) atomicAdd(&A.blk_info[last_upd >> 8], 1u);
+  const unsigned long long m = __ballot(own);
+  if (lane_id() == 0 && m) atomicAdd(&A.blk_info[blockIdx.x], (uint32_t)__popcll(m));
+}
+
+__global__ __launch_bounds__(256) void k_vc_get(const VSlot* slots, uint64_t nslots, uint32_t n, uint32_t K, const uint64_t* id, const uint32_t* field,
+                                                uint32_t* clocks, int64_t* val, uint8_t* state) {
+  uint32_t j = blockIdx.x * 256u + threadIdx.x;
+  if (j >= n) return;
+  const uint64_t kid = id[j]; const uint32_t kf = field[j];
+  uint64_t s = home_slot(key_hash(kid, kf), nslots);
+  uint8_t st = VC_ABSENT; int64_t v = 0; uint32_t c[VC_MAXK] = {0, 0, 0, 0, 0, 0, 0, 0};
+  for (uint64_t p = 0; p < nslots; ++p) {
+    const uint4* q = reinterpret_cast<const uint4*>(slots + s);
+    uint4 lo = q[0];
+    uint64_t sid = (uint64_t)lo.x | ((uint64_t)lo.y << 32);
+    if (sid == EMPTY_ID) break;
+    if (sid == kid && lo.z == kf) {
+      uint4 mid = q[1], c0 = q[2], c1 = q[3];
+      v = (int64_t)((uint64_t)mid.x | ((uint64_t)mid.y << 32)); st = (uint8_t)mid.z;
+      c[0] = c0.x; c[1] = c0.y; c[2] = c0.z; c[3] = c0.w; c[4] = c1.x; c[5] = c1.y; c[6] = c1.z; c[7] = c1.w;
+      break;
+    }
+    s = (s + 1 == nslots) ? 0 : s + 1;
+  }
+  val[j] = v; state[j] = st;
+#pragma unroll
+  for (int k = 0; k < VC_MAXK; k++) if ((uint32_t)k < K) clocks[(size_t)j * K + k] = c[k];
+}
+
+}  // namespace bmx

@@ -201,6 +201,33 @@ int bmx_partition_by_owner_slabs(bmx_ctx* ctx, uint64_t n, const uint64_t* id, c
                                  const int64_t* val, uint32_t nshards, uint64_t slab_records, bmx_delta_rec* recs_out,
                                  uint64_t* counts_out_dev);
 
+/* ---- N4: fixed-K multi-writer vector clocks -------------------------------------
+ * A second kind of table for rows whose clocks have up to 8 writers: {writer_0: c0, ..., writer_{K-1}: c_{K-1}} with small
+ * non-negative integer components and integer values. Replaces resolve() in full for such rows — dominance test
+ * (compareVectorClocks src/bullet-crt.js:68-95, missing component = 0), component-wise max merge (:103-114), the
+ * "identical clocks -> value comparison" branch (:200-233), and the "concurrent" branch whose value is
+ * compare(in,cur) >= 0 ? in : cur (:266-278, :133-135) — including the quirk that a first write stores the one-key clock
+ * {local: 2} (:172-185). Contract: incoming clocks are dense (the host lists all K writers, same order, every time).
+ * Deltas of one key are applied in index order (the result is order dependent for concurrent clocks), so batches are
+ * exact for any duplication. flags[j] additionally carries BMX_FLAG_CONCURRENT. updated_idx = ascending indices of the
+ * last delta per key that caused a store (doUpdate: src/bullet-crt.js:383). Host buffers only (synchronous). */
+#define BMX_FLAG_CONCURRENT 8u
+#define BMX_VC_MAX_WRITERS 8
+#define BMX_VC_ABSENT 0
+#define BMX_VC_DENSE  1   /* the row's clock lists all K writers */
+#define BMX_VC_SPARSE 2   /* the row still carries the one-key clock {local: 2} of its first write */
+typedef struct bmx_vc bmx_vc;
+int bmx_vc_create(int device, uint64_t capacity_rows, uint32_t k_writers, uint32_t local_writer, bmx_vc** out);
+void bmx_vc_destroy(bmx_vc* t);
+const char* bmx_vc_last_error(const bmx_vc* t);
+int bmx_vc_load_rows(bmx_vc* t, uint64_t n, const uint64_t* id, const uint32_t* field, const uint32_t* clocks /* n*K */,
+                     const int64_t* val);
+int bmx_vc_merge_batch(bmx_vc* t, uint64_t n, const uint64_t* id, const uint32_t* field, const uint32_t* clocks /* n*K */,
+                       const int64_t* val, uint32_t* updated_idx, uint64_t* n_updated, uint8_t* flags);
+int bmx_vc_get_rows(bmx_vc* t, uint64_t n, const uint64_t* id, const uint32_t* field, uint32_t* clocks_out /* n*K */,
+                    int64_t* val_out, uint8_t* state_out);
+int bmx_vc_row_count(bmx_vc* t, uint64_t* n_out);
+
 /* ---- timing helpers (HIP events on the context's stream; used by bench.py) ------------------- */
 int bmx_timer_start(bmx_ctx* ctx);
 int bmx_timer_stop(bmx_ctx* ctx, float* ms_out);    /* synchronises on the stop event */

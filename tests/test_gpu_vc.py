@@ -1,0 +1,140 @@
+"""GPU parity, N4: K-writer vector-clock rows on the device (bmx_vc_* through the C ABI) vs
+ - the golden vectors made by the real reference (tests/golden/g6_vc_*.json, oracle/gen_golden.js runVcStream), and
+ - oracle/bmx_oracle.c orc_vc_* on seeded random batches (hot keys, inserts, many batches, epoch wrap).
+Bit-exact: flags per delta, the ascending list of last-updating deltas, and every row's (clock, value, sparse/dense)."""
+import base64
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+import bmx
+from oracle import streams
+from oracle.oracle import OracleVC
+from helpers import load_golden
+
+F0 = streams.field_hash(0)
+keyid = lambda row: streams.splitmix64(row + 1)
+
+
+def _compare_rows(e, o, ids, fields):
+    clocks, val, st = e.get_rows(ids, fields)
+    for k, (i, f) in enumerate(zip(ids, fields)):
+        ref = o.get_row(int(i), int(f))
+        if ref is None:
+            assert st[k] == bmx.VC_ABSENT, (k, st[k])
+            continue
+        c, v, sparse = ref
+        assert st[k] == (bmx.VC_SPARSE if sparse else bmx.VC_DENSE), (k, st[k], sparse)
+        assert clocks[k].tolist() == c and val[k] == v, (k, clocks[k], c, val[k], v)
+
+
+@pytest.mark.parametrize("name", ["g6_vc_unique_2k.json", "g6_vc_dups_500.json", "g6_vc_empty_start.json"])
+def test_vc_device_matches_reference_golden(name):
+    g = load_golden(name)
+    K = len(g["writers"]); local = g["writers"].index("w")
+    e = bmx.EngineVC(max(4096, 2 * (len(g["resident"]) + len(g["deltas"]))), K, local)
+    if g["resident"]:
+        e.load_rows([keyid(r[0]) for r in g["resident"]], [F0] * len(g["resident"]), [r[1] for r in g["resident"]], [r[2] for r in g["resident"]])
+    d = g["deltas"]
+    flags, upd = e.merge_batch([keyid(x[0]) for x in d], [F0] * len(d), [x[1] for x in d], [x[2] for x in d])
+    assert np.array_equal(flags, np.frombuffer(base64.b64decode(g["flags_b64"]), dtype=np.uint8))
+    assert upd.tolist() == g["updated"]
+    assert e.row_count() == len(g["final_rows"])
+    ids = np.array([keyid(r[0]) for r in g["final_rows"]], np.uint64)
+    clocks, val, st = e.get_rows(ids, np.full(len(ids), F0, np.uint32))
+    for k, (row, clock, v, nkeys) in enumerate(g["final_rows"]):
+        assert clocks[k].tolist() == clock and val[k] == v, (row, clocks[k], clock, val[k], v)
+        assert st[k] == (bmx.VC_SPARSE if nkeys == 1 else bmx.VC_DENSE), (row, st[k], nkeys)
+    e.close()
+
+
+def _rand_batch(rng, n, nkeys, K, cmax, vr, hot=0.0, nfields=2):
+    rows = rng.integers(0, nkeys, n)
+    if hot > 0:
+        h = rng.random(n) < hot
+        rows[h] = rng.integers(0, 4, int(h.sum()))
+    ids = np.array([keyid(int(r)) for r in rows], np.uint64)
+    fields = np.array([streams.field_hash(int(x)) for x in rng.integers(0, nfields, n)], np.uint32)
+    clocks = rng.integers(0, cmax + 1, (n, K)).astype(np.uint32)
+    val = rng.integers(-vr, vr + 1, n).astype(np.int64)
+    return ids, fields, clocks, val
+
+
+@pytest.mark.parametrize("K,local", [(1, 0), (2, 1), (3, 2), (8, 5)])
+def test_vc_random_batches_match_oracle(K, local):
+    rng = np.random.default_rng(100 + K)
+    e = bmx.EngineVC(40000, K, local); o = OracleVC(K, local)
+    seen = set()
+    for b in range(6):
+        ids, fields, clocks, val = _rand_batch(rng, 5000, 3000, K, 3 + b, 3, hot=0.2 if b % 2 else 0.0)
+        f1, u1 = e.merge_batch(ids, fields, clocks, val)
+        f2, u2 = o.merge_batch(ids, fields, clocks, val)
+        assert np.array_equal(f1, f2), (b, np.nonzero(f1 != f2)[0][:10])
+        assert np.array_equal(u1, u2), b
+        assert e.row_count() == len(o)
+        seen.update(zip(ids.tolist(), fields.tolist()))
+    keys = sorted(seen)
+    _compare_rows(e, o, np.array([k[0] for k in keys], np.uint64), np.array([k[1] for k in keys], np.uint32))
+    e.close()
+
+
+def test_vc_all_deltas_one_key_and_absent_lookup():
+    K, local = 3, 0
+    rng = np.random.default_rng(7)
+    n = 3000
+    e = bmx.EngineVC(8192, K, local); o = OracleVC(K, local)
+    ids = np.full(n, keyid(42), np.uint64); fields = np.full(n, F0, np.uint32)
+    clocks = rng.integers(0, 50, (n, K)).astype(np.uint32); val = rng.integers(-5, 6, n).astype(np.int64)
+    f1, u1 = e.merge_batch(ids, fields, clocks, val)
+    f2, u2 = o.merge_batch(ids, fields, clocks, val)
+    assert np.array_equal(f1, f2) and np.array_equal(u1, u2) and len(u1) == 1
+    _compare_rows(e, o, np.array([keyid(42), keyid(43)], np.uint64), np.array([F0, F0], np.uint32))
+    e.close()
+
+
+def test_vc_load_rows_last_wins_then_merge():
+    K, local = 3, 2
+    rng = np.random.default_rng(11)
+    e = bmx.EngineVC(20000, K, local); o = OracleVC(K, local)
+    ids, fields, clocks, val = _rand_batch(rng, 6000, 2000, K, 5, 4)      # duplicates inside the preload: the last one stays
+    e.load_rows(ids, fields, clocks, val); o.load_rows(ids, fields, clocks, val)
+    assert e.row_count() == len(o)
+    ids2, fields2, clocks2, val2 = _rand_batch(rng, 6000, 2500, K, 6, 4)
+    f1, u1 = e.merge_batch(ids2, fields2, clocks2, val2); f2, u2 = o.merge_batch(ids2, fields2, clocks2, val2)
+    assert np.array_equal(f1, f2) and np.array_equal(u1, u2)
+    keys = sorted(set(zip(ids.tolist(), fields.tolist())) | set(zip(ids2.tolist(), fields2.tolist())))
+    _compare_rows(e, o, np.array([k[0] for k in keys], np.uint64), np.array([k[1] for k in keys], np.uint32))
+    e.close()
+
+
+def test_vc_epoch_wrap_many_small_batches():
+    K, local = 2, 0
+    rng = np.random.default_rng(5)
+    e = bmx.EngineVC(4096, K, local); o = OracleVC(K, local)
+    for b in range(300):          # > 255 batches: claim tags wrap once
+        ids, fields, clocks, val = _rand_batch(rng, 64, 200, K, 2 + b // 20, 2, hot=0.3, nfields=1)
+        f1, u1 = e.merge_batch(ids, fields, clocks, val); f2, u2 = o.merge_batch(ids, fields, clocks, val)
+        assert np.array_equal(f1, f2) and np.array_equal(u1, u2), b
+    ids = np.array([keyid(r) for r in range(200)], np.uint64)
+    _compare_rows(e, o, ids, np.full(200, F0, np.uint32))
+    e.close()
+
+
+def test_vc_errors():
+    with pytest.raises(bmx.BmxError):
+        bmx.EngineVC(100, 9, 0)
+    with pytest.raises(bmx.BmxError):
+        bmx.EngineVC(100, 3, 3)
+    e = bmx.EngineVC(2048, 2, 0)
+    f, u = e.merge_batch([], [], np.zeros((0, 2), np.uint32), [])
+    assert len(f) == 0 and len(u) == 0
+    with pytest.raises(bmx.BmxError) as ei:
+        e.merge_batch([keyid(1)], [F0], [[1, 1]], [1 << 60])
+    assert ei.value.code == bmx.ERR_RANGE
+    with pytest.raises(bmx.BmxError) as ei:
+        n = 5000
+        e.merge_batch([keyid(i) for i in range(n)], [F0] * n, np.ones((n, 2), np.uint32), [0] * n)
+    assert ei.value.code == bmx.ERR_FULL
+    e.close()
