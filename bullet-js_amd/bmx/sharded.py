@@ -36,8 +36,13 @@ class EngineOps:
     def __init__(self, engine, device):
         self.e = engine
         self.device = device
-        # merge stream = torch's current stream: all_to_all -> merge are ordered without extra events in merge_step()
-        self.main = torch.cuda.current_stream(device)
+        # merge stream = a dedicated stream that also becomes torch's CURRENT stream, so that in merge_step() partition ->
+        # counts.cpu() -> all_to_all -> merge are ordered without extra events. (Not the default stream: its handle is 0,
+        # which bmx_set_stream reads as "use the engine's own stream", and that one is not ordered with torch's work.)
+        self._prev_stream = torch.cuda.current_stream(device)
+        self.main = torch.cuda.Stream(device=device)
+        self.main.wait_stream(self._prev_stream)
+        torch.cuda.set_stream(self.main)
         engine.set_stream(self.main.cuda_stream)
         self.comm = None
         self.pe = None
@@ -84,18 +89,13 @@ class EngineOps:
     def enter_pipeline(self):
         self._pipeline()
         if not getattr(self, "_entered", False):
-            self._prev_stream = torch.cuda.current_stream(self.device)
-            self.main = torch.cuda.Stream(device=self.device)
-            self.e.set_stream(self.main.cuda_stream)
             torch.cuda.set_stream(self.comm)
             self._entered = True
 
     def leave_pipeline(self):
         if getattr(self, "_entered", False):
             self.sync()
-            torch.cuda.set_stream(self._prev_stream)
-            self.main = self._prev_stream
-            self.e.set_stream(self.main.cuda_stream)
+            torch.cuda.set_stream(self.main)
             self._entered = False
 
     def comm_ctx(self):
@@ -113,6 +113,9 @@ class EngineOps:
 
     def close(self):
         self.leave_pipeline()
+        self.sync()
+        self.e.set_stream(0)                       # back to the engine's own stream
+        torch.cuda.set_stream(self._prev_stream)
         if self.pe is not None:
             self.pe.close()
             self.pe = None

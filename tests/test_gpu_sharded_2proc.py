@@ -1,0 +1,46 @@
+"""GPU, two ranks: the N>1 product path (bmx/sharded.py with EngineOps: device partition into slabs, events between the
+merge and exchange streams, merge of received records with padding) run by two processes that share cuda:0, launched with
+torch.distributed.run exactly as the driver launches bench.py. The union of the two shards must equal ONE oracle fed
+the same batches in global order, bit for bit. (RCCL itself cannot run two ranks on one device; transport here is gloo.)"""
+import os
+import socket
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+def _free_port():
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); p = s.getsockname()[1]; s.close()
+    return p
+
+
+@pytest.mark.parametrize("mode", ["exact", "pipelined"])
+def test_two_ranks_on_one_gpu_equal_single_merge(tmp_path, mode):
+    world = 2
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world), "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.join(HERE, "sharded_gpu_worker.py"), str(tmp_path), mode]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    from bmx import synth
+    from oracle.oracle import Oracle, rows_digest, owner_of
+    R, D, NB = 40000, 6000, 5
+    o = Oracle()
+    o.load_rows(*synth.big_resident(R, seed=1, T0=1000, DT=1000))
+    for b in range(NB):
+        for rank in range(world):
+            o.merge_batch(*synth.big_deltas(D, R, seed=5 + 100 * rank, T0=1000, DT=1000, insert_pct=15, hot_pct=30, hot_keys=40, unique=False, batch=b))
+    parts = [np.load(os.path.join(str(tmp_path), "rank%d.npz" % r)) for r in range(world)]
+    assert sum(int(p["nloaded"]) for p in parts) == R
+    for r, p in enumerate(parts):
+        assert (owner_of(p["id"], world) == r).all()
+        assert int(p["recv"]) > 0 and int(p["sent"]) > 0 and int(p["winners"].sum()) > 0
+    ids = np.concatenate([p["id"] for p in parts]); f = np.concatenate([p["f"] for p in parts])
+    ts = np.concatenate([p["ts"] for p in parts]); val = np.concatenate([p["val"] for p in parts])
+    assert len(ids) == len(o)
+    assert rows_digest(ids, f, ts, val) == o.digest()
