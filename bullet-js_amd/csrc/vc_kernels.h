@@ -44,6 +44,30 @@ __global__ __launch_bounds__(256) void k_vc_sweep_heads(VSlot* slots, uint64_t n
   for (uint64_t s = (uint64_t)blockIdx.x * 256u + threadIdx.x; s < nslots; s += (uint64_t)gridDim.x * 256u) slots[s].head = 0u;
 }
 
+// growth: re-insert every row of the old table into a larger, initialised one (claim tags are dropped: head = 0)
+__global__ __launch_bounds__(256) void k_vc_rehash(const VSlot* old_slots, uint64_t old_n, VSlot* slots, uint64_t nslots, uint32_t* status) {
+  for (uint64_t i = (uint64_t)blockIdx.x * 256u + threadIdx.x; i < old_n; i += (uint64_t)gridDim.x * 256u) {
+    const uint4* q = reinterpret_cast<const uint4*>(old_slots + i);
+    const uint4 lo = q[0];
+    const uint64_t id = (uint64_t)lo.x | ((uint64_t)lo.y << 32);
+    if (id == EMPTY_ID) continue;
+    uint64_t s = home_slot(key_hash(id, lo.z), nslots);
+    bool placed = false;
+    for (uint64_t p = 0; p < nslots; ++p) {
+      VSlot* sl = slots + s;
+      if (atomicCAS(reinterpret_cast<unsigned long long*>(&sl->id), (unsigned long long)EMPTY_ID, (unsigned long long)id) == EMPTY_ID) {
+        uint4* w = reinterpret_cast<uint4*>(sl);
+        sl->field = lo.z; sl->head = 0u;
+        w[1] = q[1]; w[2] = q[2]; w[3] = q[3];
+        placed = true;
+        break;
+      }
+      s = (s + 1 == nslots) ? 0 : s + 1;
+    }
+    if (!placed) atomicOr(status, ST_FULL);
+  }
+}
+
 __global__ __launch_bounds__(256) void k_vc_link(VcArgs A) {
   const uint32_t j = blockIdx.x * 256u + threadIdx.x;
   const bool active = j < A.n;

@@ -40,4 +40,32 @@ class DeviceGraph {
   }
 }
 
+/*
+ * DeviceVcTable — N4 (SURVEY §8(f)): rows with a K-writer vector clock (a bmx_vc). `writers` fixes the component order;
+ * `local` is this peer's id (the reference stores clock {local: 2} for a first write). Host typed arrays in and out.
+ */
+class DeviceVcTable {
+  constructor(writers, local, opts = {}) {
+    this.native = requireNative();
+    if (!Array.isArray(writers) || writers.length < 1 || writers.length > this.native.VC_MAX_WRITERS || writers.indexOf(local) < 0) {
+      const err = new Error("bmx: vector-clock mode needs 1.." + this.native.VC_MAX_WRITERS + " writer ids that include this peer's id");
+      err.code = "BMX_BAD_WRITERS";
+      throw err;
+    }
+    this.writers = writers.slice();
+    this.K = writers.length;
+    this.local = writers.indexOf(local);
+    this.handle = this.native.vcCreate(opts.device || 0, opts.vcCapacityRows || opts.capacityRows || (1 << 16), this.K, this.local);
+    this.keys = new KeyDictionary();
+  }
+  loadRows(c) { this.native.vcLoadRows(this.handle, c.id, c.field, c.clocks, c.val); }
+  mergeBatch(c) { return this.native.vcMergeBatch(this.handle, c.id, c.field, c.clocks, c.val); }
+  getRows(id, field) { return this.native.vcGetRows(this.handle, id, field); }
+  rowCount() { return this.native.vcRowCount(this.handle); }
+  close() {
+    if (this.handle) { this.native.vcDestroy(this.handle); this.handle = null; }
+  }
+}
+
 module.exports = DeviceGraph;
+module.exports.DeviceVcTable = DeviceVcTable;

@@ -14,7 +14,7 @@
  *   - batches (sync chunks, bulk loads: src/bullet-network-sync.js:551-569) go to the MI355X through
  *     mergeBatch()/mergeEntries(): typed columns -> bmx_merge_batch. That path has no host implementation.
  */
-const { Columns, fieldId, isDeviceInt, scalarClock } = require("./hash");
+const { Columns, VcColumns, fieldId, isDeviceInt, scalarClock, denseClock } = require("./hash");
 
 const REASON = {
   fresh: "no current state",
@@ -44,7 +44,9 @@ function verdict(winner, clock, value, reason, extra) {
 class GpuCRT {
   /**
    * @param {object} bullet  the Bullet instance (needs .id, .meta, ._getData)
-   * @param {object} [opts]  { graph: DeviceGraph (shared with GpuQuery), device, capacityRows, writer }
+   * @param {object} [opts]  { graph: DeviceGraph (shared with GpuQuery), device, capacityRows, writer,
+   *                           writers: [ids] — N4: batch rows carry a vector clock over exactly these (<= 8) writers,
+   *                           this peer's id among them, and mergeEntries() uses the device's vector-clock table }
    */
   constructor(bullet, opts = {}) {
     this.bullet = bullet;
@@ -224,6 +226,7 @@ class GpuCRT {
    * -> {applied: [{entry, field}], nConflicts, host: [entry indices]}
    */
   mergeEntries(entries, opts = {}) {
+    if (this._opts.writers) return this._mergeEntriesVector(entries, opts);
     const writer = opts.writer || this.bullet.id;
     const g = this.graph;
     let rows = 0;
@@ -292,6 +295,104 @@ class GpuCRT {
     }
   }
 
+  /* ---------------------------------------------------------------- N4: K-writer vector clocks on the device */
+  get vcTable() {
+    if (!this._vc) {
+      const { DeviceVcTable } = require("./device-graph");
+      this._vc = new DeviceVcTable(this._opts.writers, this.bullet.id, this._opts);   // throws without the addon / a GPU
+    }
+    return this._vc;
+  }
+
+  /* stored clock of a device row as the reference would hold it: {local: n} after a first write, all K writers otherwise */
+  _clockObject(comps, off, state) {
+    const t = this.vcTable, c = {};
+    if (state === t.native.VC_SPARSE) { c[t.writers[t.local]] = comps[off + t.local]; return c; }
+    for (let k = 0; k < t.K; k++) c[t.writers[k]] = comps[off + k];
+    return c;
+  }
+
+  /**
+   * mergeEntries() when the resolver was created with opts.writers (general vector clocks, SURVEY §8(f) N4).
+   * An entry goes to the device when its clock has exactly those writers as keys, in that order, with uint32 counters, and
+   * its data is an integer or an object of integer fields; everything else is returned in `host`.
+   * Device semantics = resolve() applied delta by delta in entry order (src/bullet-crt.js:164-279).
+   * -> {applied: [{entry, field}] (last updating delta of every row that changed, in entry order), flags: Uint8Array per
+   *     device row (1 incoming, 2 current, 4 historical, 8 concurrent), rows: [{entry, field}] per device row,
+   *     nApplied, nConflicts (concurrent merges), nRows, host}
+   */
+  _mergeEntriesVector(entries, opts = {}) {
+    const t = this.vcTable;
+    const plan = [];
+    let rows = 0;
+    for (const e of entries) {
+      const comps = denseClock(e.vectorClock, t.writers);
+      let fields = null;
+      if (comps) {
+        if (isDeviceInt(e.data)) fields = [[null, e.data]];
+        else if (e.data && typeof e.data === "object" && !Array.isArray(e.data)) {
+          fields = [];
+          for (const k of Object.keys(e.data)) {
+            if (k === "__vectorClock" || k === "__fromNetwork") continue;
+            if (!isDeviceInt(e.data[k])) { fields = null; break; }
+            fields.push([k, e.data[k]]);
+          }
+        }
+      }
+      plan.push(fields && fields.length ? { comps, fields } : null);
+      if (fields) rows += fields.length;
+    }
+    const cols = new VcColumns(rows, t.K);
+    const back = new Array(rows);
+    const host = [];
+    let i = 0;
+    entries.forEach((e, ei) => {
+      const p = plan[ei];
+      if (!p) { host.push(ei); return; }
+      const cut = e.path.lastIndexOf("/");
+      const parent = cut < 0 ? "" : e.path.slice(0, cut);
+      const id = t.keys.idOf(e.path);
+      for (const [fname, v] of p.fields) {
+        cols.set(i, id, t.keys.fieldOf(parent, fname), p.comps, v);
+        back[i] = { entry: ei, field: fname };
+        i++;
+      }
+    });
+    const r = t.mergeBatch(cols);
+    const applied = Array.from(r.updated, (j) => back[j]);
+    let nConflicts = 0;
+    for (let j = 0; j < r.flags.length; j++) if (r.flags[j] & t.native.FLAG_CONCURRENT) nConflicts++;
+    if (opts.apply && r.updated.length) {
+      const n = r.updated.length;
+      const ids = new BigUint64Array(n), fields = new Uint32Array(n);
+      for (let k = 0; k < n; k++) { ids[k] = cols.id[r.updated[k]]; fields[k] = cols.field[r.updated[k]]; }
+      const got = t.getRows(ids, fields);
+      for (let k = 0; k < n; k++) {
+        const a = applied[k], e = entries[a.entry];
+        const leaf = a.field === null ? e.path : e.path + "/" + a.field;
+        const clock = this._clockObject(got.clocks, k * t.K, got.state[k]);
+        if (typeof this.bullet._applyUpdate === "function") this.bullet._applyUpdate(leaf, Number(got.val[k]), clock, true);
+        this.vectorClocks.set(leaf, clock);
+      }
+    }
+    return { applied, flags: r.flags, rows: back, nApplied: applied.length, nConflicts, nRows: r.nRows, host };
+  }
+
+  /** Stored (value, clock) of device rows in vector mode: [{path, field}] -> [{value, vectorClock} | null]. */
+  vcLookup(keys) {
+    const t = this.vcTable, n = keys.length;
+    const ids = new BigUint64Array(n), id32 = new Uint32Array(ids.buffer), fields = new Uint32Array(n);
+    keys.forEach((k, i) => {
+      const cut = k.path.lastIndexOf("/");
+      const id = t.keys.idOf(k.path);
+      id32[2 * i] = id[0]; id32[2 * i + 1] = id[1];
+      fields[i] = t.keys.fieldOf(cut < 0 ? "" : k.path.slice(0, cut), k.field === undefined ? null : k.field);
+    });
+    const got = t.getRows(ids, fields);
+    return keys.map((_, i) => (got.state[i] === t.native.VC_ABSENT ? null
+      : { value: Number(got.val[i]), vectorClock: this._clockObject(got.clocks, i * t.K, got.state[i]) }));
+  }
+
   /*
    * N3 (SURVEY §8(f)): checkpoint of the device rows in host terms — [{path, collection, field, ts, val}] — and its
    * inverse. The shape matches what the reference persists per path (value + vectorClock: src/bullet-file-storage.js:170-210).
@@ -325,6 +426,7 @@ class GpuCRT {
   close() {
     if (this._ownsGraph && this._graph) this._graph.close();
     this._graph = null;
+    if (this._vc) { this._vc.close(); this._vc = null; }
   }
 }
 

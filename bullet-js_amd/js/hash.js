@@ -113,4 +113,39 @@ function scalarClock(clock, writer) {
   return isDeviceInt(t) && t >= 0 ? t : -1;
 }
 
-module.exports = { pathId, fieldId, idKey, KeyDictionary, Columns, isDeviceInt, scalarClock, fnv1a32 };
+/* N4 column builder: like Columns, with K uint32 clock components per row instead of one timestamp */
+class VcColumns {
+  constructor(n, K) {
+    this.n = n; this.K = K;
+    this.id = new BigUint64Array(n);
+    this._id32 = new Uint32Array(this.id.buffer);
+    this.field = new Uint32Array(n);
+    this.clocks = new Uint32Array(n * K);
+    this.val = new BigInt64Array(n);
+  }
+  set(i, idPair, field, comps, val) {
+    this._id32[2 * i] = idPair[0]; this._id32[2 * i + 1] = idPair[1];
+    this.field[i] = field;
+    this.clocks.set(comps, i * this.K);
+    this.val[i] = BigInt(val);
+  }
+}
+
+/* a clock the N4 table understands: exactly the K writers as keys, in `writers` order (the reference compares clocks with
+ * JSON.stringify, so key set and order are part of a clock's identity: src/bullet-crt.js:200-203), uint32 counters.
+ * -> array of K components, or null */
+function denseClock(clock, writers) {
+  if (!clock || typeof clock !== "object") return null;
+  const ks = Object.keys(clock);
+  if (ks.length !== writers.length) return null;
+  const out = new Array(ks.length);
+  for (let k = 0; k < ks.length; k++) {
+    if (ks[k] !== writers[k]) return null;
+    const c = clock[ks[k]];
+    if (typeof c !== "number" || !Number.isInteger(c) || c < 0 || c > 0xffffffff) return null;
+    out[k] = c;
+  }
+  return out;
+}
+
+module.exports = { pathId, fieldId, idKey, KeyDictionary, Columns, VcColumns, isDeviceInt, scalarClock, denseClock, fnv1a32 };

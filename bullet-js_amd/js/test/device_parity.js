@@ -183,6 +183,86 @@ for (const name of fs.readdirSync(GOLD).filter((f) => f.startsWith("g2_stream_")
   checks += 5;
 }
 
+/* N4: K-writer vector clocks. (a) the reference's golden vectors through the addon's vc* entry points */
+for (const name of ["g6_vc_unique_2k.json", "g6_vc_dups_500.json", "g6_vc_empty_start.json"]) {
+  const g = load(name);
+  const { DeviceVcTable } = require("../device-graph");
+  const t = new DeviceVcTable(g.writers, "w", { capacityRows: 1024 });       // small on purpose: the table grows
+  const K = g.writers.length;
+  const cols = (rows) => {
+    const c = new hash.VcColumns(rows.length, K);
+    rows.forEach((r, i) => { const id = gen.splitmix64(BigInt(r[0]) + 1n); c.set(i, [Number(id & 0xffffffffn), Number(id >> 32n)], gen.rowField(0, 1), r[1], r[2]); });
+    return c;
+  };
+  if (g.resident.length) t.loadRows(cols(g.resident));
+  const r = t.mergeBatch(cols(g.deltas));
+  assert.deepStrictEqual(Buffer.from(r.flags).toString("base64"), g.flags_b64, name + " flags");
+  assert.deepStrictEqual(Array.from(r.updated), g.updated, name + " updated");
+  assert.strictEqual(r.nRows, g.final_rows.length, name + " rows");
+  const fin = cols(g.final_rows.map((x) => [x[0], x[1], x[2]]));
+  const got = t.getRows(fin.id, fin.field);
+  g.final_rows.forEach((x, i) => {
+    assert.deepStrictEqual(Array.from(got.clocks.subarray(i * K, i * K + K)), x[1], name + " clock of row " + x[0]);
+    assert.strictEqual(Number(got.val[i]), x[2]);
+    assert.strictEqual(got.state[i], x[3] === 1 ? t.native.VC_SPARSE : t.native.VC_DENSE);
+  });
+  t.close();
+  checks += 3 + g.final_rows.length;
+}
+
+/* N4 (b): GpuCRT({writers}).mergeEntries against the host resolver applied entry by entry (the host resolver is pinned on the
+ * reference by host_semantics.js); apply:true hands final values and clocks to the facade */
+{
+  const WR = ["a", "b", "w"];
+  const b = new MiniBullet("w");
+  const appliedLog = new Map();
+  b._applyUpdate = (p, value, clock) => { appliedLog.set(p, { value, clock }); };
+  const crt = new GpuCRT(b, { writers: WR, capacityRows: 256 });
+  const twin = new GpuCRT(new MiniBullet("w"));
+  const rng = gen.xorshift32(99);
+  const state = new Map();
+  const flagsOf = (d) => (d.incoming ? 1 : 0) | (d.current ? 2 : 0) | (d.historical ? 4 : 0) | (d.concurrent ? 8 : 0);
+  let rowsChecked = 0;
+  for (let round = 0; round < 3; round++) {
+    const entries = [], wantFlags = [], last = new Map();
+    let row = 0;
+    for (let j = 0; j < 1500; j++) {
+      const node = "vc/n" + (rng() % 300);
+      const clock = { a: rng() % 4, b: rng() % 4, w: rng() % 4 };
+      const single = rng() % 3 === 0;
+      const data = single ? { hits: (rng() % 5) - 2 } : { hits: (rng() % 5) - 2, level: rng() % 3 };
+      entries.push({ path: node, data, vectorClock: clock });
+      for (const f of Object.keys(data)) {
+        const key = node + "/" + f, cur = state.get(key);
+        const r = twin.processUpdate(key, data[f], clock, cur ? cur.value : undefined, cur ? cur.clock : undefined);
+        wantFlags.push(flagsOf(r.decision));
+        if (r.decision.incoming || !cur || r.decision.concurrent) { state.set(key, { value: r.value, clock: r.vectorClock }); last.set(key, row); }
+        row++;
+      }
+    }
+    entries.push({ path: "vc/skip", data: { hits: 1 }, vectorClock: { a: 1, w: 2 } });          // not all writers listed: host
+    entries.push({ path: "vc/skip2", data: { hits: "x" }, vectorClock: { a: 1, b: 1, w: 2 } }); // non-integer value: host
+    const r = crt.mergeEntries(entries, { apply: true });
+    assert.deepStrictEqual(r.host, [1500, 1501]);
+    assert.deepStrictEqual(Array.from(r.flags), wantFlags, "vector-mode flags, round " + round);
+    const wantApplied = Array.from(last.values()).sort((x, y) => x - y).map((j) => r.rows[j]);
+    assert.deepStrictEqual(r.applied, wantApplied);
+    for (const a of r.applied) {
+      const leaf = entries[a.entry].path + "/" + a.field;
+      assert.deepStrictEqual(appliedLog.get(leaf), { value: state.get(leaf).value, clock: state.get(leaf).clock }, leaf);
+      rowsChecked++;
+    }
+    checks += 3;
+  }
+  const keys = Array.from(state.keys());
+  const look = crt.vcLookup(keys.map((k) => { const c = k.lastIndexOf("/"); return { path: k.slice(0, c), field: k.slice(c + 1) }; }));
+  keys.forEach((k, i) => assert.deepStrictEqual(look[i], { value: state.get(k).value, vectorClock: state.get(k).clock }, k));
+  assert.strictEqual(crt.vcLookup([{ path: "vc/none", field: "hits" }])[0], null);
+  assert.throws(() => new GpuCRT(new MiniBullet("z"), { writers: WR }).vcTable, (e) => e.code === "BMX_BAD_WRITERS");
+  checks += keys.length + 2 + rowsChecked;
+  crt.close();
+}
+
 /* Promise variant: two batches in flight from the event loop's point of view, serialised inside the addon */
 (async () => {
   const g = load("g2_stream_hot30_10k_10k.json");

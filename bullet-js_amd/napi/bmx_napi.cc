@@ -374,11 +374,148 @@ napi_value Info(napi_env env, napi_callback_info info) {
   return out;
 }
 
+// ---- N4: vector-clock table (bmx_vc_*) -----------------------------------------------------------------------------
+struct VcHandle { bmx_vc* t; uint32_t K; std::mutex mu; };
+
+void finalize_vc(napi_env, void* data, void*) {
+  VcHandle* h = static_cast<VcHandle*>(data);
+  if (h->t) bmx_vc_destroy(h->t);
+  delete h;
+}
+
+bool get_vc(napi_env env, napi_value v, VcHandle** out) {
+  void* p = nullptr;
+  if (napi_get_value_external(env, v, &p) != napi_ok || !p || !static_cast<VcHandle*>(p)->t) {
+    napi_throw_error(env, nullptr, "bmx: invalid or closed vector-clock table handle");
+    return false;
+  }
+  *out = static_cast<VcHandle*>(p);
+  return true;
+}
+
+napi_value throw_vc(napi_env env, bmx_vc* t, int rc) {
+  std::string msg = "bmx error " + std::to_string(rc) + ": " + bmx_vc_last_error(t);
+  napi_value code, err, m;
+  napi_create_string_utf8(env, msg.c_str(), NAPI_AUTO_LENGTH, &m);
+  napi_create_error(env, nullptr, m, &err);
+  napi_create_int32(env, rc, &code);
+  napi_set_named_property(env, err, "code", code);
+  napi_throw(env, err);
+  return nullptr;
+}
+
+// vcCreate(device, capacityRows, kWriters, localWriter) -> handle
+napi_value VcCreate(napi_env env, napi_callback_info info) {
+  ARGS(4);
+  int32_t device; double cap; uint32_t K, local;
+  NAPI_OK(napi_get_value_int32(env, argv[0], &device));
+  NAPI_OK(napi_get_value_double(env, argv[1], &cap));
+  NAPI_OK(napi_get_value_uint32(env, argv[2], &K));
+  NAPI_OK(napi_get_value_uint32(env, argv[3], &local));
+  bmx_vc* t = nullptr;
+  int rc = bmx_vc_create(device, (uint64_t)cap, K, local, &t);
+  if (rc) return throw_vc(env, nullptr, rc);
+  VcHandle* h = new VcHandle();
+  h->t = t; h->K = K;
+  napi_value ext;
+  NAPI_OK(napi_create_external(env, h, finalize_vc, nullptr, &ext));
+  return ext;
+}
+
+napi_value VcDestroy(napi_env env, napi_callback_info info) {
+  ARGS(1);
+  void* p = nullptr;
+  if (napi_get_value_external(env, argv[0], &p) == napi_ok && p) {
+    VcHandle* h = static_cast<VcHandle*>(p);
+    std::lock_guard<std::mutex> g(h->mu);
+    if (h->t) { bmx_vc_destroy(h->t); h->t = nullptr; }
+  }
+  return nullptr;
+}
+
+// (id BigUint64Array, field Uint32Array, clocks Uint32Array[n*K], val BigInt64Array)
+bool get_vc_cols(napi_env env, napi_value* a, uint32_t K, const uint64_t** id, const uint32_t** field, const uint32_t** clocks, const int64_t** val, size_t* n) {
+  void *p0, *p1, *p2, *p3; size_t n0, n1, n2, n3;
+  if (!get_ta(env, a[0], napi_biguint64_array, &p0, &n0) || !get_ta(env, a[1], napi_uint32_array, &p1, &n1) ||
+      !get_ta(env, a[2], napi_uint32_array, &p2, &n2) || !get_ta(env, a[3], napi_bigint64_array, &p3, &n3)) return false;
+  if (n0 != n1 || n0 != n3 || n2 != n0 * K) { napi_throw_range_error(env, nullptr, "bmx: column lengths differ (clocks must hold n*K counters)"); return false; }
+  *id = (const uint64_t*)p0; *field = (const uint32_t*)p1; *clocks = (const uint32_t*)p2; *val = (const int64_t*)p3; *n = n0;
+  return true;
+}
+
+napi_value VcLoadRows(napi_env env, napi_callback_info info) {
+  ARGS(5);
+  VcHandle* h; if (!get_vc(env, argv[0], &h)) return nullptr;
+  const uint64_t* id; const uint32_t *field, *clocks; const int64_t* val; size_t n;
+  if (!get_vc_cols(env, argv + 1, h->K, &id, &field, &clocks, &val, &n)) return nullptr;
+  std::lock_guard<std::mutex> g(h->mu);
+  int rc = bmx_vc_load_rows(h->t, n, id, field, clocks, val);
+  if (rc) return throw_vc(env, h->t, rc);
+  return nullptr;
+}
+
+// vcMergeBatch(h, id, field, clocks, val) -> {updated: Uint32Array, flags: Uint8Array, nRows}
+napi_value VcMergeBatch(napi_env env, napi_callback_info info) {
+  ARGS(5);
+  VcHandle* h; if (!get_vc(env, argv[0], &h)) return nullptr;
+  const uint64_t* id; const uint32_t *field, *clocks; const int64_t* val; size_t n;
+  if (!get_vc_cols(env, argv + 1, h->K, &id, &field, &clocks, &val, &n)) return nullptr;
+  std::vector<uint32_t> upd(n ? n : 1);
+  void* fl = nullptr;
+  napi_value flags = make_ta(env, napi_uint8_array, 1, n, &fl);
+  uint64_t nu = 0, rows = 0;
+  std::lock_guard<std::mutex> g(h->mu);
+  int rc = bmx_vc_merge_batch(h->t, n, id, field, clocks, val, upd.data(), &nu, (uint8_t*)fl);
+  if (rc) return throw_vc(env, h->t, rc);
+  bmx_vc_row_count(h->t, &rows);
+  void* up = nullptr;
+  napi_value updated = make_ta(env, napi_uint32_array, 4, nu, &up);
+  if (nu) memcpy(up, upd.data(), nu * 4);
+  napi_value out; NAPI_OK(napi_create_object(env, &out));
+  napi_set_named_property(env, out, "updated", updated);
+  napi_set_named_property(env, out, "flags", flags);
+  set_num(env, out, "nRows", (double)rows);
+  return out;
+}
+
+// vcGetRows(h, id, field) -> {clocks: Uint32Array[n*K], val: BigInt64Array, state: Uint8Array}
+napi_value VcGetRows(napi_env env, napi_callback_info info) {
+  ARGS(3);
+  VcHandle* h; if (!get_vc(env, argv[0], &h)) return nullptr;
+  void *p0, *p1; size_t n0, n1;
+  if (!get_ta(env, argv[1], napi_biguint64_array, &p0, &n0) || !get_ta(env, argv[2], napi_uint32_array, &p1, &n1)) return nullptr;
+  if (n0 != n1) { napi_throw_range_error(env, nullptr, "bmx: column lengths differ"); return nullptr; }
+  void *c, *v, *st;
+  napi_value clocks = make_ta(env, napi_uint32_array, 4, n0 * h->K, &c);
+  napi_value val = make_ta(env, napi_bigint64_array, 8, n0, &v);
+  napi_value state = make_ta(env, napi_uint8_array, 1, n0, &st);
+  std::lock_guard<std::mutex> g(h->mu);
+  int rc = bmx_vc_get_rows(h->t, n0, (const uint64_t*)p0, (const uint32_t*)p1, (uint32_t*)c, (int64_t*)v, (uint8_t*)st);
+  if (rc) return throw_vc(env, h->t, rc);
+  napi_value out; NAPI_OK(napi_create_object(env, &out));
+  napi_set_named_property(env, out, "clocks", clocks);
+  napi_set_named_property(env, out, "val", val);
+  napi_set_named_property(env, out, "state", state);
+  return out;
+}
+
+napi_value VcRowCount(napi_env env, napi_callback_info info) {
+  ARGS(1);
+  VcHandle* h; if (!get_vc(env, argv[0], &h)) return nullptr;
+  uint64_t n = 0;
+  std::lock_guard<std::mutex> g(h->mu);
+  int rc = bmx_vc_row_count(h->t, &n);
+  if (rc) return throw_vc(env, h->t, rc);
+  napi_value v; napi_create_double(env, (double)n, &v);
+  return v;
+}
+
 napi_value Init(napi_env env, napi_value exports) {
   struct { const char* name; napi_callback fn; } fns[] = {
       {"abiVersion", AbiVersion}, {"create", Create}, {"destroy", Destroy}, {"mergeBatch", MergeBatch}, {"mergeBatchAsync", MergeBatchAsync}, {"reserve", Reserve}, {"loadRows", LoadRows},
       {"getRows", GetRows}, {"rowCount", RowCount}, {"dumpRows", DumpRows}, {"indexBuild", IndexBuild}, {"indexDrop", IndexDrop},
-      {"indexSize", IndexSize}, {"scanRange", ScanRange}, {"scanCount", ScanCount}, {"scanFilter", ScanFilter}, {"info", Info}};
+      {"indexSize", IndexSize}, {"scanRange", ScanRange}, {"scanCount", ScanCount}, {"scanFilter", ScanFilter}, {"info", Info},
+      {"vcCreate", VcCreate}, {"vcDestroy", VcDestroy}, {"vcLoadRows", VcLoadRows}, {"vcMergeBatch", VcMergeBatch}, {"vcGetRows", VcGetRows}, {"vcRowCount", VcRowCount}};
   for (auto& f : fns) {
     napi_value v;
     if (napi_create_function(env, f.name, NAPI_AUTO_LENGTH, f.fn, nullptr, &v) != napi_ok) return nullptr;
@@ -386,7 +523,8 @@ napi_value Init(napi_env env, napi_value exports) {
   }
   struct { const char* name; int v; } consts[] = {{"INSERT_REFERENCE", BMX_INSERT_REFERENCE}, {"INSERT_DELTA", BMX_INSERT_DELTA},
                                                   {"MERGE_UNIQUE_KEYS", BMX_MERGE_UNIQUE_KEYS}, {"MERGE_STRICT_FLAGS", BMX_MERGE_STRICT_FLAGS}, {"FLAG_INCOMING", BMX_FLAG_INCOMING},
-                                                  {"FLAG_CURRENT", BMX_FLAG_CURRENT}, {"FLAG_HISTORICAL", BMX_FLAG_HISTORICAL}};
+                                                  {"FLAG_CURRENT", BMX_FLAG_CURRENT}, {"FLAG_HISTORICAL", BMX_FLAG_HISTORICAL}, {"FLAG_CONCURRENT", BMX_FLAG_CONCURRENT},
+                                                  {"VC_MAX_WRITERS", BMX_VC_MAX_WRITERS}, {"VC_ABSENT", BMX_VC_ABSENT}, {"VC_DENSE", BMX_VC_DENSE}, {"VC_SPARSE", BMX_VC_SPARSE}};
   for (auto& c : consts) { napi_value v; napi_create_int32(env, c.v, &v); napi_set_named_property(env, exports, c.name, v); }
   return exports;
 }

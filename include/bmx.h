@@ -210,7 +210,8 @@ int bmx_partition_by_owner_slabs(bmx_ctx* ctx, uint64_t n, const uint64_t* id, c
  * {local: 2} (:172-185). Contract: incoming clocks are dense (the host lists all K writers, same order, every time).
  * Deltas of one key are applied in index order (the result is order dependent for concurrent clocks), so batches are
  * exact for any duplication. flags[j] additionally carries BMX_FLAG_CONCURRENT. updated_idx = ascending indices of the
- * last delta per key that caused a store (doUpdate: src/bullet-crt.js:383). Host buffers only (synchronous). */
+ * last delta per key that caused a store (doUpdate: src/bullet-crt.js:383). Host buffers only (synchronous). capacity_rows
+ * is the initial size: the table grows by a device-side rehash whenever a batch could push the load factor above 0.5. */
 #define BMX_FLAG_CONCURRENT 8u
 #define BMX_VC_MAX_WRITERS 8
 #define BMX_VC_ABSENT 0

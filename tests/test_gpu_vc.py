@@ -133,8 +133,20 @@ def test_vc_errors():
     with pytest.raises(bmx.BmxError) as ei:
         e.merge_batch([keyid(1)], [F0], [[1, 1]], [1 << 60])
     assert ei.value.code == bmx.ERR_RANGE
-    with pytest.raises(bmx.BmxError) as ei:
-        n = 5000
-        e.merge_batch([keyid(i) for i in range(n)], [F0] * n, np.ones((n, 2), np.uint32), [0] * n)
-    assert ei.value.code == bmx.ERR_FULL
+    e.close()
+
+
+def test_vc_table_grows():
+    K, local = 3, 1
+    rng = np.random.default_rng(21)
+    e = bmx.EngineVC(1000, K, local); o = OracleVC(K, local)      # 4096 slots to start with
+    seen = set()
+    for b in range(5):
+        ids, fields, clocks, val = _rand_batch(rng, 20000, 60000, K, 4, 3)
+        f1, u1 = e.merge_batch(ids, fields, clocks, val); f2, u2 = o.merge_batch(ids, fields, clocks, val)
+        assert np.array_equal(f1, f2) and np.array_equal(u1, u2), b
+        assert e.row_count() == len(o)
+        seen.update(zip(ids.tolist(), fields.tolist()))
+    keys = sorted(seen)[::7]
+    _compare_rows(e, o, np.array([k[0] for k in keys], np.uint64), np.array([k[1] for k in keys], np.uint32))
     e.close()
