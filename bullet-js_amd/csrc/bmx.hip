@@ -76,6 +76,8 @@ struct bmx_ctx {
   bool k3_pending[2] = {false, false};
   uint64_t nbatch = 0;
   uint32_t* part_counts = nullptr;    // PART_MAX_SHARDS * PART_BLOCKS
+  uint8_t* part_owner = nullptr;      // owner shard of every delta of the batch being partitioned
+  uint64_t part_owner_cap = 0;
   uint32_t epoch = 0;
   uint64_t version = 0;
   uint64_t rows_ub = 0;               // host-side upper bound of resident rows
@@ -549,7 +551,7 @@ void bmx_destroy(bmx_ctx* ctx) {
   for (auto& ix : ctx->indexes) { dev_free(ix.ids); dev_free(ix.v64); dev_free(ix.v32); }
   dev_free(ctx->slots); dev_free(ctx->ds); dev_free(ctx->next); dev_free(ctx->wflag); dev_free(ctx->slot_of); dev_free(ctx->blk_info); dev_free(ctx->shard_ctr);
   dev_free(ctx->st_id); dev_free(ctx->st_field); dev_free(ctx->st_ts); dev_free(ctx->st_val); dev_free(ctx->st_applied); dev_free(ctx->st_flags);
-  dev_free(ctx->scan_out); dev_free(ctx->block_counts); dev_free(ctx->part_counts); dev_free(ctx->scan_mask); dev_free(ctx->scan_counts);
+  dev_free(ctx->scan_out); dev_free(ctx->block_counts); dev_free(ctx->part_counts); dev_free(ctx->part_owner); dev_free(ctx->scan_mask); dev_free(ctx->scan_counts);
   for (auto ev : ctx->prof_ev) (void)hipEventDestroy(ev);
   if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
   if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);
@@ -781,10 +783,17 @@ static int partition_impl(bmx_ctx* ctx, uint64_t n, const uint64_t* id, const ui
   if (n && (!id || !field || !ts || !val || !recs_out)) return fail(ctx, BMX_ERR_INVALID, "null pointer");
   HIPCHK(hipSetDevice(ctx->device));
   uint32_t per_block = (uint32_t)((n + PART_BLOCKS - 1) / PART_BLOCKS);
-  per_block = std::max<uint32_t>(256, (per_block + 255) & ~255u);
-  hipLaunchKernelGGL(k_part_count, dim3(PART_BLOCKS), dim3(256), 0, ctx->stream, id, (uint32_t)n, nshards, per_block, ctx->part_counts);
+  per_block = std::max<uint32_t>(PART_TILE, (per_block + PART_TILE - 1) / PART_TILE * PART_TILE);
+  if (n > ctx->part_owner_cap) {
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    dev_free(ctx->part_owner); ctx->part_owner_cap = 0;
+    int rc = dev_alloc(ctx, &ctx->part_owner, n + 256);
+    if (rc) return rc;
+    ctx->part_owner_cap = n;
+  }
+  hipLaunchKernelGGL(k_part_count, dim3(PART_BLOCKS), dim3(256), 0, ctx->stream, id, (uint32_t)n, nshards, per_block, ctx->part_counts, ctx->part_owner);
   LAUNCHCHK("k_part_count");
-  hipLaunchKernelGGL(k_part_scatter, dim3(PART_BLOCKS), dim3(256), 0, ctx->stream, id, field, ts, val, (uint32_t)n, nshards, per_block, ctx->part_counts,
+  hipLaunchKernelGGL(k_part_scatter, dim3(PART_BLOCKS), dim3(256), 0, ctx->stream, id, field, ts, val, (const uint8_t*)ctx->part_owner, (uint32_t)n, nshards, per_block, ctx->part_counts,
                      recs_out, reinterpret_cast<unsigned long long*>(counts_out_dev), (uint32_t)slab);
   LAUNCHCHK("k_part_scatter");
   return BMX_OK;

@@ -543,11 +543,12 @@ __global__ __launch_bounds__(256) void k_get_rows(const Slot* slots, uint64_t ns
 // Counting and ranking are wave-ballot based (one __ballot per shard per 64 deltas): no LDS or global atomics.
 constexpr int PART_MAX_SHARDS = 16;
 constexpr int PART_BLOCKS = 1024;
+constexpr uint32_t PART_TILE = 1024;   // deltas staged in LDS per step of k_part_scatter; per_block is a multiple of it
 
 __device__ __forceinline__ uint32_t owner_of_dev(uint64_t id, uint32_t nshards) { return (uint32_t)__umul64hi(owner_hash(id), (uint64_t)nshards); }
 
 __global__ __launch_bounds__(256) void k_part_count(const uint64_t* id, uint32_t n, uint32_t nshards, uint32_t per_block,
-                                                    uint32_t* counts /*[nshards][PART_BLOCKS]*/) {
+                                                    uint32_t* counts /*[nshards][PART_BLOCKS]*/, uint8_t* owner_out /*[n]*/) {
   __shared__ uint32_t wtot[4][PART_MAX_SHARDS];
   const uint32_t lane = threadIdx.x & 63, w = threadIdx.x >> 6;
   uint32_t lo = blockIdx.x * per_block, hi = min(n, lo + per_block);
@@ -555,6 +556,7 @@ __global__ __launch_bounds__(256) void k_part_count(const uint64_t* id, uint32_t
   for (uint32_t t0 = lo; t0 < hi; t0 += 256) {
     uint32_t j = t0 + threadIdx.x;
     uint32_t g = j < hi ? owner_of_dev(id[j], nshards) : 0xFFFFFFFFu;
+    if (j < hi) owner_out[j] = (uint8_t)g;          // the scatter pass reads this byte instead of hashing again
     for (uint32_t gg = 0; gg < nshards; gg++) {
       uint32_t c = (uint32_t)__popcll(__ballot(g == gg));
       if (lane == gg) mine += c;
@@ -565,67 +567,126 @@ __global__ __launch_bounds__(256) void k_part_count(const uint64_t* id, uint32_t
   if (threadIdx.x < nshards) counts[threadIdx.x * PART_BLOCKS + blockIdx.x] = wtot[0][threadIdx.x] + wtot[1][threadIdx.x] + wtot[2][threadIdx.x] + wtot[3][threadIdx.x];
 }
 
+// wave64 inclusive prefix sum in 7 DPP adds (row_shr 1,2,3,4,8 inside each row of 16 lanes, then row_bcast:15 into rows 1 and 3 and
+// row_bcast:31 into rows 2 and 3); disabled / out-of-row source lanes contribute 0 (old = 0, bound_ctrl)
+__device__ __forceinline__ uint32_t wave_incl_scan_u32(uint32_t v) {
+  uint32_t x = v;
+  x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xf, 0xf, true);
+  x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x112, 0xf, 0xf, true);
+  x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x113, 0xf, 0xf, true);
+  x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x114, 0xf, 0xe, true);
+  x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x118, 0xf, 0xc, true);
+  x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x142, 0xa, 0xf, true);
+  x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x143, 0xc, 0xf, true);
+  return x;
+}
+
+// The scatter pass is VALU-issue bound, not bandwidth bound (every block is resident at once, 4 waves per SIMD; PMC: 1900 VALU
+// instructions per wave in the first version), so it is written to execute few instructions: owners come as bytes from the count
+// pass, ranks from packed 8-bit one-hot counters scanned with DPP (4 shards per 32-bit word), all prefix tables stay in LDS and
+// are read with computed addresses, and the copy-out walks one shard's run at a time.
 __global__ __launch_bounds__(256) void k_part_scatter(const uint64_t* id, const uint32_t* field, const int64_t* ts, const int64_t* val,
-                                                      uint32_t n, uint32_t nshards, uint32_t per_block, const uint32_t* counts,
+                                                      const uint8_t* owner, uint32_t n, uint32_t nshards, uint32_t per_block, const uint32_t* counts,
                                                       bmx_delta_rec* out, unsigned long long* totals, uint32_t slab) {
-  __shared__ uint32_t base[PART_MAX_SHARDS];   // running output cursor of this block per shard
-  __shared__ uint32_t tot[PART_MAX_SHARDS];    // shard totals over the whole batch
-  __shared__ uint32_t wcnt[4][PART_MAX_SHARDS];
-  __shared__ uint32_t red[PART_MAX_SHARDS][4][2];
+  __shared__ uint32_t base[PART_MAX_SHARDS];       // running output cursor of this block per shard
+  __shared__ uint32_t tot[PART_MAX_SHARDS];        // shard totals over the whole batch
+  __shared__ uint32_t red[PART_MAX_SHARDS][2];
+  __shared__ uint4 stage[PART_TILE * 2];           // 32 KB: one tile of records grouped by shard
+  __shared__ __attribute__((aligned(16))) uint32_t F[PART_MAX_SHARDS * 16 + 4];   // F[g*16+c]: count of shard g in sub-chunk c, then the
+                                                                                   // exclusive prefix of the flattened table; F[256] = records in the tile
   const uint32_t lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-  // per shard g: before = sum of counts[g][b] for b < this block, total = sum over all blocks (coalesced reads, wave reduce)
-  for (uint32_t g = 0; g < nshards; g++) {
-    uint32_t before = 0, all = 0;
-    for (uint32_t b = threadIdx.x; b < PART_BLOCKS; b += 256) {
-      uint32_t c = counts[g * PART_BLOCKS + b];
-      all += c;
-      if (b < blockIdx.x) before += c;
-    }
+  const uint32_t lo = blockIdx.x * per_block, hi = min(n, lo + per_block);
+  uint64_t kid[4], rt[4], rv[4]; uint32_t rf[4], g[4];
+  auto load_tile = [&](uint32_t t0) {
 #pragma unroll
-    for (int d = 32; d >= 1; d >>= 1) { before += __shfl_xor(before, d); all += __shfl_xor(all, d); }
-    if (lane == 0) { red[g][w][0] = before; red[g][w][1] = all; }
-  }
-  __syncthreads();
-  if (threadIdx.x < nshards) {
-    uint32_t g = threadIdx.x;
-    uint32_t all = red[g][0][1] + red[g][1][1] + red[g][2][1] + red[g][3][1];
-    tot[g] = all;
-    if (blockIdx.x == 0) totals[g] = all;
-  }
-  __syncthreads();
-  if (threadIdx.x < nshards) {
-    uint32_t g = threadIdx.x, start = 0;
-    if (slab) start = g * slab;                              // fixed-size slabs: shard g starts at g*slab
-    else for (uint32_t gg = 0; gg < g; gg++) start += tot[gg];
-    base[g] = start + red[g][0][0] + red[g][1][0] + red[g][2][0] + red[g][3][0];
-  }
-  __syncthreads();
-  uint32_t lo = blockIdx.x * per_block, hi = min(n, lo + per_block);
-  for (uint32_t t0 = lo; t0 < hi; t0 += 256) {
-    uint32_t j = t0 + threadIdx.x;
-    bool act = j < hi;
-    uint64_t kid = 0; uint32_t g = 0xFFFFFFFFu;
-    if (act) { kid = id[j]; g = owner_of_dev(kid, nshards); }
-    uint32_t rank_in_wave = 0;
-    for (uint32_t gg = 0; gg < nshards; gg++) {
-      unsigned long long m = __ballot(g == gg);
-      if (g == gg) rank_in_wave = (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
-      if (lane == 0) wcnt[w][gg] = (uint32_t)__popcll(m);
+    for (int i = 0; i < 4; i++) {
+      const uint32_t j = t0 + (uint32_t)i * 256u + threadIdx.x;
+      const bool act = j < hi;
+      kid[i] = act ? id[j] : EMPTY_ID; rf[i] = act ? field[j] : 0u; rt[i] = act ? (uint64_t)ts[j] : 0ull; rv[i] = act ? (uint64_t)val[j] : 0ull;
+      g[i] = act ? (uint32_t)owner[j] : 0xFFu;
     }
-    __syncthreads();
-    if (act) {
-      uint32_t pos = base[g] + rank_in_wave;
-      for (uint32_t ww = 0; ww < w; ww++) pos += wcnt[ww][g];
-      if (!slab || pos - g * slab < slab) {  // a slab overflow drops the record; totals[] tells the caller
-        uint4* q = reinterpret_cast<uint4*>(out + pos);
-        uint64_t t = (uint64_t)ts[j], v = (uint64_t)val[j];
-        q[0] = make_uint4((uint32_t)kid, (uint32_t)(kid >> 32), field[j], j);
-        q[1] = make_uint4((uint32_t)t, (uint32_t)(t >> 32), (uint32_t)v, (uint32_t)(v >> 32));
+  };
+  if (lo < hi) load_tile(lo);                      // in flight under the prologue
+  // prologue: per shard, before = sum of counts[g][b] over the blocks before this one, all = sum over every block.
+  // Wave w reduces shards w, w+4, ...; a lane reads 4 consecutive blocks per 16-byte load.
+  for (uint32_t gs = w; gs < nshards; gs += 4) {
+    const uint4* cg = reinterpret_cast<const uint4*>(counts + gs * PART_BLOCKS);
+    uint32_t before = 0, all = 0;
+#pragma unroll
+    for (uint32_t k = 0; k < PART_BLOCKS / 256; k++) {
+      const uint32_t b4 = k * 64 + lane;
+      const uint4 c = cg[b4];
+      const uint32_t b0 = b4 * 4;
+      all += c.x + c.y + c.z + c.w;
+      before += (b0 < blockIdx.x ? c.x : 0u) + (b0 + 1 < blockIdx.x ? c.y : 0u) + (b0 + 2 < blockIdx.x ? c.z : 0u) + (b0 + 3 < blockIdx.x ? c.w : 0u);
+    }
+    before = wave_incl_scan_u32(before); all = wave_incl_scan_u32(all);
+    if (lane == 63) { red[gs][0] = before; red[gs][1] = all; }
+  }
+  __syncthreads();
+  if (threadIdx.x < nshards) {
+    tot[threadIdx.x] = red[threadIdx.x][1];
+    if (blockIdx.x == 0) totals[threadIdx.x] = red[threadIdx.x][1];
+  }
+  __syncthreads();
+  if (threadIdx.x < nshards) {
+    uint32_t gg = threadIdx.x, start = 0;
+    if (slab) start = gg * slab;                             // fixed-size slabs: shard g starts at g*slab
+    else for (uint32_t x = 0; x < gg; x++) start += tot[x];
+    base[gg] = start + red[gg][0];
+  }
+  // (the barriers inside the loop order base[] before its first use)
+  const uint32_t nwords = (nshards + 3) >> 2;
+  for (uint32_t t0 = lo; t0 < hi; t0 += PART_TILE) {
+    if (t0 != lo) load_tile(t0);
+    // rank of every delta among the deltas of its shard inside its 64-delta sub-chunk (index order: sub-chunk c = i*4 + w)
+    uint32_t rk[4];
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+      rk[i] = 0;
+      const uint32_t c = (uint32_t)i * 4u + w;
+      for (uint32_t k = 0; k < nwords; k++) {
+        const uint32_t sh = (g[i] & 3u) * 8u;
+        const bool mine = (g[i] >> 2) == k;
+        const uint32_t incl = wave_incl_scan_u32(mine ? (1u << sh) : 0u);
+        if (mine) rk[i] = ((incl >> sh) & 0xFFu) - 1u;
+        const uint32_t totw = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);     // at most 64 per field: no carry between fields
+        if (lane < 4 && 4 * k + lane < nshards) F[(4 * k + lane) * 16 + c] = (totw >> (8u * lane)) & 0xFFu;
       }
     }
     __syncthreads();
-    if (threadIdx.x < nshards) { uint32_t g2 = threadIdx.x; base[g2] += wcnt[0][g2] + wcnt[1][g2] + wcnt[2][g2] + wcnt[3][g2]; }
+    if (w == 0) {   // exclusive prefix of the flattened table (shard-major, sub-chunk-minor) = tile-local position of every run
+      const bool live = lane * 4 < nshards * 16;
+      uint4 x = live ? reinterpret_cast<const uint4*>(F)[lane] : make_uint4(0u, 0u, 0u, 0u);
+      const uint32_t sum = x.x + x.y + x.z + x.w;
+      const uint32_t incl = wave_incl_scan_u32(sum);
+      const uint32_t e = incl - sum;
+      reinterpret_cast<uint4*>(F)[lane] = make_uint4(e, e + x.x, e + x.x + x.y, e + x.x + x.y + x.z);
+      if (lane == 63) F[PART_MAX_SHARDS * 16] = incl;
+    }
     __syncthreads();
+    uint32_t grow = 0;                             // this tile's contribution to the block's cursor of shard threadIdx.x
+    if (threadIdx.x < nshards) grow = F[(threadIdx.x + 1) * 16] - F[threadIdx.x * 16];
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+      if (g[i] != 0xFFu) {
+        const uint32_t p = F[g[i] * 16 + (uint32_t)i * 4u + w] + rk[i];
+        stage[2 * p] = make_uint4((uint32_t)kid[i], (uint32_t)(kid[i] >> 32), rf[i], t0 + (uint32_t)i * 256u + threadIdx.x);
+        stage[2 * p + 1] = make_uint4((uint32_t)rt[i], (uint32_t)(rt[i] >> 32), (uint32_t)rv[i], (uint32_t)(rv[i] >> 32));
+      }
+    }
+    __syncthreads();
+    uint4* out16 = reinterpret_cast<uint4*>(out);
+    for (uint32_t gg = 0; gg < nshards; gg++) {    // one shard's run at a time: consecutive lanes on consecutive 16-byte halves
+      const uint32_t s0 = F[gg * 16], e0 = F[(gg + 1) * 16], b = base[gg];
+      for (uint32_t q = 2 * s0 + threadIdx.x; q < 2 * e0; q += 256) {
+        const uint32_t pos = b + ((q >> 1) - s0);
+        if (!slab || pos - gg * slab < slab)        // a slab overflow drops the record; totals[] tells the caller
+          out16[2 * (size_t)pos + (q & 1)] = stage[q];
+      }
+    }
+    __syncthreads();
+    if (threadIdx.x < nshards) base[threadIdx.x] += grow;
   }
   // fixed-size slabs: the unused tail of every slab becomes padding (reserved id), striped over all blocks
   if (slab) {
