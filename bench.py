@@ -33,7 +33,7 @@ import numpy as np
 import torch
 
 R_PER_GPU = 10_000_000
-D_PER_STEP = 1_000_000
+D_PER_STEP = int(os.environ.get("BMX_BENCH_DELTAS", 1_000_000))   # BASELINE config 2/4: 1M; the override is for host-bound experiments only
 T0, DT = 1_000_000, 1_000_000
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec
 
@@ -230,7 +230,7 @@ def main():
         sg.load_owned_resident(R_PER_GPU, T0=T0, DT=DT)
         R_global = R_PER_GPU * world
         batches = [to_dev(gen_batch(b, R_global, seed=2 + 1000 * rank), dev) for b in range(nb)]
-        sg.setup_pipeline(D_PER_STEP)
+        sg.setup_pipeline(D_PER_STEP, partition_on=os.environ.get("BMX_BENCH_PARTITION", "merge"))
         torch.cuda.synchronize()
 
         def run(lo, hi):
@@ -246,7 +246,25 @@ def main():
             run(0, W)
         sg.ops.sync(); torch.cuda.synchronize(); dist.barrier()
         t0 = time.perf_counter()
-        run(W, nb)
+        if os.environ.get("BMX_BENCH_HOSTPROF"):      # where the host's enqueue time goes (stderr): wall time inside each call
+            acc = {}
+
+            def timed(obj, name):
+                fn = getattr(obj, name)
+
+                def w(*a, **k):
+                    t = time.perf_counter()
+                    r = fn(*a, **k)
+                    acc[name] = acc.get(name, 0.0) + time.perf_counter() - t
+                    return r
+                setattr(obj, name, w)
+            for nm in ("partition_slabs", "partition_slabs_on_comm", "merge_records", "signal", "wait_seq"):
+                timed(sg.ops, nm)
+            timed(dist, "all_to_all_single")
+            run(W, nb)
+            print("host us/step: " + ", ".join("%s %.1f" % (k, v / K * 1e6) for k, v in sorted(acc.items())), file=sys.stderr)
+        else:
+            run(W, nb)
         t_enq = time.perf_counter() - t0
         sg.ops.sync(); torch.cuda.synchronize(); dist.barrier()
         wall = time.perf_counter() - t0

@@ -24,7 +24,7 @@ FLAG_INCOMING, FLAG_CURRENT, FLAG_HISTORICAL = 1, 2, 4
 MAX_BATCH = 1 << 24
 
 EXPORTS = [
-    "bmx_create", "bmx_destroy", "bmx_last_error", "bmx_abi_version", "bmx_get_info", "bmx_sync", "bmx_set_stream", "bmx_get_stream",
+    "bmx_create", "bmx_destroy", "bmx_last_error", "bmx_abi_version", "bmx_get_info", "bmx_sync", "bmx_set_stream", "bmx_get_stream", "bmx_seq_signal", "bmx_seq_wait",
     "bmx_load_rows", "bmx_merge_batch", "bmx_merge_records", "bmx_get_rows", "bmx_get_row", "bmx_dump_rows", "bmx_row_count", "bmx_reserve",
     "bmx_index_build", "bmx_index_drop", "bmx_index_size", "bmx_scan_range", "bmx_scan_equals", "bmx_scan_count", "bmx_scan_filter",
     "bmx_owner_of", "bmx_partition_by_owner", "bmx_partition_by_owner_slabs", "bmx_timer_start", "bmx_timer_stop", "bmx_profile_enable", "bmx_profile_read",
@@ -73,6 +73,8 @@ def load_library():
     L.bmx_sync.argtypes = [vp]; L.bmx_sync.restype = i32
     L.bmx_set_stream.argtypes = [vp, vp]; L.bmx_set_stream.restype = i32
     L.bmx_get_stream.argtypes = [vp]; L.bmx_get_stream.restype = vp
+    L.bmx_seq_signal.argtypes = [vp, vp, vp, u64]; L.bmx_seq_signal.restype = i32
+    L.bmx_seq_wait.argtypes = [vp, vp, vp, u64]; L.bmx_seq_wait.restype = i32
     L.bmx_load_rows.argtypes = [vp, u64, vp, vp, vp, vp, i32]; L.bmx_load_rows.restype = i32
     L.bmx_merge_batch.argtypes = [vp, u64, vp, vp, vp, vp, i32, i32, vp, vp, vp, vp]; L.bmx_merge_batch.restype = i32
     L.bmx_merge_records.argtypes = [vp, u64, vp, i32, vp, vp, vp, vp]; L.bmx_merge_records.restype = i32
@@ -246,6 +248,14 @@ class Engine:
 
     def set_stream(self, stream_ptr):
         self._chk(self.L.bmx_set_stream(self.h, C.c_void_p(stream_ptr) if stream_ptr else None))
+
+    def seq_signal(self, stream_ptr, seq_dev, value):
+        """enqueue on the stream (0 = the engine's): *seq_dev = value once everything before it on that stream is done."""
+        self._chk(self.L.bmx_seq_signal(self.h, C.c_void_p(stream_ptr) if stream_ptr else None, _ptr(seq_dev), int(value)))
+
+    def seq_wait(self, stream_ptr, seq_dev, at_least):
+        """enqueue on the stream a device-side wait until *seq_dev >= at_least (the matching signal must already be enqueued)."""
+        self._chk(self.L.bmx_seq_wait(self.h, C.c_void_p(stream_ptr) if stream_ptr else None, _ptr(seq_dev), int(at_least)))
 
     def load_rows_dev(self, n, id, field, ts, val):
         self._chk(self.L.bmx_load_rows(self.h, int(n), _ptr(id), _ptr(field), _ptr(ts), _ptr(val), MEM_DEVICE))

@@ -102,14 +102,20 @@ class EngineOps:
         self.enter_pipeline()
         return contextlib.nullcontext()
 
-    def new_event(self):
-        return torch.cuda.Event()
+    # cross-stream ordering: 64-bit sequence words in device memory + one-wave kernels (bmx_seq_signal / bmx_seq_wait). Events are
+    # not used on the data path: a record, or a wait on a not-yet-complete event, holds the stream it is enqueued on for ~10 us.
+    def new_seq(self):
+        return torch.zeros(1, dtype=torch.int64, device=self.device)
 
-    def record(self, ev, on_comm):
-        ev.record(self.comm if on_comm else self.main)
+    def signal(self, seq, value, on_comm):
+        self.e.seq_signal((self.comm if on_comm else self.main).cuda_stream, seq, value)
 
-    def wait(self, ev, on_comm):
-        (self.comm if on_comm else self.main).wait_event(ev)
+    def wait_seq(self, seq, at_least, on_comm):
+        self.e.seq_wait((self.comm if on_comm else self.main).cuda_stream, seq, at_least)
+
+    def partition_slabs_on_comm(self, n, id, field, ts, val, nshards, slab, recs_out, counts_out):
+        # exchange stream, in front of the all-to-all that sends the slabs: runs underneath the merge of the previous batch
+        self.pe.partition_by_owner_slabs_dev(n, id, field, ts, val, nshards, slab, recs_out, counts_out)
 
     def close(self):
         self.leave_pipeline()
@@ -182,33 +188,47 @@ class ShardedGraph:
         return nrecv
 
     # ---- pipelined mode ----------------------------------------------------------------------
-    def setup_pipeline(self, max_deltas, slack=1.03, depth=2):
+    def setup_pipeline(self, max_deltas, slack=1.03, depth=2, partition_on="merge"):
         """Allocate `depth` (>= 2) send/receive slab sets for batches of up to max_deltas deltas per rank. Protocol: call
-        route(b+1) before merge(b) and merge in route order; at most `depth` routed-but-unmerged batches may exist."""
-        assert depth >= 2
+        route(b+1) before merge(b) and merge in route order; at most `depth` routed-but-unmerged batches may exist.
+        partition_on: "exchange" = the owner partition of batch b+1 runs on the exchange stream in front of its all-to-all, i.e.
+        underneath merge(b); "merge" = it runs on the merge stream between two merges (default: 121 vs 125 us per step in the
+        one-rank rehearsal — under the probe kernel the partition and the exchange kernels are dispatched late and run 2x slower)."""
+        assert depth >= 2 and partition_on in ("exchange", "merge")
         W = self.world
         self.slab = int(max_deltas / W * slack) + 64
+        self.partition_on = partition_on
         self._pipe = []
         for _ in range(depth):
             self._pipe.append(dict(send=self.ops.empty_records(W * self.slab), recv=self.ops.empty_records(W * self.slab),
                                    counts=self.ops.zeros_i64(W), applied=self.ops.zeros_i32(W * self.slab), n_applied=self.ops.zeros_i64(1),
-                                   ready=self.ops.new_event(), free=self.ops.new_event(), parted=self.ops.new_event(), used=False))
+                                   used=False))
+        # sequence words (device memory): batch k has been partitioned / exchanged / merged once the word is >= k+1
+        self._parted = self.ops.new_seq()
+        self._ready = self.ops.new_seq()
+        self._merged_seq = self.ops.new_seq()
         self._routed = 0
         self._merged = 0
         self._due = []
 
     def route(self, n, id, field, ts, val):
-        """Enqueue the owner partition of one batch (merge stream) and remember that its exchange is due; returns a ticket
-        for merge(). The all-to-all itself is issued by the next merge() call AFTER that merge's kernels are enqueued, so
-        the (slow, host-side) collective call never delays kernels the GPU could already be running."""
-        assert self._routed - self._merged < len(self._pipe), "merge() the oldest routed batch before routing another"
-        p = self._pipe[self._routed % len(self._pipe)]
+        """Enqueue the owner partition of one batch and remember that its exchange is due; returns a ticket for merge(). The
+        all-to-all itself is issued by the next merge() call AFTER that merge's kernels are enqueued, so the (slow, host-side)
+        collective call never delays kernels the GPU could already be running."""
+        depth = len(self._pipe)
+        assert self._routed - self._merged < depth, "merge() the oldest routed batch before routing another"
+        k = self._routed
+        p = self._pipe[k % depth]
         self._routed += 1
+        p["k"] = k
         with self.ops.comm_ctx():                             # GPU: a no-op after the first call (streams are set once)
-            # merge stream: partition into the send slabs (the all-to-all that last read them finished before the merge
-            # that preceded this call on the same stream)
-            self.ops.partition_slabs(n, id, field, ts, val, self.world, self.slab, p["send"], p["counts"])
-            self.ops.record(p["parted"], on_comm=False)
+            if self.partition_on == "merge":
+                # merge stream, between merge(k-2) and merge(k-1): the all-to-all that last read these send slabs finished before
+                # merge(k-depth) started, and merge(k-depth) was the last reader of the receive slabs exchange k will overwrite
+                self.ops.partition_slabs(n, id, field, ts, val, self.world, self.slab, p["send"], p["counts"])
+                self.ops.signal(self._parted, k + 1, on_comm=False)
+            else:
+                p["args"] = (n, id, field, ts, val)           # partitioned on the exchange stream when the exchange is issued
         p["used"] = True
         p["exchanged"] = False
         self._due.append(p)
@@ -216,13 +236,18 @@ class ShardedGraph:
         return p
 
     def _exchange(self, p):
-        # communication stream: exchange once the slabs are written. `parted` was recorded on the merge stream AFTER the
-        # merge that last read these receive slabs (order on that stream: ... merge(b-2), partition(b), merge(b-1) ...
-        # with two slab sets), so waiting for it also protects recv: no separate "free" event is needed.
+        k, depth = p["k"], len(self._pipe)
         with self.ops.comm_ctx():
-            self.ops.wait(p["parted"], on_comm=True)
+            if self.partition_on == "merge":
+                self.ops.wait_seq(self._parted, k + 1, on_comm=True)
+            else:
+                # the receive slabs were last read by merge(k-depth); the send slabs by exchange k-depth (this stream, earlier)
+                if k >= depth:
+                    self.ops.wait_seq(self._merged_seq, k - depth + 1, on_comm=True)
+                n, id, field, ts, val = p.pop("args")
+                self.ops.partition_slabs_on_comm(n, id, field, ts, val, self.world, self.slab, p["send"], p["counts"])
             self.dist.all_to_all_single(p["recv"], p["send"])  # equal splits: world slabs of `slab` records
-            self.ops.record(p["ready"], on_comm=True)
+            self.ops.signal(self._ready, k + 1, on_comm=True)
         p["exchanged"] = True
 
     def merge(self, ticket):
@@ -232,9 +257,11 @@ class ShardedGraph:
         if not p["exchanged"]:                                 # first batch of a pipeline: nothing to hide it behind
             self._due.remove(p)
             self._exchange(p)
-        self.ops.wait(p["ready"], on_comm=False)
+        self.ops.wait_seq(self._ready, p["k"] + 1, on_comm=False)
         nrecv = self.world * self.slab                         # padding records are skipped by the kernel
         self.ops.merge_records(nrecv, p["recv"], self.insert_mode, p["applied"], p["n_applied"])
+        if self.partition_on != "merge":
+            self.ops.signal(self._merged_seq, p["k"] + 1, on_comm=False)
         while self._due:
             self._exchange(self._due.pop(0))
         self._merged += 1

@@ -573,6 +573,25 @@ int bmx_set_stream(bmx_ctx* ctx, void* s) {
 }
 void* bmx_get_stream(bmx_ctx* ctx) { return ctx ? reinterpret_cast<void*>(ctx->stream) : nullptr; }
 
+int bmx_seq_signal(bmx_ctx* ctx, void* hip_stream, uint64_t* seq_dev, uint64_t value) {
+  if (!ctx || !seq_dev) return fail(ctx, BMX_ERR_INVALID, "bmx_seq_signal: null context or sequence word");
+  HIPCHK(hipSetDevice(ctx->device));
+  hipStream_t st = hip_stream ? reinterpret_cast<hipStream_t>(hip_stream) : ctx->stream;
+  hipLaunchKernelGGL(k_seq_signal, dim3(1), dim3(64), 0, st, reinterpret_cast<unsigned long long*>(seq_dev), (unsigned long long)value);
+  LAUNCHCHK("k_seq_signal");
+  return BMX_OK;
+}
+
+int bmx_seq_wait(bmx_ctx* ctx, void* hip_stream, const uint64_t* seq_dev, uint64_t at_least) {
+  if (!ctx || !seq_dev) return fail(ctx, BMX_ERR_INVALID, "bmx_seq_wait: null context or sequence word");
+  HIPCHK(hipSetDevice(ctx->device));
+  hipStream_t st = hip_stream ? reinterpret_cast<hipStream_t>(hip_stream) : ctx->stream;
+  hipLaunchKernelGGL(k_seq_wait, dim3(1), dim3(64), 0, st, reinterpret_cast<const unsigned long long*>(seq_dev), (unsigned long long)at_least,
+                     &ctx->ds->status);
+  LAUNCHCHK("k_seq_wait");
+  return BMX_OK;
+}
+
 int bmx_get_info(bmx_ctx* ctx, bmx_info* out) {
   if (!ctx || !out) return fail(ctx, BMX_ERR_INVALID, "bad arguments");
   HIPCHK(hipSetDevice(ctx->device));

@@ -539,6 +539,19 @@ __global__ __launch_bounds__(256) void k_get_rows(const Slot* slots, uint64_t ns
   ts[j] = t; val[j] = v; found[j] = f;
 }
 
+// Cross-stream sequencing through a word in device memory (bmx_seq_signal / bmx_seq_wait): one wave each.
+__global__ void k_seq_signal(unsigned long long* seq, unsigned long long value) {
+  if (threadIdx.x == 0) __hip_atomic_store(seq, value, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+}
+__global__ void k_seq_wait(const unsigned long long* seq, unsigned long long at_least, uint32_t* status) {
+  if (threadIdx.x != 0) return;
+  const unsigned long long t0 = wall_clock64();            // 100 MHz
+  while (__hip_atomic_load(seq, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) < at_least) {
+    __builtin_amdgcn_s_sleep(8);
+    if (wall_clock64() - t0 > 1000000000ull) { atomicOr(status, ST_SPIN); return; }   // ~10 s: report instead of hanging
+  }
+}
+
 // K7: stable partition of a delta batch by owner shard into 32-byte records (two launches: count, scatter).
 // Counting and ranking are wave-ballot based (one __ballot per shard per 64 deltas): no LDS or global atomics.
 constexpr int PART_MAX_SHARDS = 16;

@@ -119,6 +119,18 @@ int bmx_get_info(bmx_ctx* ctx, bmx_info* out);
 int bmx_sync(bmx_ctx* ctx);                         /* wait for the stream; returns a sticky device error if any */
 int bmx_set_stream(bmx_ctx* ctx, void* hip_stream); /* run on the caller's hipStream_t (NULL = context's own) */
 void* bmx_get_stream(bmx_ctx* ctx);
+/* Cross-stream ordering for BMX_MEM_DEVICE callers without command-processor markers (no reference counterpart: the reference
+ * is single threaded). Measured on MI355X: an event record, or a wait on a not-yet-complete event, between two kernels of one
+ * stream holds that stream for ~9-10 us (bench_micro/event_gap*.hip); a 64-bit sequence word in device memory plus two tiny
+ * kernels costs a launch (~2.5 us) and nothing on the other stream.
+ *   bmx_seq_signal: enqueue on `hip_stream` a store of `value` to *seq_dev (device-scope release: everything enqueued on that
+ *                   stream before it is visible to whoever observes the value).
+ *   bmx_seq_wait:   enqueue on `hip_stream` a one-wave kernel that returns once *seq_dev >= at_least. The signal it waits for
+ *                   must already be enqueued (on any stream) when this is called, otherwise the wait can never be satisfied; it
+ *                   gives up after ~10 s and raises the context's sticky device error (bmx_sync then reports it).
+ * seq_dev is 8-byte aligned device memory owned by the caller, zeroed before first use. Same GPU only. */
+int bmx_seq_signal(bmx_ctx* ctx, void* hip_stream, uint64_t* seq_dev, uint64_t value);
+int bmx_seq_wait(bmx_ctx* ctx, void* hip_stream, const uint64_t* seq_dev, uint64_t at_least);
 
 /* ---- merge ----------------------------------------------------------------------------------
  * bmx_load_rows: bulk preload of resident rows with their clocks (what storage load / initial sync

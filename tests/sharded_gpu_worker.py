@@ -31,8 +31,8 @@ def main():
     for b in range(NB):
         d = synth.big_deltas(D, R, seed=5 + 100 * rank, T0=1000, DT=1000, insert_pct=15, hot_pct=30, hot_keys=40, unique=False, batch=b)
         batches.append([torch.from_numpy(np.ascontiguousarray(x).view(np.int64 if x.dtype.itemsize == 8 else np.int32)).to(dev) for x in d])
-    if mode == "pipelined":
-        sg.setup_pipeline(D, slack=1.2)
+    if mode.startswith("pipelined"):
+        sg.setup_pipeline(D, slack=1.2, partition_on=mode.split("_")[1])
         tk = sg.route(D, *batches[0])
         for b in range(NB):
             nxt = sg.route(D, *batches[b + 1]) if b + 1 < NB else None     # route(b+1) before merge(b), as bench.py does

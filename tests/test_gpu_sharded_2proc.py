@@ -20,7 +20,7 @@ def _free_port():
     return p
 
 
-@pytest.mark.parametrize("mode", ["exact", "pipelined"])
+@pytest.mark.parametrize("mode", ["exact", "pipelined_exchange", "pipelined_merge"])
 def test_two_ranks_on_one_gpu_equal_single_merge(tmp_path, mode):
     world = 2
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world), "--master-addr", "127.0.0.1",

@@ -57,14 +57,18 @@ class OracleOps:
         import contextlib
         return contextlib.nullcontext()
 
-    def new_event(self):
-        return None
+    # CPU stand-in: everything is synchronous, so the sequence words need no device
+    def new_seq(self):
+        return [0]
 
-    def record(self, ev, on_comm):
-        pass   # CPU stand-in: everything is synchronous
+    def signal(self, seq, value, on_comm):
+        seq[0] = value
 
-    def wait(self, ev, on_comm):
-        pass
+    def wait_seq(self, seq, at_least, on_comm):
+        assert seq[0] >= at_least, "the signal a wait refers to must already have been issued"
+
+    def partition_slabs_on_comm(self, *a):
+        self.partition_slabs(*a)
 
     def merge_records(self, n, recs, insert_mode, applied, n_applied):
         import bmx
@@ -97,7 +101,7 @@ def _worker(rank, world, port, tmp, pipelined=False):
         t = [torch.from_numpy(np.ascontiguousarray(x).view(np.int64 if x.dtype.itemsize == 8 else np.int32)) for x in d]
         if pipelined:
             if b == 0:
-                sg.setup_pipeline(3000, slack=1.2)
+                sg.setup_pipeline(3000, slack=1.2, partition_on=pipelined)
             p = sg.merge(sg.route(3000, *t))
             assert not sg.overflowed()
             digests.append(int(p["n_applied"][0]))
@@ -117,7 +121,7 @@ def _free_port():
     return p
 
 
-@pytest.mark.parametrize("pipelined", [False, True])
+@pytest.mark.parametrize("pipelined", [False, "exchange", "merge"])
 def test_two_rank_routing_equals_single_merge(tmp_path, pipelined):
     world = 2
     mp.spawn(_worker, args=(world, _free_port(), str(tmp_path), pipelined), nprocs=world, join=True)
