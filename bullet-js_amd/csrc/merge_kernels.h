@@ -580,20 +580,6 @@ __global__ __launch_bounds__(256) void k_part_count(const uint64_t* id, uint32_t
   if (threadIdx.x < nshards) counts[threadIdx.x * PART_BLOCKS + blockIdx.x] = wtot[0][threadIdx.x] + wtot[1][threadIdx.x] + wtot[2][threadIdx.x] + wtot[3][threadIdx.x];
 }
 
-// wave64 inclusive prefix sum in 7 DPP adds (row_shr 1,2,3,4,8 inside each row of 16 lanes, then row_bcast:15 into rows 1 and 3 and
-// row_bcast:31 into rows 2 and 3); disabled / out-of-row source lanes contribute 0 (old = 0, bound_ctrl)
-__device__ __forceinline__ uint32_t wave_incl_scan_u32(uint32_t v) {
-  uint32_t x = v;
-  x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xf, 0xf, true);
-  x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x112, 0xf, 0xf, true);
-  x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x113, 0xf, 0xf, true);
-  x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x114, 0xf, 0xe, true);
-  x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x118, 0xf, 0xc, true);
-  x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x142, 0xa, 0xf, true);
-  x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x143, 0xc, 0xf, true);
-  return x;
-}
-
 // The scatter pass is VALU-issue bound, not bandwidth bound (every block is resident at once, 4 waves per SIMD; PMC: 1900 VALU
 // instructions per wave in the first version), so it is written to execute few instructions: owners come as bytes from the count
 // pass, ranks from packed 8-bit one-hot counters scanned with DPP (4 shards per 32-bit word), all prefix tables stay in LDS and

@@ -201,25 +201,46 @@ __global__ __launch_bounds__(SEL_THREADS) void k_compact_winners(const uint8_t* 
   uint32_t m = first < n ? P.mask(first, n) : 0u;
   const uint32_t first_kb = blockIdx.x * 16u;
   uint32_t part = 0;
-  for (uint32_t k = threadIdx.x; k < first_kb; k += SEL_THREADS) part += blk_info[k] & BLK_COUNT;
+  if ((reinterpret_cast<uintptr_t>(blk_info) & 15u) == 0) {
+    // 16-byte loads, four in flight per lane: a plain "load, add" loop waits one L2 round trip per iteration (16 of them for the
+    // last block of a 1M-delta batch, which was most of this kernel's time)
+    const uint4* bi4 = reinterpret_cast<const uint4*>(blk_info);
+    const uint32_t nq = first_kb / 4;            // first_kb is a multiple of 16
+    for (uint32_t q0 = 0; q0 < nq; q0 += 4 * SEL_THREADS) {
+      uint4 v[4];
+#pragma unroll
+      for (int u = 0; u < 4; u++) {
+        const uint32_t q = q0 + (uint32_t)u * SEL_THREADS + threadIdx.x;
+        v[u] = q < nq ? bi4[q] : make_uint4(0u, 0u, 0u, 0u);
+      }
+#pragma unroll
+      for (int u = 0; u < 4; u++) part += (v[u].x & BLK_COUNT) + (v[u].y & BLK_COUNT) + (v[u].z & BLK_COUNT) + (v[u].w & BLK_COUNT);
+    }
+  } else {
+    for (uint32_t k = threadIdx.x; k < first_kb; k += SEL_THREADS) part += blk_info[k] & BLK_COUNT;
+  }
   uint32_t offset;
   block_excl_scan(part, offset, wsum);
   uint32_t tot;
-  uint32_t pos = offset + block_excl_scan((uint32_t)__popc(m), tot, wsum);
+  uint32_t lp = block_excl_scan((uint32_t)__popc(m), tot, wsum);
   if (applied) {
+    // winners of this block in order through LDS, then consecutive lanes store consecutive ranks (a lane's own run of up to 16
+    // indices would be 16 scattered 4-byte stores per wave instruction)
+    __shared__ uint32_t loc[4096];
     while (m) {
       int e = __ffs((int)m) - 1;
       m &= m - 1;
-      applied[pos++] = (uint32_t)first + (uint32_t)e;
+      loc[lp++] = (uint32_t)first + (uint32_t)e;
     }
+    __syncthreads();
+    for (uint32_t i = threadIdx.x; i < tot; i += SEL_THREADS) applied[offset + i] = loc[i];
   }
   if (blockIdx.x == gridDim.x - 1) Fin((uint64_t)offset + tot, wsum);
 }
 
 __global__ void k_sum_counts(const uint32_t* block_counts, uint32_t nblocks, unsigned long long* n_out) {
   __shared__ uint32_t wsum[4];
-  uint32_t part = 0;
-  for (uint32_t b = threadIdx.x; b < nblocks; b += SEL_THREADS) part += block_counts[b];
+  uint32_t part = strided_partial_sum(block_counts, nblocks);
   uint32_t tot;
   block_excl_scan(part, tot, wsum);
   if (threadIdx.x == 0) *n_out = tot;

@@ -37,12 +37,7 @@ inline SelGeom sel_geom(uint64_t n) {
 // exclusive scan of one value per thread over a 256-thread block; total returned to every thread
 __device__ __forceinline__ uint32_t block_excl_scan(uint32_t cnt, uint32_t& total, uint32_t* wsum /*[4] LDS*/) {
   const uint32_t lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-  uint32_t x = cnt;
-#pragma unroll
-  for (int d = 1; d < 64; d <<= 1) {
-    uint32_t y = __shfl_up(x, d);
-    if ((int)lane >= d) x += y;
-  }
+  const uint32_t x = wave_incl_scan_u32(cnt);   // DPP: no LDS round trips (callers run it with every lane active)
   if (lane == 63) wsum[w] = x;
   __syncthreads();
   uint32_t woff = 0, tot = 0;
@@ -55,6 +50,22 @@ __device__ __forceinline__ uint32_t block_excl_scan(uint32_t cnt, uint32_t& tota
   __syncthreads();
   total = tot;
   return woff + x - cnt;
+}
+
+// this thread's share of sum(c[0..n)), eight loads in flight: a plain "load, add" loop pays one L2 round trip per iteration
+__device__ __forceinline__ uint32_t strided_partial_sum(const uint32_t* __restrict__ c, uint32_t n) {
+  uint32_t part = 0;
+  for (uint32_t b0 = 0; b0 < n; b0 += 8 * SEL_THREADS) {
+    uint32_t v[8];
+#pragma unroll
+    for (int u = 0; u < 8; u++) {
+      const uint32_t b = b0 + (uint32_t)u * SEL_THREADS + threadIdx.x;
+      v[u] = b < n ? c[b] : 0u;
+    }
+#pragma unroll
+    for (int u = 0; u < 8; u++) part += v[u];
+  }
+  return part;
 }
 
 template <class Pred>
@@ -81,8 +92,7 @@ __global__ __launch_bounds__(SEL_THREADS) void k_sel_write(Pred P, Emit Em, Fini
   constexpr int E = Pred::E;
   const uint64_t tile = (uint64_t)SEL_THREADS * E;
   // global rank of this block's first selected element
-  uint32_t part = 0;
-  for (uint32_t b = threadIdx.x; b < blockIdx.x; b += SEL_THREADS) part += block_counts[b];
+  uint32_t part = strided_partial_sum(block_counts, blockIdx.x);
   uint32_t offset;
   block_excl_scan(part, offset, wsum);
   uint64_t running = offset;
@@ -168,8 +178,7 @@ __global__ __launch_bounds__(SEL_THREADS) void k_scan_emit(const uint32_t* __res
   if (scanned) {
     offset = counts[blockIdx.x];
   } else {
-    uint32_t part = 0;
-    for (uint32_t b = threadIdx.x; b < blockIdx.x; b += SEL_THREADS) part += counts[b];
+    uint32_t part = strided_partial_sum(counts, blockIdx.x);
     block_excl_scan(part, offset, wsum);
   }
   uint32_t tot;

@@ -55,6 +55,20 @@ __device__ __forceinline__ uint64_t home_slot(uint64_t h, uint64_t nslots) { ret
 // all kernels here use 1-D blocks whose size is a multiple of 64, so the lane is the low 6 bits of threadIdx.x
 __device__ __forceinline__ uint32_t lane_id() { return threadIdx.x & 63u; }
 
+// wave64 inclusive prefix sum in 7 DPP adds (row_shr 1,2,3,4,8 inside each row of 16 lanes, then row_bcast:15 into rows 1 and 3 and
+// row_bcast:31 into rows 2 and 3); disabled / out-of-row source lanes contribute 0 (old = 0, bound_ctrl)
+__device__ __forceinline__ uint32_t wave_incl_scan_u32(uint32_t v) {
+  uint32_t x = v;
+  x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xf, 0xf, true);
+  x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x112, 0xf, 0xf, true);
+  x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x113, 0xf, 0xf, true);
+  x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x114, 0xf, 0xe, true);
+  x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x118, 0xf, 0xc, true);
+  x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x142, 0xa, 0xf, true);
+  x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x143, 0xc, 0xf, true);
+  return x;
+}
+
 // lexicographic compare of (ts,val) pairs: -1, 0, +1   (reference: clock compare then default value compare,
 // src/bullet-crt.js:68-95 scalar form, :11-15)
 __device__ __forceinline__ int lexcmp(int64_t ta, int64_t va, int64_t tb, int64_t vb) {
