@@ -67,6 +67,23 @@ def cpu_baseline(n_batches=3):
     o.close()
     out = {"value": n_batches * D_PER_STEP / dt, "unit": "merges/s", "cores": 1, "kind": "port",
            "sample": "%d x 1M-delta batches against the 10M-row resident graph (load excluded), oracle/bmx_oracle.c, 1 thread" % n_batches}
+    # extra line: the same port on all host cores, threads owning key shards
+    try:
+        from oracle.oracle import OracleMT
+        T = max(1, min(os.cpu_count() or 1, 64))
+        if hasattr(os, "sched_getaffinity"):
+            T = max(1, min(T, len(os.sched_getaffinity(0))))
+        m = OracleMT(T)
+        m.load_rows(*gen_resident(R_PER_GPU))
+        t0 = time.perf_counter()
+        for b in batches:
+            m.merge_batch(*b)
+        dtm = time.perf_counter() - t0
+        m.close()
+        out["all_cores"] = {"value": n_batches * D_PER_STEP / dtm, "unit": "merges/s", "cores": T, "kind": "port",
+                            "sample": "same batches; %d threads, thread k owns the keys with owner(id) == k and walks the whole batch" % T}
+    except Exception as e:
+        out["all_cores"] = {"error": str(e)[:200]}
     # the Node.js path on the same box: the per-delta processUpdate loop over a Map (the reference harness shape of BASELINE.md §2),
     # run by the golden-pinned JS twin of BulletCRT (bullet-js_amd/js/gpu-crt.js); bounded sample, one thread
     import shutil

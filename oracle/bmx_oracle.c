@@ -239,6 +239,45 @@ uint32_t orc_owner_of(uint64_t id, uint32_t nshards) {
   return (uint32_t)(((unsigned __int128)h * nshards) >> 64);
 }
 
+/* ---- all-cores variant of the scalar merge, for bench.py's extra CPU baseline line only ------------------------
+ * T independent tables; table k owns the keys with orc_owner_of(id, T) == k. Every thread walks the whole batch in index order
+ * and applies the deltas it owns, so each key still sees its deltas sequentially: same final state as one table. */
+#include <pthread.h>
+typedef struct { orc_t* t; uint32_t k, T; uint64_t n; const uint64_t* id; const uint32_t* field; const int64_t* ts; const int64_t* val;
+                 int mode; int load; uint64_t applied; } orc_mt_job;
+static void* orc_mt_run(void* p) {
+  orc_mt_job* j = (orc_mt_job*)p;
+  uint64_t applied = 0;
+  for (uint64_t i = 0; i < j->n; i++) {
+    if (orc_owner_of(j->id[i], j->T) != j->k) continue;
+    if (j->load) {
+      orc_row* r = find(j->t, j->id[i], j->field[i]);
+      if (!r) r = append(j->t, j->id[i], j->field[i]);
+      r->ts = j->ts[i]; r->val = j->val[i];
+    } else {
+      orc_row* r;
+      if (resolve_scalar(j->t, j->id[i], j->field[i], j->ts[i], j->val[i], j->mode, &r) & ORC_FLAG_INCOMING) applied++;
+    }
+  }
+  j->applied = applied;
+  return NULL;
+}
+/* tables: T handles from orc_create(); load != 0 preloads rows instead of merging. Returns the number of applied deltas. */
+uint64_t orc_mt_batch(orc_t** tables, uint32_t T, uint64_t n, const uint64_t* id, const uint32_t* field, const int64_t* ts,
+                      const int64_t* val, int insert_mode, int load) {
+  pthread_t* th = (pthread_t*)malloc(T * sizeof(pthread_t));
+  orc_mt_job* jobs = (orc_mt_job*)malloc(T * sizeof(orc_mt_job));
+  for (uint32_t k = 0; k < T; k++) {
+    orc_mt_job jb = {tables[k], k, T, n, id, field, ts, val, insert_mode, load, 0};
+    jobs[k] = jb;
+    pthread_create(&th[k], NULL, orc_mt_run, &jobs[k]);
+  }
+  uint64_t total = 0;
+  for (uint32_t k = 0; k < T; k++) { pthread_join(th[k], NULL); total += jobs[k].applied; }
+  free(th); free(jobs);
+  return total;
+}
+
 /* ======================================================================================================================
  * N4: fixed-K multi-writer vector clocks, integer values. Restates resolve() for general clocks
  * (src/bullet-crt.js:164-279) with compareVectorClocks :68-95 (missing component = 0), mergeVectorClocks :103-114

@@ -45,6 +45,7 @@ def lib():
         L.orc_scan_filter_and.argtypes = [C.c_void_p, C.c_uint32, u32p, i64p, i64p, u64p, C.c_uint64]
         L.orc_scan_filter_and.restype = C.c_uint64
         L.orc_owner_of.argtypes = [C.c_uint64, C.c_uint32]; L.orc_owner_of.restype = C.c_uint32
+        L.orc_mt_batch.argtypes = [C.POINTER(C.c_void_p), C.c_uint32, C.c_uint64, u64p, u32p, i64p, i64p, C.c_int, C.c_int]; L.orc_mt_batch.restype = C.c_uint64
         _lib = L
     return _lib
 
@@ -132,6 +133,38 @@ class Oracle:
 def owner_of(ids, nshards):
     L = lib()
     return np.array([L.orc_owner_of(int(i), int(nshards)) for i in np.asarray(ids, dtype=np.uint64)], dtype=np.uint32)
+
+
+class OracleMT:
+    """All-cores variant (bench.py's extra CPU baseline line): T tables, thread k owns the keys with owner_of(id, T) == k."""
+
+    def __init__(self, threads):
+        self._L = lib()
+        self.T = int(threads)
+        self.tabs = [Oracle() for _ in range(self.T)]
+        self._arr = (C.c_void_p * self.T)(*[t._h for t in self.tabs])
+
+    def _run(self, cols, mode, load):
+        id, field, ts, val = _cols(*cols)
+        return int(self._L.orc_mt_batch(self._arr, self.T, len(id), _p(id, C.c_uint64), _p(field, C.c_uint32), _p(ts, C.c_int64), _p(val, C.c_int64),
+                                        int(mode), int(load)))
+
+    def load_rows(self, id, field, ts, val):
+        self._run((id, field, ts, val), INSERT_REFERENCE, 1)
+
+    def merge_batch(self, id, field, ts, val, insert_mode=INSERT_REFERENCE):
+        """-> number of applied deltas"""
+        return self._run((id, field, ts, val), insert_mode, 0)
+
+    def __len__(self):
+        return sum(len(t) for t in self.tabs)
+
+    def digest(self):
+        return sum(t.digest() for t in self.tabs) & ((1 << 64) - 1)
+
+    def close(self):
+        for t in self.tabs:
+            t.close()
 
 
 def rows_digest(id, field, ts, val):
