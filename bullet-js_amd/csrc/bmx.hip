@@ -445,7 +445,7 @@ int run_scan(bmx_ctx* ctx, const Pred& P, const Index* ix, uint64_t* out_ids, ui
     LAUNCHCHK("k_scan_mask");
     const bool scanned = nb > 2048;   // many blocks: one small launch turns the counts into offsets
     if (scanned) {
-      hipLaunchKernelGGL(k_scan_offsets, dim3(1), dim3(SEL_THREADS), 0, ctx->stream, ctx->scan_counts, nb);
+      hipLaunchKernelGGL(k_scan_offsets, dim3(1), dim3(OFFS_THREADS), 0, ctx->stream, ctx->scan_counts, nb);
       LAUNCHCHK("k_scan_offsets");
     }
     EmitIds Em{ix->ids, d_out, d_cap};

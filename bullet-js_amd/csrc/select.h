@@ -151,20 +151,29 @@ __global__ __launch_bounds__(SEL_THREADS) void k_scan_mask(Pred P, uint64_t n, u
   if (threadIdx.x == 0) block_counts[blockIdx.x] = total;
 }
 
-// exclusive scan of the block counts in place (one workgroup; used when there are too many blocks for each emitting
-// block to sum its predecessors itself); total -> counts[nb]
-__global__ __launch_bounds__(SEL_THREADS) void k_scan_offsets(uint32_t* counts, uint32_t nb) {
-  __shared__ uint32_t wsum[4];
-  uint32_t carry = 0;
-  for (uint32_t b0 = 0; b0 < nb; b0 += SEL_THREADS) {
-    uint32_t i = b0 + threadIdx.x;
-    uint32_t c = i < nb ? counts[i] : 0u;
-    uint32_t tot;
-    uint32_t ex = block_excl_scan(c, tot, wsum);
-    if (i < nb) counts[i] = carry + ex;
-    carry += tot;
-  }
-  if (threadIdx.x == 0) counts[nb] = carry;
+// exclusive scan of the block counts in place (one workgroup of 1024 threads; used when there are too many blocks for each
+// emitting block to sum its predecessors itself); total -> counts[nb]. Every thread owns a contiguous run of counts: two passes over
+// it with the loads of a pass in flight together and ONE block scan in between (the first version looped over 256-count slices
+// with a block scan each: 22 us for the 12k blocks of a 100M-row column).
+constexpr int OFFS_THREADS = 1024;
+__global__ __launch_bounds__(OFFS_THREADS) void k_scan_offsets(uint32_t* counts, uint32_t nb) {
+  __shared__ uint32_t wsum[OFFS_THREADS / 64];
+  const uint32_t lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const uint32_t per = (nb + OFFS_THREADS - 1) / OFFS_THREADS;
+  const uint32_t lo = min(nb, threadIdx.x * per), hi = min(nb, lo + per);
+  uint32_t sum = 0;
+#pragma unroll 8
+  for (uint32_t i = lo; i < hi; i++) sum += counts[i];
+  const uint32_t incl = wave_incl_scan_u32(sum);
+  if (lane == 63) wsum[w] = incl;
+  __syncthreads();
+  uint32_t woff = 0, tot = 0;
+#pragma unroll
+  for (int i = 0; i < OFFS_THREADS / 64; i++) { const uint32_t x = wsum[i]; if (i < (int)w) woff += x; tot += x; }
+  uint32_t run = woff + incl - sum;
+#pragma unroll 8
+  for (uint32_t i = lo; i < hi; i++) { const uint32_t c = counts[i]; counts[i] = run; run += c; }
+  if (threadIdx.x == 0) counts[nb] = tot;
 }
 
 template <class Emit, class Finish>
