@@ -22,3 +22,20 @@ for b in range(6):
     fl, upd = e.merge_batch(did, np.full(D, 7, np.uint32), clocks, val)
     dt = time.perf_counter() - t0
     print("batch %d: %.2f ms host-inclusive (%.1f M deltas/s), updated %d, concurrent %d" % (b, dt * 1e3, D / dt / 1e6, len(upd), int((fl & 8).astype(bool).sum())), flush=True)
+# device-pointer form: inputs resident, REPS batches back to back
+import torch
+dev = torch.device("cuda", 0)
+REPS = 10
+batches = []
+for b in range(REPS):
+    rows = rng.integers(0, R, D); new = rng.random(D) < 0.1
+    rows[new] = R + (6 + b) * D + np.arange(int(new.sum()))
+    batches.append([torch.from_numpy(x).to(dev) for x in (mix(rows).view(np.int64), np.full(D, 7, np.int32), rng.integers(1, 12, (D, K)).astype(np.int32).reshape(-1), rng.integers(0, 100, D))])
+upd = torch.zeros(D, dtype=torch.int32, device=dev); nu = torch.zeros(1, dtype=torch.int64, device=dev)
+e.merge_batch_dev(D, *batches[0], updated=upd, n_updated=nu); e.sync()
+t0 = time.perf_counter()
+for b in range(1, REPS):
+    e.merge_batch_dev(D, *batches[b], updated=upd, n_updated=nu)
+e.sync()
+dt = (time.perf_counter() - t0) / (REPS - 1)
+print("device-resident: %.1f us per 1M-delta batch = %.2f G clock-merges/s" % (dt * 1e6, D / dt / 1e9), flush=True)

@@ -6,6 +6,7 @@ HIP library and raises BmxError if it (or a GPU) is missing.
 """
 import ctypes as C
 import os
+import sys
 
 import numpy as np
 
@@ -28,7 +29,7 @@ EXPORTS = [
     "bmx_load_rows", "bmx_merge_batch", "bmx_merge_records", "bmx_get_rows", "bmx_get_row", "bmx_dump_rows", "bmx_row_count", "bmx_reserve",
     "bmx_index_build", "bmx_index_drop", "bmx_index_size", "bmx_scan_range", "bmx_scan_equals", "bmx_scan_count", "bmx_scan_filter",
     "bmx_owner_of", "bmx_partition_by_owner", "bmx_partition_by_owner_slabs", "bmx_timer_start", "bmx_timer_stop", "bmx_profile_enable", "bmx_profile_read",
-    "bmx_vc_create", "bmx_vc_destroy", "bmx_vc_last_error", "bmx_vc_load_rows", "bmx_vc_merge_batch", "bmx_vc_get_rows", "bmx_vc_row_count",
+    "bmx_vc_create", "bmx_vc_destroy", "bmx_vc_last_error", "bmx_vc_load_rows", "bmx_vc_merge_batch", "bmx_vc_get_rows", "bmx_vc_row_count", "bmx_vc_merge_batch_dev", "bmx_vc_set_stream", "bmx_vc_sync",
 ]
 
 
@@ -63,6 +64,16 @@ def load_library():
         return _lib
     if not os.path.exists(LIB_PATH):
         raise BmxError(ERR_NO_DEVICE, "libbmx.so not built (run __graft_entry__.build() or make -C bullet-js_amd): the engine has no CPU fallback")
+    # Load order matters in a process that also uses PyTorch: its wheel bundles its own ROCm runtime (same sonames as /opt/rocm's). If
+    # libbmx.so comes first it binds the system runtime and torch later brings a second one ("No HIP GPUs are available"); if torch comes
+    # first, libbmx.so resolves libamdhip64.so.7 to the copy that is already loaded and both share streams and pointers.
+    if "torch" not in sys.modules:
+        try:
+            import importlib.util
+            if importlib.util.find_spec("torch") is not None:
+                import torch  # noqa: F401
+        except Exception:
+            pass
     L = C.CDLL(LIB_PATH)
     vp, u64, u32, i64, i32 = C.c_void_p, C.c_uint64, C.c_uint32, C.c_int64, C.c_int
     L.bmx_create.argtypes = [i32, u64, u32, C.POINTER(vp)]; L.bmx_create.restype = i32
@@ -104,6 +115,9 @@ def load_library():
     L.bmx_vc_merge_batch.argtypes = [vp, u64, vp, vp, vp, vp, vp, vp, vp]; L.bmx_vc_merge_batch.restype = i32
     L.bmx_vc_get_rows.argtypes = [vp, u64, vp, vp, vp, vp, vp]; L.bmx_vc_get_rows.restype = i32
     L.bmx_vc_row_count.argtypes = [vp, C.POINTER(u64)]; L.bmx_vc_row_count.restype = i32
+    L.bmx_vc_merge_batch_dev.argtypes = [vp, u64, vp, vp, vp, vp, vp, vp, vp]; L.bmx_vc_merge_batch_dev.restype = i32
+    L.bmx_vc_set_stream.argtypes = [vp, vp]; L.bmx_vc_set_stream.restype = i32
+    L.bmx_vc_sync.argtypes = [vp]; L.bmx_vc_sync.restype = i32
     _lib = L
     return L
 
@@ -361,6 +375,16 @@ class EngineVC:
         n = C.c_uint64()
         self._chk(self.L.bmx_vc_row_count(self.h, C.byref(n)))
         return n.value
+
+    # device-pointer form: torch tensors / raw pointers, enqueue-only
+    def merge_batch_dev(self, n, id, field, clocks, val, updated=None, n_updated=None, flags=None):
+        self._chk(self.L.bmx_vc_merge_batch_dev(self.h, int(n), _ptr(id), _ptr(field), _ptr(clocks), _ptr(val), _ptr(updated), _ptr(n_updated), _ptr(flags)))
+
+    def set_stream(self, stream_ptr):
+        self._chk(self.L.bmx_vc_set_stream(self.h, C.c_void_p(stream_ptr) if stream_ptr else None))
+
+    def sync(self):
+        self._chk(self.L.bmx_vc_sync(self.h))
 
 
 def owner_of(ids, nshards):

@@ -222,7 +222,7 @@ int bmx_partition_by_owner_slabs(bmx_ctx* ctx, uint64_t n, const uint64_t* id, c
  * {local: 2} (:172-185). Contract: incoming clocks are dense (the host lists all K writers, same order, every time).
  * Deltas of one key are applied in index order (the result is order dependent for concurrent clocks), so batches are
  * exact for any duplication. flags[j] additionally carries BMX_FLAG_CONCURRENT. updated_idx = ascending indices of the
- * last delta per key that caused a store (doUpdate: src/bullet-crt.js:383). Host buffers only (synchronous). capacity_rows
+ * last delta per key that caused a store (doUpdate: src/bullet-crt.js:383). These entry points take host buffers (synchronous). capacity_rows
  * is the initial size: the table grows by a device-side rehash whenever a batch could push the load factor above 0.5. */
 #define BMX_FLAG_CONCURRENT 8u
 #define BMX_VC_MAX_WRITERS 8
@@ -240,6 +240,13 @@ int bmx_vc_merge_batch(bmx_vc* t, uint64_t n, const uint64_t* id, const uint32_t
 int bmx_vc_get_rows(bmx_vc* t, uint64_t n, const uint64_t* id, const uint32_t* field, uint32_t* clocks_out /* n*K */,
                     int64_t* val_out, uint8_t* state_out);
 int bmx_vc_row_count(bmx_vc* t, uint64_t* n_out);
+/* Device-pointer form (all pointers are device memory; enqueue-only on the table's stream, like BMX_MEM_DEVICE for the scalar table):
+ * n_updated is a device uint64; updated_idx (capacity n) and flags (n) may be NULL. Domain errors and protocol faults are sticky and
+ * reported by bmx_vc_sync. bmx_vc_set_stream: run on the caller's hipStream_t (NULL = the table's own). */
+int bmx_vc_merge_batch_dev(bmx_vc* t, uint64_t n, const uint64_t* id, const uint32_t* field, const uint32_t* clocks, const int64_t* val,
+                           uint32_t* updated_idx, uint64_t* n_updated, uint8_t* flags);
+int bmx_vc_set_stream(bmx_vc* t, void* hip_stream);
+int bmx_vc_sync(bmx_vc* t);
 
 /* ---- timing helpers (HIP events on the context's stream; used by bench.py) ------------------- */
 int bmx_timer_start(bmx_ctx* ctx);

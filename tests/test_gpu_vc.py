@@ -6,6 +6,7 @@ import base64
 
 import numpy as np
 import pytest
+import torch
 
 pytestmark = pytest.mark.gpu
 
@@ -149,4 +150,35 @@ def test_vc_table_grows():
         seen.update(zip(ids.tolist(), fields.tolist()))
     keys = sorted(seen)[::7]
     _compare_rows(e, o, np.array([k[0] for k in keys], np.uint64), np.array([k[1] for k in keys], np.uint32))
+    e.close()
+
+
+def test_vc_device_pointer_batches_match_oracle():
+    dev = torch.device("cuda", 0)
+    K, local = 3, 1
+    rng = np.random.default_rng(31)
+    e = bmx.EngineVC(1000, K, local); o = OracleVC(K, local)        # grows while device-pointer batches are in flight
+    seen = set()
+    for b in range(5):
+        ids, fields, clocks, val = _rand_batch(rng, 7000, 20000, K, 4 + b, 3, hot=0.25)
+        n = len(ids)
+        t = [torch.from_numpy(x).to(dev) for x in (ids.view(np.int64), fields.view(np.int32), clocks.view(np.int32).reshape(-1), val)]
+        upd = torch.zeros(n, dtype=torch.int32, device=dev); nu = torch.zeros(1, dtype=torch.int64, device=dev)
+        fl = torch.zeros(n, dtype=torch.uint8, device=dev)
+        e.merge_batch_dev(n, *t, updated=upd, n_updated=nu, flags=fl)
+        e.sync()
+        f2, u2 = o.merge_batch(ids, fields, clocks, val)
+        k = int(nu.item())
+        assert np.array_equal(fl.cpu().numpy(), f2), b
+        assert np.array_equal(upd[:k].cpu().numpy().view(np.uint32), u2), b
+        assert e.row_count() == len(o)
+        seen.update(zip(ids.tolist(), fields.tolist()))
+    keys = sorted(seen)[::5]
+    _compare_rows(e, o, np.array([k[0] for k in keys], np.uint64), np.array([k[1] for k in keys], np.uint32))
+    bad = torch.tensor([1 << 60], dtype=torch.int64, device=dev)
+    one = [torch.from_numpy(x).to(dev) for x in (np.array([5], np.int64), np.array([7], np.int32), np.ones(K, np.int32))]
+    e.merge_batch_dev(1, *one, bad)
+    with pytest.raises(bmx.BmxError) as ei:
+        e.sync()
+    assert ei.value.code == bmx.ERR_RANGE
     e.close()
