@@ -201,3 +201,29 @@ def test_async_compaction_overlaps_batches_and_stays_exact():
         assert np.array_equal(a, ow)
         f0 = int(res[1][0])
         assert e.scan_count(f0, -(1 << 40), 1 << 40) == o.scan_count(f0, -(1 << 40), 1 << 40)
+
+
+def test_sequence_words_order_two_streams():
+    """bmx_seq_signal / bmx_seq_wait: a consumer stream sees the producer's data once the sequence word reaches the value."""
+    dev = torch.device("cuda", 0)
+    a, b = torch.cuda.Stream(dev), torch.cuda.Stream(dev)
+    seq = torch.zeros(1, dtype=torch.int64, device=dev)
+    n = 1 << 22
+    x = torch.zeros(n, dtype=torch.int64, device=dev)
+    y = torch.zeros(n, dtype=torch.int64, device=dev)
+    torch.cuda.synchronize()
+    with bmx.Engine(1000) as e:
+        for k in range(1, 6):
+            with torch.cuda.stream(a):
+                x.fill_(k)                                   # producer work on stream a
+            e.seq_signal(a.cuda_stream, seq, k)              # ... then seq = k
+            e.seq_wait(b.cuda_stream, seq, k)                # consumer: wait on the device for seq >= k
+            with torch.cuda.stream(b):
+                y.copy_(x)
+            b.synchronize()
+            assert int(seq.item()) == k and bool((y == k).all())
+            e.seq_wait(b.cuda_stream, seq, k - 1)            # already satisfied: returns at once
+            b.synchronize()
+        e.sync()
+        with pytest.raises(bmx.BmxError):
+            e.seq_wait(b.cuda_stream, None, 1)
