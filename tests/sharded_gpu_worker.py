@@ -1,4 +1,4 @@
-"""Worker of tests/test_gpu_sharded_2proc.py: one rank of a sharded graph with the REAL engine (HIP kernels, device slabs,
+"""Worker of tests/test_gpu_sharded_ranks.py: one rank of a sharded graph with the REAL engine (HIP kernels, device slabs,
 streams, events) on cuda:0. Launched by torch.distributed.run like bench.py; backend gloo because two ranks share the one
 GPU of the test box (RCCL refuses duplicate devices) — everything except the transport is the N>1 product path."""
 import os

@@ -20,9 +20,8 @@ def _free_port():
     return p
 
 
-@pytest.mark.parametrize("mode", ["exact", "pipelined_exchange", "pipelined_merge"])
-def test_two_ranks_on_one_gpu_equal_single_merge(tmp_path, mode):
-    world = 2
+@pytest.mark.parametrize("mode,world", [("exact", 2), ("pipelined_exchange", 2), ("pipelined_merge", 2), ("pipelined_merge", 4)])
+def test_ranks_sharing_one_gpu_equal_single_merge(tmp_path, mode, world):
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world), "--master-addr", "127.0.0.1",
            "--master-port", str(_free_port()), os.path.join(HERE, "sharded_gpu_worker.py"), str(tmp_path), mode]
     r = subprocess.run(cmd, capture_output=True, text=True, timeout=600)
