@@ -45,7 +45,7 @@ def gen_resident(R, row0=0):
 
 def gen_batch(b, R, D=D_PER_STEP, seed=2):
     from bmx import synth
-    return synth.big_deltas(D, R, seed=seed, T0=T0, DT=DT, insert_pct=10, unique=True, batch=b, drift=DT // 16)
+    return synth.big_deltas(D, R, seed=seed, T0=T0, DT=DT, insert_pct=int(os.environ.get("BMX_BENCH_INSERT_PCT", 10)), unique=True, batch=b, drift=DT // 16)   # config 2: 10 % inserts (the override is for experiments)
 
 
 def to_dev(cols, dev):
