@@ -54,7 +54,7 @@ def to_dev(cols, dev):
             torch.from_numpy(ts).to(dev), torch.from_numpy(val).to(dev))
 
 
-def cpu_baseline(n_batches=3):
+def cpu_baseline(n_batches=24):
     """Oracle (C port of the reference merge rule) on ONE host core, same workload shape."""
     from oracle.oracle import Oracle
     o = Oracle()
@@ -66,7 +66,7 @@ def cpu_baseline(n_batches=3):
     dt = time.perf_counter() - t0
     o.close()
     out = {"value": n_batches * D_PER_STEP / dt, "unit": "merges/s", "cores": 1, "kind": "port",
-           "sample": "%d x 1M-delta batches against the 10M-row resident graph (load excluded), oracle/bmx_oracle.c, 1 thread" % n_batches}
+           "sample": "%d x 1M-delta batches of the bench's own stream against the 10M-row resident graph (load excluded; %.1f s of timed CPU work), oracle/bmx_oracle.c, 1 thread" % (n_batches, dt)}
     # extra line: the same port on all host cores, threads owning key shards
     try:
         from oracle.oracle import OracleMT
@@ -91,8 +91,8 @@ def cpu_baseline(n_batches=3):
     node = shutil.which("node")
     if node:
         try:
-            r = subprocess.run([node, os.path.join(ROOT, "bullet-js_amd", "js", "test", "cpu_baseline.js"), "1000000", "300000"],
-                               capture_output=True, text=True, timeout=180)
+            r = subprocess.run([node, os.path.join(ROOT, "bullet-js_amd", "js", "test", "cpu_baseline.js"), "1000000", "2000000"],
+                               capture_output=True, text=True, timeout=240)
             j = json.loads(r.stdout.strip().splitlines()[-1])
             out["js_twin"] = {"value": j["value"], "unit": "merges/s", "cores": 1, "node": j["node"],
                               "sample": "%d deltas (10 %% inserts) against %d resident keys, processUpdate loop over a Map, 1 thread" % (j["deltas"], j["resident_keys"])}
