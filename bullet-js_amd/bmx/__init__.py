@@ -11,7 +11,7 @@ import sys
 import numpy as np
 
 _PKG = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-LIB_PATH = os.path.join(_PKG, "libbmx.so")
+LIB_PATH = os.environ.get("BMX_LIB_PATH") or os.path.join(_PKG, "libbmx.so")   # the override exists for A/B measurements of two builds
 
 OK = 0
 ERR_INVALID, ERR_HIP, ERR_FULL, ERR_NOMEM, ERR_RANGE, ERR_INTERNAL, ERR_NO_DEVICE, ERR_NO_INDEX = -1, -2, -3, -4, -5, -6, -7, -8

@@ -90,8 +90,9 @@ template <bool UNIQUE>
 __device__ __forceinline__ bool probe_or_insert(const MergeArgs& A, uint32_t tag, uint64_t id, uint32_t field, uint64_t& slot_out,
                                                 bool& is_new, bool& created, uint32_t& prev_head, int64_t& cts, int64_t& cval) {
   created = false;
-  uint64_t s = home_slot(key_hash(id, field), A.nslots);
+  ProbeSeq<4> ps(id, field, A.nslots);
   for (uint64_t p = 0; p < A.nslots; ++p) {
+    const uint64_t s = ps.slot();
     Slot* sl = A.slots + s;
     const uint4* q = reinterpret_cast<const uint4*>(sl);
     uint4 lo = q[0], hi = q[1];
@@ -135,7 +136,7 @@ __device__ __forceinline__ bool probe_or_insert(const MergeArgs& A, uint32_t tag
         return true;
       }
     }
-    s = (s + 1 == A.nslots) ? 0 : s + 1;
+    ps.next();
   }
   atomicOr(A.status, ST_FULL);
   return false;
@@ -496,17 +497,17 @@ __global__ __launch_bounds__(256) void k_rehash(const Slot* old_slots, uint64_t 
     uint4 hi = q[1];
     int64_t t = (int64_t)((uint64_t)hi.x | ((uint64_t)hi.y << 32));
     if (t != TS_NEW) t = ts_value(t);          // creation marks do not survive a rehash
-    uint64_t s = home_slot(key_hash(id, lo.z), nslots);
+    ProbeSeq<4> ps(id, lo.z, nslots);
     bool done = false;
     for (uint64_t p = 0; p < nslots && !done; ++p) {
-      Slot* sl = slots + s;
+      Slot* sl = slots + ps.slot();
       unsigned long long old = atomicCAS(reinterpret_cast<unsigned long long*>(&sl->id), (unsigned long long)EMPTY_ID, (unsigned long long)id);
       if (old == EMPTY_ID) {
         sl->field = lo.z; sl->head = 0;
         reinterpret_cast<uint4*>(sl)[1] = make_uint4((uint32_t)(uint64_t)t, (uint32_t)((uint64_t)t >> 32), hi.z, hi.w);
         done = true;
       } else {
-        s = (s + 1 == nslots) ? 0 : s + 1;
+        ps.next();
       }
     }
     if (!done) atomicOr(status, ST_FULL);
@@ -519,10 +520,10 @@ __global__ __launch_bounds__(256) void k_get_rows(const Slot* slots, uint64_t ns
   uint32_t j = blockIdx.x * 256u + threadIdx.x;
   if (j >= n) return;
   uint64_t kid = id[j]; uint32_t kf = field[j];
-  uint64_t s = home_slot(key_hash(kid, kf), nslots);
+  ProbeSeq<4> ps(kid, kf, nslots);
   uint8_t f = 0; int64_t t = 0, v = 0;
   for (uint64_t p = 0; p < nslots; ++p) {
-    const uint4* q = reinterpret_cast<const uint4*>(slots + s);
+    const uint4* q = reinterpret_cast<const uint4*>(slots + ps.slot());
     uint4 lo = q[0];
     uint64_t sid = (uint64_t)lo.x | ((uint64_t)lo.y << 32);
     if (sid == EMPTY_ID) break;
@@ -534,7 +535,7 @@ __global__ __launch_bounds__(256) void k_get_rows(const Slot* slots, uint64_t ns
       t = ts_value(t);
       break;
     }
-    s = (s + 1 == nslots) ? 0 : s + 1;
+    ps.next();
   }
   ts[j] = t; val[j] = v; found[j] = f;
 }

@@ -104,10 +104,10 @@ struct PredFilter {
   uint32_t nterms; bmx_term t[MAX_TERMS];
   __device__ bool rest(uint64_t id) const {
     for (uint32_t k = 1; k < nterms; k++) {
-      uint64_t s = home_slot(key_hash(id, t[k].field), nslots);
+      ProbeSeq<4> ps(id, t[k].field, nslots);
       bool ok = false;
       for (uint64_t p = 0; p < nslots; ++p) {
-        const uint4* q = reinterpret_cast<const uint4*>(slots + s);
+        const uint4* q = reinterpret_cast<const uint4*>(slots + ps.slot());
         uint4 lo = q[0];
         uint64_t sid = (uint64_t)lo.x | ((uint64_t)lo.y << 32);
         if (sid == EMPTY_ID) break;
@@ -117,7 +117,7 @@ struct PredFilter {
           ok = x >= t[k].lo && x <= t[k].hi;
           break;
         }
-        s = (s + 1 == nslots) ? 0 : s + 1;
+        ps.next();
       }
       if (!ok) return false;
     }

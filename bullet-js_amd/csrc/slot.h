@@ -50,7 +50,27 @@ __host__ __device__ inline uint64_t key_hash(uint64_t id, uint32_t field) {
 // owner shard of a node id; independent of key_hash so shards see uniformly hashed slots
 __host__ __device__ inline uint64_t owner_hash(uint64_t id) { return mix64(id * 0xD6E8FEB86659FD93ULL + 0x2545F4914F6CDD1DULL); }
 
-__device__ __forceinline__ uint64_t home_slot(uint64_t h, uint64_t nslots) { return __umul64hi(h, nslots); }
+// Probe sequence of a key. A 128-byte line is a bucket (SPL slots: 4 rows of 32 B, or 2 vector-clock rows of 64 B): the line comes from
+// the NODE id alone, the start inside the line from the field, and the line's slots are tried cyclically before the next line is.
+// So the fields of one node share a line while it has room — a sync chunk that carries several fields of a node costs one fill, and one
+// coalesced request when the rows sit on neighbouring lanes — and a lookup leaves its home line only if that line is full (random
+// probing crossed a line boundary on 8 % of the probes at load factor 0.3). No deletions exist, so "reached an empty slot" still means absent.
+__host__ __device__ inline uint64_t node_hash(uint64_t id) { return mix64(id * 0x9FB21C651E98DF25ULL + 0x632BE59BD9B4E019ULL); }
+template <int SPL>
+struct ProbeSeq {
+  uint64_t line, nlines; uint32_t c, k;
+  __device__ __forceinline__ ProbeSeq(uint64_t id, uint32_t field, uint64_t nslots) {
+    nlines = nslots / SPL;                                   // nslots is a multiple of SPL
+    const uint64_t h = node_hash(id);
+    line = __umul64hi(h, nlines);
+    // start inside the line: field-dependent, rotated per node (low hash bits, which the line index barely depends on) so that a
+    // single-field graph does not put every row in the same 32-byte sector of its line
+    c = (((field * 0x9E3779B9u) >> (SPL == 4 ? 30 : 31)) + (uint32_t)h) & (SPL - 1);
+    k = 0;
+  }
+  __device__ __forceinline__ uint64_t slot() const { return line * SPL + ((c + k) & (SPL - 1)); }
+  __device__ __forceinline__ void next() { if ((++k & (SPL - 1)) == 0) line = (line + 1 == nlines) ? 0 : line + 1; }
+};
 
 // all kernels here use 1-D blocks whose size is a multiple of 64, so the lane is the low 6 bits of threadIdx.x
 __device__ __forceinline__ uint32_t lane_id() { return threadIdx.x & 63u; }

@@ -51,10 +51,10 @@ __global__ __launch_bounds__(256) void k_vc_rehash(const VSlot* old_slots, uint6
     const uint4 lo = q[0];
     const uint64_t id = (uint64_t)lo.x | ((uint64_t)lo.y << 32);
     if (id == EMPTY_ID) continue;
-    uint64_t s = home_slot(key_hash(id, lo.z), nslots);
+    ProbeSeq<2> ps(id, lo.z, nslots);
     bool placed = false;
     for (uint64_t p = 0; p < nslots; ++p) {
-      VSlot* sl = slots + s;
+      VSlot* sl = slots + ps.slot();
       if (atomicCAS(reinterpret_cast<unsigned long long*>(&sl->id), (unsigned long long)EMPTY_ID, (unsigned long long)id) == EMPTY_ID) {
         uint4* w = reinterpret_cast<uint4*>(sl);
         sl->field = lo.z; sl->head = 0u;
@@ -62,7 +62,7 @@ __global__ __launch_bounds__(256) void k_vc_rehash(const VSlot* old_slots, uint6
         placed = true;
         break;
       }
-      s = (s + 1 == nslots) ? 0 : s + 1;
+      ps.next();
     }
     if (!placed) atomicOr(status, ST_FULL);
   }
@@ -79,9 +79,10 @@ __global__ __launch_bounds__(256) void k_vc_link(VcArgs A) {
     if (!valid) atomicOr(A.status, ST_RANGE);
     if (valid) {
       const uint32_t tag = (A.epoch << IDX_BITS) | j;
-      uint64_t s = home_slot(key_hash(id, field), A.nslots);
+      ProbeSeq<2> ps(id, field, A.nslots);
       bool found = false;
       for (uint64_t p = 0; p < A.nslots && !found; ++p) {
+        const uint64_t s = ps.slot();
         VSlot* sl = A.slots + s;
         uint4 lo = reinterpret_cast<const uint4*>(sl)[0];
         uint64_t sid = (uint64_t)lo.x | ((uint64_t)lo.y << 32);
@@ -109,7 +110,7 @@ __global__ __launch_bounds__(256) void k_vc_link(VcArgs A) {
             break;
           }
         }
-        s = (s + 1 == A.nslots) ? 0 : s + 1;
+        ps.next();
       }
       if (!found && slot == 0xFFFFFFFFu) atomicOr(A.status, ST_FULL);
     }
@@ -234,10 +235,10 @@ __global__ __launch_bounds__(256) void k_vc_get(const VSlot* slots, uint64_t nsl
   uint32_t j = blockIdx.x * 256u + threadIdx.x;
   if (j >= n) return;
   const uint64_t kid = id[j]; const uint32_t kf = field[j];
-  uint64_t s = home_slot(key_hash(kid, kf), nslots);
+  ProbeSeq<2> ps(kid, kf, nslots);
   uint8_t st = VC_ABSENT; int64_t v = 0; uint32_t c[VC_MAXK] = {0, 0, 0, 0, 0, 0, 0, 0};
   for (uint64_t p = 0; p < nslots; ++p) {
-    const uint4* q = reinterpret_cast<const uint4*>(slots + s);
+    const uint4* q = reinterpret_cast<const uint4*>(slots + ps.slot());
     uint4 lo = q[0];
     uint64_t sid = (uint64_t)lo.x | ((uint64_t)lo.y << 32);
     if (sid == EMPTY_ID) break;
@@ -247,7 +248,7 @@ __global__ __launch_bounds__(256) void k_vc_get(const VSlot* slots, uint64_t nsl
       c[0] = c0.x; c[1] = c0.y; c[2] = c0.z; c[3] = c0.w; c[4] = c1.x; c[5] = c1.y; c[6] = c1.z; c[7] = c1.w;
       break;
     }
-    s = (s + 1 == nslots) ? 0 : s + 1;
+    ps.next();
   }
   val[j] = v; state[j] = st;
 #pragma unroll
