@@ -44,10 +44,7 @@ __host__ __device__ inline uint64_t mix64(uint64_t x) {
   x ^= x >> 33; x *= 0xff51afd7ed558ccdULL; x ^= x >> 33; x *= 0xc4ceb9fe1a85ec53ULL; x ^= x >> 33;
   return x;
 }
-__host__ __device__ inline uint64_t key_hash(uint64_t id, uint32_t field) {
-  return mix64(id ^ ((uint64_t)field * 0x9E3779B97F4A7C15ULL));
-}
-// owner shard of a node id; independent of key_hash so shards see uniformly hashed slots
+// owner shard of a node id; independent of node_hash (below) so every shard sees uniformly hashed lines
 __host__ __device__ inline uint64_t owner_hash(uint64_t id) { return mix64(id * 0xD6E8FEB86659FD93ULL + 0x2545F4914F6CDD1DULL); }
 
 // Probe sequence of a key. A 128-byte line is a bucket (SPL slots: 4 rows of 32 B, or 2 vector-clock rows of 64 B): the line comes from
