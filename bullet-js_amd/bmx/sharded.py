@@ -203,6 +203,12 @@ class ShardedGraph:
             self._pipe.append(dict(send=self.ops.empty_records(W * self.slab), recv=self.ops.empty_records(W * self.slab),
                                    counts=self.ops.zeros_i64(W), applied=self.ops.zeros_i32(W * self.slab), n_applied=self.ops.zeros_i64(1),
                                    used=False))
+        # one throw-away exchange now: the first all-to-all of a process group sets up its peer connections (seconds on 8 GPUs), which
+        # must not happen while a device-side wait of the pipeline is spinning on it
+        with self.ops.comm_ctx():
+            self._pipe[0]["send"].zero_()
+            self.dist.all_to_all_single(self._pipe[0]["recv"], self._pipe[0]["send"])
+        self.ops.sync()
         # sequence words (device memory): batch k has been partitioned / exchanged / merged once the word is >= k+1
         self._parted = self.ops.new_seq()
         self._ready = self.ops.new_seq()

@@ -549,7 +549,7 @@ __global__ void k_seq_wait(const unsigned long long* seq, unsigned long long at_
   const unsigned long long t0 = wall_clock64();            // 100 MHz
   while (__hip_atomic_load(seq, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) < at_least) {
     __builtin_amdgcn_s_sleep(8);
-    if (wall_clock64() - t0 > 1000000000ull) { atomicOr(status, ST_SPIN); return; }   // ~10 s: report instead of hanging
+    if (wall_clock64() - t0 > 6000000000ull) { atomicOr(status, ST_SPIN); return; }   // ~60 s: report instead of hanging
   }
 }
 

@@ -127,7 +127,7 @@ void* bmx_get_stream(bmx_ctx* ctx);
  *                   stream before it is visible to whoever observes the value).
  *   bmx_seq_wait:   enqueue on `hip_stream` a one-wave kernel that returns once *seq_dev >= at_least. The signal it waits for
  *                   must already be enqueued (on any stream) when this is called, otherwise the wait can never be satisfied; it
- *                   gives up after ~10 s and raises the context's sticky device error (bmx_sync then reports it).
+ *                   gives up after ~60 s and raises the context's sticky device error (bmx_sync then reports it).
  * seq_dev is 8-byte aligned device memory owned by the caller, zeroed before first use. Same GPU only. */
 int bmx_seq_signal(bmx_ctx* ctx, void* hip_stream, uint64_t* seq_dev, uint64_t value);
 int bmx_seq_wait(bmx_ctx* ctx, void* hip_stream, const uint64_t* seq_dev, uint64_t at_least);
