@@ -43,9 +43,9 @@ def gen_resident(R, row0=0):
     return synth.big_resident(R, seed=1, T0=T0, DT=DT, row0=row0)
 
 
-def gen_batch(b, R, D=D_PER_STEP, seed=2):
+def gen_batch(b, R, D=D_PER_STEP, seed=2, part=(0, 1)):
     from bmx import synth
-    return synth.big_deltas(D, R, seed=seed, T0=T0, DT=DT, insert_pct=int(os.environ.get("BMX_BENCH_INSERT_PCT", 10)), unique=True, batch=b, drift=DT // 16)   # config 2: 10 % inserts (the override is for experiments)
+    return synth.big_deltas(D, R, seed=seed, part=part, T0=T0, DT=DT, insert_pct=int(os.environ.get("BMX_BENCH_INSERT_PCT", 10)), unique=True, batch=b, drift=DT // 16)   # config 2: 10 % inserts (the override is for experiments)
 
 
 def to_dev(cols, dev):
@@ -254,7 +254,7 @@ def main():
         sg = ShardedGraph(EngineOps(eng, dev), dist, rank, world)
         sg.load_owned_resident(R_PER_GPU, T0=T0, DT=DT)
         R_global = R_PER_GPU * world
-        batches = [to_dev(gen_batch(b, R_global, seed=2 + 1000 * rank), dev) for b in range(nb)]
+        batches = [to_dev(gen_batch(b, R_global, seed=2 + 1000 * rank, part=(rank, world)), dev) for b in range(nb)]   # disjoint rows per originator
         sg.setup_pipeline(D_PER_STEP, partition_on=os.environ.get("BMX_BENCH_PARTITION", "merge"))
         torch.cuda.synchronize()
 
@@ -302,7 +302,7 @@ def main():
         # second pass (every rank, same number of collectives): a few more steps with the per-kernel HIP-event brackets on, for this
         # rank's live k_probe_apply figure. The brackets are event records, i.e. stream bubbles: never part of the timed region.
         npro = min(K, 8)
-        pb = [to_dev(gen_batch(nb + b, R_global, seed=2 + 1000 * rank), dev) for b in range(npro)]
+        pb = [to_dev(gen_batch(nb + b, R_global, seed=2 + 1000 * rank, part=(rank, world)), dev) for b in range(npro)]
         torch.cuda.synchronize()
         eng.profile_enable(True)
         won = []

@@ -70,20 +70,23 @@ def big_resident(R, seed=1, T0=1_000_000, DT=1_000_000, F=1, row0=0):
     return ids, fld, ts, val
 
 
-def big_deltas(D, R, seed=2, T0=1_000_000, DT=1_000_000, F=1, insert_pct=10, hot_pct=0, hot_keys=0, unique=True, batch=0, drift=None):
+def big_deltas(D, R, seed=2, T0=1_000_000, DT=1_000_000, F=1, insert_pct=10, hot_pct=0, hot_keys=0, unique=True, batch=0, drift=None, part=(0, 1)):
     """Config-2/5 shaped delta batch over a resident graph of R rows.
 
     unique=True: hit rows are a stride permutation (no duplicate keys inside the batch), inserts get fresh rows.
     ts ~ U[T0 + batch*drift, T0 + batch*drift + 2*DT); drift defaults to DT/2 per batch (streaming, config 5).
     Config 2 uses drift = DT/16: consecutive unique batches walk disjoint rows (a row is revisited every R/D batches),
-    and the slow drift keeps ~75-78 % of hits winning in steady state, as SURVEY §8(d) specifies."""
+    and the slow drift keeps ~75-78 % of hits winning in steady state, as SURVEY §8(d) specifies.
+    part=(rank, world): with unique=True the originators of one global step walk DISJOINT rows (and insert disjoint new rows), so the
+    union of the world's batches of a step has unique keys too; timestamps still follow `batch`."""
     if drift is None:
         drift = DT // 2
     u = _u(seed + 7919 * batch, D, 3) % np.uint64(100)
     j = np.arange(D, dtype=np.int64)
     if unique:
-        hit_rows = ((j + batch * D) * PERM_PRIME + 7) % R
-        ins_rows = R + batch * D + j
+        gb = batch * int(part[1]) + int(part[0])          # position of this batch in the global stream of unique batches
+        hit_rows = ((j + gb * D) * PERM_PRIME + 7) % R
+        ins_rows = R + gb * D + j
     else:
         hit_rows = (_u(seed + 7919 * batch, D, 4) % np.uint64(R)).astype(np.int64)
         ins_rows = R + (_u(seed + 7919 * batch, D, 5) % np.uint64(max(1, R // 10))).astype(np.int64)
