@@ -11,8 +11,9 @@
  *
  * Data model: one resident row per (node-id hash u64, field hash u32) holding a
  * scalar clock `ts` (int64, 0 <= ts <= 2^53-1: a single-component vector clock {w: ts}) and an integer
- * value `val` (int64, |val| <= 2^53-1: exact in a JS number). Strings, objects and multi-writer clocks
- * stay on the host (GpuCRT's single-op path).
+ * value `val` (int64, |val| <= 2^53-1: exact in a JS number). Rows whose clocks name several writers live in a second kind of
+ * table (bmx_vc_*, "N4" below: up to 8 known writers). Strings, objects and clocks outside those contracts stay on the host
+ * (GpuCRT's single-op path).
  *
  * Reserved key values (never produced by the host hash functions): id 0xFFFFFFFFFFFFFFFF, field 0xFFFFFFFF.
  *
