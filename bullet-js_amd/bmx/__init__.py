@@ -25,7 +25,7 @@ FLAG_INCOMING, FLAG_CURRENT, FLAG_HISTORICAL = 1, 2, 4
 MAX_BATCH = 1 << 24
 
 EXPORTS = [
-    "bmx_create", "bmx_destroy", "bmx_last_error", "bmx_abi_version", "bmx_get_info", "bmx_sync", "bmx_set_stream", "bmx_get_stream", "bmx_seq_signal", "bmx_seq_wait",
+    "bmx_create", "bmx_create_ex", "bmx_destroy", "bmx_last_error", "bmx_abi_version", "bmx_get_info", "bmx_sync", "bmx_set_stream", "bmx_get_stream", "bmx_seq_signal", "bmx_seq_wait",
     "bmx_load_rows", "bmx_merge_batch", "bmx_merge_records", "bmx_get_rows", "bmx_get_row", "bmx_dump_rows", "bmx_row_count", "bmx_reserve",
     "bmx_index_build", "bmx_index_drop", "bmx_index_size", "bmx_scan_range", "bmx_scan_equals", "bmx_scan_count", "bmx_scan_filter",
     "bmx_owner_of", "bmx_partition_by_owner", "bmx_partition_by_owner_slabs", "bmx_timer_start", "bmx_timer_stop", "bmx_profile_enable", "bmx_profile_read",
@@ -77,6 +77,7 @@ def load_library():
     L = C.CDLL(LIB_PATH)
     vp, u64, u32, i64, i32 = C.c_void_p, C.c_uint64, C.c_uint32, C.c_int64, C.c_int
     L.bmx_create.argtypes = [i32, u64, u32, C.POINTER(vp)]; L.bmx_create.restype = i32
+    L.bmx_create_ex.argtypes = [i32, u64, u32, u32, C.POINTER(vp)]; L.bmx_create_ex.restype = i32
     L.bmx_destroy.argtypes = [vp]; L.bmx_destroy.restype = None
     L.bmx_last_error.argtypes = [vp]; L.bmx_last_error.restype = C.c_char_p
     L.bmx_abi_version.argtypes = []; L.bmx_abi_version.restype = i32
@@ -141,10 +142,10 @@ class Engine:
     """One GPU-resident graph shard (a bmx_ctx). Host-array methods are synchronous; *_dev methods take
     device tensors/pointers and only enqueue work on the engine's stream."""
 
-    def __init__(self, capacity_rows, device=0, flags=0):
+    def __init__(self, capacity_rows, device=0, flags=0, load_pct=0):
         self.L = load_library()
         h = C.c_void_p()
-        rc = self.L.bmx_create(int(device), int(capacity_rows), int(flags), C.byref(h))
+        rc = self.L.bmx_create_ex(int(device), int(capacity_rows), int(load_pct), int(flags), C.byref(h))
         if rc != OK:
             raise BmxError(rc, (self.L.bmx_last_error(None) or b"").decode())
         self.h = h

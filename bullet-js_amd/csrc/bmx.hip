@@ -11,6 +11,7 @@
 
 #include "../../include/bmx.h"
 #include "merge_kernels.h"
+#include "bin_kernels.h"
 #include "scan_kernels.h"
 #include "select.h"
 #include "slot.h"
@@ -48,6 +49,7 @@ struct bmx_ctx {
   hipStream_t own_stream = nullptr, stream = nullptr;
   Slot* slots = nullptr;
   uint64_t nslots = 0, capacity_rows = 0;
+  uint32_t load_pct = 50;             // maximum load factor (percent) at capacity_rows: nslots = capacity_rows * 100 / load_pct
   DevScalars* ds = nullptr;
   // per-batch workspace (grown on demand)
   uint32_t ws_cap = 0;
@@ -56,6 +58,10 @@ struct bmx_ctx {
   uint32_t* slot_of = nullptr;
   uint32_t* blk_info = nullptr;       // ws_cap/256 block summaries (second set right behind the first for async compaction)
   unsigned long long* shard_ctr = nullptr;  // CTR_SHARDS * CTR_STRIDE
+  // default merge path (bin_kernels.h): the batch regrouped by bin, tile by tile
+  uint32_t bin_tiles_cap = 0;
+  uint4* bin_stage = nullptr;         // bin_tiles_cap * BK_TILE records of 32 B
+  uint16_t* bin_toff = nullptr;       // bin_tiles_cap * TOFF_STRIDE offsets
   // staging for BMX_MEM_HOST calls
   uint32_t st_cap = 0;
   uint64_t* st_id = nullptr; uint32_t* st_field = nullptr; int64_t* st_ts = nullptr; int64_t* st_val = nullptr;
@@ -87,6 +93,8 @@ struct bmx_ctx {
   bool prof_on = false;
   uint32_t prof_n = 0;
   std::vector<hipEvent_t> prof_ev;    // 4 events per profiled call
+  uint8_t prof_path[64] = {0};        // 1 = the call took the default (bucketed) path: stages are bucket / merge_bins / count+compact
+  bool legacy_default = false;        // BMX_CTX_LEGACY_MERGE: every merge takes the round-1 kernels
   std::string err;
 };
 
@@ -177,6 +185,20 @@ int ensure_workspace(bmx_ctx* ctx, uint64_t n) {
   return BMX_OK;
 }
 
+int ensure_bins(bmx_ctx* ctx, uint64_t n) {
+  const uint32_t tiles = (uint32_t)((n + BK_TILE - 1) / BK_TILE);
+  if (tiles <= ctx->bin_tiles_cap) return BMX_OK;
+  HIPCHK(hipStreamSynchronize(ctx->stream));
+  { int rcj = join_side(ctx, true); if (rcj) return rcj; }
+  const uint32_t cap = std::max<uint32_t>(tiles, std::min<uint32_t>(ctx->bin_tiles_cap * 2, MAX_BATCH / BK_TILE));
+  dev_free(ctx->bin_stage); dev_free(ctx->bin_toff);
+  ctx->bin_tiles_cap = 0;
+  int rc;
+  if ((rc = dev_alloc(ctx, &ctx->bin_stage, (uint64_t)cap * BK_TILE * 2)) || (rc = dev_alloc(ctx, &ctx->bin_toff, (uint64_t)cap * TOFF_STRIDE))) return rc;
+  ctx->bin_tiles_cap = cap;
+  return BMX_OK;
+}
+
 int ensure_staging(bmx_ctx* ctx, uint64_t n) {
   if (n <= ctx->st_cap) return BMX_OK;
   HIPCHK(hipStreamSynchronize(ctx->stream));
@@ -192,14 +214,23 @@ int ensure_staging(bmx_ctx* ctx, uint64_t n) {
   return BMX_OK;
 }
 
+// Slots of a table that holds `capacity_rows` rows at load factor <= load_pct %. 0 = does not fit the 32-bit slot indices the
+// per-delta workspace (slot_of[]) carries: 2^32 slots x 32 B = 137 GB would fit the 288 GB of HBM, so it is refused explicitly.
+uint64_t slots_for(uint64_t capacity_rows, uint32_t load_pct) {
+  if (capacity_rows > (1ull << 40)) return 0;
+  uint64_t nslots = std::max<uint64_t>(4096, (capacity_rows * 100 + load_pct - 1) / load_pct);
+  nslots = (nslots + 3) & ~3ull;
+  return nslots > (1ull << 32) ? 0 : nslots;
+}
+
 // Rehash into a table for `capacity_rows` rows. Synchronous.
 int grow_table(bmx_ctx* ctx, uint64_t capacity_rows) {
   if (capacity_rows <= ctx->capacity_rows) return BMX_OK;
   int rc = join_side(ctx, true);
   if (rc) return rc;
   HIPCHK(hipStreamSynchronize(ctx->stream));
-  uint64_t nslots = std::max<uint64_t>(4096, capacity_rows * 2);
-  nslots = (nslots + 3) & ~3ull;
+  const uint64_t nslots = slots_for(capacity_rows, ctx->load_pct);
+  if (!nslots) return fail(ctx, BMX_ERR_INVALID, "table would need more than 2^32 slots (slot indices are 32-bit): shard the graph over more contexts");
   Slot* fresh = nullptr;
   if ((rc = dev_alloc(ctx, &fresh, nslots))) return rc;
   hipLaunchKernelGGL(k_init_slots, dim3(2048), dim3(256), 0, ctx->stream, fresh, nslots);
@@ -222,7 +253,8 @@ int merge_core(bmx_ctx* ctx, uint64_t n, const uint64_t* id, const uint32_t* fie
   if (n > MAX_BATCH) return fail(ctx, BMX_ERR_INVALID, "batch larger than 2^24 deltas: split it (sequential semantics are preserved)");
   const bool unique = (insert_mode & BMX_MERGE_UNIQUE_KEYS) != 0;
   const bool strict = (insert_mode & BMX_MERGE_STRICT_FLAGS) != 0;
-  insert_mode &= ~(BMX_MERGE_UNIQUE_KEYS | BMX_MERGE_STRICT_FLAGS);
+  const bool legacy = strict || (insert_mode & BMX_MERGE_LEGACY_PATH) != 0 || ctx->legacy_default;
+  insert_mode &= ~(BMX_MERGE_UNIQUE_KEYS | BMX_MERGE_STRICT_FLAGS | BMX_MERGE_LEGACY_PATH);
   if (unique && strict) return fail(ctx, BMX_ERR_INVALID, "BMX_MERGE_STRICT_FLAGS cannot be combined with BMX_MERGE_UNIQUE_KEYS");
   if (insert_mode != BMX_INSERT_REFERENCE && insert_mode != BMX_INSERT_DELTA) return fail(ctx, BMX_ERR_INVALID, "bad insert_mode");
   if (n == 0) {
@@ -243,6 +275,7 @@ int merge_core(bmx_ctx* ctx, uint64_t n, const uint64_t* id, const uint32_t* fie
   }
   rc = ensure_workspace(ctx, n);
   if (rc) return rc;
+  if (!legacy && (rc = ensure_bins(ctx, n))) return rc;
   if (++ctx->epoch > EPOCH_MAX) {  // tags wrap: forget every claim
     hipLaunchKernelGGL(k_sweep_heads, dim3(2048), dim3(256), 0, ctx->stream, ctx->slots, ctx->nslots);
     LAUNCHCHK("k_sweep_heads");
@@ -268,6 +301,26 @@ int merge_core(bmx_ctx* ctx, uint64_t n, const uint64_t* id, const uint32_t* fie
   const uint32_t rblocks = blocks;   // one lane per delta
   hipEvent_t* pe = (ctx->prof_on && ctx->prof_n < PROF_MAX_CALLS) ? &ctx->prof_ev[4 * ctx->prof_n] : nullptr;
   if (pe) HIPCHK(hipEventRecord(pe[0], ctx->stream));
+  if (!legacy) {
+    // default path: bucket the batch, merge every bucket inside one workgroup, count the winners per 256-delta block
+    BinArgs B;
+    B.slots = ctx->slots; B.nslots = ctx->nslots;
+    B.id = id; B.field = field; B.ts = ts; B.val = val; B.recs = recs;
+    B.n = (uint32_t)n; B.epoch = ctx->epoch; B.ntiles = (uint32_t)((n + BK_TILE - 1) / BK_TILE);
+    B.stage = ctx->bin_stage; B.toff = ctx->bin_toff; B.wflag = wflag; B.flags = flags;
+    B.shard_ctr = ctr; B.status = &ctx->ds->status;
+    hipLaunchKernelGGL((k_bucket<AOS>), dim3(B.ntiles), dim3(BK_THREADS), 0, ctx->stream, B);
+    LAUNCHCHK("k_bucket");
+    if (pe) HIPCHK(hipEventRecord(pe[1], ctx->stream));
+    if (insert_mode == BMX_INSERT_REFERENCE) hipLaunchKernelGGL((k_merge_bins<BMX_INSERT_REFERENCE>), dim3(NB), dim3(MB_THREADS), 0, ctx->stream, B);
+    else hipLaunchKernelGGL((k_merge_bins<BMX_INSERT_DELTA>), dim3(NB), dim3(MB_THREADS), 0, ctx->stream, B);
+    LAUNCHCHK("k_merge_bins");
+    if (pe) HIPCHK(hipEventRecord(pe[2], ctx->stream));
+    hipLaunchKernelGGL(k_count_winners, dim3((uint32_t)((n + 4095) / 4096)), dim3(256), 0, ctx->stream, (const uint8_t*)wflag, (uint32_t)n, A.blk_info);
+    LAUNCHCHK("k_count_winners");
+    if (pe) ctx->prof_path[ctx->prof_n] = 1;
+  } else {
+  if (pe) ctx->prof_path[ctx->prof_n] = 0;
   if (strict) {
     hipLaunchKernelGGL((k_probe_link_strict<AOS>), dim3(blocks), dim3(256), 0, ctx->stream, A);
   } else if (insert_mode == BMX_INSERT_REFERENCE) {
@@ -293,6 +346,7 @@ int merge_core(bmx_ctx* ctx, uint64_t n, const uint64_t* id, const uint32_t* fie
   }
   LAUNCHCHK("k_resolve_lists");
   if (pe) HIPCHK(hipEventRecord(pe[2], ctx->stream));
+  }
   // K3: ordered compaction of the winner bytes (on the side stream when asynchronous compaction is on)
   hipStream_t ks = ctx->stream;
   if (ctx->async_compact) {
@@ -495,8 +549,16 @@ const char* bmx_last_error(const bmx_ctx* ctx) { return ctx ? ctx->err.c_str() :
 uint32_t bmx_owner_of(uint64_t id, uint32_t nshards) { return (uint32_t)(((unsigned __int128)owner_hash(id) * nshards) >> 64); }
 
 int bmx_create(int device, uint64_t capacity_rows, uint32_t flags, bmx_ctx** out) {
+  return bmx_create_ex(device, capacity_rows, 0, flags, out);
+}
+
+int bmx_create_ex(int device, uint64_t capacity_rows, uint32_t max_load_pct, uint32_t flags, bmx_ctx** out) {
   if (!out || capacity_rows == 0) return fail(nullptr, BMX_ERR_INVALID, "bmx_create: bad arguments");
   *out = nullptr;
+  if (max_load_pct == 0) max_load_pct = BMX_DEFAULT_LOAD_PCT;
+  if (max_load_pct < 5 || max_load_pct > 90) return fail(nullptr, BMX_ERR_INVALID, "bmx_create_ex: max_load_pct must be 5..90 (0 = default)");
+  if (!slots_for(capacity_rows, max_load_pct))
+    return fail(nullptr, BMX_ERR_INVALID, "bmx_create: table would need more than 2^32 slots (slot indices are 32-bit): shard the graph over more contexts");
   int ndev = 0;
   hipError_t e = hipGetDeviceCount(&ndev);
   if (e != hipSuccess || ndev == 0) return fail(nullptr, BMX_ERR_NO_DEVICE, "no HIP device: this library has no CPU path");
@@ -505,6 +567,7 @@ int bmx_create(int device, uint64_t capacity_rows, uint32_t flags, bmx_ctx** out
   if (!ctx) return fail(nullptr, BMX_ERR_NOMEM, "out of host memory");
   ctx->device = device;
   ctx->capacity_rows = capacity_rows;
+  ctx->load_pct = max_load_pct;
   auto bail = [&](int rc) { std::string m = ctx->err; bmx_destroy(ctx); g_err = m; return rc; };
 #define CR(call) do { hipError_t e2 = (call); if (e2 != hipSuccess) { fail_hip(ctx, e2, #call); return bail(BMX_ERR_HIP); } } while (0)
   CR(hipSetDevice(device));
@@ -512,9 +575,7 @@ int bmx_create(int device, uint64_t capacity_rows, uint32_t flags, bmx_ctx** out
   ctx->stream = ctx->own_stream;
   CR(hipEventCreate(&ctx->ev0));
   CR(hipEventCreate(&ctx->ev1));
-  // load factor <= 0.5 at capacity_rows: expected 1.5 slots per hit, 2.5 per miss, almost always inside one 128-B line
-  uint64_t nslots = std::max<uint64_t>(4096, capacity_rows * 2);
-  nslots = (nslots + 3) & ~3ull;
+  const uint64_t nslots = slots_for(capacity_rows, max_load_pct);
   ctx->nslots = nslots;
   int rc;
   if ((rc = dev_alloc(ctx, &ctx->slots, nslots))) return bail(rc);
@@ -524,6 +585,7 @@ int bmx_create(int device, uint64_t capacity_rows, uint32_t flags, bmx_ctx** out
   if ((rc = dev_alloc(ctx, &ctx->shard_ctr, CTR_SHARDS * CTR_STRIDE))) return bail(rc);
   CR(hipMemsetAsync(ctx->shard_ctr, 0, CTR_SHARDS * CTR_STRIDE * sizeof(unsigned long long), ctx->stream));
   ctx->fixed_capacity = (flags & BMX_CTX_FIXED_CAPACITY) != 0;
+  ctx->legacy_default = (flags & BMX_CTX_LEGACY_MERGE) != 0;
   if (flags & BMX_CTX_ASYNC_COMPACT) {
     ctx->async_compact = true;
     CR(hipStreamCreateWithFlags(&ctx->side, hipStreamNonBlocking));
@@ -551,6 +613,7 @@ void bmx_destroy(bmx_ctx* ctx) {
   for (auto& ix : ctx->indexes) { dev_free(ix.ids); dev_free(ix.v64); dev_free(ix.v32); }
   dev_free(ctx->slots); dev_free(ctx->ds); dev_free(ctx->next); dev_free(ctx->wflag); dev_free(ctx->slot_of); dev_free(ctx->blk_info); dev_free(ctx->shard_ctr);
   dev_free(ctx->st_id); dev_free(ctx->st_field); dev_free(ctx->st_ts); dev_free(ctx->st_val); dev_free(ctx->st_applied); dev_free(ctx->st_flags);
+  dev_free(ctx->bin_stage); dev_free(ctx->bin_toff);
   dev_free(ctx->scan_out); dev_free(ctx->block_counts); dev_free(ctx->part_counts); dev_free(ctx->part_owner); dev_free(ctx->scan_mask); dev_free(ctx->scan_counts);
   for (auto ev : ctx->prof_ev) (void)hipEventDestroy(ev);
   if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
@@ -866,7 +929,9 @@ int bmx_profile_read(bmx_ctx* ctx, float ms_out[3], uint32_t* n_calls) {
     for (int k = 0; k < 3; k++) {
       float ms = 0;
       HIPCHK(hipEventElapsedTime(&ms, ctx->prof_ev[4 * i + k], ctx->prof_ev[4 * i + k + 1]));
-      acc[k] += ms;
+      // default path: events bracket k_bucket | k_merge_bins | count + compaction; reported as [0] main kernel, [1] pre-pass, [2] compaction
+      const int slot = ctx->prof_path[i] ? (k == 0 ? 1 : (k == 1 ? 0 : 2)) : k;
+      acc[slot] += ms;
     }
   for (int k = 0; k < 3; k++) ms_out[k] = ctx->prof_n ? (float)(acc[k] / ctx->prof_n) : 0.f;
   *n_calls = ctx->prof_n;

@@ -64,6 +64,11 @@ extern "C" {
  * no delta is applied optimistically. Cannot be combined with BMX_MERGE_UNIQUE_KEYS. */
 #define BMX_MERGE_STRICT_FLAGS 0x200
 
+/* Optional bit OR-ed into `insert_mode`: take the round-1 kernels (one lane per delta, rows claimed with a global atomic, duplicate
+ * keys resolved by a list pass) instead of the default bucketed path. Same results; kept for A/B measurements and because
+ * BMX_MERGE_STRICT_FLAGS is built on them. */
+#define BMX_MERGE_LEGACY_PATH 0x400
+
 /* per-delta decision flags (bits of `flags[j]`), the booleans of resolve()'s decision record
  * src/bullet-crt.js:174-184. Exact for batches without duplicate keys (stats.n_conflicts == 0); with duplicates they are
  * relative to the state each delta observed, unless BMX_MERGE_STRICT_FLAGS is set (then always exact). */
@@ -104,6 +109,7 @@ typedef struct bmx_info {
 /* bmx_create flags */
 #define BMX_CTX_FIXED_CAPACITY 2u /* never grow: a batch that would exceed capacity_rows fails with BMX_ERR_FULL.
                                      Default: the table is rehashed into one twice as large (synchronous, on device). */
+#define BMX_CTX_LEGACY_MERGE 4u   /* every merge of this context takes the round-1 kernels (see BMX_MERGE_LEGACY_PATH) */
 #define BMX_CTX_ASYNC_COMPACT 1u  /* run the winner compaction of batch b on a second stream, under the probe kernel of
                                      batch b+1 (double-buffered winner bytes). Outputs of a merge call (applied_idx,
                                      n_applied, stats) are then valid only after bmx_sync(), not in stream order. */
@@ -113,6 +119,12 @@ typedef struct bmx_info {
  * src/bullet-query.js:2-7 for the device-resident part of the state (reference state:
  * bullet.store/meta src/bullet.js:28-31). capacity_rows bounds the resident rows. */
 int bmx_create(int device, uint64_t capacity_rows, uint32_t flags, bmx_ctx** out);
+/* Same with the table's maximum load factor (percent, 5..90; 0 = BMX_DEFAULT_LOAD_PCT): the table gets capacity_rows * 100 / max_load_pct
+ * slots of 32 bytes. A 128-byte line is a bucket of four slots, so high load factors stay cheap to probe while the table shrinks
+ * (more of it sits in the 256 MiB Infinity Cache); measured sweep: DESIGN.md §5. Tables that would need more than 2^32 slots
+ * are refused with BMX_ERR_INVALID (slot indices in the per-batch workspace are 32-bit): shard the graph instead. */
+#define BMX_DEFAULT_LOAD_PCT 50
+int bmx_create_ex(int device, uint64_t capacity_rows, uint32_t max_load_pct, uint32_t flags, bmx_ctx** out);
 void bmx_destroy(bmx_ctx* ctx);                     /* reference: Bullet.close() src/bullet.js:288-304 */
 const char* bmx_last_error(const bmx_ctx* ctx);     /* ctx may be NULL for bmx_create failures */
 int bmx_abi_version(void);
