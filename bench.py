@@ -181,7 +181,7 @@ def main():
     # (44M slots, load factor 0.23-0.35): 17M -> 97 us/step, 22M -> 89, 30M -> 95 (probe length vs Infinity-Cache share)
     n_profiled = min(K, 12) + min(K, 8)
     cap = int(os.environ.get("BMX_BENCH_CAP", max(22_000_000, R_PER_GPU + (nb + n_profiled + 3) * D_PER_STEP // 10 + 4 * D_PER_STEP)))
-    eng = bmx.Engine(capacity_rows=cap, device=local_rank, flags=bmx.CTX_ASYNC_COMPACT if os.environ.get("BMX_BENCH_ASYNC", "0") == "1" else 0,
+    eng = bmx.Engine(capacity_rows=cap, device=local_rank, flags=(bmx.CTX_ASYNC_COMPACT if os.environ.get("BMX_BENCH_ASYNC", "0") == "1" else 0) | (bmx.CTX_BUCKETED_MERGE if os.environ.get("BMX_BENCH_BUCKETED", "0") == "1" else 0),
                      load_pct=int(os.environ.get("BMX_BENCH_LOAD_PCT", 0)))
 
     if not sharded:

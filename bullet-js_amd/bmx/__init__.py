@@ -19,8 +19,10 @@ MEM_HOST, MEM_DEVICE = 0, 1
 INSERT_REFERENCE, INSERT_DELTA = 0, 1
 MERGE_UNIQUE_KEYS = 0x100
 MERGE_STRICT_FLAGS = 0x200
+MERGE_BUCKETED = 0x800
 CTX_ASYNC_COMPACT = 1
 CTX_FIXED_CAPACITY = 2
+CTX_BUCKETED_MERGE = 8
 FLAG_INCOMING, FLAG_CURRENT, FLAG_HISTORICAL = 1, 2, 4
 MAX_BATCH = 1 << 24
 
@@ -53,6 +55,9 @@ class Info(C.Structure):
 
 
 DELTA_REC_DTYPE = np.dtype([("id", "<u8"), ("field", "<u4"), ("aux", "<u4"), ("ts", "<i8"), ("val", "<i8")])
+
+# OR-ed into the flags of every Engine this process creates (tests use it to run the same cases on the bucketed merge path)
+DEFAULT_CTX_FLAGS = int(os.environ.get("BMX_CTX_FLAGS", "0"), 0)
 
 _lib = None
 
@@ -145,7 +150,7 @@ class Engine:
     def __init__(self, capacity_rows, device=0, flags=0, load_pct=0):
         self.L = load_library()
         h = C.c_void_p()
-        rc = self.L.bmx_create_ex(int(device), int(capacity_rows), int(load_pct), int(flags), C.byref(h))
+        rc = self.L.bmx_create_ex(int(device), int(capacity_rows), int(load_pct), int(flags) | DEFAULT_CTX_FLAGS, C.byref(h))
         if rc != OK:
             raise BmxError(rc, (self.L.bmx_last_error(None) or b"").decode())
         self.h = h
@@ -300,7 +305,7 @@ class Engine:
         ms = (C.c_float * 3)()
         n = C.c_uint32()
         self._chk(self.L.bmx_profile_read(self.h, ms, C.byref(n)))
-        return {"probe_apply": ms[0], "resolve_lists": ms[1], "compact": ms[2]}, n.value
+        return {"probe_apply": ms[0], "resolve_lists": ms[1], "compact": ms[2]}, n.value   # bucketed path: merge_bins, bucket, count+compact
 
     def timer_start(self):
         self._chk(self.L.bmx_timer_start(self.h))

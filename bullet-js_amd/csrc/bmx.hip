@@ -4,6 +4,7 @@
 #include <algorithm>
 #include <climits>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <new>
 #include <string>
@@ -93,8 +94,8 @@ struct bmx_ctx {
   bool prof_on = false;
   uint32_t prof_n = 0;
   std::vector<hipEvent_t> prof_ev;    // 4 events per profiled call
-  uint8_t prof_path[64] = {0};        // 1 = the call took the default (bucketed) path: stages are bucket / merge_bins / count+compact
-  bool legacy_default = false;        // BMX_CTX_LEGACY_MERGE: every merge takes the round-1 kernels
+  uint8_t prof_path[64] = {0};        // 1 = the call took the bucketed path: stages are bucket / merge_bins / count+compact
+  bool bucketed_default = false;      // BMX_CTX_BUCKETED_MERGE: merges take the bucketed path unless they ask for strict flags / unique keys
   std::string err;
 };
 
@@ -253,8 +254,8 @@ int merge_core(bmx_ctx* ctx, uint64_t n, const uint64_t* id, const uint32_t* fie
   if (n > MAX_BATCH) return fail(ctx, BMX_ERR_INVALID, "batch larger than 2^24 deltas: split it (sequential semantics are preserved)");
   const bool unique = (insert_mode & BMX_MERGE_UNIQUE_KEYS) != 0;
   const bool strict = (insert_mode & BMX_MERGE_STRICT_FLAGS) != 0;
-  const bool legacy = strict || (insert_mode & BMX_MERGE_LEGACY_PATH) != 0 || ctx->legacy_default;
-  insert_mode &= ~(BMX_MERGE_UNIQUE_KEYS | BMX_MERGE_STRICT_FLAGS | BMX_MERGE_LEGACY_PATH);
+  const bool legacy = strict || unique || !((insert_mode & BMX_MERGE_BUCKETED) != 0 || ctx->bucketed_default);   // "legacy" = the one-lane-per-delta kernels
+  insert_mode &= ~(BMX_MERGE_UNIQUE_KEYS | BMX_MERGE_STRICT_FLAGS | BMX_MERGE_BUCKETED);
   if (unique && strict) return fail(ctx, BMX_ERR_INVALID, "BMX_MERGE_STRICT_FLAGS cannot be combined with BMX_MERGE_UNIQUE_KEYS");
   if (insert_mode != BMX_INSERT_REFERENCE && insert_mode != BMX_INSERT_DELTA) return fail(ctx, BMX_ERR_INVALID, "bad insert_mode");
   if (n == 0) {
@@ -302,13 +303,14 @@ int merge_core(bmx_ctx* ctx, uint64_t n, const uint64_t* id, const uint32_t* fie
   hipEvent_t* pe = (ctx->prof_on && ctx->prof_n < PROF_MAX_CALLS) ? &ctx->prof_ev[4 * ctx->prof_n] : nullptr;
   if (pe) HIPCHK(hipEventRecord(pe[0], ctx->stream));
   if (!legacy) {
-    // default path: bucket the batch, merge every bucket inside one workgroup, count the winners per 256-delta block
+    // bucketed path: bucket the batch, merge every bucket inside one workgroup, count the winners per 256-delta block
     BinArgs B;
     B.slots = ctx->slots; B.nslots = ctx->nslots;
     B.id = id; B.field = field; B.ts = ts; B.val = val; B.recs = recs;
     B.n = (uint32_t)n; B.epoch = ctx->epoch; B.ntiles = (uint32_t)((n + BK_TILE - 1) / BK_TILE);
     B.stage = ctx->bin_stage; B.toff = ctx->bin_toff; B.wflag = wflag; B.flags = flags;
     B.shard_ctr = ctr; B.status = &ctx->ds->status;
+    { static const char* dbg_env = getenv("BMX_DEBUG_PHASE"); B.dbg = dbg_env ? (uint32_t)atoi(dbg_env) : 0u; }
     hipLaunchKernelGGL((k_bucket<AOS>), dim3(B.ntiles), dim3(BK_THREADS), 0, ctx->stream, B);
     LAUNCHCHK("k_bucket");
     if (pe) HIPCHK(hipEventRecord(pe[1], ctx->stream));
@@ -585,7 +587,7 @@ int bmx_create_ex(int device, uint64_t capacity_rows, uint32_t max_load_pct, uin
   if ((rc = dev_alloc(ctx, &ctx->shard_ctr, CTR_SHARDS * CTR_STRIDE))) return bail(rc);
   CR(hipMemsetAsync(ctx->shard_ctr, 0, CTR_SHARDS * CTR_STRIDE * sizeof(unsigned long long), ctx->stream));
   ctx->fixed_capacity = (flags & BMX_CTX_FIXED_CAPACITY) != 0;
-  ctx->legacy_default = (flags & BMX_CTX_LEGACY_MERGE) != 0;
+  ctx->bucketed_default = (flags & BMX_CTX_BUCKETED_MERGE) != 0;
   if (flags & BMX_CTX_ASYNC_COMPACT) {
     ctx->async_compact = true;
     CR(hipStreamCreateWithFlags(&ctx->side, hipStreamNonBlocking));
@@ -929,7 +931,7 @@ int bmx_profile_read(bmx_ctx* ctx, float ms_out[3], uint32_t* n_calls) {
     for (int k = 0; k < 3; k++) {
       float ms = 0;
       HIPCHK(hipEventElapsedTime(&ms, ctx->prof_ev[4 * i + k], ctx->prof_ev[4 * i + k + 1]));
-      // default path: events bracket k_bucket | k_merge_bins | count + compaction; reported as [0] main kernel, [1] pre-pass, [2] compaction
+      // bucketed path: events bracket k_bucket | k_merge_bins | count + compaction; reported as [0] main kernel, [1] pre-pass, [2] compaction
       const int slot = ctx->prof_path[i] ? (k == 0 ? 1 : (k == 1 ? 0 : 2)) : k;
       acc[slot] += ms;
     }

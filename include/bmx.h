@@ -64,10 +64,12 @@ extern "C" {
  * no delta is applied optimistically. Cannot be combined with BMX_MERGE_UNIQUE_KEYS. */
 #define BMX_MERGE_STRICT_FLAGS 0x200
 
-/* Optional bit OR-ed into `insert_mode`: take the round-1 kernels (one lane per delta, rows claimed with a global atomic, duplicate
- * keys resolved by a list pass) instead of the default bucketed path. Same results; kept for A/B measurements and because
- * BMX_MERGE_STRICT_FLAGS is built on them. */
-#define BMX_MERGE_LEGACY_PATH 0x400
+/* Optional bit OR-ed into `insert_mode`: take the bucketed path (csrc/bin_kernels.h) instead of the default one-lane-per-delta
+ * kernels: the batch is regrouped by key range, one workgroup owns each range, duplicate keys meet in LDS, and the table sees one
+ * line read and at most one write-back per KEY and no claim atomic. Same results for every batch. Measured slower than the default
+ * on unique-key batches (regrouping moves the batch twice: DESIGN.md §5) and robust where the default degrades: thousands of deltas
+ * on one key cost LDS hops instead of dependent global loads. Ignored with BMX_MERGE_STRICT_FLAGS / BMX_MERGE_UNIQUE_KEYS. */
+#define BMX_MERGE_BUCKETED 0x800
 
 /* per-delta decision flags (bits of `flags[j]`), the booleans of resolve()'s decision record
  * src/bullet-crt.js:174-184. Exact for batches without duplicate keys (stats.n_conflicts == 0); with duplicates they are
@@ -109,7 +111,7 @@ typedef struct bmx_info {
 /* bmx_create flags */
 #define BMX_CTX_FIXED_CAPACITY 2u /* never grow: a batch that would exceed capacity_rows fails with BMX_ERR_FULL.
                                      Default: the table is rehashed into one twice as large (synchronous, on device). */
-#define BMX_CTX_LEGACY_MERGE 4u   /* every merge of this context takes the round-1 kernels (see BMX_MERGE_LEGACY_PATH) */
+#define BMX_CTX_BUCKETED_MERGE 8u /* every merge of this context takes the bucketed path (see BMX_MERGE_BUCKETED) */
 #define BMX_CTX_ASYNC_COMPACT 1u  /* run the winner compaction of batch b on a second stream, under the probe kernel of
                                      batch b+1 (double-buffered winner bytes). Outputs of a merge call (applied_idx,
                                      n_applied, stats) are then valid only after bmx_sync(), not in stream order. */
