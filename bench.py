@@ -1,22 +1,29 @@
 #!/usr/bin/env python3
 """bench.py — CRDT field-merges/s on MI355X (BASELINE.json metric), one JSON line on rank 0.
 
-A "step" is one pass of the merge hot path over one 1M-delta batch:
-  resident graph R = 10M rows per GPU (id = splitmix64(node), 1 field, ts ~ U[T0,T0+DT), val in +-2^31),
-  batch D = 1M deltas: 90 % hit resident rows (unique keys inside the batch), 10 % absent keys (inserts),
-  ts ~ U[T0 + b*DT/16, T0 + b*DT/16 + 2*DT)  (~75-78 % of hits win in steady state; batches walk disjoint rows).
-Inputs and outputs are device-resident when the timed region starts; the timed region is exactly K
-bmx_merge_batch calls (BMX_MEM_DEVICE: probe+apply, conflict resolve, winner compaction) per rank.
+A "step" is one pass of the merge hot path over one 1M-delta batch per GPU:
+  --config 2 (default; configs[1], and configs[3] when launched on N > 1 GPUs)
+      resident graph R = 10M rows per GPU (id = splitmix64(node), 1 field, ts ~ U[T0,T0+DT), val in +-2^31),
+      batch D = 1M deltas: 90 % hit resident rows (unique keys inside the batch), 10 % absent keys (inserts),
+      ts ~ U[T0 + b*DT/16, T0 + b*DT/16 + 2*DT)  (~75-78 % of hits win in steady state; batches walk disjoint rows).
+  --config 5 (configs[4]: streaming sync replay)
+      same graph, 100 batches of 1M deltas per GPU: 30 % of a batch on a hot set of R/1000 keys, 70 % uniform, no inserts,
+      ts ~ U[T0 + b*DT/2, T0 + b*DT/2 + 2*DT); default --warmup 10 --steps 90 = steady state over batches 10..99.
+Inputs and outputs are device-resident when the timed region starts; the timed region is exactly K bmx_merge_batch calls
+(BMX_MEM_DEVICE: probe+apply, conflict resolve, winner compaction) per rank.
 
-N > 1 (one process per GPU, launched by torch.distributed.run): the graph is sharded by node-id hash,
-every rank originates 1M mixed-owner deltas per step; a step = partition by owner + all-to-all (RCCL)
-+ local merge of what arrived. Weak scaling: R and D per GPU are fixed.
+N > 1 (one process per GPU, launched by torch.distributed.run): the graph is sharded by node-id hash, every rank originates
+1M mixed-owner deltas per step; a step = partition by owner + all-to-all (RCCL) + local merge of what arrived. Weak scaling.
 
-Besides the contract fields the line carries
-  roofline     — dominant kernel (k_probe_apply): algorithmic bytes per launch / its average duration,
-                 measured live with HIP events on the engine's stream in a second pass over the same batches;
-  cpu_baseline — the CPU oracle (oracle/bmx_oracle.c, a C port proven equal to the reference on golden
-                 vectors) timed on one host core on a bounded sample of the same workload (rank 0, N=1 only).
+After the timed region (never inside it) the run CHECKS ITSELF: every timed batch's winner list, the row count and an
+order-independent digest of the whole device table are compared with the CPU oracle replaying the same batches; a mismatch
+fails the run. Besides the contract fields the line carries
+  roofline     — dominant kernel (k_probe_apply): algorithmic bytes per launch / its average duration, measured live with
+                 HIP events on the engine's stream in a second pass over fresh batches of the same shape;
+  scan_config3 — configs[2]: equals/range scans over an indexed int32 field at 10M and 100M rows, with the roofline of the
+                 mask kernel (the one read of the value column);
+  cpu_baseline — the CPU oracle (oracle/bmx_oracle.c, proven equal to the reference on golden vectors) timed on one host
+                 core on a bounded sample of the same workload (rank 0, N=1 only).
 """
 import argparse
 import json
@@ -33,9 +40,10 @@ import numpy as np
 import torch
 
 R_PER_GPU = 10_000_000
-D_PER_STEP = int(os.environ.get("BMX_BENCH_DELTAS", 1_000_000))   # BASELINE config 2/4: 1M; the override is for host-bound experiments only
+D_PER_STEP = int(os.environ.get("BMX_BENCH_DELTAS", 1_000_000))   # BASELINE configs: 1M; the override is for host-bound experiments only
 T0, DT = 1_000_000, 1_000_000
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec
+CONFIG = 2             # set by --config
 
 
 def gen_resident(R, row0=0):
@@ -43,9 +51,12 @@ def gen_resident(R, row0=0):
     return synth.big_resident(R, seed=1, T0=T0, DT=DT, row0=row0)
 
 
-def gen_batch(b, R, D=D_PER_STEP, seed=2, part=(0, 1)):
+def gen_batch(b, R, D=None, seed=2, part=(0, 1)):
     from bmx import synth
-    return synth.big_deltas(D, R, seed=seed, part=part, T0=T0, DT=DT, insert_pct=int(os.environ.get("BMX_BENCH_INSERT_PCT", 10)), unique=True, batch=b, drift=DT // 16)   # config 2: 10 % inserts (the override is for experiments)
+    D = D_PER_STEP if D is None else D
+    if CONFIG == 5:    # 30 % of the deltas on R/1000 hot keys, the rest uniform over the graph; streaming drift DT/2 per batch
+        return synth.big_deltas(D, R, seed=seed + 50, part=part, T0=T0, DT=DT, insert_pct=0, hot_pct=30, hot_keys=max(1, R // 1000), unique=False, batch=b, drift=DT // 2)
+    return synth.big_deltas(D, R, seed=seed, part=part, T0=T0, DT=DT, insert_pct=int(os.environ.get("BMX_BENCH_INSERT_PCT", 10)), unique=True, batch=b, drift=DT // 16)
 
 
 def to_dev(cols, dev):
@@ -66,7 +77,7 @@ def cpu_baseline(n_batches=24):
     dt = time.perf_counter() - t0
     o.close()
     out = {"value": n_batches * D_PER_STEP / dt, "unit": "merges/s", "cores": 1, "kind": "port",
-           "sample": "%d x 1M-delta batches of the bench's own stream against the 10M-row resident graph (load excluded; %.1f s of timed CPU work), oracle/bmx_oracle.c, 1 thread" % (n_batches, dt)}
+           "sample": "%d x 1M-delta batches of the bench's own stream (config %d) against the 10M-row resident graph (load excluded; %.1f s of timed CPU work), oracle/bmx_oracle.c, 1 thread" % (n_batches, CONFIG, dt)}
     # extra line: the same port on all host cores, threads owning key shards
     try:
         from oracle.oracle import OracleMT
@@ -101,12 +112,39 @@ def cpu_baseline(n_batches=24):
     return out
 
 
-def scan_bench(bmx, dev, R=10_000_000, reps=20):
-    """Config 3 (extra fields, not the headline): range/equals scans over an indexed int32 field of R nodes.
-    Algorithmic bytes = 4*R (value column) + 8*M (ids out); time = HIP events around `reps` back-to-back scans."""
+def verify_against_oracle(eng, host_batches, winners_dev, n_applied_dev, resident_cols):
+    """Replay the very batches the device merged (warm-up + timed) through the CPU oracle and compare every batch's winner list,
+    the row count and the digest of the whole table. Runs after the timed region; raises SystemExit on any difference."""
+    from oracle.oracle import Oracle, rows_digest
+    t0 = time.perf_counter()
+    o = Oracle()
+    o.load_rows(*resident_cols)
+    n_app = n_applied_dev.cpu().numpy()
+    checked = 0
+    for b, cols in enumerate(host_batches):
+        _, want = o.merge_batch(*cols)
+        got = winners_dev[b][: int(n_app[b])].cpu().numpy().view(np.uint32)
+        if len(got) != len(want) or not np.array_equal(got, want):
+            raise SystemExit("VERIFICATION FAILED: batch %d: device reports %d winners, oracle %d (or different indices)" % (b, len(got), len(want)))
+        checked += len(want)
+    rows = eng.row_count()
+    if rows != len(o):
+        raise SystemExit("VERIFICATION FAILED: %d rows on the device, %d in the oracle" % (rows, len(o)))
+    dg = rows_digest(*eng.dump_rows())
+    if dg != o.digest():
+        raise SystemExit("VERIFICATION FAILED: table digest %x != oracle %x" % (dg, o.digest()))
+    o.close()
+    return {"against": "oracle/bmx_oracle.c replaying the same batches after the timed region", "batches": len(host_batches), "winner_indices_compared": checked,
+            "rows": rows, "table_digest": "%016x" % dg, "ok": True, "seconds": round(time.perf_counter() - t0, 2)}
+
+
+def scan_bench(bmx, dev, R, reps=20):
+    """Config 3: range/equals scans over an indexed int32 field of R nodes. Whole-scan time = HIP events around `reps` back-to-back scans;
+    the mask kernel's own time comes from per-kernel HIP events (bmx_profile_read_scan) in a second pass.
+    Algorithmic bytes: whole scan 4*R (value column) + 8*M (ids out); mask kernel 4*R."""
     from bmx import synth
     fa = synth.fnv1a32("n:age")
-    out = {}
+    out = {"rows": R}
     with bmx.Engine(capacity_rows=R + 1024, device=dev.index or 0) as e:
         for r0 in range(0, R, 10_000_000):          # load in 10M-row pieces: bounded host memory
             m = min(10_000_000, R - r0)
@@ -126,13 +164,23 @@ def scan_bench(bmx, dev, R=10_000_000, reps=20):
                 e.scan_range_dev(fa, lo, hi, out_ids, R, n_out)
             ms = e.timer_stop() / reps
             m = int(n_out.item())
+            e.profile_enable(True)
+            for _ in range(8):
+                e.scan_range_dev(fa, lo, hi, out_ids, R, n_out)
+            kms, _ = e.profile_read_scan()
+            e.profile_enable(False)
             alg = 4.0 * R + 8.0 * m
+            mask_s = kms["scan_mask"] * 1e-3
             out[name] = {"matches": m, "us": round(ms * 1e3, 2), "achieved_GBs": round(alg / (ms * 1e-3) / 1e9, 1), "frac_of_8TBs": round(alg / (ms * 1e-3) / 8e12, 4),
-                         "rows_per_s": round(R / (ms * 1e-3))}
+                         "rows_per_s": round(R / (ms * 1e-3)),
+                         "roofline_mask_kernel": {"bound": "hbm", "kernel": "k_scan_mask", "achieved": round(4.0 * R / mask_s / 1e9, 1) if mask_s > 0 else None, "peak": HBM_PEAK_GBS,
+                                                  "unit": "GB/s", "frac": round(4.0 * R / mask_s / 1e9 / HBM_PEAK_GBS, 4) if mask_s > 0 else None,
+                                                  "kernel_us": {"scan_mask": round(kms["scan_mask"] * 1e3, 2), "offsets_and_emit": round(kms["emit"] * 1e3, 2)}}}
     return out
 
 
 def main():
+    global CONFIG
     # stdout carries exactly ONE JSON line: native libraries (RCCL's version banner) print to fd 1, so fd 1 is pointed
     # at stderr for the whole run and the JSON goes to a private duplicate of the real stdout.
     sys.stdout.flush()
@@ -140,13 +188,19 @@ def main():
     os.dup2(2, 1)
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=None, help="timed steps (default: 20 for config 2, 90 for config 5)")
+    ap.add_argument("--warmup", type=int, default=None, help="untimed warm-up steps (default: 3 for config 2, 10 for config 5)")
+    ap.add_argument("--config", type=int, default=2, choices=[2, 5], help="BASELINE.json configs[1]/[3] (2) or configs[4], streaming hot-key replay (5)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--scan", action="store_true", help="also measure the config-3 index scans (extra fields)")
-    ap.add_argument("--scan-rows", type=int, default=10_000_000, help="rows of the scanned index (100000000 puts the int32 column beyond the 256 MiB Infinity Cache)")
+    ap.add_argument("--no-verify", action="store_true", help="skip the post-run comparison with the CPU oracle")
+    ap.add_argument("--no-scan", action="store_true", help="skip the config-3 index scans (10M and 100M rows)")
+    ap.add_argument("--scan", action="store_true", help="(kept for compatibility: the scans are on by default)")
+    ap.add_argument("--scan-rows", type=str, default="10000000,100000000", help="comma-separated index sizes of the config-3 scans")
     ap.add_argument("--force-sharded", action="store_true", help="run the N>1 code path (partition + all-to-all + merge) even with one rank: rehearsal only")
     args = ap.parse_args()
+    CONFIG = args.config
+    K = args.steps if args.steps is not None else (90 if CONFIG == 5 else 20)
+    W = args.warmup if args.warmup is not None else (10 if CONFIG == 5 else 3)
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -174,28 +228,29 @@ def main():
         else:
             dist.init_process_group(backend="nccl", rank=rank, world_size=world, device_id=dev)
 
-    K, W = args.steps, args.warmup
     nb = K + W
-    # every step inserts 10 % new rows: size the table for all of them (load factor stays <= 0.5)
-    # every merged batch inserts ~10 % new rows. Measured sweet spot for 10M..15M resident rows: capacity 22M rows
-    # (44M slots, load factor 0.23-0.35): 17M -> 97 us/step, 22M -> 89, 30M -> 95 (probe length vs Infinity-Cache share)
+    ins_per_step = 0 if CONFIG == 5 else D_PER_STEP // 10
+    # Table size. Measured (profiles/r02_paths_and_load_factor.json): with 10M..15M resident rows the merge is fastest on a table of
+    # ~44M slots (load factor 0.23-0.35); higher load factors lengthen the probe chains faster than the smaller table helps.
     n_profiled = min(K, 12) + min(K, 8)
-    cap = int(os.environ.get("BMX_BENCH_CAP", max(22_000_000, R_PER_GPU + (nb + n_profiled + 3) * D_PER_STEP // 10 + 4 * D_PER_STEP)))
-    eng = bmx.Engine(capacity_rows=cap, device=local_rank, flags=(bmx.CTX_ASYNC_COMPACT if os.environ.get("BMX_BENCH_ASYNC", "0") == "1" else 0) | (bmx.CTX_BUCKETED_MERGE if os.environ.get("BMX_BENCH_BUCKETED", "0") == "1" else 0),
+    cap = int(os.environ.get("BMX_BENCH_CAP", max(22_000_000, R_PER_GPU + (nb + n_profiled + 3) * ins_per_step + 4 * D_PER_STEP)))
+    eng = bmx.Engine(capacity_rows=cap, device=local_rank, flags=(bmx.CTX_BUCKETED_MERGE if os.environ.get("BMX_BENCH_BUCKETED", "0") == "1" else 0),
                      load_pct=int(os.environ.get("BMX_BENCH_LOAD_PCT", 0)))
+    main_kernel = "k_merge_bins" if os.environ.get("BMX_BENCH_BUCKETED", "0") == "1" else "k_probe_apply"
+    verified = None
 
     if not sharded:
         rid = gen_resident(R_PER_GPU)
         eng.load_rows(*rid)
-        del rid
-        batches = [to_dev(gen_batch(b, R_PER_GPU), dev) for b in range(nb)]
-        applied = torch.zeros(D_PER_STEP, dtype=torch.int32, device=dev)
-        n_applied = torch.zeros(nb, dtype=torch.int64, device=dev)
+        host_batches = [gen_batch(b, R_PER_GPU) for b in range(nb)]
+        batches = [to_dev(hb, dev) for hb in host_batches]
+        applied = torch.zeros((nb, D_PER_STEP), dtype=torch.int32, device=dev)     # every batch keeps its own winner list: compared after the run
+        n_applied = torch.zeros(nb + 1, dtype=torch.int64, device=dev)
         torch.cuda.synchronize()
 
         def step(b):
             i, f, t, v = batches[b]
-            eng.merge_batch_dev(D_PER_STEP, i, f, t, v, bmx.INSERT_REFERENCE, applied=applied, n_applied=n_applied[b:b + 1])
+            eng.merge_batch_dev(D_PER_STEP, i, f, t, v, bmx.INSERT_REFERENCE, applied=applied[b], n_applied=n_applied[b:b + 1])
 
         for b in range(W):
             step(b)
@@ -208,55 +263,65 @@ def main():
         eng.sync(); torch.cuda.synchronize()
         wall = time.perf_counter() - t0
         elapsed = wall
-        winners = n_applied[W:].cpu().numpy()
+        winners = n_applied[W:nb].cpu().numpy()
+
+        if not args.no_verify:
+            verified = verify_against_oracle(eng, host_batches, applied, n_applied[:nb], rid)
+        del rid, host_batches
 
         # second pass over fresh batches of the same shape: per-kernel HIP-event timing (live roofline figure)
         pbatches = [to_dev(gen_batch(nb + b, R_PER_GPU), dev) for b in range(min(K, 12))]
         torch.cuda.synchronize()
         eng.profile_enable(True)
         for (i, f, t, v) in pbatches:
-            eng.merge_batch_dev(D_PER_STEP, i, f, t, v, bmx.INSERT_REFERENCE, applied=applied, n_applied=n_applied[0:1])
+            eng.merge_batch_dev(D_PER_STEP, i, f, t, v, bmx.INSERT_REFERENCE, applied=applied[0], n_applied=n_applied[nb:nb + 1])
         stage_ms, ncalls = eng.profile_read()
-        # same pass once more in the opt-in mode where the CALLER guarantees unique keys (no claim atomic, no resolve pass)
-        ubatches = [to_dev(gen_batch(nb + 40 + b, R_PER_GPU), dev) for b in range(min(K, 8))]
-        torch.cuda.synchronize()
-        eng.profile_enable(True)
-        eng.sync(); eng.timer_start()
-        for (i, f, t, v) in ubatches:
-            eng.merge_batch_dev(D_PER_STEP, i, f, t, v, bmx.INSERT_REFERENCE | bmx.MERGE_UNIQUE_KEYS, applied=applied, n_applied=n_applied[0:1])
-        ums = eng.timer_stop() / len(ubatches)
-        ustage_ms, _ = eng.profile_read()
+        extra = {}
+        if CONFIG == 2:
+            # same pass once more in the opt-in mode where the CALLER guarantees unique keys (no claim atomic, no resolve pass)
+            ubatches = [to_dev(gen_batch(nb + 40 + b, R_PER_GPU), dev) for b in range(min(K, 8))]
+            torch.cuda.synchronize()
+            eng.profile_enable(True)
+            eng.sync(); eng.timer_start()
+            for (i, f, t, v) in ubatches:
+                eng.merge_batch_dev(D_PER_STEP, i, f, t, v, bmx.INSERT_REFERENCE | bmx.MERGE_UNIQUE_KEYS, applied=applied[0], n_applied=n_applied[nb:nb + 1])
+            ums = eng.timer_stop() / len(ubatches)
+            ustage_ms, _ = eng.profile_read()
+            extra["unique_keys_mode"] = {"note": "opt-in BMX_MERGE_UNIQUE_KEYS (caller guarantees no duplicate keys in the batch); not the headline",
+                                         "ms_per_step_with_event_brackets": round(ums, 5), "kernel_ms": {k: round(v, 5) for k, v in ustage_ms.items()}}
         eng.profile_enable(False)
         wavg = float(winners.mean()) if len(winners) else 0.0
-        # algorithmic bytes of one k_probe_apply launch: delta read 28*D + resident row read 28*D
+        # algorithmic bytes of one launch of the dominant kernel: delta read 28*D + resident row read 28*D
         # + (ts,val) store of the winners 16*W. (The 4*W index write belongs to the compaction launches.)
         alg_bytes = 56.0 * D_PER_STEP + 16.0 * wavg
         probe_s = stage_ms["probe_apply"] * 1e-3
         achieved = alg_bytes / probe_s / 1e9 if probe_s > 0 else 0.0
         traffic = None
         tpath = os.path.join(ROOT, "profiles", "traffic_probe_apply.json")
-        if os.path.exists(tpath):  # HBM bytes per launch from a committed rocprofv3 --pmc run of this same command
+        if os.path.exists(tpath) and CONFIG == 2 and main_kernel == "k_probe_apply":  # HBM bytes per launch from a committed rocprofv3 --pmc run of this same command
             try:
                 traffic = json.load(open(tpath)).get("bytes_per_launch")
             except Exception:
                 traffic = None
-        roofline = {"bound": "hbm", "kernel": "k_probe_apply", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+        roofline = {"bound": "hbm", "kernel": main_kernel, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                     "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "algorithmic_bytes_per_launch": alg_bytes,
                     "kernel_ms": {k: round(v, 5) for k, v in stage_ms.items()}, "launches_averaged": ncalls,
                     "whole_merge_achieved_GBs": round((56.0 * D_PER_STEP + 20.0 * wavg) / (elapsed / K) / 1e9, 1)}
         total_units = K * D_PER_STEP
-        extra = {"event_ms_per_step": round(ev_ms / K, 5), "winners_per_step": round(wavg, 1),
-                 "unique_keys_mode": {"note": "opt-in BMX_MERGE_UNIQUE_KEYS (caller guarantees no duplicate keys in the batch); not the headline",
-                                      "ms_per_step_with_event_brackets": round(ums, 5), "kernel_ms": {k: round(v, 5) for k, v in ustage_ms.items()}}}
-        cfg = {"workload": "config 2: 10M-row resident graph on 1 MI355X, 1M-delta batch merge (90% hits / 10% inserts, unique keys in batch)",
-               "resident_rows_per_gpu": R_PER_GPU, "deltas_per_step_per_gpu": D_PER_STEP, "insert_mode": "reference", "sharding": "none"}
+        extra.update({"event_ms_per_step": round(ev_ms / K, 5), "winners_per_step": round(wavg, 1)})
+        if CONFIG == 5:
+            cfg = {"workload": "config 5: streaming sync replay on 1 MI355X, %d x 1M-delta batches (30%% of a batch on R/1000 = %d hot keys, 70%% uniform), steady state over batches %d..%d" %
+                   (nb, R_PER_GPU // 1000, W, nb - 1), "resident_rows_per_gpu": R_PER_GPU, "deltas_per_step_per_gpu": D_PER_STEP, "insert_mode": "reference", "sharding": "none"}
+        else:
+            cfg = {"workload": "config 2: 10M-row resident graph on 1 MI355X, 1M-delta batch merge (90% hits / 10% inserts, unique keys in batch)",
+                   "resident_rows_per_gpu": R_PER_GPU, "deltas_per_step_per_gpu": D_PER_STEP, "insert_mode": "reference", "sharding": "none"}
     else:
         from bmx.sharded import ShardedGraph, EngineOps
         sg = ShardedGraph(EngineOps(eng, dev), dist, rank, world)
         sg.load_owned_resident(R_PER_GPU, T0=T0, DT=DT)
         R_global = R_PER_GPU * world
-        batches = [to_dev(gen_batch(b, R_global, seed=2 + 1000 * rank, part=(rank, world)), dev) for b in range(nb)]   # disjoint rows per originator
-        sg.setup_pipeline(D_PER_STEP, partition_on=os.environ.get("BMX_BENCH_PARTITION", "merge"))
+        batches = [to_dev(gen_batch(b, R_global, seed=2 + 1000 * rank, part=(rank, world)), dev) for b in range(nb)]   # config 2: disjoint rows per originator
+        sg.setup_pipeline(D_PER_STEP, partition_on=os.environ.get("BMX_BENCH_PARTITION", "merge"), slack=1.25 if CONFIG == 5 else 1.03)
         torch.cuda.synchronize()
 
         def run(lo, hi):
@@ -300,6 +365,27 @@ def main():
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed = float(tmax.item())
         total_units = K * D_PER_STEP * world
+        if not args.no_verify and world * nb <= 256:
+            # every rank replays, through the CPU oracle, the deltas of ALL originators that it owns (same generator, same order:
+            # step by step, originators in rank order) and compares its shard's row count and digest
+            from oracle.oracle import Oracle, rows_digest
+            from bmx import synth
+            tv = time.perf_counter()
+            o = Oracle()
+            o.load_rows(*sg.owned_resident_host(R_PER_GPU, T0=T0, DT=DT))
+            for b in range(nb):
+                for src in range(world):
+                    cols = gen_batch(b, R_global, seed=2 + 1000 * src, part=(src, world))
+                    mine = synth.owner_of_np(cols[0], world) == rank
+                    o.merge_batch(*[c[mine] for c in cols])
+            ok = eng.row_count() == len(o) and rows_digest(*eng.dump_rows()) == o.digest()
+            okt = torch.tensor([1 if ok else 0], dtype=torch.int64, device=dev)
+            dist.all_reduce(okt, op=dist.ReduceOp.MIN)
+            if int(okt.item()) != 1:
+                raise SystemExit("VERIFICATION FAILED: a shard's rows differ from the oracle replay (rank %d: %s)" % (rank, "ok" if ok else "MISMATCH"))
+            verified = {"against": "oracle/bmx_oracle.c: every rank replays the deltas it owns (all originators, step order) and compares its shard",
+                        "batches": nb * world, "rows_this_rank": len(o), "ok": True, "seconds": round(time.perf_counter() - tv, 2)}
+            o.close()
         # second pass (every rank, same number of collectives): a few more steps with the per-kernel HIP-event brackets on, for this
         # rank's live k_probe_apply figure. The brackets are event records, i.e. stream bubbles: never part of the timed region.
         npro = min(K, 8)
@@ -317,24 +403,26 @@ def main():
         alg_bytes = 56.0 * D_PER_STEP + 16.0 * wavg         # same accounting as the N=1 line; padding records move no row bytes
         probe_s = stage_ms["probe_apply"] * 1e-3
         achieved = alg_bytes / probe_s / 1e9 if probe_s > 0 else 0.0
-        roofline = {"bound": "hbm", "kernel": "k_probe_apply", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+        roofline = {"bound": "hbm", "kernel": main_kernel, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                     "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None, "algorithmic_bytes_per_launch": alg_bytes,
                     "kernel_ms": {k: round(v, 5) for k, v in stage_ms.items()}, "launches_averaged": ncalls,
                     "note": "rank 0, launches without a concurrent exchange (second pass); HBM traffic counters are collected on the N=1 run"}
         extra = {"host_enqueue_ms_per_step": round(t_enq / K * 1e3, 4), "exchange": dict(sg.stats(), mode="fixed slabs of %d records per ordered pair, partition+all-to-all of batch b+1 overlapped with merge of batch b" % sg.slab)}
-        cfg = {"workload": "config 4 shape: %dM-row graph id-hash sharded over %d MI355X, %dM mixed-owner deltas per step routed by RCCL all-to-all" %
-               (R_global // 1_000_000, world, world * D_PER_STEP // 1_000_000),
+        shape = ("config 5 shape: streaming replay with 30%% of every batch on %d global hot keys" % (R_global // 1000)) if CONFIG == 5 else "config 4 shape"
+        cfg = {"workload": "%s: %dM-row graph id-hash sharded over %d MI355X, %dM mixed-shard deltas per step routed by RCCL all-to-all" %
+               (shape, R_global // 1_000_000, world, world * D_PER_STEP // 1_000_000),
                "resident_rows_per_gpu": R_PER_GPU, "deltas_per_step_per_gpu": D_PER_STEP, "insert_mode": "reference", "sharding": "owner = hash(node id) mod N"}
 
     out = None
     if rank == 0:
         out = {"metric": "CRDT field-merges/s", "value": total_units / elapsed, "unit": "merges/s", "n_gpus": world, "steps": K, "warmup": W,
                "ms_per_step": elapsed / K * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "int64",
-               "data": "synthetic", "config": cfg, "roofline": roofline}
+               "data": "synthetic", "config": cfg, "roofline": roofline, "verified": verified}
         out.update(extra)
-        if not sharded and args.scan:
-            out["scan_config3"] = scan_bench(bmx, dev, R=args.scan_rows)
-            out["scan_config3"]["rows"] = args.scan_rows
+        if not sharded and not args.no_scan:
+            out["scan_config3"] = {}
+            for rs in [int(x) for x in args.scan_rows.split(",") if x]:
+                out["scan_config3"]["%dM" % (rs // 1_000_000)] = scan_bench(bmx, dev, R=rs)
         if not sharded and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline()
         else:

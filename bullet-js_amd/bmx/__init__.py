@@ -14,7 +14,7 @@ _PKG = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 LIB_PATH = os.environ.get("BMX_LIB_PATH") or os.path.join(_PKG, "libbmx.so")   # the override exists for A/B measurements of two builds
 
 OK = 0
-ERR_INVALID, ERR_HIP, ERR_FULL, ERR_NOMEM, ERR_RANGE, ERR_INTERNAL, ERR_NO_DEVICE, ERR_NO_INDEX = -1, -2, -3, -4, -5, -6, -7, -8
+ERR_INVALID, ERR_HIP, ERR_FULL, ERR_NOMEM, ERR_RANGE, ERR_INTERNAL, ERR_NO_DEVICE, ERR_NO_INDEX, ERR_OVERFLOW = -1, -2, -3, -4, -5, -6, -7, -8, -9
 MEM_HOST, MEM_DEVICE = 0, 1
 INSERT_REFERENCE, INSERT_DELTA = 0, 1
 MERGE_UNIQUE_KEYS = 0x100
@@ -30,7 +30,7 @@ EXPORTS = [
     "bmx_create", "bmx_create_ex", "bmx_destroy", "bmx_last_error", "bmx_abi_version", "bmx_get_info", "bmx_sync", "bmx_set_stream", "bmx_get_stream", "bmx_seq_signal", "bmx_seq_wait",
     "bmx_load_rows", "bmx_merge_batch", "bmx_merge_records", "bmx_get_rows", "bmx_get_row", "bmx_dump_rows", "bmx_row_count", "bmx_reserve",
     "bmx_index_build", "bmx_index_drop", "bmx_index_size", "bmx_scan_range", "bmx_scan_equals", "bmx_scan_count", "bmx_scan_filter",
-    "bmx_owner_of", "bmx_partition_by_owner", "bmx_partition_by_owner_slabs", "bmx_timer_start", "bmx_timer_stop", "bmx_profile_enable", "bmx_profile_read",
+    "bmx_owner_of", "bmx_partition_by_owner", "bmx_partition_by_owner_slabs", "bmx_timer_start", "bmx_timer_stop", "bmx_profile_enable", "bmx_profile_read", "bmx_profile_read_scan",
     "bmx_vc_create", "bmx_vc_destroy", "bmx_vc_last_error", "bmx_vc_load_rows", "bmx_vc_merge_batch", "bmx_vc_get_rows", "bmx_vc_row_count", "bmx_vc_merge_batch_dev", "bmx_vc_set_stream", "bmx_vc_sync",
 ]
 
@@ -114,6 +114,7 @@ def load_library():
     L.bmx_timer_stop.argtypes = [vp, C.POINTER(C.c_float)]; L.bmx_timer_stop.restype = i32
     L.bmx_profile_enable.argtypes = [vp, i32]; L.bmx_profile_enable.restype = i32
     L.bmx_profile_read.argtypes = [vp, C.POINTER(C.c_float), C.POINTER(u32)]; L.bmx_profile_read.restype = i32
+    L.bmx_profile_read_scan.argtypes = [vp, C.POINTER(C.c_float), C.POINTER(u32)]; L.bmx_profile_read_scan.restype = i32
     L.bmx_vc_create.argtypes = [i32, u64, u32, u32, C.POINTER(vp)]; L.bmx_vc_create.restype = i32
     L.bmx_vc_destroy.argtypes = [vp]; L.bmx_vc_destroy.restype = None
     L.bmx_vc_last_error.argtypes = [vp]; L.bmx_vc_last_error.restype = C.c_char_p
@@ -306,6 +307,13 @@ class Engine:
         n = C.c_uint32()
         self._chk(self.L.bmx_profile_read(self.h, ms, C.byref(n)))
         return {"probe_apply": ms[0], "resolve_lists": ms[1], "compact": ms[2]}, n.value   # bucketed path: merge_bins, bucket, count+compact
+
+    def profile_read_scan(self):
+        """-> (dict stage -> average ms per scan call, number of calls)"""
+        ms = (C.c_float * 2)()
+        n = C.c_uint32()
+        self._chk(self.L.bmx_profile_read_scan(self.h, ms, C.byref(n)))
+        return {"scan_mask": ms[0], "emit": ms[1]}, n.value
 
     def timer_start(self):
         self._chk(self.L.bmx_timer_start(self.h))

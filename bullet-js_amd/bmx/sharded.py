@@ -81,6 +81,8 @@ class EngineOps:
         self.e.sync()
         if self.comm is not None:
             self.comm.synchronize()
+        if self.pe is not None:
+            self.pe.sync()                             # the partition engine's sticky status (slab overflow)
         self.main.synchronize()
 
     # stream plumbing for the pipelined mode: the communication stream becomes torch's CURRENT stream once
@@ -150,8 +152,8 @@ class ShardedGraph:
             out.append(rows[synth.owner_of_np(ids, self.world) == self.rank])
         return np.concatenate(out) if out else np.zeros(0, np.int64)
 
-    def load_owned_resident(self, R_per_gpu, T0=1_000_000, DT=1_000_000, seed=1):
-        """Load this rank's part of a global graph of R_per_gpu * world rows (same rows as synth.big_resident)."""
+    def owned_resident_host(self, R_per_gpu, T0=1_000_000, DT=1_000_000, seed=1):
+        """This rank's part of a global graph of R_per_gpu * world rows (same rows as synth.big_resident), as host columns."""
         R_global = R_per_gpu * self.world
         rows = self.owned_rows(R_global)
         ids, fld = synth.rows_to_keys(rows)
@@ -164,8 +166,13 @@ class ShardedGraph:
             u2 = synth.splitmix64_np(i * np.uint64(0x9E3779B97F4A7C15) + base2)
         ts = (T0 + (u1 % np.uint64(DT))).astype(np.int64)
         val = (u2 % np.uint64(1 << 32)).astype(np.int64) - (1 << 31)
-        self.ops.load_rows(ids, fld, ts, val)
-        return len(rows)
+        return ids, fld, ts, val
+
+    def load_owned_resident(self, R_per_gpu, T0=1_000_000, DT=1_000_000, seed=1):
+        """Load this rank's part of the global graph."""
+        cols = self.owned_resident_host(R_per_gpu, T0=T0, DT=DT, seed=seed)
+        self.ops.load_rows(*cols)
+        return len(cols[0])
 
     def merge_step(self, n, id, field, ts, val):
         """Route this rank's n deltas to their owners and merge what arrives here. Returns the number received."""
@@ -276,9 +283,17 @@ class ShardedGraph:
         return p
 
     def overflowed(self):
-        """True if any slab of any in-flight buffer was too small for what its origin had to send (host sync)."""
-        self.ops.sync()
-        return any(int(p["counts"].max().item()) > self.slab for p in self._pipe if p["used"])
+        """True if a slab of ANY batch routed so far was too small for what its origin had to send (host sync). The partition kernel
+        raises a sticky error on its context when it drops records, so an overflow of an earlier batch whose counts have been
+        overwritten since is still reported."""
+        from . import BmxError, ERR_OVERFLOW
+        try:
+            self.ops.sync()
+        except BmxError as e:
+            if e.code != ERR_OVERFLOW:
+                raise
+            self._overflowed = True
+        return getattr(self, "_overflowed", False) or any(int(p["counts"].max().item()) > self.slab for p in self._pipe if p["used"])
 
     def last_applied(self):
         """(indices into the received batch, received records) of the last step's winners."""

@@ -94,6 +94,8 @@ struct bmx_ctx {
   bool prof_on = false;
   uint32_t prof_n = 0;
   std::vector<hipEvent_t> prof_ev;    // 4 events per profiled call
+  std::vector<hipEvent_t> scan_ev;    // 3 events per profiled scan call (before the mask pass, after it, after the emit pass)
+  uint32_t scan_prof_n = 0;
   uint8_t prof_path[64] = {0};        // 1 = the call took the bucketed path: stages are bucket / merge_bins / count+compact
   bool bucketed_default = false;      // BMX_CTX_BUCKETED_MERGE: merges take the bucketed path unless they ask for strict flags / unique keys
   std::string err;
@@ -156,6 +158,7 @@ int check_status(bmx_ctx* ctx) {
   HIPCHK(hipMemsetAsync(&ctx->ds->status, 0, sizeof(uint32_t), ctx->stream));
   if (st & ST_SPIN) return fail(ctx, BMX_ERR_INTERNAL, "device protocol fault: bounded spin expired");
   if (st & ST_FULL) return fail(ctx, BMX_ERR_FULL, "resident table is full");
+  if (st & ST_SLAB) return fail(ctx, BMX_ERR_OVERFLOW, "an exchange slab was too small for the records routed to one shard: records were dropped, re-route the batch with bmx_partition_by_owner");
   return fail(ctx, BMX_ERR_RANGE, "delta out of domain: reserved key, ts outside [0, 2^53-1] or |val| > 2^53-1");
 }
 
@@ -495,10 +498,13 @@ int run_scan(bmx_ctx* ctx, const Pred& P, const Index* ix, uint64_t* out_ids, ui
   if ((rc = ensure_scan_scratch(ctx, std::max<uint64_t>(ix->n, 1)))) return rc;
   unsigned long long* d_n = host ? &ctx->ds->n_out : reinterpret_cast<unsigned long long*>(n_out);
   const uint32_t nb = (uint32_t)((std::max<uint64_t>(ix->n, 1) + SCAN_BLOCK_ELEMS - 1) / SCAN_BLOCK_ELEMS);
+  hipEvent_t* se = (ctx->prof_on && ctx->scan_prof_n < PROF_MAX_CALLS && !ctx->scan_ev.empty()) ? &ctx->scan_ev[3 * ctx->scan_prof_n] : nullptr;
+  if (se) HIPCHK(hipEventRecord(se[0], ctx->stream));
   if (d_out) {
     // pass 1: one read of the column -> match mask + block counts; pass 2: ids from the mask
     hipLaunchKernelGGL((k_scan_mask<Pred, true>), dim3(nb), dim3(SEL_THREADS), 0, ctx->stream, P, ix->n, ctx->scan_mask, ctx->scan_counts);
     LAUNCHCHK("k_scan_mask");
+    if (se) HIPCHK(hipEventRecord(se[1], ctx->stream));
     const bool scanned = nb > 2048;   // many blocks: one small launch turns the counts into offsets
     if (scanned) {
       hipLaunchKernelGGL(k_scan_offsets, dim3(1), dim3(OFFS_THREADS), 0, ctx->stream, ctx->scan_counts, nb);
@@ -511,9 +517,13 @@ int run_scan(bmx_ctx* ctx, const Pred& P, const Index* ix, uint64_t* out_ids, ui
   } else if (d_n) {
     hipLaunchKernelGGL((k_scan_mask<Pred, false>), dim3(nb), dim3(SEL_THREADS), 0, ctx->stream, P, ix->n, ctx->scan_mask, ctx->scan_counts);
     LAUNCHCHK("k_scan_mask(count)");
+    if (se) HIPCHK(hipEventRecord(se[1], ctx->stream));
     hipLaunchKernelGGL(k_sum_counts, dim3(1), dim3(SEL_THREADS), 0, ctx->stream, ctx->scan_counts, nb, d_n);
     LAUNCHCHK("k_sum_counts");
+  } else if (se) {
+    HIPCHK(hipEventRecord(se[1], ctx->stream));
   }
+  if (se) { HIPCHK(hipEventRecord(se[2], ctx->stream)); ctx->scan_prof_n++; }
   if (host) {
     unsigned long long m = 0;
     HIPCHK(hipMemcpyAsync(&m, &ctx->ds->n_out, sizeof(m), hipMemcpyDeviceToHost, ctx->stream));
@@ -618,6 +628,7 @@ void bmx_destroy(bmx_ctx* ctx) {
   dev_free(ctx->bin_stage); dev_free(ctx->bin_toff);
   dev_free(ctx->scan_out); dev_free(ctx->block_counts); dev_free(ctx->part_counts); dev_free(ctx->part_owner); dev_free(ctx->scan_mask); dev_free(ctx->scan_counts);
   for (auto ev : ctx->prof_ev) (void)hipEventDestroy(ev);
+  for (auto ev : ctx->scan_ev) (void)hipEventDestroy(ev);
   if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
   if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);
   if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
@@ -878,7 +889,7 @@ static int partition_impl(bmx_ctx* ctx, uint64_t n, const uint64_t* id, const ui
   hipLaunchKernelGGL(k_part_count, dim3(PART_BLOCKS), dim3(256), 0, ctx->stream, id, (uint32_t)n, nshards, per_block, ctx->part_counts, ctx->part_owner);
   LAUNCHCHK("k_part_count");
   hipLaunchKernelGGL(k_part_scatter, dim3(PART_BLOCKS), dim3(256), 0, ctx->stream, id, field, ts, val, (const uint8_t*)ctx->part_owner, (uint32_t)n, nshards, per_block, ctx->part_counts,
-                     recs_out, reinterpret_cast<unsigned long long*>(counts_out_dev), (uint32_t)slab);
+                     recs_out, reinterpret_cast<unsigned long long*>(counts_out_dev), (uint32_t)slab, &ctx->ds->status);
   LAUNCHCHK("k_part_scatter");
   return BMX_OK;
 }
@@ -915,9 +926,12 @@ int bmx_profile_enable(bmx_ctx* ctx, int on) {
   if (on && ctx->prof_ev.empty()) {
     ctx->prof_ev.resize(4 * PROF_MAX_CALLS, nullptr);
     for (auto& ev : ctx->prof_ev) HIPCHK(hipEventCreate(&ev));
+    ctx->scan_ev.resize(3 * PROF_MAX_CALLS, nullptr);
+    for (auto& ev : ctx->scan_ev) HIPCHK(hipEventCreate(&ev));
   }
   ctx->prof_on = on != 0;
   ctx->prof_n = 0;
+  ctx->scan_prof_n = 0;
   return BMX_OK;
 }
 
@@ -937,6 +951,22 @@ int bmx_profile_read(bmx_ctx* ctx, float ms_out[3], uint32_t* n_calls) {
     }
   for (int k = 0; k < 3; k++) ms_out[k] = ctx->prof_n ? (float)(acc[k] / ctx->prof_n) : 0.f;
   *n_calls = ctx->prof_n;
+  return BMX_OK;
+}
+
+int bmx_profile_read_scan(bmx_ctx* ctx, float ms_out[2], uint32_t* n_calls) {
+  if (!ctx || !ms_out || !n_calls) return fail(ctx, BMX_ERR_INVALID, "bad arguments");
+  HIPCHK(hipSetDevice(ctx->device));
+  HIPCHK(hipStreamSynchronize(ctx->stream));
+  double acc[2] = {0, 0};
+  for (uint32_t i = 0; i < ctx->scan_prof_n; i++)
+    for (int k = 0; k < 2; k++) {
+      float ms = 0;
+      HIPCHK(hipEventElapsedTime(&ms, ctx->scan_ev[3 * i + k], ctx->scan_ev[3 * i + k + 1]));
+      acc[k] += ms;
+    }
+  for (int k = 0; k < 2; k++) ms_out[k] = ctx->scan_prof_n ? (float)(acc[k] / ctx->scan_prof_n) : 0.f;
+  *n_calls = ctx->scan_prof_n;
   return BMX_OK;
 }
 

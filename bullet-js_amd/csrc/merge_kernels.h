@@ -587,7 +587,7 @@ __global__ __launch_bounds__(256) void k_part_count(const uint64_t* id, uint32_t
 // are read with computed addresses, and the copy-out walks one shard's run at a time.
 __global__ __launch_bounds__(256) void k_part_scatter(const uint64_t* id, const uint32_t* field, const int64_t* ts, const int64_t* val,
                                                       const uint8_t* owner, uint32_t n, uint32_t nshards, uint32_t per_block, const uint32_t* counts,
-                                                      bmx_delta_rec* out, unsigned long long* totals, uint32_t slab) {
+                                                      bmx_delta_rec* out, unsigned long long* totals, uint32_t slab, uint32_t* status) {
   __shared__ uint32_t base[PART_MAX_SHARDS];       // running output cursor of this block per shard
   __shared__ uint32_t tot[PART_MAX_SHARDS];        // shard totals over the whole batch
   __shared__ uint32_t red[PART_MAX_SHARDS][2];
@@ -626,7 +626,10 @@ __global__ __launch_bounds__(256) void k_part_scatter(const uint64_t* id, const 
   __syncthreads();
   if (threadIdx.x < nshards) {
     tot[threadIdx.x] = red[threadIdx.x][1];
-    if (blockIdx.x == 0) totals[threadIdx.x] = red[threadIdx.x][1];
+    if (blockIdx.x == 0) {
+      totals[threadIdx.x] = red[threadIdx.x][1];
+      if (slab && red[threadIdx.x][1] > slab) atomicOr(status, ST_SLAB);   // records were dropped: sticky, reported by bmx_sync
+    }
   }
   __syncthreads();
   if (threadIdx.x < nshards) {

@@ -29,7 +29,7 @@ __host__ __device__ inline int64_t ts_value(int64_t w) { return w & TS_VALUE_MAS
 __host__ __device__ inline uint32_t ts_mark(int64_t w) { return (uint32_t)((uint64_t)w >> TS_MARK_SHIFT) & 0xFFu; }
 
 // device status word bits (sticky until read by the host)
-constexpr uint32_t ST_RANGE = 1, ST_FULL = 2, ST_SPIN = 4;
+constexpr uint32_t ST_RANGE = 1, ST_FULL = 2, ST_SPIN = 4, ST_SLAB = 8;
 
 struct alignas(32) Slot {
   uint64_t id;

@@ -42,6 +42,7 @@ extern "C" {
 #define BMX_ERR_INTERNAL  -6  /* device-side protocol fault (bounded spin expired) */
 #define BMX_ERR_NO_DEVICE -7
 #define BMX_ERR_NO_INDEX  -8  /* scan on a field with no index and auto-build disabled */
+#define BMX_ERR_OVERFLOW  -9  /* a fixed-size exchange slab was too small (bmx_partition_by_owner_slabs): records were dropped */
 
 /* where the caller's buffers live */
 #define BMX_MEM_HOST   0      /* host pointers: the call copies in/out and is synchronous */
@@ -223,7 +224,8 @@ int bmx_partition_by_owner(bmx_ctx* ctx, uint64_t n, const uint64_t* id, const u
  * is padding (id = 0xFFFFFFFFFFFFFFFF, skipped by bmx_merge_records), so the exchange can use equal splits and
  * needs no host round trip for counts. recs_out has nshards*slab_records records. counts_out_dev[g] is the TRUE
  * count: if it exceeds slab_records the surplus records of that shard were NOT written and the caller must
- * re-route the batch with bmx_partition_by_owner (merging is idempotent, so re-sending is safe). */
+ * re-route the batch with bmx_partition_by_owner (merging is idempotent, so re-sending is safe). The overflow is also
+ * sticky on the context: the next bmx_sync() returns BMX_ERR_OVERFLOW, so a pipelined caller cannot miss it. */
 int bmx_partition_by_owner_slabs(bmx_ctx* ctx, uint64_t n, const uint64_t* id, const uint32_t* field, const int64_t* ts,
                                  const int64_t* val, uint32_t nshards, uint64_t slab_records, bmx_delta_rec* recs_out,
                                  uint64_t* counts_out_dev);
@@ -268,10 +270,13 @@ int bmx_timer_start(bmx_ctx* ctx);
 int bmx_timer_stop(bmx_ctx* ctx, float* ms_out);    /* synchronises on the stop event */
 /* Per-kernel timing of the merge: while enabled, every merge call brackets its three stages with HIP
  * events (up to 64 calls are kept). bmx_profile_read synchronises and returns the AVERAGE milliseconds
- * per call of: [0] k_probe_apply, [1] k_resolve_lists, [2] winner compaction (2 launches), and the
- * number of calls averaged. */
+ * per call of: [0] k_probe_apply, [1] k_resolve_lists, [2] winner compaction, and the number of calls averaged
+ * (calls that took the bucketed path: [0] k_merge_bins, [1] k_bucket, [2] k_count_winners + compaction). */
 int bmx_profile_enable(bmx_ctx* ctx, int on);
 int bmx_profile_read(bmx_ctx* ctx, float ms_out[3], uint32_t* n_calls);
+/* Same for the scans issued while profiling was enabled: AVERAGE milliseconds per scan call of [0] the mask pass (k_scan_mask: the one
+ * read of the value column), [1] everything after it (offset scan + k_scan_emit, or the count reduction). */
+int bmx_profile_read_scan(bmx_ctx* ctx, float ms_out[2], uint32_t* n_calls);
 
 #ifdef __cplusplus
 }
