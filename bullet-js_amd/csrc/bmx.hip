@@ -58,6 +58,7 @@ struct bmx_ctx {
   uint8_t* wflag = nullptr;
   uint32_t* slot_of = nullptr;
   uint32_t* blk_info = nullptr;       // ws_cap/256 block summaries (second set right behind the first for async compaction)
+  uint32_t* blk_follow = nullptr;     // ws_cap/256 epoch tags: a delta of the block got a follower on its row
   unsigned long long* shard_ctr = nullptr;  // CTR_SHARDS * CTR_STRIDE
   // default merge path (bin_kernels.h): the batch regrouped by bin, tile by tile
   uint32_t bin_tiles_cap = 0;
@@ -178,13 +179,14 @@ int ensure_workspace(bmx_ctx* ctx, uint64_t n) {
   cap = std::max<uint64_t>(cap, 1u << 16);
   cap = (cap + 255) & ~255ull;
   { int rcj = join_side(ctx, true); if (rcj) return rcj; }
-  dev_free(ctx->next); dev_free(ctx->wflag); dev_free(ctx->wflag2); dev_free(ctx->slot_of); dev_free(ctx->blk_info);
+  dev_free(ctx->next); dev_free(ctx->wflag); dev_free(ctx->wflag2); dev_free(ctx->slot_of); dev_free(ctx->blk_info); dev_free(ctx->blk_follow);
   ctx->ws_cap = 0;
   int rc;
   if ((rc = dev_alloc(ctx, &ctx->next, cap)) || (rc = dev_alloc(ctx, &ctx->wflag, cap + 16)) || (rc = dev_alloc(ctx, &ctx->slot_of, cap))) return rc;
   if (ctx->async_compact && (rc = dev_alloc(ctx, &ctx->wflag2, cap + 16))) return rc;
-  if ((rc = dev_alloc(ctx, &ctx->blk_info, 2 * (cap / 256 + 16)))) return rc;
+  if ((rc = dev_alloc(ctx, &ctx->blk_info, 2 * (cap / 256 + 16))) || (rc = dev_alloc(ctx, &ctx->blk_follow, cap / 256 + 16))) return rc;
   HIPCHK(hipMemsetAsync(ctx->next, 0, cap * sizeof(uint32_t), ctx->stream));
+  HIPCHK(hipMemsetAsync(ctx->blk_follow, 0, (cap / 256 + 16) * sizeof(uint32_t), ctx->stream));
   ctx->ws_cap = (uint32_t)cap;
   return BMX_OK;
 }
@@ -284,6 +286,7 @@ int merge_core(bmx_ctx* ctx, uint64_t n, const uint64_t* id, const uint32_t* fie
     hipLaunchKernelGGL(k_sweep_heads, dim3(2048), dim3(256), 0, ctx->stream, ctx->slots, ctx->nslots);
     LAUNCHCHK("k_sweep_heads");
     HIPCHK(hipMemsetAsync(ctx->next, 0, (size_t)ctx->ws_cap * sizeof(uint32_t), ctx->stream));
+    HIPCHK(hipMemsetAsync(ctx->blk_follow, 0, ((size_t)ctx->ws_cap / 256 + 16) * sizeof(uint32_t), ctx->stream));
     ctx->epoch = 1;
   }
   // double buffering for the asynchronous compaction: batch b uses buffer b&1
@@ -299,7 +302,7 @@ int merge_core(bmx_ctx* ctx, uint64_t n, const uint64_t* id, const uint32_t* fie
   A.id = id; A.field = field; A.ts = ts; A.val = val; A.recs = recs;
   A.n = (uint32_t)n; A.epoch = ctx->epoch;
   A.next = ctx->next; A.wflag = wflag; A.flags = flags;
-  A.slot_of = ctx->slot_of; A.shard_ctr = ctr; A.status = &ctx->ds->status;
+  A.slot_of = ctx->slot_of; A.blk_follow = ctx->blk_follow; A.shard_ctr = ctr; A.status = &ctx->ds->status;
   A.blk_info = ctx->blk_info + (bi ? (ctx->ws_cap / 256 + 16) : 0);
   const uint32_t blocks = (uint32_t)((n + 255) / 256);
   const uint32_t rblocks = blocks;   // one lane per delta
@@ -623,7 +626,7 @@ void bmx_destroy(bmx_ctx* ctx) {
   for (int i = 0; i < 2; i++) { if (ctx->ev_k2[i]) (void)hipEventDestroy(ctx->ev_k2[i]); if (ctx->ev_k3[i]) (void)hipEventDestroy(ctx->ev_k3[i]); }
   if (ctx->side) (void)hipStreamDestroy(ctx->side);
   for (auto& ix : ctx->indexes) { dev_free(ix.ids); dev_free(ix.v64); dev_free(ix.v32); }
-  dev_free(ctx->slots); dev_free(ctx->ds); dev_free(ctx->next); dev_free(ctx->wflag); dev_free(ctx->slot_of); dev_free(ctx->blk_info); dev_free(ctx->shard_ctr);
+  dev_free(ctx->slots); dev_free(ctx->ds); dev_free(ctx->next); dev_free(ctx->wflag); dev_free(ctx->slot_of); dev_free(ctx->blk_info); dev_free(ctx->blk_follow); dev_free(ctx->shard_ctr);
   dev_free(ctx->st_id); dev_free(ctx->st_field); dev_free(ctx->st_ts); dev_free(ctx->st_val); dev_free(ctx->st_applied); dev_free(ctx->st_flags);
   dev_free(ctx->bin_stage); dev_free(ctx->bin_toff);
   dev_free(ctx->scan_out); dev_free(ctx->block_counts); dev_free(ctx->part_counts); dev_free(ctx->part_owner); dev_free(ctx->scan_mask); dev_free(ctx->scan_counts);

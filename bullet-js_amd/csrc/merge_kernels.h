@@ -10,11 +10,12 @@
 //                    first claimer of the batch — store (ts,val) right away (one aligned 16-B store).
 //                    An absent key is created with a CAS on slot.id plus one 8-byte store that publishes the
 //                    field and claims the head together.
-//                    Later claimers of the same row (duplicate keys) link themselves into a per-row
-//                    list (next[]) and mark themselves pending instead of writing.
-//   k_resolve_lists  pending deltas only (none for unique-key batches without inserts): the LAST claimer of
-//                    each row walks the row's list and applies the reference's sequential outcome (lexmax of
-//                    (ts,val), ties to the smaller index, first write of an absent key stored with ts := 2).
+//                    Later claimers of the same row (duplicate keys) link themselves BEHIND the previous claimer
+//                    (next[previous] = me: a forward list that starts at the first claimer) instead of writing.
+//   k_resolve_lists  first claimers that got followers only (none in a unique-key batch): each walks its row's list
+//                    forward and applies the reference's sequential outcome (lexmax of (ts,val), ties to the
+//                    smaller index, first write of an absent key stored with ts := 2). Followers do nothing there:
+//                    who has to walk is known from next[own index], a coalesced load — no row is read to find out.
 //   select (select.h) ordered compaction of the per-delta winner bytes -> applied_idx.
 //
 // Why this shape (measured, profiles/r01_micro_probe_v2.log): a random probe costs one 128-B line
@@ -37,17 +38,19 @@ struct MergeArgs {
   const bmx_delta_rec* recs;  // AoS input (id/field/ts/val unused then)
   uint32_t n;
   uint32_t epoch;             // 1..EPOCH_MAX
-  uint32_t* next;             // per delta: (epoch<<24)|previous claimer; stale epoch = end of list
+  uint32_t* next;             // per delta: (epoch<<24)|the claimer that came right after this one on the same row; stale epoch = end of list
+                              // (strict mode links backward instead: next[j] = previous claimer)
+  uint32_t* blk_follow;       // per 256-delta block: == epoch if a delta of the block got a follower (k_resolve_lists skips the others)
   uint8_t* wflag;             // per delta: W_WINNER = this delta's value is the row's final value,
                               //            W_PENDING = needs k_resolve_lists (duplicate key / reference-mode insert)
   uint8_t* flags;             // optional decision flags
-  uint32_t* slot_of;          // per delta, written for W_PENDING deltas only: the row's slot
+  uint32_t* slot_of;          // per delta, written by the claimers of a row: the row's slot
   uint32_t* blk_info;         // per 256-delta block: bit 31 = block has pending deltas, bits 0..30 = winners in the block
   unsigned long long* shard_ctr;  // CTR_SHARDS x CTR_STRIDE counters: [s][0] rows created, [s][1] conflicts
   uint32_t* status;
 };
 
-constexpr uint8_t W_NONE = 0, W_WINNER = 1, W_PENDING = 2;
+constexpr uint8_t W_NONE = 0, W_WINNER = 1, W_PENDING = 2, W_FIRST = 4;   // W_FIRST (bit): first claimer of its row in this batch; bit 0 is what the compaction reads
 constexpr uint32_t BLK_PENDING = 0x80000000u, BLK_COUNT = 0x7FFFFFFFu;
 // A single hot word takes only ~88 atomics/us (MI355X_MICROARCH.md "dequeue"), so per-batch counters are
 // spread over 256 words on separate 128-B lines and folded once per batch by the last compaction block.
@@ -169,19 +172,20 @@ __global__ __launch_bounds__(256) void k_probe_apply(MergeArgs A) {
         if (!created && !UNIQUE) prev = atomicExch(&sl->head, tag);   // UNIQUE: caller-guaranteed single claimer (prev stays 0)
         if ((prev >> IDX_BITS) != A.epoch) {
           // first claimer of this row in this batch: its snapshot is the pre-batch row
+          if (!UNIQUE) { A.slot_of[j] = (uint32_t)s; wf = W_FIRST; }   // it walks the row's list in k_resolve_lists if anybody follows
           if (is_new) {
             // first write of an absent key: the reference stores clock {id:2} (src/bullet-crt.js:172-185);
             // the creation mark keeps later deltas of this key from comparing against this provisional value
             const int64_t t0 = (MODE == BMX_INSERT_REFERENCE) ? 2 : a;
             store_tv(sl, t0 | ((int64_t)A.epoch << TS_MARK_SHIFT), v);
-            wf = W_WINNER; fl = BMX_FLAG_INCOMING;
+            wf |= W_WINNER; fl = BMX_FLAG_INCOMING;
           } else if (c > 0) {
-            store_tv(sl, a, v); wf = W_WINNER; fl = BMX_FLAG_INCOMING;
+            store_tv(sl, a, v); wf |= W_WINNER; fl = BMX_FLAG_INCOMING;
           }  // c == 0: identical clock and value: no-op, all flags false
         } else {
-          // duplicate key inside the batch: link behind the previous claimer, resolve in k_resolve_lists
-          A.next[j] = (A.epoch << IDX_BITS) | (prev & IDX_MASK);
-          A.slot_of[j] = (uint32_t)s;
+          // duplicate key inside the batch: link behind the previous claimer; the row's first claimer resolves the list in k_resolve_lists
+          A.next[prev & IDX_MASK] = tag;
+          A.blk_follow[(prev & IDX_MASK) >> 8] = A.epoch;
           wf = W_PENDING; conflict = true;
           fl = c > 0 ? BMX_FLAG_INCOMING : 0u;
         }
@@ -204,7 +208,7 @@ __global__ __launch_bounds__(256) void k_probe_apply(MergeArgs A) {
   // block summary for the two passes that follow: they skip blocks without pending deltas and need no counting phase
   {
     __shared__ uint32_t s_w[4], s_p[4];
-    unsigned long long mw = __ballot(wf == W_WINNER), mp = __ballot(wf == W_PENDING);
+    unsigned long long mw = __ballot((wf & W_WINNER) != 0), mp = __ballot(wf == W_PENDING);
     if (lane_id() == 0) { s_w[threadIdx.x >> 6] = (uint32_t)__popcll(mw); s_p[threadIdx.x >> 6] = mp != 0ull; }
     __syncthreads();
     if (threadIdx.x == 0)
@@ -213,58 +217,78 @@ __global__ __launch_bounds__(256) void k_probe_apply(MergeArgs A) {
 }
 
 // Pending pass (duplicate keys only): one lane per delta, so every walker starts at once (the pass is latency bound:
-// few walkers, each a chain of dependent reads). Only the LAST claimer of a row (slot.head names it) does anything:
-// it walks next[] back to the first claimer and applies the sequential outcome for that key.
+// few walkers, each a chain of dependent reads). Only the FIRST claimer of a row that got followers does anything:
+// it walks next[] forward to the last claimer and applies the sequential outcome for that key.
 
-// generic single-pass walk for long lists (a key hit more than RES_CAP times in one batch): tracks the smallest index,
-// the best (ts,val) with its smallest index, and the best among the other deltas, so that the creating delta of an absent
-// row (smallest index, stored with ts := 2) can be excluded afterwards without a second walk.
-template <bool AOS, int MODE>
-__device__ __forceinline__ void resolve_long(const MergeArgs& A, uint32_t j, Slot* sl, int64_t tsw, int64_t cval) {
-  const bool is_new = tsw == TS_NEW || ts_mark(tsw) == A.epoch;
-  uint32_t j0 = j, first = j;
-  int64_t v_j0 = 0, t_j0 = 0;
-  int64_t t1 = INT64_MIN, v1 = INT64_MIN, t2 = INT64_MIN, v2 = INT64_MIN;   // best and best-of-the-rest
+// top-2 tracker: best (ts,val) with its smallest index, and the best among the rest
+struct Top2 {
+  int64_t t1 = INT64_MIN, v1 = INT64_MIN, t2 = INT64_MIN, v2 = INT64_MIN;
   uint32_t o1 = ~0u, o2 = ~0u;
+  __device__ __forceinline__ void add(uint32_t idx, int64_t t, int64_t v) {
+    int c1 = o1 == ~0u ? 1 : lexcmp(t, v, t1, v1);
+    if (c1 > 0 || (c1 == 0 && idx < o1)) {
+      if (o1 != ~0u) { int c2 = o2 == ~0u ? 1 : lexcmp(t1, v1, t2, v2); if (c2 > 0 || (c2 == 0 && o1 < o2)) { t2 = t1; v2 = v1; o2 = o1; } }
+      t1 = t; v1 = v; o1 = idx;
+    } else {
+      int c2 = o2 == ~0u ? 1 : lexcmp(t, v, t2, v2);
+      if (c2 > 0 || (c2 == 0 && idx < o2)) { t2 = t; v2 = v; o2 = idx; }
+    }
+  }
+  // best entry whose index is not `skip`
+  __device__ __forceinline__ bool best_except(uint32_t skip, int64_t& t, int64_t& v, uint32_t& o) const {
+    const bool use2 = o1 == skip;
+    o = use2 ? o2 : o1;
+    if (o == ~0u) return false;
+    t = use2 ? t2 : t1; v = use2 ? v2 : v1;
+    return true;
+  }
+};
+
+// Single-pass walk of a row's list by its FIRST claimer: tracks the smallest index (it creates an absent row, stored with ts := 2),
+// the best (ts,val) with its smallest index and the best among the other deltas, so that the creating delta can be excluded
+// afterwards without a second walk. One dependent L2 round trip per list node (the node's link and its (ts,val) are loaded together).
+template <bool AOS, int MODE>
+__device__ __forceinline__ void resolve_one(const MergeArgs& A, const uint32_t j) {
+  if (j >= A.n) return;
+  const uint8_t wf = A.wflag[j];
+  if (!(wf & W_FIRST)) return;                      // followers do nothing here
+  uint32_t nx = A.next[j];
+  if ((nx >> IDX_BITS) != A.epoch) return;          // nobody followed: the row already holds the outcome
+  // independent loads: this delta's value and the row (one line)
+  int64_t t, v; load_delta_tv<AOS>(A, j, t, v);
+  Slot* sl = A.slots + A.slot_of[j];
+  const uint4 hi = reinterpret_cast<const uint4*>(sl)[1];
+  const int64_t tsw = (int64_t)((uint64_t)hi.x | ((uint64_t)hi.y << 32));
+  const int64_t cval = (int64_t)((uint64_t)hi.z | ((uint64_t)hi.w << 32));
+  const bool is_new = tsw == TS_NEW || ts_mark(tsw) == A.epoch;  // row created in this batch: no pre-batch state
+  uint32_t j0 = j;
+  int64_t v_j0 = v, t_j0 = t;
+  Top2 top;
   {
     uint32_t idx = j, steps = 0;
     for (;;) {
-      int64_t t, v; load_delta_tv<AOS>(A, idx, t, v);
-      uint32_t nx = A.next[idx];
       if (idx <= j0) { j0 = idx; t_j0 = t; v_j0 = v; }
-      int c1 = o1 == ~0u ? 1 : lexcmp(t, v, t1, v1);
-      if (c1 > 0 || (c1 == 0 && idx < o1)) {
-        // new best; the old best becomes a candidate for second place (unless it ties the new best: same value, larger index)
-        if (o1 != ~0u && c1 > 0) { int c2 = o2 == ~0u ? 1 : lexcmp(t1, v1, t2, v2); if (c2 > 0 || (c2 == 0 && o1 < o2)) { t2 = t1; v2 = v1; o2 = o1; } }
-        else if (o1 != ~0u && c1 == 0) { int c2 = o2 == ~0u ? 1 : lexcmp(t1, v1, t2, v2); if (c2 > 0 || (c2 == 0 && o1 < o2)) { t2 = t1; v2 = v1; o2 = o1; } }
-        t1 = t; v1 = v; o1 = idx;
-      } else {
-        int c2 = o2 == ~0u ? 1 : lexcmp(t, v, t2, v2);
-        if (c2 > 0 || (c2 == 0 && idx < o2)) { t2 = t; v2 = v; o2 = idx; }
-      }
-      if ((nx >> IDX_BITS) != A.epoch) { first = idx; break; }
+      top.add(idx, t, v);
+      if ((nx >> IDX_BITS) != A.epoch) break;
       idx = nx & IDX_MASK;
+      nx = A.next[idx]; load_delta_tv<AOS>(A, idx, t, v);   // the next node's link and value: independent loads, one round trip
       if (++steps > A.n) { atomicOr(A.status, ST_SPIN); return; }
     }
   }
-  const uint32_t base_owner = A.wflag[first] == W_WINNER ? first : ~0u;
+  const uint32_t base_owner = (wf & W_WINNER) ? j : ~0u;   // the first claimer stored iff it beat the pre-batch row
   int64_t bt, bv;
   uint32_t owner;
   if (is_new) {
-    // the row starts as (2 or t_j0, v_j0) owned by j0; the other deltas then compete against it
+    // the row starts as (2 or t_j0, v_j0) owned by j0 (src/bullet-crt.js:172-185); the other deltas then compete against it
     bt = (MODE == BMX_INSERT_REFERENCE) ? 2 : t_j0; bv = v_j0; owner = j0;
-    const bool use2 = o1 == j0;                      // best of the deltas other than j0
-    const uint32_t om = use2 ? o2 : o1;
-    if (om != ~0u) {
-      const int64_t tm = use2 ? t2 : t1, vm = use2 ? v2 : v1;
-      int c = lexcmp(tm, vm, bt, bv);
-      if (c > 0) { bt = tm; bv = vm; owner = om; }   // a tie keeps j0 (it has the smaller index)
-    }
+    int64_t tm, vm; uint32_t om;
+    if (top.best_except(j0, tm, vm, om) && lexcmp(tm, vm, bt, bv) > 0) { bt = tm; bv = vm; owner = om; }   // a tie keeps j0 (it has the smaller index)
   } else {
+    // lexmax over the list, ties to the smaller index ("identical clocks and values" is a no-op, :207-219)
     bt = ts_value(tsw); bv = cval; owner = base_owner;
-    int c = lexcmp(t1, v1, bt, bv);
-    if (c > 0) { bt = t1; bv = v1; owner = o1; }
-    else if (c == 0 && owner != ~0u && o1 < owner) owner = o1;
+    const int c = lexcmp(top.t1, top.v1, bt, bv);
+    if (c > 0) { bt = top.t1; bv = top.v1; owner = top.o1; }
+    else if (c == 0 && owner != ~0u && top.o1 < owner) owner = top.o1;
   }
   store_tv(sl, is_new ? (bt | ((int64_t)A.epoch << TS_MARK_SHIFT)) : bt, bv);
   // move the winner mark (and the per-block winner counts the compaction relies on) from the first claimer to the owner
@@ -275,69 +299,10 @@ __device__ __forceinline__ void resolve_long(const MergeArgs& A, uint32_t j, Slo
   if (owner != ~0u && A.flags) A.flags[owner] = (uint8_t)BMX_FLAG_INCOMING;
 }
 
-constexpr int RES_CAP = 8;  // list nodes kept in registers by the single-walk fast path
-
 template <bool AOS, int MODE>
 __global__ __launch_bounds__(256) void k_resolve_lists(MergeArgs A) {
-  if (!(A.blk_info[blockIdx.x] & BLK_PENDING)) return;      // whole block: nothing pending (same 256-delta blocks as k_probe_apply)
-  const uint32_t j = blockIdx.x * 256u + threadIdx.x;
-  if (j >= A.n || A.wflag[j] != W_PENDING) return;
-  // independent loads first: this delta's value, its link, and the row (one line)
-  int64_t t, v; load_delta_tv<AOS>(A, j, t, v);
-  uint32_t nx = A.next[j];
-  Slot* sl = A.slots + A.slot_of[j];
-  const uint4* q = reinterpret_cast<const uint4*>(sl);
-  const uint4 lo = q[0], hi = q[1];
-  if ((lo.w & IDX_MASK) != j) return;   // not the last claimer of its row
-  const int64_t tsw = (int64_t)((uint64_t)hi.x | ((uint64_t)hi.y << 32));
-  const int64_t cval = (int64_t)((uint64_t)hi.z | ((uint64_t)hi.w << 32));
-  const bool is_new = tsw == TS_NEW || ts_mark(tsw) == A.epoch;  // row created in this batch: no pre-batch state
-
-  // single walk, nodes in registers (static indices only: a runtime-indexed array would go to scratch)
-  uint32_t ni[RES_CAP]; int64_t nt[RES_CAP], nv[RES_CAP];
-  int L = 0;
-  bool alive = true;
-  uint32_t idx = j, first = j;
-#pragma unroll
-  for (int k = 0; k < RES_CAP; k++) {
-    if (alive) {
-      ni[k] = idx; nt[k] = t; nv[k] = v; L = k + 1;
-      if ((nx >> IDX_BITS) != A.epoch) { first = idx; alive = false; }
-      else { idx = nx & IDX_MASK; nx = A.next[idx]; load_delta_tv<AOS>(A, idx, t, v); }   // two independent loads per hop
-    }
-  }
-  if (alive) { resolve_long<AOS, MODE>(A, j, sl, tsw, cval); return; }
-
-  // smallest index creates an absent row with ts := 2 (src/bullet-crt.js:172-185)
-  uint32_t j0 = j; int k0 = 0;
-#pragma unroll
-  for (int k = 0; k < RES_CAP; k++) if (k < L && ni[k] < j0) { j0 = ni[k]; k0 = k; }
-  const uint32_t base_owner = A.wflag[first] == W_WINNER ? first : ~0u;   // the first claimer stored iff it beat the pre-batch row
-  int64_t bt, bv; uint32_t owner;
-  if (is_new) {
-    int64_t t0 = 0, v0 = 0;
-#pragma unroll
-    for (int k = 0; k < RES_CAP; k++) if (k == k0) { t0 = nt[k]; v0 = nv[k]; }
-    bt = (MODE == BMX_INSERT_REFERENCE) ? 2 : t0; bv = v0; owner = j0;
-  } else {
-    bt = ts_value(tsw); bv = cval; owner = base_owner;
-  }
-  // lexmax over the list, ties to the smaller index ("identical clocks and values" is a no-op, :207-219)
-#pragma unroll
-  for (int k = 0; k < RES_CAP; k++) {
-    if (k < L && !(is_new && ni[k] == j0)) {
-      int c = lexcmp(nt[k], nv[k], bt, bv);
-      if (c > 0) { bt = nt[k]; bv = nv[k]; owner = ni[k]; }
-      else if (c == 0 && owner != ~0u && ni[k] < owner) owner = ni[k];
-    }
-  }
-  store_tv(sl, is_new ? (bt | ((int64_t)A.epoch << TS_MARK_SHIFT)) : bt, bv);
-  // move the winner mark (and the per-block winner counts the compaction relies on) from the first claimer to the owner
-  if (base_owner != owner) {
-    if (base_owner != ~0u) { A.wflag[base_owner] = W_NONE; atomicSub(&A.blk_info[base_owner >> 8], 1u); }
-    if (owner != ~0u) { A.wflag[owner] = W_WINNER; atomicAdd(&A.blk_info[owner >> 8], 1u); }
-  }
-  if (owner != ~0u && A.flags) A.flags[owner] = (uint8_t)BMX_FLAG_INCOMING;
+  // 256-delta blocks none of whose deltas got a follower return after one load
+  if (A.blk_follow[blockIdx.x] == A.epoch) resolve_one<AOS, MODE>(A, blockIdx.x * 256u + threadIdx.x);
 }
 
 // ---- strict mode (BMX_MERGE_STRICT_FLAGS): exact sequential per-delta flags for any batch ----
@@ -383,30 +348,6 @@ __global__ __launch_bounds__(256) void k_probe_link_strict(MergeArgs A) {
   }
   if (threadIdx.x == 0) A.blk_info[blockIdx.x] = 0;   // winners are counted by k_resolve_strict
 }
-
-// top-2 tracker: best (ts,val) with its smallest index, and the best among the rest
-struct Top2 {
-  int64_t t1 = INT64_MIN, v1 = INT64_MIN, t2 = INT64_MIN, v2 = INT64_MIN;
-  uint32_t o1 = ~0u, o2 = ~0u;
-  __device__ __forceinline__ void add(uint32_t idx, int64_t t, int64_t v) {
-    int c1 = o1 == ~0u ? 1 : lexcmp(t, v, t1, v1);
-    if (c1 > 0 || (c1 == 0 && idx < o1)) {
-      if (o1 != ~0u) { int c2 = o2 == ~0u ? 1 : lexcmp(t1, v1, t2, v2); if (c2 > 0 || (c2 == 0 && o1 < o2)) { t2 = t1; v2 = v1; o2 = o1; } }
-      t1 = t; v1 = v; o1 = idx;
-    } else {
-      int c2 = o2 == ~0u ? 1 : lexcmp(t, v, t2, v2);
-      if (c2 > 0 || (c2 == 0 && idx < o2)) { t2 = t; v2 = v; o2 = idx; }
-    }
-  }
-  // best entry whose index is not `skip`
-  __device__ __forceinline__ bool best_except(uint32_t skip, int64_t& t, int64_t& v, uint32_t& o) const {
-    const bool use2 = o1 == skip;
-    o = use2 ? o2 : o1;
-    if (o == ~0u) return false;
-    t = use2 ? t2 : t1; v = use2 ? v2 : v1;
-    return true;
-  }
-};
 
 // APPLY = false: every delta computes its own sequential flags (rows are only READ: they still hold the pre-batch state).
 // APPLY = true : launched afterwards; only the last claimer of each row proceeds, writes the final state, names the winner.
