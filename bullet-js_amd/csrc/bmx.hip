@@ -226,7 +226,7 @@ uint64_t slots_for(uint64_t capacity_rows, uint32_t load_pct) {
   if (capacity_rows > (1ull << 40)) return 0;
   uint64_t nslots = std::max<uint64_t>(4096, (capacity_rows * 100 + load_pct - 1) / load_pct);
   nslots = (nslots + 3) & ~3ull;
-  return nslots > (1ull << 32) ? 0 : nslots;
+  return nslots >= (1ull << 32) ? 0 : nslots;   // the last 32-bit value is a sentinel (STRICT_NO_ROW)
 }
 
 // Rehash into a table for `capacity_rows` rows. Synchronous.
@@ -570,6 +570,7 @@ int bmx_create(int device, uint64_t capacity_rows, uint32_t flags, bmx_ctx** out
 int bmx_create_ex(int device, uint64_t capacity_rows, uint32_t max_load_pct, uint32_t flags, bmx_ctx** out) {
   if (!out || capacity_rows == 0) return fail(nullptr, BMX_ERR_INVALID, "bmx_create: bad arguments");
   *out = nullptr;
+  // argument checks come before the device is looked at: they hold on any machine
   if (max_load_pct == 0) max_load_pct = BMX_DEFAULT_LOAD_PCT;
   if (max_load_pct < 5 || max_load_pct > 90) return fail(nullptr, BMX_ERR_INVALID, "bmx_create_ex: max_load_pct must be 5..90 (0 = default)");
   if (!slots_for(capacity_rows, max_load_pct))

@@ -87,61 +87,82 @@ __device__ __forceinline__ void store_tv(Slot* sl, int64_t ts, int64_t val) {
 
 // Locate (or create) the slot of key (id, field). Returns false if the table is full / protocol fault.
 // is_new: the row has no resident value visible to this lane (created in this batch, by anyone).
-// created: this lane created the row AND (with the same 64-bit exchange that publishes the field) claimed it;
+// created: this lane created the row AND (with the same 64-bit store that publishes the field) claimed it;
 // prev_head is then the old head word.
+//
+// A lane that meets a slot of its own node whose field is not published yet (another lane created it a moment ago) must wait for
+// that field. The wait is NOT inside the probe loop: the lane leaves the loop, and the wait sits behind the loop's exit, where
+// the wave has reconverged — every sibling lane of the same wave that created a slot in this round has executed its publishing
+// store by then (it is in the creating lane's path through the loop body, in front of that lane's exit). So a waiter can never
+// spin in front of the store it is waiting for, whatever order the compiler gives the blocks inside the loop.
 template <bool UNIQUE>
 __device__ __forceinline__ bool probe_or_insert(const MergeArgs& A, uint32_t tag, uint64_t id, uint32_t field, uint64_t& slot_out,
                                                 bool& is_new, bool& created, uint32_t& prev_head, int64_t& cts, int64_t& cval) {
   created = false;
   ProbeSeq<4> ps(id, field, A.nslots);
-  for (uint64_t p = 0; p < A.nslots; ++p) {
-    const uint64_t s = ps.slot();
-    Slot* sl = A.slots + s;
-    const uint4* q = reinterpret_cast<const uint4*>(sl);
-    uint4 lo = q[0], hi = q[1];
-    uint64_t sid = (uint64_t)lo.x | ((uint64_t)lo.y << 32);
-    uint32_t sf = lo.z;
-    bool fresh = false;
-    if (sid == EMPTY_ID) {
-      unsigned long long old = atomicCAS(reinterpret_cast<unsigned long long*>(&sl->id), (unsigned long long)EMPTY_ID, (unsigned long long)id);
-      if (old == EMPTY_ID) {  // this lane created the row
-        // ONE aligned 8-byte agent-scope store publishes the field and claims the head together. A store (not an
-        // exchange) is enough: other lanes of this key wait for the field before they touch the head, so nobody
-        // can have claimed it earlier and every later claimer's exchange returns this tag.
-        __hip_atomic_store(reinterpret_cast<unsigned long long*>(&sl->field), (unsigned long long)field | ((unsigned long long)(UNIQUE ? 0u : tag) << 32),
-                           __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        prev_head = 0;
-        created = true;
-        slot_out = s; is_new = true; cts = TS_NEW; cval = 0;
-        return true;
+  uint64_t p = 0;
+  for (uint32_t round = 0; round < 256; ++round) {
+    Slot* wait_on = nullptr;
+    uint64_t s = 0;
+    int done = 0;
+    for (; p < A.nslots; ++p) {
+      s = ps.slot();
+      Slot* sl = A.slots + s;
+      const uint4* q = reinterpret_cast<const uint4*>(sl);
+      uint4 lo = q[0], hi = q[1];
+      uint64_t sid = (uint64_t)lo.x | ((uint64_t)lo.y << 32);
+      uint32_t sf = lo.z;
+      bool fresh = false;
+      if (sid == EMPTY_ID) {
+        unsigned long long old = atomicCAS(reinterpret_cast<unsigned long long*>(&sl->id), (unsigned long long)EMPTY_ID, (unsigned long long)id);
+        if (old == EMPTY_ID) {  // this lane created the row
+          // ONE aligned 8-byte agent-scope store publishes the field and claims the head together. A store (not an
+          // exchange) is enough: other lanes of this key wait for the field before they touch the head, so nobody
+          // can have claimed it earlier and every later claimer's exchange returns this tag.
+          __hip_atomic_store(reinterpret_cast<unsigned long long*>(&sl->field), (unsigned long long)field | ((unsigned long long)(UNIQUE ? 0u : tag) << 32),
+                             __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          prev_head = 0;
+          created = true;
+          slot_out = s; is_new = true; cts = TS_NEW; cval = 0;
+          done = 1;
+          break;
+        }
+        sid = old;            // somebody claimed it while we looked (or our L1 copy was stale)
+        sf = FIELD_PENDING;   // read the field through L2
+        fresh = true;         // whatever (ts,val) we loaded is not a resident value
       }
-      sid = old;            // somebody claimed it while we looked (or our L1 copy was stale)
-      sf = FIELD_PENDING;   // read the field through L2
-      fresh = true;         // whatever (ts,val) we loaded is not a resident value
+      if (sid == id) {
+        if (sf == FIELD_PENDING) { wait_on = sl; break; }     // leave the loop; wait behind its exit
+        if (sf == field) {
+          int64_t t = (int64_t)((uint64_t)hi.x | ((uint64_t)hi.y << 32));
+          slot_out = s;
+          // no pre-batch state: slot just claimed, still unwritten, or created earlier in this very batch
+          is_new = fresh || t == TS_NEW || ts_mark(t) == (tag >> IDX_BITS);
+          cts = is_new ? TS_NEW : ts_value(t);
+          cval = (int64_t)((uint64_t)hi.z | ((uint64_t)hi.w << 32));
+          done = 1;
+          break;
+        }
+      }
+      ps.next();
     }
-    if (sid == id) {
-      if (sf == FIELD_PENDING) {
-        uint32_t spins = 0;
-        do {
-          sf = __hip_atomic_load(&sl->field, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-          if (sf != FIELD_PENDING) break;
-          __builtin_amdgcn_s_sleep(1);
-        } while (++spins < (1u << 22));
-        if (sf == FIELD_PENDING) { atomicOr(A.status, ST_SPIN); return false; }
-      }
-      if (sf == field) {
-        int64_t t = (int64_t)((uint64_t)hi.x | ((uint64_t)hi.y << 32));
-        slot_out = s;
-        // no pre-batch state: slot just claimed, still unwritten, or created earlier in this very batch
-        is_new = fresh || t == TS_NEW || ts_mark(t) == (tag >> IDX_BITS);
-        cts = is_new ? TS_NEW : ts_value(t);
-        cval = (int64_t)((uint64_t)hi.z | ((uint64_t)hi.w << 32));
-        return true;
-      }
+    if (done) return true;
+    if (!wait_on) { atomicOr(A.status, ST_FULL); return false; }
+    __builtin_amdgcn_wave_barrier();     // nothing of the wait moves in front of the loop exit
+    uint32_t sf = FIELD_PENDING, spins = 0;
+    do {
+      sf = __hip_atomic_load(&wait_on->field, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (sf != FIELD_PENDING) break;
+      __builtin_amdgcn_s_sleep(1);
+    } while (++spins < (1u << 22));
+    if (sf == FIELD_PENDING) { atomicOr(A.status, ST_SPIN); return false; }
+    if (sf == field) {   // the row is being created in this very batch: no pre-batch state
+      slot_out = s; is_new = true; cts = TS_NEW; cval = 0;
+      return true;
     }
-    ps.next();
+    ps.next(); ++p;      // another field of the same node: keep probing behind it
   }
-  atomicOr(A.status, ST_FULL);
+  atomicOr(A.status, ST_SPIN);
   return false;
 }
 

@@ -4,15 +4,28 @@
 //   k_vc_link    every delta finds/creates its row, claims it (one atomicExch) and links into the row's list
 //   k_vc_resolve the LAST claimer of a row applies the row's deltas in index order with the reference's resolve()
 //                (src/bullet-crt.js:164-279, general clocks), writes every delta's flags, the row's final state and the
-//                last updating delta; rows are written by exactly one lane, after every read of the launch pair
+//                last updating delta; rows are written by exactly one lane, after every read of the launch pair.
+//                The list is in claim order, not index order: a lane orders a short list (<= VC_SHORT deltas) by repeated
+//                selection; longer lists are queued for
+//   k_vc_resolve_long  one workgroup per long row: one walk gathers the member indices, a bitmap over the batch puts them in
+//                ascending order (O(n/32 + m), no comparison sort), the deltas are loaded 256 at a time by the whole workgroup
+//                and applied in order by one lane. Linear in the list length: 10^5 deltas on one key take tens of milliseconds
+//                (the dependent walk), not the hours a quadratic selection would.
 #pragma once
 #include "slot.h"
 #include "merge_kernels.h"
+#include "select.h"
 
 namespace bmx {
 
 constexpr int VC_MAXK = 8;
 constexpr uint32_t VC_ABSENT = 0, VC_DENSE = 1, VC_SPARSE = 2;
+constexpr uint32_t VC_SHORT = 16;        // lists up to this length are ordered by selection inside k_vc_resolve (<= 256 hops)
+constexpr uint32_t VC_LONG_WGS = 64;     // workgroups of k_vc_resolve_long (each owns one bitmap over the batch)
+constexpr uint32_t VC_QUEUED = 0xFFFFFFFEu;
+
+struct VcLongRow { uint32_t slot, head, m, base; };
+struct VcLongCtl { uint32_t n_rows, cursor; };
 
 struct alignas(64) VSlot {
   uint64_t id; uint32_t field; uint32_t head;
@@ -28,6 +41,9 @@ struct VcArgs {
   uint32_t* next; uint32_t* slot_of; uint8_t* wflag; uint8_t* flags; uint32_t* blk_info;
   unsigned long long* row_count; uint32_t* status;
   int load;   // 1: bulk preload (the highest-index delta of a key overwrites the row, dense)
+  VcLongCtl* lctl; VcLongRow* lrows; uint32_t lrows_cap;   // queue of rows whose list is longer than VC_SHORT
+  uint32_t* ord;                                           // member indices of the queued rows (segments of m entries)
+  uint32_t* bitmap; uint32_t bitmap_words;                 // VC_LONG_WGS bitmaps of ceil(n/32) words, all zero between uses
 };
 
 __global__ __launch_bounds__(256) void k_vc_init(VSlot* slots, uint64_t nslots) {
@@ -80,38 +96,57 @@ __global__ __launch_bounds__(256) void k_vc_link(VcArgs A) {
     if (valid) {
       const uint32_t tag = (A.epoch << IDX_BITS) | j;
       ProbeSeq<2> ps(id, field, A.nslots);
-      bool found = false;
-      for (uint64_t p = 0; p < A.nslots && !found; ++p) {
-        const uint64_t s = ps.slot();
-        VSlot* sl = A.slots + s;
-        uint4 lo = reinterpret_cast<const uint4*>(sl)[0];
-        uint64_t sid = (uint64_t)lo.x | ((uint64_t)lo.y << 32);
-        uint32_t sf = lo.z;
-        if (sid == EMPTY_ID) {
-          unsigned long long old = atomicCAS(reinterpret_cast<unsigned long long*>(&sl->id), (unsigned long long)EMPTY_ID, (unsigned long long)id);
-          if (old == EMPTY_ID) {   // created: one 8-byte store publishes the field and claims the head (see merge_kernels.h)
-            __hip_atomic_store(reinterpret_cast<unsigned long long*>(&sl->field), (unsigned long long)field | ((unsigned long long)tag << 32),
-                               __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            created = true; found = true; slot = (uint32_t)s;
-            break;
+      bool found = false, failed = false;
+      uint64_t p = 0;
+      // probe rounds: a lane that meets a slot of its node whose field is still unpublished leaves the probe loop and waits BEHIND the
+      // loop's exit, where the wave has reconverged and any sibling lane that created a slot has issued its publishing store
+      // (same structure and argument as probe_or_insert in merge_kernels.h)
+      for (uint32_t round = 0; round < 256 && !found && !failed; ++round) {
+        VSlot* wait_on = nullptr;
+        uint64_t s = 0;
+        for (; p < A.nslots; ++p) {
+          s = ps.slot();
+          VSlot* sl = A.slots + s;
+          uint4 lo = reinterpret_cast<const uint4*>(sl)[0];
+          uint64_t sid = (uint64_t)lo.x | ((uint64_t)lo.y << 32);
+          uint32_t sf = lo.z;
+          if (sid == EMPTY_ID) {
+            unsigned long long old = atomicCAS(reinterpret_cast<unsigned long long*>(&sl->id), (unsigned long long)EMPTY_ID, (unsigned long long)id);
+            if (old == EMPTY_ID) {   // created: one 8-byte store publishes the field and claims the head (see merge_kernels.h)
+              __hip_atomic_store(reinterpret_cast<unsigned long long*>(&sl->field), (unsigned long long)field | ((unsigned long long)tag << 32),
+                                 __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+              created = true; found = true; slot = (uint32_t)s;
+              break;
+            }
+            sid = old; sf = FIELD_PENDING;
           }
-          sid = old; sf = FIELD_PENDING;
+          if (sid == id) {
+            if (sf == FIELD_PENDING) { wait_on = sl; break; }
+            if (sf == field) {
+              uint32_t prev = atomicExch(&sl->head, tag);
+              if ((prev >> IDX_BITS) == A.epoch) A.next[j] = (A.epoch << IDX_BITS) | (prev & IDX_MASK);
+              found = true; slot = (uint32_t)s;
+              break;
+            }
+          }
+          ps.next();
         }
-        if (sid == id) {
-          if (sf == FIELD_PENDING) {
-            uint32_t spins = 0;
-            do { sf = __hip_atomic_load(&sl->field, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); if (sf != FIELD_PENDING) break; __builtin_amdgcn_s_sleep(1); } while (++spins < (1u << 22));
-            if (sf == FIELD_PENDING) { atomicOr(A.status, ST_SPIN); break; }
-          }
-          if (sf == field) {
-            uint32_t prev = atomicExch(&sl->head, tag);
-            if ((prev >> IDX_BITS) == A.epoch) A.next[j] = (A.epoch << IDX_BITS) | (prev & IDX_MASK);
-            found = true; slot = (uint32_t)s;
-            break;
-          }
+        if (found) break;
+        if (!wait_on) { failed = true; break; }
+        __builtin_amdgcn_wave_barrier();
+        uint32_t sf = FIELD_PENDING, spins = 0;
+        do { sf = __hip_atomic_load(&wait_on->field, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); if (sf != FIELD_PENDING) break; __builtin_amdgcn_s_sleep(1); } while (++spins < (1u << 22));
+        if (sf == FIELD_PENDING) { atomicOr(A.status, ST_SPIN); failed = true; slot = 0xFFFFFFFDu; break; }
+        if (sf == field) {
+          uint32_t prev = atomicExch(&wait_on->head, tag);
+          if ((prev >> IDX_BITS) == A.epoch) A.next[j] = (A.epoch << IDX_BITS) | (prev & IDX_MASK);
+          found = true; slot = (uint32_t)s;
+          break;
         }
-        ps.next();
+        ps.next(); ++p;
       }
+      if (slot == 0xFFFFFFFDu) slot = 0xFFFFFFFFu;
+      else
       if (!found && slot == 0xFFFFFFFFu) atomicOr(A.status, ST_FULL);
     }
     A.slot_of[j] = slot;
@@ -127,6 +162,7 @@ __global__ __launch_bounds__(256) void k_vc_link(VcArgs A) {
     uint32_t c = s_c[0] + s_c[1] + s_c[2] + s_c[3];
     if (c) atomicAdd(A.row_count, (unsigned long long)c);
     A.blk_info[blockIdx.x] = 0;
+    if (blockIdx.x == 0) { A.lctl->n_rows = 0; A.lctl->cursor = 0; }   // k_vc_resolve (the next launch) fills the queue
   }
 }
 
@@ -179,6 +215,17 @@ __device__ __forceinline__ uint32_t vc_resolve_row(const VcArgs& A, VSlot* sl, u
     for (int k = 0; k < VC_MAXK; k++) R.c[k] = ((uint32_t)k < A.K) ? A.clocks[(size_t)best * A.K + k] : 0u;
     R.val = A.val[best]; R.state = VC_DENSE; last_upd = best;
   } else {
+    // how long is the list? (one walk)
+    uint32_t m = 1;
+    { uint32_t idx = head; for (;;) { uint32_t nx = A.next[idx]; if ((nx >> IDX_BITS) != A.epoch) break; idx = nx & IDX_MASK; if (++m > A.n) { atomicOr(A.status, ST_SPIN); return ~0u; } } }
+    if (m > VC_SHORT) {
+      // long list: a workgroup of k_vc_resolve_long orders and applies it (selection by one lane would be quadratic)
+      const uint32_t e = atomicAdd(&A.lctl->n_rows, 1u);
+      if (e >= A.lrows_cap) { atomicOr(A.status, ST_SPIN); return ~0u; }   // cannot happen: a batch of n deltas has fewer than n/VC_SHORT long lists
+      const uint32_t base = atomicAdd(&A.lctl->cursor, m);
+      A.lrows[e] = VcLongRow{(uint32_t)(sl - A.slots), head, m, base};
+      return VC_QUEUED;
+    }
     // apply the row's deltas in index order: each round walks the list for the smallest index above the last one applied
     uint32_t done = 0, prev_idx = 0; bool first_round = true;
     for (uint32_t guard = 0; guard <= A.n; guard++) {
@@ -219,6 +266,7 @@ __global__ __launch_bounds__(256) void k_vc_resolve(VcArgs A) {
       VSlot* sl = A.slots + slot;
       const uint32_t head = __builtin_nontemporal_load(&sl->head) & IDX_MASK;
       if (head == j) last_upd = vc_resolve_row(A, sl, head);     // only the last claimer of a row works
+      if (last_upd == VC_QUEUED) last_upd = ~0u;                  // its winner mark comes from k_vc_resolve_long
     }
   }
   // winner marks + the per-256-delta counts k_compact_winners ranks with. Winners inside this block's own 256 deltas
@@ -228,6 +276,86 @@ __global__ __launch_bounds__(256) void k_vc_resolve(VcArgs A) {
   if (last_upd != ~0u && !own) atomicAdd(&A.blk_info[last_upd >> 8], 1u);
   const unsigned long long m = __ballot(own);
   if (lane_id() == 0 && m) atomicAdd(&A.blk_info[blockIdx.x], (uint32_t)__popcll(m));
+}
+
+// Long lists, one workgroup per row (fixed grid; workgroup w takes queue entries w, w + VC_LONG_WGS, ...).
+__global__ __launch_bounds__(256) void k_vc_resolve_long(VcArgs A) {
+  __shared__ uint32_t s_clk[256][VC_MAXK];
+  __shared__ int64_t s_val[256];
+  __shared__ uint32_t s_idx[256];
+  __shared__ uint8_t s_fl[256];
+  __shared__ uint32_t wsum[4];
+  const uint32_t nrows = min(A.lctl->n_rows, A.lrows_cap);
+  uint32_t* bm = A.bitmap + (size_t)blockIdx.x * A.bitmap_words;
+  for (uint32_t e = blockIdx.x; e < nrows; e += gridDim.x) {
+    const VcLongRow r = A.lrows[e];
+    uint32_t* ord = A.ord + r.base;
+    // 1. one walk: member indices in claim order
+    if (threadIdx.x == 0) {
+      uint32_t idx = r.head;
+      for (uint32_t i = 0; i < r.m; i++) { ord[i] = idx; const uint32_t nx = A.next[idx]; if ((nx >> IDX_BITS) != A.epoch) break; idx = nx & IDX_MASK; }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    // 2. ascending order through a bitmap over the batch (atomics execute at the memory side; the scan below reads past L1)
+    for (uint32_t i = threadIdx.x; i < r.m; i += 256) { const uint32_t idx = __builtin_nontemporal_load(&ord[i]); atomicOr(&bm[idx >> 5], 1u << (idx & 31u)); }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    const uint32_t per = (A.bitmap_words + 255u) / 256u;
+    const uint32_t w0 = min(A.bitmap_words, threadIdx.x * per), w1 = min(A.bitmap_words, w0 + per);
+    uint32_t cnt = 0;
+    for (uint32_t w = w0; w < w1; w++) cnt += __popc(__builtin_nontemporal_load(&bm[w]));
+    uint32_t tot;
+    uint32_t pos = block_excl_scan(cnt, tot, wsum);
+    for (uint32_t w = w0; w < w1; w++) {
+      uint32_t bits = __builtin_nontemporal_load(&bm[w]);
+      if (bits) atomicAnd(&bm[w], 0u);          // leave the bitmap zero for the next row
+      while (bits) { const int b = __ffs((int)bits) - 1; bits &= bits - 1; ord[pos++] = (w << 5) + (uint32_t)b; }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    // 3. apply in index order: the workgroup loads 256 deltas at a time, lane 0 runs resolve() over them
+    VcState R; uint32_t last_upd = ~0u;
+    VSlot* sl = A.slots + r.slot;
+    if (threadIdx.x == 0) {
+      const uint4* q = reinterpret_cast<const uint4*>(sl);
+      const uint4 mid = q[1], c0 = q[2], c1 = q[3];
+      R.val = (int64_t)((uint64_t)mid.x | ((uint64_t)mid.y << 32)); R.state = mid.z;
+      R.c[0] = c0.x; R.c[1] = c0.y; R.c[2] = c0.z; R.c[3] = c0.w; R.c[4] = c1.x; R.c[5] = c1.y; R.c[6] = c1.z; R.c[7] = c1.w;
+    }
+    for (uint32_t c0 = 0; c0 < tot; c0 += 256) {
+      const uint32_t i = c0 + threadIdx.x;
+      if (i < tot) {
+        const uint32_t idx = __builtin_nontemporal_load(&ord[i]);
+        s_idx[threadIdx.x] = idx; s_val[threadIdx.x] = A.val[idx];
+#pragma unroll
+        for (int k = 0; k < VC_MAXK; k++) s_clk[threadIdx.x][k] = ((uint32_t)k < A.K) ? A.clocks[(size_t)idx * A.K + k] : 0u;
+      }
+      __syncthreads();
+      if (threadIdx.x == 0) {
+        const uint32_t lim = min(256u, tot - c0);
+        for (uint32_t x = 0; x < lim; x++) {
+          uint32_t in[VC_MAXK];
+#pragma unroll
+          for (int k = 0; k < VC_MAXK; k++) in[k] = s_clk[x][k];
+          const uint32_t fl = vc_apply(R, in, s_val[x], A.K, A.local);
+          s_fl[x] = (uint8_t)fl;
+          if (fl & (BMX_FLAG_INCOMING | BMX_FLAG_CONCURRENT)) last_upd = s_idx[x];
+        }
+      }
+      __syncthreads();
+      if (i < tot && A.flags) A.flags[s_idx[threadIdx.x]] = s_fl[threadIdx.x];
+      __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+      uint4* w = reinterpret_cast<uint4*>(sl);
+      w[1] = make_uint4((uint32_t)(uint64_t)R.val, (uint32_t)((uint64_t)R.val >> 32), R.state, 0u);
+      w[2] = make_uint4(R.c[0], R.c[1], R.c[2], R.c[3]);
+      w[3] = make_uint4(R.c[4], R.c[5], R.c[6], R.c[7]);
+      if (last_upd != ~0u) { A.wflag[last_upd] = W_WINNER; atomicAdd(&A.blk_info[last_upd >> 8], 1u); }
+    }
+    __syncthreads();
+  }
 }
 
 __global__ __launch_bounds__(256) void k_vc_get(const VSlot* slots, uint64_t nslots, uint32_t n, uint32_t K, const uint64_t* id, const uint32_t* field,

@@ -50,3 +50,17 @@ def test_no_cpu_fallback_without_gpu(lib):
     with pytest.raises(bmx.BmxError) as ei:
         bmx.Engine(1000)
     assert ei.value.code == bmx.ERR_NO_DEVICE
+
+
+def test_oversize_tables_are_refused_before_any_device_work(lib):
+    """Slot indices in the per-batch workspace are 32-bit: a table that would need more than 2^32 slots (137 GB of 32-byte slots would
+    fit the 288 GB of HBM) is refused with BMX_ERR_INVALID, on any machine, instead of corrupting rows silently."""
+    import ctypes as C
+    h = C.c_void_p()
+    for cap, pct in ((1 << 31, 0), ((1 << 32) + 5, 90), (1 << 50, 50)):
+        rc = lib.bmx_create_ex(0, cap, pct, 0, C.byref(h))
+        assert rc == bmx.ERR_INVALID and not h.value, (cap, pct, rc)
+        assert b"2^32 slots" in lib.bmx_last_error(None)
+    assert lib.bmx_create_ex(0, 1000, 95, 0, C.byref(h)) == bmx.ERR_INVALID      # load factor out of range
+    assert lib.bmx_vc_create(0, 1 << 31, 3, 0, C.byref(h)) == bmx.ERR_INVALID
+    assert b"2^32 slots" in lib.bmx_vc_last_error(None)

@@ -342,3 +342,25 @@ def test_strict_flags_on_duplicate_heavy_batches(mode):
     with bmx.Engine(100) as e:
         with pytest.raises(bmx.BmxError):
             e.merge_batch([1], [F0], [1], [1], INSERT_REFERENCE | bmx.MERGE_STRICT_FLAGS | bmx.MERGE_UNIQUE_KEYS)
+
+
+@pytest.mark.parametrize("mode", [INSERT_REFERENCE, INSERT_DELTA])
+def test_same_new_key_on_every_lane_of_a_wave(mode):
+    """A wave whose 64 lanes all insert the SAME absent key (one lane creates the row, 63 wait for its field), with the shared key
+    starting at every lane position (the lanes before it carry distinct other keys), and a wave of 64 different fields of one new node
+    (the creators' slots lie on each other's probe paths). Checked against the oracle; a mis-ordered creator/waiter pair would end in
+    BMX_ERR_INTERNAL (bounded spin)."""
+    rng = np.random.default_rng(5)
+    o = Oracle()
+    with bmx.Engine(1 << 16) as e:
+        for pos in range(64):
+            ids = np.concatenate([synth.splitmix64_np(np.arange(10_000 * (pos + 1), 10_000 * (pos + 1) + pos, dtype=np.uint64)),
+                                  np.full(64 - pos, 7_000_000 + pos, np.uint64),
+                                  np.full(64, 9_000_000 + pos, np.uint64)])
+            fields = np.concatenate([np.full(64, F0, np.uint32), np.array([synth.field_hash(k) for k in range(64)], np.uint32)])
+            n = len(ids)
+            ts = rng.integers(0, 4, n); val = rng.integers(-2, 3, n)
+            applied, _, st = e.merge_batch(ids, fields, ts, val, mode)
+            _, ow = o.merge_batch(ids, fields, ts, val, mode)
+            assert np.array_equal(applied, ow), (mode, pos)
+        _assert_same_state(e, o)

@@ -182,3 +182,33 @@ def test_vc_device_pointer_batches_match_oracle():
         e.sync()
     assert ei.value.code == bmx.ERR_RANGE
     e.close()
+
+
+def test_vc_long_lists_are_linear_not_quadratic():
+    """10^5 deltas on ONE key plus a field of medium lists (17..400 deltas per key: just over the selection cut-off and well beyond):
+    the long-list path (k_vc_resolve_long) must give the reference's flags, updated index and final rows, and finish in bounded time
+    (a quadratic selection over 10^5 nodes would take minutes to hours of dependent loads)."""
+    import time
+    K, local = 3, 1
+    rng = np.random.default_rng(21)
+    n_hot = 100_000
+    keys_mid = np.array([keyid(1000 + i) for i in range(300)], np.uint64)
+    mult = rng.integers(17, 400, len(keys_mid))
+    ids = np.concatenate([np.full(n_hot, keyid(77), np.uint64), np.repeat(keys_mid, mult)])
+    perm = rng.permutation(len(ids))
+    ids = ids[perm]
+    n = len(ids)
+    fields = np.full(n, F0, np.uint32)
+    clocks = rng.integers(0, 6, (n, K)).astype(np.uint32); val = rng.integers(-3, 4, n).astype(np.int64)
+    e = bmx.EngineVC(4096, K, local); o = OracleVC(K, local)
+    for b in range(2):     # second batch: the rows exist
+        t0 = time.perf_counter()
+        f1, u1 = e.merge_batch(ids, fields, clocks, val)
+        dt = time.perf_counter() - t0
+        f2, u2 = o.merge_batch(ids, fields, clocks, val)
+        assert np.array_equal(f1, f2) and np.array_equal(u1, u2), b
+        assert dt < 5.0, "long-list batch took %.1f s" % dt
+        clocks = clocks + rng.integers(0, 2, (n, K)).astype(np.uint32)
+    allk = np.concatenate([[keyid(77)], keys_mid]).astype(np.uint64)
+    _compare_rows(e, o, allk, np.full(len(allk), F0, np.uint32))
+    e.close()
