@@ -20,7 +20,6 @@ INSERT_REFERENCE, INSERT_DELTA = 0, 1
 MERGE_UNIQUE_KEYS = 0x100
 MERGE_STRICT_FLAGS = 0x200
 MERGE_BUCKETED = 0x800
-CTX_ASYNC_COMPACT = 1
 CTX_FIXED_CAPACITY = 2
 CTX_BUCKETED_MERGE = 8
 FLAG_INCOMING, FLAG_CURRENT, FLAG_HISTORICAL = 1, 2, 4
@@ -31,6 +30,9 @@ EXPORTS = [
     "bmx_load_rows", "bmx_merge_batch", "bmx_merge_records", "bmx_get_rows", "bmx_get_row", "bmx_dump_rows", "bmx_row_count", "bmx_reserve",
     "bmx_index_build", "bmx_index_drop", "bmx_index_size", "bmx_scan_range", "bmx_scan_equals", "bmx_scan_count", "bmx_scan_filter",
     "bmx_owner_of", "bmx_partition_by_owner", "bmx_partition_by_owner_slabs", "bmx_timer_start", "bmx_timer_stop", "bmx_profile_enable", "bmx_profile_read", "bmx_profile_read_scan",
+    "bmx_comm_create", "bmx_comm_destroy", "bmx_comm_last_error", "bmx_comm_nshards", "bmx_comm_shard", "bmx_comm_sync", "bmx_comm_load_rows", "bmx_comm_merge",
+    "bmx_comm_merge_dev", "bmx_comm_shard_result", "bmx_comm_row_count", "bmx_comm_get_rows", "bmx_comm_dump_rows", "bmx_comm_index_build",
+    "bmx_comm_scan_range", "bmx_comm_scan_equals", "bmx_comm_scan_count", "bmx_comm_scan_filter",
     "bmx_vc_create", "bmx_vc_destroy", "bmx_vc_last_error", "bmx_vc_load_rows", "bmx_vc_merge_batch", "bmx_vc_get_rows", "bmx_vc_row_count", "bmx_vc_merge_batch_dev", "bmx_vc_set_stream", "bmx_vc_sync",
 ]
 
@@ -115,6 +117,24 @@ def load_library():
     L.bmx_profile_enable.argtypes = [vp, i32]; L.bmx_profile_enable.restype = i32
     L.bmx_profile_read.argtypes = [vp, C.POINTER(C.c_float), C.POINTER(u32)]; L.bmx_profile_read.restype = i32
     L.bmx_profile_read_scan.argtypes = [vp, C.POINTER(C.c_float), C.POINTER(u32)]; L.bmx_profile_read_scan.restype = i32
+    L.bmx_comm_create.argtypes = [u32, C.POINTER(C.c_int), u64, u32, C.POINTER(vp)]; L.bmx_comm_create.restype = i32
+    L.bmx_comm_destroy.argtypes = [vp]; L.bmx_comm_destroy.restype = None
+    L.bmx_comm_last_error.argtypes = [vp]; L.bmx_comm_last_error.restype = C.c_char_p
+    L.bmx_comm_nshards.argtypes = [vp]; L.bmx_comm_nshards.restype = u32
+    L.bmx_comm_shard.argtypes = [vp, u32]; L.bmx_comm_shard.restype = vp
+    L.bmx_comm_sync.argtypes = [vp]; L.bmx_comm_sync.restype = i32
+    L.bmx_comm_load_rows.argtypes = [vp, u64, vp, vp, vp, vp]; L.bmx_comm_load_rows.restype = i32
+    L.bmx_comm_merge.argtypes = [vp, u64, vp, vp, vp, vp, i32, vp, vp, vp]; L.bmx_comm_merge.restype = i32
+    L.bmx_comm_merge_dev.argtypes = [vp, vp, vp, vp, vp, vp, i32, u64]; L.bmx_comm_merge_dev.restype = i32
+    L.bmx_comm_shard_result.argtypes = [vp, u32, C.POINTER(vp), C.POINTER(vp), C.POINTER(vp), C.POINTER(vp), C.POINTER(u64)]; L.bmx_comm_shard_result.restype = i32
+    L.bmx_comm_row_count.argtypes = [vp, C.POINTER(u64)]; L.bmx_comm_row_count.restype = i32
+    L.bmx_comm_get_rows.argtypes = [vp, u64, vp, vp, vp, vp, vp]; L.bmx_comm_get_rows.restype = i32
+    L.bmx_comm_dump_rows.argtypes = [vp, u64, vp, vp, vp, vp, C.POINTER(u64)]; L.bmx_comm_dump_rows.restype = i32
+    L.bmx_comm_index_build.argtypes = [vp, u32]; L.bmx_comm_index_build.restype = i32
+    L.bmx_comm_scan_range.argtypes = [vp, u32, i64, i64, vp, u64, C.POINTER(u64)]; L.bmx_comm_scan_range.restype = i32
+    L.bmx_comm_scan_equals.argtypes = [vp, u32, i64, vp, u64, C.POINTER(u64)]; L.bmx_comm_scan_equals.restype = i32
+    L.bmx_comm_scan_count.argtypes = [vp, u32, i64, i64, C.POINTER(u64)]; L.bmx_comm_scan_count.restype = i32
+    L.bmx_comm_scan_filter.argtypes = [vp, u32, C.POINTER(Term), vp, u64, C.POINTER(u64)]; L.bmx_comm_scan_filter.restype = i32
     L.bmx_vc_create.argtypes = [i32, u64, u32, u32, C.POINTER(vp)]; L.bmx_vc_create.restype = i32
     L.bmx_vc_destroy.argtypes = [vp]; L.bmx_vc_destroy.restype = None
     L.bmx_vc_last_error.argtypes = [vp]; L.bmx_vc_last_error.restype = C.c_char_p
@@ -322,6 +342,122 @@ class Engine:
         ms = C.c_float()
         self._chk(self.L.bmx_timer_stop(self.h, C.byref(ms)))
         return ms.value
+
+
+class Comm:
+    """N shards in one process (a bmx_comm): the graph split by node-id hash over N contexts. devices may repeat a GPU (logical shards)."""
+
+    def __init__(self, devices, capacity_rows_per_shard, flags=0):
+        self.L = load_library()
+        self.N = len(devices)
+        arr = (C.c_int * self.N)(*[int(d) for d in devices])
+        h = C.c_void_p()
+        rc = self.L.bmx_comm_create(self.N, arr, int(capacity_rows_per_shard), int(flags) | DEFAULT_CTX_FLAGS, C.byref(h))
+        if rc != OK:
+            raise BmxError(rc, (self.L.bmx_comm_last_error(None) or b"").decode())
+        self.h = h
+
+    def _chk(self, rc):
+        if rc < 0:
+            raise BmxError(rc, (self.L.bmx_comm_last_error(self.h) or b"").decode())
+        return rc
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.L.bmx_comm_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
+
+    def sync(self):
+        self._chk(self.L.bmx_comm_sync(self.h))
+
+    def load_rows(self, id, field, ts, val):
+        id, field, ts, val = _np(id, np.uint64), _np(field, np.uint32), _np(ts, np.int64), _np(val, np.int64)
+        self._chk(self.L.bmx_comm_load_rows(self.h, len(id), _ptr(id), _ptr(field), _ptr(ts), _ptr(val)))
+
+    def merge(self, id, field, ts, val, insert_mode=INSERT_REFERENCE):
+        """host batch -> (applied_idx u32[w] ascending indices into the batch, MergeStats summed over the shards)"""
+        id, field, ts, val = _np(id, np.uint64), _np(field, np.uint32), _np(ts, np.int64), _np(val, np.int64)
+        n = len(id)
+        applied = np.zeros(max(n, 1), np.uint32)
+        na = C.c_uint64(0)
+        st = MergeStats()
+        self._chk(self.L.bmx_comm_merge(self.h, n, _ptr(id), _ptr(field), _ptr(ts), _ptr(val), int(insert_mode), _ptr(applied),
+                                        C.cast(C.byref(na), C.c_void_p), C.cast(C.byref(st), C.c_void_p)))
+        return applied[:na.value].copy(), st
+
+    def merge_dev(self, batches, insert_mode=INSERT_REFERENCE, slab_records=0):
+        """batches[i] = (n, id, field, ts, val): device tensors on shard i's GPU, the deltas shard i originates. Enqueue-only."""
+        N = self.N
+        assert len(batches) == N
+        ns = (C.c_uint64 * N)(*[int(b[0]) for b in batches])
+        cols = [(C.c_void_p * N)(*[(b[1 + k].data_ptr() if b[0] else 0) for b in batches]) for k in range(4)]
+        self._chk(self.L.bmx_comm_merge_dev(self.h, ns, cols[0], cols[1], cols[2], cols[3], int(insert_mode), int(slab_records)))
+
+    def shard_result(self, g):
+        """-> (recs_ptr, applied_ptr, n_applied_ptr, stats_ptr, n_records): raw device addresses of shard g's last device step"""
+        r, a, n, s = C.c_void_p(), C.c_void_p(), C.c_void_p(), C.c_void_p()
+        m = C.c_uint64()
+        self._chk(self.L.bmx_comm_shard_result(self.h, int(g), C.byref(r), C.byref(a), C.byref(n), C.byref(s), C.byref(m)))
+        return r.value, a.value, n.value, s.value, m.value
+
+    def row_count(self):
+        n = C.c_uint64()
+        self._chk(self.L.bmx_comm_row_count(self.h, C.byref(n)))
+        return n.value
+
+    def get_rows(self, id, field):
+        id, field = _np(id, np.uint64), _np(field, np.uint32)
+        n = len(id)
+        ts = np.zeros(n, np.int64); val = np.zeros(n, np.int64); found = np.zeros(n, np.uint8)
+        self._chk(self.L.bmx_comm_get_rows(self.h, n, _ptr(id), _ptr(field), _ptr(ts), _ptr(val), _ptr(found)))
+        return ts, val, found.astype(bool)
+
+    def dump_rows(self):
+        n = self.row_count()
+        id = np.zeros(n, np.uint64); field = np.zeros(n, np.uint32); ts = np.zeros(n, np.int64); val = np.zeros(n, np.int64)
+        m = C.c_uint64()
+        self._chk(self.L.bmx_comm_dump_rows(self.h, n, _ptr(id), _ptr(field), _ptr(ts), _ptr(val), C.byref(m)))
+        assert m.value == n
+        return id, field, ts, val
+
+    def index_build(self, field):
+        self._chk(self.L.bmx_comm_index_build(self.h, int(field)))
+
+    def scan_count(self, field, lo, hi):
+        m = C.c_uint64()
+        self._chk(self.L.bmx_comm_scan_count(self.h, int(field), int(lo), int(hi), C.byref(m)))
+        return m.value
+
+    def scan_range(self, field, lo, hi):
+        cap = self.scan_count(field, lo, hi)
+        out = np.zeros(max(cap, 1), np.uint64)
+        m = C.c_uint64()
+        self._chk(self.L.bmx_comm_scan_range(self.h, int(field), int(lo), int(hi), _ptr(out), cap, C.byref(m)))
+        return out[:min(m.value, cap)].copy()
+
+    def scan_equals(self, field, value):
+        return self.scan_range(field, value, value)
+
+    def scan_filter(self, terms):
+        arr = (Term * len(terms))(*[Term(int(f), 0, int(lo), int(hi)) for f, lo, hi in terms])
+        m = C.c_uint64()
+        self._chk(self.L.bmx_comm_scan_filter(self.h, len(terms), arr, None, 0, C.byref(m)))
+        cap = m.value
+        out = np.zeros(max(cap, 1), np.uint64)
+        self._chk(self.L.bmx_comm_scan_filter(self.h, len(terms), arr, _ptr(out), cap, C.byref(m)))
+        return out[:min(m.value, cap)].copy()
 
 
 FLAG_CONCURRENT = 8

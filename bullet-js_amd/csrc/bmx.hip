@@ -57,7 +57,7 @@ struct bmx_ctx {
   uint32_t* next = nullptr;
   uint8_t* wflag = nullptr;
   uint32_t* slot_of = nullptr;
-  uint32_t* blk_info = nullptr;       // ws_cap/256 block summaries (second set right behind the first for async compaction)
+  uint32_t* blk_info = nullptr;       // ws_cap/256 block summaries
   uint32_t* blk_follow = nullptr;     // ws_cap/256 epoch tags: a delta of the block got a follower on its row
   unsigned long long* shard_ctr = nullptr;  // CTR_SHARDS * CTR_STRIDE
   // default merge path (bin_kernels.h): the batch regrouped by bin, tile by tile
@@ -73,15 +73,7 @@ struct bmx_ctx {
   uint32_t* scan_mask = nullptr;      // scan scratch: one match bit per index row
   uint32_t* scan_counts = nullptr;    // scan scratch: matches per 8192-row block (+ total)
   uint64_t scan_blocks_cap = 0;
-  // BMX_CTX_ASYNC_COMPACT: K3 of batch b runs on `side` while K1 of batch b+1 runs on `stream`
   bool fixed_capacity = false;
-  bool async_compact = false;
-  hipStream_t side = nullptr;
-  uint8_t* wflag2 = nullptr;                  // second winner-byte buffer
-  unsigned long long* shard_ctr2 = nullptr;   // second counter set
-  hipEvent_t ev_k2[2] = {nullptr, nullptr};   // main: K2 of the batch using buffer i is done
-  hipEvent_t ev_k3[2] = {nullptr, nullptr};   // side: K3 of the batch using buffer i is done
-  bool k3_pending[2] = {false, false};
   uint64_t nbatch = 0;
   uint32_t* part_counts = nullptr;    // PART_MAX_SHARDS * PART_BLOCKS
   uint8_t* part_owner = nullptr;      // owner shard of every delta of the batch being partitioned
@@ -137,21 +129,8 @@ void dev_free(T*& p) {
   p = nullptr;
 }
 
-// Make the main stream (and the host, if asked) see everything the side stream has produced.
-int join_side(bmx_ctx* ctx, bool host_sync) {
-  if (!ctx->async_compact) return BMX_OK;
-  for (int i = 0; i < 2; i++)
-    if (ctx->k3_pending[i]) {
-      HIPCHK(hipStreamWaitEvent(ctx->stream, ctx->ev_k3[i], 0));
-      ctx->k3_pending[i] = false;
-    }
-  if (host_sync) HIPCHK(hipStreamSynchronize(ctx->side));
-  return BMX_OK;
-}
-
 // Pull the sticky device status; translate to an error code.
 int check_status(bmx_ctx* ctx) {
-  { int rcj = join_side(ctx, true); if (rcj) return rcj; }
   uint32_t st = 0;
   HIPCHK(hipMemcpyAsync(&st, &ctx->ds->status, sizeof(st), hipMemcpyDeviceToHost, ctx->stream));
   HIPCHK(hipStreamSynchronize(ctx->stream));
@@ -164,7 +143,6 @@ int check_status(bmx_ctx* ctx) {
 }
 
 int refresh_rows(bmx_ctx* ctx) {
-  { int rcj = join_side(ctx, true); if (rcj) return rcj; }
   unsigned long long r = 0;
   HIPCHK(hipMemcpyAsync(&r, &ctx->ds->row_count, sizeof(r), hipMemcpyDeviceToHost, ctx->stream));
   HIPCHK(hipStreamSynchronize(ctx->stream));
@@ -178,13 +156,11 @@ int ensure_workspace(bmx_ctx* ctx, uint64_t n) {
   uint64_t cap = std::max<uint64_t>(n, std::min<uint64_t>((uint64_t)ctx->ws_cap * 2, MAX_BATCH));
   cap = std::max<uint64_t>(cap, 1u << 16);
   cap = (cap + 255) & ~255ull;
-  { int rcj = join_side(ctx, true); if (rcj) return rcj; }
-  dev_free(ctx->next); dev_free(ctx->wflag); dev_free(ctx->wflag2); dev_free(ctx->slot_of); dev_free(ctx->blk_info); dev_free(ctx->blk_follow);
+  dev_free(ctx->next); dev_free(ctx->wflag); dev_free(ctx->slot_of); dev_free(ctx->blk_info); dev_free(ctx->blk_follow);
   ctx->ws_cap = 0;
   int rc;
   if ((rc = dev_alloc(ctx, &ctx->next, cap)) || (rc = dev_alloc(ctx, &ctx->wflag, cap + 16)) || (rc = dev_alloc(ctx, &ctx->slot_of, cap))) return rc;
-  if (ctx->async_compact && (rc = dev_alloc(ctx, &ctx->wflag2, cap + 16))) return rc;
-  if ((rc = dev_alloc(ctx, &ctx->blk_info, 2 * (cap / 256 + 16))) || (rc = dev_alloc(ctx, &ctx->blk_follow, cap / 256 + 16))) return rc;
+  if ((rc = dev_alloc(ctx, &ctx->blk_info, cap / 256 + 16)) || (rc = dev_alloc(ctx, &ctx->blk_follow, cap / 256 + 16))) return rc;
   HIPCHK(hipMemsetAsync(ctx->next, 0, cap * sizeof(uint32_t), ctx->stream));
   HIPCHK(hipMemsetAsync(ctx->blk_follow, 0, (cap / 256 + 16) * sizeof(uint32_t), ctx->stream));
   ctx->ws_cap = (uint32_t)cap;
@@ -195,7 +171,6 @@ int ensure_bins(bmx_ctx* ctx, uint64_t n) {
   const uint32_t tiles = (uint32_t)((n + BK_TILE - 1) / BK_TILE);
   if (tiles <= ctx->bin_tiles_cap) return BMX_OK;
   HIPCHK(hipStreamSynchronize(ctx->stream));
-  { int rcj = join_side(ctx, true); if (rcj) return rcj; }
   const uint32_t cap = std::max<uint32_t>(tiles, std::min<uint32_t>(ctx->bin_tiles_cap * 2, MAX_BATCH / BK_TILE));
   dev_free(ctx->bin_stage); dev_free(ctx->bin_toff);
   ctx->bin_tiles_cap = 0;
@@ -232,8 +207,7 @@ uint64_t slots_for(uint64_t capacity_rows, uint32_t load_pct) {
 // Rehash into a table for `capacity_rows` rows. Synchronous.
 int grow_table(bmx_ctx* ctx, uint64_t capacity_rows) {
   if (capacity_rows <= ctx->capacity_rows) return BMX_OK;
-  int rc = join_side(ctx, true);
-  if (rc) return rc;
+  int rc;
   HIPCHK(hipStreamSynchronize(ctx->stream));
   const uint64_t nslots = slots_for(capacity_rows, ctx->load_pct);
   if (!nslots) return fail(ctx, BMX_ERR_INVALID, "table would need more than 2^32 slots (slot indices are 32-bit): shard the graph over more contexts");
@@ -289,21 +263,15 @@ int merge_core(bmx_ctx* ctx, uint64_t n, const uint64_t* id, const uint32_t* fie
     HIPCHK(hipMemsetAsync(ctx->blk_follow, 0, ((size_t)ctx->ws_cap / 256 + 16) * sizeof(uint32_t), ctx->stream));
     ctx->epoch = 1;
   }
-  // double buffering for the asynchronous compaction: batch b uses buffer b&1
-  const int bi = ctx->async_compact ? (int)(ctx->nbatch & 1) : 0;
-  uint8_t* wflag = bi ? ctx->wflag2 : ctx->wflag;
-  unsigned long long* ctr = bi ? ctx->shard_ctr2 : ctx->shard_ctr;
-  if (ctx->async_compact && ctx->k3_pending[bi]) {   // the compaction that last read this buffer must be done
-    HIPCHK(hipStreamWaitEvent(ctx->stream, ctx->ev_k3[bi], 0));
-    ctx->k3_pending[bi] = false;
-  }
+  uint8_t* wflag = ctx->wflag;
+  unsigned long long* ctr = ctx->shard_ctr;
   MergeArgs A;
   A.slots = ctx->slots; A.nslots = ctx->nslots;
   A.id = id; A.field = field; A.ts = ts; A.val = val; A.recs = recs;
   A.n = (uint32_t)n; A.epoch = ctx->epoch;
   A.next = ctx->next; A.wflag = wflag; A.flags = flags;
   A.slot_of = ctx->slot_of; A.blk_follow = ctx->blk_follow; A.shard_ctr = ctr; A.status = &ctx->ds->status;
-  A.blk_info = ctx->blk_info + (bi ? (ctx->ws_cap / 256 + 16) : 0);
+  A.blk_info = ctx->blk_info;
   const uint32_t blocks = (uint32_t)((n + 255) / 256);
   const uint32_t rblocks = blocks;   // one lane per delta
   hipEvent_t* pe = (ctx->prof_on && ctx->prof_n < PROF_MAX_CALLS) ? &ctx->prof_ev[4 * ctx->prof_n] : nullptr;
@@ -355,21 +323,12 @@ int merge_core(bmx_ctx* ctx, uint64_t n, const uint64_t* id, const uint32_t* fie
   LAUNCHCHK("k_resolve_lists");
   if (pe) HIPCHK(hipEventRecord(pe[2], ctx->stream));
   }
-  // K3: ordered compaction of the winner bytes (on the side stream when asynchronous compaction is on)
+  // K3: ordered compaction of the winner bytes
   hipStream_t ks = ctx->stream;
-  if (ctx->async_compact) {
-    HIPCHK(hipEventRecord(ctx->ev_k2[bi], ctx->stream));
-    HIPCHK(hipStreamWaitEvent(ctx->side, ctx->ev_k2[bi], 0));
-    ks = ctx->side;
-  }
   FinishMerge Fin{reinterpret_cast<unsigned long long*>(n_applied), stats, ctr, &ctx->ds->row_count};
   hipLaunchKernelGGL((k_compact_winners<FinishMerge>), dim3((uint32_t)((n + 4095) / 4096)), dim3(SEL_THREADS), 0, ks, wflag, A.blk_info, (uint32_t)n,
                      applied_idx, Fin);
   LAUNCHCHK("k_compact_winners");
-  if (ctx->async_compact) {
-    HIPCHK(hipEventRecord(ctx->ev_k3[bi], ctx->side));
-    ctx->k3_pending[bi] = true;
-  }
   if (pe) { HIPCHK(hipEventRecord(pe[3], ks)); ctx->prof_n++; }
   ctx->nbatch++;
   ctx->rows_ub += n;
@@ -390,7 +349,6 @@ int merge_host(bmx_ctx* ctx, uint64_t n, const uint64_t* id, const uint32_t* fie
   rc = merge_core<false>(ctx, n, ctx->st_id, ctx->st_field, ctx->st_ts, ctx->st_val, nullptr, insert_mode, ctx->st_applied,
                          reinterpret_cast<uint64_t*>(&ctx->ds->n_out), flags ? ctx->st_flags : nullptr, &ctx->ds->stats);
   if (rc) return rc;
-  if ((rc = join_side(ctx, false))) return rc;
   bmx_merge_stats hs;
   HIPCHK(hipMemcpyAsync(&hs, &ctx->ds->stats, sizeof(hs), hipMemcpyDeviceToHost, ctx->stream));
   HIPCHK(hipStreamSynchronize(ctx->stream));
@@ -602,13 +560,6 @@ int bmx_create_ex(int device, uint64_t capacity_rows, uint32_t max_load_pct, uin
   CR(hipMemsetAsync(ctx->shard_ctr, 0, CTR_SHARDS * CTR_STRIDE * sizeof(unsigned long long), ctx->stream));
   ctx->fixed_capacity = (flags & BMX_CTX_FIXED_CAPACITY) != 0;
   ctx->bucketed_default = (flags & BMX_CTX_BUCKETED_MERGE) != 0;
-  if (flags & BMX_CTX_ASYNC_COMPACT) {
-    ctx->async_compact = true;
-    CR(hipStreamCreateWithFlags(&ctx->side, hipStreamNonBlocking));
-    for (int i = 0; i < 2; i++) { CR(hipEventCreateWithFlags(&ctx->ev_k2[i], hipEventDisableTiming)); CR(hipEventCreateWithFlags(&ctx->ev_k3[i], hipEventDisableTiming)); }
-    if ((rc = dev_alloc(ctx, &ctx->shard_ctr2, CTR_SHARDS * CTR_STRIDE))) return bail(rc);
-    CR(hipMemsetAsync(ctx->shard_ctr2, 0, CTR_SHARDS * CTR_STRIDE * sizeof(unsigned long long), ctx->stream));
-  }
   CR(hipMemsetAsync(ctx->ds, 0, sizeof(DevScalars), ctx->stream));
   hipLaunchKernelGGL(k_init_slots, dim3(2048), dim3(256), 0, ctx->stream, ctx->slots, nslots);
   CR(hipGetLastError());
@@ -622,10 +573,6 @@ void bmx_destroy(bmx_ctx* ctx) {
   if (!ctx) return;
   (void)hipSetDevice(ctx->device);
   if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
-  if (ctx->side) (void)hipStreamSynchronize(ctx->side);
-  dev_free(ctx->wflag2); dev_free(ctx->shard_ctr2);
-  for (int i = 0; i < 2; i++) { if (ctx->ev_k2[i]) (void)hipEventDestroy(ctx->ev_k2[i]); if (ctx->ev_k3[i]) (void)hipEventDestroy(ctx->ev_k3[i]); }
-  if (ctx->side) (void)hipStreamDestroy(ctx->side);
   for (auto& ix : ctx->indexes) { dev_free(ix.ids); dev_free(ix.v64); dev_free(ix.v32); }
   dev_free(ctx->slots); dev_free(ctx->ds); dev_free(ctx->next); dev_free(ctx->wflag); dev_free(ctx->slot_of); dev_free(ctx->blk_info); dev_free(ctx->blk_follow); dev_free(ctx->shard_ctr);
   dev_free(ctx->st_id); dev_free(ctx->st_field); dev_free(ctx->st_ts); dev_free(ctx->st_val); dev_free(ctx->st_applied); dev_free(ctx->st_flags);
@@ -875,11 +822,14 @@ int bmx_scan_filter(bmx_ctx* ctx, uint32_t nterms, const bmx_term* terms, uint64
 }
 
 static int partition_impl(bmx_ctx* ctx, uint64_t n, const uint64_t* id, const uint32_t* field, const int64_t* ts, const int64_t* val,
-                          uint32_t nshards, uint64_t slab, bmx_delta_rec* recs_out, uint64_t* counts_out_dev) {
+                          uint32_t nshards, uint64_t slab, bmx_delta_rec* recs_out, uint64_t* counts_out_dev, const PartOut* split = nullptr, uint32_t aux_base = 0) {
   if (!ctx) return fail(nullptr, BMX_ERR_INVALID, "null context");
   if (nshards == 0 || nshards > PART_MAX_SHARDS || n > 0xFFFFFFFFull || !counts_out_dev || slab * nshards > 0xFFFFFFFFull)
     return fail(ctx, BMX_ERR_INVALID, "bad arguments (1..16 shards)");
-  if (n && (!id || !field || !ts || !val || !recs_out)) return fail(ctx, BMX_ERR_INVALID, "null pointer");
+  if (n && (!id || !field || !ts || !val || (!recs_out && !split))) return fail(ctx, BMX_ERR_INVALID, "null pointer");
+  PartOut po;
+  if (split) po = *split; else std::memset(&po, 0, sizeof(po));
+  po.split = split ? 1u : 0u; po.aux_base = aux_base;
   HIPCHK(hipSetDevice(ctx->device));
   uint32_t per_block = (uint32_t)((n + PART_BLOCKS - 1) / PART_BLOCKS);
   per_block = std::max<uint32_t>(PART_TILE, (per_block + PART_TILE - 1) / PART_TILE * PART_TILE);
@@ -893,7 +843,7 @@ static int partition_impl(bmx_ctx* ctx, uint64_t n, const uint64_t* id, const ui
   hipLaunchKernelGGL(k_part_count, dim3(PART_BLOCKS), dim3(256), 0, ctx->stream, id, (uint32_t)n, nshards, per_block, ctx->part_counts, ctx->part_owner);
   LAUNCHCHK("k_part_count");
   hipLaunchKernelGGL(k_part_scatter, dim3(PART_BLOCKS), dim3(256), 0, ctx->stream, id, field, ts, val, (const uint8_t*)ctx->part_owner, (uint32_t)n, nshards, per_block, ctx->part_counts,
-                     recs_out, reinterpret_cast<unsigned long long*>(counts_out_dev), (uint32_t)slab, &ctx->ds->status);
+                     recs_out, reinterpret_cast<unsigned long long*>(counts_out_dev), (uint32_t)slab, &ctx->ds->status, po);
   LAUNCHCHK("k_part_scatter");
   return BMX_OK;
 }
@@ -916,7 +866,6 @@ int bmx_timer_start(bmx_ctx* ctx) {
 }
 int bmx_timer_stop(bmx_ctx* ctx, float* ms_out) {
   if (!ctx || !ms_out) return fail(ctx, BMX_ERR_INVALID, "bad arguments");
-  { int rcj = join_side(ctx, false); if (rcj) return rcj; }   // the stop event also covers compactions still running on the side stream
   HIPCHK(hipEventRecord(ctx->ev1, ctx->stream));
   HIPCHK(hipEventSynchronize(ctx->ev1));
   HIPCHK(hipEventElapsedTime(ms_out, ctx->ev0, ctx->ev1));
@@ -942,7 +891,6 @@ int bmx_profile_enable(bmx_ctx* ctx, int on) {
 int bmx_profile_read(bmx_ctx* ctx, float ms_out[3], uint32_t* n_calls) {
   if (!ctx || !ms_out || !n_calls) return fail(ctx, BMX_ERR_INVALID, "bad arguments");
   HIPCHK(hipSetDevice(ctx->device));
-  { int rcj = join_side(ctx, true); if (rcj) return rcj; }
   HIPCHK(hipStreamSynchronize(ctx->stream));
   double acc[3] = {0, 0, 0};
   for (uint32_t i = 0; i < ctx->prof_n; i++)
@@ -977,3 +925,4 @@ int bmx_profile_read_scan(bmx_ctx* ctx, float ms_out[2], uint32_t* n_calls) {
 }  // extern "C"
 
 #include "bmx_vc.inc"
+#include "bmx_comm.inc"

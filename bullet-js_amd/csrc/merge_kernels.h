@@ -520,6 +520,14 @@ __global__ void k_seq_wait(const unsigned long long* seq, unsigned long long at_
 constexpr int PART_MAX_SHARDS = 16;
 constexpr int PART_BLOCKS = 1024;
 constexpr uint32_t PART_TILE = 1024;   // deltas staged in LDS per step of k_part_scatter; per_block is a multiple of it
+// Where the records of each shard go. Default: one buffer, shard g's run (or slab) at its offset. With `split` set, shard g's slab
+// starts at base[g] instead — a pointer into the RECEIVE slabs of the shard that owns g, possibly peer-mapped memory of another GPU:
+// the owner partition then scatters straight into its peers' receive buffers and no copy kernel runs afterwards (bmx_comm_*).
+struct PartOut {
+  bmx_delta_rec* base[PART_MAX_SHARDS];
+  uint32_t split;
+  uint32_t aux_base;     // added to the origin index carried in `aux` (offset of this originator's slice in a global batch)
+};
 
 __device__ __forceinline__ uint32_t owner_of_dev(uint64_t id, uint32_t nshards) { return (uint32_t)__umul64hi(owner_hash(id), (uint64_t)nshards); }
 
@@ -549,7 +557,7 @@ __global__ __launch_bounds__(256) void k_part_count(const uint64_t* id, uint32_t
 // are read with computed addresses, and the copy-out walks one shard's run at a time.
 __global__ __launch_bounds__(256) void k_part_scatter(const uint64_t* id, const uint32_t* field, const int64_t* ts, const int64_t* val,
                                                       const uint8_t* owner, uint32_t n, uint32_t nshards, uint32_t per_block, const uint32_t* counts,
-                                                      bmx_delta_rec* out, unsigned long long* totals, uint32_t slab, uint32_t* status) {
+                                                      bmx_delta_rec* out, unsigned long long* totals, uint32_t slab, uint32_t* status, PartOut po) {
   __shared__ uint32_t base[PART_MAX_SHARDS];       // running output cursor of this block per shard
   __shared__ uint32_t tot[PART_MAX_SHARDS];        // shard totals over the whole batch
   __shared__ uint32_t red[PART_MAX_SHARDS][2];
@@ -636,14 +644,14 @@ __global__ __launch_bounds__(256) void k_part_scatter(const uint64_t* id, const 
     for (int i = 0; i < 4; i++) {
       if (g[i] != 0xFFu) {
         const uint32_t p = F[g[i] * 16 + (uint32_t)i * 4u + w] + rk[i];
-        stage[2 * p] = make_uint4((uint32_t)kid[i], (uint32_t)(kid[i] >> 32), rf[i], t0 + (uint32_t)i * 256u + threadIdx.x);
+        stage[2 * p] = make_uint4((uint32_t)kid[i], (uint32_t)(kid[i] >> 32), rf[i], po.aux_base + t0 + (uint32_t)i * 256u + threadIdx.x);
         stage[2 * p + 1] = make_uint4((uint32_t)rt[i], (uint32_t)(rt[i] >> 32), (uint32_t)rv[i], (uint32_t)(rv[i] >> 32));
       }
     }
     __syncthreads();
-    uint4* out16 = reinterpret_cast<uint4*>(out);
     for (uint32_t gg = 0; gg < nshards; gg++) {    // one shard's run at a time: consecutive lanes on consecutive 16-byte halves
       const uint32_t s0 = F[gg * 16], e0 = F[(gg + 1) * 16], b = base[gg];
+      uint4* out16 = po.split ? reinterpret_cast<uint4*>(po.base[gg]) - 2 * (size_t)gg * slab : reinterpret_cast<uint4*>(out);
       for (uint32_t q = 2 * s0 + threadIdx.x; q < 2 * e0; q += 256) {
         const uint32_t pos = b + ((q >> 1) - s0);
         if (!slab || pos - gg * slab < slab)        // a slab overflow drops the record; totals[] tells the caller
@@ -659,7 +667,7 @@ __global__ __launch_bounds__(256) void k_part_scatter(const uint64_t* id, const 
     for (uint32_t g = 0; g < nshards; g++) {
       uint32_t used = min(tot[g], slab);
       for (uint32_t p = used + blockIdx.x * 256u + threadIdx.x; p < slab; p += PART_BLOCKS * 256u) {
-        uint4* q = reinterpret_cast<uint4*>(out + (size_t)g * slab + p);
+        uint4* q = reinterpret_cast<uint4*>((po.split ? po.base[g] : out + (size_t)g * slab) + p);
         q[0] = padlo; q[1] = padhi;
       }
     }

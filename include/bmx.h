@@ -113,9 +113,6 @@ typedef struct bmx_info {
 #define BMX_CTX_FIXED_CAPACITY 2u /* never grow: a batch that would exceed capacity_rows fails with BMX_ERR_FULL.
                                      Default: the table is rehashed into one twice as large (synchronous, on device). */
 #define BMX_CTX_BUCKETED_MERGE 8u /* every merge of this context takes the bucketed path (see BMX_MERGE_BUCKETED) */
-#define BMX_CTX_ASYNC_COMPACT 1u  /* run the winner compaction of batch b on a second stream, under the probe kernel of
-                                     batch b+1 (double-buffered winner bytes). Outputs of a merge call (applied_idx,
-                                     n_applied, stats) are then valid only after bmx_sync(), not in stream order. */
 
 /* ---- lifetime -------------------------------------------------------------------------------
  * Replaces `new BulletCRT(bullet)` src/bullet-crt.js:6-16 / `new BulletQuery(bullet)`
@@ -224,11 +221,56 @@ int bmx_partition_by_owner(bmx_ctx* ctx, uint64_t n, const uint64_t* id, const u
  * is padding (id = 0xFFFFFFFFFFFFFFFF, skipped by bmx_merge_records), so the exchange can use equal splits and
  * needs no host round trip for counts. recs_out has nshards*slab_records records. counts_out_dev[g] is the TRUE
  * count: if it exceeds slab_records the surplus records of that shard were NOT written and the caller must
- * re-route the batch with bmx_partition_by_owner (merging is idempotent, so re-sending is safe). The overflow is also
+ * re-route the batch with bmx_partition_by_owner (re-delivery is harmless for existing rows: their state is a lexmax; a re-delivered
+ * first write of an absent key meets the row its first delivery created, as in the reference when a sync chunk arrives twice). The overflow is also
  * sticky on the context: the next bmx_sync() returns BMX_ERR_OVERFLOW, so a pipelined caller cannot miss it. */
 int bmx_partition_by_owner_slabs(bmx_ctx* ctx, uint64_t n, const uint64_t* id, const uint32_t* field, const int64_t* ts,
                                  const int64_t* val, uint32_t nshards, uint64_t slab_records, bmx_delta_rec* recs_out,
                                  uint64_t* counts_out_dev);
+
+/* ---- one process, N shards (bmx_comm_*) --------------------------------------------------------
+ * The multi-GPU entry of the product surface (SURVEY §8(b) sketch bmx_comm_create / bmx_merge_batch_sharded; §8(e)): one handle owns
+ * N contexts, one per GPU of the node — or several per GPU ("logical shards": devices[] may repeat a device, which is how a one-GPU
+ * machine exercises N = 2, 4, 8). Replaces the gossip fan-out of src/bullet-network.js:378-418: a delta is merged once, by the shard
+ * that owns its node id, instead of once by every peer. A `Bullet` instance in Node owns all shards through the N-API binding of
+ * these calls (commCreate / commMerge / commScanRange ...). Not re-entrant. GPUs of one communicator must be peer-accessible.
+ *
+ * bmx_comm_merge: a HOST batch, same contract as bmx_merge_batch(BMX_MEM_HOST) on one context: final rows = the reference's sequential
+ *   loop over the batch, applied_idx = ascending indices (into the caller's batch) of the deltas whose value is finally stored.
+ *   (The batch is cut into N slices; slice i is partitioned by owner on shard i; runs are copied device-to-device to the owners in
+ *   origin order, so every shard sees its deltas in ascending batch order.) stats->n_rows = rows over all shards.
+ * bmx_comm_load_rows: bulk preload (true LWW), routed the same way.
+ * bmx_comm_merge_dev: every shard ORIGINATES a device-resident batch (n[i] deltas, pointers on shard i's GPU): its owner partition
+ *   writes fixed-size slabs of slab_records records (0 = mean run + 12.5 % + 64) straight into the owners' receive buffers — peer-
+ *   mapped stores over xGMI, no copy kernel, no host round trip — and every shard merges its N slabs. Enqueue-only: call
+ *   bmx_comm_sync() before reading results. A slab that was too small makes that sync return BMX_ERR_OVERFLOW (records were
+ *   dropped: re-send the step through bmx_comm_merge; re-delivery is harmless for existing rows, whose state is a lexmax). Order inside a shard: origin 0's run, origin 1's, ...
+ * bmx_comm_shard_result: device pointers to what shard g merged in the last bmx_comm_merge_dev step and to its winners (positions in
+ *   that record array), valid after bmx_comm_sync().
+ * bmx_comm_scan_*: replaces range()/equals()/count()/declarative filter() (src/bullet-query.js:186-313) on the sharded graph: every
+ *   shard scans its own rows, results are concatenated in shard order. No collective. */
+typedef struct bmx_comm bmx_comm;
+int bmx_comm_create(uint32_t nshards, const int* devices, uint64_t capacity_rows_per_shard, uint32_t flags, bmx_comm** out);
+void bmx_comm_destroy(bmx_comm* comm);
+const char* bmx_comm_last_error(const bmx_comm* comm);
+uint32_t bmx_comm_nshards(const bmx_comm* comm);
+bmx_ctx* bmx_comm_shard(bmx_comm* comm, uint32_t shard);   /* borrowed: point reads, index handling, info of one shard */
+int bmx_comm_sync(bmx_comm* comm);
+int bmx_comm_load_rows(bmx_comm* comm, uint64_t n, const uint64_t* id, const uint32_t* field, const int64_t* ts, const int64_t* val);
+int bmx_comm_merge(bmx_comm* comm, uint64_t n, const uint64_t* id, const uint32_t* field, const int64_t* ts, const int64_t* val, int insert_mode,
+                   uint32_t* applied_idx, uint64_t* n_applied, bmx_merge_stats* stats);
+int bmx_comm_merge_dev(bmx_comm* comm, const uint64_t* n, const uint64_t* const* id, const uint32_t* const* field, const int64_t* const* ts,
+                       const int64_t* const* val, int insert_mode, uint64_t slab_records);
+int bmx_comm_shard_result(bmx_comm* comm, uint32_t shard, const bmx_delta_rec** recs_dev, const uint32_t** applied_dev, const uint64_t** n_applied_dev,
+                          const bmx_merge_stats** stats_dev, uint64_t* n_records);
+int bmx_comm_row_count(bmx_comm* comm, uint64_t* n_out);
+int bmx_comm_get_rows(bmx_comm* comm, uint64_t n, const uint64_t* id, const uint32_t* field, int64_t* ts, int64_t* val, uint8_t* found);
+int bmx_comm_dump_rows(bmx_comm* comm, uint64_t cap, uint64_t* id, uint32_t* field, int64_t* ts, int64_t* val, uint64_t* n_out);
+int bmx_comm_index_build(bmx_comm* comm, uint32_t field);
+int bmx_comm_scan_range(bmx_comm* comm, uint32_t field, int64_t lo, int64_t hi, uint64_t* out_ids, uint64_t cap, uint64_t* n_out);
+int bmx_comm_scan_equals(bmx_comm* comm, uint32_t field, int64_t value, uint64_t* out_ids, uint64_t cap, uint64_t* n_out);
+int bmx_comm_scan_count(bmx_comm* comm, uint32_t field, int64_t lo, int64_t hi, uint64_t* n_out);
+int bmx_comm_scan_filter(bmx_comm* comm, uint32_t nterms, const bmx_term* terms, uint64_t* out_ids, uint64_t cap, uint64_t* n_out);
 
 /* ---- N4: fixed-K multi-writer vector clocks -------------------------------------
  * A second kind of table for rows whose clocks have up to 8 writers: {writer_0: c0, ..., writer_{K-1}: c_{K-1}} with small

@@ -1,0 +1,95 @@
+"""GPU: N shards in ONE process behind the C ABI (bmx_comm_*), N = 2, 4, 8 as logical shards on the one GPU of the box.
+The union of the shards must equal a single unsharded merge bit for bit: winners (ascending indices into the caller's batch), row
+count, state digest, point reads and scans are compared with the oracle, for the host-batch path and for the device-resident path
+(owner partition scattering straight into the owners' receive slabs)."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+import bmx
+from bmx import synth
+from oracle.oracle import Oracle, INSERT_REFERENCE, rows_digest
+
+R, D = 200_000, 60_000
+
+
+def _dev(cols):
+    i, f, t, v = cols
+    d = torch.device("cuda", 0)
+    return (torch.from_numpy(i.view(np.int64)).to(d), torch.from_numpy(f.view(np.int32)).to(d), torch.from_numpy(t).to(d), torch.from_numpy(v).to(d))
+
+
+@pytest.mark.parametrize("N", [1, 2, 4, 8])
+def test_host_batches_through_n_shards_equal_one_merge(N):
+    res = synth.big_resident(R, seed=3, F=2)
+    o = Oracle(); o.load_rows(*res)
+    with bmx.Comm([0] * N, capacity_rows_per_shard=2 * (R + 4 * D) // N + 4096) as c:
+        c.load_rows(*res)
+        assert c.row_count() == len(o)
+        for b in range(4):
+            d = synth.big_deltas(D, R, seed=40 + N, F=2, insert_pct=10, hot_pct=25, hot_keys=200, unique=False, batch=b)
+            applied, st = c.merge(*d)
+            _, ow = o.merge_batch(*d)
+            assert np.array_equal(applied, ow), (N, b, len(applied), len(ow))
+            assert st.n_rows == len(o) and st.n_applied == len(ow)
+        assert c.row_count() == len(o)
+        assert rows_digest(*c.dump_rows()) == o.digest()
+        # every shard holds exactly the rows it owns
+        for g in range(N):
+            e = bmx.Engine.__new__(bmx.Engine); e.L = c.L; e.h = C_ptr(c.L.bmx_comm_shard(c.h, g))
+            gid = e.dump_rows()[0]
+            assert (synth.owner_of_np(gid, N) == g).all()
+            e.h = None
+        # point reads routed by owner
+        ids = np.concatenate([res[0][:500], synth.splitmix64_np(np.arange(10**9, 10**9 + 50, dtype=np.uint64))])
+        flds = np.concatenate([res[1][:500], np.full(50, res[1][0], np.uint32)])
+        ts, val, found = c.get_rows(ids, flds)
+        for k in range(len(ids)):
+            want = o.get_row(int(ids[k]), int(flds[k]))
+            assert (want is None and not found[k]) or (want == (int(ts[k]), int(val[k])) and found[k])
+        # sharded scan == scan of the whole graph
+        f0 = int(res[1][0])
+        for lo, hi in [(-(1 << 31), 1 << 31), (0, 1 << 20), (5, 5), (10, 3)]:
+            got = np.sort(c.scan_range(f0, lo, hi)); want = np.sort(o.scan_range(f0, lo, hi))
+            assert np.array_equal(got, want), (N, lo, hi)
+            assert c.scan_count(f0, lo, hi) == len(want)
+        got = np.sort(c.scan_filter([(f0, 0, 1 << 30), (int(res[1][1]), -(1 << 30), 0)]))
+        want = np.sort(o.scan_filter_and([(f0, 0, 1 << 30), (int(res[1][1]), -(1 << 30), 0)]))
+        assert np.array_equal(got, want)
+
+
+def C_ptr(v):
+    import ctypes
+    return ctypes.c_void_p(v)
+
+
+@pytest.mark.parametrize("N", [2, 4, 8])
+def test_device_resident_batches_scatter_into_peer_slabs(N):
+    """Every shard originates its own device-resident batch; owner partitions write straight into the owners' receive slabs."""
+    res = synth.big_resident(R, seed=5)
+    o = Oracle(); o.load_rows(*res)
+    with bmx.Comm([0] * N, capacity_rows_per_shard=2 * (R + 4 * D) // N + 4096) as c:
+        c.load_rows(*res)
+        for step in range(3):
+            host = [synth.big_deltas(D // N, R, seed=60 + i, insert_pct=10, hot_pct=20, hot_keys=100, unique=False, batch=step) for i in range(N)]
+            devb = [(len(h[0]),) + _dev(h) for h in host]
+            c.merge_dev(devb, slab_records=0)
+            c.sync()
+            for h in host:                 # a shard merges origin 0's run, then origin 1's, ...: the oracle applies them in that order
+                o.merge_batch(*h)
+            assert c.row_count() == len(o), (N, step)
+        assert rows_digest(*c.dump_rows()) == o.digest()
+        # too small a slab: records are dropped, the step reports it (sticky error), and re-sending through the host path repairs it
+        # (hits only: the lexmax of a row is idempotent under re-delivery; a re-delivered INSERT would meet the row its first delivery
+        # created with ts := 2 and replace that clock, exactly as the reference does when a sync chunk arrives twice)
+        host = [synth.big_deltas(D // N, R, seed=90 + i, insert_pct=0, unique=False, batch=7) for i in range(N)]
+        devb = [(len(h[0]),) + _dev(h) for h in host]
+        c.merge_dev(devb, slab_records=max(1, D // N // N // 2))
+        with pytest.raises(bmx.BmxError) as ei:
+            c.sync()
+        assert ei.value.code == bmx.ERR_OVERFLOW
+        for h in host:
+            c.merge(*h); o.merge_batch(*h)
+        assert rows_digest(*c.dump_rows()) == o.digest()

@@ -171,37 +171,6 @@ def test_sharded_step_over_rccl_world1():
         dist.destroy_process_group()
 
 
-def test_async_compaction_overlaps_batches_and_stays_exact():
-    """BMX_CTX_ASYNC_COMPACT: the compaction of batch b runs on a side stream under the probe of batch b+1.
-    Several batches are enqueued back to back with no sync in between; results must equal the oracle's."""
-    dev = torch.device("cuda", 0)
-    R, D, NB = 300_000, 80_000, 7
-    res = synth.big_resident(R, seed=81)
-    o = Oracle(); o.load_rows(*res)
-    with bmx.Engine(2 * (R + NB * D), flags=bmx.CTX_ASYNC_COMPACT) as e:
-        e.load_rows(*res)
-        ds = [synth.big_deltas(D, R, seed=82, insert_pct=10, hot_pct=25, hot_keys=64, unique=False, batch=b) for b in range(NB)]
-        dd = [_dev(d, dev) for d in ds]
-        applied = [torch.zeros(D, dtype=torch.int32, device=dev) for _ in range(NB)]
-        n_applied = torch.zeros(NB, dtype=torch.int64, device=dev)
-        stats = torch.zeros((NB, 4), dtype=torch.int64, device=dev)
-        for b in range(NB):
-            e.merge_batch_dev(D, *dd[b], INSERT_REFERENCE, applied=applied[b], n_applied=n_applied[b:b + 1], stats=stats[b])
-        e.sync()
-        for b in range(NB):
-            _, ow = o.merge_batch(*ds[b])
-            na = int(n_applied[b].item())
-            assert na == len(ow) == int(stats[b, 0].item()), b
-            assert np.array_equal(applied[b][:na].cpu().numpy().view(np.uint32), ow), b
-        assert int(stats[NB - 1, 2].item()) == len(o) == e.row_count()
-        assert rows_digest(*e.dump_rows()) == o.digest()
-        # host-mode calls and scans on the same context still work
-        a, _, st = e.merge_batch(*ds[0])
-        _, ow = o.merge_batch(*ds[0])
-        assert np.array_equal(a, ow)
-        f0 = int(res[1][0])
-        assert e.scan_count(f0, -(1 << 40), 1 << 40) == o.scan_count(f0, -(1 << 40), 1 << 40)
-
 
 def test_sequence_words_order_two_streams():
     """bmx_seq_signal / bmx_seq_wait: a consumer stream sees the producer's data once the sequence word reaches the value."""
