@@ -1,7 +1,10 @@
 "use strict";
 /*
- * device-graph.js — one GPU-resident graph shard (a bmx_ctx) plus the host dictionary that maps the
- * device's hashed keys back to Bullet paths. Shared by GpuCRT (merge) and GpuQuery (index scans).
+ * device-graph.js — the GPU-resident graph plus the host dictionary that maps the device's hashed keys back to Bullet paths.
+ * Shared by GpuCRT (merge) and GpuQuery (index scans). One shard (a bmx_ctx) by default; with `devices: [0, 1, ...]` or
+ * `shards: N` the graph is split by node-id hash over N contexts owned by ONE handle (a bmx_comm): a delta is merged by the
+ * shard that owns its node instead of by every peer (reference fan-out: src/bullet-network.js:378-418), scans run on every shard
+ * and are concatenated (src/bullet-query.js:186-261). The methods below behave the same either way.
  */
 const { requireNative } = require("./native");
 const { KeyDictionary } = require("./hash");
@@ -11,32 +14,44 @@ class DeviceGraph {
     this.native = requireNative();                 // throws if the addon is missing: no CPU fallback
     this.device = opts.device || 0;
     this.capacityRows = opts.capacityRows || (1 << 16);   // grows on demand (bmx_reserve / automatic rehash)
-    this.handle = this.native.create(this.device, this.capacityRows);
+    this.devices = Array.isArray(opts.devices) ? opts.devices.slice() : (opts.shards > 1 ? new Array(opts.shards).fill(this.device) : null);
+    if (this.devices && this.devices.length > 1) {
+      this.nShards = this.devices.length;
+      this.comm = this.native.commCreate(this.devices, Math.ceil(this.capacityRows / this.nShards) + 1024);
+      this.handle = null;
+    } else {
+      this.nShards = 1;
+      this.comm = null;
+      this.handle = this.native.create(this.devices ? this.devices[0] : this.device, this.capacityRows);
+    }
     this.keys = new KeyDictionary();
     this.batches = 0;
   }
   mergeBatch(cols, mode) {
     this.batches++;
+    if (this.comm) return this.native.commMergeBatch(this.comm, cols.id, cols.field, cols.ts, cols.val, mode | 0);   // no per-delta flags across shards
     return this.native.mergeBatch(this.handle, cols.id, cols.field, cols.ts, cols.val, mode | 0);
   }
   mergeBatchAsync(cols, mode) {
     this.batches++;
+    if (this.comm) return Promise.resolve().then(() => this.native.commMergeBatch(this.comm, cols.id, cols.field, cols.ts, cols.val, mode | 0));
     return this.native.mergeBatchAsync(this.handle, cols.id, cols.field, cols.ts, cols.val, mode | 0);
   }
-  reserve(capacityRows) { this.native.reserve(this.handle, capacityRows); }
-  loadRows(cols) { this.native.loadRows(this.handle, cols.id, cols.field, cols.ts, cols.val); }
-  getRows(id, field) { return this.native.getRows(this.handle, id, field); }
-  rowCount() { return this.native.rowCount(this.handle); }
-  dumpRows() { return this.native.dumpRows(this.handle); }
-  indexBuild(f) { this.native.indexBuild(this.handle, f); }
-  indexDrop(f) { this.native.indexDrop(this.handle, f); }
-  indexSize(f) { return this.native.indexSize(this.handle, f); }
-  scanRange(f, lo, hi) { return this.native.scanRange(this.handle, f, lo, hi); }
-  scanCount(f, lo, hi) { return this.native.scanCount(this.handle, f, lo, hi); }
-  scanFilter(terms) { return this.native.scanFilter(this.handle, terms); }
-  info() { return this.native.info(this.handle); }
+  reserve(capacityRows) { if (!this.comm) this.native.reserve(this.handle, capacityRows); }   // shards grow on their own
+  loadRows(cols) { return this.comm ? this.native.commLoadRows(this.comm, cols.id, cols.field, cols.ts, cols.val) : this.native.loadRows(this.handle, cols.id, cols.field, cols.ts, cols.val); }
+  getRows(id, field) { return this.comm ? this.native.commGetRows(this.comm, id, field) : this.native.getRows(this.handle, id, field); }
+  rowCount() { return this.comm ? this.native.commRowCount(this.comm) : this.native.rowCount(this.handle); }
+  dumpRows() { return this.comm ? this.native.commDumpRows(this.comm) : this.native.dumpRows(this.handle); }
+  indexBuild(f) { return this.comm ? this.native.commIndexBuild(this.comm, f) : this.native.indexBuild(this.handle, f); }
+  indexDrop(f) { return this.comm ? this.native.commIndexDrop(this.comm, f) : this.native.indexDrop(this.handle, f); }
+  indexSize(f) { return this.comm ? this.native.commIndexSize(this.comm, f) : this.native.indexSize(this.handle, f); }
+  scanRange(f, lo, hi) { return this.comm ? this.native.commScanRange(this.comm, f, lo, hi) : this.native.scanRange(this.handle, f, lo, hi); }
+  scanCount(f, lo, hi) { return this.comm ? this.native.commScanCount(this.comm, f, lo, hi) : this.native.scanCount(this.handle, f, lo, hi); }
+  scanFilter(terms) { return this.comm ? this.native.commScanFilter(this.comm, terms) : this.native.scanFilter(this.handle, terms); }
+  info() { return this.comm ? { nShards: this.nShards, devices: this.devices, nRows: this.rowCount() } : this.native.info(this.handle); }
   close() {
     if (this.handle) { this.native.destroy(this.handle); this.handle = null; }
+    if (this.comm) { this.native.commDestroy(this.comm); this.comm = null; }
   }
 }
 

@@ -50,6 +50,50 @@ for (const name of fs.readdirSync(GOLD).filter((f) => f.startsWith("g2_stream_")
   checks += 4;
 }
 
+/* Sharded graph (bmx_comm_*): one handle owns N shards (logical shards on this box's one GPU). Winners in the caller's index
+ * space, row count and state digest must equal the reference's, and so must the queries, which now run on every shard. */
+for (const shards of [2, 4, 8]) {
+  for (const name of ["g2_stream_hot30_10k_10k.json", "g2_stream_mixed_100k_10k.json", "g2_stream_multifield_1k_1k.json"]) {
+    if (!fs.existsSync(path.join(GOLD, name))) continue;
+    const g = load(name);
+    const { resident, deltas, F } = gen.genStream(g.spec);
+    const crt = new GpuCRT({ id: "w", meta: {}, _getData() {} }, { capacityRows: Math.max(8192, 2 * (g.spec.R + g.spec.D)), shards });
+    crt.graph.loadRows(columns(resident, F));
+    const r = crt.mergeBatch(columns(deltas, F));
+    assert.deepStrictEqual(Array.from(r.applied), g.winners, name + " winners over " + shards + " shards");
+    assert.strictEqual(r.nRows, g.n_rows_final, name + " rows");
+    const d = crt.graph.dumpRows();
+    let digest = 0n;
+    for (let i = 0; i < d.id.length; i++) digest = (digest + gen.rowDigest(d.id[i], d.field[i], d.ts[i], d.val[i])) & ((1n << 64n) - 1n);
+    assert.strictEqual(digest.toString(16), g.digest, name + " state digest over " + shards + " shards");
+    crt.close();
+    checks += 3;
+  }
+}
+{
+  const g = load("g5_query_seeded_2k.json");
+  const rng = gen.xorshift32(g.seed);
+  const b = new MiniBullet("w");
+  const { query } = attach(b, { capacityRows: 1 << 16, shards: 4 });
+  for (let i = 0; i < g.N; i++) {
+    const age = rng() % 100, score = (rng() % 200001) - 100000;
+    b.setData("n/k" + i, { age, score, __fromNetwork: true, __vectorClock: { w: 10 + (i % 7) } }, false);
+  }
+  const ord = (nodes) => nodes.map((n) => parseInt(n.path.split("/").pop().slice(1), 10));
+  for (const q of g.queries) {
+    let got;
+    if (q.op === "equals") got = ord(query.equals("n", q.field, q.args[0]));
+    else if (q.op === "range") got = ord(query.range("n", q.field, q.args[0], q.args[1]));
+    else if (q.op === "count") { assert.strictEqual(query.count("n", q.field, q.args[0]), q.count); checks++; continue; }
+    else if (q.op === "filter_and") got = ord(query.filterWhere("n", [{ field: "age", min: q.args[0][0], max: q.args[0][1] }, { field: "score", min: q.args[1][0], max: q.args[1][1] }]));
+    assert.strictEqual(query.lastPath, "device", JSON.stringify(q));
+    if (q.op === "filter_and") assert.deepStrictEqual(got.slice().sort((a, b) => a - b), q.ordinals.slice().sort((a, b) => a - b));
+    else assert.deepStrictEqual(got, q.ordinals, "reference order over 4 shards " + JSON.stringify(q.args));
+    checks++;
+  }
+  b.close();
+}
+
 /* G5: integer indices on the device, reference order included */
 {
   const g = load("g5_query_seeded_2k.json");

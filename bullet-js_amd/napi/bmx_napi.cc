@@ -510,12 +510,213 @@ napi_value VcRowCount(napi_env env, napi_callback_info info) {
   return v;
 }
 
+// ---- N shards in one process (bmx_comm_*): one JS object owns all GPUs of the node ------------------------------------
+struct CommHandle { bmx_comm* c; std::mutex mu; };
+
+void finalize_comm(napi_env, void* data, void*) {
+  CommHandle* h = static_cast<CommHandle*>(data);
+  if (h->c) bmx_comm_destroy(h->c);
+  delete h;
+}
+bool get_comm(napi_env env, napi_value v, CommHandle** out) {
+  void* p = nullptr;
+  if (napi_get_value_external(env, v, &p) != napi_ok || !p || !static_cast<CommHandle*>(p)->c) {
+    napi_throw_error(env, nullptr, "bmx: invalid or closed communicator handle");
+    return false;
+  }
+  *out = static_cast<CommHandle*>(p);
+  return true;
+}
+napi_value throw_comm(napi_env env, bmx_comm* c, int rc) {
+  std::string msg = "bmx error " + std::to_string(rc) + ": " + bmx_comm_last_error(c);
+  napi_value code, err, m;
+  napi_create_string_utf8(env, msg.c_str(), NAPI_AUTO_LENGTH, &m);
+  napi_create_error(env, nullptr, m, &err);
+  napi_create_int32(env, rc, &code);
+  napi_set_named_property(env, err, "code", code);
+  napi_throw(env, err);
+  return nullptr;
+}
+
+// commCreate([device, device, ...], capacityRowsPerShard) -> handle   (a device may be listed several times: logical shards)
+napi_value CommCreate(napi_env env, napi_callback_info info) {
+  ARGS(2);
+  uint32_t n = 0; NAPI_OK(napi_get_array_length(env, argv[0], &n));
+  if (n == 0 || n > 16) { napi_throw_range_error(env, nullptr, "bmx: a communicator has 1..16 shards"); return nullptr; }
+  std::vector<int> devs(n);
+  for (uint32_t i = 0; i < n; i++) { napi_value e; NAPI_OK(napi_get_element(env, argv[0], i, &e)); int32_t d; NAPI_OK(napi_get_value_int32(env, e, &d)); devs[i] = d; }
+  double cap; NAPI_OK(napi_get_value_double(env, argv[1], &cap));
+  bmx_comm* c = nullptr;
+  int rc = bmx_comm_create(n, devs.data(), (uint64_t)cap, 0, &c);
+  if (rc) return throw_comm(env, nullptr, rc);
+  CommHandle* h = new CommHandle(); h->c = c;
+  napi_value ext;
+  NAPI_OK(napi_create_external(env, h, finalize_comm, nullptr, &ext));
+  return ext;
+}
+napi_value CommDestroy(napi_env env, napi_callback_info info) {
+  ARGS(1);
+  void* p = nullptr;
+  if (napi_get_value_external(env, argv[0], &p) == napi_ok && p) {
+    CommHandle* h = static_cast<CommHandle*>(p);
+    std::lock_guard<std::mutex> g(h->mu);
+    if (h->c) { bmx_comm_destroy(h->c); h->c = nullptr; }
+  }
+  return nullptr;
+}
+// commMergeBatch(h, id, field, ts, val, mode) -> {applied: Uint32Array (indices into this batch), nApplied, nConflicts, nRows}
+napi_value CommMergeBatch(napi_env env, napi_callback_info info) {
+  ARGS(6);
+  CommHandle* h; if (!get_comm(env, argv[0], &h)) return nullptr;
+  const uint64_t* id; const uint32_t* field; const int64_t *ts, *val; size_t n;
+  if (!get_cols(env, argv + 1, &id, &field, &ts, &val, &n)) return nullptr;
+  int32_t mode; NAPI_OK(napi_get_value_int32(env, argv[5], &mode));
+  std::vector<uint32_t> applied(n ? n : 1);
+  uint64_t na = 0; bmx_merge_stats st; memset(&st, 0, sizeof(st));
+  std::lock_guard<std::mutex> g(h->mu);
+  int rc = bmx_comm_merge(h->c, n, id, field, ts, val, mode, applied.data(), &na, &st);
+  if (rc) return throw_comm(env, h->c, rc);
+  void* ap = nullptr;
+  napi_value ta = make_ta(env, napi_uint32_array, 4, (size_t)na, &ap);
+  if (na) memcpy(ap, applied.data(), (size_t)na * 4);
+  napi_value out; NAPI_OK(napi_create_object(env, &out));
+  napi_set_named_property(env, out, "applied", ta);
+  set_num(env, out, "nApplied", (double)st.n_applied); set_num(env, out, "nConflicts", (double)st.n_conflicts); set_num(env, out, "nRows", (double)st.n_rows);
+  return out;
+}
+napi_value CommLoadRows(napi_env env, napi_callback_info info) {
+  ARGS(5);
+  CommHandle* h; if (!get_comm(env, argv[0], &h)) return nullptr;
+  const uint64_t* id; const uint32_t* field; const int64_t *ts, *val; size_t n;
+  if (!get_cols(env, argv + 1, &id, &field, &ts, &val, &n)) return nullptr;
+  std::lock_guard<std::mutex> g(h->mu);
+  int rc = bmx_comm_load_rows(h->c, n, id, field, ts, val);
+  if (rc) return throw_comm(env, h->c, rc);
+  return nullptr;
+}
+napi_value CommGetRows(napi_env env, napi_callback_info info) {
+  ARGS(3);
+  CommHandle* h; if (!get_comm(env, argv[0], &h)) return nullptr;
+  void *p0, *p1; size_t n0, n1;
+  if (!get_ta(env, argv[1], napi_biguint64_array, &p0, &n0) || !get_ta(env, argv[2], napi_uint32_array, &p1, &n1)) return nullptr;
+  if (n0 != n1) { napi_throw_range_error(env, nullptr, "bmx: column lengths differ"); return nullptr; }
+  void *ts, *val, *found;
+  napi_value a = make_ta(env, napi_bigint64_array, 8, n0, &ts), b = make_ta(env, napi_bigint64_array, 8, n0, &val), c = make_ta(env, napi_uint8_array, 1, n0, &found);
+  std::lock_guard<std::mutex> g(h->mu);
+  int rc = bmx_comm_get_rows(h->c, n0, (const uint64_t*)p0, (const uint32_t*)p1, (int64_t*)ts, (int64_t*)val, (uint8_t*)found);
+  if (rc) return throw_comm(env, h->c, rc);
+  napi_value out; NAPI_OK(napi_create_object(env, &out));
+  napi_set_named_property(env, out, "ts", a); napi_set_named_property(env, out, "val", b); napi_set_named_property(env, out, "found", c);
+  return out;
+}
+napi_value CommRowCount(napi_env env, napi_callback_info info) {
+  ARGS(1);
+  CommHandle* h; if (!get_comm(env, argv[0], &h)) return nullptr;
+  std::lock_guard<std::mutex> g(h->mu);
+  uint64_t n = 0; int rc = bmx_comm_row_count(h->c, &n);
+  if (rc) return throw_comm(env, h->c, rc);
+  napi_value v; napi_create_double(env, (double)n, &v); return v;
+}
+napi_value CommDumpRows(napi_env env, napi_callback_info info) {
+  ARGS(1);
+  CommHandle* h; if (!get_comm(env, argv[0], &h)) return nullptr;
+  std::lock_guard<std::mutex> g(h->mu);
+  uint64_t n = 0; int rc = bmx_comm_row_count(h->c, &n);
+  if (rc) return throw_comm(env, h->c, rc);
+  void *id, *f, *ts, *val;
+  napi_value a = make_ta(env, napi_biguint64_array, 8, n, &id), b = make_ta(env, napi_uint32_array, 4, n, &f),
+             c = make_ta(env, napi_bigint64_array, 8, n, &ts), d = make_ta(env, napi_bigint64_array, 8, n, &val);
+  uint64_t m = 0;
+  rc = bmx_comm_dump_rows(h->c, n, (uint64_t*)id, (uint32_t*)f, (int64_t*)ts, (int64_t*)val, &m);
+  if (rc) return throw_comm(env, h->c, rc);
+  napi_value out; NAPI_OK(napi_create_object(env, &out));
+  napi_set_named_property(env, out, "id", a); napi_set_named_property(env, out, "field", b);
+  napi_set_named_property(env, out, "ts", c); napi_set_named_property(env, out, "val", d);
+  return out;
+}
+napi_value CommIndexBuild(napi_env env, napi_callback_info info) {
+  ARGS(2);
+  CommHandle* h; if (!get_comm(env, argv[0], &h)) return nullptr;
+  uint32_t f; NAPI_OK(napi_get_value_uint32(env, argv[1], &f));
+  std::lock_guard<std::mutex> g(h->mu);
+  int rc = bmx_comm_index_build(h->c, f);
+  if (rc) return throw_comm(env, h->c, rc);
+  return nullptr;
+}
+napi_value CommIndexDrop(napi_env env, napi_callback_info info) {
+  ARGS(2);
+  CommHandle* h; if (!get_comm(env, argv[0], &h)) return nullptr;
+  uint32_t f; NAPI_OK(napi_get_value_uint32(env, argv[1], &f));
+  std::lock_guard<std::mutex> g(h->mu);
+  for (uint32_t s = 0; s < bmx_comm_nshards(h->c); s++) (void)bmx_index_drop(bmx_comm_shard(h->c, s), f);
+  return nullptr;
+}
+napi_value CommIndexSize(napi_env env, napi_callback_info info) {
+  ARGS(2);
+  CommHandle* h; if (!get_comm(env, argv[0], &h)) return nullptr;
+  uint32_t f; NAPI_OK(napi_get_value_uint32(env, argv[1], &f));
+  std::lock_guard<std::mutex> g(h->mu);
+  uint64_t tot = 0;
+  for (uint32_t s = 0; s < bmx_comm_nshards(h->c); s++) {
+    uint64_t n = 0; int rc = bmx_index_size(bmx_comm_shard(h->c, s), f, &n);
+    if (rc) return throw_bmx(env, bmx_comm_shard(h->c, s), rc);
+    tot += n;
+  }
+  napi_value v; napi_create_double(env, (double)tot, &v); return v;
+}
+napi_value CommScanRange(napi_env env, napi_callback_info info) {
+  ARGS(4);
+  CommHandle* h; if (!get_comm(env, argv[0], &h)) return nullptr;
+  uint32_t f; NAPI_OK(napi_get_value_uint32(env, argv[1], &f));
+  int64_t lo, hi; if (!get_i64(env, argv[2], &lo) || !get_i64(env, argv[3], &hi)) return nullptr;
+  std::lock_guard<std::mutex> g(h->mu);
+  uint64_t m = 0; int rc = bmx_comm_scan_count(h->c, f, lo, hi, &m);
+  if (rc) return throw_comm(env, h->c, rc);
+  void* out; napi_value ta = make_ta(env, napi_biguint64_array, 8, m, &out);
+  if (m) { uint64_t m2 = 0; rc = bmx_comm_scan_range(h->c, f, lo, hi, (uint64_t*)out, m, &m2); if (rc) return throw_comm(env, h->c, rc); }
+  return ta;
+}
+napi_value CommScanCount(napi_env env, napi_callback_info info) {
+  ARGS(4);
+  CommHandle* h; if (!get_comm(env, argv[0], &h)) return nullptr;
+  uint32_t f; NAPI_OK(napi_get_value_uint32(env, argv[1], &f));
+  int64_t lo, hi; if (!get_i64(env, argv[2], &lo) || !get_i64(env, argv[3], &hi)) return nullptr;
+  std::lock_guard<std::mutex> g(h->mu);
+  uint64_t m = 0; int rc = bmx_comm_scan_count(h->c, f, lo, hi, &m);
+  if (rc) return throw_comm(env, h->c, rc);
+  napi_value v; napi_create_double(env, (double)m, &v); return v;
+}
+napi_value CommScanFilter(napi_env env, napi_callback_info info) {
+  ARGS(2);
+  CommHandle* h; if (!get_comm(env, argv[0], &h)) return nullptr;
+  uint32_t nt = 0; NAPI_OK(napi_get_array_length(env, argv[1], &nt));
+  if (nt == 0 || nt > 8) { napi_throw_range_error(env, nullptr, "bmx: filter needs 1..8 terms"); return nullptr; }
+  bmx_term terms[8];
+  for (uint32_t k = 0; k < nt; k++) {
+    napi_value t, e0, e1, e2;
+    NAPI_OK(napi_get_element(env, argv[1], k, &t));
+    NAPI_OK(napi_get_element(env, t, 0, &e0)); NAPI_OK(napi_get_element(env, t, 1, &e1)); NAPI_OK(napi_get_element(env, t, 2, &e2));
+    NAPI_OK(napi_get_value_uint32(env, e0, &terms[k].field));
+    terms[k].reserved = 0;
+    if (!get_i64(env, e1, &terms[k].lo) || !get_i64(env, e2, &terms[k].hi)) return nullptr;
+  }
+  std::lock_guard<std::mutex> g(h->mu);
+  uint64_t m = 0; int rc = bmx_comm_scan_filter(h->c, nt, terms, nullptr, 0, &m);
+  if (rc) return throw_comm(env, h->c, rc);
+  void* out; napi_value ta = make_ta(env, napi_biguint64_array, 8, m, &out);
+  if (m) { uint64_t m2 = 0; rc = bmx_comm_scan_filter(h->c, nt, terms, (uint64_t*)out, m, &m2); if (rc) return throw_comm(env, h->c, rc); }
+  return ta;
+}
+
 napi_value Init(napi_env env, napi_value exports) {
   struct { const char* name; napi_callback fn; } fns[] = {
       {"abiVersion", AbiVersion}, {"create", Create}, {"destroy", Destroy}, {"mergeBatch", MergeBatch}, {"mergeBatchAsync", MergeBatchAsync}, {"reserve", Reserve}, {"loadRows", LoadRows},
       {"getRows", GetRows}, {"rowCount", RowCount}, {"dumpRows", DumpRows}, {"indexBuild", IndexBuild}, {"indexDrop", IndexDrop},
       {"indexSize", IndexSize}, {"scanRange", ScanRange}, {"scanCount", ScanCount}, {"scanFilter", ScanFilter}, {"info", Info},
-      {"vcCreate", VcCreate}, {"vcDestroy", VcDestroy}, {"vcLoadRows", VcLoadRows}, {"vcMergeBatch", VcMergeBatch}, {"vcGetRows", VcGetRows}, {"vcRowCount", VcRowCount}};
+      {"vcCreate", VcCreate}, {"vcDestroy", VcDestroy}, {"vcLoadRows", VcLoadRows}, {"vcMergeBatch", VcMergeBatch}, {"vcGetRows", VcGetRows}, {"vcRowCount", VcRowCount},
+      {"commCreate", CommCreate}, {"commDestroy", CommDestroy}, {"commMergeBatch", CommMergeBatch}, {"commLoadRows", CommLoadRows}, {"commGetRows", CommGetRows},
+      {"commRowCount", CommRowCount}, {"commDumpRows", CommDumpRows}, {"commIndexBuild", CommIndexBuild}, {"commIndexDrop", CommIndexDrop}, {"commIndexSize", CommIndexSize},
+      {"commScanRange", CommScanRange}, {"commScanCount", CommScanCount}, {"commScanFilter", CommScanFilter}};
   for (auto& f : fns) {
     napi_value v;
     if (napi_create_function(env, f.name, NAPI_AUTO_LENGTH, f.fn, nullptr, &v) != napi_ok) return nullptr;
