@@ -112,6 +112,23 @@ def cpu_baseline(n_batches=24):
     return out
 
 
+def js_host_rate():
+    """End-to-end rate of the JS host on this box (extra key, N=1 only): sync-chunk entries -> path hashing -> typed columns -> N-API ->
+    GPU merge -> winners, one thread; and the same with the keys already hashed. bullet-js_amd/js/test/e2e_rate.js, bounded sample."""
+    import shutil
+    import subprocess
+    node = shutil.which("node")
+    if not node:
+        return None
+    try:
+        r = subprocess.run([node, os.path.join(ROOT, "bullet-js_amd", "js", "test", "e2e_rate.js"), "1000000", "200000", "5"], capture_output=True, text=True, timeout=240)
+        j = json.loads(r.stdout.strip().splitlines()[-1])
+        j["sample"] = "5 batches of 200k sync entries (10 % new keys) against 1M resident keys; GpuCRT.mergeEntries / GpuCRT.mergeBatch over the N-API addon, host buffers"
+        return j
+    except Exception as e:
+        return {"error": str(e)[:200]}
+
+
 def verify_against_oracle(eng, host_batches, winners_dev, n_applied_dev, resident_cols):
     """Replay the very batches the device merged (warm-up + timed) through the CPU oracle and compare every batch's winner list,
     the row count and the digest of the whole table. Runs after the timed region; raises SystemExit on any difference."""
@@ -424,6 +441,7 @@ def main():
             for rs in [int(x) for x in args.scan_rows.split(",") if x]:
                 out["scan_config3"]["%dM" % (rs // 1_000_000)] = scan_bench(bmx, dev, R=rs)
         if not sharded and not args.no_cpu_baseline:
+            out["js_host"] = js_host_rate()
             out["cpu_baseline"] = cpu_baseline()
         else:
             out["cpu_baseline"] = None

@@ -27,7 +27,7 @@ MAX_BATCH = 1 << 24
 
 EXPORTS = [
     "bmx_create", "bmx_create_ex", "bmx_destroy", "bmx_last_error", "bmx_abi_version", "bmx_get_info", "bmx_sync", "bmx_set_stream", "bmx_get_stream", "bmx_seq_signal", "bmx_seq_wait",
-    "bmx_load_rows", "bmx_merge_batch", "bmx_merge_records", "bmx_get_rows", "bmx_get_row", "bmx_dump_rows", "bmx_row_count", "bmx_reserve",
+    "bmx_load_rows", "bmx_merge_batch", "bmx_merge_submit", "bmx_merge_collect", "bmx_merge_records", "bmx_get_rows", "bmx_get_row", "bmx_dump_rows", "bmx_row_count", "bmx_reserve",
     "bmx_index_build", "bmx_index_drop", "bmx_index_size", "bmx_scan_range", "bmx_scan_equals", "bmx_scan_count", "bmx_scan_filter",
     "bmx_owner_of", "bmx_partition_by_owner", "bmx_partition_by_owner_slabs", "bmx_timer_start", "bmx_timer_stop", "bmx_profile_enable", "bmx_profile_read", "bmx_profile_read_scan",
     "bmx_comm_create", "bmx_comm_destroy", "bmx_comm_last_error", "bmx_comm_nshards", "bmx_comm_shard", "bmx_comm_sync", "bmx_comm_load_rows", "bmx_comm_merge",
@@ -97,6 +97,8 @@ def load_library():
     L.bmx_load_rows.argtypes = [vp, u64, vp, vp, vp, vp, i32]; L.bmx_load_rows.restype = i32
     L.bmx_merge_batch.argtypes = [vp, u64, vp, vp, vp, vp, i32, i32, vp, vp, vp, vp]; L.bmx_merge_batch.restype = i32
     L.bmx_merge_records.argtypes = [vp, u64, vp, i32, vp, vp, vp, vp]; L.bmx_merge_records.restype = i32
+    L.bmx_merge_submit.argtypes = [vp, u64, vp, vp, vp, vp, i32, i32, C.POINTER(u64)]; L.bmx_merge_submit.restype = i32
+    L.bmx_merge_collect.argtypes = [vp, u64, vp, vp, vp, vp]; L.bmx_merge_collect.restype = i32
     L.bmx_get_rows.argtypes = [vp, u64, vp, vp, vp, vp, vp, i32]; L.bmx_get_rows.restype = i32
     L.bmx_get_row.argtypes = [vp, u64, u32, C.POINTER(i64), C.POINTER(i64)]; L.bmx_get_row.restype = i32
     L.bmx_dump_rows.argtypes = [vp, u64, vp, vp, vp, vp, vp, i32]; L.bmx_dump_rows.restype = i32
@@ -214,6 +216,23 @@ class Engine:
         st = MergeStats()
         self._chk(self.L.bmx_merge_batch(self.h, n, _ptr(id), _ptr(field), _ptr(ts), _ptr(val), int(insert_mode), MEM_HOST,
                                          _ptr(applied), C.cast(C.byref(na), C.c_void_p), _ptr(flags), C.cast(C.byref(st), C.c_void_p)))
+        return applied[:na.value].copy(), (flags[:n] if want_flags else None), st
+
+    def merge_submit(self, id, field, ts, val, insert_mode=INSERT_REFERENCE, want_flags=False):
+        """Upload a host batch and enqueue its merge; -> ticket for merge_collect(). At most two batches in flight."""
+        id, field, ts, val = _np(id, np.uint64), _np(field, np.uint32), _np(ts, np.int64), _np(val, np.int64)
+        t = C.c_uint64()
+        self._chk(self.L.bmx_merge_submit(self.h, len(id), _ptr(id), _ptr(field), _ptr(ts), _ptr(val), int(insert_mode), 1 if want_flags else 0, C.byref(t)))
+        return (t.value, len(id), want_flags)
+
+    def merge_collect(self, ticket):
+        """-> (applied_idx u32[w], flags u8[n] or None, MergeStats) of a submitted batch (collect in submission order)."""
+        t, n, want_flags = ticket
+        applied = np.zeros(max(n, 1), np.uint32)
+        flags = np.zeros(max(n, 1), np.uint8) if want_flags else None
+        na = C.c_uint64(0)
+        st = MergeStats()
+        self._chk(self.L.bmx_merge_collect(self.h, int(t), _ptr(applied), C.cast(C.byref(na), C.c_void_p), _ptr(flags), C.cast(C.byref(st), C.c_void_p)))
         return applied[:na.value].copy(), (flags[:n] if want_flags else None), st
 
     def get_rows(self, id, field):

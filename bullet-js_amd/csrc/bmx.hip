@@ -65,9 +65,20 @@ struct bmx_ctx {
   uint4* bin_stage = nullptr;         // bin_tiles_cap * BK_TILE records of 32 B
   uint16_t* bin_toff = nullptr;       // bin_tiles_cap * TOFF_STRIDE offsets
   // staging for BMX_MEM_HOST calls
-  uint32_t st_cap = 0;
-  uint64_t* st_id = nullptr; uint32_t* st_field = nullptr; int64_t* st_ts = nullptr; int64_t* st_val = nullptr;
-  uint32_t* st_applied = nullptr; uint8_t* st_flags = nullptr;
+  // Two staging sets: batch b+1 is uploaded (copy stream) while batch b is merged (main stream); bmx_merge_submit / bmx_merge_collect
+  struct Staging {
+    uint32_t cap = 0;
+    uint64_t* id = nullptr; uint32_t* field = nullptr; int64_t* ts = nullptr; int64_t* val = nullptr;
+    uint32_t* applied = nullptr; uint8_t* flags = nullptr;
+    unsigned long long* n_out = nullptr; bmx_merge_stats* stats = nullptr;   // device words of this set
+    hipEvent_t up = nullptr, done = nullptr;                                  // inputs uploaded / kernels of the batch finished
+    uint64_t n = 0; bool want_flags = false; bool busy = false; uint64_t ticket = 0;
+  } stg[2];
+  hipStream_t copy_stream = nullptr;
+  uint64_t next_ticket = 1;
+  // persistent device buffers of the host-mode point reads and dumps (grow-only)
+  uint64_t pr_cap = 0;
+  uint64_t* pr_id = nullptr; uint32_t* pr_field = nullptr; int64_t* pr_ts = nullptr; int64_t* pr_val = nullptr; uint8_t* pr_found = nullptr;
   uint64_t scan_cap = 0; uint64_t* scan_out = nullptr;
   uint32_t* block_counts = nullptr;   // SEL_MAX_BLOCKS
   uint32_t* scan_mask = nullptr;      // scan scratch: one match bit per index row
@@ -180,18 +191,34 @@ int ensure_bins(bmx_ctx* ctx, uint64_t n) {
   return BMX_OK;
 }
 
-int ensure_staging(bmx_ctx* ctx, uint64_t n) {
-  if (n <= ctx->st_cap) return BMX_OK;
+int ensure_staging(bmx_ctx* ctx, int k, uint64_t n) {
+  bmx_ctx::Staging& S = ctx->stg[k];
+  if (n <= S.cap) return BMX_OK;
   HIPCHK(hipStreamSynchronize(ctx->stream));
+  HIPCHK(hipStreamSynchronize(ctx->copy_stream));
   uint64_t cap = std::max<uint64_t>(n, 1u << 16);
   cap = (cap + 255) & ~255ull;
-  dev_free(ctx->st_id); dev_free(ctx->st_field); dev_free(ctx->st_ts); dev_free(ctx->st_val); dev_free(ctx->st_applied); dev_free(ctx->st_flags);
-  ctx->st_cap = 0;
+  dev_free(S.id); dev_free(S.field); dev_free(S.ts); dev_free(S.val); dev_free(S.applied); dev_free(S.flags);
+  S.cap = 0;
   int rc;
-  if ((rc = dev_alloc(ctx, &ctx->st_id, cap)) || (rc = dev_alloc(ctx, &ctx->st_field, cap)) || (rc = dev_alloc(ctx, &ctx->st_ts, cap)) ||
-      (rc = dev_alloc(ctx, &ctx->st_val, cap)) || (rc = dev_alloc(ctx, &ctx->st_applied, cap)) || (rc = dev_alloc(ctx, &ctx->st_flags, cap)))
+  if ((rc = dev_alloc(ctx, &S.id, cap)) || (rc = dev_alloc(ctx, &S.field, cap)) || (rc = dev_alloc(ctx, &S.ts, cap)) ||
+      (rc = dev_alloc(ctx, &S.val, cap)) || (rc = dev_alloc(ctx, &S.applied, cap)) || (rc = dev_alloc(ctx, &S.flags, cap)))
     return rc;
-  ctx->st_cap = (uint32_t)cap;
+  S.cap = (uint32_t)cap;
+  return BMX_OK;
+}
+
+int ensure_point_read(bmx_ctx* ctx, uint64_t n) {
+  if (n <= ctx->pr_cap) return BMX_OK;
+  HIPCHK(hipStreamSynchronize(ctx->stream));
+  dev_free(ctx->pr_id); dev_free(ctx->pr_field); dev_free(ctx->pr_ts); dev_free(ctx->pr_val); dev_free(ctx->pr_found);
+  ctx->pr_cap = 0;
+  const uint64_t cap = (std::max<uint64_t>(n + n / 4, 1u << 12) + 255) & ~255ull;
+  int rc;
+  if ((rc = dev_alloc(ctx, &ctx->pr_id, cap)) || (rc = dev_alloc(ctx, &ctx->pr_field, cap)) || (rc = dev_alloc(ctx, &ctx->pr_ts, cap)) ||
+      (rc = dev_alloc(ctx, &ctx->pr_val, cap)) || (rc = dev_alloc(ctx, &ctx->pr_found, cap)))
+    return rc;
+  ctx->pr_cap = cap;
   return BMX_OK;
 }
 
@@ -336,32 +363,66 @@ int merge_core(bmx_ctx* ctx, uint64_t n, const uint64_t* id, const uint32_t* fie
   return BMX_OK;
 }
 
-int merge_host(bmx_ctx* ctx, uint64_t n, const uint64_t* id, const uint32_t* field, const int64_t* ts, const int64_t* val,
-               int insert_mode, uint32_t* applied_idx, uint64_t* n_applied, uint8_t* flags, bmx_merge_stats* stats) {
-  int rc = ensure_staging(ctx, n);
+// Host batches go through two staging sets. submit: upload on the copy stream, then the merge on the main stream behind an event;
+// collect: results back on the copy stream once the batch's kernels are done. While the host uploads batch b+1 (a pageable
+// hipMemcpyAsync keeps the calling thread busy for the whole transfer) the GPU merges batch b.
+int submit_host(bmx_ctx* ctx, uint64_t n, const uint64_t* id, const uint32_t* field, const int64_t* ts, const int64_t* val,
+                int insert_mode, bool want_flags, uint64_t* ticket) {
+  int k = -1;
+  for (int i = 0; i < 2; i++) if (!ctx->stg[i].busy) { k = i; break; }
+  if (k < 0) return fail(ctx, BMX_ERR_INVALID, "two batches are already in flight: collect the oldest first (bmx_merge_collect)");
+  bmx_ctx::Staging& S = ctx->stg[k];
+  int rc = ensure_staging(ctx, k, n);
   if (rc) return rc;
   if (n) {
-    HIPCHK(hipMemcpyAsync(ctx->st_id, id, n * 8, hipMemcpyHostToDevice, ctx->stream));
-    HIPCHK(hipMemcpyAsync(ctx->st_field, field, n * 4, hipMemcpyHostToDevice, ctx->stream));
-    HIPCHK(hipMemcpyAsync(ctx->st_ts, ts, n * 8, hipMemcpyHostToDevice, ctx->stream));
-    HIPCHK(hipMemcpyAsync(ctx->st_val, val, n * 8, hipMemcpyHostToDevice, ctx->stream));
+    HIPCHK(hipMemcpyAsync(S.id, id, n * 8, hipMemcpyHostToDevice, ctx->copy_stream));
+    HIPCHK(hipMemcpyAsync(S.field, field, n * 4, hipMemcpyHostToDevice, ctx->copy_stream));
+    HIPCHK(hipMemcpyAsync(S.ts, ts, n * 8, hipMemcpyHostToDevice, ctx->copy_stream));
+    HIPCHK(hipMemcpyAsync(S.val, val, n * 8, hipMemcpyHostToDevice, ctx->copy_stream));
+    HIPCHK(hipEventRecord(S.up, ctx->copy_stream));
+    HIPCHK(hipStreamWaitEvent(ctx->stream, S.up, 0));
   }
-  rc = merge_core<false>(ctx, n, ctx->st_id, ctx->st_field, ctx->st_ts, ctx->st_val, nullptr, insert_mode, ctx->st_applied,
-                         reinterpret_cast<uint64_t*>(&ctx->ds->n_out), flags ? ctx->st_flags : nullptr, &ctx->ds->stats);
+  rc = merge_core<false>(ctx, n, S.id, S.field, S.ts, S.val, nullptr, insert_mode, S.applied, reinterpret_cast<uint64_t*>(S.n_out),
+                         want_flags ? S.flags : nullptr, S.stats);
   if (rc) return rc;
-  bmx_merge_stats hs;
-  HIPCHK(hipMemcpyAsync(&hs, &ctx->ds->stats, sizeof(hs), hipMemcpyDeviceToHost, ctx->stream));
-  HIPCHK(hipStreamSynchronize(ctx->stream));
-  if (n == 0) std::memset(&hs, 0, sizeof(hs));
-  rc = check_status(ctx);
-  if (rc) return rc;
-  if (n) ctx->rows_ub = hs.n_rows;
-  if (applied_idx && hs.n_applied) HIPCHK(hipMemcpyAsync(applied_idx, ctx->st_applied, hs.n_applied * 4, hipMemcpyDeviceToHost, ctx->stream));
-  if (flags && n) HIPCHK(hipMemcpyAsync(flags, ctx->st_flags, n, hipMemcpyDeviceToHost, ctx->stream));
-  HIPCHK(hipStreamSynchronize(ctx->stream));
+  HIPCHK(hipEventRecord(S.done, ctx->stream));
+  S.n = n; S.want_flags = want_flags; S.busy = true; S.ticket = ctx->next_ticket++;
+  *ticket = S.ticket;
+  return BMX_OK;
+}
+
+int collect_host(bmx_ctx* ctx, uint64_t ticket, uint32_t* applied_idx, uint64_t* n_applied, uint8_t* flags, bmx_merge_stats* stats) {
+  int k = -1;
+  for (int i = 0; i < 2; i++) if (ctx->stg[i].busy && ctx->stg[i].ticket == ticket) k = i;
+  if (k < 0) return fail(ctx, BMX_ERR_INVALID, "unknown or already collected ticket");
+  if (ctx->stg[1 - k].busy && ctx->stg[1 - k].ticket < ticket) return fail(ctx, BMX_ERR_INVALID, "collect tickets in submission order");
+  bmx_ctx::Staging& S = ctx->stg[k];
+  S.busy = false;
+  bmx_merge_stats hs; std::memset(&hs, 0, sizeof(hs));
+  HIPCHK(hipStreamWaitEvent(ctx->copy_stream, S.done, 0));
+  uint32_t st = 0;
+  HIPCHK(hipMemcpyAsync(&hs, S.stats, sizeof(hs), hipMemcpyDeviceToHost, ctx->copy_stream));
+  HIPCHK(hipMemcpyAsync(&st, &ctx->ds->status, sizeof(st), hipMemcpyDeviceToHost, ctx->copy_stream));
+  HIPCHK(hipStreamSynchronize(ctx->copy_stream));
+  if (st) return check_status(ctx);     // sticky device error of this (or an earlier, uncollected) batch
+  if (S.n == 0) std::memset(&hs, 0, sizeof(hs));
+  if (applied_idx && hs.n_applied) HIPCHK(hipMemcpyAsync(applied_idx, S.applied, hs.n_applied * 4, hipMemcpyDeviceToHost, ctx->copy_stream));
+  if (flags && S.n && S.want_flags) HIPCHK(hipMemcpyAsync(flags, S.flags, S.n, hipMemcpyDeviceToHost, ctx->copy_stream));
+  HIPCHK(hipStreamSynchronize(ctx->copy_stream));
+  if (!ctx->stg[1 - k].busy && S.n) ctx->rows_ub = hs.n_rows;   // exact again once nothing else is in flight
   if (n_applied) *n_applied = hs.n_applied;
   if (stats) *stats = hs;
   return BMX_OK;
+}
+
+int merge_host(bmx_ctx* ctx, uint64_t n, const uint64_t* id, const uint32_t* field, const int64_t* ts, const int64_t* val,
+               int insert_mode, uint32_t* applied_idx, uint64_t* n_applied, uint8_t* flags, bmx_merge_stats* stats) {
+  for (int i = 0; i < 2; i++)
+    if (ctx->stg[i].busy) return fail(ctx, BMX_ERR_INVALID, "a submitted batch is still in flight: collect it before a synchronous merge");
+  uint64_t ticket = 0;
+  int rc = submit_host(ctx, n, id, field, ts, val, insert_mode, flags != nullptr, &ticket);
+  if (rc) return rc;
+  return collect_host(ctx, ticket, applied_idx, n_applied, flags, stats);
 }
 
 Index* find_index(bmx_ctx* ctx, uint32_t field) {
@@ -549,11 +610,18 @@ int bmx_create_ex(int device, uint64_t capacity_rows, uint32_t max_load_pct, uin
   ctx->stream = ctx->own_stream;
   CR(hipEventCreate(&ctx->ev0));
   CR(hipEventCreate(&ctx->ev1));
+  CR(hipStreamCreateWithFlags(&ctx->copy_stream, hipStreamNonBlocking));
+  for (int i = 0; i < 2; i++) { CR(hipEventCreateWithFlags(&ctx->stg[i].up, hipEventDisableTiming)); CR(hipEventCreateWithFlags(&ctx->stg[i].done, hipEventDisableTiming)); }
   const uint64_t nslots = slots_for(capacity_rows, max_load_pct);
   ctx->nslots = nslots;
   int rc;
   if ((rc = dev_alloc(ctx, &ctx->slots, nslots))) return bail(rc);
   if ((rc = dev_alloc(ctx, &ctx->ds, 1))) return bail(rc);
+  for (int i = 0; i < 2; i++) {
+    if ((rc = dev_alloc(ctx, &ctx->stg[i].n_out, 1)) || (rc = dev_alloc(ctx, &ctx->stg[i].stats, 1))) return bail(rc);
+    CR(hipMemsetAsync(ctx->stg[i].n_out, 0, sizeof(unsigned long long), ctx->stream));
+    CR(hipMemsetAsync(ctx->stg[i].stats, 0, sizeof(bmx_merge_stats), ctx->stream));
+  }
   if ((rc = dev_alloc(ctx, &ctx->block_counts, SEL_MAX_BLOCKS))) return bail(rc);
   if ((rc = dev_alloc(ctx, &ctx->part_counts, PART_MAX_SHARDS * PART_BLOCKS))) return bail(rc);
   if ((rc = dev_alloc(ctx, &ctx->shard_ctr, CTR_SHARDS * CTR_STRIDE))) return bail(rc);
@@ -575,7 +643,15 @@ void bmx_destroy(bmx_ctx* ctx) {
   if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
   for (auto& ix : ctx->indexes) { dev_free(ix.ids); dev_free(ix.v64); dev_free(ix.v32); }
   dev_free(ctx->slots); dev_free(ctx->ds); dev_free(ctx->next); dev_free(ctx->wflag); dev_free(ctx->slot_of); dev_free(ctx->blk_info); dev_free(ctx->blk_follow); dev_free(ctx->shard_ctr);
-  dev_free(ctx->st_id); dev_free(ctx->st_field); dev_free(ctx->st_ts); dev_free(ctx->st_val); dev_free(ctx->st_applied); dev_free(ctx->st_flags);
+  if (ctx->copy_stream) (void)hipStreamSynchronize(ctx->copy_stream);
+  for (int i = 0; i < 2; i++) {
+    bmx_ctx::Staging& S = ctx->stg[i];
+    dev_free(S.id); dev_free(S.field); dev_free(S.ts); dev_free(S.val); dev_free(S.applied); dev_free(S.flags); dev_free(S.n_out); dev_free(S.stats);
+    if (S.up) (void)hipEventDestroy(S.up);
+    if (S.done) (void)hipEventDestroy(S.done);
+  }
+  dev_free(ctx->pr_id); dev_free(ctx->pr_field); dev_free(ctx->pr_ts); dev_free(ctx->pr_val); dev_free(ctx->pr_found);
+  if (ctx->copy_stream) (void)hipStreamDestroy(ctx->copy_stream);
   dev_free(ctx->bin_stage); dev_free(ctx->bin_toff);
   dev_free(ctx->scan_out); dev_free(ctx->block_counts); dev_free(ctx->part_counts); dev_free(ctx->part_owner); dev_free(ctx->scan_mask); dev_free(ctx->scan_counts);
   for (auto ev : ctx->prof_ev) (void)hipEventDestroy(ev);
@@ -655,6 +731,21 @@ int bmx_merge_batch(bmx_ctx* ctx, uint64_t n, const uint64_t* id, const uint32_t
   return merge_host(ctx, n, id, field, ts, val, insert_mode, applied_idx, n_applied, flags, stats);
 }
 
+int bmx_merge_submit(bmx_ctx* ctx, uint64_t n, const uint64_t* id, const uint32_t* field, const int64_t* ts, const int64_t* val, int insert_mode,
+                     int want_flags, uint64_t* ticket) {
+  if (!ctx || !ticket) return fail(ctx, BMX_ERR_INVALID, "bmx_merge_submit: null context or ticket");
+  if (n && (!id || !field || !ts || !val)) return fail(ctx, BMX_ERR_INVALID, "null input column");
+  if (n > MAX_BATCH) return fail(ctx, BMX_ERR_INVALID, "batch larger than 2^24 deltas: split it (sequential semantics are preserved)");
+  HIPCHK(hipSetDevice(ctx->device));
+  return submit_host(ctx, n, id, field, ts, val, insert_mode, want_flags != 0, ticket);
+}
+
+int bmx_merge_collect(bmx_ctx* ctx, uint64_t ticket, uint32_t* applied_idx, uint64_t* n_applied, uint8_t* flags, bmx_merge_stats* stats) {
+  if (!ctx) return fail(nullptr, BMX_ERR_INVALID, "null context");
+  HIPCHK(hipSetDevice(ctx->device));
+  return collect_host(ctx, ticket, applied_idx, n_applied, flags, stats);
+}
+
 int bmx_merge_records(bmx_ctx* ctx, uint64_t n, const bmx_delta_rec* recs, int insert_mode, uint32_t* applied_idx, uint64_t* n_applied,
                       uint8_t* flags, bmx_merge_stats* stats) {
   if (!ctx) return fail(nullptr, BMX_ERR_INVALID, "null context");
@@ -693,25 +784,16 @@ int bmx_get_rows(bmx_ctx* ctx, uint64_t n, const uint64_t* id, const uint32_t* f
     return BMX_OK;
   }
   if (mem != BMX_MEM_HOST) return fail(ctx, BMX_ERR_INVALID, "bad mem kind");
-  uint64_t* d_id = nullptr; uint32_t* d_f = nullptr; int64_t* d_ts = nullptr; int64_t* d_val = nullptr; uint8_t* d_found = nullptr;
-  int rc;
-  if ((rc = dev_alloc(ctx, &d_id, n)) || (rc = dev_alloc(ctx, &d_f, n)) || (rc = dev_alloc(ctx, &d_ts, n)) || (rc = dev_alloc(ctx, &d_val, n)) ||
-      (rc = dev_alloc(ctx, &d_found, n))) {
-    dev_free(d_id); dev_free(d_f); dev_free(d_ts); dev_free(d_val); dev_free(d_found);
-    return rc;
-  }
-  hipError_t e = hipMemcpyAsync(d_id, id, n * 8, hipMemcpyHostToDevice, ctx->stream);
-  if (e == hipSuccess) e = hipMemcpyAsync(d_f, field, n * 4, hipMemcpyHostToDevice, ctx->stream);
-  if (e == hipSuccess) {
-    hipLaunchKernelGGL(k_get_rows, dim3(blocks), dim3(256), 0, ctx->stream, ctx->slots, ctx->nslots, (uint32_t)n, d_id, d_f, d_ts, d_val, d_found);
-    e = hipGetLastError();
-  }
-  if (e == hipSuccess) e = hipMemcpyAsync(ts, d_ts, n * 8, hipMemcpyDeviceToHost, ctx->stream);
-  if (e == hipSuccess) e = hipMemcpyAsync(val, d_val, n * 8, hipMemcpyDeviceToHost, ctx->stream);
-  if (e == hipSuccess) e = hipMemcpyAsync(found, d_found, n, hipMemcpyDeviceToHost, ctx->stream);
-  if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
-  dev_free(d_id); dev_free(d_f); dev_free(d_ts); dev_free(d_val); dev_free(d_found);
-  if (e != hipSuccess) return fail_hip(ctx, e, "bmx_get_rows");
+  int rc = ensure_point_read(ctx, n);
+  if (rc) return rc;
+  HIPCHK(hipMemcpyAsync(ctx->pr_id, id, n * 8, hipMemcpyHostToDevice, ctx->stream));
+  HIPCHK(hipMemcpyAsync(ctx->pr_field, field, n * 4, hipMemcpyHostToDevice, ctx->stream));
+  hipLaunchKernelGGL(k_get_rows, dim3(blocks), dim3(256), 0, ctx->stream, ctx->slots, ctx->nslots, (uint32_t)n, ctx->pr_id, ctx->pr_field, ctx->pr_ts, ctx->pr_val, ctx->pr_found);
+  LAUNCHCHK("k_get_rows");
+  HIPCHK(hipMemcpyAsync(ts, ctx->pr_ts, n * 8, hipMemcpyDeviceToHost, ctx->stream));
+  HIPCHK(hipMemcpyAsync(val, ctx->pr_val, n * 8, hipMemcpyDeviceToHost, ctx->stream));
+  HIPCHK(hipMemcpyAsync(found, ctx->pr_found, n, hipMemcpyDeviceToHost, ctx->stream));
+  HIPCHK(hipStreamSynchronize(ctx->stream));
   return BMX_OK;
 }
 
@@ -732,12 +814,9 @@ int bmx_dump_rows(bmx_ctx* ctx, uint64_t cap, uint64_t* id, uint32_t* field, int
   const bool host = mem == BMX_MEM_HOST;
   uint64_t* d_id = id; uint32_t* d_f = field; int64_t* d_ts = ts; int64_t* d_val = val;
   int rc = BMX_OK;
-  if (host && cap) {
-    d_id = nullptr; d_f = nullptr; d_ts = nullptr; d_val = nullptr;
-    if ((rc = dev_alloc(ctx, &d_id, cap)) || (rc = dev_alloc(ctx, &d_f, cap)) || (rc = dev_alloc(ctx, &d_ts, cap)) || (rc = dev_alloc(ctx, &d_val, cap))) {
-      dev_free(d_id); dev_free(d_f); dev_free(d_ts); dev_free(d_val);
-      return rc;
-    }
+  if (host && cap) {   // persistent (grow-only) device columns: no allocation per call
+    if ((rc = ensure_point_read(ctx, cap))) return rc;
+    d_id = ctx->pr_id; d_f = ctx->pr_field; d_ts = ctx->pr_ts; d_val = ctx->pr_val;
   }
   PredSlotAny P{ctx->slots};
   EmitRows Em{ctx->slots, cap, d_id, d_f, d_ts, d_val};
@@ -758,7 +837,6 @@ int bmx_dump_rows(bmx_ctx* ctx, uint64_t cap, uint64_t* id, uint32_t* field, int
       if (e == hipSuccess) e = hipMemcpy(ts, d_ts, k * 8, hipMemcpyDeviceToHost);
       if (e == hipSuccess) e = hipMemcpy(val, d_val, k * 8, hipMemcpyDeviceToHost);
     }
-    if (cap) { dev_free(d_id); dev_free(d_f); dev_free(d_ts); dev_free(d_val); }
     if (n_out) *n_out = m;
   }
   if (e != hipSuccess) return fail_hip(ctx, e, "bmx_dump_rows");

@@ -1,0 +1,51 @@
+"use strict";
+/*
+ * e2e_rate.js — end-to-end rate of the JS host on this box (bench.py's `js_host` key): sync-chunk entries in, winners out.
+ *   mergeEntries : [{path, data: {f: int}, vectorClock: {w: ts}}] -> path hashing + typed columns + GPU merge + winner mapping
+ *   mergeBatch   : typed columns -> GPU merge (what is left when the host keeps its keys hashed)
+ * Resident graph R keys, B batches of D entries (10 % new keys). One thread. Needs an MI355X.
+ * Usage: node e2e_rate.js [R] [D] [B]   -> one JSON line
+ */
+const { GpuCRT, hash } = require("..");
+const R = parseInt(process.argv[2] || "1000000", 10);
+const D = parseInt(process.argv[3] || "200000", 10);
+const B = parseInt(process.argv[4] || "5", 10);
+let s = 12345;
+const rnd = () => { s ^= s << 13; s >>>= 0; s ^= s >>> 17; s ^= s << 5; s >>>= 0; return s; };
+const crt = new GpuCRT({ id: "w", meta: {}, _getData() {} }, { capacityRows: 2 * (R + B * D) });
+const g = crt.graph;
+{
+  const cols = new hash.Columns(R);
+  const f = g.keys.fieldOf("n", "f");
+  for (let i = 0; i < R; i++) cols.set(i, g.keys.idOf("n/k" + i), f, 1000000 + (rnd() % 1000000), (rnd() % 2001) - 1000);
+  g.loadRows(cols);
+}
+const batches = [];
+for (let b = 0; b < B; b++) {
+  const entries = new Array(D);
+  for (let j = 0; j < D; j++) {
+    const ins = rnd() % 100 < 10;
+    const clock = { w: 1000000 + (rnd() % 2000000) };
+    entries[j] = { path: "n/k" + (ins ? R + b * D + j : rnd() % R), data: { f: (rnd() % 2001) - 1000 }, vectorClock: clock };
+  }
+  batches.push(entries);
+}
+crt.mergeEntries(batches[0].slice(0, 1000));                     // warm the addon and the JIT
+let applied = 0;
+let t0 = process.hrtime.bigint();
+for (const entries of batches) applied += crt.mergeEntries(entries).nApplied;
+const dtEntries = Number(process.hrtime.bigint() - t0) / 1e9;
+// the same amount of work with the keys already hashed (typed columns in, winners out)
+const colsB = [];
+for (let b = 0; b < B; b++) {
+  const cols = new hash.Columns(D);
+  const f = g.keys.fieldOf("n", "f");
+  for (let j = 0; j < D; j++) cols.set(j, g.keys.idOf(batches[b][j].path), f, 3000000 + (rnd() % 1000000), (rnd() % 2001) - 1000);
+  colsB.push(cols);
+}
+t0 = process.hrtime.bigint();
+for (const cols of colsB) applied += crt.mergeBatch(cols).nApplied;
+const dtCols = Number(process.hrtime.bigint() - t0) / 1e9;
+console.log(JSON.stringify({ mergeEntries_per_s: (B * D) / dtEntries, mergeBatch_typed_columns_per_s: (B * D) / dtCols, unit: "deltas/s", resident_keys: R,
+  entries_per_batch: D, batches: B, applied, node: process.version }));
+crt.close();

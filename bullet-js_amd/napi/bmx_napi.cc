@@ -6,6 +6,7 @@
 #include <stdint.h>
 #include <math.h>
 #include <string.h>
+#include <condition_variable>
 #include <mutex>
 #include <string>
 #include <vector>
@@ -33,7 +34,21 @@ napi_value throw_bmx(napi_env env, bmx_ctx* ctx, int rc) {
   return nullptr;
 }
 
-struct Handle { bmx_ctx* ctx; std::mutex mu; };   // a context is not re-entrant: async work serialises on mu
+// A context is not re-entrant and the ORDER of merges matters (which delta creates a row decides its stored clock), so every
+// operation on a handle takes a ticket when it is issued on the JS thread and runs when its turn comes: asynchronous merges
+// (libuv workers) and synchronous calls execute in exactly the order JS issued them.
+struct Handle {
+  bmx_ctx* ctx = nullptr;
+  std::mutex mu; std::condition_variable cv;
+  uint64_t next_ticket = 0, serving = 0;
+  uint64_t take() { std::lock_guard<std::mutex> g(mu); return next_ticket++; }
+};
+struct Turn {   // RAII: wait for the ticket's turn, release it on scope exit
+  Handle* h; std::unique_lock<std::mutex> lk;
+  Turn(Handle* hh, uint64_t ticket) : h(hh), lk(hh->mu) { h->cv.wait(lk, [&] { return h->serving == ticket; }); }
+  explicit Turn(Handle* hh) : h(hh), lk(hh->mu) { const uint64_t t = h->next_ticket++; h->cv.wait(lk, [&] { return h->serving == t; }); }
+  ~Turn() { h->serving++; lk.unlock(); h->cv.notify_all(); }
+};
 
 void finalize_handle(napi_env, void* data, void*) {
   Handle* h = static_cast<Handle*>(data);
@@ -111,7 +126,7 @@ napi_value Destroy(napi_env env, napi_callback_info info) {
   void* p = nullptr;
   if (napi_get_value_external(env, argv[0], &p) == napi_ok && p) {
     Handle* h = static_cast<Handle*>(p);
-    std::lock_guard<std::mutex> g(h->mu);
+    Turn turn(h);                                   // after every operation issued before the close
     if (h->ctx) { bmx_destroy(h->ctx); h->ctx = nullptr; }
   }
   return nullptr;
@@ -137,7 +152,7 @@ napi_value MergeBatch(napi_env env, napi_callback_info info) {
   void* fl = nullptr;
   napi_value flags = make_ta(env, napi_uint8_array, 1, n, &fl);
   uint64_t na = 0; bmx_merge_stats st; memset(&st, 0, sizeof(st));
-  std::lock_guard<std::mutex> g(h->mu);
+  Turn turn(h);
   int rc = bmx_merge_batch(h->ctx, n, id, field, ts, val, mode, BMX_MEM_HOST, applied.data(), &na, (uint8_t*)fl, &st);
   if (rc) return throw_bmx(env, h->ctx, rc);
   void* ap = nullptr;
@@ -155,8 +170,9 @@ napi_value MergeBatch(napi_env env, napi_callback_info info) {
 struct MergeJob {
   napi_async_work work = nullptr;
   napi_deferred deferred = nullptr;
-  napi_ref refs[4] = {nullptr, nullptr, nullptr, nullptr};
+  napi_ref refs[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};   // the four columns and the engine handle itself: the engine outlives the job
   Handle* h = nullptr;
+  uint64_t ticket = 0;
   const uint64_t* id = nullptr; const uint32_t* field = nullptr; const int64_t* ts = nullptr; const int64_t* val = nullptr;
   size_t n = 0; int mode = 0;
   std::vector<uint32_t> applied; std::vector<uint8_t> flags;
@@ -165,7 +181,7 @@ struct MergeJob {
 
 void merge_execute(napi_env, void* data) {
   MergeJob* j = static_cast<MergeJob*>(data);
-  std::lock_guard<std::mutex> g(j->h->mu);
+  Turn turn(j->h, j->ticket);                       // merges apply in the order JS issued them, whatever worker picks them up
   if (!j->h->ctx) { j->rc = BMX_ERR_INVALID; j->err = "engine closed"; return; }
   j->rc = bmx_merge_batch(j->h->ctx, j->n, j->id, j->field, j->ts, j->val, j->mode, BMX_MEM_HOST, j->applied.data(), &j->na, j->flags.data(), &j->st);
   if (j->rc) j->err = bmx_last_error(j->h->ctx);
@@ -211,6 +227,8 @@ napi_value MergeBatchAsync(napi_env env, napi_callback_info info) {
   j->applied.resize(j->n ? j->n : 1); j->flags.resize(j->n ? j->n : 1);
   memset(&j->st, 0, sizeof(j->st));
   for (int k = 0; k < 4; k++) napi_create_reference(env, argv[1 + k], 1, &j->refs[k]);
+  napi_create_reference(env, argv[0], 1, &j->refs[4]);
+  j->ticket = h->take();
   napi_value promise, name;
   NAPI_OK(napi_create_promise(env, &j->deferred, &promise));
   NAPI_OK(napi_create_string_utf8(env, "bmx.mergeBatchAsync", NAPI_AUTO_LENGTH, &name));
@@ -223,7 +241,7 @@ napi_value Reserve(napi_env env, napi_callback_info info) {
   ARGS(2);
   Handle* h; if (!get_handle(env, argv[0], &h)) return nullptr;
   double cap; NAPI_OK(napi_get_value_double(env, argv[1], &cap));
-  std::lock_guard<std::mutex> g(h->mu);
+  Turn turn(h);
   int rc = bmx_reserve(h->ctx, (uint64_t)cap);
   if (rc) return throw_bmx(env, h->ctx, rc);
   return nullptr;
@@ -232,7 +250,7 @@ napi_value Reserve(napi_env env, napi_callback_info info) {
 napi_value LoadRows(napi_env env, napi_callback_info info) {
   ARGS(5);
   Handle* h; if (!get_handle(env, argv[0], &h)) return nullptr;
-  std::lock_guard<std::mutex> lock(h->mu);   // a context is not re-entrant; async merges run on worker threads
+  Turn turn(h);   // runs in issue order with the asynchronous merges
   const uint64_t* id; const uint32_t* field; const int64_t *ts, *val; size_t n;
   if (!get_cols(env, argv + 1, &id, &field, &ts, &val, &n)) return nullptr;
   int rc = bmx_load_rows(h->ctx, n, id, field, ts, val, BMX_MEM_HOST);
@@ -244,7 +262,7 @@ napi_value LoadRows(napi_env env, napi_callback_info info) {
 napi_value GetRows(napi_env env, napi_callback_info info) {
   ARGS(3);
   Handle* h; if (!get_handle(env, argv[0], &h)) return nullptr;
-  std::lock_guard<std::mutex> lock(h->mu);   // a context is not re-entrant; async merges run on worker threads
+  Turn turn(h);   // runs in issue order with the asynchronous merges
   void *p0, *p1; size_t n0, n1;
   if (!get_ta(env, argv[1], napi_biguint64_array, &p0, &n0) || !get_ta(env, argv[2], napi_uint32_array, &p1, &n1)) return nullptr;
   if (n0 != n1) { napi_throw_range_error(env, nullptr, "bmx: column lengths differ"); return nullptr; }
@@ -260,7 +278,7 @@ napi_value GetRows(napi_env env, napi_callback_info info) {
 napi_value RowCount(napi_env env, napi_callback_info info) {
   ARGS(1);
   Handle* h; if (!get_handle(env, argv[0], &h)) return nullptr;
-  std::lock_guard<std::mutex> lock(h->mu);   // a context is not re-entrant; async merges run on worker threads
+  Turn turn(h);   // runs in issue order with the asynchronous merges
   uint64_t n = 0; int rc = bmx_row_count(h->ctx, &n);
   if (rc) return throw_bmx(env, h->ctx, rc);
   napi_value v; napi_create_double(env, (double)n, &v); return v;
@@ -269,7 +287,7 @@ napi_value RowCount(napi_env env, napi_callback_info info) {
 napi_value DumpRows(napi_env env, napi_callback_info info) {
   ARGS(1);
   Handle* h; if (!get_handle(env, argv[0], &h)) return nullptr;
-  std::lock_guard<std::mutex> lock(h->mu);   // a context is not re-entrant; async merges run on worker threads
+  Turn turn(h);   // runs in issue order with the asynchronous merges
   uint64_t n = 0; int rc = bmx_row_count(h->ctx, &n);
   if (rc) return throw_bmx(env, h->ctx, rc);
   void *id, *f, *ts, *val;
@@ -287,7 +305,7 @@ napi_value DumpRows(napi_env env, napi_callback_info info) {
 napi_value IndexBuild(napi_env env, napi_callback_info info) {
   ARGS(2);
   Handle* h; if (!get_handle(env, argv[0], &h)) return nullptr;
-  std::lock_guard<std::mutex> lock(h->mu);   // a context is not re-entrant; async merges run on worker threads
+  Turn turn(h);   // runs in issue order with the asynchronous merges
   uint32_t f; NAPI_OK(napi_get_value_uint32(env, argv[1], &f));
   int rc = bmx_index_build(h->ctx, f);
   if (rc) return throw_bmx(env, h->ctx, rc);
@@ -296,7 +314,7 @@ napi_value IndexBuild(napi_env env, napi_callback_info info) {
 napi_value IndexDrop(napi_env env, napi_callback_info info) {
   ARGS(2);
   Handle* h; if (!get_handle(env, argv[0], &h)) return nullptr;
-  std::lock_guard<std::mutex> lock(h->mu);   // a context is not re-entrant; async merges run on worker threads
+  Turn turn(h);   // runs in issue order with the asynchronous merges
   uint32_t f; NAPI_OK(napi_get_value_uint32(env, argv[1], &f));
   int rc = bmx_index_drop(h->ctx, f);
   if (rc && rc != BMX_ERR_NO_INDEX) return throw_bmx(env, h->ctx, rc);
@@ -305,7 +323,7 @@ napi_value IndexDrop(napi_env env, napi_callback_info info) {
 napi_value IndexSize(napi_env env, napi_callback_info info) {
   ARGS(2);
   Handle* h; if (!get_handle(env, argv[0], &h)) return nullptr;
-  std::lock_guard<std::mutex> lock(h->mu);   // a context is not re-entrant; async merges run on worker threads
+  Turn turn(h);   // runs in issue order with the asynchronous merges
   uint32_t f; NAPI_OK(napi_get_value_uint32(env, argv[1], &f));
   uint64_t n = 0; int rc = bmx_index_size(h->ctx, f, &n);
   if (rc) return throw_bmx(env, h->ctx, rc);
@@ -316,7 +334,7 @@ napi_value IndexSize(napi_env env, napi_callback_info info) {
 napi_value ScanRange(napi_env env, napi_callback_info info) {
   ARGS(4);
   Handle* h; if (!get_handle(env, argv[0], &h)) return nullptr;
-  std::lock_guard<std::mutex> lock(h->mu);   // a context is not re-entrant; async merges run on worker threads
+  Turn turn(h);   // runs in issue order with the asynchronous merges
   uint32_t f; NAPI_OK(napi_get_value_uint32(env, argv[1], &f));
   int64_t lo, hi; if (!get_i64(env, argv[2], &lo) || !get_i64(env, argv[3], &hi)) return nullptr;
   uint64_t m = 0; int rc = bmx_scan_count(h->ctx, f, lo, hi, &m, BMX_MEM_HOST);
@@ -328,7 +346,7 @@ napi_value ScanRange(napi_env env, napi_callback_info info) {
 napi_value ScanCount(napi_env env, napi_callback_info info) {
   ARGS(4);
   Handle* h; if (!get_handle(env, argv[0], &h)) return nullptr;
-  std::lock_guard<std::mutex> lock(h->mu);   // a context is not re-entrant; async merges run on worker threads
+  Turn turn(h);   // runs in issue order with the asynchronous merges
   uint32_t f; NAPI_OK(napi_get_value_uint32(env, argv[1], &f));
   int64_t lo, hi; if (!get_i64(env, argv[2], &lo) || !get_i64(env, argv[3], &hi)) return nullptr;
   uint64_t m = 0; int rc = bmx_scan_count(h->ctx, f, lo, hi, &m, BMX_MEM_HOST);
@@ -339,7 +357,7 @@ napi_value ScanCount(napi_env env, napi_callback_info info) {
 napi_value ScanFilter(napi_env env, napi_callback_info info) {
   ARGS(2);
   Handle* h; if (!get_handle(env, argv[0], &h)) return nullptr;
-  std::lock_guard<std::mutex> lock(h->mu);   // a context is not re-entrant; async merges run on worker threads
+  Turn turn(h);   // runs in issue order with the asynchronous merges
   uint32_t nt = 0; NAPI_OK(napi_get_array_length(env, argv[1], &nt));
   if (nt == 0 || nt > 8) { napi_throw_range_error(env, nullptr, "bmx: filter needs 1..8 terms"); return nullptr; }
   bmx_term terms[8];
@@ -364,7 +382,7 @@ napi_value ScanFilter(napi_env env, napi_callback_info info) {
 napi_value Info(napi_env env, napi_callback_info info) {
   ARGS(1);
   Handle* h; if (!get_handle(env, argv[0], &h)) return nullptr;
-  std::lock_guard<std::mutex> lock(h->mu);   // a context is not re-entrant; async merges run on worker threads
+  Turn turn(h);   // runs in issue order with the asynchronous merges
   bmx_info i; int rc = bmx_get_info(h->ctx, &i);
   if (rc) return throw_bmx(env, h->ctx, rc);
   napi_value out; NAPI_OK(napi_create_object(env, &out));

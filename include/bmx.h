@@ -164,6 +164,15 @@ int bmx_load_rows(bmx_ctx* ctx, uint64_t n, const uint64_t* id, const uint32_t* 
 int bmx_merge_batch(bmx_ctx* ctx, uint64_t n, const uint64_t* id, const uint32_t* field, const int64_t* ts,
                     const int64_t* val, int insert_mode, int mem, uint32_t* applied_idx, uint64_t* n_applied,
                     uint8_t* flags, bmx_merge_stats* stats);
+/* Pipelined form of bmx_merge_batch(BMX_MEM_HOST) for a host that streams batches (the sync replay of
+ * src/bullet-network-sync.js:551-569 with chunks of 10^5..10^6 entries): bmx_merge_submit uploads the batch and enqueues its merge,
+ * bmx_merge_collect returns that batch's winners / flags / stats. Up to TWO batches may be in flight, so the upload of batch b+1
+ * (PCIe, the expensive part of a host batch) runs while the GPU merges batch b; results arrive one batch late. Batches are applied
+ * in submission order; collect in the same order. The input arrays may be reused as soon as bmx_merge_submit returns.
+ * bmx_merge_batch(BMX_MEM_HOST) is exactly submit + collect. want_flags = 0 skips the per-delta flag transfer. */
+int bmx_merge_submit(bmx_ctx* ctx, uint64_t n, const uint64_t* id, const uint32_t* field, const int64_t* ts, const int64_t* val, int insert_mode,
+                     int want_flags, uint64_t* ticket);
+int bmx_merge_collect(bmx_ctx* ctx, uint64_t ticket, uint32_t* applied_idx, uint64_t* n_applied, uint8_t* flags, bmx_merge_stats* stats);
 /* same, deltas as 32-byte records (device pointers only): the receive side of the sharded exchange */
 int bmx_merge_records(bmx_ctx* ctx, uint64_t n, const bmx_delta_rec* recs, int insert_mode, uint32_t* applied_idx,
                       uint64_t* n_applied, uint8_t* flags, bmx_merge_stats* stats);

@@ -196,3 +196,37 @@ def test_sequence_words_order_two_streams():
         e.sync()
         with pytest.raises(bmx.BmxError):
             e.seq_wait(b.cuda_stream, None, 1)
+
+
+def test_pipelined_host_batches_submit_collect():
+    """bmx_merge_submit / bmx_merge_collect: two host batches in flight (upload of b+1 under the merge of b), results one batch late,
+    same winners / flags / state as the synchronous calls; a third submit, an unknown ticket and an out-of-order collect are refused."""
+    R, D, NBATCH = 50_000, 20_000, 6
+    res = synth.big_resident(R, seed=31)
+    bs = [synth.big_deltas(D, R, seed=32, insert_pct=10, hot_pct=20, hot_keys=64, unique=False, batch=b) for b in range(NBATCH)]
+    o = Oracle(); o.load_rows(*res)
+    want = [o.merge_batch(*b) for b in bs]
+    with bmx.Engine(4 * (R + NBATCH * D)) as e:
+        e.load_rows(*res)
+        t_prev = e.merge_submit(*bs[0], want_flags=True)
+        for b in range(1, NBATCH):
+            t = e.merge_submit(*bs[b], want_flags=(b % 2 == 0))
+            if b == 1:
+                with pytest.raises(bmx.BmxError):            # a third batch before the first is collected
+                    e.merge_submit(*bs[2])
+                with pytest.raises(bmx.BmxError):            # out of order
+                    e.merge_collect(t)
+                with pytest.raises(bmx.BmxError):            # a synchronous merge while batches are in flight
+                    e.merge_batch(*bs[0])
+            applied, flags, st = e.merge_collect(t_prev)
+            assert np.array_equal(applied, want[b - 1][1]), b
+            assert st.n_applied == len(applied)
+            t_prev = t
+        applied, flags, st = e.merge_collect(t_prev)
+        assert np.array_equal(applied, want[-1][1]) and st.n_rows == len(o)
+        with pytest.raises(bmx.BmxError):
+            e.merge_collect(t_prev)                          # already collected
+        assert rows_digest(*e.dump_rows()) == o.digest()
+        a2, _, _ = e.merge_batch(*bs[0])                     # the synchronous form still works afterwards
+        _, w2 = o.merge_batch(*bs[0])
+        assert np.array_equal(a2, w2)
