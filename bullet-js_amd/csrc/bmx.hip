@@ -74,7 +74,8 @@ struct bmx_ctx {
     hipEvent_t up = nullptr, done = nullptr;                                  // inputs uploaded / kernels of the batch finished
     uint64_t n = 0; bool want_flags = false; bool busy = false; uint64_t ticket = 0;
   } stg[2];
-  hipStream_t copy_stream = nullptr;
+  hipStream_t copy_stream = nullptr;   // uploads
+  hipStream_t down_stream = nullptr;   // downloads (PCIe is full duplex: results of batch b come back while batch b+1 goes up)
   uint64_t next_ticket = 1;
   // persistent device buffers of the host-mode point reads and dumps (grow-only)
   uint64_t pr_cap = 0;
@@ -196,6 +197,7 @@ int ensure_staging(bmx_ctx* ctx, int k, uint64_t n) {
   if (n <= S.cap) return BMX_OK;
   HIPCHK(hipStreamSynchronize(ctx->stream));
   HIPCHK(hipStreamSynchronize(ctx->copy_stream));
+  HIPCHK(hipStreamSynchronize(ctx->down_stream));
   uint64_t cap = std::max<uint64_t>(n, 1u << 16);
   cap = (cap + 255) & ~255ull;
   dev_free(S.id); dev_free(S.field); dev_free(S.ts); dev_free(S.val); dev_free(S.applied); dev_free(S.flags);
@@ -399,16 +401,16 @@ int collect_host(bmx_ctx* ctx, uint64_t ticket, uint32_t* applied_idx, uint64_t*
   bmx_ctx::Staging& S = ctx->stg[k];
   S.busy = false;
   bmx_merge_stats hs; std::memset(&hs, 0, sizeof(hs));
-  HIPCHK(hipStreamWaitEvent(ctx->copy_stream, S.done, 0));
+  HIPCHK(hipStreamWaitEvent(ctx->down_stream, S.done, 0));
   uint32_t st = 0;
-  HIPCHK(hipMemcpyAsync(&hs, S.stats, sizeof(hs), hipMemcpyDeviceToHost, ctx->copy_stream));
-  HIPCHK(hipMemcpyAsync(&st, &ctx->ds->status, sizeof(st), hipMemcpyDeviceToHost, ctx->copy_stream));
-  HIPCHK(hipStreamSynchronize(ctx->copy_stream));
+  HIPCHK(hipMemcpyAsync(&hs, S.stats, sizeof(hs), hipMemcpyDeviceToHost, ctx->down_stream));
+  HIPCHK(hipMemcpyAsync(&st, &ctx->ds->status, sizeof(st), hipMemcpyDeviceToHost, ctx->down_stream));
+  HIPCHK(hipStreamSynchronize(ctx->down_stream));
   if (st) return check_status(ctx);     // sticky device error of this (or an earlier, uncollected) batch
   if (S.n == 0) std::memset(&hs, 0, sizeof(hs));
-  if (applied_idx && hs.n_applied) HIPCHK(hipMemcpyAsync(applied_idx, S.applied, hs.n_applied * 4, hipMemcpyDeviceToHost, ctx->copy_stream));
-  if (flags && S.n && S.want_flags) HIPCHK(hipMemcpyAsync(flags, S.flags, S.n, hipMemcpyDeviceToHost, ctx->copy_stream));
-  HIPCHK(hipStreamSynchronize(ctx->copy_stream));
+  if (applied_idx && hs.n_applied) HIPCHK(hipMemcpyAsync(applied_idx, S.applied, hs.n_applied * 4, hipMemcpyDeviceToHost, ctx->down_stream));
+  if (flags && S.n && S.want_flags) HIPCHK(hipMemcpyAsync(flags, S.flags, S.n, hipMemcpyDeviceToHost, ctx->down_stream));
+  HIPCHK(hipStreamSynchronize(ctx->down_stream));
   if (!ctx->stg[1 - k].busy && S.n) ctx->rows_ub = hs.n_rows;   // exact again once nothing else is in flight
   if (n_applied) *n_applied = hs.n_applied;
   if (stats) *stats = hs;
@@ -611,6 +613,7 @@ int bmx_create_ex(int device, uint64_t capacity_rows, uint32_t max_load_pct, uin
   CR(hipEventCreate(&ctx->ev0));
   CR(hipEventCreate(&ctx->ev1));
   CR(hipStreamCreateWithFlags(&ctx->copy_stream, hipStreamNonBlocking));
+  CR(hipStreamCreateWithFlags(&ctx->down_stream, hipStreamNonBlocking));
   for (int i = 0; i < 2; i++) { CR(hipEventCreateWithFlags(&ctx->stg[i].up, hipEventDisableTiming)); CR(hipEventCreateWithFlags(&ctx->stg[i].done, hipEventDisableTiming)); }
   const uint64_t nslots = slots_for(capacity_rows, max_load_pct);
   ctx->nslots = nslots;
@@ -652,6 +655,7 @@ void bmx_destroy(bmx_ctx* ctx) {
   }
   dev_free(ctx->pr_id); dev_free(ctx->pr_field); dev_free(ctx->pr_ts); dev_free(ctx->pr_val); dev_free(ctx->pr_found);
   if (ctx->copy_stream) (void)hipStreamDestroy(ctx->copy_stream);
+  if (ctx->down_stream) { (void)hipStreamSynchronize(ctx->down_stream); (void)hipStreamDestroy(ctx->down_stream); }
   dev_free(ctx->bin_stage); dev_free(ctx->bin_toff);
   dev_free(ctx->scan_out); dev_free(ctx->block_counts); dev_free(ctx->part_counts); dev_free(ctx->part_owner); dev_free(ctx->scan_mask); dev_free(ctx->scan_counts);
   for (auto ev : ctx->prof_ev) (void)hipEventDestroy(ev);

@@ -223,7 +223,8 @@ class GpuCRT {
    * entries: [{path, data, vectorClock}] where data is an integer or an object of integer fields and
    * vectorClock is {<writer>: ts}. Each (node, field) becomes one device row. Entries outside that contract
    * (strings, nested objects, multi-writer clocks) are returned in `host` for the caller to pass to setData().
-   * -> {applied: [{entry, field}], nConflicts, host: [entry indices]}
+   * opts.apply: true = update the facade's store/meta/log/listeners once for the batch (N1), "each" = one _applyUpdate per winner.
+   * -> {applied: [{entry, field}], nConflicts, host: [entry indices], broadcast: [{path, broadcastData}] when applied}
    */
   mergeEntries(entries, opts = {}) {
     if (this._opts.writers) return this._mergeEntriesVector(entries, opts);
@@ -266,33 +267,42 @@ class GpuCRT {
     });
     const r = this.mergeBatch(cols, opts);
     const applied = Array.from(r.applied, (j) => back[j]);
-    if (opts.apply) this._applyWinners(entries, cols, r.applied, applied);
-    return { applied, nApplied: r.nApplied, nConflicts: r.nConflicts, nRows: r.nRows, host };
+    const broadcast = opts.apply ? this._applyWinners(entries, cols, r.applied, applied, opts.apply) : undefined;
+    return { applied, nApplied: r.nApplied, nConflicts: r.nConflicts, nRows: r.nRows, host, broadcast };
   }
 
   /*
    * N1 (SURVEY §8(f)): hand the batch's final winners to the facade in ONE pass. Each winning row is the leaf
    * `<entry.path>[/<field>]`; its stored clock and value are read back from the device (an inserted row's clock is
-   * {writer: 2}, not the incoming one) and applied through the facade's own _applyUpdate (store, meta, op log,
-   * listeners: src/bullet.js:184-266) when it has one.
+   * {writer: 2}, not the incoming one). opts.apply === true: store, meta, op log and listeners are updated once for the whole
+   * batch (batch-apply.js: ring-style log, ancestor listeners de-duplicated; a facade may supply its own `_applyBatch`);
+   * opts.apply === "each": the facade's per-write `_applyUpdate` is called once per winner (src/bullet.js:184-266), the
+   * reference's own cost per write. Returns what setData would have broadcast per winner (src/bullet-crt.js:371-376).
    */
-  _applyWinners(entries, cols, appliedIdx, applied) {
+  _applyWinners(entries, cols, appliedIdx, applied, mode) {
     const n = appliedIdx.length;
-    if (n === 0) return;
+    if (n === 0) return [];
     const ids = new BigUint64Array(n), fields = new Uint32Array(n);
     for (let k = 0; k < n; k++) { ids[k] = cols.id[appliedIdx[k]]; fields[k] = cols.field[appliedIdx[k]]; }
     const rows = this.graph.getRows(ids, fields);
     const writer = this._opts.writer || this.bullet.id;
+    const updates = new Array(n);
     for (let k = 0; k < n; k++) {
       const a = applied[k];
       const e = entries[a.entry];
       const leaf = a.field === null ? e.path : e.path + "/" + a.field;
       const clock = {};
       clock[writer] = Number(rows.ts[k]);
-      const value = Number(rows.val[k]);
-      if (typeof this.bullet._applyUpdate === "function") this.bullet._applyUpdate(leaf, value, clock, true);
+      updates[k] = { path: leaf, value: Number(rows.val[k]), vectorClock: clock };
       this.vectorClocks.set(leaf, clock);
     }
+    const b = this.bullet;
+    if (mode === "each") {
+      if (typeof b._applyUpdate === "function") for (const u of updates) b._applyUpdate(u.path, u.value, u.vectorClock, true);
+      return updates.map((u) => ({ path: u.path, broadcastData: u.value }));
+    }
+    if (typeof b._applyBatch === "function") return b._applyBatch(updates, true) || [];
+    return require("./batch-apply").applyBatch(b, updates, true);
   }
 
   /* ---------------------------------------------------------------- N4: K-writer vector clocks on the device */

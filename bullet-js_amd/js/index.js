@@ -9,16 +9,26 @@
  */
 const GpuCRT = require("./gpu-crt");
 const GpuQuery = require("./gpu-query");
+const GpuStorage = require("./gpu-storage");
+const { installBatchSync } = require("./batch-sync");
+const { applyBatch } = require("./batch-apply");
 const hash = require("./hash");
 const native = require("./native");
 
-/** Install GpuCRT and GpuQuery on a Bullet instance; one DeviceGraph is shared and created on first device use. */
+/** Install GpuCRT and GpuQuery on a Bullet instance; one DeviceGraph is shared and created on first device use.
+ *  opts.batchSync: also route the facade's remote-write ingestion (sync chunks, network puts: src/bullet-network-sync.js:551-569,
+ *  src/bullet-network.js:332-346) through the batch path (batch-sync.js). If the instance was created with
+ *  `storageType: GpuStorage`, the rows that storage loaded from disk are preloaded into the device table when the graph is created. */
 function attach(bullet, opts = {}) {
   const shared = Object.assign({}, opts);
   let graph = opts.graph || null;
   const lazy = {
     get graph() {
-      if (!graph) { const DeviceGraph = require("./device-graph"); graph = new DeviceGraph(shared); }
+      if (!graph) {
+        const DeviceGraph = require("./device-graph");
+        graph = new DeviceGraph(shared);
+        if (bullet.storage instanceof GpuStorage) bullet.storage.restoreDevice(graph);
+      }
       return graph;
     },
   };
@@ -28,12 +38,17 @@ function attach(bullet, opts = {}) {
   const query = new GpuQuery(bullet, opts);
   Object.defineProperty(query, "graph", { get: () => lazy.graph });
   bullet.query = query;
+  Object.defineProperty(crt, "_graph", { get: () => graph, set: (g) => { graph = g; }, configurable: true });
+  const sync = opts.batchSync ? installBatchSync(bullet, crt, typeof opts.batchSync === "object" ? opts.batchSync : {}) : null;
   const close = bullet.close ? bullet.close.bind(bullet) : null;
   bullet.close = async function () {
+    if (sync) sync.uninstall();
+    let r;
+    if (close) r = await close();          // storage.close() saves first: it may still need the device rows
     if (graph) { graph.close(); graph = null; }
-    if (close) return close();
+    return r;
   };
-  return { crt, query };
+  return { crt, query, sync };
 }
 
-module.exports = { GpuCRT, GpuQuery, attach, hash, nativeAvailable: native.available };
+module.exports = { GpuCRT, GpuQuery, GpuStorage, attach, installBatchSync, applyBatch, hash, nativeAvailable: native.available };

@@ -188,7 +188,7 @@ for (const shards of [2, 4, 8]) {
     { path: "acct/b", data: { bal: 20 }, vectorClock: { w: 100 } },
     { path: "acct/a", data: { bal: 15 }, vectorClock: { w: 101 } },
   ];
-  const r1 = crt.mergeEntries(entries, { apply: true });
+  const r1 = crt.mergeEntries(entries, { apply: "each" });   // the facade's own per-write hook
   // reference insert rule: a first write stores clock {w:2}; the later delta (101 > 2) then wins acct/a/bal
   assert.deepStrictEqual(applied, [["acct/a/seq", 1, 2, true], ["acct/b/bal", 20, 2, true], ["acct/a/bal", 15, 101, true]]);
   assert.deepStrictEqual(b.store, { acct: { a: { seq: 1, bal: 15 }, b: { bal: 20 } } });
@@ -204,6 +204,87 @@ for (const shards of [2, 4, 8]) {
   assert.deepStrictEqual(again.applied, [{ entry: 1, field: "bal" }]);      // 50 < 101 loses; (2,21) > (2,20) wins the tie by value
   b2.close();
   checks += 6;
+}
+
+/* N2: the reference's sync-chunk loop, batched. Fixture generated by running the REAL BulletNetworkSync._processSyncEntries
+ * (tests/golden/g8_sync_chunk.json): final store, and clock + source of every path the host path owns — including the tagging quirk
+ * (primitives arrive untagged, are treated as local writes and always accepted). Device-eligible entries ({ints}, clock {w: ts}) go
+ * through one merge per run; their clocks live per leaf. */
+{
+  const g = load("g8_sync_chunk.json");
+  const b = new MiniBullet(g.id);
+  const { crt, sync } = attach(b, { capacityRows: 4096, batchSync: true });
+  for (const chunk of g.chunks) sync.processSyncEntries(JSON.parse(JSON.stringify(chunk)), "peer-1");
+  assert.deepStrictEqual(JSON.parse(JSON.stringify(b.store)), g.store, "store after three sync chunks");
+  const deviceNodes = new Set(["acct/a", "acct/b", "acct/e"]);     // nodes that only ever arrived inside the device contract
+  for (const p of Object.keys(g.meta)) {
+    if (deviceNodes.has(p)) {
+      for (const f of Object.keys(g.store.acct[p.split("/")[1]])) {
+        assert.deepStrictEqual(b.meta[p + "/" + f].vectorClock, g.meta[p].vectorClock, "leaf clock of " + p + "/" + f);
+        assert.strictEqual(b.meta[p + "/" + f].source, "network");
+        checks++;
+      }
+    } else if (p !== "acct/c") {                                    // acct/c: created on the device, then deleted through the host path
+      assert.deepStrictEqual(b.meta[p].vectorClock, g.meta[p].vectorClock, "clock of " + p);
+      assert.strictEqual(b.meta[p].source, g.meta[p].source, "source of " + p);
+      checks++;
+    }
+  }
+  assert.strictEqual(b.meta["cfg/limit"].source, "local");          // the quirk: a primitive from the network is a local write
+  assert.strictEqual(b.store.acct.c, null);
+  assert.ok(sync.stats.deviceBatches >= 3 && sync.stats.hostEntries >= 7, JSON.stringify(sync.stats));
+  // network puts: queued and merged when the event loop turns, in arrival order
+  sync.handlePut("peer-2", { path: "acct/a", data: { bal: 500, seq: 9, __vectorClock: { w: 151 } } });
+  sync.handlePut("peer-2", { path: "acct/a", data: { bal: 1, seq: 1, __vectorClock: { w: 3 } } });
+  sync.handlePut("peer-2", { path: "cfg/name", data: "gamma" });
+  sync.flush();
+  assert.deepStrictEqual(b.store.acct.a, { bal: 500, seq: 9 });
+  assert.strictEqual(b.store.cfg.name, "gamma");
+  b.close();
+  checks += 6;
+}
+
+/* N3 (device side): a reference-written storage directory -> device rows; rows that reach the device through typed columns only
+ * are folded back into store.json / meta.json on save */
+{
+  const os = require("os");
+  const { GpuStorage } = require("..");
+  const src = path.join(GOLD, "g7_storage_dir");
+  const tmp = fs.mkdtempSync(path.join(os.tmpdir(), "bmx-n3d-"));
+  for (const f of ["store.json", "meta.json"]) fs.copyFileSync(path.join(src, f), path.join(tmp, f));
+  const b = new MiniBullet("w");
+  b.storage = new GpuStorage(b, { path: tmp, saveInterval: 0 });
+  const { crt } = attach(b, { capacityRows: 4096 });
+  const wantStore = JSON.parse(fs.readFileSync(path.join(src, "store.json"), "utf8")), wantMeta = JSON.parse(fs.readFileSync(path.join(src, "meta.json"), "utf8"));
+  const g = crt.graph;                                               // created now: preloaded from what the storage loaded
+  assert.strictEqual(g.rowCount(), 40 * 2 + 1);                       // 40 nodes x {age, score} + cfg/count
+  const ids = new BigUint64Array(80), id32 = new Uint32Array(ids.buffer), fields = new Uint32Array(80);
+  let k = 0;
+  for (let i = 0; i < 40; i++) for (const f of ["age", "score"]) { const id = g.keys.idOf("n/k" + i); id32[2 * k] = id[0]; id32[2 * k + 1] = id[1]; fields[k] = g.keys.fieldOf("n", f); k++; }
+  const rows = g.getRows(ids, fields);
+  k = 0;
+  for (let i = 0; i < 40; i++) for (const f of ["age", "score"]) {
+    assert.strictEqual(rows.found[k], 1);
+    assert.strictEqual(Number(rows.val[k]), wantStore.n["k" + i][f]);
+    assert.strictEqual(Number(rows.ts[k]), wantMeta["n/k" + i].vectorClock.w);
+    k++;
+  }
+  // a sync chunk merges against the restored clocks: 1 is historical everywhere, 1000 wins everywhere
+  const r = crt.mergeEntries([{ path: "n/k0", data: { age: 1 }, vectorClock: { w: 1 } }, { path: "n/k1", data: { age: 77 }, vectorClock: { w: 1000 } }], { apply: true });
+  assert.deepStrictEqual(r.applied, [{ entry: 1, field: "age" }]);
+  // rows that arrive as typed columns only (no facade write) are folded into the files on save
+  const cols = new hash.Columns(1);
+  cols.set(0, g.keys.idOf("n/k2"), g.keys.fieldOf("n", "score"), 5000, 4242);
+  crt.mergeBatch(cols);
+  b.storage.save();
+  const savedStore = JSON.parse(fs.readFileSync(path.join(tmp, "store.json"), "utf8")), savedMeta = JSON.parse(fs.readFileSync(path.join(tmp, "meta.json"), "utf8"));
+  assert.strictEqual(savedStore.n.k2.score, 4242);
+  assert.deepStrictEqual(savedMeta["n/k2/score"].vectorClock, { w: 5000 });
+  assert.strictEqual(savedStore.n.k1.age, 77);
+  assert.deepStrictEqual(savedMeta["n/k1/age"].vectorClock, { w: 1000 });
+  assert.strictEqual(savedStore.n.k0.age, wantStore.n.k0.age);
+  b.close();
+  checks += 8 + 80;
 }
 
 /* device-sourced index: rows ingested by mergeEntries are queried without re-uploading anything from the JS store */

@@ -97,6 +97,81 @@ function queryExample(makeBullet, label) {
 }
 queryExample(() => { const b = new MiniBullet("w"); b.crt = new GpuCRT(b); b.query = new GpuQuery(b); return b; }, "mini");
 
+/* N1: one batched apply pass == the facade's per-write _applyUpdate loop (store, meta, log tail, what listeners see) */
+const { applyBatch, GpuStorage } = require("..");
+function perWriteApply(b, path, value, vectorClock, fromNetwork) {      // the facade's tail as MiniBullet/the reference run it per write
+  if (typeof b._applyUpdate === "function") return b._applyUpdate(path, value, vectorClock, fromNetwork);
+  const segs = path.split("/").filter(Boolean); let node = b.store;
+  for (const sgm of segs.slice(0, -1)) { if (!node[sgm]) node[sgm] = {}; node = node[sgm]; }
+  node[segs[segs.length - 1]] = value;
+  b.meta[path] = Object.assign({}, b.meta[path] || {}, { source: fromNetwork ? "network" : "local", vectorClock, lastModified: Date.now() });
+  b.log.push({ op: "set", path, data: value, vectorClock, timestamp: Date.now() });
+  if (b.log.length > 1000) b.log.splice(0, b.log.length - 1000);
+}
+function batchApplyCase(makeBullet, label, n) {
+  let s = 777; const rnd = () => { s ^= s << 13; s >>>= 0; s ^= s >>> 17; s ^= s << 5; s >>>= 0; return s; };
+  const updates = [];
+  for (let i = 0; i < n; i++) updates.push({ path: "n/k" + (rnd() % 300) + "/" + ["age", "score", "hits"][rnd() % 3], value: (rnd() % 2001) - 1000, vectorClock: { w: 2 + (rnd() % 500) } });
+  const a = makeBullet(), b = makeBullet();
+  const seenA = { leaf: [], node: [], root: [] }, seenB = { leaf: [], node: [], root: [] };
+  for (const [bb, seen] of [[a, seenA], [b, seenB]]) {
+    bb.listeners = bb.listeners || {};
+    bb.listeners[updates[0].path] = [(v) => seen.leaf.push(v)];
+    bb.listeners["n/" + updates[0].path.split("/")[1]] = [(v) => seen.node.push(JSON.stringify(v))];
+    bb.listeners["n"] = [(v) => seen.root.push(Object.keys(v).length)];
+  }
+  for (const u of updates) perWriteApply(a, u.path, u.value, u.vectorClock, true);
+  const out = applyBatch(b, updates, true);
+  assert.deepStrictEqual(JSON.parse(JSON.stringify(b.store)), JSON.parse(JSON.stringify(a.store)), label + " store");
+  const strip = (m) => { const o = {}; for (const k of Object.keys(m)) o[k] = { source: m[k].source, vectorClock: m[k].vectorClock }; return o; };
+  assert.deepStrictEqual(strip(b.meta), strip(a.meta), label + " meta");
+  const ops = (l) => l.map((e) => [e.op, e.path, e.data, e.vectorClock.w]);
+  assert.deepStrictEqual(ops(b.log), ops(a.log), label + " log tail");
+  assert.ok(b.log.length <= 1000);
+  assert.strictEqual(out.length, n);
+  assert.deepStrictEqual(out[n - 1], { path: updates[n - 1].path, broadcastData: updates[n - 1].value });
+  if (typeof a._notify === "function" || a.listeners) {   // a facade that notifies: exact-path listeners see every write, ancestors end on the same data
+    if (seenA.leaf.length) assert.deepStrictEqual(seenB.leaf, seenA.leaf, label + " leaf listener");
+    if (seenA.node.length) { assert.strictEqual(seenB.node[seenB.node.length - 1], seenA.node[seenA.node.length - 1]); assert.strictEqual(seenB.node.length, 1); }
+    if (seenA.root.length) { assert.strictEqual(seenB.root[seenB.root.length - 1], seenA.root[seenA.root.length - 1]); assert.strictEqual(seenB.root.length, 1); }
+  }
+  checks += 6;
+}
+batchApplyCase(() => new MiniBullet("w"), "mini 400", 400);
+batchApplyCase(() => new MiniBullet("w"), "mini 2500", 2500);     // more winners than the log keeps
+
+/* N3 (file side, no GPU): a directory written by the reference's BulletFileStorage loads through GpuStorage, yields the device rows
+ * of the contract, and is written back in the same shape */
+{
+  const os = require("os");
+  const src = path.join(GOLD, "g7_storage_dir");
+  const tmp = fs.mkdtempSync(path.join(os.tmpdir(), "bmx-n3-"));
+  for (const f of ["store.json", "meta.json"]) fs.copyFileSync(path.join(src, f), path.join(tmp, f));
+  const b = new MiniBullet("w");
+  b.crt = new GpuCRT(b);
+  const st = new GpuStorage(b, { path: tmp, saveInterval: 0 });
+  const wantStore = JSON.parse(fs.readFileSync(path.join(src, "store.json"), "utf8")), wantMeta = JSON.parse(fs.readFileSync(path.join(src, "meta.json"), "utf8"));
+  assert.deepStrictEqual(JSON.parse(JSON.stringify(b.store)), wantStore);
+  assert.deepStrictEqual(JSON.parse(JSON.stringify(b.meta)), wantMeta);
+  const { KeyDictionary } = require("../hash");
+  const { cols, n } = st.deviceRows(new KeyDictionary());
+  let expect = 0;
+  for (const p of Object.keys(wantMeta)) {
+    const v = p.split("/").reduce((o, k) => (o === undefined ? o : o[k]), wantStore);
+    const c = wantMeta[p].vectorClock;
+    if (Object.keys(c).length !== 1 || c.w === undefined) continue;
+    if (Number.isInteger(v)) expect += 1; else if (v && typeof v === "object" && Object.values(v).every(Number.isInteger)) expect += Object.keys(v).length;
+  }
+  assert.strictEqual(n, expect);
+  assert.ok(n >= 80);
+  assert.strictEqual(Number(cols.ts[0]), wantMeta["n/k0"].vectorClock.w);
+  st.save();
+  assert.deepStrictEqual(JSON.parse(fs.readFileSync(path.join(tmp, "store.json"), "utf8")), wantStore, "round trip store.json");
+  assert.deepStrictEqual(JSON.parse(fs.readFileSync(path.join(tmp, "meta.json"), "utf8")), wantMeta, "round trip meta.json");
+  st.close();
+  checks += 7;
+}
+
 /* With the real reference present: plug into the real Bullet at its two seams */
 const REF = process.env.BULLET_REF || "/root/reference";
 if (fs.existsSync(path.join(REF, "src", "bullet.js"))) {
@@ -112,6 +187,22 @@ if (fs.existsSync(path.join(REF, "src", "bullet.js"))) {
   });
   replayL1(() => mk(false), "real-bullet");
   quiet(() => queryExample(() => mk(true), "real-bullet"));
+  quiet(() => batchApplyCase(() => mk(false), "real-bullet 2500", 2500));     // against the reference's own _applyUpdate/_notify
+  {
+    // the reference's file storage reads what GpuStorage wrote, and the real facade accepts GpuStorage at its provider hook
+    const os = require("os");
+    const tmp = fs.mkdtempSync(path.join(os.tmpdir(), "bmx-n3r-"));
+    const b1 = quiet(() => new Bullet({ disableNetwork: true, storage: true, storageType: GpuStorage, storagePath: tmp, saveInterval: 0, server: false, enableIndexing: false, disableCRT: true }));
+    b1.id = "w"; b1.crt = new GpuCRT(b1);
+    assert.ok(b1.storage instanceof GpuStorage);
+    quiet(() => { b1.setData("n/a", { x: 1, y: 2, __fromNetwork: true, __vectorClock: { w: 9 } }, false); b1.setData("cfg/t", "s", false); });
+    b1.storage.save();
+    const b2 = quiet(() => new Bullet({ disableNetwork: true, storage: true, storageType: "file", storagePath: tmp, saveInterval: 0, server: false, enableIndexing: false }));
+    assert.deepStrictEqual(JSON.parse(JSON.stringify(b2.store)), JSON.parse(JSON.stringify(b1.store)));
+    assert.deepStrictEqual(b2.meta["n/a"].vectorClock, b1.meta["n/a"].vectorClock);
+    if (b2.storage.saveInterval) clearInterval(b2.storage.saveInterval);
+    checks += 3;
+  }
   console.log("reference facade present: replayed through the real Bullet with GpuCRT/GpuQuery plugged in");
 }
 

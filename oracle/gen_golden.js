@@ -399,6 +399,72 @@ function genQuerySeeded(N, seed, full) {
     gen: "for i<N: age=rng()%100; score=rng()%200001-100000 (xorshift32, interleaved per node)", queries };
 }
 
+
+/* ------------------------------------------------------------------ g8: a sync chunk through the reference's own loop (N2)
+ * BulletNetworkSync._processSyncEntries (src/bullet-network-sync.js:551-569) run on a real Bullet (network disabled: the method
+ * only needs this.bullet). The chunk mixes the two kinds of entry the loop treats differently — objects are tagged with
+ * __fromNetwork/__vectorClock and resolved against the sender's clock, primitives are passed UNTAGGED and therefore handled as
+ * local writes (clock ignored, always accepted) — plus deletions and off-contract values. Expected: store and per-path clock/source. */
+function genSyncChunk() {
+  const Sync = require(path.join(REF, "src", "bullet-network-sync.js"));
+  const b = newBullet({ enableIndexing: false });
+  const chunks = [
+    [ /* chunk 1: first sight of everything */
+      { path: "acct/a", data: { bal: 10, seq: 1 }, vectorClock: { w: 100 } },
+      { path: "acct/b", data: { bal: 20, seq: 1 }, vectorClock: { w: 100 } },
+      { path: "acct/c", data: { bal: 30, seq: 1 }, vectorClock: { w: 100 } },
+      { path: "cfg/limit", data: 5, vectorClock: { w: 100 } },                 /* primitive: untagged -> local write */
+      { path: "cfg/name", data: "alpha", vectorClock: { w: 100 } },
+      { path: "users/u1", data: { name: "Ann", age: 30 }, vectorClock: { w: 100 } },   /* string field: host path in the batch adapter */
+    ],
+    [ /* chunk 2: the first writes stored clock {w:2}; 150 dominates, 1 is historical */
+      { path: "acct/a", data: { bal: 11, seq: 2 }, vectorClock: { w: 150 } },
+      { path: "acct/b", data: { bal: 99, seq: 9 }, vectorClock: { w: 1 } },
+      { path: "cfg/limit", data: 4, vectorClock: { w: 1 } },                   /* stale clock, still applied: the clock of a primitive is ignored */
+      { path: "cfg/name", data: "beta", vectorClock: { w: 1 } },
+      { path: "users/u1", data: { name: "Bea", age: 31 }, vectorClock: { w: 150 } },
+      { path: "acct/c", deleted: true, vectorClock: { w: 150 } },              /* deletion: setData(path, null) */
+      { path: "acct/d", data: { bal: 40, seq: 1 }, vectorClock: { w: 120, q: 3 } },    /* two writers: host path */
+    ],
+    [ /* chunk 3 */
+      { path: "acct/a", data: { bal: 12, seq: 3 }, vectorClock: { w: 149 } },  /* older than 150: historical */
+      { path: "acct/b", data: { bal: 21, seq: 2 }, vectorClock: { w: 200 } },
+      { path: "acct/e", data: { bal: 50, seq: 1 }, vectorClock: { w: 7 } },
+      { path: "acct/e", data: { bal: 51, seq: 2 }, vectorClock: { w: 8 } },    /* same node twice in one chunk */
+      { path: "cfg/limit", data: 6, vectorClock: { w: 300 } },
+    ],
+  ];
+  const fake = { bullet: b };
+  quiet(() => { for (const c of chunks) Sync.prototype._processSyncEntries.call(fake, c, "peer-1"); });
+  const meta = {};
+  for (const k of Object.keys(b.meta)) meta[k] = { vectorClock: b.meta[k].vectorClock, source: b.meta[k].source };
+  return { kind: "sync_chunk", source: "reference BulletNetworkSync._processSyncEntries on a real Bullet (id 'w', network disabled)", id: "w",
+    chunks, store: JSON.parse(JSON.stringify(b.store)), meta };
+}
+
+/* ------------------------------------------------------------------ g7: a directory written by the reference's file storage (N3)
+ * src/bullet-file-storage.js:170-210 writes store.json / meta.json / log.json; the files themselves are the fixture
+ * (tests/golden/g7_storage_dir/). */
+function genStorageDir(outDir) {
+  const os = require("os");
+  const Bullet = require(path.join(REF, "src", "bullet.js"));
+  const tmp = fs.mkdtempSync(path.join(os.tmpdir(), "bmx-g7-"));
+  const b = quiet(() => new Bullet({ disableNetwork: true, storage: true, storageType: "file", storagePath: tmp, saveInterval: 0, enableIndexing: false, server: false }));
+  b.id = "w";
+  const rng = xorshift32(97);
+  quiet(() => {
+    for (let i = 0; i < 40; i++) b.setData("n/k" + i, { age: rng() % 90, score: (rng() % 2001) - 1000, __fromNetwork: true, __vectorClock: { w: 10 + (rng() % 50) } }, false);
+    for (let i = 0; i < 40; i += 3) b.setData("n/k" + i, { age: rng() % 90, score: (rng() % 2001) - 1000, __fromNetwork: true, __vectorClock: { w: 100 + i } }, false);
+    b.setData("cfg/title", "hello", false);
+    b.setData("cfg/count", 3, false);
+  });
+  b.storage._saveData();
+  fs.mkdirSync(outDir, { recursive: true });
+  for (const f of ["store.json", "meta.json"]) fs.copyFileSync(path.join(tmp, f), path.join(outDir, f));
+  if (b.storage.saveInterval) clearInterval(b.storage.saveInterval);
+  console.log("wrote", outDir, "(store.json, meta.json as written by the reference's BulletFileStorage)");
+}
+
 /* ------------------------------------------------------------------ main */
 function write(name, obj) {
   const p = path.join(OUT, name);
@@ -431,6 +497,8 @@ function main() {
   write("g5_query_example.json", genQueryExample());
   write("g5_query_seeded_2k.json", genQuerySeeded(2000, 4711, true));
   write("g5_query_seeded_100k.json", genQuerySeeded(100000, 4712, false));
+  write("g8_sync_chunk.json", genSyncChunk());
+  genStorageDir(path.join(OUT, "g7_storage_dir"));
 }
 
 module.exports = { genStream, rowId, rowField, xorshift32, splitmix64, fnv1a32, rowDigest };
