@@ -192,6 +192,15 @@ int ensure_bins(bmx_ctx* ctx, uint64_t n) {
   return BMX_OK;
 }
 
+// The copy streams exist only once a host batch is submitted: HIP maps streams onto a few hardware queues, and a device-mode caller
+// that overlaps its own streams (the sharded pipeline: exchange beside merge) must not find them sharing a queue with idle ones of ours
+// (measured: with two extra streams per context the exchange kernel serialised behind the merge kernels, 164 vs 125 us per step).
+int ensure_copy_streams(bmx_ctx* ctx) {
+  if (!ctx->copy_stream) HIPCHK(hipStreamCreateWithFlags(&ctx->copy_stream, hipStreamNonBlocking));
+  if (!ctx->down_stream) HIPCHK(hipStreamCreateWithFlags(&ctx->down_stream, hipStreamNonBlocking));
+  return BMX_OK;
+}
+
 int ensure_staging(bmx_ctx* ctx, int k, uint64_t n) {
   bmx_ctx::Staging& S = ctx->stg[k];
   if (n <= S.cap) return BMX_OK;
@@ -374,8 +383,9 @@ int submit_host(bmx_ctx* ctx, uint64_t n, const uint64_t* id, const uint32_t* fi
   for (int i = 0; i < 2; i++) if (!ctx->stg[i].busy) { k = i; break; }
   if (k < 0) return fail(ctx, BMX_ERR_INVALID, "two batches are already in flight: collect the oldest first (bmx_merge_collect)");
   bmx_ctx::Staging& S = ctx->stg[k];
-  int rc = ensure_staging(ctx, k, n);
+  int rc = ensure_copy_streams(ctx);
   if (rc) return rc;
+  if ((rc = ensure_staging(ctx, k, n))) return rc;
   if (n) {
     HIPCHK(hipMemcpyAsync(S.id, id, n * 8, hipMemcpyHostToDevice, ctx->copy_stream));
     HIPCHK(hipMemcpyAsync(S.field, field, n * 4, hipMemcpyHostToDevice, ctx->copy_stream));
@@ -612,8 +622,6 @@ int bmx_create_ex(int device, uint64_t capacity_rows, uint32_t max_load_pct, uin
   ctx->stream = ctx->own_stream;
   CR(hipEventCreate(&ctx->ev0));
   CR(hipEventCreate(&ctx->ev1));
-  CR(hipStreamCreateWithFlags(&ctx->copy_stream, hipStreamNonBlocking));
-  CR(hipStreamCreateWithFlags(&ctx->down_stream, hipStreamNonBlocking));
   for (int i = 0; i < 2; i++) { CR(hipEventCreateWithFlags(&ctx->stg[i].up, hipEventDisableTiming)); CR(hipEventCreateWithFlags(&ctx->stg[i].done, hipEventDisableTiming)); }
   const uint64_t nslots = slots_for(capacity_rows, max_load_pct);
   ctx->nslots = nslots;
