@@ -1,4 +1,4 @@
-"""Turn three rocprofv3 --pmc passes over `python3 bench.py --steps 6 --warmup 2 --no-cpu-baseline` into profiles/traffic_probe_apply.json
+"""Turn three rocprofv3 --pmc passes over `python3 bench.py --steps 6 --warmup 2 --no-cpu-baseline --no-scan --no-verify` into profiles/traffic_probe_apply.json
 (HBM bytes per k_probe_apply launch, corrected as MI355X_MICROARCH.md prescribes for gfx950).
 usage: python profiles/make_traffic.py <dir with pass_fetch/ pass_write/ pass_req/ counter_collection CSVs> <out.json>"""
 import csv, glob, json, os, sys
@@ -24,7 +24,7 @@ rd, _ = m["TCC_EA0_RDREQ_sum"]; rd128, _ = m["TCC_EA0_RDREQ_128B_sum"]; wr, _ = 
 read_bytes = fetch_kb * 1024 * 2          # gfx950: FETCH_SIZE tallies 128-B read requests at 64 B
 write_bytes = write_kb * 1024
 json.dump({"kernel": "k_probe_apply<false,0,false>",
-           "source": "rocprofv3 --kernel-trace --pmc FETCH_SIZE / --pmc WRITE_SIZE / --pmc TCC_EA0_* (three separate passes) on `python3 bench.py --steps 6 --warmup 2 --no-cpu-baseline`; profiles/make_traffic.py",
+           "source": "rocprofv3 --kernel-trace --pmc FETCH_SIZE / --pmc WRITE_SIZE / --pmc TCC_EA0_* (three separate passes) on `python3 bench.py --steps 6 --warmup 2 --no-cpu-baseline --no-scan --no-verify`; profiles/make_traffic.py",
            "launches_averaged": n, "FETCH_SIZE_KB_raw": round(fetch_kb, 1), "WRITE_SIZE_KB": round(write_kb, 1),
            "read_requests": round(rd), "read_requests_128B": round(rd128), "write_requests": round(wr), "atomic_requests": round(at),
            "correction": "gfx950 FETCH_SIZE tallies 128-B read requests at 64 B (MI355X_MICROARCH.md, HBM): x2; checked in round 1 on a 1 GiB copy (reports 524293 KB). WRITE_SIZE is exact (32-B partial write-backs + atomics counted as 32-B writes).",

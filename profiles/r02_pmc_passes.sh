@@ -9,7 +9,7 @@ i=0
 while read -r line; do
   [ -z "$line" ] && continue
   i=$((i+1))
-  rocprofv3 --kernel-trace --pmc $line --output-format csv -d $OUT/pass$i -- python3 $GRAFT_REPO_ROOT/bench.py --steps 6 --warmup 2 --no-cpu-baseline > $OUT/pass$i.json 2> $OUT/pass$i.err || echo "pass $i failed: $line"
+  rocprofv3 --kernel-trace --pmc $line --output-format csv -d $OUT/pass$i -- python3 $GRAFT_REPO_ROOT/bench.py --steps 6 --warmup 2 --no-cpu-baseline --no-scan --no-verify > $OUT/pass$i.json 2> $OUT/pass$i.err || echo "pass $i failed: $line"
   echo "pass $i done: $line"
 done <<'PASSES'
 TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_LEVEL_sum TCC_EA0_RDREQ_DRAM_CREDIT_STALL_sum TCC_EA0_RDREQ_GMI_CREDIT_STALL_sum
