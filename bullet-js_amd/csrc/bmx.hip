@@ -2,6 +2,7 @@
 // No CPU fallback exists: every entry point fails with BMX_ERR_NO_DEVICE / BMX_ERR_HIP when there is no GPU.
 #include <hip/hip_runtime.h>
 #include <algorithm>
+#include <chrono>
 #include <climits>
 #include <cstdio>
 #include <cstdlib>
