@@ -46,8 +46,11 @@ function applyBatch(bullet, updates, fromNetwork) {
     if (!key) continue;
     node[key] = u.value;
     const old = bullet.meta[path];
-    const m = old ? Object.assign({}, old) : {};
-    m.source = source; m.vectorClock = u.vectorClock; m.lastModified = now;
+    // {...old, source, vectorClock, lastModified}: the reference's entries carry exactly these three keys, so a fresh literal is the
+    // spread's result unless somebody hung more on the entry
+    let m;
+    if (old === undefined || (old.source !== undefined && old.vectorClock !== undefined && old.lastModified !== undefined && Object.keys(old).length === 3)) m = { source, vectorClock: u.vectorClock, lastModified: now };
+    else { m = Object.assign({}, old); m.source = source; m.vectorClock = u.vectorClock; m.lastModified = now; }
     bullet.meta[path] = m;
     const rec = { op: "set", path, data: u.value, vectorClock: u.vectorClock, timestamp: now };
     if (bullet.log) {

@@ -32,6 +32,15 @@ function threeWay(a, b) {
 
 function isMergeable(v) { return typeof v === "object" && v !== null && !Array.isArray(v); }
 
+function growColumns(cols, rowEntry, rowField, used, cap) {
+  const bigger = new Columns(cap);
+  bigger.id.set(cols.id.subarray(0, used)); bigger.field.set(cols.field.subarray(0, used));
+  bigger.ts.set(cols.ts.subarray(0, used)); bigger.val.set(cols.val.subarray(0, used));
+  const re = new Int32Array(cap), rf = new Int32Array(cap);
+  re.set(rowEntry.subarray(0, used)); rf.set(rowField.subarray(0, used));
+  return { cols: bigger, rowEntry: re, rowField: rf, cap };
+}
+
 function verdict(winner, clock, value, reason, extra) {
   /* decision record; field set of the reference's resolve() results */
   return Object.assign({
@@ -230,44 +239,56 @@ class GpuCRT {
     if (this._opts.writers) return this._mergeEntriesVector(entries, opts);
     const writer = opts.writer || this.bullet.id;
     const g = this.graph;
-    let rows = 0;
-    const plan = [];                      // per entry: list of [fieldName|null, value] or null (host)
-    for (const e of entries) {
-      const ts = scalarClock(e.vectorClock, writer);
-      let fields = null;
-      if (ts >= 0) {
-        if (isDeviceInt(e.data)) fields = [[null, e.data]];
-        else if (e.data && typeof e.data === "object" && !Array.isArray(e.data)) {
-          fields = [];
-          for (const k of Object.keys(e.data)) {
-            if (k === "__vectorClock" || k === "__fromNetwork") continue;
-            if (!isDeviceInt(e.data[k])) { fields = null; break; }
-            fields.push([k, e.data[k]]);
-          }
-        }
-      }
-      plan.push(fields && fields.length ? { ts, fields } : null);
-      if (fields) rows += fields.length;
-    }
-    const cols = new Columns(rows);
-    const back = new Array(rows);
-    let i = 0;
+    const keys = g.keys;
+    // one pass: eligible entries are written straight into growable typed columns (a second pass over a million JS objects costs
+    // more than the GPU merge); rowEntry / rowField map device rows back to (entry, field name)
+    let cap = Math.max(16, entries.length * 2);
+    let cols = new Columns(cap);
+    let rowEntry = new Int32Array(cap), rowField = new Int32Array(cap);
+    const fieldNames = [], fieldIndex = new Map();          // names seen in this call, -1 = the node's own value
     const host = [];
-    entries.forEach((e, ei) => {
-      const p = plan[ei];
-      if (!p) { host.push(ei); return; }
-      const cut = e.path.lastIndexOf("/");
-      const parent = cut < 0 ? "" : e.path.slice(0, cut);
-      const id = g.keys.idOf(e.path);
-      for (const [fname, v] of p.fields) {
-        cols.set(i, id, g.keys.fieldOf(parent, fname), p.ts, v);
-        back[i] = { entry: ei, field: fname };
-        i++;
-      }
-    });
-    const r = this.mergeBatch(cols, opts);
-    const applied = Array.from(r.applied, (j) => back[j]);
-    const broadcast = opts.apply ? this._applyWinners(entries, cols, r.applied, applied, opts.apply) : undefined;
+    let i = 0;
+    let lastParent = "";                                    // consecutive entries usually share their collection: reuse the sliced string
+    const parentOf = (path, cut) => {
+      if (cut < 0) return "";
+      if (cut === lastParent.length && path.startsWith(lastParent)) return lastParent;
+      lastParent = path.slice(0, cut);
+      return lastParent;
+    };
+    for (let ei = 0; ei < entries.length; ei++) {
+      const e = entries[ei];
+      const ts = scalarClock(e.vectorClock, writer);
+      const d = e.data;
+      if (ts < 0) { host.push(ei); continue; }
+      const first = i;
+      let ok = true;
+      if (isDeviceInt(d)) {
+        if (i + 1 > cap) ({ cols, rowEntry, rowField, cap } = growColumns(cols, rowEntry, rowField, i, cap * 2));
+        cols.set(i, keys.idOf(e.path), keys.fieldOf(parentOf(e.path, e.path.lastIndexOf("/")), null), ts, d);
+        rowEntry[i] = ei; rowField[i] = -1; i++;
+      } else if (d && typeof d === "object" && !Array.isArray(d)) {
+        const parent = parentOf(e.path, e.path.lastIndexOf("/"));
+        let id = null;
+        for (const k in d) {
+          if (k === "__vectorClock" || k === "__fromNetwork" || !Object.prototype.hasOwnProperty.call(d, k)) continue;
+          const v = d[k];
+          if (!isDeviceInt(v)) { ok = false; break; }
+          if (id === null) id = keys.idOf(e.path);
+          if (i + 1 > cap) ({ cols, rowEntry, rowField, cap } = growColumns(cols, rowEntry, rowField, i, cap * 2));
+          let fi = fieldIndex.get(k);
+          if (fi === undefined) { fi = fieldNames.length; fieldNames.push(k); fieldIndex.set(k, fi); }
+          cols.set(i, id, keys.fieldOf(parent, k), ts, v);
+          rowEntry[i] = ei; rowField[i] = fi; i++;
+        }
+        if (ok && i === first) ok = false;                   // an object without fields: nothing for the device
+      } else ok = false;
+      if (!ok) { i = first; host.push(ei); }                 // roll back the rows of an entry that turned out to be off-contract
+    }
+    const used = cols.slice(i);
+    const r = this.mergeBatch(used, opts);
+    const applied = new Array(r.applied.length);
+    for (let k = 0; k < applied.length; k++) { const j = r.applied[k]; applied[k] = { entry: rowEntry[j], field: rowField[j] < 0 ? null : fieldNames[rowField[j]] }; }
+    const broadcast = opts.apply ? this._applyWinners(entries, used, r.applied, applied, opts.apply) : undefined;
     return { applied, nApplied: r.nApplied, nConflicts: r.nConflicts, nRows: r.nRows, host, broadcast };
   }
 
@@ -282,9 +303,12 @@ class GpuCRT {
   _applyWinners(entries, cols, appliedIdx, applied, mode) {
     const n = appliedIdx.length;
     if (n === 0) return [];
-    const ids = new BigUint64Array(n), fields = new Uint32Array(n);
-    for (let k = 0; k < n; k++) { ids[k] = cols.id[appliedIdx[k]]; fields[k] = cols.field[appliedIdx[k]]; }
+    const ids = new BigUint64Array(n), id32 = new Uint32Array(ids.buffer), fields = new Uint32Array(n);
+    const src32 = cols._id32 || new Uint32Array(cols.id.buffer, cols.id.byteOffset, cols.id.length * 2);
+    for (let k = 0; k < n; k++) { const j = appliedIdx[k]; id32[2 * k] = src32[2 * j]; id32[2 * k + 1] = src32[2 * j + 1]; fields[k] = cols.field[j]; }
     const rows = this.graph.getRows(ids, fields);
+    const ts32 = new Uint32Array(rows.ts.buffer, rows.ts.byteOffset, n * 2), val32 = new Int32Array(rows.val.buffer, rows.val.byteOffset, n * 2);
+    const valLo = new Uint32Array(rows.val.buffer, rows.val.byteOffset, n * 2);
     const writer = this._opts.writer || this.bullet.id;
     const updates = new Array(n);
     for (let k = 0; k < n; k++) {
@@ -292,8 +316,8 @@ class GpuCRT {
       const e = entries[a.entry];
       const leaf = a.field === null ? e.path : e.path + "/" + a.field;
       const clock = {};
-      clock[writer] = Number(rows.ts[k]);
-      updates[k] = { path: leaf, value: Number(rows.val[k]), vectorClock: clock };
+      clock[writer] = ts32[2 * k + 1] * 4294967296 + ts32[2 * k];                        // 0 <= ts <= 2^53-1
+      updates[k] = { path: leaf, value: val32[2 * k + 1] * 4294967296 + valLo[2 * k], vectorClock: clock };   // signed high half, unsigned low half
       this.vectorClocks.set(leaf, clock);
     }
     const b = this.bullet;

@@ -48,8 +48,20 @@ class KeyDictionary {
     this.byPath = new Map();   // path -> [lo, hi]
     this.byId = new Map();     // idKey -> path
     this.fields = new Map();   // field hash -> [collection, field name]
+    this._fieldCache = new Map();   // collection -> Map(field name -> hash)
   }
   fieldOf(collection, field) {
+    // (collection, field) -> hash, cached: a sync chunk names the same few fields of the same few collections over and over
+    const fkey = field === null || field === undefined ? "" : field;
+    let per = this._fieldCache.get(collection);
+    if (per === undefined) { per = new Map(); this._fieldCache.set(collection, per); }
+    const cached = per.get(fkey);
+    if (cached !== undefined) return cached;
+    const h = this._fieldOfSlow(collection, field);
+    per.set(fkey, h);
+    return h;
+  }
+  _fieldOfSlow(collection, field) {
     const h = fieldId(collection, field);
     const known = this.fields.get(h);
     if (known === undefined) this.fields.set(h, [collection, field === undefined ? null : field]);
@@ -87,17 +99,24 @@ class Columns {
     this.field = new Uint32Array(n);
     this.ts = new BigInt64Array(n);
     this.val = new BigInt64Array(n);
+    this._ts32 = new Uint32Array(this.ts.buffer);
+    this._val32 = new Uint32Array(this.val.buffer);
   }
+  /* ts and val are safe integers (|x| <= 2^53-1): written as two 32-bit halves, no BigInt allocated per element */
   set(i, idPair, field, ts, val) {
     this._id32[2 * i] = idPair[0]; this._id32[2 * i + 1] = idPair[1];
     this.field[i] = field;
-    this.ts[i] = BigInt(ts); this.val[i] = BigInt(val);
+    let hi = Math.floor(ts / 4294967296);
+    this._ts32[2 * i] = ts - hi * 4294967296; this._ts32[2 * i + 1] = hi;
+    hi = Math.floor(val / 4294967296);
+    this._val32[2 * i] = val - hi * 4294967296; this._val32[2 * i + 1] = hi;      // a negative hi wraps to its two's complement in the Uint32Array
   }
   slice(n) {
     if (n === this.n) return this;
     const c = Object.create(Columns.prototype);
     c.n = n; c.id = this.id.subarray(0, n); c._id32 = this._id32.subarray(0, 2 * n);
     c.field = this.field.subarray(0, n); c.ts = this.ts.subarray(0, n); c.val = this.val.subarray(0, n);
+    c._ts32 = this._ts32.subarray(0, 2 * n); c._val32 = this._val32.subarray(0, 2 * n);
     return c;
   }
 }
@@ -107,8 +126,9 @@ function isDeviceInt(v) { return typeof v === "number" && Number.isInteger(v) &&
 /* a clock the device understands: exactly one component, owned by `writer`, a non-negative safe integer */
 function scalarClock(clock, writer) {
   if (!clock || typeof clock !== "object") return -1;
-  const ks = Object.keys(clock);
-  if (ks.length !== 1 || ks[0] !== writer) return -1;
+  let seen = 0;
+  for (const k in clock) { if (k !== writer || ++seen > 1) return -1; }     // no key array allocated per entry
+  if (seen !== 1) return -1;
   const t = clock[writer];
   return isDeviceInt(t) && t >= 0 ? t : -1;
 }
