@@ -540,14 +540,12 @@ int run_scan(bmx_ctx* ctx, const Pred& P, const Index* ix, uint64_t* out_ids, ui
     hipLaunchKernelGGL((k_scan_mask<Pred, true>), dim3(nb), dim3(SEL_THREADS), 0, ctx->stream, P, ix->n, ctx->scan_mask, ctx->scan_counts);
     LAUNCHCHK("k_scan_mask");
     if (se) HIPCHK(hipEventRecord(se[1], ctx->stream));
-    const bool scanned = nb > 2048;   // many blocks: one small launch turns the counts into offsets
-    if (scanned) {
-      hipLaunchKernelGGL(k_scan_offsets, dim3(1), dim3(OFFS_THREADS), 0, ctx->stream, ctx->scan_counts, nb);
-      LAUNCHCHK("k_scan_offsets");
-    }
     EmitIds Em{ix->ids, d_out, d_cap};
     FinishCount Fin{d_n};
-    hipLaunchKernelGGL((k_scan_emit<EmitIds, FinishCount>), dim3(nb), dim3(SEL_THREADS), 0, ctx->stream, ctx->scan_mask, ctx->scan_counts, scanned, ix->n, Em, Fin);
+    if (nb > 2048)   // large column: an eighth of the workgroups, each sums the counts in front of it once (no offsets launch)
+      hipLaunchKernelGGL((k_scan_emit<EmitIds, FinishCount, 8>), dim3((nb + 7) / 8), dim3(SEL_THREADS), 0, ctx->stream, ctx->scan_mask, ctx->scan_counts, ix->n, nb, Em, Fin);
+    else
+      hipLaunchKernelGGL((k_scan_emit<EmitIds, FinishCount, 1>), dim3(nb), dim3(SEL_THREADS), 0, ctx->stream, ctx->scan_mask, ctx->scan_counts, ix->n, nb, Em, Fin);
     LAUNCHCHK("k_scan_emit");
   } else if (d_n) {
     hipLaunchKernelGGL((k_scan_mask<Pred, false>), dim3(nb), dim3(SEL_THREADS), 0, ctx->stream, P, ix->n, ctx->scan_mask, ctx->scan_counts);

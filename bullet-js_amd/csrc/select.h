@@ -151,57 +151,69 @@ __global__ __launch_bounds__(SEL_THREADS) void k_scan_mask(Pred P, uint64_t n, u
   if (threadIdx.x == 0) block_counts[blockIdx.x] = total;
 }
 
-// exclusive scan of the block counts in place (one workgroup of 1024 threads; used when there are too many blocks for each
-// emitting block to sum its predecessors itself); total -> counts[nb]. Every thread owns a contiguous run of counts: two passes over
-// it with the loads of a pass in flight together and ONE block scan in between (the first version looped over 256-count slices
-// with a block scan each: 22 us for the 12k blocks of a 100M-row column).
-constexpr int OFFS_THREADS = 1024;
-__global__ __launch_bounds__(OFFS_THREADS) void k_scan_offsets(uint32_t* counts, uint32_t nb) {
-  __shared__ uint32_t wsum[OFFS_THREADS / 64];
-  const uint32_t lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-  const uint32_t per = (nb + OFFS_THREADS - 1) / OFFS_THREADS;
-  const uint32_t lo = min(nb, threadIdx.x * per), hi = min(nb, lo + per);
-  uint32_t sum = 0;
-#pragma unroll 8
-  for (uint32_t i = lo; i < hi; i++) sum += counts[i];
-  const uint32_t incl = wave_incl_scan_u32(sum);
-  if (lane == 63) wsum[w] = incl;
-  __syncthreads();
-  uint32_t woff = 0, tot = 0;
-#pragma unroll
-  for (int i = 0; i < OFFS_THREADS / 64; i++) { const uint32_t x = wsum[i]; if (i < (int)w) woff += x; tot += x; }
-  uint32_t run = woff + incl - sum;
-#pragma unroll 8
-  for (uint32_t i = lo; i < hi; i++) { const uint32_t c = counts[i]; counts[i] = run; run += c; }
-  if (threadIdx.x == 0) counts[nb] = tot;
-}
-
-template <class Emit, class Finish>
-__global__ __launch_bounds__(SEL_THREADS) void k_scan_emit(const uint32_t* __restrict__ mask_words, const uint32_t* __restrict__ counts, bool scanned,
-                                                            uint64_t n, Emit Em, Finish Fin) {
+// SUB consecutive 8192-row blocks per workgroup; the rank of its first match = the counts of all blocks before its first block, summed by the
+// workgroup itself (counts written by the PREVIOUS launch). SUB = 1 for columns up to 2048 blocks; SUB = 8 for large ones: an eighth of the
+// workgroups, each sums <= 48 KB of counts from L2 once (100M-row column) and carries the rank through its blocks. (Round 1 ran a one-block
+// prefix kernel between the two passes for large columns: 7 us of launch + boundary for a 100M-row column; dropped.)
+template <class Emit, class Finish, int SUB>
+__global__ __launch_bounds__(SEL_THREADS) void k_scan_emit(const uint32_t* __restrict__ mask_words, const uint32_t* __restrict__ counts,
+                                                            uint64_t n, uint32_t nblocks, Emit Em, Finish Fin) {
   __shared__ uint32_t wsum[4];
   __shared__ uint16_t loc[SCAN_BLOCK_ELEMS];   // block-local row offsets of the matches, in rank order (16 KB)
-  const uint64_t w = (uint64_t)blockIdx.x * SEL_THREADS + threadIdx.x;
-  uint32_t mk = (w << 5) < n ? mask_words[w] : 0u;
+  const uint32_t b0 = blockIdx.x * (uint32_t)SUB;
   uint32_t offset;
-  if (scanned) {
-    offset = counts[blockIdx.x];
-  } else {
-    uint32_t part = strided_partial_sum(counts, blockIdx.x);
+  {
+    uint32_t part = strided_partial_sum(counts, b0);
     block_excl_scan(part, offset, wsum);
   }
-  uint32_t tot;
-  uint32_t r = block_excl_scan((uint32_t)__popc(mk), tot, wsum);
-  // transpose through LDS: a lane owns 32 consecutive rows, but the output wants consecutive lanes on consecutive ranks
-  while (mk) {
-    int e = __ffs((int)mk) - 1;
-    mk &= mk - 1;
-    loc[r++] = (uint16_t)(threadIdx.x * 32u + (uint32_t)e);
+  uint64_t running = offset;
+  if (SUB > 1) {
+    // fast path (<= 8192 matches in the workgroup's SUB blocks, i.e. selectivity up to 1/SUB): a thread owns SUB consecutive mask words
+    // (SUB*32 consecutive rows), so ONE block scan ranks every match of the SUB blocks; otherwise block by block below
+    uint32_t mk[SUB];
+    uint32_t cnt = 0;
+#pragma unroll
+    for (int q = 0; q < SUB; q++) {
+      const uint64_t w = (uint64_t)b0 * SEL_THREADS + (uint64_t)threadIdx.x * SUB + q;
+      mk[q] = (w << 5) < n ? mask_words[w] : 0u;
+      cnt += __popc(mk[q]);
+    }
+    uint32_t tot;
+    uint32_t r = block_excl_scan(cnt, tot, wsum);
+    if (tot <= SCAN_BLOCK_ELEMS) {
+#pragma unroll
+      for (int q = 0; q < SUB; q++) {
+        uint32_t m = mk[q];
+        while (m) { const int e = __ffs((int)m) - 1; m &= m - 1; loc[r++] = (uint16_t)((threadIdx.x * SUB + q) * 32u + (uint32_t)e); }
+      }
+      __syncthreads();
+      const uint64_t base = (uint64_t)b0 * SCAN_BLOCK_ELEMS;
+      for (uint32_t q = threadIdx.x; q < tot; q += SEL_THREADS) Em(running + q, base + loc[q]);
+      if (blockIdx.x == gridDim.x - 1) Fin(running + tot, wsum);
+      return;
+    }
   }
-  __syncthreads();
-  const uint64_t base = (uint64_t)blockIdx.x * SCAN_BLOCK_ELEMS;
-  for (uint32_t k = threadIdx.x; k < tot; k += SEL_THREADS) Em((uint64_t)offset + k, base + loc[k]);   // coalesced stores, near-sequential gathers
-  if (blockIdx.x == gridDim.x - 1) Fin((uint64_t)offset + tot, wsum);
+#pragma unroll 1
+  for (uint32_t k = 0; k < (uint32_t)SUB; k++) {
+    const uint32_t blk = b0 + k;
+    if (blk >= nblocks) break;
+    const uint64_t w = (uint64_t)blk * SEL_THREADS + threadIdx.x;
+    uint32_t mk = (w << 5) < n ? mask_words[w] : 0u;
+    uint32_t tot;
+    uint32_t r = block_excl_scan((uint32_t)__popc(mk), tot, wsum);
+    // transpose through LDS: a lane owns 32 consecutive rows, but the output wants consecutive lanes on consecutive ranks
+    while (mk) {
+      int e = __ffs((int)mk) - 1;
+      mk &= mk - 1;
+      loc[r++] = (uint16_t)(threadIdx.x * 32u + (uint32_t)e);
+    }
+    __syncthreads();
+    const uint64_t base = (uint64_t)blk * SCAN_BLOCK_ELEMS;
+    for (uint32_t q = threadIdx.x; q < tot; q += SEL_THREADS) Em(running + q, base + loc[q]);   // coalesced stores, near-sequential gathers
+    running += tot;
+    __syncthreads();
+  }
+  if (blockIdx.x == gridDim.x - 1) Fin(running, wsum);
 }
 
 }  // namespace bmx
