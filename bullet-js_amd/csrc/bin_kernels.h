@@ -53,7 +53,6 @@ struct BinArgs {
   uint8_t* wflag;      // per delta: 1 = this delta's value is the row's final value
   uint8_t* flags;      // optional decision flags
   unsigned long long* shard_ctr; uint32_t* status;
-  uint32_t dbg;        // measurement only (BMX_DEBUG_PHASE): 1 = stop after the gather, 2 = after the LDS dedupe, 3 = probe but store nothing
 };
 
 __device__ __forceinline__ uint32_t bin_of(uint64_t id) { return (uint32_t)__umul64hi(node_hash(id), (uint64_t)NB); }
@@ -197,7 +196,6 @@ __global__ __launch_bounds__(MB_THREADS) void k_merge_bins(BinArgs A) {
       }
       m = filled;
     }
-    if (A.dbg == 1) { __syncthreads(); if (cut > 0) t0 += cut; else if (++sub == MB_SUB) { sub = 0; t0 += 1; } if (tid == 0 && m == 0x7FFFFFFF) A.status[1] = r_lo[0].x; continue; }
     // ---- 2. duplicate keys meet in LDS ----
     for (uint32_t i = tid; i < MB_HS; i += MB_THREADS) H[i] = L_EMPTY;
     for (uint32_t i = tid; i < m; i += MB_THREADS) lhead[i] = L_EMPTY;
@@ -221,7 +219,6 @@ __global__ __launch_bounds__(MB_THREADS) void k_merge_bins(BinArgs A) {
     // Creating rows may need a second look at a slot whose field another thread of THIS workgroup is about to publish (same node id
     // means same bin, so it is never another workgroup's): such keys are retried after a barrier instead of spinning.
     uint32_t pending_mask = 0;   // bit k: my k-th record still has to be processed
-    if (A.dbg == 2) { if (cut > 0) t0 += cut; else if (++sub == MB_SUB) { sub = 0; t0 += 1; } if (tid == 0 && m == 0x7FFFFFFF) A.status[1] = nxt[0]; __syncthreads(); continue; }
     for (uint32_t k = 0; k * MB_THREADS + tid < m; k++) if (nxt[k * MB_THREADS + tid] == NXT_REP) pending_mask |= 1u << k;
     for (uint32_t round = 0;; round++) {
       for (uint32_t k = 0; k * MB_THREADS + tid < m; k++) {
@@ -269,7 +266,6 @@ __global__ __launch_bounds__(MB_THREADS) void k_merge_bins(BinArgs A) {
         }
         if (blocked) continue;                 // stays pending: retried after the barrier
         pending_mask &= ~(1u << k);
-        if (A.dbg == 3) { if (found && cts == 0x7FFFFFFF12345678ll) A.status[1] = 1; continue; }
         if (full || !found) { atomicOr(A.status, ST_FULL); continue; }
         conflicts += cnt - 1 + ((!is_new && (head >> IDX_BITS) == A.epoch) ? 1u : 0u);   // the row was already written by an earlier chunk of this batch
         // the reference's sequential outcome for this key (src/bullet-crt.js:164-279, scalar clocks)

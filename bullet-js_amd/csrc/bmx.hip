@@ -323,7 +323,6 @@ int merge_core(bmx_ctx* ctx, uint64_t n, const uint64_t* id, const uint32_t* fie
     B.n = (uint32_t)n; B.epoch = ctx->epoch; B.ntiles = (uint32_t)((n + BK_TILE - 1) / BK_TILE);
     B.stage = ctx->bin_stage; B.toff = ctx->bin_toff; B.wflag = wflag; B.flags = flags;
     B.shard_ctr = ctr; B.status = &ctx->ds->status;
-    { static const char* dbg_env = getenv("BMX_DEBUG_PHASE"); B.dbg = dbg_env ? (uint32_t)atoi(dbg_env) : 0u; }
     hipLaunchKernelGGL((k_bucket<AOS>), dim3(B.ntiles), dim3(BK_THREADS), 0, ctx->stream, B);
     LAUNCHCHK("k_bucket");
     if (pe) HIPCHK(hipEventRecord(pe[1], ctx->stream));
