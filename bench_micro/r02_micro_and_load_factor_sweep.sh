@@ -2,7 +2,7 @@
 # round 2, GPU call 1: no-atomic two-pass microbenchmark + load-factor sweep of the round-1 merge kernel with line buckets
 set -e
 mkdir -p gpurun_out/r02
-./bench_micro/twopass_micro > gpurun_out/r02/twopass_micro.log 2>&1
+hipcc -O3 --offload-arch=gfx950 -o bench_micro/twopass_micro bench_micro/twopass_micro.hip && ./bench_micro/twopass_micro > gpurun_out/r02/twopass_micro.log 2>&1
 cat gpurun_out/r02/twopass_micro.log
 for lp in 35 50 60 70 80 90; do
   BMX_BENCH_CAP=15000000 BMX_BENCH_LOAD_PCT=$lp timeout -k 10 300 python bench.py --steps 20 --warmup 3 --no-cpu-baseline > gpurun_out/r02/lf_$lp.json 2> gpurun_out/r02/lf_$lp.err
