@@ -29,6 +29,7 @@ struct DevScalars {  // one small device allocation; zeroed at create
   bmx_merge_stats stats;           // scratch stats for host-mode calls
   uint32_t status;
   uint32_t wide;
+  unsigned long long seq_diag[3];  // k_seq_wait expiry: {sequence word address, value waited for, value last seen}
 };
 
 struct Index {
@@ -149,7 +150,18 @@ int check_status(bmx_ctx* ctx) {
   HIPCHK(hipStreamSynchronize(ctx->stream));
   if (!st) return BMX_OK;
   HIPCHK(hipMemsetAsync(&ctx->ds->status, 0, sizeof(uint32_t), ctx->stream));
-  if (st & ST_SPIN) return fail(ctx, BMX_ERR_INTERNAL, "device protocol fault: bounded spin expired");
+  if (st & ST_SPIN) {
+    unsigned long long d[3] = {0, 0, 0};
+    (void)hipMemcpy(d, ctx->ds->seq_diag, sizeof(d), hipMemcpyDeviceToHost);
+    (void)hipMemset(ctx->ds->seq_diag, 0, sizeof(d));
+    if (d[0]) {
+      char buf[200];
+      snprintf(buf, sizeof(buf), "device protocol fault: bmx_seq_wait on word %p expired after ~60 s waiting for %llu (last seen %llu): the signalling stream or peer never got there",
+               (void*)(uintptr_t)d[0], d[1], d[2]);
+      return fail(ctx, BMX_ERR_INTERNAL, buf);
+    }
+    return fail(ctx, BMX_ERR_INTERNAL, "device protocol fault: bounded spin expired");
+  }
   if (st & ST_FULL) return fail(ctx, BMX_ERR_FULL, "resident table is full");
   if (st & ST_SLAB) return fail(ctx, BMX_ERR_OVERFLOW, "an exchange slab was too small for the records routed to one shard: records were dropped, re-route the batch with bmx_partition_by_owner");
   return fail(ctx, BMX_ERR_RANGE, "delta out of domain: reserved key, ts outside [0, 2^53-1] or |val| > 2^53-1");
@@ -700,7 +712,7 @@ int bmx_seq_wait(bmx_ctx* ctx, void* hip_stream, const uint64_t* seq_dev, uint64
   HIPCHK(hipSetDevice(ctx->device));
   hipStream_t st = hip_stream ? reinterpret_cast<hipStream_t>(hip_stream) : ctx->stream;
   hipLaunchKernelGGL(k_seq_wait, dim3(1), dim3(64), 0, st, reinterpret_cast<const unsigned long long*>(seq_dev), (unsigned long long)at_least,
-                     &ctx->ds->status);
+                     &ctx->ds->status, ctx->ds->seq_diag);
   LAUNCHCHK("k_seq_wait");
   return BMX_OK;
 }

@@ -509,12 +509,19 @@ __global__ __launch_bounds__(256) void k_get_rows(const Slot* slots, uint64_t ns
 __global__ void k_seq_signal(unsigned long long* seq, unsigned long long value) {
   if (threadIdx.x == 0) __hip_atomic_store(seq, value, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
 }
-__global__ void k_seq_wait(const unsigned long long* seq, unsigned long long at_least, uint32_t* status) {
+// `diag` (3 words, optional): on expiry {address of the word, value waited for, value last seen} so that the host can say WHICH
+// hand-off never came (a peer that died or fell behind shows up as "waited for 17, saw 16", not as an anonymous timeout)
+__global__ void k_seq_wait(const unsigned long long* seq, unsigned long long at_least, uint32_t* status, unsigned long long* diag) {
   if (threadIdx.x != 0) return;
   const unsigned long long t0 = wall_clock64();            // 100 MHz
-  while (__hip_atomic_load(seq, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) < at_least) {
+  unsigned long long seen;
+  while ((seen = __hip_atomic_load(seq, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT)) < at_least) {
     __builtin_amdgcn_s_sleep(8);
-    if (wall_clock64() - t0 > 6000000000ull) { atomicOr(status, ST_SPIN); return; }   // ~60 s: report instead of hanging
+    if (wall_clock64() - t0 > 6000000000ull) {             // ~60 s: report instead of hanging
+      if (diag) { diag[0] = (unsigned long long)(uintptr_t)seq; diag[1] = at_least; diag[2] = seen; }
+      atomicOr(status, ST_SPIN);
+      return;
+    }
   }
 }
 
