@@ -93,3 +93,29 @@ def test_device_resident_batches_scatter_into_peer_slabs(N):
         for h in host:
             c.merge(*h); o.merge_batch(*h)
         assert rows_digest(*c.dump_rows()) == o.digest()
+
+
+def test_shards_grow_and_keep_indexes_fresh():
+    """Tiny initial shards: every shard rehashes into larger tables as batches arrive (host and device path), indexes built before the
+    growth are rebuilt on the next scan, and the union still equals the oracle."""
+    N = 4
+    o = Oracle()
+    with bmx.Comm([0] * N, capacity_rows_per_shard=2048) as c:
+        f0 = int(synth.field_hash(0))
+        c.index_build(f0)                                   # on empty shards
+        for b in range(5):
+            d = synth.big_deltas(40_000, 30_000, seed=77, insert_pct=50, hot_pct=10, hot_keys=50, unique=False, batch=b)
+            if b % 2 == 0:
+                applied, st = c.merge(*d)
+                _, ow = o.merge_batch(*d)
+                assert np.array_equal(applied, ow), b
+            else:
+                parts = [tuple(x[i::N] for x in d) for i in range(N)]          # every shard originates a quarter
+                c.merge_dev([(len(p[0]),) + _dev(tuple(np.ascontiguousarray(x) for x in p)) for p in parts], slab_records=20_000)
+                c.sync()
+                for p in parts:
+                    o.merge_batch(*p)
+            assert c.row_count() == len(o), b
+            got = np.sort(c.scan_range(f0, -(1 << 40), 1 << 40)); want = np.sort(o.scan_range(f0, -(1 << 40), 1 << 40))
+            assert np.array_equal(got, want), b
+        assert rows_digest(*c.dump_rows()) == o.digest()
