@@ -282,34 +282,47 @@ __device__ __forceinline__ void resolve_one(const MergeArgs& A, const uint32_t j
   const int64_t tsw = (int64_t)((uint64_t)hi.x | ((uint64_t)hi.y << 32));
   const int64_t cval = (int64_t)((uint64_t)hi.z | ((uint64_t)hi.w << 32));
   const bool is_new = tsw == TS_NEW || ts_mark(tsw) == A.epoch;  // row created in this batch: no pre-batch state
-  uint32_t j0 = j;
-  int64_t v_j0 = v, t_j0 = t;
-  Top2 top;
-  {
+  const uint32_t base_owner = (wf & W_WINNER) ? j : ~0u;   // the first claimer stored iff it beat the pre-batch row
+  int64_t bt, bv;
+  uint32_t owner;
+  if (!is_new) {
+    // Resident row (every hot key of a streaming replay): lexmax over the list with ties to the smaller index, starting from what the row
+    // holds now — the pre-batch value, or the first claimer's if it won. A dozen instructions per hop: with one active lane per wave the walk
+    // is paced by instruction issue as much as by the dependent load, so the general tracker below (second-best, smallest index) is kept
+    // for rows created in this batch only.
+    bt = ts_value(tsw); bv = cval; owner = base_owner;
     uint32_t idx = j, steps = 0;
     for (;;) {
-      if (idx <= j0) { j0 = idx; t_j0 = t; v_j0 = v; }
-      top.add(idx, t, v);
+      if (idx != j) {       // the first claimer's own value is what the row already holds (or it lost against the pre-batch row)
+        const bool gt = t > bt || (t == bt && v > bv);
+        const bool eq = t == bt && v == bv;
+        if (gt) { bt = t; bv = v; owner = idx; }
+        else if (eq && owner != ~0u && idx < owner) owner = idx;
+      }
       if ((nx >> IDX_BITS) != A.epoch) break;
       idx = nx & IDX_MASK;
       nx = A.next[idx]; load_delta_tv<AOS>(A, idx, t, v);   // the next node's link and value: independent loads, one round trip
       if (++steps > A.n) { atomicOr(A.status, ST_SPIN); return; }
     }
-  }
-  const uint32_t base_owner = (wf & W_WINNER) ? j : ~0u;   // the first claimer stored iff it beat the pre-batch row
-  int64_t bt, bv;
-  uint32_t owner;
-  if (is_new) {
+  } else {
+    uint32_t j0 = j;
+    int64_t v_j0 = v, t_j0 = t;
+    Top2 top;
+    {
+      uint32_t idx = j, steps = 0;
+      for (;;) {
+        if (idx <= j0) { j0 = idx; t_j0 = t; v_j0 = v; }
+        top.add(idx, t, v);
+        if ((nx >> IDX_BITS) != A.epoch) break;
+        idx = nx & IDX_MASK;
+        nx = A.next[idx]; load_delta_tv<AOS>(A, idx, t, v);
+        if (++steps > A.n) { atomicOr(A.status, ST_SPIN); return; }
+      }
+    }
     // the row starts as (2 or t_j0, v_j0) owned by j0 (src/bullet-crt.js:172-185); the other deltas then compete against it
     bt = (MODE == BMX_INSERT_REFERENCE) ? 2 : t_j0; bv = v_j0; owner = j0;
     int64_t tm, vm; uint32_t om;
     if (top.best_except(j0, tm, vm, om) && lexcmp(tm, vm, bt, bv) > 0) { bt = tm; bv = vm; owner = om; }   // a tie keeps j0 (it has the smaller index)
-  } else {
-    // lexmax over the list, ties to the smaller index ("identical clocks and values" is a no-op, :207-219)
-    bt = ts_value(tsw); bv = cval; owner = base_owner;
-    const int c = lexcmp(top.t1, top.v1, bt, bv);
-    if (c > 0) { bt = top.t1; bv = top.v1; owner = top.o1; }
-    else if (c == 0 && owner != ~0u && top.o1 < owner) owner = top.o1;
   }
   store_tv(sl, is_new ? (bt | ((int64_t)A.epoch << TS_MARK_SHIFT)) : bt, bv);
   // move the winner mark (and the per-block winner counts the compaction relies on) from the first claimer to the owner
