@@ -20,7 +20,7 @@ order-independent digest of the whole device table are compared with the CPU ora
 fails the run. Besides the contract fields the line carries
   roofline     — dominant kernel (k_probe_apply): algorithmic bytes per launch / its average duration, measured live with
                  HIP events on the engine's stream in a second pass over fresh batches of the same shape;
-  scan_config3 — configs[2]: equals/range scans over an indexed int32 field at 10M and 100M rows, with the roofline of the
+  scan_config3 — configs[2]: equals/range scans over an indexed int32 field and a wide int64 field at 10M and 100M rows, with the roofline of the
                  mask kernel (the one read of the value column);
   cpu_baseline — the CPU oracle (oracle/bmx_oracle.c, proven equal to the reference on golden vectors) timed on one host
                  core on a bounded sample of the same workload (rank 0, N=1 only).
@@ -155,43 +155,55 @@ def verify_against_oracle(eng, host_batches, winners_dev, n_applied_dev, residen
             "rows": rows, "table_digest": "%016x" % dg, "ok": True, "seconds": round(time.perf_counter() - t0, 2)}
 
 
-def scan_bench(bmx, dev, R, reps=20):
-    """Config 3: range/equals scans over an indexed int32 field of R nodes. Whole-scan time = HIP events around `reps` back-to-back scans;
+def scan_bench(bmx, dev, R, reps=20, wide=False):
+    """Config 3: range/equals scans over an indexed field of R nodes: int32 values in [0,1000) or, with `wide`, the same values shifted
+    beyond 32 bits (the int64 column variant of SURVEY 8(d) config 3). Whole-scan time = HIP events around `reps` back-to-back scans;
     the mask kernel's own time comes from per-kernel HIP events (bmx_profile_read_scan) in a second pass.
-    Algorithmic bytes: whole scan 4*R (value column) + 8*M (ids out); mask kernel 4*R."""
+    Algorithmic bytes: whole scan w*R (value column, w = 4 or 8) + 8*M (ids out); mask kernel w*R."""
     from bmx import synth
-    fa = synth.fnv1a32("n:age")
-    out = {"rows": R}
+    fa = synth.fnv1a32("n:score" if wide else "n:age")
+    w = 8.0 if wide else 4.0
+    sh = 33 if wide else 0
+    out = {"rows": R, "column": "int64" if wide else "int32"}
+    tscan = {}
+    try:      # HBM bytes per launch from the committed rocprofv3 --pmc passes over this same scan (profiles/r02_traffic_scan_passes.sh), 100M rows only
+        tj = json.load(open(os.path.join(ROOT, "profiles", "traffic_scan.json")))
+        if tj.get("rows") == R:
+            tscan = {q.split("/", 1)[1]: e for q, e in tj["queries"].items() if q.startswith(out["column"] + "/")}
+    except Exception:
+        tscan = {}
     with bmx.Engine(capacity_rows=R + 1024, device=dev.index or 0) as e:
         for r0 in range(0, R, 10_000_000):          # load in 10M-row pieces: bounded host memory
             m = min(10_000_000, R - r0)
             ids = synth.splitmix64_np(np.arange(r0 + 1, r0 + m + 1, dtype=np.uint64))
             with np.errstate(over="ignore"):
                 ages = (synth.splitmix64_np(ids ^ np.uint64(0xABCDEF)) % np.uint64(1000)).astype(np.int64)
-            e.load_rows(ids, np.full(m, fa, np.uint32), np.full(m, 5, np.int64), ages)
+            e.load_rows(ids, np.full(m, fa, np.uint32), np.full(m, 5, np.int64), ages << sh)
         del ids, ages
         t0 = time.perf_counter(); e.index_build(fa); out["index_build_ms"] = round((time.perf_counter() - t0) * 1e3, 3)
         out_ids = torch.zeros(R, dtype=torch.int64, device=dev)
         n_out = torch.zeros(1, dtype=torch.int64, device=dev)
         for name, lo, hi in [("equals_0.1pct", 42, 42), ("range_1pct", 100, 109), ("range_10pct", 100, 199), ("range_50pct", 0, 499)]:
             for _ in range(3):
-                e.scan_range_dev(fa, lo, hi, out_ids, R, n_out)
+                e.scan_range_dev(fa, lo << sh, hi << sh, out_ids, R, n_out)
             e.sync(); e.timer_start()
             for _ in range(reps):
-                e.scan_range_dev(fa, lo, hi, out_ids, R, n_out)
+                e.scan_range_dev(fa, lo << sh, hi << sh, out_ids, R, n_out)
             ms = e.timer_stop() / reps
             m = int(n_out.item())
             e.profile_enable(True)
             for _ in range(8):
-                e.scan_range_dev(fa, lo, hi, out_ids, R, n_out)
+                e.scan_range_dev(fa, lo << sh, hi << sh, out_ids, R, n_out)
             kms, _ = e.profile_read_scan()
             e.profile_enable(False)
-            alg = 4.0 * R + 8.0 * m
+            alg = w * R + 8.0 * m
             mask_s = kms["scan_mask"] * 1e-3
             out[name] = {"matches": m, "us": round(ms * 1e3, 2), "achieved_GBs": round(alg / (ms * 1e-3) / 1e9, 1), "frac_of_8TBs": round(alg / (ms * 1e-3) / 8e12, 4),
                          "rows_per_s": round(R / (ms * 1e-3)),
-                         "roofline_mask_kernel": {"bound": "hbm", "kernel": "k_scan_mask", "achieved": round(4.0 * R / mask_s / 1e9, 1) if mask_s > 0 else None, "peak": HBM_PEAK_GBS,
-                                                  "unit": "GB/s", "frac": round(4.0 * R / mask_s / 1e9 / HBM_PEAK_GBS, 4) if mask_s > 0 else None,
+                         "roofline_mask_kernel": {"bound": "hbm", "kernel": "k_scan_mask", "achieved": round(w * R / mask_s / 1e9, 1) if mask_s > 0 else None, "peak": HBM_PEAK_GBS,
+                                                  "unit": "GB/s", "frac": round(w * R / mask_s / 1e9 / HBM_PEAK_GBS, 4) if mask_s > 0 else None,
+                                                  "traffic": tscan.get(name, {}).get("mask", {}).get("bytes_per_launch"),
+                                                  "traffic_emit": tscan.get(name, {}).get("emit", {}).get("bytes_per_launch"),
                                                   "kernel_us": {"scan_mask": round(kms["scan_mask"] * 1e3, 2), "offsets_and_emit": round(kms["emit"] * 1e3, 2)}}}
     return out
 
@@ -440,6 +452,7 @@ def main():
             out["scan_config3"] = {}
             for rs in [int(x) for x in args.scan_rows.split(",") if x]:
                 out["scan_config3"]["%dM" % (rs // 1_000_000)] = scan_bench(bmx, dev, R=rs)
+                out["scan_config3"]["%dM_int64" % (rs // 1_000_000)] = scan_bench(bmx, dev, R=rs, wide=True)
         if not sharded and not args.no_cpu_baseline:
             out["js_host"] = js_host_rate()
             out["cpu_baseline"] = cpu_baseline()
