@@ -1,6 +1,8 @@
 """GPU parity, randomized: many small shapes against the oracle (merge, scans) and against a numpy stable sort (owner partition).
 Sizes sit on the kernels' internal boundaries (64-lane waves, 256-delta blocks, 1024-delta partition tiles, 4096-delta compaction
 blocks); timestamps and values come from tiny ranges so ties and duplicate keys are the norm, plus the domain's extreme values."""
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -16,8 +18,9 @@ VMAX = 2**53 - 1
 
 def _batch(rng, n, nkeys, nfields, tmax, vr, extremes):
     rows = rng.integers(0, max(nkeys, 1), n)
-    ids = np.array([streams.splitmix64(int(r) + 1) for r in rows], np.uint64)
-    fields = np.array([streams.field_hash(int(x)) for x in rng.integers(0, nfields, n)], np.uint32)
+    ids = streams.splitmix64_np(rows.astype(np.uint64) + np.uint64(1)) if n else np.zeros(0, np.uint64)
+    ftab = np.array([streams.field_hash(x) for x in range(nfields)], np.uint32)
+    fields = ftab[rng.integers(0, nfields, n)]
     ts = rng.integers(0, tmax + 1, n).astype(np.int64)
     val = rng.integers(-vr, vr + 1, n).astype(np.int64)
     if extremes and n:
@@ -29,15 +32,22 @@ def _batch(rng, n, nkeys, nfields, tmax, vr, extremes):
 
 
 SIZES = [0, 1, 2, 63, 64, 65, 255, 256, 257, 1023, 1024, 1025, 4095, 4096, 4097, 9000]
+# soak mode (spare GPU time): BMX_FUZZ_SEEDS=<count> [BMX_FUZZ_SEED0=<first>] runs more seeds, BMX_FUZZ_BIG=1 adds batches that span many
+# compute units at once (races between waves of different CUs on one key or one line)
+N_SEEDS = int(os.environ.get("BMX_FUZZ_SEEDS", "12"))
+SEED0 = int(os.environ.get("BMX_FUZZ_SEED0", "0"))
+BIG = os.environ.get("BMX_FUZZ_BIG") == "1"
+if BIG:
+    SIZES = SIZES + [65536, 200000, 300001]
 
 
-@pytest.mark.parametrize("seed", range(12))
+@pytest.mark.parametrize("seed", range(SEED0, SEED0 + N_SEEDS))
 def test_merge_random_shapes_match_oracle(seed):
     rng = np.random.default_rng(1000 + seed)
     for case in range(25):
         mode = [INSERT_REFERENCE, INSERT_DELTA][int(rng.integers(0, 2))]
         strict = bool(rng.integers(0, 2))
-        nkeys = int(rng.choice([1, 3, 50, 2000, 100000]))
+        nkeys = int(rng.choice([1, 3, 50, 2000, 100000] + ([20000, 1000000] if BIG else [])))
         nfields = int(rng.choice([1, 2, 5]))
         tmax = int(rng.choice([1, 4, 1000]))
         vr = int(rng.choice([0, 1, 100]))
