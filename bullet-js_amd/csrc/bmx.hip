@@ -83,6 +83,7 @@ struct bmx_ctx {
   uint64_t pr_cap = 0;
   uint64_t* pr_id = nullptr; uint32_t* pr_field = nullptr; int64_t* pr_ts = nullptr; int64_t* pr_val = nullptr; uint8_t* pr_found = nullptr;
   uint64_t scan_cap = 0; uint64_t* scan_out = nullptr;
+  bool scan_defer = false; uint64_t scan_defer_cap = 0;   // host-mode scan split in two (bmx_comm_scan_*): enqueue now, scan_collect() later
   uint32_t* block_counts = nullptr;   // SEL_MAX_BLOCKS
   uint32_t* scan_mask = nullptr;      // scan scratch: one match bit per index row
   uint32_t* scan_counts = nullptr;    // scan scratch: matches per 8192-row block (+ total)
@@ -568,6 +569,7 @@ int run_scan(bmx_ctx* ctx, const Pred& P, const Index* ix, uint64_t* out_ids, ui
     HIPCHK(hipEventRecord(se[1], ctx->stream));
   }
   if (se) { HIPCHK(hipEventRecord(se[2], ctx->stream)); ctx->scan_prof_n++; }
+  if (host && ctx->scan_defer) { ctx->scan_defer_cap = out_ids ? d_cap : 0; return BMX_OK; }   // the caller fetches with scan_collect()
   if (host) {
     unsigned long long m = 0;
     HIPCHK(hipMemcpyAsync(&m, &ctx->ds->n_out, sizeof(m), hipMemcpyDeviceToHost, ctx->stream));
@@ -575,6 +577,18 @@ int run_scan(bmx_ctx* ctx, const Pred& P, const Index* ix, uint64_t* out_ids, ui
     if (out_ids && m) HIPCHK(hipMemcpy(out_ids, ctx->scan_out, std::min<uint64_t>(m, d_cap) * 8, hipMemcpyDeviceToHost));
     if (n_out) *n_out = m;
   }
+  return BMX_OK;
+}
+
+// second half of a deferred host-mode scan: wait for the scan enqueued with ctx->scan_defer set, deliver the count and up to `cap` ids
+int scan_collect(bmx_ctx* ctx, uint64_t* out_ids, uint64_t cap, uint64_t* n_out) {
+  HIPCHK(hipSetDevice(ctx->device));
+  unsigned long long m = 0;
+  HIPCHK(hipMemcpyAsync(&m, &ctx->ds->n_out, sizeof(m), hipMemcpyDeviceToHost, ctx->stream));
+  HIPCHK(hipStreamSynchronize(ctx->stream));
+  const uint64_t k = std::min<uint64_t>(std::min<uint64_t>(m, ctx->scan_defer_cap), cap);
+  if (out_ids && k) HIPCHK(hipMemcpy(out_ids, ctx->scan_out, k * 8, hipMemcpyDeviceToHost));
+  if (n_out) *n_out = m;
   return BMX_OK;
 }
 

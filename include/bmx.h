@@ -257,7 +257,10 @@ int bmx_partition_by_owner_slabs(bmx_ctx* ctx, uint64_t n, const uint64_t* id, c
  * bmx_comm_shard_result: device pointers to what shard g merged in the last bmx_comm_merge_dev step and to its winners (positions in
  *   that record array), valid after bmx_comm_sync().
  * bmx_comm_scan_*: replaces range()/equals()/count()/declarative filter() (src/bullet-query.js:186-313) on the sharded graph: every
- *   shard scans its own rows, results are concatenated in shard order. No collective. */
+ *   shard scans its own rows, results are concatenated in shard order. No collective. The scans of all shards are enqueued before the
+ *   first result is fetched, so N GPUs scan at the same time.
+ * Every bmx_comm_* call restores the calling thread's current HIP device before it returns (single-context calls leave the context's
+ * device current). */
 typedef struct bmx_comm bmx_comm;
 int bmx_comm_create(uint32_t nshards, const int* devices, uint64_t capacity_rows_per_shard, uint32_t flags, bmx_comm** out);
 void bmx_comm_destroy(bmx_comm* comm);
