@@ -226,14 +226,25 @@ napi_value MergeBatchAsync(napi_env env, napi_callback_info info) {
   j->mode = mode;
   j->applied.resize(j->n ? j->n : 1); j->flags.resize(j->n ? j->n : 1);
   memset(&j->st, 0, sizeof(j->st));
+  napi_value promise, name;
+  auto drop = [&](const char* what) {
+    for (auto& r : j->refs) if (r) napi_delete_reference(env, r);
+    if (j->work) napi_delete_async_work(env, j->work);
+    delete j;
+    napi_throw_error(env, nullptr, what);
+    return (napi_value) nullptr;
+  };
+  if (napi_create_promise(env, &j->deferred, &promise) != napi_ok) return drop("bmx: could not create a promise");
   for (int k = 0; k < 4; k++) napi_create_reference(env, argv[1 + k], 1, &j->refs[k]);
   napi_create_reference(env, argv[0], 1, &j->refs[4]);
+  if (napi_create_string_utf8(env, "bmx.mergeBatchAsync", NAPI_AUTO_LENGTH, &name) != napi_ok ||
+      napi_create_async_work(env, nullptr, name, merge_execute, merge_complete, j, &j->work) != napi_ok) return drop("bmx: could not create the async work item");
+  // the ticket is taken last: a ticket that never runs would block every later operation on this handle
   j->ticket = h->take();
-  napi_value promise, name;
-  NAPI_OK(napi_create_promise(env, &j->deferred, &promise));
-  NAPI_OK(napi_create_string_utf8(env, "bmx.mergeBatchAsync", NAPI_AUTO_LENGTH, &name));
-  NAPI_OK(napi_create_async_work(env, nullptr, name, merge_execute, merge_complete, j, &j->work));
-  NAPI_OK(napi_queue_async_work(env, j->work));
+  if (napi_queue_async_work(env, j->work) != napi_ok) {
+    { Turn skip(h, j->ticket); }                    // give the turn back
+    return drop("bmx: could not queue the async work item");
+  }
   return promise;
 }
 
