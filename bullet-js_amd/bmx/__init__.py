@@ -28,7 +28,7 @@ MAX_BATCH = 1 << 24
 EXPORTS = [
     "bmx_create", "bmx_create_ex", "bmx_destroy", "bmx_last_error", "bmx_abi_version", "bmx_get_info", "bmx_sync", "bmx_set_stream", "bmx_get_stream", "bmx_seq_signal", "bmx_seq_wait",
     "bmx_load_rows", "bmx_merge_batch", "bmx_merge_submit", "bmx_merge_collect", "bmx_merge_records", "bmx_get_rows", "bmx_get_row", "bmx_dump_rows", "bmx_row_count", "bmx_reserve",
-    "bmx_index_build", "bmx_index_drop", "bmx_index_size", "bmx_scan_range", "bmx_scan_equals", "bmx_scan_count", "bmx_scan_filter",
+    "bmx_index_build", "bmx_index_drop", "bmx_index_size", "bmx_index_refresh_counts", "bmx_scan_range", "bmx_scan_equals", "bmx_scan_count", "bmx_scan_filter",
     "bmx_owner_of", "bmx_partition_by_owner", "bmx_partition_by_owner_slabs", "bmx_timer_start", "bmx_timer_stop", "bmx_profile_enable", "bmx_profile_read", "bmx_profile_read_scan",
     "bmx_comm_create", "bmx_comm_destroy", "bmx_comm_last_error", "bmx_comm_nshards", "bmx_comm_shard", "bmx_comm_sync", "bmx_comm_load_rows", "bmx_comm_merge",
     "bmx_comm_merge_dev", "bmx_comm_shard_result", "bmx_comm_row_count", "bmx_comm_get_rows", "bmx_comm_dump_rows", "bmx_comm_index_build",
@@ -107,6 +107,7 @@ def load_library():
     L.bmx_index_build.argtypes = [vp, u32]; L.bmx_index_build.restype = i32
     L.bmx_index_drop.argtypes = [vp, u32]; L.bmx_index_drop.restype = i32
     L.bmx_index_size.argtypes = [vp, u32, C.POINTER(u64)]; L.bmx_index_size.restype = i32
+    L.bmx_index_refresh_counts.argtypes = [vp, C.POINTER(u64), C.POINTER(u64)]; L.bmx_index_refresh_counts.restype = i32
     L.bmx_scan_range.argtypes = [vp, u32, i64, i64, vp, u64, vp, i32]; L.bmx_scan_range.restype = i32
     L.bmx_scan_equals.argtypes = [vp, u32, i64, vp, u64, vp, i32]; L.bmx_scan_equals.restype = i32
     L.bmx_scan_count.argtypes = [vp, u32, i64, i64, vp, i32]; L.bmx_scan_count.restype = i32
@@ -273,6 +274,12 @@ class Engine:
         n = C.c_uint64()
         self._chk(self.L.bmx_index_size(self.h, int(field), C.byref(n)))
         return n.value
+
+    def index_refresh_counts(self):
+        """-> (full index builds, incremental updates from the change log) since the engine was created"""
+        a, b = C.c_uint64(), C.c_uint64()
+        self._chk(self.L.bmx_index_refresh_counts(self.h, C.byref(a), C.byref(b)))
+        return a.value, b.value
 
     def scan_range(self, field, lo, hi, cap=None):
         cap = self.index_size(field) if cap is None else cap

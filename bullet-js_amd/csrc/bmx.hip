@@ -30,6 +30,7 @@ struct DevScalars {  // one small device allocation; zeroed at create
   uint32_t status;
   uint32_t wide;
   unsigned long long seq_diag[3];  // k_seq_wait expiry: {sequence word address, value waited for, value last seen}
+  unsigned long long chg_n[2];     // entries in the index change log: batch k reads [k&1], its compaction writes [(k+1)&1]
 };
 
 struct Index {
@@ -40,6 +41,7 @@ struct Index {
   int32_t* v32 = nullptr;
   bool fits32 = false;
   uint64_t version = ~0ull;  // table version it was built from
+  bool has_pos = false;      // its rows' positions are in ctx->slot_pos (it can be maintained from the change log)
 };
 
 thread_local std::string g_err;
@@ -97,6 +99,12 @@ struct bmx_ctx {
   uint64_t version = 0;
   uint64_t rows_ub = 0;               // host-side upper bound of resident rows
   std::vector<Index> indexes;
+  // incremental index maintenance (scan_kernels.h): slot -> position in its field's index, and the log of the winners' slots since the
+  // indices were last brought up to date. chg_valid: the log is complete (every merge since then was logged and nothing moved the slots).
+  uint32_t* slot_pos = nullptr; uint64_t slot_pos_n = 0;
+  uint2* chg = nullptr; uint64_t chg_cap = 0, chg_ub = 0;
+  bool chg_valid = false; uint32_t chg_par = 0;
+  uint64_t ix_full_builds = 0, ix_incremental = 0;
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
   // optional per-kernel profiling (bmx_profile_enable)
   bool prof_on = false;
@@ -274,6 +282,9 @@ int grow_table(bmx_ctx* ctx, uint64_t capacity_rows) {
   ctx->slots = fresh; ctx->nslots = nslots; ctx->capacity_rows = capacity_rows;
   // the batch epoch keeps counting: next[] still holds links tagged with earlier epochs; the new heads are all 0
   ctx->version++;          // indices are rebuilt on their next use
+  ctx->chg_valid = false;  // every row moved: the recorded slot positions mean nothing any more
+  dev_free(ctx->slot_pos); ctx->slot_pos_n = 0;
+  for (auto& ix : ctx->indexes) ix.has_pos = false;
   return check_status(ctx);
 }
 
@@ -374,11 +385,21 @@ int merge_core(bmx_ctx* ctx, uint64_t n, const uint64_t* id, const uint32_t* fie
   LAUNCHCHK("k_resolve_lists");
   if (pe) HIPCHK(hipEventRecord(pe[2], ctx->stream));
   }
-  // K3: ordered compaction of the winner bytes
+  // K3: ordered compaction of the winner bytes (+ the index change log while an index is being maintained)
   hipStream_t ks = ctx->stream;
   FinishMerge Fin{reinterpret_cast<unsigned long long*>(n_applied), stats, ctr, &ctx->ds->row_count};
+  ChgLog L{};
+  if (ctx->chg_valid) {
+    if (legacy && !strict && !unique && ctx->chg_ub + n <= ctx->chg_cap && ctx->nslots < (1ull << 31)) {
+      L.chg = ctx->chg; L.base = &ctx->ds->chg_n[ctx->chg_par]; L.next = &ctx->ds->chg_n[ctx->chg_par ^ 1u];
+      L.slot_of = ctx->slot_of; L.field = field; L.recs = recs; L.cap = ctx->chg_cap;
+      ctx->chg_par ^= 1u; ctx->chg_ub += n;
+    } else {
+      ctx->chg_valid = false;   // this batch is not in the log (another merge path, or the log is full): the next scan rebuilds
+    }
+  }
   hipLaunchKernelGGL((k_compact_winners<FinishMerge>), dim3((uint32_t)((n + 4095) / 4096)), dim3(SEL_THREADS), 0, ks, wflag, A.blk_info, (uint32_t)n,
-                     applied_idx, Fin);
+                     applied_idx, Fin, L);
   LAUNCHCHK("k_compact_winners");
   if (pe) { HIPCHK(hipEventRecord(pe[3], ks)); ctx->prof_n++; }
   ctx->nbatch++;
@@ -456,8 +477,42 @@ Index* find_index(bmx_ctx* ctx, uint32_t field) {
   return nullptr;
 }
 
+constexpr size_t IX_MAINTAINED_MAX = PART_MAX_SHARDS / 2;   // two scratch words of DevScalars::part_totals per maintained index
+
+// slot -> index position map (4 B per slot) and the change log; both exist from the first index build on
+int ensure_ix_maintenance(bmx_ctx* ctx) {
+  int rc;
+  if (ctx->slot_pos_n != ctx->nslots) {
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    dev_free(ctx->slot_pos); ctx->slot_pos_n = 0;
+    for (auto& ix : ctx->indexes) ix.has_pos = false;
+    ctx->chg_valid = false;
+    if (ctx->nslots >= (1ull << 31)) return BMX_OK;      // bit 31 of a log entry is the "created" mark: larger tables are rebuilt, not maintained
+    if ((rc = dev_alloc(ctx, &ctx->slot_pos, ctx->nslots))) { g_err.clear(); ctx->err.clear(); return BMX_OK; }   // no memory for it: fall back to rebuilds
+    ctx->slot_pos_n = ctx->nslots;
+    HIPCHK(hipMemsetAsync(ctx->slot_pos, 0xFF, ctx->nslots * sizeof(uint32_t), ctx->stream));
+  }
+  const uint64_t want = std::min<uint64_t>(std::max<uint64_t>(ctx->nslots / 4, 1u << 22), 1u << 26);   // 4M .. 64M entries of 8 B
+  if (ctx->chg_cap < want) {
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    dev_free(ctx->chg); ctx->chg_cap = 0; ctx->chg_valid = false;
+    if ((rc = dev_alloc(ctx, &ctx->chg, want))) { g_err.clear(); ctx->err.clear(); return BMX_OK; }
+    ctx->chg_cap = want;
+  }
+  return BMX_OK;
+}
+
+// forget the log: every index is either fresh or about to be rebuilt
+int reset_chg_log(bmx_ctx* ctx) {
+  HIPCHK(hipMemsetAsync(ctx->ds->chg_n, 0, sizeof(ctx->ds->chg_n), ctx->stream));
+  ctx->chg_par = 0; ctx->chg_ub = 0;
+  return BMX_OK;
+}
+
 // (Re)build the dense columns of `field` from the table, in slot order. Synchronous.
 int build_index(bmx_ctx* ctx, Index* ix) {
+  int mrc = ensure_ix_maintenance(ctx);
+  if (mrc) return mrc;
   PredSlotField P{ctx->slots, ix->field};
   SelGeom g = sel_geom<PredSlotField::E>(ctx->nslots);
   hipLaunchKernelGGL((k_sel_count<PredSlotField>), dim3(g.blocks), dim3(SEL_THREADS), 0, ctx->stream, P, ctx->nslots, g.tiles_per_block, ctx->block_counts);
@@ -470,13 +525,13 @@ int build_index(bmx_ctx* ctx, Index* ix) {
   if (n > ix->cap) {
     dev_free(ix->ids); dev_free(ix->v64); dev_free(ix->v32);
     ix->cap = 0;
-    uint64_t cap = (n + n / 8 + 1023) & ~1023ull;
+    uint64_t cap = (n + n / 8 + (1u << 16) + 1023) & ~1023ull;   // head room: rows created later are appended
     int rc;
     if ((rc = dev_alloc(ctx, &ix->ids, cap)) || (rc = dev_alloc(ctx, &ix->v64, cap)) || (rc = dev_alloc(ctx, &ix->v32, cap + 4))) return rc;
     ix->cap = cap;
   }
   HIPCHK(hipMemsetAsync(&ctx->ds->wide, 0, sizeof(uint32_t), ctx->stream));
-  EmitIndex Em{ctx->slots, ix->ids, ix->v64, ix->v32, &ctx->ds->wide};
+  EmitIndex Em{ctx->slots, ix->ids, ix->v64, ix->v32, &ctx->ds->wide, ctx->slot_pos};
   FinishCount Fin{nullptr};
   hipLaunchKernelGGL((k_sel_write<PredSlotField, EmitIndex, FinishCount>), dim3(g.blocks), dim3(SEL_THREADS), 0, ctx->stream, P, Em, Fin, ctx->nslots,
                      g.tiles_per_block, ctx->block_counts);
@@ -487,19 +542,86 @@ int build_index(bmx_ctx* ctx, Index* ix) {
   ix->n = n;
   ix->fits32 = wide == 0;
   ix->version = ctx->version;
+  ix->has_pos = ctx->slot_pos != nullptr;
+  ctx->ix_full_builds++;
+  // the log starts (or goes on) only if every index now knows its rows' positions and none is waiting for entries already logged
+  if (ctx->slot_pos && ctx->chg && !ctx->chg_valid && ctx->indexes.size() <= IX_MAINTAINED_MAX) {
+    bool all = true;
+    for (auto& o : ctx->indexes) all = all && o.has_pos && o.version == ctx->version;
+    if (all) { int rc = reset_chg_log(ctx); if (rc) return rc; ctx->chg_valid = true; }
+  }
+  return BMX_OK;
+}
+
+// Bring EVERY maintained index up to date from the change log (they share it), then forget the log. Per index: created rows of its field are
+// appended in log order, then every logged row of the field gets its current value. One host sync at the end (appended counts, wide flags).
+int refresh_from_log(bmx_ctx* ctx) {
+  const unsigned long long* n_dev = &ctx->ds->chg_n[ctx->chg_par];
+  const uint64_t ub = ctx->chg_ub;
+  struct Res { unsigned long long added; uint32_t wide; };
+  std::vector<Res> res(ctx->indexes.size());
+  // results of index k live in its own scratch words: part_totals[] is free between partitions (k < PART_MAX_SHARDS indexes are maintained)
+  if (ctx->indexes.size() > IX_MAINTAINED_MAX) return fail(ctx, BMX_ERR_INTERNAL, "index maintenance with more indexes than result words");
+  if (ub) {
+    for (size_t k = 0; k < ctx->indexes.size(); k++) {
+      Index& ix = ctx->indexes[k];
+      unsigned long long* d_added = &ctx->ds->part_totals[2 * k];
+      uint32_t* d_wide = reinterpret_cast<uint32_t*>(&ctx->ds->part_totals[2 * k + 1]);
+      HIPCHK(hipMemsetAsync(d_added, 0, 2 * sizeof(unsigned long long), ctx->stream));
+      PredLogCreated P{ctx->chg, n_dev, ix.field, ctx->slot_pos};
+      SelGeom g = sel_geom<PredLogCreated::E>(ub);
+      hipLaunchKernelGGL((k_sel_count<PredLogCreated>), dim3(g.blocks), dim3(SEL_THREADS), 0, ctx->stream, P, ub, g.tiles_per_block, ctx->block_counts);
+      LAUNCHCHK("k_sel_count(log)");
+      EmitAppend Em{ctx->chg, ctx->slots, ix.ids, ix.v64, ix.v32, d_wide, ctx->slot_pos, ix.n, ix.cap};
+      FinishCount Fin{d_added};
+      hipLaunchKernelGGL((k_sel_write<PredLogCreated, EmitAppend, FinishCount>), dim3(g.blocks), dim3(SEL_THREADS), 0, ctx->stream, P, Em, Fin, ub, g.tiles_per_block,
+                         ctx->block_counts);
+      LAUNCHCHK("k_sel_write(log)");
+      const uint32_t ublocks = (uint32_t)std::min<uint64_t>((ub + 255) / 256, 4096);
+      hipLaunchKernelGGL(k_ix_update, dim3(ublocks), dim3(256), 0, ctx->stream, (const uint2*)ctx->chg, n_dev, (const Slot*)ctx->slots, ix.field, (const uint32_t*)ctx->slot_pos,
+                         ix.v64, ix.v32, d_wide);
+      LAUNCHCHK("k_ix_update");
+    }
+    for (size_t k = 0; k < ctx->indexes.size(); k++) {
+      HIPCHK(hipMemcpyAsync(&res[k].added, &ctx->ds->part_totals[2 * k], sizeof(unsigned long long), hipMemcpyDeviceToHost, ctx->stream));
+      HIPCHK(hipMemcpyAsync(&res[k].wide, &ctx->ds->part_totals[2 * k + 1], sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
+    }
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+  }
+  int rc = reset_chg_log(ctx);
+  if (rc) return rc;
+  for (size_t k = 0; k < ctx->indexes.size(); k++) {
+    Index& ix = ctx->indexes[k];
+    if (ub && ix.n + res[k].added > ix.cap) { ix.version = ~0ull; continue; }   // the appended rows did not fit: rebuilt on its next use
+    if (ub) { ix.n += res[k].added; if (res[k].wide) ix.fits32 = false; }
+    ix.version = ctx->version;
+  }
+  ctx->ix_incremental++;
   return BMX_OK;
 }
 
 int fresh_index(bmx_ctx* ctx, uint32_t field, Index** out) {
   Index* ix = find_index(ctx, field);
   if (!ix) {  // equals()/range() auto-create a missing index: src/bullet-query.js:194-196, 230-232
+    if (ctx->indexes.size() >= IX_MAINTAINED_MAX) ctx->chg_valid = false;   // more indexes than the maintenance pass has result words for: they are rebuilt when stale
     ctx->indexes.emplace_back();
     ix = &ctx->indexes.back();
     ix->field = field;
   }
   if (ix->version != ctx->version) {
-    int rc = build_index(ctx, ix);
-    if (rc) return rc;
+    // maintained: every index has its positions recorded, the log is complete, and it is shorter than a quarter of the table
+    // (beyond that the rebuild's two sequential passes over the table are cheaper than the log's random accesses)
+    bool inc = ctx->chg_valid && ix->has_pos && ctx->chg_ub <= std::max<uint64_t>(ctx->nslots / 8, 1u << 20);
+    if (inc) for (auto& o : ctx->indexes) inc = inc && (o.has_pos || &o == ix);
+    if (inc) {
+      int rc = refresh_from_log(ctx);
+      if (rc) return rc;
+    }
+    if (ix->version != ctx->version) {   // not maintained (or its appended rows did not fit): rebuild from the table
+      ctx->chg_valid = false;
+      int rc = build_index(ctx, ix);
+      if (rc) return rc;
+    }
   }
   *out = ix;
   return BMX_OK;
@@ -689,6 +811,7 @@ void bmx_destroy(bmx_ctx* ctx) {
   if (ctx->copy_stream) (void)hipStreamDestroy(ctx->copy_stream);
   if (ctx->down_stream) { (void)hipStreamSynchronize(ctx->down_stream); (void)hipStreamDestroy(ctx->down_stream); }
   dev_free(ctx->bin_stage); dev_free(ctx->bin_toff);
+  dev_free(ctx->slot_pos); dev_free(ctx->chg);
   dev_free(ctx->scan_out); dev_free(ctx->block_counts); dev_free(ctx->part_counts); dev_free(ctx->part_owner); dev_free(ctx->scan_mask); dev_free(ctx->scan_counts);
   for (auto ev : ctx->prof_ev) (void)hipEventDestroy(ev);
   for (auto ev : ctx->scan_ev) (void)hipEventDestroy(ev);
@@ -906,6 +1029,13 @@ int bmx_index_size(bmx_ctx* ctx, uint32_t field, uint64_t* n_out) {
   int rc = fresh_index(ctx, field, &ix);
   if (rc) return rc;
   *n_out = ix->n;
+  return BMX_OK;
+}
+
+int bmx_index_refresh_counts(bmx_ctx* ctx, uint64_t* full_builds, uint64_t* incremental_updates) {
+  if (!ctx) return fail(nullptr, BMX_ERR_INVALID, "null context");
+  if (full_builds) *full_builds = ctx->ix_full_builds;
+  if (incremental_updates) *incremental_updates = ctx->ix_incremental;
   return BMX_OK;
 }
 

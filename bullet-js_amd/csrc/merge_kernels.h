@@ -51,6 +51,7 @@ struct MergeArgs {
 };
 
 constexpr uint8_t W_NONE = 0, W_WINNER = 1, W_PENDING = 2, W_FIRST = 4;   // W_FIRST (bit): first claimer of its row in this batch; bit 0 is what the compaction reads
+constexpr uint8_t W_CREATED = 8;   // (bit, on a winner) its row did not exist before this batch: the index change log appends it instead of updating it
 constexpr uint32_t BLK_PENDING = 0x80000000u, BLK_COUNT = 0x7FFFFFFFu;
 // A single hot word takes only ~88 atomics/us (MI355X_MICROARCH.md "dequeue"), so per-batch counters are
 // spread over 256 words on separate 128-B lines and folded once per batch by the last compaction block.
@@ -199,7 +200,7 @@ __global__ __launch_bounds__(256) void k_probe_apply(MergeArgs A) {
             // the creation mark keeps later deltas of this key from comparing against this provisional value
             const int64_t t0 = (MODE == BMX_INSERT_REFERENCE) ? 2 : a;
             store_tv(sl, t0 | ((int64_t)A.epoch << TS_MARK_SHIFT), v);
-            wf |= W_WINNER; fl = BMX_FLAG_INCOMING;
+            wf |= W_WINNER | W_CREATED; fl = BMX_FLAG_INCOMING;
           } else if (c > 0) {
             store_tv(sl, a, v); wf |= W_WINNER; fl = BMX_FLAG_INCOMING;
           }  // c == 0: identical clock and value: no-op, all flags false
@@ -328,7 +329,10 @@ __device__ __forceinline__ void resolve_one(const MergeArgs& A, const uint32_t j
   // move the winner mark (and the per-block winner counts the compaction relies on) from the first claimer to the owner
   if (base_owner != owner) {
     if (base_owner != ~0u) { A.wflag[base_owner] = W_NONE; atomicSub(&A.blk_info[base_owner >> 8], 1u); }
-    if (owner != ~0u) { A.wflag[owner] = W_WINNER; atomicAdd(&A.blk_info[owner >> 8], 1u); }
+    if (owner != ~0u) {
+      A.wflag[owner] = is_new ? (uint8_t)(W_WINNER | W_CREATED) : W_WINNER; atomicAdd(&A.blk_info[owner >> 8], 1u);
+      A.slot_of[owner] = A.slot_of[j];    // the compaction's index change log names the winner's row
+    }
   }
   if (owner != ~0u && A.flags) A.flags[owner] = (uint8_t)BMX_FLAG_INCOMING;
 }

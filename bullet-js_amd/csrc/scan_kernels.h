@@ -46,15 +46,78 @@ struct PredSlotAny {  // every occupied slot
     return m;
   }
 };
-struct EmitIndex {  // slot -> index columns
+struct EmitIndex {  // slot -> index columns (+ the slot's position in its index: what the incremental maintenance looks up)
   const Slot* slots; uint64_t* ids; int64_t* v64; int32_t* v32; uint32_t* wide;  // *wide set if a value does not fit i32
+  uint32_t* slot_pos;   // [nslots] or nullptr
   __device__ void operator()(uint64_t pos, uint64_t s) const {
     const Slot& sl = slots[s];
     int64_t v = sl.val;
     ids[pos] = sl.id; v64[pos] = v; v32[pos] = (int32_t)v;
     if (v != (int64_t)(int32_t)v) *wide = 1u;
+    if (slot_pos) slot_pos[s] = (uint32_t)pos;
   }
 };
+
+// ---- incremental index maintenance (the device-side _updateIndices, src/bullet-query.js:82-110) ----
+// While an index exists, the compaction of every merge appends one entry per winner to a change log: the winner's slot (bit 31: the row was
+// created by this batch) and its field. Before the next scan the log is applied to the dense columns: created rows of the indexed field are
+// appended in log order (ordered select over the log: deterministic), the others overwrite their value at the position the build recorded
+// for their slot. Values are read from the TABLE at that moment, not from the log, so a row that appears twice gets the same (current) value
+// from both entries. ~50 us per logged 1M-delta batch instead of a rebuild that reads the whole table twice (0.5 ms at 10M rows, 3.5 ms at 100M).
+constexpr uint32_t POS_NONE = 0xFFFFFFFFu;
+constexpr uint32_t CHG_CREATED = 0x80000000u;
+struct ChgLog {   // k_compact_winners' view; chg == nullptr: no logging
+  uint2* chg; const unsigned long long* base; unsigned long long* next;   // entries so far (read), entries after this batch (written by the last block)
+  const uint32_t* slot_of; const uint32_t* field; const bmx_delta_rec* recs; uint64_t cap;
+};
+struct PredLogCreated {   // log entries that create a row of `field` which the index does not hold yet
+  static constexpr int E = 2;
+  const uint2* chg; const unsigned long long* n_dev; uint32_t field; const uint32_t* slot_pos;
+  __device__ uint32_t mask(uint64_t first, uint64_t) const {
+    const uint64_t n = *n_dev;
+    uint32_t m = 0;
+#pragma unroll
+    for (int e = 0; e < E; e++) {
+      const uint64_t i = first + e;
+      if (i < n) {
+        const uint2 x = chg[i];
+        if ((x.x & CHG_CREATED) && x.y == field && slot_pos[x.x & ~CHG_CREATED] == POS_NONE) m |= 1u << e;
+      }
+    }
+    return m;
+  }
+};
+struct EmitAppend {   // created row -> the end of the index columns, in log order
+  const uint2* chg; const Slot* slots; uint64_t* ids; int64_t* v64; int32_t* v32; uint32_t* wide; uint32_t* slot_pos; uint64_t base, cap;
+  __device__ void operator()(uint64_t rank, uint64_t i) const {
+    const uint64_t pos = base + rank;
+    if (pos >= cap) return;                       // the host sees the total and rebuilds
+    const uint32_t s = chg[i].x & ~CHG_CREATED;
+    const Slot& sl = slots[s];
+    const int64_t v = sl.val;
+    ids[pos] = sl.id; v64[pos] = v; v32[pos] = (int32_t)v;
+    if (v != (int64_t)(int32_t)v) *wide = 1u;
+    slot_pos[s] = (uint32_t)pos;
+  }
+};
+// every log entry of `field` that changed a row the index holds: refresh its value from the table (both value columns: the declarative
+// filter reads the int64 one whatever the range scans use). Entries that created their row were appended with the current value already.
+__global__ __launch_bounds__(256) void k_ix_update(const uint2* __restrict__ chg, const unsigned long long* __restrict__ n_dev, const Slot* __restrict__ slots,
+                                                   uint32_t field, const uint32_t* __restrict__ slot_pos, int64_t* __restrict__ v64, int32_t* __restrict__ v32,
+                                                   uint32_t* wide) {
+  const uint64_t n = *n_dev;
+  for (uint64_t i = (uint64_t)blockIdx.x * 256u + threadIdx.x; i < n; i += (uint64_t)gridDim.x * 256u) {
+    const uint2 x = chg[i];
+    if (x.y != field || (x.x & CHG_CREATED)) continue;
+    const uint32_t s = x.x;
+    const uint32_t p = slot_pos[s];
+    if (p == POS_NONE) continue;
+    const uint4 hi = reinterpret_cast<const uint4*>(slots + s)[1];
+    const int64_t v = (int64_t)((uint64_t)hi.z | ((uint64_t)hi.w << 32));
+    v64[p] = v; v32[p] = (int32_t)v;
+    if (v != (int64_t)(int32_t)v) *wide = 1u;
+  }
+}
 struct EmitRows {  // slot -> dumped row columns (bounded by cap)
   const Slot* slots; uint64_t cap; uint64_t* id; uint32_t* field; int64_t* ts; int64_t* val;
   __device__ void operator()(uint64_t pos, uint64_t s) const {
@@ -193,7 +256,7 @@ struct FinishMerge {  // totals -> caller; fold and clear the sharded per-batch 
 // EARLIER launches: no counting phase, no in-launch hand-off. One block = 4096 deltas = 16 count entries.
 template <class Finish>
 __global__ __launch_bounds__(SEL_THREADS) void k_compact_winners(const uint8_t* __restrict__ wflag, const uint32_t* __restrict__ blk_info, uint32_t n,
-                                                                  uint32_t* __restrict__ applied, Finish Fin) {
+                                                                  uint32_t* __restrict__ applied, Finish Fin, ChgLog L) {
   __shared__ uint32_t wsum[4];
   // both loads are issued before the first wait: this block's 16 winner bytes per lane and its share of the count prefix
   PredWinner P{wflag};
@@ -223,7 +286,7 @@ __global__ __launch_bounds__(SEL_THREADS) void k_compact_winners(const uint8_t* 
   block_excl_scan(part, offset, wsum);
   uint32_t tot;
   uint32_t lp = block_excl_scan((uint32_t)__popc(m), tot, wsum);
-  if (applied) {
+  if (applied || L.chg) {
     // winners of this block in order through LDS, then consecutive lanes store consecutive ranks (a lane's own run of up to 16
     // indices would be 16 scattered 4-byte stores per wave instruction)
     __shared__ uint32_t loc[4096];
@@ -233,9 +296,20 @@ __global__ __launch_bounds__(SEL_THREADS) void k_compact_winners(const uint8_t* 
       loc[lp++] = (uint32_t)first + (uint32_t)e;
     }
     __syncthreads();
-    for (uint32_t i = threadIdx.x; i < tot; i += SEL_THREADS) applied[offset + i] = loc[i];
+    if (applied) for (uint32_t i = threadIdx.x; i < tot; i += SEL_THREADS) applied[offset + i] = loc[i];
+    if (L.chg) {   // index change log: (slot | created, field) of every winner, behind the entries of the batches before
+      const unsigned long long base = *L.base + offset;
+      for (uint32_t i = threadIdx.x; i < tot; i += SEL_THREADS) {
+        const uint32_t j = loc[i];
+        const uint32_t f = L.recs ? L.recs[j].field : L.field[j];
+        if (base + i < L.cap) L.chg[base + i] = make_uint2(L.slot_of[j] | ((wflag[j] & W_CREATED) ? CHG_CREATED : 0u), f);
+      }
+    }
   }
-  if (blockIdx.x == gridDim.x - 1) Fin((uint64_t)offset + tot, wsum);
+  if (blockIdx.x == gridDim.x - 1) {
+    if (L.chg && threadIdx.x == 0) *L.next = *L.base + offset + tot;
+    Fin((uint64_t)offset + tot, wsum);
+  }
 }
 
 __global__ void k_sum_counts(const uint32_t* block_counts, uint32_t nblocks, unsigned long long* n_out) {

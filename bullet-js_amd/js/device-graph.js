@@ -45,6 +45,8 @@ class DeviceGraph {
   indexBuild(f) { return this.comm ? this.native.commIndexBuild(this.comm, f) : this.native.indexBuild(this.handle, f); }
   indexDrop(f) { return this.comm ? this.native.commIndexDrop(this.comm, f) : this.native.indexDrop(this.handle, f); }
   indexSize(f) { return this.comm ? this.native.commIndexSize(this.comm, f) : this.native.indexSize(this.handle, f); }
+  /* {fullBuilds, incremental}: index rebuilds from the table vs updates from the merges' change log (one context only) */
+  indexRefreshCounts() { return this.comm ? null : this.native.indexRefreshCounts(this.handle); }
   scanRange(f, lo, hi) { return this.comm ? this.native.commScanRange(this.comm, f, lo, hi) : this.native.scanRange(this.handle, f, lo, hi); }
   scanCount(f, lo, hi) { return this.comm ? this.native.commScanCount(this.comm, f, lo, hi) : this.native.scanCount(this.handle, f, lo, hi); }
   scanFilter(terms) { return this.comm ? this.native.commScanFilter(this.comm, terms) : this.native.scanFilter(this.handle, terms); }

@@ -302,10 +302,15 @@ for (const shards of [2, 4, 8]) {
   assert.strictEqual(query.lastPath, "device");
   assert.strictEqual(query.range("dev", "age", 0, 4).length, 50);
   assert.strictEqual(query.count("dev", "age", 7), 9);                              // n7 moved away from 7
-  crt.mergeEntries([{ path: "dev/n1", data: { age: 49 }, vectorClock: { w: 12 } }], { insertMode: "delta" });
-  assert.ok(keys(query.equals("dev", "age", 49)).includes("n1"));                   // bmx rebuilds the device index when the table changed
+  const before = crt.graph.indexRefreshCounts();
+  crt.mergeEntries([{ path: "dev/n1", data: { age: 49 }, vectorClock: { w: 12 } }, { path: "dev/fresh", data: { age: 49 }, vectorClock: { w: 12 } }], { insertMode: "delta" });
+  const got49 = keys(query.equals("dev", "age", 49));
+  assert.ok(got49.includes("n1") && got49.includes("fresh"));                       // changed row and created row, both through the change log:
+  const after = crt.graph.indexRefreshCounts();
+  assert.strictEqual(after.fullBuilds, before.fullBuilds);                          // the index was not rebuilt from the table
+  assert.strictEqual(after.incremental, before.incremental + 1);
   b.close();
-  checks += 5;
+  checks += 7;
 }
 
 /* N4: K-writer vector clocks. (a) the reference's golden vectors through the addon's vc* entry points */

@@ -340,6 +340,17 @@ napi_value IndexSize(napi_env env, napi_callback_info info) {
   if (rc) return throw_bmx(env, h->ctx, rc);
   napi_value v; napi_create_double(env, (double)n, &v); return v;
 }
+// indexRefreshCounts(h) -> {fullBuilds, incremental}: how often the indexes were rebuilt from the table / brought up to date from the change log
+napi_value IndexRefreshCounts(napi_env env, napi_callback_info info) {
+  ARGS(1);
+  Handle* h; if (!get_handle(env, argv[0], &h)) return nullptr;
+  Turn turn(h);
+  uint64_t a = 0, b = 0; int rc = bmx_index_refresh_counts(h->ctx, &a, &b);
+  if (rc) return throw_bmx(env, h->ctx, rc);
+  napi_value out; NAPI_OK(napi_create_object(env, &out));
+  set_num(env, out, "fullBuilds", (double)a); set_num(env, out, "incremental", (double)b);
+  return out;
+}
 
 // scanRange(h, field, lo, hi) -> BigUint64Array of node ids
 napi_value ScanRange(napi_env env, napi_callback_info info) {
@@ -741,7 +752,7 @@ napi_value Init(napi_env env, napi_value exports) {
   struct { const char* name; napi_callback fn; } fns[] = {
       {"abiVersion", AbiVersion}, {"create", Create}, {"destroy", Destroy}, {"mergeBatch", MergeBatch}, {"mergeBatchAsync", MergeBatchAsync}, {"reserve", Reserve}, {"loadRows", LoadRows},
       {"getRows", GetRows}, {"rowCount", RowCount}, {"dumpRows", DumpRows}, {"indexBuild", IndexBuild}, {"indexDrop", IndexDrop},
-      {"indexSize", IndexSize}, {"scanRange", ScanRange}, {"scanCount", ScanCount}, {"scanFilter", ScanFilter}, {"info", Info},
+      {"indexSize", IndexSize}, {"indexRefreshCounts", IndexRefreshCounts}, {"scanRange", ScanRange}, {"scanCount", ScanCount}, {"scanFilter", ScanFilter}, {"info", Info},
       {"vcCreate", VcCreate}, {"vcDestroy", VcDestroy}, {"vcLoadRows", VcLoadRows}, {"vcMergeBatch", VcMergeBatch}, {"vcGetRows", VcGetRows}, {"vcRowCount", VcRowCount},
       {"commCreate", CommCreate}, {"commDestroy", CommDestroy}, {"commMergeBatch", CommMergeBatch}, {"commLoadRows", CommLoadRows}, {"commGetRows", CommGetRows},
       {"commRowCount", CommRowCount}, {"commDumpRows", CommDumpRows}, {"commIndexBuild", CommIndexBuild}, {"commIndexDrop", CommIndexDrop}, {"commIndexSize", CommIndexSize},

@@ -201,12 +201,20 @@ int bmx_reserve(bmx_ctx* ctx, uint64_t capacity_rows);
  *
  * bmx_scan_range replaces range(path, field, min, max) src/bullet-query.js:221-261: lo <= val <= hi,
  * both inclusive. bmx_scan_equals replaces equals() :186-210, bmx_scan_count replaces count() :293-313.
- * Results are node ids in index-column order (deterministic for a given table state); the host mirror
- * maps ids back to paths and can reproduce the reference's first-seen-value order.
+ * Results are node ids in index-column order (deterministic for a given history of calls: table order for the rows
+ * present at the last full build, then creation order); the host mirror maps ids back to paths and can reproduce the
+ * reference's first-seen-value order.
+ *
+ * Maintenance (the device-side _updateIndices, src/bullet-query.js:82-110): while an index exists, every merge on the default path
+ * logs its winners' rows; the next scan applies that log to the dense columns (created rows appended, changed rows overwritten)
+ * instead of rebuilding them from the table. A full rebuild still happens after a table growth, after merges that do not log
+ * (BMX_MERGE_UNIQUE_KEYS, BMX_MERGE_STRICT_FLAGS, the bucketed path), when the log outgrows an eighth of the table, with more than 8
+ * indexes, or for tables of 2^31 slots and more. bmx_index_refresh_counts reports how often each happened.
  * out_ids may be NULL (count only). *n_out = number of matches even if cap is smaller. */
 int bmx_index_build(bmx_ctx* ctx, uint32_t field);
 int bmx_index_drop(bmx_ctx* ctx, uint32_t field);
 int bmx_index_size(bmx_ctx* ctx, uint32_t field, uint64_t* n_out);
+int bmx_index_refresh_counts(bmx_ctx* ctx, uint64_t* full_builds, uint64_t* incremental_updates);
 int bmx_scan_range(bmx_ctx* ctx, uint32_t field, int64_t lo, int64_t hi, uint64_t* out_ids, uint64_t cap,
                    uint64_t* n_out, int mem);
 int bmx_scan_equals(bmx_ctx* ctx, uint32_t field, int64_t value, uint64_t* out_ids, uint64_t cap, uint64_t* n_out,
