@@ -522,7 +522,7 @@ int build_index(bmx_ctx* ctx, Index* ix) {
   unsigned long long n = 0;
   HIPCHK(hipMemcpyAsync(&n, &ctx->ds->n_out, sizeof(n), hipMemcpyDeviceToHost, ctx->stream));
   HIPCHK(hipStreamSynchronize(ctx->stream));
-  if (n > ix->cap) {
+  if (n + (n >> 4) + (1u << 16) > ix->cap) {   // too little head room left for appended rows: a new set of columns
     dev_free(ix->ids); dev_free(ix->v64); dev_free(ix->v32);
     ix->cap = 0;
     uint64_t cap = (n + n / 8 + (1u << 16) + 1023) & ~1023ull;   // head room: rows created later are appended
