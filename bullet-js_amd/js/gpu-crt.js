@@ -289,7 +289,27 @@ class GpuCRT {
     const applied = new Array(r.applied.length);
     for (let k = 0; k < applied.length; k++) { const j = r.applied[k]; applied[k] = { entry: rowEntry[j], field: rowField[j] < 0 ? null : fieldNames[rowField[j]] }; }
     const broadcast = opts.apply ? this._applyWinners(entries, used, r.applied, applied, opts.apply) : undefined;
+    if (opts.apply) this._notifyIndexHook(entries, host);
     return { applied, nApplied: r.nApplied, nConflicts: r.nConflicts, nRows: r.nRows, host, broadcast };
+  }
+
+  /*
+   * The reference's query engine keeps its indices current through a wrapper around setData (src/bullet-query.js:13-21): after EVERY
+   * write, accepted or not, it calls _updateIndices(path, data). A batch that is applied here never passes through setData, so the
+   * hook is called for it: GpuQuery marks the touched children of its indexed collections (it re-reads them from the store at the next
+   * query), a reference BulletQuery gets its own _updateIndices. Entries the batch handed back (`host`) reach the hook through setData.
+   */
+  _notifyIndexHook(entries, hostIdx) {
+    const q = this.bullet.query;
+    if (!q) return;
+    const skip = hostIdx && hostIdx.length ? new Set(hostIdx) : null;
+    if (typeof q._touch === "function") {
+      if (!q.indexedPaths || q.indexedPaths.size === 0) return;
+      for (let i = 0; i < entries.length; i++) if (!skip || !skip.has(i)) q._touch(entries[i].path);
+    } else if (typeof q._updateIndices === "function") {
+      if (!q.indexedPaths || q.indexedPaths.size === 0) return;
+      for (let i = 0; i < entries.length; i++) if (!skip || !skip.has(i)) q._updateIndices(entries[i].path, entries[i].data);
+    }
   }
 
   /*

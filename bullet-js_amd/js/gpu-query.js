@@ -16,7 +16,12 @@
  *   - filter/map/find take arbitrary JS callbacks and run on the host, as in the reference.
  *
  * Freshness: the reference maintains its indices incrementally and drifts (SURVEY §8(a) Q4); parity is defined
- * on the FRESH state. Here a write under an indexed path marks the index stale and the next query rebuilds it.
+ * on the FRESH state: what _buildIndex would produce from the store at query time. A write under an indexed path is
+ * remembered per CHILD; the next query re-reads only those children from the store, patches its host mirror and
+ * sends their rows to the device, whose own change log brings the dense columns up to date (include/bmx.h
+ * "Maintenance") — work proportional to what changed, not to the collection. Whenever the patched state could
+ * differ from a fresh build (a child left the index or the integer domain, a child that existed without the field
+ * gained it, an integer-like new key, a write at or above the indexed path) the index is rebuilt from the store.
  */
 const { Columns, fieldId, isDeviceInt } = require("./hash");
 
@@ -32,6 +37,8 @@ class GpuQuery {
     this._opts = opts;
     this._graph = opts.graph || null;
     this._gen = 0;
+    this._byBase = new Map();       // indexed path -> its index records
+    this.stats = { builds: 0, patches: 0 };
     this._hookWrites();
   }
 
@@ -53,9 +60,18 @@ class GpuQuery {
   }
 
   _touch(path) {
-    for (const base of this.indexedPaths) {
-      if (path === base || path.startsWith(base + "/") || base.startsWith(path + "/")) {
-        for (const k of Object.keys(this.indices)) if (this.indices[k].path === base) this.indices[k].stale = true;
+    for (const [base, list] of this._byBase) {
+      if (path.length > base.length && path.charCodeAt(base.length) === 47 && path.startsWith(base)) {
+        // below the indexed path: only this child has to be looked at again
+        const cut = path.indexOf("/", base.length + 1);
+        const child = cut < 0 ? path.slice(base.length + 1) : path.slice(base.length + 1, cut);
+        for (const ix of list) {
+          if (ix.stale === true) continue;
+          if (!ix.stale) { ix.stale = "partial"; ix.dirty = new Set(); }
+          ix.dirty.add(child);
+        }
+      } else if (path === base || base.startsWith(path + "/")) {
+        for (const ix of list) { ix.stale = true; ix.dirty = null; }
       }
     }
   }
@@ -70,8 +86,10 @@ class GpuQuery {
   index(path, field = null, opts = {}) {
     const key = GpuQuery.keyOf(path, field);
     if (this.indices[key]) return this;
-    this.indices[key] = { path, field, stale: true, kind: null, source: opts.source === "device" ? "device" : "store" };
+    this.indices[key] = { path, field, stale: true, dirty: null, kind: null, source: opts.source === "device" ? "device" : "store" };
     this.indexedPaths.add(path);
+    if (!this._byBase.has(path)) this._byBase.set(path, []);
+    this._byBase.get(path).push(this.indices[key]);
     this._build(this.indices[key]);
     return this;
   }
@@ -82,7 +100,7 @@ class GpuQuery {
     ix.kind = "device";
     ix.deviceField = g.keys.fieldOf(ix.path, ix.field);
     g.indexBuild(ix.deviceField);
-    ix.paths = null; ix.values = null; ix.stale = false; ix.rank = null; ix._posByPath = null;
+    ix.paths = null; ix.values = null; ix.stale = false; ix.dirty = null; ix.rank = null; ix._posByPath = null;
   }
 
   /* scan the direct children of `path` (one level, as _buildIndex does) and materialise the index */
@@ -90,6 +108,8 @@ class GpuQuery {
     if (ix.source === "device") { this._buildFromDevice(ix); return; }
     const base = this.bullet._getData(ix.path);
     const paths = [], values = [];
+    this.stats.builds++;
+    ix.allChildren = new Set(typeof base === "object" && base !== null ? Object.keys(base) : []);
     if (typeof base === "object" && base !== null) {
       for (const [child, v] of Object.entries(base)) {
         let x;
@@ -107,6 +127,7 @@ class GpuQuery {
     ix.paths = paths;
     ix.values = values;
     ix.stale = false;
+    ix.dirty = null;
     ix.rank = null;
     ix._posByPath = null;
     if (values.length > 0 && values.every(isDeviceInt)) this._buildDevice(ix);
@@ -135,12 +156,58 @@ class GpuQuery {
     for (let i = 0; i < n; i++) cols.set(i, g.keys.idOf(ix.paths[i]), ix.deviceField, 1, ix.values[i]);
     g.loadRows(cols);
     g.indexBuild(ix.deviceField);
+    ix.seq = 1;                                 // ts of the device rows of this build; patches use 2, 3, ...
+  }
+
+  /*
+   * Q4 (_updateIndices, src/bullet-query.js:139-174) without its drift: re-read the children written since the last query and patch the
+   * index instead of rebuilding it. Returns false when only a fresh build is guaranteed to give the reference's state.
+   */
+  _applyDirty(ix) {
+    if (ix.kind !== "device" || ix.source === "device" || !ix.dirty || !ix.paths) return false;
+    const base = this.bullet._getData(ix.path);
+    if (typeof base !== "object" || base === null) return false;
+    const pos = ix._posByPath || (ix._posByPath = new Map(ix.paths.map((p, i) => [p, i])));
+    const changed = [];                          // ordinals whose device row has to be rewritten (a bail-out below rebuilds the mirror: nothing to roll back)
+    for (const child of ix.dirty) {
+      const v = base[child];
+      let x, present = true;
+      if (ix.field) {
+        if (typeof v !== "object" || v === null || !(ix.field in v)) present = false; else x = v[ix.field];
+      } else x = v;
+      if (present && (x === null || x === undefined)) present = false;
+      const p = `${ix.path}/${child}`;
+      const at = pos.get(p);
+      if (at !== undefined) {
+        if (!present || !isDeviceInt(x)) return false;              // left the index, or the integer domain
+        if (ix.values[at] !== x) { ix.values[at] = x; changed.push(at); }
+      } else {
+        if (!present) { if (v !== undefined) ix.allChildren.add(child); continue; }
+        if (!isDeviceInt(x)) return false;                           // the index stops being an integer index
+        if (ix.allChildren.has(child)) return false;                 // it existed without the field: a fresh scan lists it where it was created, not last
+        if (/^(0|[1-9][0-9]*)$/.test(child)) return false;           // integer-like keys are enumerated before all others, in numeric order
+        ix.allChildren.add(child);
+        pos.set(p, ix.paths.length); ix.paths.push(p); ix.values.push(x); changed.push(ix.paths.length - 1);
+      }
+    }
+    if (changed.length) {
+      const g = this.graph;
+      const cols = new Columns(changed.length);
+      const ts = ++ix.seq;
+      for (let k = 0; k < changed.length; k++) cols.set(k, g.keys.idOf(ix.paths[changed[k]]), ix.deviceField, ts, ix.values[changed[k]]);
+      g.loadRows(cols);                          // newer ts: plain LWW on the device; its change log updates the dense columns at the next scan
+      ix.rank = null;
+    }
+    ix.stale = false; ix.dirty = null;
+    this.stats.patches++;
+    return true;
   }
 
   _fresh(path, field) {
     const key = GpuQuery.keyOf(path, field);
     if (!this.indices[key]) this.index(path, field);
     const ix = this.indices[key];
+    if (ix.stale === "partial" && this._applyDirty(ix)) return ix;
     if (ix.stale) this._build(ix);
     return ix;
   }

@@ -313,6 +313,61 @@ for (const shards of [2, 4, 8]) {
   checks += 7;
 }
 
+/* Q4: writes under an indexed path patch the index (dirty children -> device rows -> the device's change log) and every query equals what a
+ * FRESH GpuQuery builds from the same store; the cases where only a rebuild is safe fall back to it and still agree */
+{
+  const GpuQuery = require("../gpu-query");
+  const b = new MiniBullet("w");
+  const { crt, query } = attach(b, { capacityRows: 1 << 16 });
+  for (let i = 0; i < 400; i++) b.setData("users/u" + i, { age: i % 40, score: i * 3, name: "n" + i });
+  query.index("users", "age"); query.index("users", "score");
+  const paths = (nodes) => nodes.map((n) => n.path);
+  const sameAsFresh = (tag) => {
+    const b2 = new MiniBullet("w"); b2.store = b.store; b2.crt = { handleUpdate() { throw new Error("read-only twin"); } };
+    const q2 = new GpuQuery(b2, { capacityRows: 1 << 16 });
+    for (const [f, v] of [["age", 39], ["age", 7], ["score", 15], ["age", 1000]]) {
+      assert.deepStrictEqual(paths(query.equals("users", f, v)), paths(q2.equals("users", f, v)), tag + " equals " + f + "=" + v);
+      assert.strictEqual(query.count("users", f, v), q2.count("users", f, v), tag + " count " + f + "=" + v);
+    }
+    assert.deepStrictEqual(paths(query.range("users", "age", 0, 10)), paths(q2.range("users", "age", 0, 10)), tag + " range age");
+    assert.deepStrictEqual(paths(query.range("users", "score", 100, 900)), paths(q2.range("users", "score", 100, 900)), tag + " range score");
+    if (query.indices["users:age"].kind === "device" && query.indices["users:score"].kind === "device") {
+      const t = [{ field: "age", min: 5, max: 20 }, { field: "score", min: 0, max: 600 }];
+      assert.deepStrictEqual(paths(query.filterWhere("users", t)), paths(q2.filterWhere("users", t)), tag + " filterWhere");
+    }
+    q2.close();
+    checks += 12;
+  };
+  sameAsFresh("fresh");
+  const s0 = Object.assign({}, query.stats), d0 = crt.graph.indexRefreshCounts();
+  b.setData("users/u5", { age: 39, score: 15, name: "n5" });                    // an existing child changes both indexed fields
+  b.setData("users/u9/age", 7);                                                 // a leaf write below a child
+  b.setData("users/zed", { age: 7, score: 15 });                                // new children, in creation order
+  b.setData("users/yan", { age: 39, score: 450 });
+  sameAsFresh("patched once");
+  b.setData("users/zed/score", 451); b.setData("users/u5/age", 1000);
+  crt.mergeEntries([{ path: "users/u1", data: { age: 39 }, vectorClock: { w: 999999 } }, { path: "users/batchnew", data: { age: 7, score: 200 }, vectorClock: { w: 5 } }], { apply: true });
+  sameAsFresh("patched twice, one of them through a batch");
+  assert.strictEqual(query.stats.builds, s0.builds, "patched indexes were rebuilt from the store");
+  assert.ok(query.stats.patches >= s0.patches + 4);
+  const d1 = crt.graph.indexRefreshCounts();
+  assert.strictEqual(d1.fullBuilds, d0.fullBuilds, "the device rebuilt a maintained index");
+  assert.ok(d1.incremental > d0.incremental);
+  // where only a rebuild gives the reference's state
+  b.setData("users/123", { age: 7, score: 1 });                                 // integer-like key: enumerated first by a fresh scan
+  sameAsFresh("integer-like key");
+  b.setData("users/u3", null);                                                  // a child disappears
+  sameAsFresh("deleted child");
+  b.setData("users/nofield", { name: "x" }); sameAsFresh("child without the field");
+  b.setData("users/nofield/age", 7); b.setData("users/later", { age: 7, score: 2 });
+  sameAsFresh("existing child gains the field");
+  b.setData("users/u7/age", "old");                                             // leaves the integer domain: the index becomes a host index
+  sameAsFresh("non-integer value");
+  assert.ok(query.stats.builds > s0.builds);
+  b.close();
+  checks += 6;
+}
+
 /* N4: K-writer vector clocks. (a) the reference's golden vectors through the addon's vc* entry points */
 for (const name of ["g6_vc_unique_2k.json", "g6_vc_dups_500.json", "g6_vc_empty_start.json"]) {
   const g = load(name);

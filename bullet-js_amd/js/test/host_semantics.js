@@ -206,4 +206,34 @@ if (fs.existsSync(path.join(REF, "src", "bullet.js"))) {
   console.log("reference facade present: replayed through the real Bullet with GpuCRT/GpuQuery plugged in");
 }
 
+/* N2 and the wrappers around setData: with put middleware registered nothing is batched (every entry takes setData, one by one);
+ * without it the device-eligible run goes to mergeEntries, and the query engine's index hook is told about every batched entry */
+{
+  const { installBatchSync } = require("../batch-sync");
+  const GpuCRTc = require("../gpu-crt");
+  const seen = [];
+  const fake = { id: "w", meta: {}, store: {}, setData(p, d) { seen.push(p); }, _getData() { return {}; }, middleware: { middleware: { put: [], afterPut: [] }, eventListeners: {} } };
+  let merged = 0;
+  const crtStub = { mergeEntries(run) { merged += run.length; return { host: [], nApplied: 0 }; } };
+  const sync = installBatchSync(fake, crtStub, {});
+  const entries = [0, 1, 2].map((i) => ({ path: "m/k" + i, data: { v: i }, vectorClock: { w: 10 + i } }));
+  sync.processSyncEntries(entries);
+  assert.strictEqual(merged, 3); assert.strictEqual(seen.length, 0);
+  fake.middleware.middleware.put.push((p, d) => d);
+  sync.processSyncEntries(entries);
+  assert.strictEqual(merged, 3); assert.deepStrictEqual(seen, ["m/k0", "m/k1", "m/k2"]);
+  fake.middleware.middleware.put.length = 0; fake.middleware.eventListeners.write = [() => {}];
+  sync.processSyncEntries(entries);
+  assert.strictEqual(merged, 3); assert.strictEqual(seen.length, 6);
+  // the index hook of a batch that never passes through setData
+  const touched = [], updated = [];
+  const c1 = new GpuCRTc({ id: "w", meta: {}, query: { indexedPaths: new Set(["m"]), _touch(p) { touched.push(p); } } });
+  c1._notifyIndexHook(entries, [1]);
+  assert.deepStrictEqual(touched, ["m/k0", "m/k2"]);
+  const c2 = new GpuCRTc({ id: "w", meta: {}, query: { indexedPaths: new Set(["m"]), _updateIndices(p, d) { updated.push([p, d.v]); } } });
+  c2._notifyIndexHook(entries, []);
+  assert.deepStrictEqual(updated, [["m/k0", 0], ["m/k1", 1], ["m/k2", 2]]);
+  checks += 8;
+}
+
 console.log("host_semantics ok:", checks, "checks");
