@@ -178,13 +178,44 @@ class GpuCRT {
         ? broadcastData.concat([{ __vectorClock: d.vectorClock }])
         : Object.assign({}, broadcastData, { __vectorClock: d.vectorClock });
     }
+    const doUpdate = d.incoming || !currentClock || d.concurrent;
+    if (doUpdate) this._queueDeviceWrite(path, d.value, d.vectorClock);
     return {
       value: d.value,
       vectorClock: d.vectorClock,
       broadcastData,
       decision: d,
-      doUpdate: d.incoming || !currentClock || d.concurrent,
+      doUpdate,
     };
+  }
+
+  /*
+   * Write-through of single writes: once the device holds rows, a leaf that is written through setData (a local put, or a remote write that
+   * took the host path) has to reach its row too, or the next batch would be resolved against a state the host has already left behind.
+   * Only what the device can hold: the leaf `<node>/<field>` with a safe-integer value and the scalar clock {writer: ts}. Queued here, sent
+   * as one LWW load in front of the next device operation (no device call per put).
+   */
+  _queueDeviceWrite(path, value, clock) {
+    if (!this._graph || this._opts.writers) return;           // no device table in use (or the K-writer table: its rows are not scalar-clock rows)
+    if (!isDeviceInt(value)) return;
+    const ts = scalarClock(clock, this._opts.writer || this.bullet.id);
+    if (ts < 0) return;
+    const cut = path.lastIndexOf("/");
+    if (cut <= 0) return;
+    (this._pendingRows || (this._pendingRows = [])).push(path.slice(0, cut), path.slice(cut + 1), ts, value);
+  }
+
+  _flushDeviceWrites() {
+    const q = this._pendingRows;
+    if (!q || q.length === 0) return;
+    this._pendingRows = null;
+    const g = this.graph, keys = g.keys, n = q.length / 4;
+    const cols = new Columns(n);
+    for (let i = 0; i < n; i++) {
+      const node = q[4 * i], c = node.lastIndexOf("/");
+      cols.set(i, keys.idOf(node), keys.fieldOf(c < 0 ? "" : node.slice(0, c), q[4 * i + 1]), q[4 * i + 2], q[4 * i + 3]);
+    }
+    g.loadRows(cols);
   }
 
   formatClock(clock) {
@@ -210,6 +241,7 @@ class GpuCRT {
    * -> {applied: Uint32Array (ascending delta indices whose value is now stored), flags, nApplied, nConflicts, nRows}
    */
   mergeBatch(cols, opts = {}) {
+    this._flushDeviceWrites();
     const g = this.graph;
     let mode = opts.insertMode === "delta" ? g.native.INSERT_DELTA : g.native.INSERT_REFERENCE;
     if (opts.uniqueKeys) mode |= g.native.MERGE_UNIQUE_KEYS;
@@ -220,6 +252,7 @@ class GpuCRT {
   /** Same as mergeBatch but off the event loop: resolves to the same result object (the reference API is synchronous;
    *  this is the Promise variant SURVEY §8(b) calls for). The columns must not be mutated until it settles. */
   mergeBatchAsync(cols, opts = {}) {
+    this._flushDeviceWrites();
     const g = this.graph;
     let mode = opts.insertMode === "delta" ? g.native.INSERT_DELTA : g.native.INSERT_REFERENCE;
     if (opts.uniqueKeys) mode |= g.native.MERGE_UNIQUE_KEYS;
@@ -452,6 +485,7 @@ class GpuCRT {
    * inverse. The shape matches what the reference persists per path (value + vectorClock: src/bullet-file-storage.js:170-210).
    */
   checkpoint() {
+    this._flushDeviceWrites();
     const g = this.graph;
     const d = g.dumpRows();
     const id32 = new Uint32Array(d.id.buffer, d.id.byteOffset, d.id.length * 2);

@@ -207,6 +207,8 @@ class GpuQuery {
     const key = GpuQuery.keyOf(path, field);
     if (!this.indices[key]) this.index(path, field);
     const ix = this.indices[key];
+    const crt = this.bullet.crt;
+    if (crt && typeof crt._flushDeviceWrites === "function") crt._flushDeviceWrites();   // single writes queued for the device (GpuCRT write-through)
     if (ix.stale === "partial" && this._applyDirty(ix)) return ix;
     if (ix.stale) this._build(ix);
     return ix;

@@ -95,6 +95,7 @@ class GpuStorage {
   /* device rows that the JS store does not reflect yet -> store/meta leaves */
   foldDevice(graph) {
     const b = this.bullet, writer = (b.crt && b.crt._opts && b.crt._opts.writer) || b.id;
+    if (b.crt && typeof b.crt._flushDeviceWrites === "function") b.crt._flushDeviceWrites();   // single writes still queued for the device
     const d = graph.dumpRows();
     const id32 = new Uint32Array(d.id.buffer, d.id.byteOffset, d.id.length * 2);
     let folded = 0;

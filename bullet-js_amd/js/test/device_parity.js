@@ -313,6 +313,29 @@ for (const shards of [2, 4, 8]) {
   checks += 7;
 }
 
+/* write-through: a leaf written through setData reaches its device row before the next batch is resolved */
+{
+  const b = new MiniBullet("w");
+  const { crt } = attach(b, { capacityRows: 4096 });
+  crt.mergeEntries([{ path: "wt/k1", data: { age: 10, hits: 1 }, vectorClock: { w: 4 } }], { apply: true });
+  assert.deepStrictEqual(b.meta["wt/k1/age"].vectorClock, { w: 2 });              // first write of an absent key: clock 2 (src/bullet-crt.js:172-185)
+  b.setData("wt/k1/age", 50);                                                     // local put: the host clock of the leaf goes to 3
+  assert.deepStrictEqual(b.meta["wt/k1/age"].vectorClock, { w: 3 });
+  let r = crt.mergeEntries([{ path: "wt/k1", data: { age: 40 }, vectorClock: { w: 3 } }], { apply: true });
+  assert.strictEqual(r.nApplied, 0);                                              // (3, 40) loses the tie against (3, 50); the stale row (2, 10) would have lost
+  assert.strictEqual(b.store.wt.k1.age, 50);
+  r = crt.mergeEntries([{ path: "wt/k1", data: { age: 45 }, vectorClock: { w: 4 } }], { apply: true });
+  assert.strictEqual(r.nApplied, 1);
+  assert.strictEqual(b.store.wt.k1.age, 45);
+  b.setData("wt/k2/age", 7);                                                      // a leaf the device has never seen
+  r = crt.mergeEntries([{ path: "wt/k2", data: { age: 9 }, vectorClock: { w: 1 } }], { apply: true });
+  assert.strictEqual(r.nApplied, 0);                                              // not a first write any more: (1, 9) is older than the local put
+  const row = crt.checkpoint().find((x) => x.path === "wt/k2" && x.field === "age");
+  assert.strictEqual(row.val, 7);
+  b.close();
+  checks += 9;
+}
+
 /* Q4: writes under an indexed path patch the index (dirty children -> device rows -> the device's change log) and every query equals what a
  * FRESH GpuQuery builds from the same store; the cases where only a rebuild is safe fall back to it and still agree */
 {
