@@ -163,3 +163,49 @@ def test_index_created_while_another_is_being_maintained():
     e.merge_batch(*d); o.merge_batch(*d, INSERT_REFERENCE)
     _check_scans(e, o, rng, 50, "after drop")
     e.close(); o.close()
+
+
+N_FUZZ = int(__import__("os").environ.get("BMX_FUZZ_SEEDS", "6"))
+
+
+@pytest.mark.parametrize("seed", range(N_FUZZ))
+def test_random_sequences_of_merges_index_changes_and_scans(seed):
+    """Whatever mixes of merges (all modes), index builds/drops, table growth and scans: every scan equals the oracle's."""
+    rng = np.random.default_rng(9000 + seed)
+    nodes = int(rng.choice([200, 5000, 40000]))
+    span = int(rng.choice([5, 1000]))
+    fixed = bool(rng.integers(0, 2))
+    e = bmx.Engine(capacity_rows=(8 * nodes + 600_000) if fixed else max(64, nodes // 2), flags=bmx.CTX_FIXED_CAPACITY if fixed else 0); o = Oracle()
+    ids = _ids(np.arange(nodes))
+    for f in (FA, FB):
+        v = rng.integers(-span, span + 1, nodes).astype(np.int64)
+        e.load_rows(ids, np.full(nodes, f, np.uint32), np.full(nodes, 5, np.int64), v); o.load_rows(ids, np.full(nodes, f, np.uint32), np.full(nodes, 5, np.int64), v)
+    new_from = nodes
+    have = set()
+    for step in range(40):
+        op = rng.choice(["merge", "merge", "merge", "delta", "strict", "unique", "scan", "scan", "build", "drop", "reserve"])
+        if op in ("merge", "delta", "strict"):
+            n = int(rng.choice([1, 64, 700, 9000]))
+            d = _batch(rng, n, nodes, new_from, span, 10 + step); new_from += n
+            mode = INSERT_DELTA if op == "delta" else INSERT_REFERENCE
+            flags = bmx.MERGE_STRICT_FLAGS if op == "strict" else 0
+            applied, _, _ = e.merge_batch(*d, insert_mode=mode | flags, want_flags=bool(flags))
+            _, ow = o.merge_batch(*d, mode)
+            assert np.array_equal(applied, ow), (seed, step, op)
+        elif op == "unique":
+            n = int(rng.choice([1, 300, 5000]))
+            rows = rng.permutation(nodes)[:min(n, nodes)]
+            d = (_ids(rows), np.full(len(rows), FA, np.uint32), rng.integers(1, 60, len(rows)).astype(np.int64), rng.integers(-span, span + 1, len(rows)).astype(np.int64))
+            applied, _, _ = e.merge_batch(*d, insert_mode=INSERT_REFERENCE | bmx.MERGE_UNIQUE_KEYS)
+            _, ow = o.merge_batch(*d, INSERT_REFERENCE)
+            assert np.array_equal(applied, ow), (seed, step, op)
+        elif op == "build":
+            f = [FA, FB][int(rng.integers(0, 2))]; e.index_build(f); have.add(f)
+        elif op == "drop" and have:
+            f = sorted(have)[int(rng.integers(0, len(have)))]; e.index_drop(f); have.discard(f)
+        elif op == "reserve" and not fixed:
+            e.reserve(int(e.row_count() * 1.5) + 1000)
+        else:
+            _check_scans(e, o, rng, span, (seed, step)); have.update((FA, FB))
+    _check_scans(e, o, rng, span, (seed, "end"))
+    e.close(); o.close()
