@@ -374,6 +374,8 @@ def main():
         sg.setup_pipeline(D_PER_STEP, partition_on=os.environ.get("BMX_BENCH_PARTITION", "merge"), slack=1.25 if CONFIG == 5 else 1.03)
         torch.cuda.synchronize()
 
+        step_events = [] if os.environ.get("BMX_BENCH_STEPTIMES") else None   # debugging aid: when each step's merge finished (stderr)
+
         def run(lo, hi):
             # exactly (hi-lo) routes and (hi-lo) merges. route(b+1) is enqueued before merge(b): its partition runs on the merge
             # stream ahead of merge(b), its all-to-all on the communication stream underneath merge(b)
@@ -381,6 +383,8 @@ def main():
             for b in range(lo, hi):
                 nxt = sg.route(D_PER_STEP, *batches[b + 1]) if b + 1 < hi else None
                 sg.merge(tk)
+                if step_events is not None:
+                    ev = torch.cuda.Event(enable_timing=True); ev.record(sg.ops.main); step_events.append(ev)
                 tk = nxt
 
         if W:
@@ -409,6 +413,10 @@ def main():
         t_enq = time.perf_counter() - t0
         sg.ops.sync(); torch.cuda.synchronize(); dist.barrier()
         wall = time.perf_counter() - t0
+        if step_events:
+            te = step_events[-K:]
+            print("step end-to-end gaps (us): " + " ".join("%.0f" % (te[i].elapsed_time(te[i + 1]) * 1e3) for i in range(len(te) - 1)) +
+                  " | first timed step ends %.0f us after the last warm-up step" % (step_events[-K - 1].elapsed_time(te[0]) * 1e3 if len(step_events) > K else -1), file=sys.stderr)
         if sg.overflowed():
             raise SystemExit("exchange slab overflow: run invalid (raise ShardedGraph.setup_pipeline slack)")
         tmax = torch.tensor([wall], dtype=torch.float64, device=dev)
