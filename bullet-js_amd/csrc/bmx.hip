@@ -7,6 +7,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <deque>
 #include <new>
 #include <string>
 #include <vector>
@@ -98,6 +99,11 @@ struct bmx_ctx {
   uint32_t epoch = 0;
   uint64_t version = 0;
   uint64_t rows_ub = 0;               // host-side upper bound of resident rows
+  // {rows, sequence number of the batch that produced them}, written by every merge's last workgroup into mapped host memory: the capacity
+  // guard tightens rows_ub from it (rows seen + deltas of the batches enqueued since) instead of synchronising the stream every few batches
+  unsigned long long* host_rows = nullptr;
+  uint64_t batch_seq = 0;
+  std::deque<std::pair<uint64_t, uint64_t>> inflight;   // (sequence number, deltas) of batches whose row count the host has not seen yet
   std::vector<Index> indexes;
   // incremental index maintenance (scan_kernels.h): slot -> position in its field's index, and the log of the winners' slots since the
   // indices were last brought up to date. chg_valid: the log is complete (every merge since then was logged and nothing moved the slots).
@@ -181,7 +187,20 @@ int refresh_rows(bmx_ctx* ctx) {
   HIPCHK(hipMemcpyAsync(&r, &ctx->ds->row_count, sizeof(r), hipMemcpyDeviceToHost, ctx->stream));
   HIPCHK(hipStreamSynchronize(ctx->stream));
   ctx->rows_ub = r;
+  ctx->inflight.clear();
   return BMX_OK;
+}
+
+// rows_ub from the mirror the merges write, no sync: rows the host has seen + every delta of the batches enqueued after that one
+void tighten_rows_ub(bmx_ctx* ctx) {
+  if (!ctx->host_rows) return;
+  const uint64_t seen_seq = __atomic_load_n(ctx->host_rows + 1, __ATOMIC_ACQUIRE);
+  const uint64_t seen_rows = __atomic_load_n(ctx->host_rows, __ATOMIC_RELAXED);   // this count, or a later one: still an upper bound with the sum below
+  if (seen_seq == 0) return;
+  while (!ctx->inflight.empty() && ctx->inflight.front().first <= seen_seq) ctx->inflight.pop_front();
+  uint64_t pending = 0;
+  for (const auto& b : ctx->inflight) pending += b.second;
+  ctx->rows_ub = std::min<uint64_t>(ctx->rows_ub, seen_rows + pending);
 }
 
 int ensure_workspace(bmx_ctx* ctx, uint64_t n) {
@@ -307,6 +326,7 @@ int merge_core(bmx_ctx* ctx, uint64_t n, const uint64_t* id, const uint32_t* fie
   }
   // capacity guards: physical (never let probing run out of empty slots) and logical (capacity_rows)
   int rc;
+  if (ctx->rows_ub + n >= ctx->nslots || ctx->rows_ub > ctx->capacity_rows) tighten_rows_ub(ctx);
   if (ctx->rows_ub + n >= ctx->nslots || ctx->rows_ub > ctx->capacity_rows) {
     rc = refresh_rows(ctx);
     if (rc) return rc;
@@ -388,6 +408,7 @@ int merge_core(bmx_ctx* ctx, uint64_t n, const uint64_t* id, const uint32_t* fie
   // K3: ordered compaction of the winner bytes (+ the index change log while an index is being maintained)
   hipStream_t ks = ctx->stream;
   FinishMerge Fin{reinterpret_cast<unsigned long long*>(n_applied), stats, ctr, &ctx->ds->row_count};
+  if (ctx->host_rows) { Fin.host_mirror = ctx->host_rows; Fin.seq = ++ctx->batch_seq; ctx->inflight.emplace_back(Fin.seq, n); }
   ChgLog L{};
   if (ctx->chg_valid) {
     if (legacy && !strict && !unique && ctx->chg_ub + n <= ctx->chg_cap && ctx->nslots < (1ull << 31)) {
@@ -783,6 +804,10 @@ int bmx_create_ex(int device, uint64_t capacity_rows, uint32_t max_load_pct, uin
   if ((rc = dev_alloc(ctx, &ctx->part_counts, PART_MAX_SHARDS * PART_BLOCKS))) return bail(rc);
   if ((rc = dev_alloc(ctx, &ctx->shard_ctr, CTR_SHARDS * CTR_STRIDE))) return bail(rc);
   CR(hipMemsetAsync(ctx->shard_ctr, 0, CTR_SHARDS * CTR_STRIDE * sizeof(unsigned long long), ctx->stream));
+  // the row-count mirror is an optimisation: without mapped host memory the capacity guard simply synchronises as before
+  if (hipHostMalloc(reinterpret_cast<void**>(&ctx->host_rows), 2 * sizeof(unsigned long long), hipHostMallocMapped) == hipSuccess) {
+    ctx->host_rows[0] = 0; ctx->host_rows[1] = 0;
+  } else { ctx->host_rows = nullptr; (void)hipGetLastError(); }
   ctx->fixed_capacity = (flags & BMX_CTX_FIXED_CAPACITY) != 0;
   ctx->bucketed_default = (flags & BMX_CTX_BUCKETED_MERGE) != 0;
   CR(hipMemsetAsync(ctx->ds, 0, sizeof(DevScalars), ctx->stream));
@@ -812,6 +837,7 @@ void bmx_destroy(bmx_ctx* ctx) {
   if (ctx->down_stream) { (void)hipStreamSynchronize(ctx->down_stream); (void)hipStreamDestroy(ctx->down_stream); }
   dev_free(ctx->bin_stage); dev_free(ctx->bin_toff);
   dev_free(ctx->slot_pos); dev_free(ctx->chg);
+  if (ctx->host_rows) { (void)hipHostFree(ctx->host_rows); ctx->host_rows = nullptr; }
   dev_free(ctx->scan_out); dev_free(ctx->block_counts); dev_free(ctx->part_counts); dev_free(ctx->part_owner); dev_free(ctx->scan_mask); dev_free(ctx->scan_counts);
   for (auto ev : ctx->prof_ev) (void)hipEventDestroy(ev);
   for (auto ev : ctx->scan_ev) (void)hipEventDestroy(ev);

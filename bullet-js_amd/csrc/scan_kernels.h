@@ -234,6 +234,8 @@ struct EmitApplied {
 struct FinishMerge {  // totals -> caller; fold and clear the sharded per-batch counters
   unsigned long long* n_applied; bmx_merge_stats* stats;
   unsigned long long* shard_ctr; unsigned long long* row_count;
+  // optional: {rows, batch sequence number} in host memory the GPU can write (the host bounds the row count from it without a sync)
+  unsigned long long* host_mirror = nullptr; unsigned long long seq = 0;
   __device__ void operator()(uint64_t total, uint32_t* lds4) const {
     static_assert(CTR_SHARDS == SEL_THREADS, "one counter shard per thread");
     unsigned long long* c = shard_ctr + (size_t)threadIdx.x * CTR_STRIDE;
@@ -245,6 +247,10 @@ struct FinishMerge {  // totals -> caller; fold and clear the sharded per-batch 
     if (threadIdx.x == 0) {
       unsigned long long r = *row_count + trows;
       *row_count = r;
+      if (host_mirror) {   // rows first, then the sequence number: a host that reads the number first never pairs it with an OLDER count
+        __hip_atomic_store(host_mirror, r, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        __hip_atomic_store(host_mirror + 1, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+      }
       if (n_applied) *n_applied = total;
       if (stats) { stats->n_applied = total; stats->n_conflicts = tconf; stats->n_rows = r; stats->reserved = 0; }
     }
