@@ -297,20 +297,21 @@ class GpuCRT {
       let ok = true;
       if (isDeviceInt(d)) {
         if (i + 1 > cap) ({ cols, rowEntry, rowField, cap } = growColumns(cols, rowEntry, rowField, i, cap * 2));
-        cols.set(i, keys.idOf(e.path), keys.fieldOf(parentOf(e.path, e.path.lastIndexOf("/")), null), ts, d);
+        keys.lookup(e.path);
+        cols.set2(i, keys.lo, keys.hi, keys.fieldOf(parentOf(e.path, e.path.lastIndexOf("/")), null), ts, d);
         rowEntry[i] = ei; rowField[i] = -1; i++;
       } else if (d && typeof d === "object" && !Array.isArray(d)) {
         const parent = parentOf(e.path, e.path.lastIndexOf("/"));
-        let id = null;
+        let idLo = 0, idHi = 0, haveId = false;
         for (const k in d) {
           if (k === "__vectorClock" || k === "__fromNetwork" || !Object.prototype.hasOwnProperty.call(d, k)) continue;
           const v = d[k];
           if (!isDeviceInt(v)) { ok = false; break; }
-          if (id === null) id = keys.idOf(e.path);
+          if (!haveId) { keys.lookup(e.path); idLo = keys.lo; idHi = keys.hi; haveId = true; }
           if (i + 1 > cap) ({ cols, rowEntry, rowField, cap } = growColumns(cols, rowEntry, rowField, i, cap * 2));
           let fi = fieldIndex.get(k);
           if (fi === undefined) { fi = fieldNames.length; fieldNames.push(k); fieldIndex.set(k, fi); }
-          cols.set(i, id, keys.fieldOf(parent, k), ts, v);
+          cols.set2(i, idLo, idHi, keys.fieldOf(parent, k), ts, v);
           rowEntry[i] = ei; rowField[i] = fi; i++;
         }
         if (ok && i === first) ok = false;                   // an object without fields: nothing for the device
