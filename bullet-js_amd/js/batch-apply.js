@@ -18,7 +18,7 @@
  */
 const LOG_CAP = 1000;   // src/bullet.js:213-215
 
-function applyBatch(bullet, updates, fromNetwork) {
+function applyBatch(bullet, updates, fromNetwork, wantBroadcast = true) {
   const n = updates.length;
   if (n === 0) return [];
   const now = Date.now();
@@ -26,7 +26,7 @@ function applyBatch(bullet, updates, fromNetwork) {
   const listeners = bullet.listeners || {};
   const hasListeners = Object.keys(listeners).length > 0;
   const parentsToNotify = hasListeners ? new Set() : null;
-  const broadcast = new Array(n);
+  const broadcast = wantBroadcast ? new Array(n) : null;   // remote writes are not re-broadcast (setData(path, data, false)): their caller skips it
   // parent object cache: consecutive winners of one node (its fields) share the walk
   let lastParentPath = null, lastParentNode = null;
   const entries = bullet.log && n < LOG_CAP ? null : [];
@@ -46,19 +46,20 @@ function applyBatch(bullet, updates, fromNetwork) {
     if (!key) continue;
     node[key] = u.value;
     const old = bullet.meta[path];
-    // {...old, source, vectorClock, lastModified}: the reference's entries carry exactly these three keys, so a fresh literal is the
-    // spread's result unless somebody hung more on the entry
-    let m;
-    if (old === undefined || (old.source !== undefined && old.vectorClock !== undefined && old.lastModified !== undefined && Object.keys(old).length === 3)) m = { source, vectorClock: u.vectorClock, lastModified: now };
-    else { m = Object.assign({}, old); m.source = source; m.vectorClock = u.vectorClock; m.lastModified = now; }
-    bullet.meta[path] = m;
-    const rec = { op: "set", path, data: u.value, vectorClock: u.vectorClock, timestamp: now };
-    if (bullet.log) {
-      if (entries) { if (i >= n - LOG_CAP) entries.push(rec); } else bullet.log.push(rec);
+    // {...old, source, vectorClock, lastModified} (src/bullet.js:196-201): the entry keeps whatever else somebody hung on it and gets these
+    // three keys. An existing entry is updated in place: same content as the spread's copy, without re-inserting a key into a meta object of
+    // millions of entries (2 us per write in V8's dictionary mode against 0.5 us; the entry OBJECT is then the same one as before the write)
+    if (old === undefined) bullet.meta[path] = { source, vectorClock: u.vectorClock, lastModified: now };
+    else { old.source = source; old.vectorClock = u.vectorClock; old.lastModified = now; }
+    if (bullet.log && (!entries || i >= n - LOG_CAP)) {   // only the records that stay in the log are built
+      const rec = { op: "set", path, data: u.value, vectorClock: u.vectorClock, timestamp: now };
+      if (entries) entries.push(rec); else bullet.log.push(rec);
     }
-    let b = u.value;
-    if (typeof b === "object" && b !== null) b = Array.isArray(b) ? b.concat([{ __vectorClock: u.vectorClock }]) : Object.assign({}, b, { __vectorClock: u.vectorClock });
-    broadcast[i] = { path, broadcastData: b };
+    if (broadcast) {
+      let b = u.value;
+      if (typeof b === "object" && b !== null) b = Array.isArray(b) ? b.concat([{ __vectorClock: u.vectorClock }]) : Object.assign({}, b, { __vectorClock: u.vectorClock });
+      broadcast[i] = { path, broadcastData: b };
+    }
     if (hasListeners) {
       const ls = listeners[path];
       if (ls) for (const cb of ls) { try { cb(u.value); } catch (err) { console.error(`Error in listener callback for ${path}:`, err); } }
@@ -90,7 +91,7 @@ function applyBatch(bullet, updates, fromNetwork) {
     clearTimeout(bullet._saveTimeout);
     bullet._saveTimeout = setTimeout(() => { bullet.storage.save(); }, 1000);
   }
-  return broadcast;
+  return broadcast || [];
 }
 
 module.exports = { applyBatch, LOG_CAP };

@@ -322,7 +322,7 @@ class GpuCRT {
     const r = this.mergeBatch(used, opts);
     const applied = new Array(r.applied.length);
     for (let k = 0; k < applied.length; k++) { const j = r.applied[k]; applied[k] = { entry: rowEntry[j], field: rowField[j] < 0 ? null : fieldNames[rowField[j]] }; }
-    const broadcast = opts.apply ? this._applyWinners(entries, used, r.applied, applied, opts.apply) : undefined;
+    const broadcast = opts.apply ? this._applyWinners(entries, used, r.applied, applied, opts.apply, opts.broadcast !== false) : undefined;
     if (opts.apply) this._notifyIndexHook(entries, host);
     return { applied, nApplied: r.nApplied, nConflicts: r.nConflicts, nRows: r.nRows, host, broadcast };
   }
@@ -354,7 +354,7 @@ class GpuCRT {
    * opts.apply === "each": the facade's per-write `_applyUpdate` is called once per winner (src/bullet.js:184-266), the
    * reference's own cost per write. Returns what setData would have broadcast per winner (src/bullet-crt.js:371-376).
    */
-  _applyWinners(entries, cols, appliedIdx, applied, mode) {
+  _applyWinners(entries, cols, appliedIdx, applied, mode, wantBroadcast = true) {
     const n = appliedIdx.length;
     if (n === 0) return [];
     const ids = new BigUint64Array(n), id32 = new Uint32Array(ids.buffer), fields = new Uint32Array(n);
@@ -377,10 +377,10 @@ class GpuCRT {
     const b = this.bullet;
     if (mode === "each") {
       if (typeof b._applyUpdate === "function") for (const u of updates) b._applyUpdate(u.path, u.value, u.vectorClock, true);
-      return updates.map((u) => ({ path: u.path, broadcastData: u.value }));
+      return wantBroadcast ? updates.map((u) => ({ path: u.path, broadcastData: u.value })) : [];
     }
     if (typeof b._applyBatch === "function") return b._applyBatch(updates, true) || [];
-    return require("./batch-apply").applyBatch(b, updates, true);
+    return require("./batch-apply").applyBatch(b, updates, true, wantBroadcast);
   }
 
   /* ---------------------------------------------------------------- N4: K-writer vector clocks on the device */
