@@ -79,6 +79,9 @@ struct bmx_ctx {
     hipEvent_t up = nullptr, done = nullptr;                                  // inputs uploaded / kernels of the batch finished
     uint64_t n = 0; bool want_flags = false; bool busy = false; uint64_t ticket = 0;
   } stg[2];
+  // small host batches (<= SMALL_HOST_N deltas): inputs are packed into mapped host memory the kernels read directly, results are written
+  // straight into mapped host memory: three launches and one stream synchronisation per call, no copies, no second stream
+  uint8_t* pin_in = nullptr; uint8_t* pin_out = nullptr;
   hipStream_t copy_stream = nullptr;   // uploads
   hipStream_t down_stream = nullptr;   // downloads (PCIe is full duplex: results of batch b come back while batch b+1 goes up)
   uint64_t next_ticket = 1;
@@ -482,10 +485,63 @@ int collect_host(bmx_ctx* ctx, uint64_t ticket, uint32_t* applied_idx, uint64_t*
   return BMX_OK;
 }
 
+// Small host batch (the reference's sync chunks hold 50 entries, src/bullet-network-sync.js:18): the general path costs ~115 us per call whatever
+// the size (four pageable uploads, two extra streams, three downloads); here the columns are packed into mapped host memory that the kernels read
+// over PCIe, and winners, count, stats and the device status come back through mapped host memory as well.
+constexpr uint64_t SMALL_HOST_N = 32768;
+constexpr int SMALL_PATH_UNAVAILABLE = 1;
+struct SmallOut { unsigned long long n_applied; bmx_merge_stats stats; uint32_t status; uint32_t pad; };
+constexpr size_t SMALL_IN_BYTES = SMALL_HOST_N * 28, SMALL_OUT_APPLIED = 0, SMALL_OUT_FLAGS = SMALL_HOST_N * 4, SMALL_OUT_TAIL = SMALL_HOST_N * 5,
+                 SMALL_OUT_BYTES = SMALL_OUT_TAIL + sizeof(SmallOut);
+__global__ void k_small_tail(const unsigned long long* n_applied, const bmx_merge_stats* stats, const uint32_t* status, SmallOut* out) {
+  if (threadIdx.x == 0) { out->n_applied = *n_applied; out->stats = *stats; out->status = *status; }
+}
+int merge_host_small(bmx_ctx* ctx, uint64_t n, const uint64_t* id, const uint32_t* field, const int64_t* ts, const int64_t* val,
+                     int insert_mode, uint32_t* applied_idx, uint64_t* n_applied, uint8_t* flags, bmx_merge_stats* stats) {
+  if (!ctx->pin_in) {
+    if (hipHostMalloc(reinterpret_cast<void**>(&ctx->pin_in), SMALL_IN_BYTES, hipHostMallocMapped) != hipSuccess ||
+        hipHostMalloc(reinterpret_cast<void**>(&ctx->pin_out), SMALL_OUT_BYTES, hipHostMallocMapped) != hipSuccess) {
+      (void)hipGetLastError();
+      if (ctx->pin_in) { (void)hipHostFree(ctx->pin_in); ctx->pin_in = nullptr; }
+      ctx->pin_out = nullptr;
+      return SMALL_PATH_UNAVAILABLE;
+    }
+  }
+  // the previous small batch's kernels are done (every call ends with a synchronisation): the buffers are free
+  uint64_t* p_id = reinterpret_cast<uint64_t*>(ctx->pin_in);
+  int64_t* p_ts = reinterpret_cast<int64_t*>(ctx->pin_in + n * 8);
+  int64_t* p_val = reinterpret_cast<int64_t*>(ctx->pin_in + n * 16);
+  uint32_t* p_field = reinterpret_cast<uint32_t*>(ctx->pin_in + n * 24);
+  std::memcpy(p_id, id, n * 8); std::memcpy(p_ts, ts, n * 8); std::memcpy(p_val, val, n * 8); std::memcpy(p_field, field, n * 4);
+  uint32_t* o_applied = reinterpret_cast<uint32_t*>(ctx->pin_out + SMALL_OUT_APPLIED);
+  uint8_t* o_flags = ctx->pin_out + SMALL_OUT_FLAGS;
+  SmallOut* o_tail = reinterpret_cast<SmallOut*>(ctx->pin_out + SMALL_OUT_TAIL);
+  // count and stats go through device scalars first (the merge's last workgroup read-modify-writes them), then one thread copies them out
+  int rc = merge_core<false>(ctx, n, p_id, p_field, p_ts, p_val, nullptr, insert_mode, applied_idx ? o_applied : nullptr, reinterpret_cast<uint64_t*>(&ctx->ds->n_out),
+                             flags ? o_flags : nullptr, &ctx->ds->stats);
+  if (rc) return rc;
+  hipLaunchKernelGGL(k_small_tail, dim3(1), dim3(64), 0, ctx->stream, (const unsigned long long*)&ctx->ds->n_out, (const bmx_merge_stats*)&ctx->ds->stats,
+                     (const uint32_t*)&ctx->ds->status, o_tail);
+  LAUNCHCHK("k_small_tail");
+  HIPCHK(hipStreamSynchronize(ctx->stream));
+  if (o_tail->status) return check_status(ctx);
+  const bmx_merge_stats hs = o_tail->stats;
+  if (applied_idx && hs.n_applied) std::memcpy(applied_idx, o_applied, hs.n_applied * 4);
+  if (flags) std::memcpy(flags, o_flags, n);
+  ctx->rows_ub = hs.n_rows; ctx->inflight.clear();
+  if (n_applied) *n_applied = hs.n_applied;
+  if (stats) *stats = hs;
+  return BMX_OK;
+}
+
 int merge_host(bmx_ctx* ctx, uint64_t n, const uint64_t* id, const uint32_t* field, const int64_t* ts, const int64_t* val,
                int insert_mode, uint32_t* applied_idx, uint64_t* n_applied, uint8_t* flags, bmx_merge_stats* stats) {
   for (int i = 0; i < 2; i++)
     if (ctx->stg[i].busy) return fail(ctx, BMX_ERR_INVALID, "a submitted batch is still in flight: collect it before a synchronous merge");
+  if (n && n <= SMALL_HOST_N) {
+    int src = merge_host_small(ctx, n, id, field, ts, val, insert_mode, applied_idx, n_applied, flags, stats);
+    if (src != SMALL_PATH_UNAVAILABLE) return src;
+  }
   uint64_t ticket = 0;
   int rc = submit_host(ctx, n, id, field, ts, val, insert_mode, flags != nullptr, &ticket);
   if (rc) return rc;
@@ -838,6 +894,8 @@ void bmx_destroy(bmx_ctx* ctx) {
   dev_free(ctx->bin_stage); dev_free(ctx->bin_toff);
   dev_free(ctx->slot_pos); dev_free(ctx->chg);
   if (ctx->host_rows) { (void)hipHostFree(ctx->host_rows); ctx->host_rows = nullptr; }
+  if (ctx->pin_in) { (void)hipHostFree(ctx->pin_in); ctx->pin_in = nullptr; }
+  if (ctx->pin_out) { (void)hipHostFree(ctx->pin_out); ctx->pin_out = nullptr; }
   dev_free(ctx->scan_out); dev_free(ctx->block_counts); dev_free(ctx->part_counts); dev_free(ctx->part_owner); dev_free(ctx->scan_mask); dev_free(ctx->scan_counts);
   for (auto ev : ctx->prof_ev) (void)hipEventDestroy(ev);
   for (auto ev : ctx->scan_ev) (void)hipEventDestroy(ev);
