@@ -119,3 +119,21 @@ def test_shards_grow_and_keep_indexes_fresh():
             got = np.sort(c.scan_range(f0, -(1 << 40), 1 << 40)); want = np.sort(o.scan_range(f0, -(1 << 40), 1 << 40))
             assert np.array_equal(got, want), b
         assert rows_digest(*c.dump_rows()) == o.digest()
+
+
+@pytest.mark.parametrize("N", [1, 3, 8])
+def test_small_host_batches_are_routed_on_the_host(N):
+    """Batches of up to 32768 deltas take the host-routed path (owner per delta on the CPU, each shard's small-batch merge): same winners, in the
+    caller's index space, as one sequential merge — including duplicates of one key inside a batch and keys created by the batch."""
+    rng = np.random.default_rng(50 + N)
+    res = synth.big_resident(20_000, seed=5, F=2)
+    o = Oracle(); o.load_rows(*res)
+    with bmx.Comm([0] * N, capacity_rows_per_shard=200_000) as c:
+        c.load_rows(*res)
+        for b, n in enumerate([1, 2, 50, 777, 5000, 32768, 1]):
+            d = synth.big_deltas(n, 20_000, seed=60 + N, F=2, insert_pct=20, hot_pct=30, hot_keys=7, unique=False, batch=b)
+            applied, st = c.merge(*d)
+            _, ow = o.merge_batch(*d)
+            assert np.array_equal(applied, ow), (N, b, n)
+            assert st.n_rows == len(o) and st.n_applied == len(ow), (N, b, n)
+        assert rows_digest(*c.dump_rows()) == o.digest()
