@@ -92,7 +92,9 @@ typedef struct bmx_delta_rec {
 
 typedef struct bmx_merge_stats {
   uint64_t n_applied;    /* final winners: keys whose stored (ts,val) changed */
-  uint64_t n_conflicts;  /* deltas that met another delta of the same key inside the batch */
+  uint64_t n_conflicts;  /* deltas that claimed a row another delta of the batch had claimed before them. 0 for a batch without duplicate keys; exact for
+                          * rows created by the batch; otherwise a lower bound that can differ from run to run: a duplicate that is already below the
+                          * value it sees drops out uncounted, and which of its predecessors' values it sees is a matter of timing */
   uint64_t n_rows;       /* resident rows after the batch */
   uint64_t reserved;
 } bmx_merge_stats;
