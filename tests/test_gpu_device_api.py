@@ -230,3 +230,34 @@ def test_pipelined_host_batches_submit_collect():
         a2, _, _ = e.merge_batch(*bs[0])                     # the synchronous form still works afterwards
         _, w2 = o.merge_batch(*bs[0])
         assert np.array_equal(a2, w2)
+
+
+@pytest.mark.parametrize("n", [1, 32767, 32768, 32769])
+def test_host_batches_on_both_sides_of_the_small_batch_limit(n):
+    """Host batches of up to 32768 deltas go through mapped host memory, larger ones through the staging copies: same winners, flags, stats,
+    point reads and small scans either way."""
+    from oracle.oracle import Oracle
+    from bmx import synth
+    rng = np.random.default_rng(n)
+    res = synth.big_resident(50_000, seed=9)
+    o = Oracle(); o.load_rows(*res)
+    with bmx.Engine(400_000) as e:
+        e.load_rows(*res)
+        for b in range(3):
+            d = synth.big_deltas(n, 50_000, seed=70, insert_pct=15, hot_pct=20, hot_keys=11, unique=False, batch=b)
+            strict = bmx.MERGE_STRICT_FLAGS if b == 1 else 0
+            applied, flags, st = e.merge_batch(*d, insert_mode=bmx.INSERT_REFERENCE | strict, want_flags=True)
+            of, ow = o.merge_batch(*d)
+            assert np.array_equal(applied, ow), (n, b)
+            if strict:
+                assert np.array_equal(flags, of), (n, b)
+            assert st.n_applied == len(ow) and st.n_rows == len(o) == e.row_count()
+        k = min(len(res[0]), 9000)                   # point reads: 8192 keys is the limit of the mapped-memory answer
+        for m in (1, 8192, k):
+            ts, val, found = e.get_rows(res[0][:m], res[1][:m])
+            for i in (0, m - 1):
+                assert found[i] and (int(ts[i]), int(val[i])) == o.get_row(int(res[0][i]), int(res[1][i]))
+        f0 = int(res[1][0])
+        for lo, hi in [(5, 5), (-(1 << 31), 1 << 31), (0, 1 << 24)]:   # a few ids, every id (more than the mapped answer holds), many
+            assert np.array_equal(np.sort(e.scan_range(f0, lo, hi)), np.sort(o.scan_range(f0, lo, hi)))
+            assert e.scan_count(f0, lo, hi) == o.scan_count(f0, lo, hi)
