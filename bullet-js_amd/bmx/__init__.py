@@ -33,7 +33,7 @@ EXPORTS = [
     "bmx_comm_create", "bmx_comm_destroy", "bmx_comm_last_error", "bmx_comm_nshards", "bmx_comm_shard", "bmx_comm_sync", "bmx_comm_load_rows", "bmx_comm_merge",
     "bmx_comm_merge_dev", "bmx_comm_shard_result", "bmx_comm_row_count", "bmx_comm_get_rows", "bmx_comm_dump_rows", "bmx_comm_index_build",
     "bmx_comm_scan_range", "bmx_comm_scan_equals", "bmx_comm_scan_count", "bmx_comm_scan_filter",
-    "bmx_vc_create", "bmx_vc_destroy", "bmx_vc_last_error", "bmx_vc_load_rows", "bmx_vc_merge_batch", "bmx_vc_get_rows", "bmx_vc_row_count", "bmx_vc_merge_batch_dev", "bmx_vc_set_stream", "bmx_vc_sync",
+    "bmx_vc_create", "bmx_vc_destroy", "bmx_vc_last_error", "bmx_vc_load_rows", "bmx_vc_merge_batch", "bmx_vc_get_rows", "bmx_vc_row_count", "bmx_vc_scan_range", "bmx_vc_merge_batch_dev", "bmx_vc_set_stream", "bmx_vc_sync",
 ]
 
 
@@ -145,6 +145,7 @@ def load_library():
     L.bmx_vc_merge_batch.argtypes = [vp, u64, vp, vp, vp, vp, vp, vp, vp]; L.bmx_vc_merge_batch.restype = i32
     L.bmx_vc_get_rows.argtypes = [vp, u64, vp, vp, vp, vp, vp]; L.bmx_vc_get_rows.restype = i32
     L.bmx_vc_row_count.argtypes = [vp, C.POINTER(u64)]; L.bmx_vc_row_count.restype = i32
+    L.bmx_vc_scan_range.argtypes = [vp, u32, i64, i64, vp, u64, C.POINTER(u64)]; L.bmx_vc_scan_range.restype = i32
     L.bmx_vc_merge_batch_dev.argtypes = [vp, u64, vp, vp, vp, vp, vp, vp, vp]; L.bmx_vc_merge_batch_dev.restype = i32
     L.bmx_vc_set_stream.argtypes = [vp, vp]; L.bmx_vc_set_stream.restype = i32
     L.bmx_vc_sync.argtypes = [vp]; L.bmx_vc_sync.restype = i32
@@ -551,6 +552,17 @@ class EngineVC:
         n = C.c_uint64()
         self._chk(self.L.bmx_vc_row_count(self.h, C.byref(n)))
         return n.value
+
+    def scan_range(self, field, lo, hi, count_only=False):
+        """node ids of the rows of `field` with lo <= val <= hi (table order), or their number"""
+        m = C.c_uint64()
+        if count_only:
+            self._chk(self.L.bmx_vc_scan_range(self.h, int(field), int(lo), int(hi), None, 0, C.byref(m)))
+            return m.value
+        cap = max(self.row_count(), 1)
+        out = np.zeros(cap, np.uint64)
+        self._chk(self.L.bmx_vc_scan_range(self.h, int(field), int(lo), int(hi), _ptr(out), cap, C.byref(m)))
+        return out[:min(m.value, cap)].copy()
 
     # device-pointer form: torch tensors / raw pointers, enqueue-only
     def merge_batch_dev(self, n, id, field, clocks, val, updated=None, n_updated=None, flags=None):

@@ -383,4 +383,32 @@ __global__ __launch_bounds__(256) void k_vc_get(const VSlot* slots, uint64_t nsl
   for (int k = 0; k < VC_MAXK; k++) if ((uint32_t)k < K) clocks[(size_t)j * K + k] = c[k];
 }
 
+// scan of the vector-clock table itself (range()/equals()/count() of src/bullet-query.js:186-313 over K-writer rows): rows of `field` with
+// lo <= val <= hi, in slot order. No dense index column here: 64 bytes are read per slot (a 10M-row table at load 0.5: 1.3 GB, ~0.25 ms).
+struct PredVSlotRange {
+  static constexpr int E = 2;
+  const VSlot* slots; uint32_t field; int64_t lo, hi;
+  __device__ uint32_t mask(uint64_t first, uint64_t n) const {
+    uint32_t m = 0;
+#pragma unroll
+    for (int e = 0; e < E; e++) {
+      const uint64_t s = first + e;
+      if (s < n) {
+        const uint4* q = reinterpret_cast<const uint4*>(slots + s);
+        const uint4 a = q[0];
+        if (!(a.x == 0xFFFFFFFFu && a.y == 0xFFFFFFFFu) && a.z == field) {
+          const uint4 b = q[1];
+          const int64_t v = (int64_t)((uint64_t)b.x | ((uint64_t)b.y << 32));
+          if (b.z != VC_ABSENT && v >= lo && v <= hi) m |= 1u << e;
+        }
+      }
+    }
+    return m;
+  }
+};
+struct EmitVIds {
+  const VSlot* slots; uint64_t* out; uint64_t cap;
+  __device__ void operator()(uint64_t pos, uint64_t s) const { if (out && pos < cap) out[pos] = slots[s].id; }
+};
+
 }  // namespace bmx

@@ -79,6 +79,8 @@ class DeviceVcTable {
   mergeBatch(c) { return this.native.vcMergeBatch(this.handle, c.id, c.field, c.clocks, c.val); }
   getRows(id, field) { return this.native.vcGetRows(this.handle, id, field); }
   rowCount() { return this.native.vcRowCount(this.handle); }
+  /* node ids (BigUint64Array) of the rows of `field` with lo <= value <= hi: range()/equals() over the K-writer rows */
+  scanRange(field, lo, hi) { return this.native.vcScanRange(this.handle, field, lo, hi); }
   close() {
     if (this.handle) { this.native.vcDestroy(this.handle); this.handle = null; }
   }

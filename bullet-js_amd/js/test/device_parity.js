@@ -414,8 +414,14 @@ for (const name of ["g6_vc_unique_2k.json", "g6_vc_dups_500.json", "g6_vc_empty_
     assert.strictEqual(Number(got.val[i]), x[2]);
     assert.strictEqual(got.state[i], x[3] === 1 ? t.native.VC_SPARSE : t.native.VC_DENSE);
   });
+  // range scan over the K-writer rows == the reference's final rows filtered on the host
+  const vals = g.final_rows.map((x) => x[2]).sort((a, b2) => a - b2);
+  const lo = vals[Math.floor(vals.length / 4)], hi = vals[Math.floor(3 * vals.length / 4)];
+  const ids = t.scanRange(gen.rowField(0, 1), lo, hi);
+  const wantIds = g.final_rows.filter((x) => x[2] >= lo && x[2] <= hi).map((x) => gen.splitmix64(BigInt(x[0]) + 1n)).sort((a, b2) => (a < b2 ? -1 : a > b2 ? 1 : 0));
+  assert.deepStrictEqual(Array.from(ids).sort((a, b2) => (a < b2 ? -1 : a > b2 ? 1 : 0)), wantIds, name + " range scan");
   t.close();
-  checks += 3 + g.final_rows.length;
+  checks += 4 + g.final_rows.length;
 }
 
 /* N4 (b): GpuCRT({writers}).mergeEntries against the host resolver applied entry by entry (the host resolver is pinned on the

@@ -539,6 +539,19 @@ napi_value VcGetRows(napi_env env, napi_callback_info info) {
   return out;
 }
 
+// vcScanRange(h, field, lo, hi) -> BigUint64Array of node ids (rows of `field` with lo <= val <= hi)
+napi_value VcScanRange(napi_env env, napi_callback_info info) {
+  ARGS(4);
+  VcHandle* h; if (!get_vc(env, argv[0], &h)) return nullptr;
+  uint32_t f; NAPI_OK(napi_get_value_uint32(env, argv[1], &f));
+  int64_t lo, hi; if (!get_i64(env, argv[2], &lo) || !get_i64(env, argv[3], &hi)) return nullptr;
+  std::lock_guard<std::mutex> g(h->mu);
+  uint64_t m = 0; int rc = bmx_vc_scan_range(h->t, f, lo, hi, nullptr, 0, &m);
+  if (rc) return throw_vc(env, h->t, rc);
+  void* out; napi_value ta = make_ta(env, napi_biguint64_array, 8, m, &out);
+  if (m) { uint64_t m2 = 0; rc = bmx_vc_scan_range(h->t, f, lo, hi, (uint64_t*)out, m, &m2); if (rc) return throw_vc(env, h->t, rc); }
+  return ta;
+}
 napi_value VcRowCount(napi_env env, napi_callback_info info) {
   ARGS(1);
   VcHandle* h; if (!get_vc(env, argv[0], &h)) return nullptr;
@@ -753,7 +766,7 @@ napi_value Init(napi_env env, napi_value exports) {
       {"abiVersion", AbiVersion}, {"create", Create}, {"destroy", Destroy}, {"mergeBatch", MergeBatch}, {"mergeBatchAsync", MergeBatchAsync}, {"reserve", Reserve}, {"loadRows", LoadRows},
       {"getRows", GetRows}, {"rowCount", RowCount}, {"dumpRows", DumpRows}, {"indexBuild", IndexBuild}, {"indexDrop", IndexDrop},
       {"indexSize", IndexSize}, {"indexRefreshCounts", IndexRefreshCounts}, {"scanRange", ScanRange}, {"scanCount", ScanCount}, {"scanFilter", ScanFilter}, {"info", Info},
-      {"vcCreate", VcCreate}, {"vcDestroy", VcDestroy}, {"vcLoadRows", VcLoadRows}, {"vcMergeBatch", VcMergeBatch}, {"vcGetRows", VcGetRows}, {"vcRowCount", VcRowCount},
+      {"vcCreate", VcCreate}, {"vcDestroy", VcDestroy}, {"vcLoadRows", VcLoadRows}, {"vcMergeBatch", VcMergeBatch}, {"vcGetRows", VcGetRows}, {"vcRowCount", VcRowCount}, {"vcScanRange", VcScanRange},
       {"commCreate", CommCreate}, {"commDestroy", CommDestroy}, {"commMergeBatch", CommMergeBatch}, {"commLoadRows", CommLoadRows}, {"commGetRows", CommGetRows},
       {"commRowCount", CommRowCount}, {"commDumpRows", CommDumpRows}, {"commIndexBuild", CommIndexBuild}, {"commIndexDrop", CommIndexDrop}, {"commIndexSize", CommIndexSize},
       {"commScanRange", CommScanRange}, {"commScanCount", CommScanCount}, {"commScanFilter", CommScanFilter}};

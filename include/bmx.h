@@ -321,6 +321,9 @@ int bmx_vc_merge_batch(bmx_vc* t, uint64_t n, const uint64_t* id, const uint32_t
 int bmx_vc_get_rows(bmx_vc* t, uint64_t n, const uint64_t* id, const uint32_t* field, uint32_t* clocks_out /* n*K */,
                     int64_t* val_out, uint8_t* state_out);
 int bmx_vc_row_count(bmx_vc* t, uint64_t* n_out);
+/* range()/equals()/count() (src/bullet-query.js:186-313) over the rows of this table: node ids of the rows of `field` with lo <= val <= hi, in
+ * table order; out_ids may be NULL (count only); *n_out = matches even if cap is smaller. Scans the table itself (64 B per slot), host buffers. */
+int bmx_vc_scan_range(bmx_vc* t, uint32_t field, int64_t lo, int64_t hi, uint64_t* out_ids, uint64_t cap, uint64_t* n_out);
 /* Device-pointer form (all pointers are device memory; enqueue-only on the table's stream, like BMX_MEM_DEVICE for the scalar table):
  * n_updated is a device uint64; updated_idx (capacity n) and flags (n) may be NULL. Domain errors and protocol faults are sticky and
  * reported by bmx_vc_sync. bmx_vc_set_stream: run on the caller's hipStream_t (NULL = the table's own). */

@@ -212,3 +212,26 @@ def test_vc_long_lists_are_linear_not_quadratic():
     allk = np.concatenate([[keyid(77)], keys_mid]).astype(np.uint64)
     _compare_rows(e, o, allk, np.full(len(allk), F0, np.uint32))
     e.close()
+
+
+def test_vc_scans_over_the_table_match_the_rows_read_back():
+    """range / equals / count over the K-writer rows: the ids a scan returns are exactly the rows whose stored value (read back row by row) lies in
+    the range, for every field, before and after the table grew."""
+    rng = np.random.default_rng(77)
+    K = 3
+    e = bmx.EngineVC(2000, K, 1)                     # small: the table grows along the way
+    seen = set()
+    for b in range(5):
+        ids, fields, clocks, val = _rand_batch(rng, 6000, 4000, K, 3 + b, 40, hot=0.1)
+        e.merge_batch(ids, fields, clocks, val)
+        seen.update(zip(ids.tolist(), fields.tolist()))
+        keys = sorted(seen)
+        kid = np.array([k[0] for k in keys], np.uint64); kf = np.array([k[1] for k in keys], np.uint32)
+        _, vals, state = e.get_rows(kid, kf)
+        for f in np.unique(kf):
+            for lo, hi in [(-1000, 1000), (0, 0), (-5, 7), (10, -10)]:
+                want = np.sort(kid[(kf == f) & (state != 0) & (vals >= lo) & (vals <= hi)])
+                got = np.sort(e.scan_range(int(f), lo, hi))
+                assert np.array_equal(got, want), (b, int(f), lo, hi, len(got), len(want))
+                assert e.scan_range(int(f), lo, hi, count_only=True) == len(want)
+    e.close()
