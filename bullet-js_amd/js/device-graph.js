@@ -62,6 +62,9 @@ class DeviceGraph {
  * `local` is this peer's id (the reference stores clock {local: 2} for a first write). Host typed arrays in and out.
  */
 class DeviceVcTable {
+  /** opts: { device, capacityRows | vcCapacityRows, shards: n (logical shards on one GPU) | devices: [..] (one table per GPU) } — with more than one
+   *  table, rows are owned by bmx_owner_of(node id): a batch is split on the host in batch order (a key never straddles tables, so the
+   *  order-dependent outcome of concurrent clocks is the single-table outcome) and flags / updated indices come back in the caller's index space. */
   constructor(writers, local, opts = {}) {
     this.native = requireNative();
     if (!Array.isArray(writers) || writers.length < 1 || writers.length > this.native.VC_MAX_WRITERS || writers.indexOf(local) < 0) {
@@ -72,17 +75,79 @@ class DeviceVcTable {
     this.writers = writers.slice();
     this.K = writers.length;
     this.local = writers.indexOf(local);
-    this.handle = this.native.vcCreate(opts.device || 0, opts.vcCapacityRows || opts.capacityRows || (1 << 16), this.K, this.local);
+    const devs = Array.isArray(opts.devices) && opts.devices.length ? opts.devices.slice() : new Array(Math.max(1, opts.shards | 0)).fill(opts.device || 0);
+    const cap = opts.vcCapacityRows || opts.capacityRows || (1 << 16);
+    this.handles = devs.map((d) => this.native.vcCreate(d, Math.max(1024, Math.ceil(cap / devs.length)), this.K, this.local));
+    this.handle = this.handles[0];
+    this.N = devs.length;
     this.keys = new KeyDictionary();
   }
-  loadRows(c) { this.native.vcLoadRows(this.handle, c.id, c.field, c.clocks, c.val); }
-  mergeBatch(c) { return this.native.vcMergeBatch(this.handle, c.id, c.field, c.clocks, c.val); }
-  getRows(id, field) { return this.native.vcGetRows(this.handle, id, field); }
-  rowCount() { return this.native.vcRowCount(this.handle); }
-  /* node ids (BigUint64Array) of the rows of `field` with lo <= value <= hi: range()/equals() over the K-writer rows */
-  scanRange(field, lo, hi) { return this.native.vcScanRange(this.handle, field, lo, hi); }
+  /* rows of shard g (indices into the caller's columns), in batch order */
+  _split(id) {
+    const owners = this.native.ownersOf(id, this.N);
+    const counts = new Uint32Array(this.N);
+    for (let i = 0; i < owners.length; i++) counts[owners[i]]++;
+    const back = []; for (let g = 0; g < this.N; g++) back.push(new Uint32Array(counts[g]));
+    counts.fill(0);
+    for (let i = 0; i < owners.length; i++) { const g = owners[i]; back[g][counts[g]++] = i; }
+    return back;
+  }
+  _sub(c, idx) {
+    const m = idx.length, K = this.K;
+    const id = new BigUint64Array(m), field = new Uint32Array(m), clocks = new Uint32Array(m * K), val = new BigInt64Array(m);
+    for (let x = 0; x < m; x++) {
+      const j = idx[x];
+      id[x] = c.id[j]; field[x] = c.field[j]; val[x] = c.val[j];
+      for (let k = 0; k < K; k++) clocks[x * K + k] = c.clocks[j * K + k];
+    }
+    return { id, field, clocks, val };
+  }
+  loadRows(c) {
+    if (this.N === 1) { this.native.vcLoadRows(this.handle, c.id, c.field, c.clocks, c.val); return; }
+    const back = this._split(c.id);
+    for (let g = 0; g < this.N; g++) if (back[g].length) { const s = this._sub(c, back[g]); this.native.vcLoadRows(this.handles[g], s.id, s.field, s.clocks, s.val); }
+  }
+  mergeBatch(c) {
+    if (this.N === 1) return this.native.vcMergeBatch(this.handle, c.id, c.field, c.clocks, c.val);
+    const n = c.id.length, back = this._split(c.id);
+    const flags = new Uint8Array(n), upd = [];
+    let nRows = 0;
+    for (let g = 0; g < this.N; g++) {
+      if (!back[g].length) { nRows += this.native.vcRowCount(this.handles[g]); continue; }
+      const s = this._sub(c, back[g]);
+      const r = this.native.vcMergeBatch(this.handles[g], s.id, s.field, s.clocks, s.val);
+      for (let x = 0; x < r.flags.length; x++) flags[back[g][x]] = r.flags[x];
+      for (let x = 0; x < r.updated.length; x++) upd.push(back[g][r.updated[x]]);
+      nRows += r.nRows;
+    }
+    return { updated: Uint32Array.from(upd).sort(), flags, nRows };
+  }
+  getRows(id, field) {
+    if (this.N === 1) return this.native.vcGetRows(this.handle, id, field);
+    const n = id.length, K = this.K, back = this._split(id);
+    const clocks = new Uint32Array(n * K), val = new BigInt64Array(n), state = new Uint8Array(n);
+    for (let g = 0; g < this.N; g++) {
+      const idx = back[g], m = idx.length;
+      if (!m) continue;
+      const gi = new BigUint64Array(m), gf = new Uint32Array(m);
+      for (let x = 0; x < m; x++) { gi[x] = id[idx[x]]; gf[x] = field[idx[x]]; }
+      const r = this.native.vcGetRows(this.handles[g], gi, gf);
+      for (let x = 0; x < m; x++) { const j = idx[x]; val[j] = r.val[x]; state[j] = r.state[x]; for (let k = 0; k < K; k++) clocks[j * K + k] = r.clocks[x * K + k]; }
+    }
+    return { clocks, val, state };
+  }
+  rowCount() { let t = 0; for (const h of this.handles) t += this.native.vcRowCount(h); return t; }
+  /* node ids (BigUint64Array) of the rows of `field` with lo <= value <= hi: range()/equals() over the K-writer rows (every table scans its own) */
+  scanRange(field, lo, hi) {
+    if (this.N === 1) return this.native.vcScanRange(this.handle, field, lo, hi);
+    const parts = this.handles.map((h) => this.native.vcScanRange(h, field, lo, hi));
+    const out = new BigUint64Array(parts.reduce((a, p) => a + p.length, 0));
+    let o = 0; for (const p of parts) { out.set(p, o); o += p.length; }
+    return out;
+  }
   close() {
-    if (this.handle) { this.native.vcDestroy(this.handle); this.handle = null; }
+    for (const h of this.handles || []) this.native.vcDestroy(h);
+    this.handles = []; this.handle = null;
   }
 }
 

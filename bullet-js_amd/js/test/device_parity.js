@@ -392,10 +392,11 @@ for (const shards of [2, 4, 8]) {
 }
 
 /* N4: K-writer vector clocks. (a) the reference's golden vectors through the addon's vc* entry points */
-for (const name of ["g6_vc_unique_2k.json", "g6_vc_dups_500.json", "g6_vc_empty_start.json"]) {
+for (const [name, shards] of [["g6_vc_unique_2k.json", 1], ["g6_vc_dups_500.json", 1], ["g6_vc_empty_start.json", 1],
+                              ["g6_vc_unique_2k.json", 3], ["g6_vc_dups_500.json", 4], ["g6_vc_empty_start.json", 2]]) {   // > 1: rows split over that many tables by owner
   const g = load(name);
   const { DeviceVcTable } = require("../device-graph");
-  const t = new DeviceVcTable(g.writers, "w", { capacityRows: 1024 });       // small on purpose: the table grows
+  const t = new DeviceVcTable(g.writers, "w", { capacityRows: 1024, shards });       // small on purpose: the tables grow
   const K = g.writers.length;
   const cols = (rows) => {
     const c = new hash.VcColumns(rows.length, K);

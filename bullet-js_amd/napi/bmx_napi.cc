@@ -104,6 +104,19 @@ void set_num(napi_env env, napi_value obj, const char* k, double v) { napi_value
   NAPI_OK(napi_get_cb_info(env, info, &argc, argv, nullptr, nullptr)); \
   if (argc < N) { napi_throw_type_error(env, nullptr, "bmx: missing arguments"); return nullptr; }
 
+// ownersOf(id: BigUint64Array, nshards) -> Uint8Array: bmx_owner_of for every id (the host-side routing of small batches and of the K-writer table)
+napi_value OwnersOf(napi_env env, napi_callback_info info) {
+  ARGS(2);
+  void* p; size_t n;
+  if (!get_ta(env, argv[0], napi_biguint64_array, &p, &n)) return nullptr;
+  uint32_t ns; NAPI_OK(napi_get_value_uint32(env, argv[1], &ns));
+  if (ns == 0 || ns > 255) { napi_throw_range_error(env, nullptr, "bmx: 1..255 shards"); return nullptr; }
+  void* o; napi_value out = make_ta(env, napi_uint8_array, 1, n, &o);
+  const uint64_t* id = (const uint64_t*)p; uint8_t* ow = (uint8_t*)o;
+  for (size_t i = 0; i < n; i++) ow[i] = (uint8_t)bmx_owner_of(id[i], ns);
+  return out;
+}
+
 napi_value AbiVersion(napi_env env, napi_callback_info) { napi_value v; napi_create_int32(env, bmx_abi_version(), &v); return v; }
 
 napi_value Create(napi_env env, napi_callback_info info) {
@@ -766,7 +779,7 @@ napi_value Init(napi_env env, napi_value exports) {
       {"abiVersion", AbiVersion}, {"create", Create}, {"destroy", Destroy}, {"mergeBatch", MergeBatch}, {"mergeBatchAsync", MergeBatchAsync}, {"reserve", Reserve}, {"loadRows", LoadRows},
       {"getRows", GetRows}, {"rowCount", RowCount}, {"dumpRows", DumpRows}, {"indexBuild", IndexBuild}, {"indexDrop", IndexDrop},
       {"indexSize", IndexSize}, {"indexRefreshCounts", IndexRefreshCounts}, {"scanRange", ScanRange}, {"scanCount", ScanCount}, {"scanFilter", ScanFilter}, {"info", Info},
-      {"vcCreate", VcCreate}, {"vcDestroy", VcDestroy}, {"vcLoadRows", VcLoadRows}, {"vcMergeBatch", VcMergeBatch}, {"vcGetRows", VcGetRows}, {"vcRowCount", VcRowCount}, {"vcScanRange", VcScanRange},
+      {"vcCreate", VcCreate}, {"vcDestroy", VcDestroy}, {"vcLoadRows", VcLoadRows}, {"vcMergeBatch", VcMergeBatch}, {"vcGetRows", VcGetRows}, {"vcRowCount", VcRowCount}, {"vcScanRange", VcScanRange}, {"ownersOf", OwnersOf},
       {"commCreate", CommCreate}, {"commDestroy", CommDestroy}, {"commMergeBatch", CommMergeBatch}, {"commLoadRows", CommLoadRows}, {"commGetRows", CommGetRows},
       {"commRowCount", CommRowCount}, {"commDumpRows", CommDumpRows}, {"commIndexBuild", CommIndexBuild}, {"commIndexDrop", CommIndexDrop}, {"commIndexSize", CommIndexSize},
       {"commScanRange", CommScanRange}, {"commScanCount", CommScanCount}, {"commScanFilter", CommScanFilter}};
