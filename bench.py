@@ -379,7 +379,7 @@ def main():
         def run(lo, hi):
             # exactly (hi-lo) routes and (hi-lo) merges. route(b+1) is enqueued before merge(b): its partition runs on the merge
             # stream ahead of merge(b), its all-to-all on the communication stream underneath merge(b)
-            tk = sg.route(D_PER_STEP, *batches[lo])
+            tk = sg.route(D_PER_STEP, *batches[lo], exchange_now=True)   # nothing to hide the first exchange behind: start it before the next partition
             for b in range(lo, hi):
                 nxt = sg.route(D_PER_STEP, *batches[b + 1]) if b + 1 < hi else None
                 sg.merge(tk)

@@ -228,10 +228,11 @@ class ShardedGraph:
         self._merged = 0
         self._due = []
 
-    def route(self, n, id, field, ts, val):
+    def route(self, n, id, field, ts, val, exchange_now=False):
         """Enqueue the owner partition of one batch and remember that its exchange is due; returns a ticket for merge(). The
         all-to-all itself is issued by the next merge() call AFTER that merge's kernels are enqueued, so the (slow, host-side)
-        collective call never delays kernels the GPU could already be running."""
+        collective call never delays kernels the GPU could already be running. exchange_now: issue it at once instead — for the
+        first batch of a pipeline, which has no merge to hide behind (its exchange then overlaps the next batch's partition)."""
         depth = len(self._pipe)
         assert self._routed - self._merged < depth, "merge() the oldest routed batch before routing another"
         k = self._routed
@@ -248,7 +249,10 @@ class ShardedGraph:
                 p["args"] = (n, id, field, ts, val)           # partitioned on the exchange stream when the exchange is issued
         p["used"] = True
         p["exchanged"] = False
-        self._due.append(p)
+        if exchange_now:
+            self._exchange(p)
+        else:
+            self._due.append(p)
         self.sent_remote += n - n // self.world
         return p
 
