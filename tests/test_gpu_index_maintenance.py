@@ -209,3 +209,54 @@ def test_random_sequences_of_merges_index_changes_and_scans(seed):
             _check_scans(e, o, rng, span, (seed, step)); have.update((FA, FB))
     _check_scans(e, o, rng, span, (seed, "end"))
     e.close(); o.close()
+
+
+def test_more_indexes_than_the_maintenance_pass_handles_and_appends_beyond_the_head_room():
+    """Nine indexes: beyond the eight the change-log pass keeps up to date, every stale index is rebuilt instead — scans stay right. And a batch that
+    creates more rows than an index column has head room for (n/8 + 64K) makes that index rebuild once, after which it is maintained again."""
+    rng = np.random.default_rng(3)
+    fields = [streams.field_hash(10 + k) for k in range(9)]
+    nodes = 3000
+    e = bmx.Engine(capacity_rows=2_000_000, flags=bmx.CTX_FIXED_CAPACITY); o = Oracle()
+    ids = _ids(np.arange(nodes))
+    for f in fields:
+        v = rng.integers(-50, 51, nodes).astype(np.int64)
+        e.load_rows(ids, np.full(nodes, f, np.uint32), np.full(nodes, 5, np.int64), v); o.load_rows(ids, np.full(nodes, f, np.uint32), np.full(nodes, 5, np.int64), v)
+    for f in fields[:8]:
+        e.index_build(f)
+
+    def check(tag, fs):
+        for f in fs:
+            got = np.sort(e.scan_range(f, -20, 20)); ref = np.sort(o.scan_range(f, -20, 20))
+            assert np.array_equal(got, ref), (tag, f)
+
+    for b in range(3):
+        n = 4000
+        rows = rng.integers(0, nodes + 500, n)
+        d = (_ids(rows), np.array(fields, np.uint32)[rng.integers(0, 9, n)], rng.integers(6, 40, n).astype(np.int64), rng.integers(-50, 51, n).astype(np.int64))
+        e.merge_batch(*d); o.merge_batch(*d, INSERT_REFERENCE)
+        check(("eight", b), fields[:8])
+    assert e.index_refresh_counts()[1] >= 3                   # eight indexes: maintained
+    e.index_build(fields[8])                                   # the ninth
+    for b in range(3):
+        n = 4000
+        rows = rng.integers(0, nodes + 2000, n)
+        d = (_ids(rows), np.array(fields, np.uint32)[rng.integers(0, 9, n)], rng.integers(40, 80, n).astype(np.int64), rng.integers(-50, 51, n).astype(np.int64))
+        e.merge_batch(*d); o.merge_batch(*d, INSERT_REFERENCE)
+        check(("nine", b), fields)
+    for f in fields[1:]:
+        e.index_drop(f)
+    check("one left", fields[:1])
+    # far more new rows of the indexed field than its columns have room for: 3000 rows + 64K + n/8 head room < 120000 new rows
+    full0, inc0 = e.index_refresh_counts()
+    n = 120_000
+    d = (_ids(np.arange(10_000_000, 10_000_000 + n)), np.full(n, fields[0], np.uint32), np.full(n, 7, np.int64), rng.integers(-50, 51, n).astype(np.int64))
+    e.merge_batch(*d); o.merge_batch(*d, INSERT_REFERENCE)
+    check("overflow", fields[:1])
+    full1, _ = e.index_refresh_counts()
+    assert full1 > full0, "the appended rows cannot have fitted: the index must have been rebuilt"
+    d = (_ids(np.arange(10_000_000, 10_000_000 + 500)), np.full(500, fields[0], np.uint32), np.full(500, 9, np.int64), rng.integers(-50, 51, 500).astype(np.int64))
+    e.merge_batch(*d); o.merge_batch(*d, INSERT_REFERENCE)
+    check("after overflow", fields[:1])
+    assert e.index_refresh_counts()[0] == full1                # maintained again
+    e.close(); o.close()
