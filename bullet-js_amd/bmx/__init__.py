@@ -28,7 +28,7 @@ MAX_BATCH = 1 << 24
 EXPORTS = [
     "bmx_create", "bmx_create_ex", "bmx_destroy", "bmx_last_error", "bmx_abi_version", "bmx_get_info", "bmx_sync", "bmx_set_stream", "bmx_get_stream", "bmx_seq_signal", "bmx_seq_wait",
     "bmx_load_rows", "bmx_merge_batch", "bmx_merge_submit", "bmx_merge_collect", "bmx_merge_records", "bmx_get_rows", "bmx_get_row", "bmx_dump_rows", "bmx_row_count", "bmx_reserve",
-    "bmx_index_build", "bmx_index_drop", "bmx_index_size", "bmx_index_refresh_counts", "bmx_scan_range", "bmx_scan_equals", "bmx_scan_count", "bmx_scan_filter",
+    "bmx_index_build", "bmx_index_drop", "bmx_index_size", "bmx_index_refresh_counts", "bmx_scan_range", "bmx_scan_equals", "bmx_scan_count", "bmx_scan_filter", "bmx_scan_range_pos", "bmx_index_ids",
     "bmx_owner_of", "bmx_partition_by_owner", "bmx_partition_by_owner_slabs", "bmx_timer_start", "bmx_timer_stop", "bmx_profile_enable", "bmx_profile_read", "bmx_profile_read_scan",
     "bmx_comm_create", "bmx_comm_destroy", "bmx_comm_last_error", "bmx_comm_nshards", "bmx_comm_shard", "bmx_comm_sync", "bmx_comm_load_rows", "bmx_comm_merge",
     "bmx_comm_merge_dev", "bmx_comm_shard_result", "bmx_comm_row_count", "bmx_comm_get_rows", "bmx_comm_dump_rows", "bmx_comm_index_build",
@@ -112,6 +112,8 @@ def load_library():
     L.bmx_scan_equals.argtypes = [vp, u32, i64, vp, u64, vp, i32]; L.bmx_scan_equals.restype = i32
     L.bmx_scan_count.argtypes = [vp, u32, i64, i64, vp, i32]; L.bmx_scan_count.restype = i32
     L.bmx_scan_filter.argtypes = [vp, u32, C.POINTER(Term), vp, u64, vp, i32]; L.bmx_scan_filter.restype = i32
+    L.bmx_scan_range_pos.argtypes = [vp, u32, i64, i64, vp, u64, vp, i32]; L.bmx_scan_range_pos.restype = i32
+    L.bmx_index_ids.argtypes = [vp, u32, u64, u64, vp, i32]; L.bmx_index_ids.restype = i32
     L.bmx_owner_of.argtypes = [u64, u32]; L.bmx_owner_of.restype = u32
     L.bmx_partition_by_owner.argtypes = [vp, u64, vp, vp, vp, vp, u32, vp, vp]; L.bmx_partition_by_owner.restype = i32
     L.bmx_partition_by_owner_slabs.argtypes = [vp, u64, vp, vp, vp, vp, u32, u64, vp, vp]; L.bmx_partition_by_owner_slabs.restype = i32
@@ -289,6 +291,20 @@ class Engine:
         self._chk(self.L.bmx_scan_range(self.h, int(field), int(lo), int(hi), _ptr(out), cap, C.cast(C.byref(m), C.c_void_p), MEM_HOST))
         return out[:min(m.value, cap)].copy()
 
+    def scan_range_pos(self, field, lo, hi, cap=None):
+        """positions (u32, ascending) of the matches in the index columns instead of their node ids"""
+        cap = self.index_size(field) if cap is None else cap
+        out = np.zeros(max(cap, 1), np.uint32)
+        m = C.c_uint64()
+        self._chk(self.L.bmx_scan_range_pos(self.h, int(field), int(lo), int(hi), _ptr(out), cap, C.cast(C.byref(m), C.c_void_p), MEM_HOST))
+        return out[:min(m.value, cap)].copy()
+
+    def index_ids(self, field, first=0, count=None):
+        count = self.index_size(field) - first if count is None else count
+        out = np.zeros(max(count, 1), np.uint64)
+        self._chk(self.L.bmx_index_ids(self.h, int(field), int(first), int(count), _ptr(out), MEM_HOST))
+        return out[:count].copy()
+
     def scan_equals(self, field, value):
         return self.scan_range(field, value, value)
 
@@ -344,6 +360,12 @@ class Engine:
 
     def scan_range_dev(self, field, lo, hi, out_ids, cap, n_out):
         self._chk(self.L.bmx_scan_range(self.h, int(field), int(lo), int(hi), _ptr(out_ids), int(cap), _ptr(n_out), MEM_DEVICE))
+
+    def scan_range_pos_dev(self, field, lo, hi, out_pos, cap, n_out):
+        self._chk(self.L.bmx_scan_range_pos(self.h, int(field), int(lo), int(hi), _ptr(out_pos), int(cap), _ptr(n_out), MEM_DEVICE))
+
+    def index_ids_dev(self, field, first, count, out_ids):
+        self._chk(self.L.bmx_index_ids(self.h, int(field), int(first), int(count), _ptr(out_ids), MEM_DEVICE))
 
     def profile_enable(self, on=True):
         self._chk(self.L.bmx_profile_enable(self.h, 1 if on else 0))

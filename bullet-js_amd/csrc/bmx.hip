@@ -10,6 +10,7 @@
 #include <deque>
 #include <new>
 #include <string>
+#include <type_traits>
 #include <vector>
 
 #include "../../include/bmx.h"
@@ -62,9 +63,12 @@ struct bmx_ctx {
   uint32_t* next = nullptr;
   uint8_t* wflag = nullptr;
   uint32_t* slot_of = nullptr;
-  uint32_t* blk_info = nullptr;       // ws_cap/256 block summaries
+  uint32_t* blk_info = nullptr;       // 2 x (ws_cap/256 + 16) block summaries: batch k uses half k & 1 (INS_WAVE zeroes the other half for batch k + 1)
+  uint32_t blk_half = 0, blk_par = 0; bool blk_clean[2] = {false, false}; int wave_nt = 64;
   uint32_t* blk_follow = nullptr;     // ws_cap/256 epoch tags: a delta of the block got a follower on its row
   unsigned long long* shard_ctr = nullptr;  // CTR_SHARDS * CTR_STRIDE
+  int ins_variant = INS_NOBAR; uint32_t k1_dbg = 0;       // where k_probe_apply's absent keys get their rows (merge_kernels.h); BMX_K1_INSERTS=inline|block|launch overrides (A/B)
+  uint4* miss = nullptr; uint32_t* miss_n = nullptr;   // INS_LAUNCH only: ws_cap entries / ws_cap/256 counts
   // default merge path (bin_kernels.h): the batch regrouped by bin, tile by tile
   uint32_t bin_tiles_cap = 0;
   uint4* bin_stage = nullptr;         // bin_tiles_cap * BK_TILE records of 32 B
@@ -133,6 +137,7 @@ int fail(bmx_ctx* c, int code, const std::string& msg) {
   g_err = msg;
   return code;
 }
+inline hipMemcpyKind host_or_dev(int mem) { return mem == BMX_MEM_HOST ? hipMemcpyDeviceToHost : hipMemcpyDeviceToDevice; }
 int fail_hip(bmx_ctx* c, hipError_t e, const char* what) {
   return fail(c, BMX_ERR_HIP, std::string(what) + ": " + hipGetErrorString(e));
 }
@@ -217,13 +222,17 @@ int ensure_workspace(bmx_ctx* ctx, uint64_t n) {
   uint64_t cap = std::max<uint64_t>(n, std::min<uint64_t>((uint64_t)ctx->ws_cap * 2, MAX_BATCH));
   cap = std::max<uint64_t>(cap, 1u << 16);
   cap = (cap + 255) & ~255ull;
-  dev_free(ctx->next); dev_free(ctx->wflag); dev_free(ctx->slot_of); dev_free(ctx->blk_info); dev_free(ctx->blk_follow);
+  dev_free(ctx->next); dev_free(ctx->wflag); dev_free(ctx->slot_of); dev_free(ctx->blk_info); dev_free(ctx->blk_follow); dev_free(ctx->miss); dev_free(ctx->miss_n);
   ctx->ws_cap = 0;
   int rc;
   if ((rc = dev_alloc(ctx, &ctx->next, cap)) || (rc = dev_alloc(ctx, &ctx->wflag, cap + 16)) || (rc = dev_alloc(ctx, &ctx->slot_of, cap))) return rc;
-  if ((rc = dev_alloc(ctx, &ctx->blk_info, cap / 256 + 16)) || (rc = dev_alloc(ctx, &ctx->blk_follow, cap / 256 + 16))) return rc;
+  if ((rc = dev_alloc(ctx, &ctx->blk_info, 2 * ((cap / 256 + 16 + 3) & ~3ull))) || (rc = dev_alloc(ctx, &ctx->blk_follow, cap / 256 + 16))) return rc;
+  if (ctx->ins_variant == INS_LAUNCH && ((rc = dev_alloc(ctx, &ctx->miss, cap)) || (rc = dev_alloc(ctx, &ctx->miss_n, cap / 256 + 16)))) return rc;
   HIPCHK(hipMemsetAsync(ctx->next, 0, cap * sizeof(uint32_t), ctx->stream));
   HIPCHK(hipMemsetAsync(ctx->blk_follow, 0, (cap / 256 + 16) * sizeof(uint32_t), ctx->stream));
+  ctx->blk_half = (uint32_t)((cap / 256 + 16 + 3) & ~3ull);    // a multiple of four entries: both halves stay 16-byte aligned for the compaction's wide loads
+  HIPCHK(hipMemsetAsync(ctx->blk_info, 0, 2 * (size_t)ctx->blk_half * sizeof(uint32_t), ctx->stream));
+  ctx->blk_clean[0] = ctx->blk_clean[1] = true;
   ctx->ws_cap = (uint32_t)cap;
   return BMX_OK;
 }
@@ -362,7 +371,12 @@ int merge_core(bmx_ctx* ctx, uint64_t n, const uint64_t* id, const uint32_t* fie
   A.n = (uint32_t)n; A.epoch = ctx->epoch;
   A.next = ctx->next; A.wflag = wflag; A.flags = flags;
   A.slot_of = ctx->slot_of; A.blk_follow = ctx->blk_follow; A.shard_ctr = ctr; A.status = &ctx->ds->status;
-  A.blk_info = ctx->blk_info;
+  A.blk_info = ctx->blk_info + (size_t)ctx->blk_par * ctx->blk_half; A.blk_next = ctx->blk_info + (size_t)(ctx->blk_par ^ 1u) * ctx->blk_half; A.blk_ents = ctx->blk_half;
+  const bool wave_k1 = legacy && !strict && ctx->ins_variant == INS_WAVE;
+  if (wave_k1 && !ctx->blk_clean[ctx->blk_par]) HIPCHK(hipMemsetAsync(A.blk_info, 0, (size_t)ctx->blk_half * sizeof(uint32_t), ctx->stream));   // a batch on another path used this half last
+  ctx->blk_clean[ctx->blk_par] = false; if (wave_k1) ctx->blk_clean[ctx->blk_par ^ 1u] = true;
+  ctx->blk_par ^= 1u;
+  A.miss = ctx->miss; A.miss_n = ctx->miss_n; A.dbg = ctx->k1_dbg;
   const uint32_t blocks = (uint32_t)((n + 255) / 256);
   const uint32_t rblocks = blocks;   // one lane per delta
   hipEvent_t* pe = (ctx->prof_on && ctx->prof_n < PROF_MAX_CALLS) ? &ctx->prof_ev[4 * ctx->prof_n] : nullptr;
@@ -389,12 +403,23 @@ int merge_core(bmx_ctx* ctx, uint64_t n, const uint64_t* id, const uint32_t* fie
   if (pe) ctx->prof_path[ctx->prof_n] = 0;
   if (strict) {
     hipLaunchKernelGGL((k_probe_link_strict<AOS>), dim3(blocks), dim3(256), 0, ctx->stream, A);
-  } else if (insert_mode == BMX_INSERT_REFERENCE) {
-    if (unique) hipLaunchKernelGGL((k_probe_apply<AOS, BMX_INSERT_REFERENCE, true>), dim3(blocks), dim3(256), 0, ctx->stream, A);
-    else hipLaunchKernelGGL((k_probe_apply<AOS, BMX_INSERT_REFERENCE, false>), dim3(blocks), dim3(256), 0, ctx->stream, A);
   } else {
-    if (unique) hipLaunchKernelGGL((k_probe_apply<AOS, BMX_INSERT_DELTA, true>), dim3(blocks), dim3(256), 0, ctx->stream, A);
-    else hipLaunchKernelGGL((k_probe_apply<AOS, BMX_INSERT_DELTA, false>), dim3(blocks), dim3(256), 0, ctx->stream, A);
+    // one instantiation per (insert mode, unique-key guarantee, insert placement); the placement is a context constant
+#define BMX_K1(MODE_, UNIQ_, INS_) hipLaunchKernelGGL((k_probe_apply<AOS, MODE_, UNIQ_, INS_>), dim3(blocks), dim3(256), 0, ctx->stream, A)
+#define BMX_K4(MODE_, UNIQ_) hipLaunchKernelGGL((k_insert_misses<AOS, MODE_, UNIQ_>), dim3((blocks + 7) / 8), dim3(256), 0, ctx->stream, A, blocks)
+#define BMX_K1W(MODE_, UNIQ_, NT_) hipLaunchKernelGGL((k_probe_apply_w<AOS, MODE_, UNIQ_, NT_>), dim3((uint32_t)((n + NT_ - 1) / NT_)), dim3(NT_), 0, ctx->stream, A)
+#define BMX_K1NB(MODE_, UNIQ_, DEFER_) hipLaunchKernelGGL((k_probe_apply_nb<AOS, MODE_, UNIQ_, DEFER_>), dim3(blocks), dim3(256), 0, ctx->stream, A)
+#define BMX_K1_INS(MODE_, UNIQ_) do { if (ctx->ins_variant == INS_INLINE) BMX_K1(MODE_, UNIQ_, INS_INLINE); else if (ctx->ins_variant == INS_BLOCK) BMX_K1(MODE_, UNIQ_, INS_BLOCK); \
+                                      else if (ctx->ins_variant == INS_NOBAR) BMX_K1NB(MODE_, UNIQ_, false); else if (ctx->ins_variant == INS_LASTWAVE) BMX_K1NB(MODE_, UNIQ_, true); \
+                                      else if (ctx->ins_variant == INS_WAVE) { if (ctx->wave_nt == 64) BMX_K1W(MODE_, UNIQ_, 64); else if (ctx->wave_nt == 128) BMX_K1W(MODE_, UNIQ_, 128); else BMX_K1W(MODE_, UNIQ_, 256); } \
+                                      else { BMX_K1(MODE_, UNIQ_, INS_LAUNCH); BMX_K4(MODE_, UNIQ_); } } while (0)
+    if (insert_mode == BMX_INSERT_REFERENCE) { if (unique) BMX_K1_INS(BMX_INSERT_REFERENCE, true); else BMX_K1_INS(BMX_INSERT_REFERENCE, false); }
+    else { if (unique) BMX_K1_INS(BMX_INSERT_DELTA, true); else BMX_K1_INS(BMX_INSERT_DELTA, false); }
+#undef BMX_K1_INS
+#undef BMX_K1NB
+#undef BMX_K1W
+#undef BMX_K4
+#undef BMX_K1
   }
   LAUNCHCHK("k_probe_apply");
   if (pe) HIPCHK(hipEventRecord(pe[1], ctx->stream));
@@ -577,7 +602,8 @@ int ensure_ix_maintenance(bmx_ctx* ctx) {
     ctx->slot_pos_n = ctx->nslots;
     HIPCHK(hipMemsetAsync(ctx->slot_pos, 0xFF, ctx->nslots * sizeof(uint32_t), ctx->stream));
   }
-  const uint64_t want = std::min<uint64_t>(std::max<uint64_t>(ctx->nslots / 4, 1u << 22), 1u << 26);   // 4M .. 64M entries of 8 B
+  // the log is only used while it is shorter than max(nslots/8, 1M) entries (fresh_index): size it for that, not for the largest table
+  const uint64_t want = std::min<uint64_t>(std::max<uint64_t>(ctx->nslots / 4, 1u << 20) + (1u << 16), 1u << 26);   // 1M .. 64M entries of 8 B
   if (ctx->chg_cap < want) {
     HIPCHK(hipStreamSynchronize(ctx->stream));
     dev_free(ctx->chg); ctx->chg_cap = 0; ctx->chg_valid = false;
@@ -677,7 +703,12 @@ int refresh_from_log(bmx_ctx* ctx) {
   if (rc) return rc;
   for (size_t k = 0; k < ctx->indexes.size(); k++) {
     Index& ix = ctx->indexes[k];
-    if (ub && ix.n + res[k].added > ix.cap) { ix.version = ~0ull; continue; }   // the appended rows did not fit: rebuilt on its next use
+    if (ub && ix.n + res[k].added > ix.cap) {
+      // The appended rows did not fit. The entries it missed are gone with the log, so this index must never be refreshed from a LATER log:
+      // without its positions it can only come back through build_index(), and the log stops until every index is fresh again.
+      ix.version = ~0ull; ix.has_pos = false; ctx->chg_valid = false;
+      continue;
+    }
     if (ub) { ix.n += res[k].added; if (res[k].wide) ix.fits32 = false; }
     ix.version = ctx->version;
   }
@@ -737,11 +768,14 @@ int ensure_scan_scratch(bmx_ctx* ctx, uint64_t n) {
   return BMX_OK;
 }
 
-// Run one predicate over an index and deliver ids / count according to `mem`.
-template <class Pred>
-int run_scan(bmx_ctx* ctx, const Pred& P, const Index* ix, uint64_t* out_ids, uint64_t cap, uint64_t* n_out, int mem) {
+// Run one predicate over an index and deliver ids (POS = false: u64 node ids gathered from the id column) or index positions (POS = true: u32,
+// no gather) / the count according to `mem`. `out` is uint64_t* or uint32_t* accordingly.
+template <bool POS, class Pred>
+int run_scan_t(bmx_ctx* ctx, const Pred& P, const Index* ix, void* out_v, uint64_t cap, uint64_t* n_out, int mem) {
+  using OutT = typename std::conditional<POS, uint32_t, uint64_t>::type;
+  OutT* out_ids = static_cast<OutT*>(out_v);
   const bool host = mem == BMX_MEM_HOST;
-  uint64_t* d_out = out_ids;
+  OutT* d_out = out_ids;
   uint64_t d_cap = cap;
   int rc;
   // small host-mode answers (count only, or room for at most SCAN_PIN_IDS ids) come back through mapped host memory: no download, one synchronisation
@@ -750,10 +784,10 @@ int run_scan(bmx_ctx* ctx, const Pred& P, const Index* ix, uint64_t* out_ids, ui
   const bool pinned = host && !ctx->scan_defer && (!out_ids || std::min<uint64_t>(cap, ix->n) <= SCAN_PIN_IDS) && ensure_pinned(ctx);
   if (host && out_ids) {
     d_cap = std::min<uint64_t>(cap, ix->n);
-    if (pinned) d_out = reinterpret_cast<uint64_t*>(ctx->pin_out);
+    if (pinned) d_out = reinterpret_cast<OutT*>(ctx->pin_out);
     else {
       if ((rc = ensure_scan_out(ctx, std::max<uint64_t>(d_cap, 1)))) return rc;
-      d_out = ctx->scan_out;
+      d_out = reinterpret_cast<OutT*>(ctx->scan_out);
     }
   }
   if ((rc = ensure_scan_scratch(ctx, std::max<uint64_t>(ix->n, 1)))) return rc;
@@ -762,16 +796,18 @@ int run_scan(bmx_ctx* ctx, const Pred& P, const Index* ix, uint64_t* out_ids, ui
   hipEvent_t* se = (ctx->prof_on && ctx->scan_prof_n < PROF_MAX_CALLS && !ctx->scan_ev.empty()) ? &ctx->scan_ev[3 * ctx->scan_prof_n] : nullptr;
   if (se) HIPCHK(hipEventRecord(se[0], ctx->stream));
   if (d_out) {
-    // pass 1: one read of the column -> match mask + block counts; pass 2: ids from the mask
+    // pass 1: one read of the column -> match mask + block counts; pass 2: ids / positions from the mask
     hipLaunchKernelGGL((k_scan_mask<Pred, true>), dim3(nb), dim3(SEL_THREADS), 0, ctx->stream, P, ix->n, ctx->scan_mask, ctx->scan_counts);
     LAUNCHCHK("k_scan_mask");
     if (se) HIPCHK(hipEventRecord(se[1], ctx->stream));
-    EmitIds Em{ix->ids, d_out, d_cap};
+    typename std::conditional<POS, EmitPos, EmitIds>::type Em;
+    if constexpr (POS) Em = EmitPos{d_out, d_cap}; else Em = EmitIds{ix->ids, d_out, d_cap};
+    using EmT = decltype(Em);
     FinishCount Fin{d_n};
-    if (nb > 2048)   // large column: an eighth of the workgroups, each sums the counts in front of it once (no offsets launch)
-      hipLaunchKernelGGL((k_scan_emit<EmitIds, FinishCount, 8>), dim3((nb + 7) / 8), dim3(SEL_THREADS), 0, ctx->stream, ctx->scan_mask, ctx->scan_counts, ix->n, nb, Em, Fin);
+    if (nb > SCAN_SUB8_BLOCKS)   // large column: an eighth of the workgroups, each sums the counts in front of it once (no offsets launch)
+      hipLaunchKernelGGL((k_scan_emit<EmT, FinishCount, 8>), dim3((nb + 7) / 8), dim3(SEL_THREADS), 0, ctx->stream, ctx->scan_mask, ctx->scan_counts, ix->n, nb, Em, Fin);
     else
-      hipLaunchKernelGGL((k_scan_emit<EmitIds, FinishCount, 1>), dim3(nb), dim3(SEL_THREADS), 0, ctx->stream, ctx->scan_mask, ctx->scan_counts, ix->n, nb, Em, Fin);
+      hipLaunchKernelGGL((k_scan_emit<EmT, FinishCount, 1>), dim3(nb), dim3(SEL_THREADS), 0, ctx->stream, ctx->scan_mask, ctx->scan_counts, ix->n, nb, Em, Fin);
     LAUNCHCHK("k_scan_emit");
   } else if (d_n) {
     hipLaunchKernelGGL((k_scan_mask<Pred, false>), dim3(nb), dim3(SEL_THREADS), 0, ctx->stream, P, ix->n, ctx->scan_mask, ctx->scan_counts);
@@ -787,7 +823,7 @@ int run_scan(bmx_ctx* ctx, const Pred& P, const Index* ix, uint64_t* out_ids, ui
   if (pinned) {
     HIPCHK(hipStreamSynchronize(ctx->stream));
     const unsigned long long m = *d_n;
-    if (out_ids && m) std::memcpy(out_ids, d_out, std::min<uint64_t>(m, d_cap) * 8);
+    if (out_ids && m) std::memcpy(out_ids, d_out, std::min<uint64_t>(m, d_cap) * sizeof(OutT));
     if (n_out) *n_out = m;
     return BMX_OK;
   }
@@ -795,10 +831,14 @@ int run_scan(bmx_ctx* ctx, const Pred& P, const Index* ix, uint64_t* out_ids, ui
     unsigned long long m = 0;
     HIPCHK(hipMemcpyAsync(&m, &ctx->ds->n_out, sizeof(m), hipMemcpyDeviceToHost, ctx->stream));
     HIPCHK(hipStreamSynchronize(ctx->stream));
-    if (out_ids && m) HIPCHK(hipMemcpy(out_ids, ctx->scan_out, std::min<uint64_t>(m, d_cap) * 8, hipMemcpyDeviceToHost));
+    if (out_ids && m) HIPCHK(hipMemcpy(out_ids, ctx->scan_out, std::min<uint64_t>(m, d_cap) * sizeof(OutT), hipMemcpyDeviceToHost));
     if (n_out) *n_out = m;
   }
   return BMX_OK;
+}
+template <class Pred>
+int run_scan(bmx_ctx* ctx, const Pred& P, const Index* ix, uint64_t* out_ids, uint64_t cap, uint64_t* n_out, int mem) {
+  return run_scan_t<false>(ctx, P, ix, out_ids, cap, n_out, mem);
 }
 
 // second half of a deferred host-mode scan: wait for the scan enqueued with ctx->scan_defer set, deliver the count and up to `cap` ids
@@ -813,7 +853,8 @@ int scan_collect(bmx_ctx* ctx, uint64_t* out_ids, uint64_t cap, uint64_t* n_out)
   return BMX_OK;
 }
 
-int scan_range_impl(bmx_ctx* ctx, uint32_t field, int64_t lo, int64_t hi, uint64_t* out_ids, uint64_t cap, uint64_t* n_out, int mem) {
+template <bool POS>
+int scan_range_impl_t(bmx_ctx* ctx, uint32_t field, int64_t lo, int64_t hi, void* out, uint64_t cap, uint64_t* n_out, int mem) {
   if (mem != BMX_MEM_HOST && mem != BMX_MEM_DEVICE) return fail(ctx, BMX_ERR_INVALID, "bad mem kind");
   Index* ix;
   int rc = fresh_index(ctx, field, &ix);
@@ -823,10 +864,13 @@ int scan_range_impl(bmx_ctx* ctx, uint32_t field, int64_t lo, int64_t hi, uint64
     int64_t l = std::max<int64_t>(lo, INT32_MIN), h = std::min<int64_t>(hi, INT32_MAX);
     if (lo > INT32_MAX || hi < INT32_MIN) { l = 1; h = 0; }
     PredRange32 P{ix->v32, (int32_t)l, (int32_t)h};
-    return run_scan(ctx, P, ix, out_ids, cap, n_out, mem);
+    return run_scan_t<POS>(ctx, P, ix, out, cap, n_out, mem);
   }
   PredRange64 P{ix->v64, lo, hi};
-  return run_scan(ctx, P, ix, out_ids, cap, n_out, mem);
+  return run_scan_t<POS>(ctx, P, ix, out, cap, n_out, mem);
+}
+int scan_range_impl(bmx_ctx* ctx, uint32_t field, int64_t lo, int64_t hi, uint64_t* out_ids, uint64_t cap, uint64_t* n_out, int mem) {
+  return scan_range_impl_t<false>(ctx, field, lo, hi, out_ids, cap, n_out, mem);
 }
 
 }  // namespace
@@ -887,6 +931,13 @@ int bmx_create_ex(int device, uint64_t capacity_rows, uint32_t max_load_pct, uin
     ctx->host_rows[0] = 0; ctx->host_rows[1] = 0;
   } else { ctx->host_rows = nullptr; (void)hipGetLastError(); }
   ctx->fixed_capacity = (flags & BMX_CTX_FIXED_CAPACITY) != 0;
+  if (const char* v = getenv("BMX_K1_DBG")) ctx->k1_dbg = (uint32_t)atoi(v);
+  if (const char* v = getenv("BMX_K1_INSERTS")) {   // A/B switch (bench_micro/ab/): not part of the API
+    if (!strcmp(v, "inline")) ctx->ins_variant = INS_INLINE; else if (!strcmp(v, "launch")) ctx->ins_variant = INS_LAUNCH; else if (!strcmp(v, "block")) ctx->ins_variant = INS_BLOCK;
+    else if (!strcmp(v, "wave64")) { ctx->ins_variant = INS_WAVE; ctx->wave_nt = 64; } else if (!strcmp(v, "wave128")) { ctx->ins_variant = INS_WAVE; ctx->wave_nt = 128; }
+    else if (!strcmp(v, "wave256")) { ctx->ins_variant = INS_WAVE; ctx->wave_nt = 256; }
+    else if (!strcmp(v, "nobar")) ctx->ins_variant = INS_NOBAR; else if (!strcmp(v, "lastwave")) ctx->ins_variant = INS_LASTWAVE;
+  }
   ctx->bucketed_default = (flags & BMX_CTX_BUCKETED_MERGE) != 0;
   CR(hipMemsetAsync(ctx->ds, 0, sizeof(DevScalars), ctx->stream));
   hipLaunchKernelGGL(k_init_slots, dim3(2048), dim3(256), 0, ctx->stream, ctx->slots, nslots);
@@ -902,7 +953,7 @@ void bmx_destroy(bmx_ctx* ctx) {
   (void)hipSetDevice(ctx->device);
   if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
   for (auto& ix : ctx->indexes) { dev_free(ix.ids); dev_free(ix.v64); dev_free(ix.v32); }
-  dev_free(ctx->slots); dev_free(ctx->ds); dev_free(ctx->next); dev_free(ctx->wflag); dev_free(ctx->slot_of); dev_free(ctx->blk_info); dev_free(ctx->blk_follow); dev_free(ctx->shard_ctr);
+  dev_free(ctx->slots); dev_free(ctx->ds); dev_free(ctx->next); dev_free(ctx->wflag); dev_free(ctx->slot_of); dev_free(ctx->blk_info); dev_free(ctx->blk_follow); dev_free(ctx->shard_ctr); dev_free(ctx->miss); dev_free(ctx->miss_n);
   if (ctx->copy_stream) (void)hipStreamSynchronize(ctx->copy_stream);
   for (int i = 0; i < 2; i++) {
     bmx_ctx::Staging& S = ctx->stg[i];
@@ -1136,6 +1187,11 @@ int bmx_index_drop(bmx_ctx* ctx, uint32_t field) {
     if (ctx->indexes[i].field == field) {
       dev_free(ctx->indexes[i].ids); dev_free(ctx->indexes[i].v64); dev_free(ctx->indexes[i].v32);
       ctx->indexes.erase(ctx->indexes.begin() + (long)i);
+      if (ctx->indexes.empty()) {   // nothing left to maintain: the merges stop logging and the maintenance memory goes back
+        ctx->chg_valid = false; ctx->chg_ub = 0;
+        dev_free(ctx->chg); ctx->chg_cap = 0;
+        dev_free(ctx->slot_pos); ctx->slot_pos_n = 0;
+      }
       return BMX_OK;
     }
   return fail(ctx, BMX_ERR_NO_INDEX, "no index on that field");
@@ -1168,6 +1224,27 @@ int bmx_scan_equals(bmx_ctx* ctx, uint32_t field, int64_t value, uint64_t* out_i
 }
 int bmx_scan_count(bmx_ctx* ctx, uint32_t field, int64_t lo, int64_t hi, uint64_t* n_out, int mem) {
   return bmx_scan_range(ctx, field, lo, hi, nullptr, 0, n_out, mem);
+}
+
+int bmx_scan_range_pos(bmx_ctx* ctx, uint32_t field, int64_t lo, int64_t hi, uint32_t* out_pos, uint64_t cap, uint64_t* n_out, int mem) {
+  if (!ctx) return fail(nullptr, BMX_ERR_INVALID, "null context");
+  HIPCHK(hipSetDevice(ctx->device));
+  return scan_range_impl_t<true>(ctx, field, lo, hi, out_pos, cap, n_out, mem);
+}
+
+int bmx_index_ids(bmx_ctx* ctx, uint32_t field, uint64_t first, uint64_t count, uint64_t* out_ids, int mem) {
+  if (!ctx) return fail(nullptr, BMX_ERR_INVALID, "null context");
+  if (mem != BMX_MEM_HOST && mem != BMX_MEM_DEVICE) return fail(ctx, BMX_ERR_INVALID, "bad mem kind");
+  HIPCHK(hipSetDevice(ctx->device));
+  Index* ix;
+  int rc = fresh_index(ctx, field, &ix);
+  if (rc) return rc;
+  if (first > ix->n || count > ix->n - first) return fail(ctx, BMX_ERR_INVALID, "bmx_index_ids: range beyond the index (bmx_index_size)");
+  if (count == 0) return BMX_OK;
+  if (!out_ids) return fail(ctx, BMX_ERR_INVALID, "null output");
+  HIPCHK(hipMemcpyAsync(out_ids, ix->ids + first, count * sizeof(uint64_t), host_or_dev(mem), ctx->stream));
+  if (mem == BMX_MEM_HOST) HIPCHK(hipStreamSynchronize(ctx->stream));
+  return BMX_OK;
 }
 
 int bmx_scan_filter(bmx_ctx* ctx, uint32_t nterms, const bmx_term* terms, uint64_t* out_ids, uint64_t cap, uint64_t* n_out, int mem) {

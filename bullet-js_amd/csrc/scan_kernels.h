@@ -201,6 +201,10 @@ struct EmitIds {  // index position -> node id (bounded by cap)
   const uint64_t* ids; uint64_t* out; uint64_t cap;
   __device__ void operator()(uint64_t pos, uint64_t i) const { if (out && pos < cap) out[pos] = ids[i]; }
 };
+struct EmitPos {  // index position itself (u32, bounded by cap): no read of the id column — the caller maps positions to whatever it mirrors per index row
+  uint32_t* out; uint64_t cap;
+  __device__ void operator()(uint64_t pos, uint64_t i) const { if (out && pos < cap) out[pos] = (uint32_t)i; }
+};
 struct FinishCount {  // total -> *n_out (device), optional
   unsigned long long* n_out;
   __device__ void operator()(uint64_t total, uint32_t*) const { if (n_out && threadIdx.x == 0) *n_out = total; }

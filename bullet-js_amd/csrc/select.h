@@ -120,6 +120,7 @@ __global__ __launch_bounds__(SEL_THREADS) void k_sel_write(Pred P, Emit Em, Fini
 // int32 column) and writes the matching ids at ranks derived from the counts of the PREVIOUS launch: no in-launch
 // communication between workgroups, any column size, deterministic element order.
 constexpr uint32_t SCAN_BLOCK_ELEMS = 8192;   // elements per block in both passes = 256 mask words
+constexpr uint32_t SCAN_SUB8_BLOCKS = 2048;   // beyond this many blocks (16.78M rows) the emit pass takes eight blocks per workgroup
 
 template <class Pred, bool WRITE_MASK>
 __global__ __launch_bounds__(SEL_THREADS) void k_scan_mask(Pred P, uint64_t n, uint32_t* __restrict__ mask_words, uint32_t* __restrict__ block_counts) {

@@ -222,6 +222,16 @@ int bmx_scan_range(bmx_ctx* ctx, uint32_t field, int64_t lo, int64_t hi, uint64_
 int bmx_scan_equals(bmx_ctx* ctx, uint32_t field, int64_t value, uint64_t* out_ids, uint64_t cap, uint64_t* n_out,
                     int mem);
 int bmx_scan_count(bmx_ctx* ctx, uint32_t field, int64_t lo, int64_t hi, uint64_t* n_out, int mem);
+/* Position output (same query as bmx_scan_range, src/bullet-query.js:221-261): out_pos[k] = the k-th match's POSITION in the index columns
+ * (u32, ascending) instead of its node id. The emit pass then never touches the id column — from ~6 % selectivity on, gathering ids reads
+ * most lines of that column and bounds the whole scan (profiles/traffic_scan.json). For callers that mirror something per index row
+ * (the JS host keeps child paths by position: GpuQuery): fetch the id column once with bmx_index_ids, map positions thereafter.
+ * Positions are stable while the index is maintained from the change log (rows only get appended); a full rebuild
+ * (bmx_index_refresh_counts: full_builds changes) renumbers them. */
+int bmx_scan_range_pos(bmx_ctx* ctx, uint32_t field, int64_t lo, int64_t hi, uint32_t* out_pos, uint64_t cap,
+                       uint64_t* n_out, int mem);
+/* ids[first .. first+count) of the index columns of `field` (brought up to date first), in position order. */
+int bmx_index_ids(bmx_ctx* ctx, uint32_t field, uint64_t first, uint64_t count, uint64_t* out_ids, int mem);
 /* Declarative subset of filter(path, fn) src/bullet-query.js:270-283: fn = AND of range terms over
  * fields of the same node. Arbitrary JS predicates stay on the host. */
 int bmx_scan_filter(bmx_ctx* ctx, uint32_t nterms, const bmx_term* terms, uint64_t* out_ids, uint64_t cap,

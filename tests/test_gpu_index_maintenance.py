@@ -260,3 +260,44 @@ def test_more_indexes_than_the_maintenance_pass_handles_and_appends_beyond_the_h
     check("after overflow", fields[:1])
     assert e.index_refresh_counts()[0] == full1                # maintained again
     e.close(); o.close()
+
+
+def test_overflow_of_an_index_that_was_not_the_one_asked_for():
+    """Two maintained indexes share the change log. A merge creates more rows of B's field than B's columns have head room for; then A is scanned
+    (which applies the log to BOTH and forgets it), then B. B must come back through a rebuild — it can never be refreshed from a later log, whose
+    entries no longer hold the rows it missed (bmx.hip refresh_from_log)."""
+    rng = np.random.default_rng(11)
+    nodes = 3000
+    e = bmx.Engine(capacity_rows=2_000_000, flags=bmx.CTX_FIXED_CAPACITY); o = Oracle()
+    ids = _ids(np.arange(nodes))
+    for f in (FA, FB):
+        v = rng.integers(-50, 51, nodes).astype(np.int64)
+        e.load_rows(ids, np.full(nodes, f, np.uint32), np.full(nodes, 5, np.int64), v); o.load_rows(ids, np.full(nodes, f, np.uint32), np.full(nodes, 5, np.int64), v)
+    e.index_build(FA); e.index_build(FB)
+
+    def check(tag, f):
+        got = np.sort(e.scan_range(f, -20, 20)); ref = np.sort(o.scan_range(f, -20, 20))
+        assert np.array_equal(got, ref), (tag, f, len(got), len(ref))
+        assert e.index_size(f) == o.scan_count(f, -2**62, 2**62), (tag, f)
+
+    for variant in ("scan B right away", "another merge before B is scanned"):
+        n = 120_000                                           # B: 3000 (+ earlier) rows + 64K + n/8 head room < 120000 new rows
+        base = 10_000_000 if variant.startswith("scan") else 20_000_000
+        d = (_ids(np.arange(base, base + n)), np.full(n, FB, np.uint32), np.full(n, 7, np.int64), rng.integers(-50, 51, n).astype(np.int64))
+        e.merge_batch(*d); o.merge_batch(*d, INSERT_REFERENCE)
+        full0, _ = e.index_refresh_counts()
+        check((variant, "A"), FA)                             # brings A up to date from the log; B's appended rows do not fit
+        if not variant.startswith("scan"):
+            m = 700                                           # new log entries behind the ones B missed
+            d = (_ids(np.concatenate([np.arange(base, base + m // 2), np.arange(30_000_000, 30_000_000 + m // 2)])), np.full(m, FB, np.uint32),
+                 np.full(m, 9, np.int64), rng.integers(-50, 51, m).astype(np.int64))
+            e.merge_batch(*d); o.merge_batch(*d, INSERT_REFERENCE)
+        check((variant, "B"), FB)
+        assert e.index_refresh_counts()[0] > full0, "B cannot have been maintained through the overflow: it must have been rebuilt"
+        check((variant, "A again"), FA)
+    # and with nothing left to maintain the merges stop logging; a new index starts from a fresh build
+    e.index_drop(FA); e.index_drop(FB)
+    d = (_ids(np.arange(40_000_000, 40_000_500)), np.full(500, FA, np.uint32), np.full(500, 7, np.int64), rng.integers(-50, 51, 500).astype(np.int64))
+    e.merge_batch(*d); o.merge_batch(*d, INSERT_REFERENCE)
+    check("after dropping every index", FA)
+    e.close(); o.close()

@@ -110,8 +110,8 @@ def test_empty_index_and_small_capacity():
         assert e.scan_count(FA, 1, 3) == 3           # auto re-created, like the reference's equals()/range()
 
 
-def test_scan_at_bench_size_properties():
-    """10M-row int32 column (config 3): counts add up across a partition of the value domain; equals matches a numpy count."""
+def test_scan_at_bench_size():
+    """10M-row int32 column (config 3): counts add up across a partition of the value domain; equals / range id sets equal numpy's."""
     R = 10_000_000
     ids = streams.splitmix64_np(np.arange(1, R + 1, dtype=np.uint64))
     with np.errstate(over="ignore"):
@@ -123,7 +123,74 @@ def test_scan_at_bench_size_properties():
         counts = [e.scan_count(FA, lo, hi) for lo, hi in parts]
         assert sum(counts) == R
         assert counts[3] == int((ages == 99).sum())
-        got = e.scan_equals(FA, 42)
-        assert len(got) == int((ages == 42).sum())
-        assert set(got[:1000].tolist()) <= set(ids[ages == 42].tolist())
-        assert len(np.unique(got)) == len(got)
+        for lo, hi in [(42, 42), (10, 19), (0, 49)]:        # full id-set comparison with numpy: 1 %, 10 %, 50 % of the rows
+            got = e.scan_range(FA, lo, hi)
+            assert np.array_equal(np.sort(got), _expected_ids(ids, ages, lo, hi)), (lo, hi)
+
+
+def _expected_ids(ids, vals, lo, hi):
+    return np.sort(ids[(vals >= lo) & (vals <= hi)])
+
+
+@pytest.mark.parametrize("wide", [False, True])
+def test_large_column_scans_match_numpy(wide):
+    """Index beyond 2048 scan blocks (16.78M rows): the emit pass takes EIGHT 8192-row blocks per workgroup (k_scan_emit<.., 8>) — its one-scan fast
+    path (<= 8192 matches in the eight blocks) and its block-by-block fall-through, workgroups on both sides of that limit in one scan, a row count
+    that is no multiple of 65536 (the last workgroup owns fewer than eight blocks, the last block is ragged). Full sorted-id-set comparison with numpy
+    for ids and for positions (reference: src/bullet-query.js:186-261 on a fresh index). int32 column and the int64 column of wide values."""
+    R = 20_000_003 + (4099 if wide else 0)
+    assert R > 2048 * 8192 and R % 65536 != 0
+    f = FS if wide else FA
+    sh = 33 if wide else 0
+    ids = streams.splitmix64_np(np.arange(1, R + 1, dtype=np.uint64))
+    with np.errstate(over="ignore"):
+        vals = ((streams.splitmix64_np(ids ^ np.uint64(0xABCDEF)) % np.uint64(1000)).astype(np.int64)) << sh
+    with bmx.Engine(R + 1000) as e:
+        for r0 in range(0, R, 5_000_000):
+            sl = slice(r0, min(R, r0 + 5_000_000))
+            e.load_rows(ids[sl], np.full(sl.stop - sl.start, f, np.uint32), np.full(sl.stop - sl.start, 5, np.int64), vals[sl])
+        assert e.index_size(f) == R
+        col_ids = e.index_ids(f)
+        assert len(col_ids) == R and np.array_equal(np.sort(col_ids), np.sort(ids))
+        # selectivity: 0.1 % and 10 % (fast path everywhere), 12.5 % (workgroups on both sides of the 8192-match limit), 20 % and 50 % (fall-through),
+        # nothing, everything
+        for lo, hi in [(42, 42), (100, 199), (100, 224), (300, 499), (0, 499), (2000, 3000), (-5, 5000)]:
+            want = _expected_ids(ids, vals, lo << sh, hi << sh)
+            got = e.scan_range(f, lo << sh, hi << sh)
+            assert len(got) == len(want), (wide, lo, hi, len(got), len(want))
+            assert e.scan_count(f, lo << sh, hi << sh) == len(want)
+            pos = e.scan_range_pos(f, lo << sh, hi << sh)
+            assert len(pos) == len(want) and (len(pos) < 2 or bool(np.all(pos[1:] > pos[:-1]))), (wide, lo, hi)
+            assert np.array_equal(col_ids[pos], got), (wide, lo, hi, "positions and ids name the same rows in the same order")
+            assert np.array_equal(np.sort(got), want), (wide, lo, hi)
+        # truncated outputs keep the full count
+        got = e.scan_range(f, 0, 499 << sh, cap=1000); pos = e.scan_range_pos(f, 0, 499 << sh, cap=1000)
+        assert len(got) == 1000 and np.array_equal(col_ids[pos], got)
+
+
+def test_positions_on_small_and_maintained_indexes():
+    """bmx_scan_range_pos / bmx_index_ids on the one-block-per-workgroup path, through the mapped-memory small-answer path and after rows were
+    appended by the change log: ids[pos] always equals the id-mode answer."""
+    rng = np.random.default_rng(21)
+    n = 50_000
+    ids = streams.splitmix64_np(np.arange(1, n + 1, dtype=np.uint64))
+    vals = rng.integers(-100, 101, n).astype(np.int64)
+    o = Oracle()
+    with bmx.Engine(400_000) as e:
+        e.load_rows(ids, np.full(n, FA, np.uint32), np.full(n, 5, np.int64), vals); o.load_rows(ids, np.full(n, FA, np.uint32), np.full(n, 5, np.int64), vals)
+        e.index_build(FA)
+        for b in range(3):
+            m = 20_000
+            rows = rng.integers(0, n + 30_000, m)
+            d = (streams.splitmix64_np(rows.astype(np.uint64) + np.uint64(1)), np.full(m, FA, np.uint32), rng.integers(6, 50, m).astype(np.int64), rng.integers(-100, 101, m).astype(np.int64))
+            e.merge_batch(*d); o.merge_batch(*d)
+            col = e.index_ids(FA)
+            assert len(col) == e.index_size(FA) == o.scan_count(FA, -2**62, 2**62)
+            for lo, hi in [(-100, 100), (0, 0), (7, 30), (200, 300), (5, 4)]:
+                got = e.scan_range(FA, lo, hi); pos = e.scan_range_pos(FA, lo, hi)
+                assert np.array_equal(col[pos], got), (b, lo, hi)
+                assert np.array_equal(np.sort(got), np.sort(o.scan_range(FA, lo, hi))), (b, lo, hi)
+            assert np.array_equal(e.index_ids(FA, 10, 5), col[10:15])
+        with pytest.raises(bmx.BmxError):
+            e.index_ids(FA, e.index_size(FA) - 1, 5)
+    o.close()
