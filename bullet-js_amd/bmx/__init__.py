@@ -17,6 +17,7 @@ OK = 0
 ERR_INVALID, ERR_HIP, ERR_FULL, ERR_NOMEM, ERR_RANGE, ERR_INTERNAL, ERR_NO_DEVICE, ERR_NO_INDEX, ERR_OVERFLOW = -1, -2, -3, -4, -5, -6, -7, -8, -9
 MEM_HOST, MEM_DEVICE = 0, 1
 INSERT_REFERENCE, INSERT_DELTA = 0, 1
+VAL_DELETED = -(1 << 63)   # BMX_VAL_DELETED: tombstone value of bmx_put_rows
 MERGE_UNIQUE_KEYS = 0x100
 MERGE_STRICT_FLAGS = 0x200
 MERGE_BUCKETED = 0x800
@@ -27,10 +28,10 @@ MAX_BATCH = 1 << 24
 
 EXPORTS = [
     "bmx_create", "bmx_create_ex", "bmx_destroy", "bmx_last_error", "bmx_abi_version", "bmx_get_info", "bmx_sync", "bmx_set_stream", "bmx_get_stream", "bmx_seq_signal", "bmx_seq_wait",
-    "bmx_load_rows", "bmx_merge_batch", "bmx_merge_submit", "bmx_merge_collect", "bmx_merge_records", "bmx_get_rows", "bmx_get_row", "bmx_dump_rows", "bmx_row_count", "bmx_reserve",
+    "bmx_load_rows", "bmx_put_rows", "bmx_merge_batch", "bmx_merge_submit", "bmx_merge_collect", "bmx_merge_records", "bmx_get_rows", "bmx_get_row", "bmx_dump_rows", "bmx_row_count", "bmx_reserve",
     "bmx_index_build", "bmx_index_drop", "bmx_index_size", "bmx_index_refresh_counts", "bmx_scan_range", "bmx_scan_equals", "bmx_scan_count", "bmx_scan_filter", "bmx_scan_range_pos", "bmx_index_ids",
     "bmx_owner_of", "bmx_partition_by_owner", "bmx_partition_by_owner_slabs", "bmx_timer_start", "bmx_timer_stop", "bmx_profile_enable", "bmx_profile_read", "bmx_profile_read_scan",
-    "bmx_comm_create", "bmx_comm_destroy", "bmx_comm_last_error", "bmx_comm_nshards", "bmx_comm_shard", "bmx_comm_sync", "bmx_comm_load_rows", "bmx_comm_merge",
+    "bmx_comm_create", "bmx_comm_destroy", "bmx_comm_last_error", "bmx_comm_nshards", "bmx_comm_shard", "bmx_comm_sync", "bmx_comm_load_rows", "bmx_comm_put_rows", "bmx_comm_merge",
     "bmx_comm_merge_dev", "bmx_comm_shard_result", "bmx_comm_row_count", "bmx_comm_get_rows", "bmx_comm_dump_rows", "bmx_comm_index_build",
     "bmx_comm_scan_range", "bmx_comm_scan_equals", "bmx_comm_scan_count", "bmx_comm_scan_filter",
     "bmx_vc_create", "bmx_vc_destroy", "bmx_vc_last_error", "bmx_vc_load_rows", "bmx_vc_merge_batch", "bmx_vc_get_rows", "bmx_vc_row_count", "bmx_vc_scan_range", "bmx_vc_merge_batch_dev", "bmx_vc_set_stream", "bmx_vc_sync",
@@ -95,6 +96,7 @@ def load_library():
     L.bmx_seq_signal.argtypes = [vp, vp, vp, u64]; L.bmx_seq_signal.restype = i32
     L.bmx_seq_wait.argtypes = [vp, vp, vp, u64]; L.bmx_seq_wait.restype = i32
     L.bmx_load_rows.argtypes = [vp, u64, vp, vp, vp, vp, i32]; L.bmx_load_rows.restype = i32
+    L.bmx_put_rows.argtypes = [vp, u64, vp, vp, vp, vp, i32]; L.bmx_put_rows.restype = i32
     L.bmx_merge_batch.argtypes = [vp, u64, vp, vp, vp, vp, i32, i32, vp, vp, vp, vp]; L.bmx_merge_batch.restype = i32
     L.bmx_merge_records.argtypes = [vp, u64, vp, i32, vp, vp, vp, vp]; L.bmx_merge_records.restype = i32
     L.bmx_merge_submit.argtypes = [vp, u64, vp, vp, vp, vp, i32, i32, C.POINTER(u64)]; L.bmx_merge_submit.restype = i32
@@ -129,6 +131,7 @@ def load_library():
     L.bmx_comm_shard.argtypes = [vp, u32]; L.bmx_comm_shard.restype = vp
     L.bmx_comm_sync.argtypes = [vp]; L.bmx_comm_sync.restype = i32
     L.bmx_comm_load_rows.argtypes = [vp, u64, vp, vp, vp, vp]; L.bmx_comm_load_rows.restype = i32
+    L.bmx_comm_put_rows.argtypes = [vp, u64, vp, vp, vp, vp]; L.bmx_comm_put_rows.restype = i32
     L.bmx_comm_merge.argtypes = [vp, u64, vp, vp, vp, vp, i32, vp, vp, vp]; L.bmx_comm_merge.restype = i32
     L.bmx_comm_merge_dev.argtypes = [vp, vp, vp, vp, vp, vp, i32, u64]; L.bmx_comm_merge_dev.restype = i32
     L.bmx_comm_shard_result.argtypes = [vp, u32, C.POINTER(vp), C.POINTER(vp), C.POINTER(vp), C.POINTER(vp), C.POINTER(u64)]; L.bmx_comm_shard_result.restype = i32
@@ -210,6 +213,11 @@ class Engine:
         id, field, ts, val = _np(id, np.uint64), _np(field, np.uint32), _np(ts, np.int64), _np(val, np.int64)
         self._chk(self.L.bmx_load_rows(self.h, len(id), _ptr(id), _ptr(field), _ptr(ts), _ptr(val), MEM_HOST))
 
+    def put_rows(self, id, field, ts, val):
+        """rows decided elsewhere, stored as given (unique keys per call); val == VAL_DELETED leaves a tombstone"""
+        id, field, ts, val = _np(id, np.uint64), _np(field, np.uint32), _np(ts, np.int64), _np(val, np.int64)
+        self._chk(self.L.bmx_put_rows(self.h, len(id), _ptr(id), _ptr(field), _ptr(ts), _ptr(val), MEM_HOST))
+
     def merge_batch(self, id, field, ts, val, insert_mode=INSERT_REFERENCE, want_flags=True):
         """Returns (applied_idx u32[w] ascending, flags u8[n] or None, MergeStats)."""
         id, field, ts, val = _np(id, np.uint64), _np(field, np.uint32), _np(ts, np.int64), _np(val, np.int64)
@@ -264,8 +272,9 @@ class Engine:
         id = np.zeros(n, np.uint64); field = np.zeros(n, np.uint32); ts = np.zeros(n, np.int64); val = np.zeros(n, np.int64)
         m = C.c_uint64()
         self._chk(self.L.bmx_dump_rows(self.h, n, _ptr(id), _ptr(field), _ptr(ts), _ptr(val), C.cast(C.byref(m), C.c_void_p), MEM_HOST))
-        assert m.value == n
-        return id, field, ts, val
+        assert m.value <= n       # tombstones hold a slot (row_count) but are not dumped
+        k = m.value
+        return id[:k], field[:k], ts[:k], val[:k]
 
     def index_build(self, field):
         self._chk(self.L.bmx_index_build(self.h, int(field)))
@@ -435,6 +444,10 @@ class Comm:
         id, field, ts, val = _np(id, np.uint64), _np(field, np.uint32), _np(ts, np.int64), _np(val, np.int64)
         self._chk(self.L.bmx_comm_load_rows(self.h, len(id), _ptr(id), _ptr(field), _ptr(ts), _ptr(val)))
 
+    def put_rows(self, id, field, ts, val):
+        id, field, ts, val = _np(id, np.uint64), _np(field, np.uint32), _np(ts, np.int64), _np(val, np.int64)
+        self._chk(self.L.bmx_comm_put_rows(self.h, len(id), _ptr(id), _ptr(field), _ptr(ts), _ptr(val)))
+
     def merge(self, id, field, ts, val, insert_mode=INSERT_REFERENCE):
         """host batch -> (applied_idx u32[w] ascending indices into the batch, MergeStats summed over the shards)"""
         id, field, ts, val = _np(id, np.uint64), _np(field, np.uint32), _np(ts, np.int64), _np(val, np.int64)
@@ -478,8 +491,9 @@ class Comm:
         id = np.zeros(n, np.uint64); field = np.zeros(n, np.uint32); ts = np.zeros(n, np.int64); val = np.zeros(n, np.int64)
         m = C.c_uint64()
         self._chk(self.L.bmx_comm_dump_rows(self.h, n, _ptr(id), _ptr(field), _ptr(ts), _ptr(val), C.byref(m)))
-        assert m.value == n
-        return id, field, ts, val
+        assert m.value <= n
+        k = m.value
+        return id[:k], field[:k], ts[:k], val[:k]
 
     def index_build(self, field):
         self._chk(self.L.bmx_comm_index_build(self.h, int(field)))

@@ -48,6 +48,7 @@ struct Index {
 
 thread_local std::string g_err;
 constexpr uint32_t PROF_MAX_CALLS = 64;
+constexpr int MERGE_FORCE_INTERNAL = 0x4000;   // insert_mode bit used by bmx_put_rows only (not in bmx.h)
 
 }  // namespace
 
@@ -63,12 +64,10 @@ struct bmx_ctx {
   uint32_t* next = nullptr;
   uint8_t* wflag = nullptr;
   uint32_t* slot_of = nullptr;
-  uint32_t* blk_info = nullptr;       // 2 x (ws_cap/256 + 16) block summaries: batch k uses half k & 1 (INS_WAVE zeroes the other half for batch k + 1)
-  uint32_t blk_half = 0, blk_par = 0; bool blk_clean[2] = {false, false}; int wave_nt = 64;
+  uint32_t* blk_info = nullptr;       // 2 x (ws_cap/256 + 16) block summaries: batch k uses half k & 1, k_probe_apply zeroes the other half for batch k + 1
+  uint32_t blk_half = 0, blk_par = 0; bool blk_clean[2] = {false, false};   // blk_clean[h]: half h is known to be all zero
   uint32_t* blk_follow = nullptr;     // ws_cap/256 epoch tags: a delta of the block got a follower on its row
   unsigned long long* shard_ctr = nullptr;  // CTR_SHARDS * CTR_STRIDE
-  int ins_variant = INS_NOBAR; uint32_t k1_dbg = 0;       // where k_probe_apply's absent keys get their rows (merge_kernels.h); BMX_K1_INSERTS=inline|block|launch overrides (A/B)
-  uint4* miss = nullptr; uint32_t* miss_n = nullptr;   // INS_LAUNCH only: ws_cap entries / ws_cap/256 counts
   // default merge path (bin_kernels.h): the batch regrouped by bin, tile by tile
   uint32_t bin_tiles_cap = 0;
   uint4* bin_stage = nullptr;         // bin_tiles_cap * BK_TILE records of 32 B
@@ -222,12 +221,11 @@ int ensure_workspace(bmx_ctx* ctx, uint64_t n) {
   uint64_t cap = std::max<uint64_t>(n, std::min<uint64_t>((uint64_t)ctx->ws_cap * 2, MAX_BATCH));
   cap = std::max<uint64_t>(cap, 1u << 16);
   cap = (cap + 255) & ~255ull;
-  dev_free(ctx->next); dev_free(ctx->wflag); dev_free(ctx->slot_of); dev_free(ctx->blk_info); dev_free(ctx->blk_follow); dev_free(ctx->miss); dev_free(ctx->miss_n);
+  dev_free(ctx->next); dev_free(ctx->wflag); dev_free(ctx->slot_of); dev_free(ctx->blk_info); dev_free(ctx->blk_follow);
   ctx->ws_cap = 0;
   int rc;
   if ((rc = dev_alloc(ctx, &ctx->next, cap)) || (rc = dev_alloc(ctx, &ctx->wflag, cap + 16)) || (rc = dev_alloc(ctx, &ctx->slot_of, cap))) return rc;
   if ((rc = dev_alloc(ctx, &ctx->blk_info, 2 * ((cap / 256 + 16 + 3) & ~3ull))) || (rc = dev_alloc(ctx, &ctx->blk_follow, cap / 256 + 16))) return rc;
-  if (ctx->ins_variant == INS_LAUNCH && ((rc = dev_alloc(ctx, &ctx->miss, cap)) || (rc = dev_alloc(ctx, &ctx->miss_n, cap / 256 + 16)))) return rc;
   HIPCHK(hipMemsetAsync(ctx->next, 0, cap * sizeof(uint32_t), ctx->stream));
   HIPCHK(hipMemsetAsync(ctx->blk_follow, 0, (cap / 256 + 16) * sizeof(uint32_t), ctx->stream));
   ctx->blk_half = (uint32_t)((cap / 256 + 16 + 3) & ~3ull);    // a multiple of four entries: both halves stay 16-byte aligned for the compaction's wide loads
@@ -330,10 +328,12 @@ int merge_core(bmx_ctx* ctx, uint64_t n, const uint64_t* id, const uint32_t* fie
                const bmx_delta_rec* recs, int insert_mode, uint32_t* applied_idx, uint64_t* n_applied, uint8_t* flags,
                bmx_merge_stats* stats) {
   if (n > MAX_BATCH) return fail(ctx, BMX_ERR_INVALID, "batch larger than 2^24 deltas: split it (sequential semantics are preserved)");
-  const bool unique = (insert_mode & BMX_MERGE_UNIQUE_KEYS) != 0;
+  const bool force = (insert_mode & MERGE_FORCE_INTERNAL) != 0;      // bmx_put_rows: unique keys, stored as given
+  const bool unique = (insert_mode & BMX_MERGE_UNIQUE_KEYS) != 0 || force;
   const bool strict = (insert_mode & BMX_MERGE_STRICT_FLAGS) != 0;
   const bool legacy = strict || unique || !((insert_mode & BMX_MERGE_BUCKETED) != 0 || ctx->bucketed_default);   // "legacy" = the one-lane-per-delta kernels
-  insert_mode &= ~(BMX_MERGE_UNIQUE_KEYS | BMX_MERGE_STRICT_FLAGS | BMX_MERGE_BUCKETED);
+  insert_mode &= ~(BMX_MERGE_UNIQUE_KEYS | BMX_MERGE_STRICT_FLAGS | BMX_MERGE_BUCKETED | MERGE_FORCE_INTERNAL);
+  if (force) insert_mode = BMX_INSERT_DELTA;
   if (unique && strict) return fail(ctx, BMX_ERR_INVALID, "BMX_MERGE_STRICT_FLAGS cannot be combined with BMX_MERGE_UNIQUE_KEYS");
   if (insert_mode != BMX_INSERT_REFERENCE && insert_mode != BMX_INSERT_DELTA) return fail(ctx, BMX_ERR_INVALID, "bad insert_mode");
   if (n == 0) {
@@ -372,11 +372,11 @@ int merge_core(bmx_ctx* ctx, uint64_t n, const uint64_t* id, const uint32_t* fie
   A.next = ctx->next; A.wflag = wflag; A.flags = flags;
   A.slot_of = ctx->slot_of; A.blk_follow = ctx->blk_follow; A.shard_ctr = ctr; A.status = &ctx->ds->status;
   A.blk_info = ctx->blk_info + (size_t)ctx->blk_par * ctx->blk_half; A.blk_next = ctx->blk_info + (size_t)(ctx->blk_par ^ 1u) * ctx->blk_half; A.blk_ents = ctx->blk_half;
-  const bool wave_k1 = legacy && !strict && ctx->ins_variant == INS_WAVE;
+  const bool wave_k1 = legacy && !strict;       // k_probe_apply: adds into its half, zeroes the other one
   if (wave_k1 && !ctx->blk_clean[ctx->blk_par]) HIPCHK(hipMemsetAsync(A.blk_info, 0, (size_t)ctx->blk_half * sizeof(uint32_t), ctx->stream));   // a batch on another path used this half last
   ctx->blk_clean[ctx->blk_par] = false; if (wave_k1) ctx->blk_clean[ctx->blk_par ^ 1u] = true;
   ctx->blk_par ^= 1u;
-  A.miss = ctx->miss; A.miss_n = ctx->miss_n; A.dbg = ctx->k1_dbg;
+  A.force = force ? 1u : 0u;
   const uint32_t blocks = (uint32_t)((n + 255) / 256);
   const uint32_t rblocks = blocks;   // one lane per delta
   hipEvent_t* pe = (ctx->prof_on && ctx->prof_n < PROF_MAX_CALLS) ? &ctx->prof_ev[4 * ctx->prof_n] : nullptr;
@@ -404,22 +404,15 @@ int merge_core(bmx_ctx* ctx, uint64_t n, const uint64_t* id, const uint32_t* fie
   if (strict) {
     hipLaunchKernelGGL((k_probe_link_strict<AOS>), dim3(blocks), dim3(256), 0, ctx->stream, A);
   } else {
-    // one instantiation per (insert mode, unique-key guarantee, insert placement); the placement is a context constant
-#define BMX_K1(MODE_, UNIQ_, INS_) hipLaunchKernelGGL((k_probe_apply<AOS, MODE_, UNIQ_, INS_>), dim3(blocks), dim3(256), 0, ctx->stream, A)
-#define BMX_K4(MODE_, UNIQ_) hipLaunchKernelGGL((k_insert_misses<AOS, MODE_, UNIQ_>), dim3((blocks + 7) / 8), dim3(256), 0, ctx->stream, A, blocks)
-#define BMX_K1W(MODE_, UNIQ_, NT_) hipLaunchKernelGGL((k_probe_apply_w<AOS, MODE_, UNIQ_, NT_>), dim3((uint32_t)((n + NT_ - 1) / NT_)), dim3(NT_), 0, ctx->stream, A)
-#define BMX_K1NB(MODE_, UNIQ_, DEFER_) hipLaunchKernelGGL((k_probe_apply_nb<AOS, MODE_, UNIQ_, DEFER_>), dim3(blocks), dim3(256), 0, ctx->stream, A)
-#define BMX_K1_INS(MODE_, UNIQ_) do { if (ctx->ins_variant == INS_INLINE) BMX_K1(MODE_, UNIQ_, INS_INLINE); else if (ctx->ins_variant == INS_BLOCK) BMX_K1(MODE_, UNIQ_, INS_BLOCK); \
-                                      else if (ctx->ins_variant == INS_NOBAR) BMX_K1NB(MODE_, UNIQ_, false); else if (ctx->ins_variant == INS_LASTWAVE) BMX_K1NB(MODE_, UNIQ_, true); \
-                                      else if (ctx->ins_variant == INS_WAVE) { if (ctx->wave_nt == 64) BMX_K1W(MODE_, UNIQ_, 64); else if (ctx->wave_nt == 128) BMX_K1W(MODE_, UNIQ_, 128); else BMX_K1W(MODE_, UNIQ_, 256); } \
-                                      else { BMX_K1(MODE_, UNIQ_, INS_LAUNCH); BMX_K4(MODE_, UNIQ_); } } while (0)
-    if (insert_mode == BMX_INSERT_REFERENCE) { if (unique) BMX_K1_INS(BMX_INSERT_REFERENCE, true); else BMX_K1_INS(BMX_INSERT_REFERENCE, false); }
-    else { if (unique) BMX_K1_INS(BMX_INSERT_DELTA, true); else BMX_K1_INS(BMX_INSERT_DELTA, false); }
-#undef BMX_K1_INS
-#undef BMX_K1NB
-#undef BMX_K1W
-#undef BMX_K4
-#undef BMX_K1
+    constexpr int NT = 64;    // every wave its own workgroup (profiles/r03_ab_inserts.log)
+    const dim3 grid((uint32_t)((n + NT - 1) / NT));
+    if (insert_mode == BMX_INSERT_REFERENCE) {
+      if (unique) hipLaunchKernelGGL((k_probe_apply<AOS, BMX_INSERT_REFERENCE, true, NT>), grid, dim3(NT), 0, ctx->stream, A);
+      else hipLaunchKernelGGL((k_probe_apply<AOS, BMX_INSERT_REFERENCE, false, NT>), grid, dim3(NT), 0, ctx->stream, A);
+    } else {
+      if (unique) hipLaunchKernelGGL((k_probe_apply<AOS, BMX_INSERT_DELTA, true, NT>), grid, dim3(NT), 0, ctx->stream, A);
+      else hipLaunchKernelGGL((k_probe_apply<AOS, BMX_INSERT_DELTA, false, NT>), grid, dim3(NT), 0, ctx->stream, A);
+    }
   }
   LAUNCHCHK("k_probe_apply");
   if (pe) HIPCHK(hipEventRecord(pe[1], ctx->stream));
@@ -444,7 +437,7 @@ int merge_core(bmx_ctx* ctx, uint64_t n, const uint64_t* id, const uint32_t* fie
   if (ctx->host_rows) { Fin.host_mirror = ctx->host_rows; Fin.seq = ++ctx->batch_seq; ctx->inflight.emplace_back(Fin.seq, n); }
   ChgLog L{};
   if (ctx->chg_valid) {
-    if (legacy && !strict && !unique && ctx->chg_ub + n <= ctx->chg_cap && ctx->nslots < (1ull << 31)) {
+    if (legacy && !strict && (!unique || force) && ctx->chg_ub + n <= ctx->chg_cap && ctx->nslots < (1ull << 31)) {
       L.chg = ctx->chg; L.base = &ctx->ds->chg_n[ctx->chg_par]; L.next = &ctx->ds->chg_n[ctx->chg_par ^ 1u];
       L.slot_of = ctx->slot_of; L.field = field; L.recs = recs; L.cap = ctx->chg_cap;
       ctx->chg_par ^= 1u; ctx->chg_ub += n;
@@ -860,13 +853,14 @@ int scan_range_impl_t(bmx_ctx* ctx, uint32_t field, int64_t lo, int64_t hi, void
   int rc = fresh_index(ctx, field, &ix);
   if (rc) return rc;
   if (ix->fits32) {
-    // every value fits int32: scan the 4-byte column with bounds clamped into int32 (an empty range stays empty)
-    int64_t l = std::max<int64_t>(lo, INT32_MIN), h = std::min<int64_t>(hi, INT32_MAX);
+    // every value fits int32: scan the 4-byte column with bounds clamped into int32 (an empty range stays empty). INT32_MIN itself is what a
+    // tombstone looks like in this column and is never matched (a real -2^31 makes the index wide: scan_kernels.h v32_of)
+    int64_t l = std::max<int64_t>(lo, (int64_t)INT32_MIN + 1), h = std::min<int64_t>(hi, INT32_MAX);
     if (lo > INT32_MAX || hi < INT32_MIN) { l = 1; h = 0; }
     PredRange32 P{ix->v32, (int32_t)l, (int32_t)h};
     return run_scan_t<POS>(ctx, P, ix, out, cap, n_out, mem);
   }
-  PredRange64 P{ix->v64, lo, hi};
+  PredRange64 P{ix->v64, std::max<int64_t>(lo, -VAL_MAX), hi};    // values live in +-(2^53-1): the clamp changes no answer and keeps tombstones (INT64_MIN) out
   return run_scan_t<POS>(ctx, P, ix, out, cap, n_out, mem);
 }
 int scan_range_impl(bmx_ctx* ctx, uint32_t field, int64_t lo, int64_t hi, uint64_t* out_ids, uint64_t cap, uint64_t* n_out, int mem) {
@@ -931,14 +925,6 @@ int bmx_create_ex(int device, uint64_t capacity_rows, uint32_t max_load_pct, uin
     ctx->host_rows[0] = 0; ctx->host_rows[1] = 0;
   } else { ctx->host_rows = nullptr; (void)hipGetLastError(); }
   ctx->fixed_capacity = (flags & BMX_CTX_FIXED_CAPACITY) != 0;
-  if (const char* v = getenv("BMX_K1_DBG")) ctx->k1_dbg = (uint32_t)atoi(v);
-  if (const char* v = getenv("BMX_K1_INSERTS")) {   // A/B switch (bench_micro/ab/): not part of the API
-    if (!strcmp(v, "inline")) ctx->ins_variant = INS_INLINE; else if (!strcmp(v, "launch")) ctx->ins_variant = INS_LAUNCH; else if (!strcmp(v, "block")) ctx->ins_variant = INS_BLOCK;
-    else if (!strcmp(v, "wave64")) { ctx->ins_variant = INS_WAVE; ctx->wave_nt = 64; } else if (!strcmp(v, "wave128")) { ctx->ins_variant = INS_WAVE; ctx->wave_nt = 128; }
-    else if (!strcmp(v, "wave256")) { ctx->ins_variant = INS_WAVE; ctx->wave_nt = 256; }
-    else if (!strcmp(v, "nobar")) ctx->ins_variant = INS_NOBAR; else if (!strcmp(v, "lastwave")) ctx->ins_variant = INS_LASTWAVE;
-  }
-  ctx->bucketed_default = (flags & BMX_CTX_BUCKETED_MERGE) != 0;
   CR(hipMemsetAsync(ctx->ds, 0, sizeof(DevScalars), ctx->stream));
   hipLaunchKernelGGL(k_init_slots, dim3(2048), dim3(256), 0, ctx->stream, ctx->slots, nslots);
   CR(hipGetLastError());
@@ -953,7 +939,7 @@ void bmx_destroy(bmx_ctx* ctx) {
   (void)hipSetDevice(ctx->device);
   if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
   for (auto& ix : ctx->indexes) { dev_free(ix.ids); dev_free(ix.v64); dev_free(ix.v32); }
-  dev_free(ctx->slots); dev_free(ctx->ds); dev_free(ctx->next); dev_free(ctx->wflag); dev_free(ctx->slot_of); dev_free(ctx->blk_info); dev_free(ctx->blk_follow); dev_free(ctx->shard_ctr); dev_free(ctx->miss); dev_free(ctx->miss_n);
+  dev_free(ctx->slots); dev_free(ctx->ds); dev_free(ctx->next); dev_free(ctx->wflag); dev_free(ctx->slot_of); dev_free(ctx->blk_info); dev_free(ctx->blk_follow); dev_free(ctx->shard_ctr);
   if (ctx->copy_stream) (void)hipStreamSynchronize(ctx->copy_stream);
   for (int i = 0; i < 2; i++) {
     bmx_ctx::Staging& S = ctx->stg[i];
@@ -1083,6 +1069,24 @@ int bmx_load_rows(bmx_ctx* ctx, uint64_t n, const uint64_t* id, const uint32_t* 
       rc = merge_core<false>(ctx, m, id + off, field + off, ts + off, val + off, nullptr, BMX_INSERT_DELTA, nullptr, nullptr, nullptr, nullptr);
     else
       rc = merge_host(ctx, m, id + off, field + off, ts + off, val + off, BMX_INSERT_DELTA, nullptr, nullptr, nullptr, nullptr);
+    if (rc) return rc;
+  }
+  return mem == BMX_MEM_DEVICE ? BMX_OK : check_status(ctx);
+}
+
+int bmx_put_rows(bmx_ctx* ctx, uint64_t n, const uint64_t* id, const uint32_t* field, const int64_t* ts, const int64_t* val, int mem) {
+  if (!ctx) return fail(nullptr, BMX_ERR_INVALID, "null context");
+  if (n && (!id || !field || !ts || !val)) return fail(ctx, BMX_ERR_INVALID, "null input column");
+  if (mem != BMX_MEM_HOST && mem != BMX_MEM_DEVICE) return fail(ctx, BMX_ERR_INVALID, "bad mem kind");
+  HIPCHK(hipSetDevice(ctx->device));
+  const uint64_t chunk = 1u << 22;
+  for (uint64_t off = 0; off < n; off += chunk) {
+    const uint64_t m = std::min<uint64_t>(chunk, n - off);
+    int rc;
+    if (mem == BMX_MEM_DEVICE)
+      rc = merge_core<false>(ctx, m, id + off, field + off, ts + off, val + off, nullptr, MERGE_FORCE_INTERNAL, nullptr, nullptr, nullptr, nullptr);
+    else
+      rc = merge_host(ctx, m, id + off, field + off, ts + off, val + off, MERGE_FORCE_INTERNAL, nullptr, nullptr, nullptr, nullptr);
     if (rc) return rc;
   }
   return mem == BMX_MEM_DEVICE ? BMX_OK : check_status(ctx);
@@ -1257,7 +1261,7 @@ int bmx_scan_filter(bmx_ctx* ctx, uint32_t nterms, const bmx_term* terms, uint64
   if (rc) return rc;
   PredFilter P;
   P.v = ix->v64; P.ids = ix->ids; P.slots = ctx->slots; P.nslots = ctx->nslots; P.nterms = nterms;
-  for (uint32_t k = 0; k < nterms; k++) P.t[k] = terms[k];
+  for (uint32_t k = 0; k < nterms; k++) { P.t[k] = terms[k]; P.t[k].lo = std::max<int64_t>(terms[k].lo, -VAL_MAX); }   // tombstones (INT64_MIN) match no term
   return run_scan(ctx, P, ix, out_ids, cap, n_out, mem);
 }
 

@@ -45,20 +45,17 @@ struct MergeArgs {
                               //            W_PENDING = needs k_resolve_lists (duplicate key / reference-mode insert)
   uint8_t* flags;             // optional decision flags
   uint32_t* slot_of;          // per delta, written by the claimers of a row: the row's slot
-  uint32_t* blk_info;         // per 256-delta block: bit 31 = block has pending deltas, bits 0..30 = winners in the block
+  uint32_t* blk_info;         // per 256-delta block: winners in the block (this batch's half of the double buffer, zero when the batch starts)
   unsigned long long* shard_ctr;  // CTR_SHARDS x CTR_STRIDE counters: [s][0] rows created, [s][1] conflicts
   uint32_t* status;
-  // INS_LAUNCH only: deltas whose key the read-only probe did not find, per 256-delta block (k_insert_misses takes them)
-  uint4* miss;                // [blocks][256] {delta index, probes done, line lo, line hi}
-  uint32_t* miss_n;           // [blocks] entries used
-  uint32_t* blk_next;         // INS_WAVE: the block summaries of the NEXT batch (the other half of the double buffer): zeroed here
+  uint32_t* blk_next;         // the block summaries of the NEXT batch (the other half of the double buffer): zeroed by k_probe_apply
   uint32_t blk_ents;          // entries per half
-  uint32_t dbg;               // measurement-only switches (BMX_K1_DBG): 1 plain publishing store, 2 no per-wave counters, 4 no (ts,val) store for created rows
+  uint32_t force;             // bmx_put_rows: store every delta as given (unique keys, BMX_INSERT_DELTA); BMX_VAL_DELETED is a legal value then
 };
 
 constexpr uint8_t W_NONE = 0, W_WINNER = 1, W_PENDING = 2, W_FIRST = 4;   // W_FIRST (bit): first claimer of its row in this batch; bit 0 is what the compaction reads
 constexpr uint8_t W_CREATED = 8;   // (bit, on a winner) its row did not exist before this batch: the index change log appends it instead of updating it
-constexpr uint32_t BLK_PENDING = 0x80000000u, BLK_COUNT = 0x7FFFFFFFu;
+constexpr uint32_t BLK_COUNT = 0x7FFFFFFFu;
 // A single hot word takes only ~88 atomics/us (MI355X_MICROARCH.md "dequeue"), so per-batch counters are
 // spread over 256 words on separate 128-B lines and folded once per batch by the last compaction block.
 constexpr uint32_t CTR_SHARDS = 256, CTR_STRIDE = 16;
@@ -104,9 +101,10 @@ __device__ __forceinline__ void store_tv(Slot* sl, int64_t ts, int64_t val) {
 // spin in front of the store it is waiting for, whatever order the compiler gives the blocks inside the loop.
 template <bool UNIQUE>
 __device__ __forceinline__ bool probe_or_insert(const MergeArgs& A, uint32_t tag, uint64_t id, uint32_t field, uint64_t& slot_out,
-                                                bool& is_new, bool& created, uint32_t& prev_head, int64_t& cts, int64_t& cval,
-                                                ProbeSeq<4> ps, uint64_t p) {
+                                                bool& is_new, bool& created, uint32_t& prev_head, int64_t& cts, int64_t& cval) {
   created = false;
+  ProbeSeq<4> ps(id, field, A.nslots);
+  uint64_t p = 0;
   for (uint32_t round = 0; round < 256; ++round) {
     Slot* wait_on = nullptr;
     uint64_t s = 0;
@@ -125,8 +123,6 @@ __device__ __forceinline__ bool probe_or_insert(const MergeArgs& A, uint32_t tag
           // ONE aligned 8-byte agent-scope store publishes the field and claims the head together. A store (not an
           // exchange) is enough: other lanes of this key wait for the field before they touch the head, so nobody
           // can have claimed it earlier and every later claimer's exchange returns this tag.
-          if (A.dbg & 1u) *reinterpret_cast<volatile unsigned long long*>(&sl->field) = (unsigned long long)field | ((unsigned long long)(UNIQUE ? 0u : tag) << 32);
-          else
           __hip_atomic_store(reinterpret_cast<unsigned long long*>(&sl->field), (unsigned long long)field | ((unsigned long long)(UNIQUE ? 0u : tag) << 32),
                              __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
           prev_head = 0;
@@ -182,7 +178,7 @@ __device__ __forceinline__ void decide_and_claim(const MergeArgs& A, const uint3
                                                  const int64_t cts, const int64_t cval, const int64_t a, const int64_t v,
                                                  uint32_t& fl, uint32_t& wf, bool& conflict) {
   const uint32_t tag = (A.epoch << IDX_BITS) | j;
-  const int c = is_new ? 1 : lexcmp(a, v, cts, cval);
+  const int c = (is_new || A.force) ? 1 : lexcmp(a, v, cts, cval);
   if (c < 0) {
     // strictly below a pre-batch value or a value stored in this batch by a delta of a resident row:
     // it can never be the final value
@@ -194,11 +190,12 @@ __device__ __forceinline__ void decide_and_claim(const MergeArgs& A, const uint3
   if ((prev >> IDX_BITS) != A.epoch) {
     // first claimer of this row in this batch: its snapshot is the pre-batch row
     if (!UNIQUE) { A.slot_of[j] = (uint32_t)s; wf = W_FIRST; }   // it walks the row's list in k_resolve_lists if anybody follows
+    else if (A.force) A.slot_of[j] = (uint32_t)s;                // a put is logged for the maintained indexes like any other winner
     if (is_new) {
       // first write of an absent key: the reference stores clock {id:2} (src/bullet-crt.js:172-185);
       // the creation mark keeps later deltas of this key from comparing against this provisional value
       const int64_t t0 = (MODE == BMX_INSERT_REFERENCE) ? 2 : a;
-      if (!(A.dbg & 4u)) store_tv(sl, t0 | ((int64_t)A.epoch << TS_MARK_SHIFT), v);
+      store_tv(sl, t0 | ((int64_t)A.epoch << TS_MARK_SHIFT), v);
       wf |= W_WINNER | W_CREATED; fl = BMX_FLAG_INCOMING;
     } else if (c > 0) {
       store_tv(sl, a, v); wf |= W_WINNER; fl = BMX_FLAG_INCOMING;
@@ -212,249 +209,27 @@ __device__ __forceinline__ void decide_and_claim(const MergeArgs& A, const uint3
   }
 }
 
-// Read-only probe (phase 1 of the split kernels): PR_FOUND with the row's snapshot, or PR_MISS with `ps`/`p` left ON the slot that ended
-// the search — an empty slot (the key is absent), or a slot of this node whose field is not published yet (somebody is creating a row of this
-// node right now) — so that probe_or_insert can take over from exactly there. No atomic, no wait: nothing a sibling lane could be held up by.
-constexpr int PR_FOUND = 0, PR_MISS = 1, PR_FULL = 2;
-__device__ __forceinline__ int probe_readonly(const MergeArgs& A, const uint64_t id, const uint32_t field, ProbeSeq<4>& ps, uint64_t& p,
-                                              uint64_t& slot_out, bool& is_new, int64_t& cts, int64_t& cval) {
-  for (; p < A.nslots; ++p) {
-    const uint64_t s = ps.slot();
-    const uint4* q = reinterpret_cast<const uint4*>(A.slots + s);
-    const uint4 lo = q[0], hi = q[1];
-    const uint64_t sid = (uint64_t)lo.x | ((uint64_t)lo.y << 32);
-    if (sid == EMPTY_ID) return PR_MISS;
-    if (sid == id) {
-      if (lo.z == FIELD_PENDING) return PR_MISS;
-      if (lo.z == field) {
-        const int64_t t = (int64_t)((uint64_t)hi.x | ((uint64_t)hi.y << 32));
-        slot_out = s;
-        is_new = t == TS_NEW || ts_mark(t) == A.epoch;   // claimed but still unwritten, or created earlier in this very batch: no pre-batch state
-        cts = is_new ? TS_NEW : ts_value(t);
-        cval = (int64_t)((uint64_t)hi.z | ((uint64_t)hi.w << 32));
-        return PR_FOUND;
-      }
-    }
-    ps.next();
-  }
-  return PR_FULL;
-}
-
-// Where the rows an absent key needs are created (DESIGN.md §4, A/B in profiles/r03_ab_inserts.log):
-//   INS_INLINE  the lane that meets the empty slot creates the row inside its probe loop (rounds 1-2). With 10 % absent keys nearly every wave
-//               carries a creating lane, and the whole wave waits for that lane's compare-and-swap and its longer probe chain.
-//   INS_BLOCK   phase 1 probes read-only; the lanes whose key was not found leave their delta in LDS, and after a workgroup barrier the first
-//               ceil(misses/64) waves create those rows densely (phase 2). Three waves in four never execute a compare-and-swap.
-//   INS_LAUNCH  as INS_BLOCK, but the misses go to a per-block list in global memory and a second launch (k_insert_misses) creates them.
-constexpr int INS_INLINE = 0, INS_BLOCK = 1, INS_LAUNCH = 2, INS_NOBAR = 3, INS_LASTWAVE = 4, INS_WAVE = 5;   // 3, 4: k_probe_apply_nb; 5: k_probe_apply_w
-
-struct alignas(16) MissRec { uint64_t id; uint64_t line; int64_t ts; int64_t val; uint32_t field; uint32_t k; uint32_t j; uint32_t pad; };
-
-template <bool AOS, int MODE, bool UNIQUE, int INS>
-__global__ __launch_bounds__(256) void k_probe_apply(MergeArgs A) {
-  const uint32_t j = blockIdx.x * 256u + threadIdx.x;
-  const bool active = j < A.n;
-  uint64_t id = EMPTY_ID; uint32_t field = 0; int64_t a = 0, v = 0;
-  if (active) load_delta<AOS>(A, j, id, field, a, v);
-  const bool pad = AOS && id == EMPTY_ID;  // padding record of a fixed-size exchange slab
-  const bool valid = active && id != EMPTY_ID && field != FIELD_PENDING && a >= 0 && a <= TS_MAX && v >= -VAL_MAX && v <= VAL_MAX;
-  if (active && !valid && !pad) atomicOr(A.status, ST_RANGE);
-
-  uint32_t fl = 0, wf = W_NONE;
-  bool conflict = false, created = false;
-  // second delta a lane may take in phase 2 (INS_BLOCK): a miss of this workgroup, compacted through LDS
-  uint32_t fl2 = 0, wf2 = W_NONE, j2 = ~0u;
-  bool conflict2 = false, created2 = false, miss = false;
-  __shared__ uint32_t s_w[4], s_p[4];
-  if constexpr (INS == INS_INLINE) {
-    if (valid) {
-      bool is_new; int64_t cts, cval; uint64_t s; uint32_t prev = 0;
-      const uint32_t tag = (A.epoch << IDX_BITS) | j;
-      if (probe_or_insert<UNIQUE>(A, tag, id, field, s, is_new, created, prev, cts, cval, ProbeSeq<4>(id, field, A.nslots), 0))
-        decide_and_claim<MODE, UNIQUE>(A, j, s, is_new, created, prev, cts, cval, a, v, fl, wf, conflict);
-    }
-  } else {
-    __shared__ MissRec s_miss[INS == INS_BLOCK ? 256 : 1];
-    __shared__ uint32_t s_nmiss;
-    if (threadIdx.x == 0) s_nmiss = 0;
-    __syncthreads();
-    ProbeSeq<4> ps(id, field, A.nslots);
-    uint64_t p = 0;
-    if (valid) {
-      bool is_new; int64_t cts, cval; uint64_t s;
-      const int pr = probe_readonly(A, id, field, ps, p, s, is_new, cts, cval);
-      if (pr == PR_FOUND) decide_and_claim<MODE, UNIQUE>(A, j, s, is_new, false, 0u, cts, cval, a, v, fl, wf, conflict);
-      else if (pr == PR_MISS) miss = true;
-      else atomicOr(A.status, ST_FULL);
-    }
-    // compact the misses of the workgroup (any order: what a key's deltas leave behind depends on their indices, not on who claims first)
-    const unsigned long long mm = __ballot(miss);
-    uint32_t wbase = 0;
-    if (mm) {
-      if (lane_id() == 0) wbase = atomicAdd(&s_nmiss, (uint32_t)__popcll(mm));
-      wbase = (uint32_t)__builtin_amdgcn_readfirstlane((int)wbase);
-    }
-    if (miss) {
-      const uint32_t r = wbase + (uint32_t)__popcll(mm & ((1ull << lane_id()) - 1ull));
-      if constexpr (INS == INS_BLOCK) {
-        MissRec m; m.id = id; m.line = ps.line; m.ts = a; m.val = v; m.field = field; m.k = ps.k; m.j = j; m.pad = 0;
-        s_miss[r] = m;
-      } else {
-        A.miss[(size_t)blockIdx.x * 256u + r] = make_uint4(j, ps.k, (uint32_t)ps.line, (uint32_t)(ps.line >> 32));
-      }
-    }
-    __syncthreads();
-    const uint32_t nmiss = s_nmiss;
-    if constexpr (INS == INS_LAUNCH) {
-      if (threadIdx.x == 0) A.miss_n[blockIdx.x] = nmiss;
-    } else if (threadIdx.x < nmiss) {
-      // phase 2: the misses, dense over the first waves of the workgroup
-      const MissRec m = s_miss[threadIdx.x];
-      j2 = m.j;
-      bool is_new; int64_t cts, cval; uint64_t s; uint32_t prev = 0;
-      ProbeSeq<4> ps2(m.id, m.field, A.nslots);
-      ps2.line = m.line; ps2.k = m.k;
-      if (probe_or_insert<UNIQUE>(A, (A.epoch << IDX_BITS) | j2, m.id, m.field, s, is_new, created2, prev, cts, cval, ps2, (uint64_t)m.k))
-        decide_and_claim<MODE, UNIQUE>(A, j2, s, is_new, created2, prev, cts, cval, m.ts, m.val, fl2, wf2, conflict2);
-      A.wflag[j2] = (uint8_t)wf2;
-      if (A.flags) A.flags[j2] = (uint8_t)fl2;
-    }
-  }
-  // per-wave counts into sharded counters (no return value: the wave does not wait for them)
-  {
-    const uint32_t nc = (uint32_t)__popcll(__ballot(created)) + (uint32_t)__popcll(__ballot(created2));
-    const uint32_t nx = (uint32_t)__popcll(__ballot(conflict)) + (uint32_t)__popcll(__ballot(conflict2));
-    if (lane_id() == 0 && (nc | nx) && !(A.dbg & 2u)) {
-      unsigned long long* ctr = A.shard_ctr + (size_t)((blockIdx.x * 4u + (threadIdx.x >> 6)) & (CTR_SHARDS - 1)) * CTR_STRIDE;
-      if (nc) atomicAdd(ctr + 0, (unsigned long long)nc);
-      if (nx) atomicAdd(ctr + 1, (unsigned long long)nx);
-    }
-  }
-  if (active && !(INS == INS_BLOCK && miss)) {       // a miss's bytes were written by the lane that took it in phase 2
-    A.wflag[j] = (uint8_t)wf;
-    if (A.flags) A.flags[j] = (uint8_t)fl;
-  }
-  // block summary for the two passes that follow: they skip blocks without pending deltas and need no counting phase
-  {
-    const uint32_t nw = (uint32_t)__popcll(__ballot((wf & W_WINNER) != 0)) + (uint32_t)__popcll(__ballot((wf2 & W_WINNER) != 0));
-    const unsigned long long mp = __ballot(wf == W_PENDING) | __ballot(wf2 == W_PENDING);
-    if (lane_id() == 0) { s_w[threadIdx.x >> 6] = nw; s_p[threadIdx.x >> 6] = mp != 0ull; }
-    __syncthreads();
-    if (threadIdx.x == 0)
-      A.blk_info[blockIdx.x] = (s_w[0] + s_w[1] + s_w[2] + s_w[3]) | ((s_p[0] | s_p[1] | s_p[2] | s_p[3]) ? BLK_PENDING : 0u);
-  }
-}
-
-// Barrier-free variants (INS_NOBAR, INS_LASTWAVE): the waves of a workgroup never wait for each other after the first instruction. Each wave adds
-// its winner count to LDS and takes a ticket; the wave that draws the last ticket writes the block summary. With DEFER the lanes whose key was not
-// found leave their delta in LDS (read-only probe, no compare-and-swap in the probe loop) and that LAST wave creates the rows, 64 at a time:
-// three waves in four retire after load -> exchange -> store, and nothing ever waits at a barrier behind a slow lane.
-template <bool AOS, int MODE, bool UNIQUE, bool DEFER>
-__global__ __launch_bounds__(256) void k_probe_apply_nb(MergeArgs A) {
-  __shared__ uint32_t s_ctl[4];                       // misses queued | waves arrived | winners | a delta is pending
-  __shared__ MissRec s_miss[DEFER ? 256 : 1];
-  if (threadIdx.x == 0) { s_ctl[0] = 0; s_ctl[1] = 0; s_ctl[2] = 0; s_ctl[3] = 0; }
-  __syncthreads();                                    // the only barrier: in front of the first memory instruction, nothing is in flight yet
-  const uint32_t j = blockIdx.x * 256u + threadIdx.x;
-  const bool active = j < A.n;
-  uint64_t id = EMPTY_ID; uint32_t field = 0; int64_t a = 0, v = 0;
-  if (active) load_delta<AOS>(A, j, id, field, a, v);
-  const bool pad = AOS && id == EMPTY_ID;
-  const bool valid = active && id != EMPTY_ID && field != FIELD_PENDING && a >= 0 && a <= TS_MAX && v >= -VAL_MAX && v <= VAL_MAX;
-  if (active && !valid && !pad) atomicOr(A.status, ST_RANGE);
-  uint32_t fl = 0, wf = W_NONE;
-  bool conflict = false, created = false, miss = false;
-  if constexpr (!DEFER) {
-    if (valid) {
-      bool is_new; int64_t cts, cval; uint64_t s; uint32_t prev = 0;
-      if (probe_or_insert<UNIQUE>(A, (A.epoch << IDX_BITS) | j, id, field, s, is_new, created, prev, cts, cval, ProbeSeq<4>(id, field, A.nslots), 0))
-        decide_and_claim<MODE, UNIQUE>(A, j, s, is_new, created, prev, cts, cval, a, v, fl, wf, conflict);
-    }
-  } else {
-    ProbeSeq<4> ps(id, field, A.nslots);
-    uint64_t p = 0;
-    if (valid) {
-      bool is_new; int64_t cts, cval; uint64_t s;
-      const int pr = probe_readonly(A, id, field, ps, p, s, is_new, cts, cval);
-      if (pr == PR_FOUND) decide_and_claim<MODE, UNIQUE>(A, j, s, is_new, false, 0u, cts, cval, a, v, fl, wf, conflict);
-      else if (pr == PR_MISS) miss = true;
-      else atomicOr(A.status, ST_FULL);
-    }
-    const unsigned long long mm = __ballot(miss);
-    if (mm) {
-      uint32_t wbase = 0;
-      if (lane_id() == 0) wbase = atomicAdd(&s_ctl[0], (uint32_t)__popcll(mm));
-      wbase = (uint32_t)__builtin_amdgcn_readfirstlane((int)wbase);
-      if (miss) {
-        MissRec m; m.id = id; m.line = ps.line; m.ts = a; m.val = v; m.field = field; m.k = ps.k; m.j = j; m.pad = 0;
-        s_miss[wbase + (uint32_t)__popcll(mm & ((1ull << lane_id()) - 1ull))] = m;
-      }
-    }
-  }
-  if (active && !miss) {
-    A.wflag[j] = (uint8_t)wf;
-    if (A.flags) A.flags[j] = (uint8_t)fl;
-  }
-  uint32_t nc = (uint32_t)__popcll(__ballot(created)), nx = (uint32_t)__popcll(__ballot(conflict));
-  const uint32_t nw = (uint32_t)__popcll(__ballot((wf & W_WINNER) != 0));
-  const bool pend = __ballot(wf == W_PENDING) != 0ull;
-  uint32_t ticket = 0;
-  __threadfence_block();                              // this wave's queue entries are in LDS before its ticket is
-  if (lane_id() == 0) {
-    if (nw) atomicAdd(&s_ctl[2], nw);
-    if (pend) atomicOr(&s_ctl[3], 1u);
-    ticket = atomicAdd(&s_ctl[1], 1u);
-  }
-  ticket = (uint32_t)__builtin_amdgcn_readfirstlane((int)ticket);
-  uint32_t nw2 = 0, pend2 = 0;
-  if (ticket == 3u) {                                 // last of the four waves
-    __threadfence_block();
-    if constexpr (DEFER) {
-      const uint32_t nmiss = s_ctl[0];
-      uint32_t c2 = 0, x2 = 0;
-      for (uint32_t t = lane_id(); t < nmiss; t += 64u) {
-        const MissRec m = s_miss[t];
-        bool is_new, cr = false, cf = false; int64_t cts, cval; uint64_t s; uint32_t prev = 0, f2 = 0, w2 = W_NONE;
-        ProbeSeq<4> ps2(m.id, m.field, A.nslots);
-        ps2.line = m.line; ps2.k = m.k;
-        if (probe_or_insert<UNIQUE>(A, (A.epoch << IDX_BITS) | m.j, m.id, m.field, s, is_new, cr, prev, cts, cval, ps2, (uint64_t)m.k))
-          decide_and_claim<MODE, UNIQUE>(A, m.j, s, is_new, cr, prev, cts, cval, m.ts, m.val, f2, w2, cf);
-        A.wflag[m.j] = (uint8_t)w2;
-        if (A.flags) A.flags[m.j] = (uint8_t)f2;
-        c2 += cr; x2 += cf; nw2 += (w2 & W_WINNER) != 0; pend2 |= w2 == W_PENDING;
-      }
-      nc += (uint32_t)__builtin_amdgcn_readlane((int)wave_incl_scan_u32(c2), 63);
-      nx += (uint32_t)__builtin_amdgcn_readlane((int)wave_incl_scan_u32(x2), 63);
-      nw2 = (uint32_t)__builtin_amdgcn_readlane((int)wave_incl_scan_u32(nw2), 63);
-      pend2 = __ballot(pend2 != 0) != 0ull;
-    }
-    if (lane_id() == 0) A.blk_info[blockIdx.x] = (s_ctl[2] + nw2) | ((s_ctl[3] | pend2) ? BLK_PENDING : 0u);
-  }
-  if (lane_id() == 0 && (nc | nx)) {                  // per-wave counts into sharded counters (no return value: the wave does not wait for them)
-    unsigned long long* ctr = A.shard_ctr + (size_t)((blockIdx.x * 4u + (threadIdx.x >> 6)) & (CTR_SHARDS - 1)) * CTR_STRIDE;
-    if (nc) atomicAdd(ctr + 0, (unsigned long long)nc);
-    if (nx) atomicAdd(ctr + 1, (unsigned long long)nx);
-  }
-}
-
-// INS_WAVE: no barrier and no LDS at all. A wave adds its winner count to its 256-delta block's summary with one global atomic that returns
-// nothing; the summaries are double-buffered and this launch zeroes the half the NEXT batch will add into (its last readers, the compaction of
-// the batch before, are long done). Waves of any workgroup size retire on their own: NT = 64 makes every wave its own workgroup.
+// K1. One lane per delta, NO workgroup barrier and no LDS: a wave adds its winner count to its 256-delta block's summary with one global atomic
+// that returns nothing; the summaries are double-buffered and this launch zeroes the half the NEXT batch will add into (its last readers, the
+// compaction of the batch before, are long done). Waves retire on their own — NT = 64 makes every wave its own workgroup — and the CU takes new
+// ones earlier. Measured against the rounds 1-2 kernel (block summary behind a __syncthreads) and against three ways of moving the row creations
+// out of the probing waves (LDS-compacted behind a barrier, by the last wave, by a second launch = SURVEY §2.1 K4): profiles/r03_ab_inserts.log —
+// the barrier cost 2-7 us per 1M-delta launch, every split of the creations cost more than it saved.
 template <bool AOS, int MODE, bool UNIQUE, int NT>
-__global__ __launch_bounds__(NT) void k_probe_apply_w(MergeArgs A) {
+__global__ __launch_bounds__(NT) void k_probe_apply(MergeArgs A) {
   const uint32_t j = blockIdx.x * (uint32_t)NT + threadIdx.x;
   for (uint32_t t = j; t < A.blk_ents; t += gridDim.x * (uint32_t)NT) A.blk_next[t] = 0u;
   const bool active = j < A.n;
   uint64_t id = EMPTY_ID; uint32_t field = 0; int64_t a = 0, v = 0;
   if (active) load_delta<AOS>(A, j, id, field, a, v);
   const bool pad = AOS && id == EMPTY_ID;
-  const bool valid = active && id != EMPTY_ID && field != FIELD_PENDING && a >= 0 && a <= TS_MAX && v >= -VAL_MAX && v <= VAL_MAX;
+  const bool valid = active && id != EMPTY_ID && field != FIELD_PENDING && a >= 0 && a <= TS_MAX && ((v >= -VAL_MAX && v <= VAL_MAX) || (A.force && v == VAL_DELETED));
   if (active && !valid && !pad) atomicOr(A.status, ST_RANGE);
   uint32_t fl = 0, wf = W_NONE;
   bool conflict = false, created = false;
   if (valid) {
     bool is_new; int64_t cts, cval; uint64_t s; uint32_t prev = 0;
-    if (probe_or_insert<UNIQUE>(A, (A.epoch << IDX_BITS) | j, id, field, s, is_new, created, prev, cts, cval, ProbeSeq<4>(id, field, A.nslots), 0))
+    if (probe_or_insert<UNIQUE>(A, (A.epoch << IDX_BITS) | j, id, field, s, is_new, created, prev, cts, cval))
       decide_and_claim<MODE, UNIQUE>(A, j, s, is_new, created, prev, cts, cval, a, v, fl, wf, conflict);
   }
   if (active) {
@@ -470,46 +245,6 @@ __global__ __launch_bounds__(NT) void k_probe_apply_w(MergeArgs A) {
       if (nc) atomicAdd(ctr + 0, (unsigned long long)nc);
       if (nx) atomicAdd(ctr + 1, (unsigned long long)nx);
     }
-  }
-}
-
-// K4 (INS_LAUNCH): the deltas whose key k_probe_apply did not find, eight 256-delta blocks per workgroup, dense. Creates the rows
-// (src/bullet-crt.js:172-185, the "no current state" branch) or — when another delta of the same key got there first — claims and links like any
-// other duplicate. Adjusts the winner bytes and the per-block summaries k_probe_apply left for these deltas.
-template <bool AOS, int MODE, bool UNIQUE>
-__global__ __launch_bounds__(256) void k_insert_misses(MergeArgs A, uint32_t nblocks) {
-  __shared__ uint32_t s_off[9];
-  const uint32_t b0 = blockIdx.x * 8u;
-  if (threadIdx.x < 8) s_off[threadIdx.x + 1] = b0 + threadIdx.x < nblocks ? A.miss_n[b0 + threadIdx.x] : 0u;
-  __syncthreads();
-  if (threadIdx.x == 0) { s_off[0] = 0; for (int i = 1; i <= 8; i++) s_off[i] += s_off[i - 1]; }
-  __syncthreads();
-  const uint32_t total = s_off[8];
-  uint32_t ncr = 0, ncf = 0;   // rows this lane created / duplicates it linked (a lane takes more than one delta when the group holds > 256 misses)
-  for (uint32_t t = threadIdx.x; t < total; t += 256u) {
-    uint32_t b = 0;
-#pragma unroll
-    for (int i = 1; i < 8; i++) b += t >= s_off[i];
-    const uint4 m = A.miss[(size_t)(b0 + b) * 256u + (t - s_off[b])];
-    const uint32_t j = m.x;
-    uint64_t id; uint32_t field; int64_t a, v;
-    load_delta<AOS>(A, j, id, field, a, v);
-    ProbeSeq<4> ps(id, field, A.nslots);
-    ps.line = (uint64_t)m.z | ((uint64_t)m.w << 32); ps.k = m.y;
-    bool is_new, cr = false, cf = false; int64_t cts, cval; uint64_t s; uint32_t prev = 0, fl = 0, wf = W_NONE;
-    if (probe_or_insert<UNIQUE>(A, (A.epoch << IDX_BITS) | j, id, field, s, is_new, cr, prev, cts, cval, ps, (uint64_t)m.y))
-      decide_and_claim<MODE, UNIQUE>(A, j, s, is_new, cr, prev, cts, cval, a, v, fl, wf, cf);
-    ncr += cr; ncf += cf;
-    A.wflag[j] = (uint8_t)wf;
-    if (A.flags) A.flags[j] = (uint8_t)fl;
-    if (wf & W_WINNER) atomicAdd(&A.blk_info[j >> 8], 1u);
-    if (wf == W_PENDING) atomicOr(&A.blk_info[j >> 8], BLK_PENDING);
-  }
-  const uint32_t nc = (uint32_t)__builtin_amdgcn_readlane((int)wave_incl_scan_u32(ncr), 63), nx = (uint32_t)__builtin_amdgcn_readlane((int)wave_incl_scan_u32(ncf), 63);
-  if (lane_id() == 0 && (nc | nx)) {
-    unsigned long long* ctr = A.shard_ctr + (size_t)((blockIdx.x * 4u + (threadIdx.x >> 6)) & (CTR_SHARDS - 1)) * CTR_STRIDE;
-    if (nc) atomicAdd(ctr + 0, (unsigned long long)nc);
-    if (nx) atomicAdd(ctr + 1, (unsigned long long)nx);
   }
 }
 
@@ -636,14 +371,14 @@ __global__ __launch_bounds__(256) void k_probe_link_strict(MergeArgs A) {
   uint64_t id = EMPTY_ID; uint32_t field = 0; int64_t a = 0, v = 0;
   if (active) load_delta<AOS>(A, j, id, field, a, v);
   const bool pad = AOS && id == EMPTY_ID;
-  const bool valid = active && id != EMPTY_ID && field != FIELD_PENDING && a >= 0 && a <= TS_MAX && v >= -VAL_MAX && v <= VAL_MAX;
+  const bool valid = active && id != EMPTY_ID && field != FIELD_PENDING && a >= 0 && a <= TS_MAX && ((v >= -VAL_MAX && v <= VAL_MAX) || (A.force && v == VAL_DELETED));
   if (active && !valid && !pad) atomicOr(A.status, ST_RANGE);
   uint32_t slot = STRICT_NO_ROW;
   bool conflict = false, created = false;
   if (valid) {
     bool is_new; int64_t cts, cval; uint64_t s; uint32_t prev = 0;
     const uint32_t tag = (A.epoch << IDX_BITS) | j;
-    if (probe_or_insert<false>(A, tag, id, field, s, is_new, created, prev, cts, cval, ProbeSeq<4>(id, field, A.nslots), 0)) {
+    if (probe_or_insert<false>(A, tag, id, field, s, is_new, created, prev, cts, cval)) {
       if (!created) prev = atomicExch(&(A.slots + s)->head, tag);
       if ((prev >> IDX_BITS) == A.epoch) { A.next[j] = (A.epoch << IDX_BITS) | (prev & IDX_MASK); conflict = true; }
       slot = (uint32_t)s;

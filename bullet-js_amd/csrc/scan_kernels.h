@@ -12,6 +12,11 @@
 
 namespace bmx {
 
+// A value in the int32 column. A tombstone (VAL_DELETED) becomes INT32_MIN, which no int32 scan matches (bounds are clamped to INT32_MIN + 1), and does
+// not count as a wide value; a real -2^31 therefore does count as wide (the index then scans its int64 column).
+__device__ __forceinline__ int32_t v32_of(int64_t v) { return v == VAL_DELETED ? INT32_MIN : (int32_t)v; }
+__device__ __forceinline__ bool is_wide(int64_t v) { return v != VAL_DELETED && (v != (int64_t)(int32_t)v || v == (int64_t)INT32_MIN); }
+
 // ---- predicates over the resident table (index build, dump) ----
 struct PredSlotField {  // slots holding a row of `field`
   static constexpr int E = 2;
@@ -30,7 +35,7 @@ struct PredSlotField {  // slots holding a row of `field`
     return m;
   }
 };
-struct PredSlotAny {  // every occupied slot
+struct PredSlotAny {  // every occupied slot that holds data (tombstones are not dumped)
   static constexpr int E = 2;
   const Slot* slots;
   __device__ uint32_t mask(uint64_t first, uint64_t n) const {
@@ -39,8 +44,10 @@ struct PredSlotAny {  // every occupied slot
     for (int e = 0; e < E; e++) {
       uint64_t s = first + e;
       if (s < n) {
-        uint4 lo = reinterpret_cast<const uint4*>(slots + s)[0];
-        if (!(lo.x == 0xFFFFFFFFu && lo.y == 0xFFFFFFFFu)) m |= 1u << e;
+        const uint4* q = reinterpret_cast<const uint4*>(slots + s);
+        uint4 lo = q[0], hi = q[1];
+        const int64_t v = (int64_t)((uint64_t)hi.z | ((uint64_t)hi.w << 32));
+        if (!(lo.x == 0xFFFFFFFFu && lo.y == 0xFFFFFFFFu) && v != VAL_DELETED) m |= 1u << e;
       }
     }
     return m;
@@ -52,8 +59,8 @@ struct EmitIndex {  // slot -> index columns (+ the slot's position in its index
   __device__ void operator()(uint64_t pos, uint64_t s) const {
     const Slot& sl = slots[s];
     int64_t v = sl.val;
-    ids[pos] = sl.id; v64[pos] = v; v32[pos] = (int32_t)v;
-    if (v != (int64_t)(int32_t)v) *wide = 1u;
+    ids[pos] = sl.id; v64[pos] = v; v32[pos] = v32_of(v);
+    if (is_wide(v)) *wide = 1u;
     if (slot_pos) slot_pos[s] = (uint32_t)pos;
   }
 };
@@ -95,8 +102,8 @@ struct EmitAppend {   // created row -> the end of the index columns, in log ord
     const uint32_t s = chg[i].x & ~CHG_CREATED;
     const Slot& sl = slots[s];
     const int64_t v = sl.val;
-    ids[pos] = sl.id; v64[pos] = v; v32[pos] = (int32_t)v;
-    if (v != (int64_t)(int32_t)v) *wide = 1u;
+    ids[pos] = sl.id; v64[pos] = v; v32[pos] = v32_of(v);
+    if (is_wide(v)) *wide = 1u;
     slot_pos[s] = (uint32_t)pos;
   }
 };
@@ -114,8 +121,8 @@ __global__ __launch_bounds__(256) void k_ix_update(const uint2* __restrict__ chg
     if (p == POS_NONE) continue;
     const uint4 hi = reinterpret_cast<const uint4*>(slots + s)[1];
     const int64_t v = (int64_t)((uint64_t)hi.z | ((uint64_t)hi.w << 32));
-    v64[p] = v; v32[p] = (int32_t)v;
-    if (v != (int64_t)(int32_t)v) *wide = 1u;
+    v64[p] = v; v32[p] = v32_of(v);
+    if (is_wide(v)) *wide = 1u;
   }
 }
 struct EmitRows {  // slot -> dumped row columns (bounded by cap)

@@ -16,6 +16,7 @@ constexpr uint32_t FIELD_PENDING = 0xFFFFFFFFu; // reserved field: slot claimed,
 constexpr int64_t TS_NEW = INT64_MIN;           // ts of an empty slot / of a row created in the running batch
 constexpr int64_t TS_MAX = (1ll << 53) - 1;     // JS safe-integer range
 constexpr int64_t VAL_MAX = (1ll << 53) - 1;
+constexpr int64_t VAL_DELETED = INT64_MIN;      // tombstone (== BMX_VAL_DELETED): below every legal value, so any delta at the tombstone's ts or later wins against it
 constexpr uint32_t IDX_BITS = 24;               // batch index bits in a head / next tag
 constexpr uint32_t IDX_MASK = (1u << IDX_BITS) - 1;
 constexpr uint32_t MAX_BATCH = 1u << IDX_BITS;

@@ -179,6 +179,18 @@ int bmx_merge_collect(bmx_ctx* ctx, uint64_t ticket, uint32_t* applied_idx, uint
 int bmx_merge_records(bmx_ctx* ctx, uint64_t n, const bmx_delta_rec* recs, int insert_mode, uint32_t* applied_idx,
                       uint64_t* n_applied, uint8_t* flags, bmx_merge_stats* stats);
 
+/* bmx_put_rows: rows whose outcome was decided ELSEWHERE are stored as given (no comparison with the resident row; absent rows are created
+ * with the given ts). This is how the host keeps the device table in step with writes it resolved itself — single puts, values or clocks the
+ * device cannot compare (src/bullet-crt.js:329-385 run on the host), and node-level writes: a dominating object REPLACES the node, so the
+ * fields it no longer carries are removed (src/bullet-crt.js:236-248), and `deleted` sync entries become setData(path, null)
+ * (src/bullet-network-sync.js:553-555). val == BMX_VAL_DELETED leaves a TOMBSTONE: the key keeps its slot and clock, but the row is no data —
+ * index builds, scans, filters and dumps skip it exactly as _addToIndex skips null values (src/bullet-query.js:83-85); bmx_get_rows reports it
+ * found with val == BMX_VAL_DELETED; a later merge or put of a real value brings it back (against a tombstone any delta with ts >= the
+ * tombstone's wins). Keys must be unique within one call (the caller keeps the last write per key). Maintained indexes follow through the
+ * change log like after any merge. */
+#define BMX_VAL_DELETED INT64_MIN
+int bmx_put_rows(bmx_ctx* ctx, uint64_t n, const uint64_t* id, const uint32_t* field, const int64_t* ts, const int64_t* val, int mem);
+
 /* ---- point reads ----------------------------------------------------------------------------
  * Replaces bullet._getData(path) + bullet.meta[path].vectorClock (src/bullet.js:115-129,
  * src/bullet-crt.js:331-333) for device-resident rows. found[i] = 1/0. */
@@ -289,6 +301,8 @@ uint32_t bmx_comm_nshards(const bmx_comm* comm);
 bmx_ctx* bmx_comm_shard(bmx_comm* comm, uint32_t shard);   /* borrowed: point reads, index handling, info of one shard */
 int bmx_comm_sync(bmx_comm* comm);
 int bmx_comm_load_rows(bmx_comm* comm, uint64_t n, const uint64_t* id, const uint32_t* field, const int64_t* ts, const int64_t* val);
+/* bmx_put_rows over the shards: every row goes to the shard that owns its node (host buffers). */
+int bmx_comm_put_rows(bmx_comm* comm, uint64_t n, const uint64_t* id, const uint32_t* field, const int64_t* ts, const int64_t* val);
 int bmx_comm_merge(bmx_comm* comm, uint64_t n, const uint64_t* id, const uint32_t* field, const int64_t* ts, const int64_t* val, int insert_mode,
                    uint32_t* applied_idx, uint64_t* n_applied, bmx_merge_stats* stats);
 int bmx_comm_merge_dev(bmx_comm* comm, const uint64_t* n, const uint64_t* const* id, const uint32_t* const* field, const int64_t* const* ts,

@@ -32,6 +32,7 @@
 
 #define ORC_INSERT_REFERENCE 0 /* stored clock of a first write is {localId: 2}: src/bullet-crt.js:172-185 + :33-60 */
 #define ORC_INSERT_DELTA     1 /* stored clock is the incoming one (true LWW); not what the reference does */
+#define ORC_VAL_DELETED INT64_MIN /* tombstone value (== BMX_VAL_DELETED): outside the value domain |val| <= 2^53-1 */
 
 typedef struct {
   uint64_t id;
@@ -96,7 +97,9 @@ static orc_row* append(orc_t* t, uint64_t id, uint32_t field) {
   return r;
 }
 
-/* Direct preload of resident rows: the harness state is set without a merge. */
+/* Direct preload of resident rows: the harness state is set without a merge. Also the restatement of bmx_put_rows: rows whose
+ * outcome was decided elsewhere are stored as given; val == ORC_VAL_DELETED leaves a tombstone (the reference's setData(path, null) for a
+ * deleted entry, src/bullet-network-sync.js:553-555: the key keeps its clock, _addToIndex skips the null value, src/bullet-query.js:83-85). */
 void orc_load_rows(orc_t* t, uint64_t n, const uint64_t* id, const uint32_t* field, const int64_t* ts, const int64_t* val) {
   for (uint64_t i = 0; i < n; i++) {
     orc_row* r = find(t, id[i], field[i]);
@@ -169,9 +172,13 @@ int orc_get_row(orc_t* t, uint64_t id, uint32_t field, int64_t* ts, int64_t* val
 }
 
 uint64_t orc_dump_rows(const orc_t* t, uint64_t cap, uint64_t* id, uint32_t* field, int64_t* ts, int64_t* val) {
-  uint64_t m = t->n < cap ? t->n : cap;
-  for (uint64_t i = 0; i < m; i++) { id[i] = t->rows[i].id; field[i] = t->rows[i].field; ts[i] = t->rows[i].ts; val[i] = t->rows[i].val; }
-  return t->n;
+  uint64_t m = 0;
+  for (uint64_t i = 0; i < t->n; i++) {
+    if (t->rows[i].val == ORC_VAL_DELETED) continue;          /* tombstones are not data */
+    if (m < cap) { id[m] = t->rows[i].id; field[m] = t->rows[i].field; ts[m] = t->rows[i].ts; val[m] = t->rows[i].val; }
+    m++;
+  }
+  return m;
 }
 
 static uint64_t splitmix64(uint64_t x) {
@@ -190,7 +197,8 @@ uint64_t orc_row_digest(uint64_t id, uint32_t field, int64_t ts, int64_t val) {
 }
 uint64_t orc_digest(const orc_t* t) {
   uint64_t d = 0;
-  for (uint64_t i = 0; i < t->n; i++) d += orc_row_digest(t->rows[i].id, t->rows[i].field, t->rows[i].ts, t->rows[i].val);
+  for (uint64_t i = 0; i < t->n; i++)
+    if (t->rows[i].val != ORC_VAL_DELETED) d += orc_row_digest(t->rows[i].id, t->rows[i].field, t->rows[i].ts, t->rows[i].val);
   return d;
 }
 
@@ -205,7 +213,7 @@ uint64_t orc_scan_range(const orc_t* t, uint32_t field, int64_t lo, int64_t hi, 
   uint64_t m = 0;
   for (uint64_t i = 0; i < t->n; i++) {
     const orc_row* r = &t->rows[i];
-    if (r->field != field) continue;
+    if (r->field != field || r->val == ORC_VAL_DELETED) continue;   /* _addToIndex skips null: src/bullet-query.js:83-85 */
     if (r->val >= lo && r->val <= hi) { if (out_ids && m < cap) out_ids[m] = r->id; m++; }
   }
   return m;
@@ -222,11 +230,11 @@ uint64_t orc_scan_filter_and(orc_t* t, uint32_t nterms, const uint32_t* fields, 
   if (nterms == 0) return 0;
   for (uint64_t i = 0; i < t->n; i++) {
     const orc_row* r = &t->rows[i];
-    if (r->field != fields[0] || r->val < lo[0] || r->val > hi[0]) continue;
+    if (r->field != fields[0] || r->val == ORC_VAL_DELETED || r->val < lo[0] || r->val > hi[0]) continue;
     int ok = 1;
     for (uint32_t k = 1; k < nterms && ok; k++) {
       orc_row* q = find(t, r->id, fields[k]);
-      ok = q && q->val >= lo[k] && q->val <= hi[k];
+      ok = q && q->val != ORC_VAL_DELETED && q->val >= lo[k] && q->val <= hi[k];
     }
     if (ok) { if (out_ids && m < cap) out_ids[m] = r->id; m++; }
   }

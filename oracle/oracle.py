@@ -13,6 +13,7 @@ _LIB = os.path.join(_HERE, "libbmx_oracle.so")
 
 FLAG_INCOMING, FLAG_CURRENT, FLAG_HISTORICAL = 1, 2, 4
 INSERT_REFERENCE, INSERT_DELTA = 0, 1
+VAL_DELETED = -(1 << 63)   # ORC_VAL_DELETED: tombstone value
 
 
 def build(force=False):
@@ -99,11 +100,13 @@ class Oracle:
         ok = self._L.orc_get_row(self._h, int(id), int(field), C.byref(ts), C.byref(val))
         return (ts.value, val.value) if ok else None
 
+    put_rows = load_rows     # rows decided elsewhere, stored as given (val == VAL_DELETED: tombstone): the restatement of bmx_put_rows
+
     def dump_rows(self):
         n = len(self)
         id = np.zeros(n, np.uint64); field = np.zeros(n, np.uint32); ts = np.zeros(n, np.int64); val = np.zeros(n, np.int64)
-        self._L.orc_dump_rows(self._h, n, _p(id, C.c_uint64), _p(field, C.c_uint32), _p(ts, C.c_int64), _p(val, C.c_int64))
-        return id, field, ts, val
+        m = int(self._L.orc_dump_rows(self._h, n, _p(id, C.c_uint64), _p(field, C.c_uint32), _p(ts, C.c_int64), _p(val, C.c_int64)))   # tombstones are not dumped
+        return id[:m], field[:m], ts[:m], val[:m]
 
     def digest(self):
         return int(self._L.orc_digest(self._h))

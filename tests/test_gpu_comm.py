@@ -137,3 +137,28 @@ def test_small_host_batches_are_routed_on_the_host(N):
             assert np.array_equal(applied, ow), (N, b, n)
             assert st.n_rows == len(o) and st.n_applied == len(ow), (N, b, n)
         assert rows_digest(*c.dump_rows()) == o.digest()
+
+
+@pytest.mark.parametrize("nshards", [1, 2, 4])
+def test_put_rows_and_tombstones_over_shards(nshards):
+    """bmx_comm_put_rows: rows decided on the host reach the shard that owns their node; tombstoned rows leave every shard's scans and dumps."""
+    from oracle.oracle import VAL_DELETED
+    from oracle import streams
+    rng = np.random.default_rng(90 + nshards)
+    n = 30_000
+    ids = streams.splitmix64_np(np.arange(1, n + 1, dtype=np.uint64))
+    f = streams.field_hash(1)
+    o = Oracle()
+    with bmx.Comm([0] * nshards, capacity_rows_per_shard=n) as c:
+        v = rng.integers(-100, 101, n).astype(np.int64)
+        c.load_rows(ids, np.full(n, f, np.uint32), np.full(n, 50, np.int64), v); o.load_rows(ids, np.full(n, f, np.uint32), np.full(n, 50, np.int64), v)
+        c.index_build(f)
+        sel = rng.choice(n, n // 3, replace=False)
+        vals = rng.integers(-100, 101, len(sel)).astype(np.int64)
+        vals[::4] = VAL_DELETED
+        d = (ids[sel], np.full(len(sel), f, np.uint32), rng.integers(1, 90, len(sel)).astype(np.int64), vals)
+        c.put_rows(*d); o.put_rows(*d)
+        for lo, hi in [(-2**62, 2**62), (-10, 10), (0, 0)]:
+            assert np.array_equal(np.sort(c.scan_range(f, lo, hi)), np.sort(o.scan_range(f, lo, hi))), (lo, hi)
+        assert rows_digest(*c.dump_rows()) == o.digest()
+    o.close()
