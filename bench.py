@@ -123,7 +123,7 @@ def js_host_rate():
     try:
         r = subprocess.run([node, os.path.join(ROOT, "bullet-js_amd", "js", "test", "e2e_rate.js"), "1000000", "200000", "5"], capture_output=True, text=True, timeout=240)
         j = json.loads(r.stdout.strip().splitlines()[-1])
-        j["sample"] = "5 batches of 200k sync entries (10 % new keys) against 1M resident keys; GpuCRT.mergeEntries / GpuCRT.mergeBatch over the N-API addon, host buffers"
+        j["sample"] = "5 batches of 200k sync entries (10 % new nodes) against 1M resident nodes, node-level resolution (one clock-row delta per entry + the winners' value rows); GpuCRT.mergeEntries (synchronous), GpuCRT.mergeEntriesPipelined (mergeEntriesAsync, two chunks in flight) and GpuCRT.mergeBatch (typed columns) over the N-API addon, host buffers"
         return j
     except Exception as e:
         return {"error": str(e)[:200]}
@@ -172,20 +172,33 @@ def scan_bench(bmx, dev, R, reps=20, wide=False):
             tscan = {q.split("/", 1)[1]: e for q, e in tj["queries"].items() if q.startswith(out["column"] + "/")}
     except Exception:
         tscan = {}
+    QUERIES = [("equals_0.1pct", 42, 42), ("range_1pct", 100, 109), ("range_10pct", 100, 199), ("range_50pct", 0, 499)]
+    want = {name: [0, 0] for name, _, _ in QUERIES}     # per query: match count and the wrap-around sum of the matching ids, from numpy while the rows are generated
     with bmx.Engine(capacity_rows=R + 1024 + 2 * D_PER_STEP, device=dev.index or 0) as e:
         for r0 in range(0, R, 10_000_000):          # load in 10M-row pieces: bounded host memory
             m = min(10_000_000, R - r0)
             ids = synth.splitmix64_np(np.arange(r0 + 1, r0 + m + 1, dtype=np.uint64))
             with np.errstate(over="ignore"):
                 ages = (synth.splitmix64_np(ids ^ np.uint64(0xABCDEF)) % np.uint64(1000)).astype(np.int64)
+                for name, lo, hi in QUERIES:
+                    sel = (ages >= lo) & (ages <= hi)
+                    want[name][0] += int(sel.sum()); want[name][1] = (want[name][1] + int(ids[sel].sum(dtype=np.uint64))) & ((1 << 64) - 1)
             e.load_rows(ids, np.full(m, fa, np.uint32), np.full(m, 5, np.int64), ages << sh)
         del ids, ages
         t0 = time.perf_counter(); e.index_build(fa); out["index_first_build_ms"] = round((time.perf_counter() - t0) * 1e3, 3)   # + one-time allocation of the maintenance map
         e.index_drop(fa)
         t0 = time.perf_counter(); e.index_build(fa); out["index_build_ms"] = round((time.perf_counter() - t0) * 1e3, 3)
         out_ids = torch.zeros(R, dtype=torch.int64, device=dev)
+        out_pos = torch.zeros(R, dtype=torch.int32, device=dev)
+        id_col = torch.zeros(R, dtype=torch.int64, device=dev)
+        e.index_ids_dev(fa, 0, R, id_col)           # the index's id column: what a position stands for (verification of the position output)
         n_out = torch.zeros(1, dtype=torch.int64, device=dev)
-        for name, lo, hi in [("equals_0.1pct", 42, 42), ("range_1pct", 100, 109), ("range_10pct", 100, 199), ("range_50pct", 0, 499)]:
+        checked = 0
+
+        def i64(x):
+            return x - (1 << 64) if x >= (1 << 63) else x
+
+        for name, lo, hi in QUERIES:
             for _ in range(3):
                 e.scan_range_dev(fa, lo << sh, hi << sh, out_ids, R, n_out)
             e.sync(); e.timer_start()
@@ -193,20 +206,47 @@ def scan_bench(bmx, dev, R, reps=20, wide=False):
                 e.scan_range_dev(fa, lo << sh, hi << sh, out_ids, R, n_out)
             ms = e.timer_stop() / reps
             m = int(n_out.item())
+            # every timed scan answers the same query: count and id checksum against numpy (after the timed region)
+            if m != want[name][0] or int(out_ids[:m].sum().item()) != i64(want[name][1]):
+                raise SystemExit("VERIFICATION FAILED: scan %s over %d %s rows: %d matches (numpy: %d) or a different id checksum" % (name, R, out["column"], m, want[name][0]))
+            # the same query with POSITION output (u32 index positions, no id gather): bmx_scan_range_pos
+            for _ in range(3):
+                e.scan_range_pos_dev(fa, lo << sh, hi << sh, out_pos, R, n_out)
+            e.sync(); e.timer_start()
+            for _ in range(reps):
+                e.scan_range_pos_dev(fa, lo << sh, hi << sh, out_pos, R, n_out)
+            ms_pos = e.timer_stop() / reps
+            mp = int(n_out.item())
+            if mp != m or int(id_col[out_pos[:mp].long()].sum().item()) != i64(want[name][1]):
+                raise SystemExit("VERIFICATION FAILED: position scan %s over %d %s rows names other rows than the id scan" % (name, R, out["column"]))
+            checked += 2
+            # the mask pass alone, un-bracketed: the count-only form of the same query (k_scan_mask without the mask write + a one-workgroup sum), back to back
+            e.sync(); e.timer_start()
+            for _ in range(reps):
+                e.scan_range_dev(fa, lo << sh, hi << sh, None, 0, n_out)
+            ms_cnt = e.timer_stop() / reps
             e.profile_enable(True)
             for _ in range(8):
                 e.scan_range_dev(fa, lo << sh, hi << sh, out_ids, R, n_out)
             kms, _ = e.profile_read_scan()
             e.profile_enable(False)
             alg = w * R + 8.0 * m
-            mask_s = kms["scan_mask"] * 1e-3
+            alg_pos = w * R + 4.0 * m
+            mask_s = ms_cnt * 1e-3
             out[name] = {"matches": m, "us": round(ms * 1e3, 2), "achieved_GBs": round(alg / (ms * 1e-3) / 1e9, 1), "frac_of_8TBs": round(alg / (ms * 1e-3) / 8e12, 4),
                          "rows_per_s": round(R / (ms * 1e-3)),
+                         "position_output": {"us": round(ms_pos * 1e3, 2), "achieved_GBs": round(alg_pos / (ms_pos * 1e-3) / 1e9, 1), "frac_of_8TBs": round(alg_pos / (ms_pos * 1e-3) / 8e12, 4),
+                                             "algorithmic_bytes": "w*R + 4*M"},
                          "roofline_mask_kernel": {"bound": "hbm", "kernel": "k_scan_mask", "achieved": round(w * R / mask_s / 1e9, 1) if mask_s > 0 else None, "peak": HBM_PEAK_GBS,
                                                   "unit": "GB/s", "frac": round(w * R / mask_s / 1e9 / HBM_PEAK_GBS, 4) if mask_s > 0 else None,
+                                                  "timed_as": "count-only scan (k_scan_mask without the mask write + one-workgroup sum), back to back, no event brackets: an upper bound of the kernel's duration",
+                                                  "count_only_scan_us": round(ms_cnt * 1e3, 2),
                                                   "traffic": tscan.get(name, {}).get("mask", {}).get("bytes_per_launch"),
                                                   "traffic_emit": tscan.get(name, {}).get("emit", {}).get("bytes_per_launch"),
-                                                  "kernel_us": {"scan_mask": round(kms["scan_mask"] * 1e3, 2), "offsets_and_emit": round(kms["emit"] * 1e3, 2)}}}
+                                                  "kernel_us_between_events": {"scan_mask": round(kms["scan_mask"] * 1e3, 2), "offsets_and_emit": round(kms["emit"] * 1e3, 2)}}}
+        out["verified"] = {"against": "numpy over the generated rows: match count and wrap-around sum of the matching ids, id output and position output (ids gathered through the index's id column)",
+                           "scans_checked": checked, "ok": True}
+        del out_pos, id_col
         # index maintenance: a 1M-delta merge on the indexed field (90 % updates of existing nodes, 10 % new nodes), then the first scan — which brings
         # the index up to date from the merge's change log instead of rebuilding it from the table (include/bmx.h "Maintenance")
         rng = np.random.default_rng(7)

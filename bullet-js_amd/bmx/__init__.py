@@ -18,6 +18,7 @@ ERR_INVALID, ERR_HIP, ERR_FULL, ERR_NOMEM, ERR_RANGE, ERR_INTERNAL, ERR_NO_DEVIC
 MEM_HOST, MEM_DEVICE = 0, 1
 INSERT_REFERENCE, INSERT_DELTA = 0, 1
 VAL_DELETED = -(1 << 63)   # BMX_VAL_DELETED: tombstone value of bmx_put_rows
+MERGE_MARK_CREATED, APPLIED_CREATED, APPLIED_INDEX = 0x1000, 0x80000000, 0x00FFFFFF
 MERGE_UNIQUE_KEYS = 0x100
 MERGE_STRICT_FLAGS = 0x200
 MERGE_BUCKETED = 0x800

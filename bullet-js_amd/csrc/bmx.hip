@@ -328,11 +328,12 @@ int merge_core(bmx_ctx* ctx, uint64_t n, const uint64_t* id, const uint32_t* fie
                const bmx_delta_rec* recs, int insert_mode, uint32_t* applied_idx, uint64_t* n_applied, uint8_t* flags,
                bmx_merge_stats* stats) {
   if (n > MAX_BATCH) return fail(ctx, BMX_ERR_INVALID, "batch larger than 2^24 deltas: split it (sequential semantics are preserved)");
+  const uint32_t mark_created = (insert_mode & BMX_MERGE_MARK_CREATED) ? 1u : 0u;
   const bool force = (insert_mode & MERGE_FORCE_INTERNAL) != 0;      // bmx_put_rows: unique keys, stored as given
   const bool unique = (insert_mode & BMX_MERGE_UNIQUE_KEYS) != 0 || force;
   const bool strict = (insert_mode & BMX_MERGE_STRICT_FLAGS) != 0;
-  const bool legacy = strict || unique || !((insert_mode & BMX_MERGE_BUCKETED) != 0 || ctx->bucketed_default);   // "legacy" = the one-lane-per-delta kernels
-  insert_mode &= ~(BMX_MERGE_UNIQUE_KEYS | BMX_MERGE_STRICT_FLAGS | BMX_MERGE_BUCKETED | MERGE_FORCE_INTERNAL);
+  const bool legacy = strict || unique || mark_created || !((insert_mode & BMX_MERGE_BUCKETED) != 0 || ctx->bucketed_default);   // "legacy" = the one-lane-per-delta kernels
+  insert_mode &= ~(BMX_MERGE_UNIQUE_KEYS | BMX_MERGE_STRICT_FLAGS | BMX_MERGE_BUCKETED | BMX_MERGE_MARK_CREATED | MERGE_FORCE_INTERNAL);
   if (force) insert_mode = BMX_INSERT_DELTA;
   if (unique && strict) return fail(ctx, BMX_ERR_INVALID, "BMX_MERGE_STRICT_FLAGS cannot be combined with BMX_MERGE_UNIQUE_KEYS");
   if (insert_mode != BMX_INSERT_REFERENCE && insert_mode != BMX_INSERT_DELTA) return fail(ctx, BMX_ERR_INVALID, "bad insert_mode");
@@ -446,7 +447,7 @@ int merge_core(bmx_ctx* ctx, uint64_t n, const uint64_t* id, const uint32_t* fie
     }
   }
   hipLaunchKernelGGL((k_compact_winners<FinishMerge>), dim3((uint32_t)((n + 4095) / 4096)), dim3(SEL_THREADS), 0, ks, wflag, A.blk_info, (uint32_t)n,
-                     applied_idx, Fin, L);
+                     applied_idx, Fin, L, mark_created);
   LAUNCHCHK("k_compact_winners");
   if (pe) { HIPCHK(hipEventRecord(pe[3], ks)); ctx->prof_n++; }
   ctx->nbatch++;

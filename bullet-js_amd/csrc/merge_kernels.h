@@ -55,6 +55,7 @@ struct MergeArgs {
 
 constexpr uint8_t W_NONE = 0, W_WINNER = 1, W_PENDING = 2, W_FIRST = 4;   // W_FIRST (bit): first claimer of its row in this batch; bit 0 is what the compaction reads
 constexpr uint8_t W_CREATED = 8;   // (bit, on a winner) its row did not exist before this batch: the index change log appends it instead of updating it
+constexpr uint8_t W_FIRSTWRITE = 16;   // (bit, on a winner) it is the delta that CREATED its row: what the row stores is the insert rule's clock (2 in reference mode), not the delta's own
 constexpr uint32_t BLK_COUNT = 0x7FFFFFFFu;
 // A single hot word takes only ~88 atomics/us (MI355X_MICROARCH.md "dequeue"), so per-batch counters are
 // spread over 256 words on separate 128-B lines and folded once per batch by the last compaction block.
@@ -196,7 +197,7 @@ __device__ __forceinline__ void decide_and_claim(const MergeArgs& A, const uint3
       // the creation mark keeps later deltas of this key from comparing against this provisional value
       const int64_t t0 = (MODE == BMX_INSERT_REFERENCE) ? 2 : a;
       store_tv(sl, t0 | ((int64_t)A.epoch << TS_MARK_SHIFT), v);
-      wf |= W_WINNER | W_CREATED; fl = BMX_FLAG_INCOMING;
+      wf |= W_WINNER | W_CREATED | W_FIRSTWRITE; fl = BMX_FLAG_INCOMING;    // (a first claimer with followers is corrected by k_resolve_lists: the creating delta is the smallest index)
     } else if (c > 0) {
       store_tv(sl, a, v); wf |= W_WINNER; fl = BMX_FLAG_INCOMING;
     }  // c == 0: identical clock and value: no-op, all flags false
@@ -295,7 +296,7 @@ __device__ __forceinline__ void resolve_one(const MergeArgs& A, const uint32_t j
   const bool is_new = tsw == TS_NEW || ts_mark(tsw) == A.epoch;  // row created in this batch: no pre-batch state
   const uint32_t base_owner = (wf & W_WINNER) ? j : ~0u;   // the first claimer stored iff it beat the pre-batch row
   int64_t bt, bv;
-  uint32_t owner;
+  uint32_t owner, created_by = ~0u;     // created_by: the delta whose write creates the row (the smallest index of the list)
   if (!is_new) {
     // Resident row (every hot key of a streaming replay): lexmax over the list with ties to the smaller index, starting from what the row
     // holds now — the pre-batch value, or the first claimer's if it won. A dozen instructions per hop: with one active lane per wave the walk
@@ -331,7 +332,7 @@ __device__ __forceinline__ void resolve_one(const MergeArgs& A, const uint32_t j
       }
     }
     // the row starts as (2 or t_j0, v_j0) owned by j0 (src/bullet-crt.js:172-185); the other deltas then compete against it
-    bt = (MODE == BMX_INSERT_REFERENCE) ? 2 : t_j0; bv = v_j0; owner = j0;
+    bt = (MODE == BMX_INSERT_REFERENCE) ? 2 : t_j0; bv = v_j0; owner = j0; created_by = j0;
     int64_t tm, vm; uint32_t om;
     if (top.best_except(j0, tm, vm, om) && lexcmp(tm, vm, bt, bv) > 0) { bt = tm; bv = vm; owner = om; }   // a tie keeps j0 (it has the smaller index)
   }
@@ -340,9 +341,11 @@ __device__ __forceinline__ void resolve_one(const MergeArgs& A, const uint32_t j
   if (base_owner != owner) {
     if (base_owner != ~0u) { A.wflag[base_owner] = W_NONE; atomicSub(&A.blk_info[base_owner >> 8], 1u); }
     if (owner != ~0u) {
-      A.wflag[owner] = is_new ? (uint8_t)(W_WINNER | W_CREATED) : W_WINNER; atomicAdd(&A.blk_info[owner >> 8], 1u);
+      A.wflag[owner] = is_new ? (uint8_t)(W_WINNER | W_CREATED | (owner == created_by ? W_FIRSTWRITE : 0)) : W_WINNER; atomicAdd(&A.blk_info[owner >> 8], 1u);
       A.slot_of[owner] = A.slot_of[j];    // the compaction's index change log names the winner's row
     }
+  } else if (is_new && owner != ~0u) {
+    A.wflag[owner] = (uint8_t)(W_FIRST | W_WINNER | W_CREATED | (owner == created_by ? W_FIRSTWRITE : 0));   // the first claimer stays the owner, but is it the creating delta?
   }
   if (owner != ~0u && A.flags) A.flags[owner] = (uint8_t)BMX_FLAG_INCOMING;
 }
@@ -445,7 +448,7 @@ __global__ __launch_bounds__(256) void k_resolve_strict(MergeArgs A) {
   if (APPLY) {
     if (owner != ~0u) {
       store_tv(sl, is_new ? (bt | ((int64_t)A.epoch << TS_MARK_SHIFT)) : bt, bv);
-      A.wflag[owner] = W_WINNER;
+      A.wflag[owner] = (uint8_t)(W_WINNER | (is_new ? W_CREATED | (owner == j0 ? W_FIRSTWRITE : 0) : 0));
       atomicAdd(&A.blk_info[owner >> 8], 1u);
     }
   } else if (A.flags) {

@@ -273,7 +273,7 @@ struct FinishMerge {  // totals -> caller; fold and clear the sharded per-batch 
 // EARLIER launches: no counting phase, no in-launch hand-off. One block = 4096 deltas = 16 count entries.
 template <class Finish>
 __global__ __launch_bounds__(SEL_THREADS) void k_compact_winners(const uint8_t* __restrict__ wflag, const uint32_t* __restrict__ blk_info, uint32_t n,
-                                                                  uint32_t* __restrict__ applied, Finish Fin, ChgLog L) {
+                                                                  uint32_t* __restrict__ applied, Finish Fin, ChgLog L, uint32_t mark_created = 0) {
   __shared__ uint32_t wsum[4];
   // both loads are issued before the first wait: this block's 16 winner bytes per lane and its share of the count prefix
   PredWinner P{wflag};
@@ -313,7 +313,12 @@ __global__ __launch_bounds__(SEL_THREADS) void k_compact_winners(const uint8_t* 
       loc[lp++] = (uint32_t)first + (uint32_t)e;
     }
     __syncthreads();
-    if (applied) for (uint32_t i = threadIdx.x; i < tot; i += SEL_THREADS) applied[offset + i] = loc[i];
+    if (applied) {
+      if (mark_created)   // BMX_MERGE_MARK_CREATED: bit 31 on the winners that created their row
+        for (uint32_t i = threadIdx.x; i < tot; i += SEL_THREADS) applied[offset + i] = loc[i] | ((wflag[loc[i]] & W_FIRSTWRITE) ? 0x80000000u : 0u);
+      else
+        for (uint32_t i = threadIdx.x; i < tot; i += SEL_THREADS) applied[offset + i] = loc[i];
+    }
     if (L.chg) {   // index change log: (slot | created, field) of every winner, behind the entries of the batches before
       const unsigned long long base = *L.base + offset;
       for (uint32_t i = threadIdx.x; i < tot; i += SEL_THREADS) {

@@ -26,8 +26,9 @@ class DeviceGraph {
     }
     this.keys = new KeyDictionary();
     this.batches = 0;
+    this.preOp = null;             // GpuCRT hangs its queue of host-decided rows here: flushed in front of every operation below
   }
-  mergeBatch(cols, mode) {
+  mergeBatch(cols, mode) {          // (merges come from GpuCRT, which decides itself what has to be flushed in front of them)
     this.batches++;
     if (this.comm) return this.native.commMergeBatch(this.comm, cols.id, cols.field, cols.ts, cols.val, mode | 0);   // no per-delta flags across shards
     return this.native.mergeBatch(this.handle, cols.id, cols.field, cols.ts, cols.val, mode | 0);
@@ -38,18 +39,23 @@ class DeviceGraph {
     return this.native.mergeBatchAsync(this.handle, cols.id, cols.field, cols.ts, cols.val, mode | 0);
   }
   reserve(capacityRows) { if (!this.comm) this.native.reserve(this.handle, capacityRows); }   // shards grow on their own
-  loadRows(cols) { return this.comm ? this.native.commLoadRows(this.comm, cols.id, cols.field, cols.ts, cols.val) : this.native.loadRows(this.handle, cols.id, cols.field, cols.ts, cols.val); }
-  getRows(id, field) { return this.comm ? this.native.commGetRows(this.comm, id, field) : this.native.getRows(this.handle, id, field); }
-  rowCount() { return this.comm ? this.native.commRowCount(this.comm) : this.native.rowCount(this.handle); }
-  dumpRows() { return this.comm ? this.native.commDumpRows(this.comm) : this.native.dumpRows(this.handle); }
-  indexBuild(f) { return this.comm ? this.native.commIndexBuild(this.comm, f) : this.native.indexBuild(this.handle, f); }
+  loadRows(cols) { if (this.preOp) this.preOp(); return this.comm ? this.native.commLoadRows(this.comm, cols.id, cols.field, cols.ts, cols.val) : this.native.loadRows(this.handle, cols.id, cols.field, cols.ts, cols.val); }
+  /* rows decided on the host, stored as given (bmx_put_rows); val === VAL_DELETED leaves a tombstone. Keys unique within one call. */
+  putRows(cols) { return this.comm ? this.native.commPutRows(this.comm, cols.id, cols.field, cols.ts, cols.val) : this.native.putRows(this.handle, cols.id, cols.field, cols.ts, cols.val); }
+  getRows(id, field) { if (this.preOp) this.preOp(); return this.comm ? this.native.commGetRows(this.comm, id, field) : this.native.getRows(this.handle, id, field); }
+  rowCount() { if (this.preOp) this.preOp(); return this.comm ? this.native.commRowCount(this.comm) : this.native.rowCount(this.handle); }
+  dumpRows() { if (this.preOp) this.preOp(); return this.comm ? this.native.commDumpRows(this.comm) : this.native.dumpRows(this.handle); }
+  indexBuild(f) { if (this.preOp) this.preOp(); return this.comm ? this.native.commIndexBuild(this.comm, f) : this.native.indexBuild(this.handle, f); }
   indexDrop(f) { return this.comm ? this.native.commIndexDrop(this.comm, f) : this.native.indexDrop(this.handle, f); }
-  indexSize(f) { return this.comm ? this.native.commIndexSize(this.comm, f) : this.native.indexSize(this.handle, f); }
+  indexSize(f) { if (this.preOp) this.preOp(); return this.comm ? this.native.commIndexSize(this.comm, f) : this.native.indexSize(this.handle, f); }
   /* {fullBuilds, incremental}: index rebuilds from the table vs updates from the merges' change log (one context only) */
   indexRefreshCounts() { return this.comm ? null : this.native.indexRefreshCounts(this.handle); }
-  scanRange(f, lo, hi) { return this.comm ? this.native.commScanRange(this.comm, f, lo, hi) : this.native.scanRange(this.handle, f, lo, hi); }
-  scanCount(f, lo, hi) { return this.comm ? this.native.commScanCount(this.comm, f, lo, hi) : this.native.scanCount(this.handle, f, lo, hi); }
-  scanFilter(terms) { return this.comm ? this.native.commScanFilter(this.comm, terms) : this.native.scanFilter(this.handle, terms); }
+  scanRange(f, lo, hi) { if (this.preOp) this.preOp(); return this.comm ? this.native.commScanRange(this.comm, f, lo, hi) : this.native.scanRange(this.handle, f, lo, hi); }
+  /* positions of the matches in the index columns (one context only: shards number their rows independently) and the ids behind positions */
+  scanRangePos(f, lo, hi) { if (this.preOp) this.preOp(); return this.native.scanRangePos(this.handle, f, lo, hi); }
+  indexIds(f, first, count) { if (this.preOp) this.preOp(); return this.native.indexIds(this.handle, f, first, count); }
+  scanCount(f, lo, hi) { if (this.preOp) this.preOp(); return this.comm ? this.native.commScanCount(this.comm, f, lo, hi) : this.native.scanCount(this.handle, f, lo, hi); }
+  scanFilter(terms) { if (this.preOp) this.preOp(); return this.comm ? this.native.commScanFilter(this.comm, terms) : this.native.scanFilter(this.handle, terms); }
   info() { return this.comm ? { nShards: this.nShards, devices: this.devices, nRows: this.rowCount() } : this.native.info(this.handle); }
   close() {
     if (this.handle) { this.native.destroy(this.handle); this.handle = null; }
@@ -122,6 +128,8 @@ class DeviceVcTable {
     }
     return { updated: Uint32Array.from(upd).sort(), flags, nRows };
   }
+  /* rows decided on the host, stored as given (bmx_put_rows); val === VAL_DELETED leaves a tombstone. Keys unique within one call. */
+  putRows(cols) { return this.comm ? this.native.commPutRows(this.comm, cols.id, cols.field, cols.ts, cols.val) : this.native.putRows(this.handle, cols.id, cols.field, cols.ts, cols.val); }
   getRows(id, field) {
     if (this.N === 1) return this.native.vcGetRows(this.handle, id, field);
     const n = id.length, K = this.K, back = this._split(id);

@@ -14,7 +14,7 @@
  *   - batches (sync chunks, bulk loads: src/bullet-network-sync.js:551-569) go to the MI355X through
  *     mergeBatch()/mergeEntries(): typed columns -> bmx_merge_batch. That path has no host implementation.
  */
-const { Columns, VcColumns, fieldId, isDeviceInt, scalarClock, denseClock } = require("./hash");
+const { Columns, VcColumns, fieldId, isDeviceInt, scalarClock, denseClock, NODE_CLOCK, VAL_DELETED } = require("./hash");
 
 const REASON = {
   fresh: "no current state",
@@ -32,13 +32,57 @@ function threeWay(a, b) {
 
 function isMergeable(v) { return typeof v === "object" && v !== null && !Array.isArray(v); }
 
-function growColumns(cols, rowEntry, rowField, used, cap) {
-  const bigger = new Columns(cap);
-  bigger.id.set(cols.id.subarray(0, used)); bigger.field.set(cols.field.subarray(0, used));
-  bigger.ts.set(cols.ts.subarray(0, used)); bigger.val.set(cols.val.subarray(0, used));
-  const re = new Int32Array(cap), rf = new Int32Array(cap);
-  re.set(rowEntry.subarray(0, used)); rf.set(rowField.subarray(0, used));
-  return { cols: bigger, rowEntry: re, rowField: rf, cap };
+/* value at `path` without the facade's autovivification (src/bullet.js:115-129 creates {} on the way): undefined when absent */
+function peek(root, path) {
+  let cur = root;
+  if (!path) return cur;
+  let from = 0;
+  for (;;) {
+    const cut = path.indexOf("/", from);
+    const seg = cut < 0 ? path.slice(from) : path.slice(from, cut);
+    if (seg) {
+      if (cur === null || typeof cur !== "object" || !Object.prototype.hasOwnProperty.call(cur, seg)) return undefined;
+      cur = cur[seg];
+    }
+    if (cut < 0) return cur;
+    from = cut + 1;
+  }
+}
+
+/* Rows for bmx_put_rows, kept as SEGMENTS that are sent in order, one call each (a call wants unique keys). Single host writes go to a segment that
+ * keeps the LAST write per key (a Map keyed by the row key: fine for a put at a time); the winners of a batch are unique by construction — one
+ * winner per node, one row per field — and are appended to a segment of their own with no look-up at all. */
+class PutQueue {
+  constructor() { this.segs = []; this.n = 0; }
+  _seg(dedupe, room) {
+    let sg = this.segs.length ? this.segs[this.segs.length - 1] : null;
+    if (!sg || sg.dedupe !== dedupe) { sg = { dedupe, n: 0, cap: Math.max(64, room), cols: new Columns(Math.max(64, room)), at: dedupe ? new Map() : null }; this.segs.push(sg); }
+    if (sg.n + room > sg.cap) {
+      let cap = sg.cap; while (sg.n + room > cap) cap *= 2;
+      const bigger = new Columns(cap);
+      bigger.id.set(sg.cols.id); bigger.field.set(sg.cols.field); bigger.ts.set(sg.cols.ts); bigger.val.set(sg.cols.val);
+      sg.cols = bigger; sg.cap = cap;
+    }
+    return sg;
+  }
+  push(lo, hi, field, ts, val) {                      // a single host write: the last one per key stays
+    const sg = this._seg(true, 1);
+    const key = lo + ":" + hi + ":" + field;
+    let i = sg.at.get(key);
+    if (i === undefined) { i = sg.n++; sg.at.set(key, i); this.n++; }
+    sg.cols.set2(i, lo, hi, field, ts, val);
+  }
+  pushUnique(lo, hi, field, ts, val) {                // a batch winner's row: unique within its batch by construction
+    const sg = this._seg(false, 1);
+    sg.cols.set2(sg.n++, lo, hi, field, ts, val);
+    this.n++;
+  }
+  closeBatch() {                                      // the next batch's rows may name the same keys: they start a new segment
+    if (this.segs.length && !this.segs[this.segs.length - 1].dedupe) this.segs.push({ dedupe: true, n: 0, cap: 64, cols: new Columns(64), at: new Map() });
+  }
+  /* rows of single host writes are waiting (they may be clock rows: a merge must see them); batch winners' value rows alone can wait for a reader */
+  hasHostRows() { for (const sg of this.segs) if (sg.dedupe && sg.n) return true; return false; }
+  take() { const out = this.segs.filter((sg) => sg.n > 0).map((sg) => sg.cols.slice(sg.n)); this.segs = []; this.n = 0; return out; }
 }
 
 function verdict(winner, clock, value, reason, extra) {
@@ -63,12 +107,17 @@ class GpuCRT {
     this.compare = threeWay;
     this._opts = opts;
     this._graph = opts.graph || null;
+    this._apiClocks = new Set();    // paths whose clock the public helpers touched before any write gave them a meta entry (entryEligible)
+    this._hostOnly = new Set();     // paths whose clock the device cannot hold (more than one writer, foreign key sets): their entries stay on the host
+    this._nodeSeq = 1;              // arrival number of node writes (val of the clock rows): a tie on the clock goes to the later write
+    this._puts = null;              // PutQueue: rows the host decided, not yet on the device
   }
 
   /* ---------------------------------------------------------------- clock bookkeeping (host) */
   setCompare(fn) { this.compare = fn; return this; }
 
   createVectorClock(key) {
+    if (!this._inUpdate) this._apiClocks.add(key);
     const c = {};
     c[this.bullet.id] = 1;
     this.vectorClocks.set(key, c);
@@ -153,6 +202,11 @@ class GpuCRT {
   }
 
   handleUpdate(path, incomingData, isFromNetwork = false) {
+    this._inUpdate = true;
+    try { return this._handleUpdate(path, incomingData, isFromNetwork); } finally { this._inUpdate = false; }
+  }
+
+  _handleUpdate(path, incomingData, isFromNetwork) {
     const currentData = this.bullet._getData(path);
     const currentClock = (this.bullet.meta[path] || {}).vectorClock;
 
@@ -179,7 +233,7 @@ class GpuCRT {
         : Object.assign({}, broadcastData, { __vectorClock: d.vectorClock });
     }
     const doUpdate = d.incoming || !currentClock || d.concurrent;
-    if (doUpdate) this._queueDeviceWrite(path, d.value, d.vectorClock);
+    if (doUpdate) this._mirrorWrite(path, currentData, d.value, d.vectorClock);
     return {
       value: d.value,
       vectorClock: d.vectorClock,
@@ -190,32 +244,132 @@ class GpuCRT {
   }
 
   /*
-   * Write-through of single writes: once the device holds rows, a leaf that is written through setData (a local put, or a remote write that
-   * took the host path) has to reach its row too, or the next batch would be resolved against a state the host has already left behind.
-   * Only what the device can hold: the leaf `<node>/<field>` with a safe-integer value and the scalar clock {writer: ts}. Queued here, sent
-   * as one LWW load in front of the next device operation (no device call per put).
+   * Write-through of writes the HOST resolved (single puts, values or clocks outside the device contract, deletions): once the device holds
+   * rows, its table has to follow, or the next batch would be resolved against a state the host has already left behind, and device-side
+   * indexes would keep rows of nodes that are gone (src/bullet-query.js:83-85 skips null). What is mirrored for a write of `value` at `path`
+   * (parent = its collection, key = its last segment) that ended with clock `clock`:
+   *   clock row   (path, NODE_CLOCK)            ts = the clock if it is the single component {writer: ts}; otherwise the path is marked host-only
+   *   value rows  (path, f) for every safe-integer field f of an object value; (path, null) for a safe-integer primitive;
+   *               (parent node, key) as well — the same leaf seen as a FIELD of its parent node, which is what index(collection, field) scans;
+   *   tombstones  for every such row the old value had and the new one has not: a dominating object REPLACES the node
+   *               (src/bullet-crt.js:236-248), a deleted entry becomes null (src/bullet-network-sync.js:553-555).
+   * Queued here, sent with ONE bmx_put_rows in front of the next device operation (no device call per put).
    */
-  _queueDeviceWrite(path, value, clock) {
+  _mirrorWrite(path, oldValue, value, clock) {
     if (!this._graph || this._opts.writers) return;           // no device table in use (or the K-writer table: its rows are not scalar-clock rows)
-    if (!isDeviceInt(value)) return;
     const ts = scalarClock(clock, this._opts.writer || this.bullet.id);
-    if (ts < 0) return;
+    if (ts < 0) this._hostOnly.add(path); else this._hostOnly.delete(path);
     const cut = path.lastIndexOf("/");
-    if (cut <= 0) return;
-    (this._pendingRows || (this._pendingRows = [])).push(path.slice(0, cut), path.slice(cut + 1), ts, value);
+    const parent = cut < 0 ? "" : path.slice(0, cut);
+    const keys = this._graph.keys;
+    const q = this._putQueue();
+    keys.lookup(path);
+    const lo = keys.lo, hi = keys.hi;
+    if (ts >= 0) q.push(lo, hi, keys.fieldOf(parent, NODE_CLOCK), ts, this._nodeSeq++);
+    this._queueValueRows(q, path, parent, lo, hi, oldValue, value, ts < 0 ? 0 : ts, false);
+    if (cut > 0) {                                             // the leaf as a field of its parent node
+      const key = path.slice(cut + 1), c2 = parent.lastIndexOf("/");
+      const was = isDeviceInt(oldValue), is = isDeviceInt(value);
+      if (was || is) {
+        keys.lookup(parent);
+        q.push(keys.lo, keys.hi, keys.fieldOf(c2 < 0 ? "" : parent.slice(0, c2), key), ts < 0 ? 0 : ts, is ? value : VAL_DELETED);
+      }
+    }
+  }
+
+  /* value rows of node `path` (id lo:hi) for `value`, tombstones for what `oldValue` had on the device and `value` has not */
+  _queueValueRows(q, path, parent, lo, hi, oldValue, value, ts, unique) {
+    const keys = this._graph.keys;
+    const put = unique ? (f, v) => q.pushUnique(lo, hi, f, ts, v) : (f, v) => q.push(lo, hi, f, ts, v);
+    const newObj = isMergeable(value), oldObj = isMergeable(oldValue);
+    if (newObj) {
+      for (const f in value) {
+        if (f === "__vectorClock" || f === "__fromNetwork" || !Object.prototype.hasOwnProperty.call(value, f)) continue;
+        const v = value[f];
+        if (isDeviceInt(v)) put(keys.fieldOf(parent, f), v);
+        else if (oldObj && isDeviceInt(oldValue[f])) put(keys.fieldOf(parent, f), VAL_DELETED);
+      }
+    }
+    if (oldObj) {
+      for (const f in oldValue) {
+        if (!Object.prototype.hasOwnProperty.call(oldValue, f) || !isDeviceInt(oldValue[f])) continue;
+        if (!newObj || !Object.prototype.hasOwnProperty.call(value, f)) put(keys.fieldOf(parent, f), VAL_DELETED);
+      }
+    }
+    if (isDeviceInt(value)) put(keys.fieldOf(parent, null), value);
+    else if (isDeviceInt(oldValue)) put(keys.fieldOf(parent, null), VAL_DELETED);
+  }
+
+  /* the queue of rows for bmx_put_rows; the graph flushes it in front of every device operation it is asked for (DeviceGraph.preOp), so
+   * direct readers of the graph (getRows, scans, dumps) never see a table that lags the host's own writes */
+  _putQueue() {
+    if (!this._puts) {
+      this._puts = new PutQueue();
+      const g = this._graph;
+      if (g && !g.preOp) g.preOp = () => this._flushDeviceWrites();
+    }
+    return this._puts;
+  }
+
+  /* in front of a merge: rows of host writes must be there (clock rows decide the merge); the value rows of earlier batches' winners only feed
+   * scans, so they stay queued — a synchronous put would make the event loop wait for the merge in flight — until a reader comes or a million wait */
+  _flushBeforeMerge() {
+    const q = this._puts;
+    if (q && q.n && (q.hasHostRows() || q.n > (1 << 20))) this._flushDeviceWrites();
   }
 
   _flushDeviceWrites() {
-    const q = this._pendingRows;
-    if (!q || q.length === 0) return;
-    this._pendingRows = null;
-    const g = this.graph, keys = g.keys, n = q.length / 4;
-    const cols = new Columns(n);
-    for (let i = 0; i < n; i++) {
-      const node = q[4 * i], c = node.lastIndexOf("/");
-      cols.set(i, keys.idOf(node), keys.fieldOf(c < 0 ? "" : node.slice(0, c), q[4 * i + 1]), q[4 * i + 2], q[4 * i + 3]);
+    const q = this._puts;
+    if (!q || q.n === 0) return;
+    const g = this.graph;
+    for (const cols of q.take()) g.putRows(cols);
+  }
+
+  /*
+   * Bring a NEW device table in step with what the facade already holds (writes that happened before the graph existed, a store loaded from
+   * disk: gpu-storage.js): every path with a clock gets its clock row (or the host-only mark) and its value rows. Called once when the graph
+   * is created (index.js attach(), GpuStorage.restoreDevice()). -> rows queued
+   */
+  seedDevice() {
+    if (!this._graph || this._opts.writers) return 0;
+    const b = this.bullet, meta = b.meta || {};
+    let n = 0;
+    for (const p of Object.keys(meta)) {
+      const m = meta[p];
+      if (!m || !m.vectorClock) continue;
+      this._mirrorWrite(p, undefined, peek(b.store, p), m.vectorClock);
+      n++;
     }
-    g.loadRows(cols);
+    this._flushDeviceWrites();
+    return n;
+  }
+
+  /* May entry e = {path, data, vectorClock} be resolved by the device?  (SURVEY §8(a) contract, node level)
+   *   data: a safe integer, or a plain object with at least one field, all safe integers; clock: the single component {writer: ts};
+   *   the path's stored clock is one the device holds (not host-only), and a first sight of it would store {writer: 2} in the reference too
+   *   (src/bullet-crt.js:172-185 increments whatever crt.vectorClocks already holds for a path that has no meta clock yet). */
+  entryEligible(e, writer, objectsOnly) {
+    if (!e || e.deleted) return false;
+    if (scalarClock(e.vectorClock, writer) < 0) return false;
+    const d = e.data;
+    if (isDeviceInt(d)) { if (objectsOnly) return false; }
+    else {
+      if (!isMergeable(d)) return false;
+      let k = 0;
+      for (const f in d) {
+        if (f === "__vectorClock" || f === "__fromNetwork" || !Object.prototype.hasOwnProperty.call(d, f)) continue;
+        if (!isDeviceInt(d[f])) return false;
+        k++;
+      }
+      if (k === 0) return false;
+    }
+    if (this._hostOnly.size && this._hostOnly.has(e.path)) return false;
+    if (this._apiClocks.size && this._apiClocks.has(e.path)) {   // createVectorClock / getVectorClock / createUpdate were used on this path
+      const m = this.bullet.meta[e.path];
+      if (m && m.vectorClock) this._apiClocks.delete(e.path);
+      else if (scalarClock(this.vectorClocks.get(e.path), writer) !== 1) return false;   // the reference would store that clock + 1, not {writer: 2}
+    }
+    return true;
   }
 
   formatClock(clock) {
@@ -237,94 +391,115 @@ class GpuCRT {
    * Merge typed columns on the GPU.
    * cols: {id: BigUint64Array, field: Uint32Array, ts: BigInt64Array, val: BigInt64Array}
    * opts: {insertMode: 'reference'|'delta', uniqueKeys: bool, strictFlags: bool (exact sequential per-delta flags even with
-   *        duplicate keys in the batch; about twice as slow)}
+   *        duplicate keys in the batch; about twice as slow), markCreated: bool (bit 31 of an applied index: that delta created its row)}
    * -> {applied: Uint32Array (ascending delta indices whose value is now stored), flags, nApplied, nConflicts, nRows}
    */
   mergeBatch(cols, opts = {}) {
-    this._flushDeviceWrites();
+    this._flushBeforeMerge();
     const g = this.graph;
     let mode = opts.insertMode === "delta" ? g.native.INSERT_DELTA : g.native.INSERT_REFERENCE;
     if (opts.uniqueKeys) mode |= g.native.MERGE_UNIQUE_KEYS;
     if (opts.strictFlags) mode |= g.native.MERGE_STRICT_FLAGS;
+    if (opts.markCreated) mode |= g.native.MERGE_MARK_CREATED;
     return g.mergeBatch(cols, mode);
   }
 
   /** Same as mergeBatch but off the event loop: resolves to the same result object (the reference API is synchronous;
    *  this is the Promise variant SURVEY §8(b) calls for). The columns must not be mutated until it settles. */
   mergeBatchAsync(cols, opts = {}) {
-    this._flushDeviceWrites();
+    this._flushBeforeMerge();
     const g = this.graph;
     let mode = opts.insertMode === "delta" ? g.native.INSERT_DELTA : g.native.INSERT_REFERENCE;
     if (opts.uniqueKeys) mode |= g.native.MERGE_UNIQUE_KEYS;
     if (opts.strictFlags) mode |= g.native.MERGE_STRICT_FLAGS;
+    if (opts.markCreated) mode |= g.native.MERGE_MARK_CREATED;
     return g.mergeBatchAsync(cols, mode);
   }
 
   /**
-   * Batch adapter for sync chunks (reference loop: src/bullet-network-sync.js:551-569).
-   * entries: [{path, data, vectorClock}] where data is an integer or an object of integer fields and
-   * vectorClock is {<writer>: ts}. Each (node, field) becomes one device row. Entries outside that contract
-   * (strings, nested objects, multi-writer clocks) are returned in `host` for the caller to pass to setData().
-   * opts.apply: true = update the facade's store/meta/log/listeners once for the batch (N1), "each" = one _applyUpdate per winner.
-   * -> {applied: [{entry, field}], nConflicts, host: [entry indices], broadcast: [{path, broadcastData}] when applied}
+   * Batch adapter for sync chunks (reference loop: src/bullet-network-sync.js:551-569), NODE-level like the reference: an entry
+   * {path, data, vectorClock} is ONE conflict-resolution unit — the object (or integer) at `path` under the clock in meta[path]
+   * (src/bullet-crt.js:329-385). Every eligible entry (entryEligible) becomes one device delta on the node's CLOCK row
+   * (path, NODE_CLOCK): ts = its clock, val = its arrival number. The scalar-clock merge then IS resolve() for the node: first sight stores
+   * {writer: 2} (:172-185), a dominating clock wins (:236-248), an older one is historical (:251-263), and on equal clocks the later
+   * arrival wins — what compare() answers for two objects (:11-15, :200-233). Winners are the entries whose object is the node's final
+   * value; entries outside the contract are returned in `host` for setData().
+   * opts.apply: true = the winners REPLACE their nodes in the facade's store, meta[path] gets the stored clock, log and listeners run once
+   * for the batch (N1, batch-apply.js); "each" = one _applyUpdate per winner. The winners' integer fields are queued as device value rows
+   * (and tombstones for the fields the replaced node had: known only when the store is kept, i.e. with opts.apply) for the device-side
+   * indexes; they reach the device in front of the next device read (opts.valueRows: false leaves them out: clock rows only).
+   * -> {applied: [{entry, field: null}], nApplied, nConflicts, nRows, host: [entry indices], broadcast: [{path, broadcastData}] when applied}
    */
   mergeEntries(entries, opts = {}) {
     if (this._opts.writers) return this._mergeEntriesVector(entries, opts);
+    const p = this._packEntries(entries, opts);
+    return this._finishEntries(entries, p, this.mergeBatch(p.cols, p.mergeOpts), opts);
+  }
+
+  /**
+   * mergeEntries off the event loop: the merge runs on a worker thread of the addon, the Promise resolves to the same result. Calls may be issued
+   * back to back without awaiting: the addon keeps the issue order, so while chunk b is on the GPU the event loop packs chunk b + 1 (path hashing,
+   * typed columns), and the winners of chunk b are applied when its Promise settles — one chunk late, in order (src/bullet-network-sync.js:551-569
+   * is the loop this pipelines). Host-path writes issued in between are ordered with the merges through the same queue.
+   */
+  mergeEntriesAsync(entries, opts = {}) {
+    if (this._opts.writers) return Promise.resolve().then(() => this._mergeEntriesVector(entries, opts));
+    const p = this._packEntries(entries, opts);
+    return this.mergeBatchAsync(p.cols, p.mergeOpts).then((r) => this._finishEntries(entries, p, r, opts));
+  }
+
+  /** Run chunks of entries through mergeEntriesAsync with `depth` (default 2) in flight. -> Promise<{nApplied, nConflicts, nRows, host: [[chunk, entry index]]}> */
+  async mergeEntriesPipelined(chunks, opts = {}) {
+    const depth = Math.max(1, opts.depth || 2);
+    const inflight = [];
+    const total = { nApplied: 0, nConflicts: 0, nRows: 0, host: [] };
+    let ci = 0;
+    const settle = async () => {
+      const f = inflight.shift();
+      const r = await f.promise;
+      total.nApplied += r.nApplied; total.nConflicts += r.nConflicts; total.nRows = r.nRows;
+      for (const k of r.host) total.host.push([f.chunk, k]);
+    };
+    for (const chunk of chunks) {
+      inflight.push({ chunk: ci++, promise: this.mergeEntriesAsync(chunk, opts) });
+      if (inflight.length >= depth) await settle();
+    }
+    while (inflight.length) await settle();
+    return total;
+  }
+
+  /* entries -> one clock-row delta per eligible entry */
+  _packEntries(entries, opts) {
     const writer = opts.writer || this.bullet.id;
     const g = this.graph;
     const keys = g.keys;
-    // one pass: eligible entries are written straight into growable typed columns (a second pass over a million JS objects costs
-    // more than the GPU merge); rowEntry / rowField map device rows back to (entry, field name)
-    let cap = Math.max(16, entries.length * 2);
-    let cols = new Columns(cap);
-    let rowEntry = new Int32Array(cap), rowField = new Int32Array(cap);
-    const fieldNames = [], fieldIndex = new Map();          // names seen in this call, -1 = the node's own value
+    const n = entries.length;
+    const cols = new Columns(Math.max(n, 1));
+    const rowEntry = new Int32Array(Math.max(n, 1));
     const host = [];
     let i = 0;
     let lastParent = "";                                    // consecutive entries usually share their collection: reuse the sliced string
-    const parentOf = (path, cut) => {
-      if (cut < 0) return "";
-      if (cut === lastParent.length && path.startsWith(lastParent)) return lastParent;
-      lastParent = path.slice(0, cut);
-      return lastParent;
-    };
-    for (let ei = 0; ei < entries.length; ei++) {
+    for (let ei = 0; ei < n; ei++) {
       const e = entries[ei];
-      const ts = scalarClock(e.vectorClock, writer);
-      const d = e.data;
-      if (ts < 0) { host.push(ei); continue; }
-      const first = i;
-      let ok = true;
-      if (isDeviceInt(d)) {
-        if (i + 1 > cap) ({ cols, rowEntry, rowField, cap } = growColumns(cols, rowEntry, rowField, i, cap * 2));
-        keys.lookup(e.path);
-        cols.set2(i, keys.lo, keys.hi, keys.fieldOf(parentOf(e.path, e.path.lastIndexOf("/")), null), ts, d);
-        rowEntry[i] = ei; rowField[i] = -1; i++;
-      } else if (d && typeof d === "object" && !Array.isArray(d)) {
-        const parent = parentOf(e.path, e.path.lastIndexOf("/"));
-        let idLo = 0, idHi = 0, haveId = false;
-        for (const k in d) {
-          if (k === "__vectorClock" || k === "__fromNetwork" || !Object.prototype.hasOwnProperty.call(d, k)) continue;
-          const v = d[k];
-          if (!isDeviceInt(v)) { ok = false; break; }
-          if (!haveId) { keys.lookup(e.path); idLo = keys.lo; idHi = keys.hi; haveId = true; }
-          if (i + 1 > cap) ({ cols, rowEntry, rowField, cap } = growColumns(cols, rowEntry, rowField, i, cap * 2));
-          let fi = fieldIndex.get(k);
-          if (fi === undefined) { fi = fieldNames.length; fieldNames.push(k); fieldIndex.set(k, fi); }
-          cols.set2(i, idLo, idHi, keys.fieldOf(parent, k), ts, v);
-          rowEntry[i] = ei; rowField[i] = fi; i++;
-        }
-        if (ok && i === first) ok = false;                   // an object without fields: nothing for the device
-      } else ok = false;
-      if (!ok) { i = first; host.push(ei); }                 // roll back the rows of an entry that turned out to be off-contract
+      if (!this.entryEligible(e, writer, false)) { host.push(ei); continue; }
+      const path = e.path, cut = path.lastIndexOf("/");
+      if (cut < 0) lastParent = "";
+      else if (!(cut === lastParent.length && path.startsWith(lastParent))) lastParent = path.slice(0, cut);
+      keys.lookup(path);
+      cols.set2(i, keys.lo, keys.hi, keys.fieldOf(lastParent, NODE_CLOCK), e.vectorClock[writer], this._nodeSeq++);
+      rowEntry[i++] = ei;
     }
-    const used = cols.slice(i);
-    const r = this.mergeBatch(used, opts);
+    // one context: the winners that created their node are marked (stored clock = the insert rule's, no read-back); shards: read back
+    const mergeOpts = g.comm ? opts : Object.assign({}, opts, { markCreated: true });
+    return { cols: cols.slice(i), rowEntry, host, writer, mergeOpts };
+  }
+
+  _finishEntries(entries, p, r, opts) {
     const applied = new Array(r.applied.length);
-    for (let k = 0; k < applied.length; k++) { const j = r.applied[k]; applied[k] = { entry: rowEntry[j], field: rowField[j] < 0 ? null : fieldNames[rowField[j]] }; }
-    const broadcast = opts.apply ? this._applyWinners(entries, used, r.applied, applied, opts.apply, opts.broadcast !== false) : undefined;
-    if (opts.apply) this._notifyIndexHook(entries, host);
-    return { applied, nApplied: r.nApplied, nConflicts: r.nConflicts, nRows: r.nRows, host, broadcast };
+    for (let k = 0; k < applied.length; k++) applied[k] = { entry: p.rowEntry[r.applied[k] & 0xffffff], field: null };
+    const broadcast = this._applyWinners(entries, p.cols, r.applied, applied, opts.apply, opts.broadcast !== false, !this.graph.comm, opts.insertMode === "delta", p.writer, opts.valueRows !== false);
+    if (opts.apply) this._notifyIndexHook(entries, p.host);
+    return { applied, nApplied: r.nApplied, nConflicts: r.nConflicts, nRows: r.nRows, host: p.host, broadcast: opts.apply ? broadcast : undefined };
   }
 
   /*
@@ -347,37 +522,55 @@ class GpuCRT {
   }
 
   /*
-   * N1 (SURVEY §8(f)): hand the batch's final winners to the facade in ONE pass. Each winning row is the leaf
-   * `<entry.path>[/<field>]`; its stored clock and value are read back from the device (an inserted row's clock is
-   * {writer: 2}, not the incoming one). opts.apply === true: store, meta, op log and listeners are updated once for the whole
-   * batch (batch-apply.js: ring-style log, ancestor listeners de-duplicated; a facade may supply its own `_applyBatch`);
-   * opts.apply === "each": the facade's per-write `_applyUpdate` is called once per winner (src/bullet.js:184-266), the
-   * reference's own cost per write. Returns what setData would have broadcast per winner (src/bullet-crt.js:371-376).
+   * N1 (SURVEY §8(f)): hand the batch's final winners to the facade in ONE pass. A winner is a whole node: its stored clock is read back
+   * from its clock row (a first sight stored {writer: 2}, not the incoming clock), its value replaces the node. mode === true: store, meta,
+   * op log and listeners are updated once for the whole batch (batch-apply.js: ring-style log, ancestor listeners de-duplicated; a facade
+   * may supply its own `_applyBatch`); mode === "each": the facade's per-write `_applyUpdate` is called once per winner
+   * (src/bullet.js:184-266), the reference's own cost per write; falsy: the store is left alone (the caller applies). In every mode the
+   * winners' value rows are queued for the device. Returns what setData would have broadcast per winner (src/bullet-crt.js:371-376).
    */
-  _applyWinners(entries, cols, appliedIdx, applied, mode, wantBroadcast = true) {
+  _applyWinners(entries, cols, appliedIdx, applied, mode, wantBroadcast = true, marked = false, deltaMode = false, writerOpt, valueRows = true) {
     const n = appliedIdx.length;
     if (n === 0) return [];
-    const ids = new BigUint64Array(n), id32 = new Uint32Array(ids.buffer), fields = new Uint32Array(n);
+    const id32 = new Uint32Array(2 * n);
     const src32 = cols._id32 || new Uint32Array(cols.id.buffer, cols.id.byteOffset, cols.id.length * 2);
-    for (let k = 0; k < n; k++) { const j = appliedIdx[k]; id32[2 * k] = src32[2 * j]; id32[2 * k + 1] = src32[2 * j + 1]; fields[k] = cols.field[j]; }
-    const rows = this.graph.getRows(ids, fields);
-    const ts32 = new Uint32Array(rows.ts.buffer, rows.ts.byteOffset, n * 2), val32 = new Int32Array(rows.val.buffer, rows.val.byteOffset, n * 2);
-    const valLo = new Uint32Array(rows.val.buffer, rows.val.byteOffset, n * 2);
-    const writer = this._opts.writer || this.bullet.id;
-    const updates = new Array(n);
-    for (let k = 0; k < n; k++) {
-      const a = applied[k];
-      const e = entries[a.entry];
-      const leaf = a.field === null ? e.path : e.path + "/" + a.field;
-      const clock = {};
-      clock[writer] = ts32[2 * k + 1] * 4294967296 + ts32[2 * k];                        // 0 <= ts <= 2^53-1
-      updates[k] = { path: leaf, value: val32[2 * k + 1] * 4294967296 + valLo[2 * k], vectorClock: clock };   // signed high half, unsigned low half
-      this.vectorClocks.set(leaf, clock);
+    for (let k = 0; k < n; k++) { const j = appliedIdx[k] & 0xffffff; id32[2 * k] = src32[2 * j]; id32[2 * k + 1] = src32[2 * j + 1]; }
+    let ts32 = null;
+    if (!marked) {        // sharded graph: the stored clocks are read back from the clock rows
+      const ids = new BigUint64Array(id32.buffer), fields = new Uint32Array(n);
+      for (let k = 0; k < n; k++) fields[k] = cols.field[appliedIdx[k] & 0xffffff];
+      const rows = this.graph.getRows(ids, fields);
+      ts32 = new Uint32Array(rows.ts.buffer, rows.ts.byteOffset, n * 2);
     }
+    const writer = writerOpt || this._opts.writer || this.bullet.id;
     const b = this.bullet;
+    const q = this._putQueue();
+    const updates = mode ? new Array(n) : null;
+    for (let k = 0; k < n; k++) {
+      const e = entries[applied[k].entry];
+      const path = e.path, cut = path.lastIndexOf("/");
+      // the clock the node now stores: read back, or — one context — the entry's own unless this winner CREATED the node (bit 31: the insert rule's {writer: 2})
+      const ts = ts32 ? ts32[2 * k + 1] * 4294967296 + ts32[2 * k] : ((appliedIdx[k] >>> 31) && !deltaMode ? 2 : e.vectorClock[writer]);
+      let value = e.data, old;
+      if (mode) {
+        const clock = {};
+        clock[writer] = ts;
+        if (isMergeable(value)) {                                                       // the node's new value: the entry's object without the transport tags
+          const clean = {};
+          for (const f of Object.keys(value)) if (f !== "__vectorClock" && f !== "__fromNetwork") clean[f] = value[f];
+          value = clean;
+        }
+        updates[k] = { path, value, vectorClock: clock };
+        this.vectorClocks.set(path, clock);                                             // the same object meta will hold: local writes increment it in place, like the reference's (SURVEY §5 aliasing)
+        old = peek(b.store, path);
+      }
+      if (valueRows) this._queueValueRows(q, path, cut < 0 ? "" : path.slice(0, cut), id32[2 * k], id32[2 * k + 1], old, value, ts, true);
+    }
+    q.closeBatch();
+    if (!mode) return [];
     if (mode === "each") {
       if (typeof b._applyUpdate === "function") for (const u of updates) b._applyUpdate(u.path, u.value, u.vectorClock, true);
-      return wantBroadcast ? updates.map((u) => ({ path: u.path, broadcastData: u.value })) : [];
+      return wantBroadcast ? updates.map((u) => ({ path: u.path, broadcastData: isMergeable(u.value) ? Object.assign({}, u.value, { __vectorClock: u.vectorClock }) : u.value })) : [];
     }
     if (typeof b._applyBatch === "function") return b._applyBatch(updates, true) || [];
     return require("./batch-apply").applyBatch(b, updates, true, wantBroadcast);
@@ -506,7 +699,7 @@ class GpuCRT {
     rows.forEach((r, i) => {
       const id = r.path !== null && r.path !== undefined ? g.keys.idOf(r.path) : [Number(BigInt("0x" + r.id) & 0xffffffffn), Number(BigInt("0x" + r.id) >> 32n)];
       const f = r.collection !== null && r.collection !== undefined ? g.keys.fieldOf(r.collection, r.field) : r.fieldHash;
-      cols.set(i, id, f, r.ts, r.val);
+      cols.set(i, id, f, r.ts, r.field === NODE_CLOCK ? 0 : r.val);      // arrival numbers start over: every write after the restore is later than the restored ones
     });
     g.loadRows(cols);
     return rows.length;

@@ -130,6 +130,7 @@ class GpuQuery {
     ix.dirty = null;
     ix.rank = null;
     ix._posByPath = null;
+    ix.ordOfPos = null;
     if (values.length > 0 && values.every(isDeviceInt)) this._buildDevice(ix);
     else this._buildHost(ix);
   }
@@ -238,6 +239,27 @@ class GpuQuery {
     return out;
   }
 
+  /* Matches of lo..hi as child ordinals of the build scan, through index POSITIONS (bmx_scan_range_pos): the device gathers no ids, and the host
+   * turns a position into an ordinal with one typed-array read instead of an id -> path -> ordinal lookup per match. ordOfPos is fetched once
+   * per build of the device columns (bmx_index_ids) and extended when rows were appended; a full rebuild renumbers the positions (detected by
+   * the engine's own count of full builds). Sharded graphs number positions per shard: they keep the id path. */
+  _matches(ix, lo, hi) {
+    const g = this.graph;
+    if (g.comm) return this._ordinals(ix, g.scanRange(ix.deviceField, lo, hi));
+    const pos = g.scanRangePos(ix.deviceField, lo, hi);
+    const builds = g.indexRefreshCounts().fullBuilds;
+    if (!ix.ordOfPos || ix.posBuilds !== builds) { ix.ordOfPos = []; ix.posBuilds = builds; }
+    const n = g.indexSize(ix.deviceField);
+    if (ix.ordOfPos.length < n) {
+      const have = ix.ordOfPos.length;
+      const ords = this._ordinals(ix, g.indexIds(ix.deviceField, have, n - have));
+      for (let i = 0; i < ords.length; i++) ix.ordOfPos.push(ords[i]);
+    }
+    const out = new Array(pos.length);
+    for (let i = 0; i < pos.length; i++) out[i] = ix.ordOfPos[pos[i]];
+    return out;
+  }
+
   /* reference order of a result set: distinct values in first-seen order of the build scan, children of one value in scan order */
   _inReferenceOrder(ix, ordinals) {
     if (!ix.rank) {
@@ -260,9 +282,8 @@ class GpuQuery {
     // the reference compares String(value): 30 and "30" are the same bucket
     const n = typeof value === "string" && value.trim() !== "" ? Number(value) : value;
     if (!isDeviceInt(n) || String(n) !== String(value)) return [];
-    const ids = this.graph.scanRange(ix.deviceField, n, n);
-    if (ix.source === "device") return this._nodesFromIds(ids);
-    return this._nodes(ix, this._ordinals(ix, ids).sort((a, b) => a - b));
+    if (ix.source === "device") return this._nodesFromIds(this.graph.scanRange(ix.deviceField, n, n));
+    return this._nodes(ix, this._matches(ix, n, n).sort((a, b) => a - b));
   }
 
   range(path, field, min, max) {
@@ -272,9 +293,8 @@ class GpuQuery {
     if (typeof min === "undefined" || typeof max === "undefined") return [];
     if (ix.kind === "device" && typeof min === "number" && typeof max === "number" && !Number.isNaN(min) && !Number.isNaN(max)) {
       // integer column: lo = ceil(min), hi = floor(max) select exactly the values with min <= v <= max
-      const ids = this.graph.scanRange(ix.deviceField, Math.ceil(min), Math.floor(max));
-      if (ix.source === "device") return this._nodesFromIds(ids);
-      return this._nodes(ix, this._inReferenceOrder(ix, this._ordinals(ix, ids)));
+      if (ix.source === "device") return this._nodesFromIds(this.graph.scanRange(ix.deviceField, Math.ceil(min), Math.floor(max)));
+      return this._nodes(ix, this._inReferenceOrder(ix, this._matches(ix, Math.ceil(min), Math.floor(max))));
     }
     if (ix.source === "device") return [];   // non-numeric bounds cannot match integer rows
     // host index, or bounds the device cannot express (strings): JS comparison semantics on the host

@@ -9,17 +9,17 @@
  * A directory written by the reference's BulletFileStorage loads here and vice versa (encryption is not offered).
  *
  * What it adds is the DEVICE side of both directions:
- *   load  — after store/meta are in place, every path whose value is a safe integer (leaf entry) or an object of safe integers (node
- *           entry) and whose clock is the single component {<peer id>: ts} is preloaded into the GPU-resident table with that clock
- *           (bmx_load_rows), so a restart does not lose the resident graph;
+ *   load  — after store/meta are in place, the device table is seeded from them when the graph is created (GpuCRT.seedDevice): every path with
+ *           a clock gets its clock row (single-component clocks {<peer id>: ts}; any other clock marks the path host-only) and the value rows of
+ *           its safe-integer fields, so a restart does not lose the resident graph nor the clocks later sync entries are resolved against;
  *   save  — rows that reached the device through typed columns only (no facade write) are folded back into store/meta first:
- *           the device table is dumped (bmx_dump_rows), rows whose path is known to the key dictionary are written as leaves
- *           `<node path>/<field>` with clock {<peer id>: ts}, then the three files are written.
+ *           the device table is dumped (bmx_dump_rows), value rows whose path is known to the key dictionary and whose value the store does
+ *           not hold are written as leaves `<node path>/<field>` with clock {<peer id>: ts}, then the three files are written.
  * Interface of the reference's BulletStorage that the core calls: save(), close() (src/bullet.js:257-265, 288-304).
  */
 const fs = require("fs");
 const path = require("path");
-const { Columns, isDeviceInt, scalarClock } = require("./hash");
+const { Columns, isDeviceInt, scalarClock, NODE_CLOCK } = require("./hash");
 
 class GpuStorage {
   constructor(bullet, options = {}) {
@@ -85,8 +85,10 @@ class GpuStorage {
     return { cols, n: rows.length };
   }
 
-  /* preload the device table from what was loaded (called by attach() once the graph exists, or by hand) */
+  /* preload the device table from what was loaded (attach() does it once the graph exists; by hand for a graph of one's own) */
   restoreDevice(graph) {
+    const crt = this.bullet.crt;
+    if (crt && typeof crt.seedDevice === "function" && crt._graph === graph) return crt.seedDevice();
     const { cols, n } = this.deviceRows(graph.keys);
     if (n) graph.loadRows(cols);
     return n;
@@ -103,10 +105,11 @@ class GpuStorage {
       const nodePath = graph.keys.pathOf(id32[2 * i], id32[2 * i + 1]);
       const f = graph.keys.fields.get(d.field[i]);
       if (nodePath === undefined || !f) continue;          // raw hashed keys: nothing to call them in the store
+      if (f[1] === NODE_CLOCK) continue;                   // a node's clock row: meta[path] is where the facade keeps it
       const leaf = f[1] === null ? nodePath : nodePath + "/" + f[1];
       const ts = Number(d.ts[i]), val = Number(d.val[i]);
+      if (readPath(b.store, leaf) === val) continue;       // the store holds it: a row that mirrors a facade write (its clock lives in the node's meta entry)
       const m = b.meta[leaf];
-      if (m && scalarClock(m.vectorClock, writer) === ts && readPath(b.store, leaf) === val) continue;
       writePath(b.store, leaf, val);
       const clock = {}; clock[writer] = ts;
       b.meta[leaf] = Object.assign({}, m || {}, { source: (m && m.source) || "network", vectorClock: clock, lastModified: (m && m.lastModified) || Date.now() });

@@ -191,6 +191,12 @@ class Columns {
 }
 
 const MAX_SAFE = Number.MAX_SAFE_INTEGER;
+/* Field name of a node's CLOCK row on the device: (node id, fieldOf(collection, NODE_CLOCK)) holds ts = the clock the reference keeps in
+ * meta[path].vectorClock (src/bullet.js:196-201) and val = the arrival number of the write that set it (so that a tie on ts goes to the LATER
+ * write, as compare() does for two objects: src/bullet-crt.js:11-15). No JSON field name starts with U+0000. */
+const NODE_CLOCK = "\u0000clock";
+/* BMX_VAL_DELETED (include/bmx.h): the tombstone value of bmx_put_rows. -2^63 is exact as a double and splits into the halves 0x80000000:00000000 */
+const VAL_DELETED = -9223372036854775808;
 function isDeviceInt(v) { return typeof v === "number" && Number.isInteger(v) && v <= MAX_SAFE && v >= -MAX_SAFE; }
 /* a clock the device understands: exactly one component, owned by `writer`, a non-negative safe integer */
 function scalarClock(clock, writer) {
@@ -237,4 +243,4 @@ function denseClock(clock, writers) {
   return out;
 }
 
-module.exports = { pathId, fieldId, idKey, KeyDictionary, Columns, VcColumns, isDeviceInt, scalarClock, denseClock, fnv1a32 };
+module.exports = { pathId, fieldId, idKey, KeyDictionary, Columns, VcColumns, isDeviceInt, scalarClock, denseClock, fnv1a32, NODE_CLOCK, VAL_DELETED };

@@ -18,7 +18,8 @@ const native = require("./native");
 /** Install GpuCRT and GpuQuery on a Bullet instance; one DeviceGraph is shared and created on first device use.
  *  opts.batchSync: also route the facade's remote-write ingestion (sync chunks, network puts: src/bullet-network-sync.js:551-569,
  *  src/bullet-network.js:332-346) through the batch path (batch-sync.js). If the instance was created with
- *  `storageType: GpuStorage`, the rows that storage loaded from disk are preloaded into the device table when the graph is created. */
+ *  `storageType: GpuStorage`, the rows that storage loaded from disk are preloaded into the device table when the graph is created (as is
+ *  everything else the facade holds by then: GpuCRT.seedDevice). */
 function attach(bullet, opts = {}) {
   const shared = Object.assign({}, opts);
   let graph = opts.graph || null;
@@ -27,7 +28,7 @@ function attach(bullet, opts = {}) {
       if (!graph) {
         const DeviceGraph = require("./device-graph");
         graph = new DeviceGraph(shared);
-        if (bullet.storage instanceof GpuStorage) bullet.storage.restoreDevice(graph);
+        crt.seedDevice();        // what the facade already holds (earlier writes, a store loaded from disk: GpuStorage): clocks and integer values -> device rows
       }
       return graph;
     },

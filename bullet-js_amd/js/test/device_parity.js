@@ -152,24 +152,26 @@ for (const shards of [2, 4, 8]) {
   b.close();
 }
 
-/* sync-chunk adapter: entries -> device rows; off-contract entries are handed back */
+/* sync-chunk adapter: every eligible entry is ONE delta on its node's clock row; off-contract entries are handed back */
 {
   const b = new MiniBullet("w");
   const { crt } = attach(b, { capacityRows: 4096 });
   const entries = [
     { path: "s/a", data: { n: 1, m: 5 }, vectorClock: { w: 10 } },
     { path: "s/b", data: 7, vectorClock: { w: 3 } },
-    { path: "s/a", data: { n: 2 }, vectorClock: { w: 9 } },          // older than the first: loses against it
+    { path: "s/a", data: { n: 2 }, vectorClock: { w: 9 } },          // older than the first (delta mode keeps the incoming clock): historical
     { path: "s/c", data: { name: "x" }, vectorClock: { w: 4 } },     // string: host path
     { path: "s/d", data: { n: 1 }, vectorClock: { w: 4, q: 1 } },    // multi-writer clock: host path
     { path: "s/a", data: { n: 3 }, vectorClock: { w: 11 } },
   ];
   const r = crt.mergeEntries(entries, { insertMode: "delta" });
   assert.deepStrictEqual(r.host, [3, 4]);
-  assert.deepStrictEqual(r.applied, [{ entry: 0, field: "m" }, { entry: 1, field: null }, { entry: 5, field: "n" }]);
-  assert.strictEqual(r.nRows, 3);
+  assert.deepStrictEqual(r.applied, [{ entry: 1, field: null }, { entry: 5, field: null }]);   // one winner per NODE: the object that is its final value
+  assert.strictEqual(r.nRows, 2);                                    // two clock rows (the winners' value rows are still queued)
+  const snap = crt.checkpoint();                                     // flushes them: s/a {n:3}, s/b 7
+  assert.deepStrictEqual(snap.filter((x) => x.field !== hash.NODE_CLOCK).map((x) => [x.path, x.field, x.ts, x.val]).sort(), [["s/a", "n", 11, 3], ["s/b", null, 3, 7]]);
   b.close();
-  checks += 3;
+  checks += 4;
 }
 
 /* N1 + N3: winners applied to the store in one pass; checkpoint / restore of the device rows */
@@ -189,59 +191,97 @@ for (const shards of [2, 4, 8]) {
     { path: "acct/a", data: { bal: 15 }, vectorClock: { w: 101 } },
   ];
   const r1 = crt.mergeEntries(entries, { apply: "each" });   // the facade's own per-write hook
-  // reference insert rule: a first write stores clock {w:2}; the later delta (101 > 2) then wins acct/a/bal
-  assert.deepStrictEqual(applied, [["acct/a/seq", 1, 2, true], ["acct/b/bal", 20, 2, true], ["acct/a/bal", 15, 101, true]]);
-  assert.deepStrictEqual(b.store, { acct: { a: { seq: 1, bal: 15 }, b: { bal: 20 } } });
-  assert.strictEqual(r1.nRows, 3);
+  // reference insert rule: a first write stores clock {w:2}; the later object (101 > 2) dominates and REPLACES the node: seq is gone
+  assert.deepStrictEqual(applied, [["acct/b", { bal: 20 }, 2, true], ["acct/a", { bal: 15 }, 101, true]]);
+  assert.deepStrictEqual(b.store, { acct: { a: { bal: 15 }, b: { bal: 20 } } });
+  assert.strictEqual(r1.nRows, 2);
   const snap = crt.checkpoint().sort((x, y) => (x.path + x.field < y.path + y.field ? -1 : 1));
-  assert.deepStrictEqual(snap.map((x) => [x.path, x.collection, x.field, x.ts, x.val]),
-    [["acct/a", "acct", "bal", 101, 15], ["acct/a", "acct", "seq", 2, 1], ["acct/b", "acct", "bal", 2, 20]]);
+  assert.deepStrictEqual(snap.map((x) => [x.path, x.collection, x.field, x.ts, x.field === hash.NODE_CLOCK ? "seq" : x.val]),
+    [["acct/a", "acct", hash.NODE_CLOCK, 101, "seq"], ["acct/a", "acct", "bal", 101, 15], ["acct/b", "acct", hash.NODE_CLOCK, 2, "seq"], ["acct/b", "acct", "bal", 2, 20]]);
   b.close();
   const b2 = new MiniBullet("w");
   const h2 = attach(b2, { capacityRows: 4096 });
-  assert.strictEqual(h2.crt.restore(snap), 3);
-  const again = h2.crt.mergeEntries([{ path: "acct/a", data: { bal: 1 }, vectorClock: { w: 50 } }, { path: "acct/b", data: { bal: 21 }, vectorClock: { w: 2 } }]);
-  assert.deepStrictEqual(again.applied, [{ entry: 1, field: "bal" }]);      // 50 < 101 loses; (2,21) > (2,20) wins the tie by value
+  assert.strictEqual(h2.crt.restore(snap), 4);
+  const again = h2.crt.mergeEntries([{ path: "acct/a", data: { bal: 1 }, vectorClock: { w: 50 } }, { path: "acct/b", data: { bal: 19 }, vectorClock: { w: 2 } }]);
+  assert.deepStrictEqual(again.applied, [{ entry: 1, field: null }]);      // 50 < 101 is historical; {w:2} ties with the stored clock and the INCOMING object wins, smaller value or not
   b2.close();
   checks += 6;
 }
 
 /* N2: the reference's sync-chunk loop, batched. Fixture generated by running the REAL BulletNetworkSync._processSyncEntries
- * (tests/golden/g8_sync_chunk.json): final store, and clock + source of every path the host path owns — including the tagging quirk
- * (primitives arrive untagged, are treated as local writes and always accepted). Device-eligible entries ({ints}, clock {w: ts}) go
- * through one merge per run; their clocks live per leaf. */
+ * (tests/golden/g8_sync_chunk.json): final store, clock + source of EVERY path — including the tagging quirk (primitives arrive untagged,
+ * are treated as local writes and always accepted) and a node created on the device and deleted through the host path. */
 {
   const g = load("g8_sync_chunk.json");
-  const b = new MiniBullet(g.id);
+  const b = new MiniBullet("w");
   const { crt, sync } = attach(b, { capacityRows: 4096, batchSync: true });
   for (const chunk of g.chunks) sync.processSyncEntries(JSON.parse(JSON.stringify(chunk)), "peer-1");
   assert.deepStrictEqual(JSON.parse(JSON.stringify(b.store)), g.store, "store after three sync chunks");
-  const deviceNodes = new Set(["acct/a", "acct/b", "acct/e"]);     // nodes that only ever arrived inside the device contract
+  assert.deepStrictEqual(Object.keys(b.meta).sort(), Object.keys(g.meta).sort(), "the same paths carry a clock");
   for (const p of Object.keys(g.meta)) {
-    if (deviceNodes.has(p)) {
-      for (const f of Object.keys(g.store.acct[p.split("/")[1]])) {
-        assert.deepStrictEqual(b.meta[p + "/" + f].vectorClock, g.meta[p].vectorClock, "leaf clock of " + p + "/" + f);
-        assert.strictEqual(b.meta[p + "/" + f].source, "network");
-        checks++;
-      }
-    } else if (p !== "acct/c") {                                    // acct/c: created on the device, then deleted through the host path
-      assert.deepStrictEqual(b.meta[p].vectorClock, g.meta[p].vectorClock, "clock of " + p);
-      assert.strictEqual(b.meta[p].source, g.meta[p].source, "source of " + p);
-      checks++;
-    }
+    assert.deepStrictEqual(b.meta[p].vectorClock, g.meta[p].vectorClock, "clock of " + p);
+    assert.strictEqual(b.meta[p].source, g.meta[p].source, "source of " + p);
+    checks++;
   }
   assert.strictEqual(b.meta["cfg/limit"].source, "local");          // the quirk: a primitive from the network is a local write
   assert.strictEqual(b.store.acct.c, null);
   assert.ok(sync.stats.deviceBatches >= 3 && sync.stats.hostEntries >= 7, JSON.stringify(sync.stats));
-  // network puts: queued and merged when the event loop turns, in arrival order
+  // network puts (batching off: applied as they arrive, like the reference)
   sync.handlePut("peer-2", { path: "acct/a", data: { bal: 500, seq: 9, __vectorClock: { w: 151 } } });
   sync.handlePut("peer-2", { path: "acct/a", data: { bal: 1, seq: 1, __vectorClock: { w: 3 } } });
   sync.handlePut("peer-2", { path: "cfg/name", data: "gamma" });
-  sync.flush();
   assert.deepStrictEqual(b.store.acct.a, { bal: 500, seq: 9 });
   assert.strictEqual(b.store.cfg.name, "gamma");
+  // ... and the device followed the host-path write: a sync entry at the put's clock ties and wins, an older one is historical
+  sync.processSyncEntries([{ path: "acct/a", data: { bal: 2 }, vectorClock: { w: 150 } }, { path: "acct/a", data: { bal: 3 }, vectorClock: { w: 151 } }], "peer-1");
+  assert.deepStrictEqual(b.store.acct.a, { bal: 3 });
   b.close();
-  checks += 6;
+  checks += 7;
+}
+
+/* N2/N4: NODE-level semantics, pinned on tests/golden/g9_sync_node_semantics.json (the reference's own loop): shrinking and growing field
+ * sets, ties on the stored clock (also the {w:2} of a first sight), deletions and re-creations, a node that starts on the host path. Store and
+ * every path's clock + source after EVERY chunk; then the reference's query answers from a store-sourced index (reference order) and from a
+ * device-sourced one (the rows the batches and the host-path mirror left on the GPU: deleted nodes and replaced fields must be gone). */
+for (const batchPuts of [false, true]) {
+  const g = load("g9_sync_node_semantics.json");
+  const b = new MiniBullet(g.id);
+  const { crt, query, sync } = attach(b, { capacityRows: 4096, batchSync: { batchPuts } });
+  g.chunks.forEach((chunk, ci) => {
+    if (batchPuts && ci === 2) {     // the same entries as network puts: queued, merged when the queue is flushed (here: by the next chunk's first use)
+      for (const e of chunk) {
+        if (e.deleted || typeof e.data !== "object") sync.processSyncEntries([JSON.parse(JSON.stringify(e))], "peer-1");
+        else sync.handlePut("peer-1", { path: e.path, data: Object.assign({}, e.data, { __vectorClock: e.vectorClock }) });
+      }
+      sync.flush();
+    } else sync.processSyncEntries(JSON.parse(JSON.stringify(chunk)), "peer-1");
+    const want = g.after[ci];
+    assert.deepStrictEqual(JSON.parse(JSON.stringify(b.store)), want.store, "g9 store after chunk " + (ci + 1));
+    assert.deepStrictEqual(Object.keys(b.meta).sort(), Object.keys(want.meta).sort(), "g9 paths with a clock after chunk " + (ci + 1));
+    for (const p of Object.keys(want.meta)) {
+      assert.deepStrictEqual(b.meta[p].vectorClock, want.meta[p].vectorClock, "g9 clock of " + p + " after chunk " + (ci + 1));
+      assert.strictEqual(b.meta[p].source, want.meta[p].source, "g9 source of " + p + " after chunk " + (ci + 1));
+      checks++;
+    }
+  });
+  assert.ok(sync.stats.deviceEntries >= 20 && sync.stats.hostEntries >= 7, JSON.stringify(sync.stats));
+  const G2 = require("../gpu-query");
+  const dq = new G2({ id: "w", _getData: (p) => b._getData(p), setData() {}, get: (p) => b.get(p) }, { graph: crt.graph });   // a second engine on the same device rows
+  for (const q of g.queries) {
+    if (q.op === "count") {
+      assert.strictEqual(query.count(q.path, q.field, q.args[0]), q.count, "g9 count");
+      dq.index(q.path, q.field, { source: "device" });
+      assert.strictEqual(dq.count(q.path, q.field, q.args[0]), q.count, "g9 count (device rows)");
+    } else {
+      const got = q.op === "range" ? query.range(q.path, q.field, q.args[0], q.args[1]) : query.equals(q.path, q.field, q.args[0]);
+      assert.deepStrictEqual(got.map((n) => n.path), q.paths, "g9 " + q.op + " " + q.field + " (store-sourced index, reference order)");
+      dq.index(q.path, q.field, { source: "device" });
+      const dev = q.op === "range" ? dq.range(q.path, q.field, q.args[0], q.args[1]) : dq.equals(q.path, q.field, q.args[0]);
+      assert.deepStrictEqual(dev.map((n) => n.path).sort(), q.paths.slice().sort(), "g9 " + q.op + " " + q.field + " (device-sourced index)");
+    }
+    checks += 2;
+  }
+  b.close();
 }
 
 /* N3 (device side): a reference-written storage directory -> device rows; rows that reach the device through typed columns only
@@ -256,8 +296,8 @@ for (const shards of [2, 4, 8]) {
   b.storage = new GpuStorage(b, { path: tmp, saveInterval: 0 });
   const { crt } = attach(b, { capacityRows: 4096 });
   const wantStore = JSON.parse(fs.readFileSync(path.join(src, "store.json"), "utf8")), wantMeta = JSON.parse(fs.readFileSync(path.join(src, "meta.json"), "utf8"));
-  const g = crt.graph;                                               // created now: preloaded from what the storage loaded
-  assert.strictEqual(g.rowCount(), 40 * 2 + 1);                       // 40 nodes x {age, score} + cfg/count
+  const g = crt.graph;                                               // created now: seeded from what the storage loaded
+  assert.strictEqual(g.rowCount(), 40 * 3 + 1 + 3);                   // 40 nodes x {clock, age, score} + cfg/title (clock only: a string) + cfg/count (clock, value, field of cfg)
   const ids = new BigUint64Array(80), id32 = new Uint32Array(ids.buffer), fields = new Uint32Array(80);
   let k = 0;
   for (let i = 0; i < 40; i++) for (const f of ["age", "score"]) { const id = g.keys.idOf("n/k" + i); id32[2 * k] = id[0]; id32[2 * k + 1] = id[1]; fields[k] = g.keys.fieldOf("n", f); k++; }
@@ -269,9 +309,9 @@ for (const shards of [2, 4, 8]) {
     assert.strictEqual(Number(rows.ts[k]), wantMeta["n/k" + i].vectorClock.w);
     k++;
   }
-  // a sync chunk merges against the restored clocks: 1 is historical everywhere, 1000 wins everywhere
+  // a sync chunk is resolved against the restored NODE clocks: 1 is historical everywhere, 1000 dominates and replaces the node
   const r = crt.mergeEntries([{ path: "n/k0", data: { age: 1 }, vectorClock: { w: 1 } }, { path: "n/k1", data: { age: 77 }, vectorClock: { w: 1000 } }], { apply: true });
-  assert.deepStrictEqual(r.applied, [{ entry: 1, field: "age" }]);
+  assert.deepStrictEqual(r.applied, [{ entry: 1, field: null }]);
   // rows that arrive as typed columns only (no facade write) are folded into the files on save
   const cols = new hash.Columns(1);
   cols.set(0, g.keys.idOf("n/k2"), g.keys.fieldOf("n", "score"), 5000, 4242);
@@ -280,11 +320,12 @@ for (const shards of [2, 4, 8]) {
   const savedStore = JSON.parse(fs.readFileSync(path.join(tmp, "store.json"), "utf8")), savedMeta = JSON.parse(fs.readFileSync(path.join(tmp, "meta.json"), "utf8"));
   assert.strictEqual(savedStore.n.k2.score, 4242);
   assert.deepStrictEqual(savedMeta["n/k2/score"].vectorClock, { w: 5000 });
-  assert.strictEqual(savedStore.n.k1.age, 77);
-  assert.deepStrictEqual(savedMeta["n/k1/age"].vectorClock, { w: 1000 });
-  assert.strictEqual(savedStore.n.k0.age, wantStore.n.k0.age);
+  assert.deepStrictEqual(savedStore.n.k1, { age: 77 });
+  assert.deepStrictEqual(savedMeta["n/k1"].vectorClock, { w: 1000 });
+  assert.deepStrictEqual(savedStore.n.k0, wantStore.n.k0);
+  assert.deepStrictEqual(Object.keys(savedMeta).sort(), Object.keys(wantMeta).concat(["n/k2/score"]).sort());   // nothing else was folded: mirrored rows are recognised
   b.close();
-  checks += 8 + 80;
+  checks += 9 + 80;
 }
 
 /* device-sourced index: rows ingested by mergeEntries are queried without re-uploading anything from the JS store */
@@ -293,8 +334,8 @@ for (const shards of [2, 4, 8]) {
   const { crt, query } = attach(b, { capacityRows: 4096 });
   const entries = [];
   for (let i = 0; i < 500; i++) entries.push({ path: "dev/n" + i, data: { age: i % 50, score: 1000 - i }, vectorClock: { w: 10 } });
-  entries.push({ path: "dev/n7", data: { age: 49 }, vectorClock: { w: 11 } });     // newer clock: n7 moves from 7 to 49
-  crt.mergeEntries(entries, { insertMode: "delta" });
+  entries.push({ path: "dev/n7", data: { age: 49 }, vectorClock: { w: 11 } });     // newer clock: n7 is replaced, its age moves from 7 to 49
+  crt.mergeEntries(entries, { insertMode: "delta", apply: true });
   query.index("dev", "age", { source: "device" });
   const keys = (nodes) => nodes.map((n) => n.path.split("/").pop());
   const want49 = []; for (let i = 0; i < 500; i++) if (i % 50 === 49 || i === 7) want49.push("n" + i);
@@ -302,38 +343,51 @@ for (const shards of [2, 4, 8]) {
   assert.strictEqual(query.lastPath, "device");
   assert.strictEqual(query.range("dev", "age", 0, 4).length, 50);
   assert.strictEqual(query.count("dev", "age", 7), 9);                              // n7 moved away from 7
+  query.index("dev", "score", { source: "device" });
+  assert.strictEqual(query.count("dev", "score", 993), 0);                          // ... and its score went with the replaced node (a tombstone on the device)
+  assert.strictEqual(query.count("dev", "score", 992), 1);
   const before = crt.graph.indexRefreshCounts();
-  crt.mergeEntries([{ path: "dev/n1", data: { age: 49 }, vectorClock: { w: 12 } }, { path: "dev/fresh", data: { age: 49 }, vectorClock: { w: 12 } }], { insertMode: "delta" });
+  crt.mergeEntries([{ path: "dev/n1", data: { age: 49 }, vectorClock: { w: 12 } }, { path: "dev/fresh", data: { age: 49 }, vectorClock: { w: 12 } }], { insertMode: "delta", apply: true });
   const got49 = keys(query.equals("dev", "age", 49));
   assert.ok(got49.includes("n1") && got49.includes("fresh"));                       // changed row and created row, both through the change log:
   const after = crt.graph.indexRefreshCounts();
-  assert.strictEqual(after.fullBuilds, before.fullBuilds);                          // the index was not rebuilt from the table
-  assert.strictEqual(after.incremental, before.incremental + 1);
-  b.close();
-  checks += 7;
-}
-
-/* write-through: a leaf written through setData reaches its device row before the next batch is resolved */
-{
-  const b = new MiniBullet("w");
-  const { crt } = attach(b, { capacityRows: 4096 });
-  crt.mergeEntries([{ path: "wt/k1", data: { age: 10, hits: 1 }, vectorClock: { w: 4 } }], { apply: true });
-  assert.deepStrictEqual(b.meta["wt/k1/age"].vectorClock, { w: 2 });              // first write of an absent key: clock 2 (src/bullet-crt.js:172-185)
-  b.setData("wt/k1/age", 50);                                                     // local put: the host clock of the leaf goes to 3
-  assert.deepStrictEqual(b.meta["wt/k1/age"].vectorClock, { w: 3 });
-  let r = crt.mergeEntries([{ path: "wt/k1", data: { age: 40 }, vectorClock: { w: 3 } }], { apply: true });
-  assert.strictEqual(r.nApplied, 0);                                              // (3, 40) loses the tie against (3, 50); the stale row (2, 10) would have lost
-  assert.strictEqual(b.store.wt.k1.age, 50);
-  r = crt.mergeEntries([{ path: "wt/k1", data: { age: 45 }, vectorClock: { w: 4 } }], { apply: true });
-  assert.strictEqual(r.nApplied, 1);
-  assert.strictEqual(b.store.wt.k1.age, 45);
-  b.setData("wt/k2/age", 7);                                                      // a leaf the device has never seen
-  r = crt.mergeEntries([{ path: "wt/k2", data: { age: 9 }, vectorClock: { w: 1 } }], { apply: true });
-  assert.strictEqual(r.nApplied, 0);                                              // not a first write any more: (1, 9) is older than the local put
-  const row = crt.checkpoint().find((x) => x.path === "wt/k2" && x.field === "age");
-  assert.strictEqual(row.val, 7);
+  assert.strictEqual(after.fullBuilds, before.fullBuilds);                          // the indexes were not rebuilt from the table
+  assert.ok(after.incremental > before.incremental);
   b.close();
   checks += 9;
+}
+
+/* write-through: what the host path decides (local puts, deletions) reaches the device before the next batch is resolved — node level */
+{
+  const b = new MiniBullet("w");
+  const { crt, query } = attach(b, { capacityRows: 4096 });
+  crt.mergeEntries([{ path: "wt/k1", data: { age: 10, hits: 1 }, vectorClock: { w: 4 } }], { apply: true });
+  assert.deepStrictEqual(b.meta["wt/k1"].vectorClock, { w: 2 });                   // first write of an absent node: clock 2 (src/bullet-crt.js:172-185)
+  b.setData("wt/k1/age", 50);                                                     // local put of a LEAF: its own path gets its own clock ({w:3}: a local first write increments twice, src/bullet-crt.js:358 + :172-185), the node's stays
+  assert.deepStrictEqual(b.meta["wt/k1/age"].vectorClock, { w: 3 });
+  assert.deepStrictEqual(b.meta["wt/k1"].vectorClock, { w: 2 });
+  let r = crt.mergeEntries([{ path: "wt/k1", data: { age: 45 }, vectorClock: { w: 1 } }], { apply: true });
+  assert.strictEqual(r.nApplied, 0);                                              // older than the node's clock: historical
+  assert.strictEqual(b.store.wt.k1.age, 50);
+  r = crt.mergeEntries([{ path: "wt/k1", data: { age: 40 }, vectorClock: { w: 2 } }], { apply: true });
+  assert.strictEqual(r.nApplied, 1);                                              // a tie on the node's clock: the incoming object wins and replaces the node
+  assert.deepStrictEqual(b.store.wt.k1, { age: 40 });
+  b.setData("wt/k2", { age: 7 });                                                 // a node the device has never seen, written locally: clock {w:3}
+  r = crt.mergeEntries([{ path: "wt/k2", data: { age: 9 }, vectorClock: { w: 2 } }], { apply: true });
+  assert.strictEqual(r.nApplied, 0);                                              // not a first sight any more: 2 is older than the local write's clock
+  r = crt.mergeEntries([{ path: "wt/k2", data: { age: 9, hits: 3 }, vectorClock: { w: 3 } }], { apply: true });
+  assert.strictEqual(r.nApplied, 1);
+  b.setData("wt/k1", null);                                                       // deletion (what a `deleted` sync entry becomes): the clock goes to 3
+  assert.deepStrictEqual(b.meta["wt/k1"].vectorClock, { w: 3 });
+  query.index("wt", "age", { source: "device" });
+  assert.deepStrictEqual(query.range("wt", "age", 0, 100).map((n) => n.path), ["wt/k2"]);   // the deleted node left the device-side index
+  r = crt.mergeEntries([{ path: "wt/k1", data: { age: 41 }, vectorClock: { w: 2 } }, { path: "wt/k1", data: { age: 42 }, vectorClock: { w: 3 } }], { apply: true });
+  assert.deepStrictEqual(r.applied, [{ entry: 1, field: null }]);                 // 2 is older than the delete's clock, 3 ties with it and wins
+  assert.deepStrictEqual(query.range("wt", "age", 0, 100).map((n) => n.path), ["wt/k1", "wt/k2"]);
+  const row = crt.checkpoint().find((x) => x.path === "wt/k2" && x.field === "hits");
+  assert.strictEqual(row.val, 3);
+  b.close();
+  checks += 14;
 }
 
 /* Q4: writes under an indexed path patch the index (dirty children -> device rows -> the device's change log) and every query equals what a
@@ -369,7 +423,7 @@ for (const shards of [2, 4, 8]) {
   b.setData("users/yan", { age: 39, score: 450 });
   sameAsFresh("patched once");
   b.setData("users/zed/score", 451); b.setData("users/u5/age", 1000);
-  crt.mergeEntries([{ path: "users/u1", data: { age: 39 }, vectorClock: { w: 999999 } }, { path: "users/batchnew", data: { age: 7, score: 200 }, vectorClock: { w: 5 } }], { apply: true });
+  crt.mergeEntries([{ path: "users/u1", data: { age: 39, score: 3 }, vectorClock: { w: 999999 } }, { path: "users/batchnew", data: { age: 7, score: 200 }, vectorClock: { w: 5 } }], { apply: true });
   sameAsFresh("patched twice, one of them through a batch");
   assert.strictEqual(query.stats.builds, s0.builds, "patched indexes were rebuilt from the store");
   assert.ok(query.stats.patches >= s0.patches + 4);
@@ -500,5 +554,40 @@ for (const [name, shards] of [["g6_vc_unique_2k.json", 1], ["g6_vc_dups_500.json
     (e) => e.code === -5);
   crt.close();
   checks += 3;
+
+  /* the ingestion pipeline (mergeEntriesAsync, two chunks in flight: chunk b + 1 is packed while chunk b is on the GPU, winners are applied one
+   * chunk late): same store, same clocks, same device rows as the synchronous loop over the same chunks — first sights, ties and replaced nodes
+   * spread over chunk boundaries */
+  {
+    let s = 777;
+    const rnd = () => { s ^= s << 13; s >>>= 0; s ^= s >>> 17; s ^= s << 5; s >>>= 0; return s; };
+    const chunks = [];
+    for (let c = 0; c < 6; c++) {
+      const entries = [];
+      for (let j = 0; j < 3000; j++) {
+        const data = rnd() % 3 === 0 ? { a: rnd() % 50 } : (rnd() % 2 ? { a: rnd() % 50, b: rnd() % 9 } : { b: rnd() % 9, c: 1 });
+        entries.push({ path: "p/n" + (rnd() % 2500), data, vectorClock: { w: rnd() % 12 } });     // few clocks: ties everywhere, {w:2} included
+      }
+      chunks.push(entries);
+    }
+    const run = async (pipelined) => {
+      const b = new MiniBullet("w");
+      const { crt: c2, query } = attach(b, { capacityRows: 1 << 15 });
+      if (pipelined) await c2.mergeEntriesPipelined(chunks.map((c) => JSON.parse(JSON.stringify(c))), { apply: true });
+      else for (const c of chunks) c2.mergeEntries(JSON.parse(JSON.stringify(c)), { apply: true });
+      query.index("p", "a", { source: "device" });
+      const out = { store: JSON.parse(JSON.stringify(b.store)), clocks: Object.keys(b.meta).sort().map((k) => [k, b.meta[k].vectorClock.w]),
+        scan: query.range("p", "a", 10, 30).map((n) => n.path), rows: c2.checkpoint().filter((x) => x.field !== hash.NODE_CLOCK).map((x) => [x.path, x.field, x.ts, x.val].join()).sort() };
+      b.close();
+      return out;
+    };
+    const seq = await run(false), pip = await run(true);
+    assert.deepStrictEqual(pip.store, seq.store, "pipelined ingestion: store");
+    assert.deepStrictEqual(pip.clocks, seq.clocks, "pipelined ingestion: clocks");
+    assert.deepStrictEqual(pip.scan, seq.scan, "pipelined ingestion: device-side scan");
+    assert.deepStrictEqual(pip.rows, seq.rows, "pipelined ingestion: device value rows");
+    assert.ok(seq.scan.length > 100 && seq.clocks.length > 2000);
+    checks += 5;
+  }
   console.log("device_parity ok:", checks, "checks");
 })().catch((e) => { console.error(e); process.exit(1); });

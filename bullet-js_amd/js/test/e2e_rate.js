@@ -1,8 +1,9 @@
 "use strict";
 /*
  * e2e_rate.js — end-to-end rate of the JS host on this box (bench.py's `js_host` key): sync-chunk entries in, winners out.
- *   mergeEntries : [{path, data: {f: int}, vectorClock: {w: ts}}] -> path hashing + typed columns + GPU merge + winner mapping
- *   mergeBatch   : typed columns -> GPU merge (what is left when the host keeps its keys hashed)
+ *   mergeEntries          : [{path, data: {f: int}, vectorClock: {w: ts}}] -> path hashing + one clock-row delta per entry + GPU merge + winners' value rows
+ *   mergeEntriesPipelined : the same through mergeEntriesAsync, two chunks in flight (chunk b + 1 is packed while chunk b is on the GPU)
+ *   mergeBatch            : typed columns -> GPU merge (what is left when the host keeps its keys hashed)
  * Resident graph R keys, B batches of D entries (10 % new keys). One thread. Needs an MI355X.
  * Usage: node e2e_rate.js [R] [D] [B]   -> one JSON line
  */
@@ -15,26 +16,39 @@ const rnd = () => { s ^= s << 13; s >>>= 0; s ^= s >>> 17; s ^= s << 5; s >>>= 0
 const crt = new GpuCRT({ id: "w", meta: {}, _getData() {} }, { capacityRows: 2 * (R + B * D) });
 const g = crt.graph;
 {
-  const cols = new hash.Columns(R);
-  const f = g.keys.fieldOf("n", "f");
-  for (let i = 0; i < R; i++) cols.set(i, g.keys.idOf("n/k" + i), f, 1000000 + (rnd() % 1000000), (rnd() % 2001) - 1000);
+  // resident nodes: a clock row (what entries are resolved against) and the value row of their field
+  const cols = new hash.Columns(2 * R);
+  const f = g.keys.fieldOf("n", "f"), fc = g.keys.fieldOf("n", hash.NODE_CLOCK);
+  for (let i = 0; i < R; i++) {
+    const id = g.keys.idOf("n/k" + i), ts = 1000000 + (rnd() % 1000000);
+    cols.set(2 * i, id, fc, ts, 0); cols.set(2 * i + 1, id, f, ts, (rnd() % 2001) - 1000);
+  }
   g.loadRows(cols);
 }
-const batches = [];
-for (let b = 0; b < B; b++) {
-  const entries = new Array(D);
-  for (let j = 0; j < D; j++) {
-    const ins = rnd() % 100 < 10;
-    const clock = { w: 1000000 + (rnd() % 2000000) };
-    entries[j] = { path: "n/k" + (ins ? R + b * D + j : rnd() % R), data: { f: (rnd() % 2001) - 1000 }, vectorClock: clock };
+const mkBatches = (salt) => {
+  const out = [];
+  for (let b = 0; b < B; b++) {
+    const entries = new Array(D);
+    for (let j = 0; j < D; j++) {
+      const ins = rnd() % 100 < 10;
+      const clock = { w: 1000000 + (rnd() % 2000000) };
+      entries[j] = { path: "n/k" + (ins ? R + salt * B * D + b * D + j : rnd() % R), data: { f: (rnd() % 2001) - 1000 }, vectorClock: clock };
+    }
+    out.push(entries);
   }
-  batches.push(entries);
-}
+  return out;
+};
+const batches = mkBatches(0), batches2 = mkBatches(1);
 crt.mergeEntries(batches[0].slice(0, 1000));                     // warm the addon and the JIT
 let applied = 0;
 let t0 = process.hrtime.bigint();
 for (const entries of batches) applied += crt.mergeEntries(entries).nApplied;
 const dtEntries = Number(process.hrtime.bigint() - t0) / 1e9;
+(async () => {
+t0 = process.hrtime.bigint();
+const pr = await crt.mergeEntriesPipelined(batches2);
+applied += pr.nApplied;
+const dtPipe = Number(process.hrtime.bigint() - t0) / 1e9;
 // the same amount of work with the keys already hashed (typed columns in, winners out)
 const colsB = [];
 for (let b = 0; b < B; b++) {
@@ -46,6 +60,7 @@ for (let b = 0; b < B; b++) {
 t0 = process.hrtime.bigint();
 for (const cols of colsB) applied += crt.mergeBatch(cols).nApplied;
 const dtCols = Number(process.hrtime.bigint() - t0) / 1e9;
-console.log(JSON.stringify({ mergeEntries_per_s: (B * D) / dtEntries, mergeBatch_typed_columns_per_s: (B * D) / dtCols, unit: "deltas/s", resident_keys: R,
+console.log(JSON.stringify({ mergeEntries_per_s: (B * D) / dtEntries, mergeEntriesPipelined_per_s: (B * D) / dtPipe, mergeBatch_typed_columns_per_s: (B * D) / dtCols, unit: "deltas/s", resident_keys: R,
   entries_per_batch: D, batches: B, applied, node: process.version }));
 crt.close();
+})().catch((e) => { console.error(e); process.exit(1); });

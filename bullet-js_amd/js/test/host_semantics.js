@@ -188,6 +188,7 @@ if (fs.existsSync(path.join(REF, "src", "bullet.js"))) {
   replayL1(() => mk(false), "real-bullet");
   quiet(() => queryExample(() => mk(true), "real-bullet"));
   quiet(() => batchApplyCase(() => mk(false), "real-bullet 2500", 2500));     // against the reference's own _applyUpdate/_notify
+  quiet(() => g9OnTheHost(() => mk(false), "real-bullet"));
   {
     // the reference's file storage reads what GpuStorage wrote, and the real facade accepts GpuStorage at its provider hook
     const os = require("os");
@@ -206,6 +207,29 @@ if (fs.existsSync(path.join(REF, "src", "bullet.js"))) {
   console.log("reference facade present: replayed through the real Bullet with GpuCRT/GpuQuery plugged in");
 }
 
+/* g9 (host side, no GPU): the reference's sync loop entry by entry through GpuCRT.handleUpdate — the host resolver that takes every entry the device
+ * contract leaves out — reproduces the reference's node-level outcomes: store and every clock + source after each chunk, then the queries */
+function g9OnTheHost(makeBullet, label) {
+  const g = load("g9_sync_node_semantics.json");
+  const b = makeBullet();
+  g.chunks.forEach((chunk, ci) => {
+    for (const e of JSON.parse(JSON.stringify(chunk))) {              // the loop body of src/bullet-network-sync.js:552-568
+      if (e.deleted) b.setData(e.path, null, false);
+      else b.setData(e.path, typeof e.data === "object" && e.data !== null ? Object.assign({}, e.data, { __fromNetwork: true, __vectorClock: e.vectorClock }) : e.data, false);
+    }
+    const want = g.after[ci];
+    assert.deepStrictEqual(JSON.parse(JSON.stringify(b.store)), want.store, label + ": g9 store after chunk " + (ci + 1));
+    assert.deepStrictEqual(Object.keys(b.meta).sort(), Object.keys(want.meta).sort(), label);
+    for (const p of Object.keys(want.meta)) {
+      assert.deepStrictEqual(JSON.parse(JSON.stringify(b.meta[p].vectorClock)), want.meta[p].vectorClock, label + ": g9 clock of " + p + " after chunk " + (ci + 1));
+      assert.strictEqual(b.meta[p].source, want.meta[p].source, label + ": g9 source of " + p);
+      checks++;
+    }
+  });
+  return b;
+}
+g9OnTheHost(() => { const b = new MiniBullet("w"); b.crt = new GpuCRT(b); return b; }, "mini");
+
 /* N2 and the wrappers around setData: with put middleware registered nothing is batched (every entry takes setData, one by one);
  * without it the device-eligible run goes to mergeEntries, and the query engine's index hook is told about every batched entry */
 {
@@ -214,7 +238,8 @@ if (fs.existsSync(path.join(REF, "src", "bullet.js"))) {
   const seen = [];
   const fake = { id: "w", meta: {}, store: {}, setData(p, d) { seen.push(p); }, _getData() { return {}; }, middleware: { middleware: { put: [], afterPut: [] }, eventListeners: {} } };
   let merged = 0;
-  const crtStub = { mergeEntries(run) { merged += run.length; return { host: [], nApplied: 0 }; } };
+  const crtStub = new GpuCRTc(fake);                     // the real eligibility rules; the device call is stubbed
+  crtStub.mergeEntries = function (run) { merged += run.length; return { host: [], nApplied: 0 }; };
   const sync = installBatchSync(fake, crtStub, {});
   const entries = [0, 1, 2].map((i) => ({ path: "m/k" + i, data: { v: i }, vectorClock: { w: 10 + i } }));
   sync.processSyncEntries(entries);

@@ -282,6 +282,18 @@ napi_value LoadRows(napi_env env, napi_callback_info info) {
   return nullptr;
 }
 
+// putRows(h, id, field, ts, val): rows decided on the host, stored as given; val == -2^63 (BMX_VAL_DELETED) leaves a tombstone
+napi_value PutRows(napi_env env, napi_callback_info info) {
+  ARGS(5);
+  Handle* h; if (!get_handle(env, argv[0], &h)) return nullptr;
+  Turn turn(h);   // runs in issue order with the asynchronous merges
+  const uint64_t* id; const uint32_t* field; const int64_t *ts, *val; size_t n;
+  if (!get_cols(env, argv + 1, &id, &field, &ts, &val, &n)) return nullptr;
+  int rc = bmx_put_rows(h->ctx, n, id, field, ts, val, BMX_MEM_HOST);
+  if (rc) return throw_bmx(env, h->ctx, rc);
+  return nullptr;
+}
+
 // getRows(h, id, field) -> {ts, val, found}
 napi_value GetRows(napi_env env, napi_callback_info info) {
   ARGS(3);
@@ -314,12 +326,15 @@ napi_value DumpRows(napi_env env, napi_callback_info info) {
   Turn turn(h);   // runs in issue order with the asynchronous merges
   uint64_t n = 0; int rc = bmx_row_count(h->ctx, &n);
   if (rc) return throw_bmx(env, h->ctx, rc);
-  void *id, *f, *ts, *val;
-  napi_value a = make_ta(env, napi_biguint64_array, 8, n, &id), b = make_ta(env, napi_uint32_array, 4, n, &f),
-             c = make_ta(env, napi_bigint64_array, 8, n, &ts), d = make_ta(env, napi_bigint64_array, 8, n, &val);
+  std::vector<uint64_t> id(n ? n : 1); std::vector<uint32_t> f(n ? n : 1); std::vector<int64_t> ts(n ? n : 1), val(n ? n : 1);
   uint64_t m = 0;
-  rc = bmx_dump_rows(h->ctx, n, (uint64_t*)id, (uint32_t*)f, (int64_t*)ts, (int64_t*)val, &m, BMX_MEM_HOST);
+  rc = bmx_dump_rows(h->ctx, n, id.data(), f.data(), ts.data(), val.data(), &m, BMX_MEM_HOST);
   if (rc) return throw_bmx(env, h->ctx, rc);
+  if (m > n) m = n;                    // rows in use >= rows dumped: tombstones keep their slot and are not data
+  void *pi, *pf, *pt, *pv;
+  napi_value a = make_ta(env, napi_biguint64_array, 8, m, &pi), b = make_ta(env, napi_uint32_array, 4, m, &pf),
+             c = make_ta(env, napi_bigint64_array, 8, m, &pt), d = make_ta(env, napi_bigint64_array, 8, m, &pv);
+  if (m) { memcpy(pi, id.data(), m * 8); memcpy(pf, f.data(), m * 4); memcpy(pt, ts.data(), m * 8); memcpy(pv, val.data(), m * 8); }
   napi_value out; NAPI_OK(napi_create_object(env, &out));
   napi_set_named_property(env, out, "id", a); napi_set_named_property(env, out, "field", b);
   napi_set_named_property(env, out, "ts", c); napi_set_named_property(env, out, "val", d);
@@ -387,6 +402,31 @@ napi_value ScanCount(napi_env env, napi_callback_info info) {
   uint64_t m = 0; int rc = bmx_scan_count(h->ctx, f, lo, hi, &m, BMX_MEM_HOST);
   if (rc) return throw_bmx(env, h->ctx, rc);
   napi_value v; napi_create_double(env, (double)m, &v); return v;
+}
+// scanRangePos(h, field, lo, hi) -> Uint32Array of index positions (ascending): no id gather on the device, no id -> path lookup on the host
+napi_value ScanRangePos(napi_env env, napi_callback_info info) {
+  ARGS(4);
+  Handle* h; if (!get_handle(env, argv[0], &h)) return nullptr;
+  Turn turn(h);
+  uint32_t f; NAPI_OK(napi_get_value_uint32(env, argv[1], &f));
+  int64_t lo, hi; if (!get_i64(env, argv[2], &lo) || !get_i64(env, argv[3], &hi)) return nullptr;
+  uint64_t m = 0; int rc = bmx_scan_count(h->ctx, f, lo, hi, &m, BMX_MEM_HOST);
+  if (rc) return throw_bmx(env, h->ctx, rc);
+  void* out; napi_value ta = make_ta(env, napi_uint32_array, 4, m, &out);
+  if (m) { uint64_t m2 = 0; rc = bmx_scan_range_pos(h->ctx, f, lo, hi, (uint32_t*)out, m, &m2, BMX_MEM_HOST); if (rc) return throw_bmx(env, h->ctx, rc); }
+  return ta;
+}
+// indexIds(h, field, first, count) -> BigUint64Array: node ids of index positions [first, first + count)
+napi_value IndexIds(napi_env env, napi_callback_info info) {
+  ARGS(4);
+  Handle* h; if (!get_handle(env, argv[0], &h)) return nullptr;
+  Turn turn(h);
+  uint32_t f; NAPI_OK(napi_get_value_uint32(env, argv[1], &f));
+  double first, count; NAPI_OK(napi_get_value_double(env, argv[2], &first)); NAPI_OK(napi_get_value_double(env, argv[3], &count));
+  void* out; napi_value ta = make_ta(env, napi_biguint64_array, 8, (size_t)count, &out);
+  int rc = bmx_index_ids(h->ctx, f, (uint64_t)first, (uint64_t)count, (uint64_t*)out, BMX_MEM_HOST);
+  if (rc) return throw_bmx(env, h->ctx, rc);
+  return ta;
 }
 // scanFilter(h, [[field, lo, hi], ...]) -> BigUint64Array
 napi_value ScanFilter(napi_env env, napi_callback_info info) {
@@ -660,6 +700,16 @@ napi_value CommLoadRows(napi_env env, napi_callback_info info) {
   if (rc) return throw_comm(env, h->c, rc);
   return nullptr;
 }
+napi_value CommPutRows(napi_env env, napi_callback_info info) {
+  ARGS(5);
+  CommHandle* h; if (!get_comm(env, argv[0], &h)) return nullptr;
+  const uint64_t* id; const uint32_t* field; const int64_t *ts, *val; size_t n;
+  if (!get_cols(env, argv + 1, &id, &field, &ts, &val, &n)) return nullptr;
+  std::lock_guard<std::mutex> g(h->mu);
+  int rc = bmx_comm_put_rows(h->c, n, id, field, ts, val);
+  if (rc) return throw_comm(env, h->c, rc);
+  return nullptr;
+}
 napi_value CommGetRows(napi_env env, napi_callback_info info) {
   ARGS(3);
   CommHandle* h; if (!get_comm(env, argv[0], &h)) return nullptr;
@@ -689,12 +739,15 @@ napi_value CommDumpRows(napi_env env, napi_callback_info info) {
   std::lock_guard<std::mutex> g(h->mu);
   uint64_t n = 0; int rc = bmx_comm_row_count(h->c, &n);
   if (rc) return throw_comm(env, h->c, rc);
-  void *id, *f, *ts, *val;
-  napi_value a = make_ta(env, napi_biguint64_array, 8, n, &id), b = make_ta(env, napi_uint32_array, 4, n, &f),
-             c = make_ta(env, napi_bigint64_array, 8, n, &ts), d = make_ta(env, napi_bigint64_array, 8, n, &val);
+  std::vector<uint64_t> id(n ? n : 1); std::vector<uint32_t> f(n ? n : 1); std::vector<int64_t> ts(n ? n : 1), val(n ? n : 1);
   uint64_t m = 0;
-  rc = bmx_comm_dump_rows(h->c, n, (uint64_t*)id, (uint32_t*)f, (int64_t*)ts, (int64_t*)val, &m);
+  rc = bmx_comm_dump_rows(h->c, n, id.data(), f.data(), ts.data(), val.data(), &m);
   if (rc) return throw_comm(env, h->c, rc);
+  if (m > n) m = n;                    // tombstones keep their slot and are not dumped
+  void *pi, *pf, *pt, *pv;
+  napi_value a = make_ta(env, napi_biguint64_array, 8, m, &pi), b = make_ta(env, napi_uint32_array, 4, m, &pf),
+             c = make_ta(env, napi_bigint64_array, 8, m, &pt), d = make_ta(env, napi_bigint64_array, 8, m, &pv);
+  if (m) { memcpy(pi, id.data(), m * 8); memcpy(pf, f.data(), m * 4); memcpy(pt, ts.data(), m * 8); memcpy(pv, val.data(), m * 8); }
   napi_value out; NAPI_OK(napi_create_object(env, &out));
   napi_set_named_property(env, out, "id", a); napi_set_named_property(env, out, "field", b);
   napi_set_named_property(env, out, "ts", c); napi_set_named_property(env, out, "val", d);
@@ -776,7 +829,7 @@ napi_value CommScanFilter(napi_env env, napi_callback_info info) {
 
 napi_value Init(napi_env env, napi_value exports) {
   struct { const char* name; napi_callback fn; } fns[] = {
-      {"abiVersion", AbiVersion}, {"create", Create}, {"destroy", Destroy}, {"mergeBatch", MergeBatch}, {"mergeBatchAsync", MergeBatchAsync}, {"reserve", Reserve}, {"loadRows", LoadRows},
+      {"abiVersion", AbiVersion}, {"create", Create}, {"destroy", Destroy}, {"mergeBatch", MergeBatch}, {"mergeBatchAsync", MergeBatchAsync}, {"reserve", Reserve}, {"loadRows", LoadRows}, {"putRows", PutRows}, {"scanRangePos", ScanRangePos}, {"indexIds", IndexIds}, {"commPutRows", CommPutRows},
       {"getRows", GetRows}, {"rowCount", RowCount}, {"dumpRows", DumpRows}, {"indexBuild", IndexBuild}, {"indexDrop", IndexDrop},
       {"indexSize", IndexSize}, {"indexRefreshCounts", IndexRefreshCounts}, {"scanRange", ScanRange}, {"scanCount", ScanCount}, {"scanFilter", ScanFilter}, {"info", Info},
       {"vcCreate", VcCreate}, {"vcDestroy", VcDestroy}, {"vcLoadRows", VcLoadRows}, {"vcMergeBatch", VcMergeBatch}, {"vcGetRows", VcGetRows}, {"vcRowCount", VcRowCount}, {"vcScanRange", VcScanRange}, {"ownersOf", OwnersOf},
@@ -789,7 +842,7 @@ napi_value Init(napi_env env, napi_value exports) {
     napi_set_named_property(env, exports, f.name, v);
   }
   struct { const char* name; int v; } consts[] = {{"INSERT_REFERENCE", BMX_INSERT_REFERENCE}, {"INSERT_DELTA", BMX_INSERT_DELTA},
-                                                  {"MERGE_UNIQUE_KEYS", BMX_MERGE_UNIQUE_KEYS}, {"MERGE_STRICT_FLAGS", BMX_MERGE_STRICT_FLAGS}, {"FLAG_INCOMING", BMX_FLAG_INCOMING},
+                                                  {"MERGE_UNIQUE_KEYS", BMX_MERGE_UNIQUE_KEYS}, {"MERGE_STRICT_FLAGS", BMX_MERGE_STRICT_FLAGS}, {"MERGE_MARK_CREATED", BMX_MERGE_MARK_CREATED}, {"FLAG_INCOMING", BMX_FLAG_INCOMING},
                                                   {"FLAG_CURRENT", BMX_FLAG_CURRENT}, {"FLAG_HISTORICAL", BMX_FLAG_HISTORICAL}, {"FLAG_CONCURRENT", BMX_FLAG_CONCURRENT},
                                                   {"VC_MAX_WRITERS", BMX_VC_MAX_WRITERS}, {"VC_ABSENT", BMX_VC_ABSENT}, {"VC_DENSE", BMX_VC_DENSE}, {"VC_SPARSE", BMX_VC_SPARSE}};
   for (auto& c : consts) { napi_value v; napi_create_int32(env, c.v, &v); napi_set_named_property(env, exports, c.name, v); }

@@ -71,6 +71,12 @@ extern "C" {
  * on unique-key batches (regrouping moves the batch twice: DESIGN.md §5) and robust where the default degrades: thousands of deltas
  * on one key cost LDS hops instead of dependent global loads. Ignored with BMX_MERGE_STRICT_FLAGS / BMX_MERGE_UNIQUE_KEYS. */
 #define BMX_MERGE_BUCKETED 0x800
+/* applied_idx[k] carries bit 31 (BMX_APPLIED_CREATED) when winner k is the delta that CREATED its row: the row then stores the insert rule's
+ * clock ({id: 2} with BMX_INSERT_REFERENCE, src/bullet-crt.js:172-185), not the delta's own ts — what the host writes into meta[path].vectorClock
+ * (src/bullet.js:196-201) without reading the row back. Mask with BMX_APPLIED_INDEX to get the index. Not with the bucketed path. */
+#define BMX_MERGE_MARK_CREATED 0x1000
+#define BMX_APPLIED_CREATED 0x80000000u
+#define BMX_APPLIED_INDEX   0x00FFFFFFu
 
 /* per-delta decision flags (bits of `flags[j]`), the booleans of resolve()'s decision record
  * src/bullet-crt.js:174-184. Exact for batches without duplicate keys (stats.n_conflicts == 0); with duplicates they are

@@ -145,14 +145,18 @@ static unsigned resolve_scalar(orc_t* t, uint64_t id, uint32_t field, int64_t a,
  *   the last applied delta of that key (== smallest index attaining the key's final lexmax).
  * Returns the number of winners.
  */
-uint64_t orc_merge_batch(orc_t* t, uint64_t n, const uint64_t* id, const uint32_t* field, const int64_t* ts,
-                         const int64_t* val, int insert_mode, uint8_t* flags, uint32_t* winners) {
+/* created (optional): created[j] = 1 iff delta j took the "no current state" branch (src/bullet-crt.js:172-185): its row stores the insert
+ * rule's clock, not its own — what BMX_MERGE_MARK_CREATED reports for winners. */
+uint64_t orc_merge_batch_marked(orc_t* t, uint64_t n, const uint64_t* id, const uint32_t* field, const int64_t* ts,
+                                const int64_t* val, int insert_mode, uint8_t* flags, uint32_t* winners, uint8_t* created) {
   t->stamp++;
   uint8_t* applied = (uint8_t*)calloc(n ? n : 1, 1);
   for (uint64_t j = 0; j < n; j++) {
     orc_row* r;
+    const uint64_t rows_before = t->n;
     unsigned f = resolve_scalar(t, id[j], field[j], ts[j], val[j], insert_mode, &r);
     if (flags) flags[j] = (uint8_t)f;
+    if (created) created[j] = t->n != rows_before;
     if (f & ORC_FLAG_INCOMING) {
       if (r->stamp == t->stamp) applied[r->last_j] = 0;
       r->stamp = t->stamp; r->last_j = (uint32_t)j; applied[j] = 1;
@@ -162,6 +166,10 @@ uint64_t orc_merge_batch(orc_t* t, uint64_t n, const uint64_t* id, const uint32_
   for (uint64_t j = 0; j < n; j++) if (applied[j]) { if (winners) winners[w] = (uint32_t)j; w++; }
   free(applied);
   return w;
+}
+uint64_t orc_merge_batch(orc_t* t, uint64_t n, const uint64_t* id, const uint32_t* field, const int64_t* ts,
+                         const int64_t* val, int insert_mode, uint8_t* flags, uint32_t* winners) {
+  return orc_merge_batch_marked(t, n, id, field, ts, val, insert_mode, flags, winners, NULL);
 }
 
 int orc_get_row(orc_t* t, uint64_t id, uint32_t field, int64_t* ts, int64_t* val) {

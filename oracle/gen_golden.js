@@ -442,6 +442,86 @@ function genSyncChunk() {
     chunks, store: JSON.parse(JSON.stringify(b.store)), meta };
 }
 
+/* ------------------------------------------------------------------ g9: NODE-level semantics of synced objects (N2/N4)
+ * The same loop as g8, with exactly the entries a per-FIELD last-writer-wins table gets wrong (VERDICT r2 weak #1):
+ *   - a dominating object REPLACES the node: fields it no longer carries disappear (src/bullet-crt.js:236-248);
+ *   - equal clocks + object values: compare() is +1 for objects, the INCOMING object wins whatever its values (:11-15, :200-233),
+ *     also against the {w:2} clock a first write leaves behind (:172-185);
+ *   - a field that appears later belongs to the node's clock, not to a clock of its own;
+ *   - deletions (setData(path, null), src/bullet-network-sync.js:553-555) and what an index / a query sees afterwards
+ *     (_addToIndex skips null and non-object children, src/bullet-query.js:53-94);
+ *   - a node first written through the host path (string field), later by an all-integer object.
+ * After every chunk the reference's store and per-path clock/source are recorded; after the last one, queries on a fresh index. */
+function genSyncNodeSemantics() {
+  const Sync = require(path.join(REF, "src", "bullet-network-sync.js"));
+  const b = newBullet({ enableIndexing: true });
+  const chunks = [
+    [ /* chunk 1: first sight (stored clock {w:2}); acct/t twice: the second entry TIES with that stored clock and wins with the smaller value */
+      { path: "acct/a", data: { bal: 10, seq: 1 }, vectorClock: { w: 100 } },
+      { path: "acct/b", data: { bal: 20, seq: 1, lim: 5 }, vectorClock: { w: 100 } },
+      { path: "acct/c", data: { bal: 30 }, vectorClock: { w: 100 } },
+      { path: "acct/d", data: { bal: 40, seq: 1 }, vectorClock: { w: 100 } },
+      { path: "acct/t", data: { bal: 9 }, vectorClock: { w: 50 } },
+      { path: "acct/t", data: { bal: 1 }, vectorClock: { w: 2 } },
+      { path: "acct/g", data: { bal: 60, seq: 1 }, vectorClock: { w: 100 } },
+      { path: "users/u1", data: { name: "Ann", age: 30 }, vectorClock: { w: 100 } },
+      { path: "cfg/limit", data: 5, vectorClock: { w: 100 } },
+    ],
+    [ /* chunk 2: shrinking and growing field sets under dominating clocks, a tie on {w:2}, a deletion */
+      { path: "acct/a", data: { bal: 13 }, vectorClock: { w: 151 } },
+      { path: "acct/b", data: { bal: 21, seq: 2 }, vectorClock: { w: 150 } },
+      { path: "acct/c", data: { bal: 31, extra: 7 }, vectorClock: { w: 150 } },
+      { path: "acct/d", deleted: true, vectorClock: { w: 150 } },
+      { path: "acct/t", data: { bal: 0, seq: 4 }, vectorClock: { w: 2 } },
+      { path: "acct/g", data: { bal: 61 }, vectorClock: { w: 1 } },
+      { path: "users/u1", data: { age: 31 }, vectorClock: { w: 150 } },
+    ],
+    [ /* chunk 3: equal clocks after a dominating write, a historical write, the late field under a clock below the node's, re-creation after a delete,
+         one node three times (the last two tie: the later one wins) */
+      { path: "acct/a", data: { bal: 1, seq: 9 }, vectorClock: { w: 151 } },
+      { path: "acct/a", data: { bal: 99 }, vectorClock: { w: 150 } },
+      { path: "acct/c", data: { bal: 32 }, vectorClock: { w: 3 } },
+      { path: "acct/d", data: { bal: 41, seq: 2 }, vectorClock: { w: 200 } },
+      { path: "acct/e", data: { bal: 50 }, vectorClock: { w: 7 } },
+      { path: "acct/e", data: { bal: 51, seq: 2 }, vectorClock: { w: 8 } },
+      { path: "acct/e", data: { bal: 52 }, vectorClock: { w: 8 } },
+      { path: "cfg/limit", data: 6, vectorClock: { w: 300 } },
+    ],
+    [ /* chunk 4: delete, then a write at the clock the delete left behind (a tie: incoming wins), a second delete that stays */
+      { path: "acct/b", deleted: true, vectorClock: { w: 160 } },
+      { path: "acct/g", deleted: true, vectorClock: { w: 160 } },
+      { path: "acct/g", data: { bal: 62, seq: 3 }, vectorClock: { w: 3 } },
+      { path: "acct/h", data: { bal: 70 }, vectorClock: { w: 9 } },
+      { path: "acct/h", deleted: true, vectorClock: { w: 10 } },
+    ],
+  ];
+  const fake = { bullet: b };
+  const after = [];
+  quiet(() => {
+    for (const c of chunks) {
+      Sync.prototype._processSyncEntries.call(fake, c, "peer-1");
+      const meta = {};
+      for (const k of Object.keys(b.meta)) meta[k] = { vectorClock: JSON.parse(JSON.stringify(b.meta[k].vectorClock)), source: b.meta[k].source };
+      after.push({ store: JSON.parse(JSON.stringify(b.store)), meta });
+    }
+  });
+  /* queries on an index that is first built now (the fresh state: SURVEY §8(a) "Scan parity target") */
+  const paths = (nodes) => nodes.map((n) => n.path);
+  const queries = [];
+  quiet(() => {
+    queries.push({ op: "range", path: "acct", field: "bal", args: [0, 100], paths: paths(b.range("acct", "bal", 0, 100)) });
+    queries.push({ op: "equals", path: "acct", field: "bal", args: [41], paths: paths(b.equals("acct", "bal", 41)) });
+    queries.push({ op: "equals", path: "acct", field: "bal", args: [21], paths: paths(b.equals("acct", "bal", 21)) });
+    queries.push({ op: "range", path: "acct", field: "seq", args: [0, 100], paths: paths(b.range("acct", "seq", 0, 100)) });
+    queries.push({ op: "range", path: "acct", field: "lim", args: [0, 100], paths: paths(b.range("acct", "lim", 0, 100)) });
+    queries.push({ op: "range", path: "acct", field: "extra", args: [0, 100], paths: paths(b.range("acct", "extra", 0, 100)) });
+    queries.push({ op: "range", path: "users", field: "age", args: [0, 100], paths: paths(b.range("users", "age", 0, 100)) });
+    queries.push({ op: "count", path: "acct", field: "bal", args: [52], count: b.query.count("acct", "bal", 52) });
+  });
+  return { kind: "sync_node_semantics", source: "reference BulletNetworkSync._processSyncEntries + BulletQuery on a real Bullet (id 'w', network disabled)", id: "w",
+    chunks, after, queries };
+}
+
 /* ------------------------------------------------------------------ g7: a directory written by the reference's file storage (N3)
  * src/bullet-file-storage.js:170-210 writes store.json / meta.json / log.json; the files themselves are the fixture
  * (tests/golden/g7_storage_dir/). */
@@ -498,6 +578,7 @@ function main() {
   write("g5_query_seeded_2k.json", genQuerySeeded(2000, 4711, true));
   write("g5_query_seeded_100k.json", genQuerySeeded(100000, 4712, false));
   write("g8_sync_chunk.json", genSyncChunk());
+  write("g9_sync_node_semantics.json", genSyncNodeSemantics());
   genStorageDir(path.join(OUT, "g7_storage_dir"));
 }
 

@@ -37,6 +37,7 @@ def lib():
         L.orc_size.argtypes = [C.c_void_p]; L.orc_size.restype = C.c_uint64
         L.orc_load_rows.argtypes = [C.c_void_p, C.c_uint64, u64p, u32p, i64p, i64p]
         L.orc_merge_batch.argtypes = [C.c_void_p, C.c_uint64, u64p, u32p, i64p, i64p, C.c_int, u8p, u32p]
+        L.orc_merge_batch_marked.argtypes = [C.c_void_p, C.c_uint64, u64p, u32p, i64p, i64p, C.c_int, u8p, u32p, u8p]; L.orc_merge_batch_marked.restype = C.c_uint64
         L.orc_merge_batch.restype = C.c_uint64
         L.orc_get_row.argtypes = [C.c_void_p, C.c_uint64, C.c_uint32, i64p, i64p]; L.orc_get_row.restype = C.c_int
         L.orc_dump_rows.argtypes = [C.c_void_p, C.c_uint64, u64p, u32p, i64p, i64p]; L.orc_dump_rows.restype = C.c_uint64
@@ -94,6 +95,16 @@ class Oracle:
         w = self._L.orc_merge_batch(self._h, n, _p(id, C.c_uint64), _p(field, C.c_uint32), _p(ts, C.c_int64), _p(val, C.c_int64),
                                     int(insert_mode), _p(flags, C.c_uint8), _p(winners, C.c_uint32))
         return flags, winners[:w].copy()
+
+    def merge_batch_marked(self, id, field, ts, val, insert_mode=INSERT_REFERENCE):
+        """winners u32[w] ascending with bit 31 set on the winners that created their row (what BMX_MERGE_MARK_CREATED reports)"""
+        id, field, ts, val = _cols(id, field, ts, val)
+        n = len(id)
+        winners = np.zeros(max(n, 1), dtype=np.uint32); created = np.zeros(max(n, 1), dtype=np.uint8)
+        w = self._L.orc_merge_batch_marked(self._h, n, _p(id, C.c_uint64), _p(field, C.c_uint32), _p(ts, C.c_int64), _p(val, C.c_int64),
+                                           int(insert_mode), None, _p(winners, C.c_uint32), _p(created, C.c_uint8))
+        win = winners[:w].copy()
+        return win | (created[win].astype(np.uint32) << np.uint32(31))
 
     def get_row(self, id, field):
         ts, val = C.c_int64(), C.c_int64()

@@ -364,3 +364,34 @@ def test_same_new_key_on_every_lane_of_a_wave(mode):
             _, ow = o.merge_batch(ids, fields, ts, val, mode)
             assert np.array_equal(applied, ow), (mode, pos)
         _assert_same_state(e, o)
+
+
+@pytest.mark.parametrize("seed,hot", [(1, 0), (2, 40), (3, 90)])
+def test_mark_created_names_the_delta_that_created_each_row(seed, hot):
+    """BMX_MERGE_MARK_CREATED: bit 31 of applied_idx[k] <=> winner k took resolve()'s "no current state" branch (src/bullet-crt.js:172-185) — its row
+    stores clock 2, not its own ts. Unique keys, heavy duplication (the creating delta is the SMALLEST index of a key, not whoever claimed first) and
+    strict mode; every marked winner's row is read back."""
+    rng = np.random.default_rng(seed)
+    R, D = 3000, 20000
+    rid, rf, rts, rval = synth.big_resident(R, seed=seed)
+    keys = rng.integers(0, 2 * R, D)                    # half of them absent
+    if hot:
+        m = rng.random(D) < hot / 100
+        keys[m] = 2 * R + rng.integers(0, 25, int(m.sum()))   # 25 absent hot keys
+    did = streams.splitmix64_np(keys.astype(np.uint64) + np.uint64(1))
+    did[keys < R] = rid[keys[keys < R]]
+    df = np.full(D, rf[0], np.uint32)
+    dts = rng.integers(0, 6, D).astype(np.int64) if hot else rng.integers(1, 5000, D).astype(np.int64)      # clocks around the stored 2: ties with it happen
+    dval = rng.integers(-3, 4, D).astype(np.int64)
+    for mode in (0, bmx.MERGE_STRICT_FLAGS):
+        o = Oracle(); o.load_rows(rid, rf, rts, rval)
+        want = o.merge_batch_marked(did, df, dts, dval)
+        with bmx.Engine(capacity_rows=4 * (R + D)) as e:
+            e.load_rows(rid, rf, rts, rval)
+            applied, _, st = e.merge_batch(did, df, dts, dval, bmx.INSERT_REFERENCE | bmx.MERGE_MARK_CREATED | mode)
+            assert np.array_equal(applied, want), (mode, int((applied != want).sum()) if len(applied) == len(want) else (len(applied), len(want)))
+            marked = applied[(applied & bmx.APPLIED_CREATED) != 0] & bmx.APPLIED_INDEX
+            assert len(marked) > 100
+            ts, val, found = e.get_rows(did[marked], df[marked])
+            assert found.all() and (ts == 2).all() and np.array_equal(val, dval[marked])
+        o.close()
