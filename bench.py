@@ -386,15 +386,17 @@ def main():
         alg_bytes = 56.0 * D_PER_STEP + 16.0 * wavg
         probe_s = stage_ms["probe_apply"] * 1e-3
         achieved = alg_bytes / probe_s / 1e9 if probe_s > 0 else 0.0
-        traffic = None
+        traffic = requests = None
         tpath = os.path.join(ROOT, "profiles", "traffic_probe_apply.json")
         if os.path.exists(tpath) and CONFIG == 2 and main_kernel == "k_probe_apply":  # HBM bytes per launch from a committed rocprofv3 --pmc run of this same command
             try:
-                traffic = json.load(open(tpath)).get("bytes_per_launch")
+                tj = json.load(open(tpath))
+                traffic = tj.get("bytes_per_launch")
+                requests = {"total": tj.get("requests_per_launch"), "reads": tj.get("read_requests"), "writes_incl_atomics": tj.get("write_requests"), "atomics": tj.get("atomic_requests")}
             except Exception:
-                traffic = None
+                traffic = requests = None
         roofline = {"bound": "hbm", "kernel": main_kernel, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                    "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "algorithmic_bytes_per_launch": alg_bytes,
+                    "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "requests_per_launch": requests, "algorithmic_bytes_per_launch": alg_bytes,
                     "kernel_ms": {k: round(v, 5) for k, v in stage_ms.items()}, "launches_averaged": ncalls,
                     "whole_merge_achieved_GBs": round((56.0 * D_PER_STEP + 20.0 * wavg) / (elapsed / K) / 1e9, 1)}
         total_units = K * D_PER_STEP

@@ -31,7 +31,7 @@ EXPORTS = [
     "bmx_create", "bmx_create_ex", "bmx_destroy", "bmx_last_error", "bmx_abi_version", "bmx_get_info", "bmx_sync", "bmx_set_stream", "bmx_get_stream", "bmx_seq_signal", "bmx_seq_wait",
     "bmx_load_rows", "bmx_put_rows", "bmx_merge_batch", "bmx_merge_submit", "bmx_merge_collect", "bmx_merge_records", "bmx_get_rows", "bmx_get_row", "bmx_dump_rows", "bmx_row_count", "bmx_reserve",
     "bmx_index_build", "bmx_index_drop", "bmx_index_size", "bmx_index_refresh_counts", "bmx_scan_range", "bmx_scan_equals", "bmx_scan_count", "bmx_scan_filter", "bmx_scan_range_pos", "bmx_index_ids",
-    "bmx_owner_of", "bmx_partition_by_owner", "bmx_partition_by_owner_slabs", "bmx_timer_start", "bmx_timer_stop", "bmx_profile_enable", "bmx_profile_read", "bmx_profile_read_scan",
+    "bmx_owner_of", "bmx_partition_by_owner", "bmx_partition_by_owner_slabs", "bmx_partition_scatter", "bmx_ipc_alloc", "bmx_ipc_open", "bmx_ipc_close", "bmx_ipc_free", "bmx_seq_wait_all", "bmx_merge_notify", "bmx_timer_start", "bmx_timer_stop", "bmx_profile_enable", "bmx_profile_read", "bmx_profile_read_scan",
     "bmx_comm_create", "bmx_comm_destroy", "bmx_comm_last_error", "bmx_comm_nshards", "bmx_comm_shard", "bmx_comm_sync", "bmx_comm_load_rows", "bmx_comm_put_rows", "bmx_comm_merge",
     "bmx_comm_merge_dev", "bmx_comm_shard_result", "bmx_comm_row_count", "bmx_comm_get_rows", "bmx_comm_dump_rows", "bmx_comm_index_build",
     "bmx_comm_scan_range", "bmx_comm_scan_equals", "bmx_comm_scan_count", "bmx_comm_scan_filter",

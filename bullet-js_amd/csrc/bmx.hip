@@ -33,6 +33,8 @@ struct DevScalars {  // one small device allocation; zeroed at create
   uint32_t wide;
   unsigned long long seq_diag[3];  // k_seq_wait expiry: {sequence word address, value waited for, value last seen}
   unsigned long long chg_n[2];     // entries in the index change log: batch k reads [k&1], its compaction writes [(k+1)&1]
+  uint32_t part_done;              // bmx_partition_scatter: workgroups of the running scatter that have finished (reset by the last one)
+  uint32_t pad_;
 };
 
 struct Index {
@@ -117,6 +119,8 @@ struct bmx_ctx {
   uint2* chg = nullptr; uint64_t chg_cap = 0, chg_ub = 0;
   bool chg_valid = false; uint32_t chg_par = 0;
   uint64_t ix_full_builds = 0, ix_incremental = 0;
+  // bmx_merge_notify: words (possibly in other GPUs' memory) that every merge's last workgroup sets to the number of merges finished since
+  SeqPtrs notify{}; uint32_t n_notify = 0; uint64_t notify_seq = 0;
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
   // optional per-kernel profiling (bmx_profile_enable)
   bool prof_on = false;
@@ -436,6 +440,8 @@ int merge_core(bmx_ctx* ctx, uint64_t n, const uint64_t* id, const uint32_t* fie
   hipStream_t ks = ctx->stream;
   FinishMerge Fin{reinterpret_cast<unsigned long long*>(n_applied), stats, ctr, &ctx->ds->row_count};
   if (ctx->host_rows) { Fin.host_mirror = ctx->host_rows; Fin.seq = ++ctx->batch_seq; ctx->inflight.emplace_back(Fin.seq, n); }
+  const bool notify_after = ctx->n_notify && ctx->chg_valid;   // with an index change log the compaction's workgroups still read the batch: tell the peers from a launch behind it
+  if (ctx->n_notify) { ++ctx->notify_seq; if (!notify_after) { Fin.notify = ctx->notify; Fin.n_notify = ctx->n_notify; Fin.notify_value = ctx->notify_seq; } }
   ChgLog L{};
   if (ctx->chg_valid) {
     if (legacy && !strict && (!unique || force) && ctx->chg_ub + n <= ctx->chg_cap && ctx->nslots < (1ull << 31)) {
@@ -449,6 +455,7 @@ int merge_core(bmx_ctx* ctx, uint64_t n, const uint64_t* id, const uint32_t* fie
   hipLaunchKernelGGL((k_compact_winners<FinishMerge>), dim3((uint32_t)((n + 4095) / 4096)), dim3(SEL_THREADS), 0, ks, wflag, A.blk_info, (uint32_t)n,
                      applied_idx, Fin, L, mark_created);
   LAUNCHCHK("k_compact_winners");
+  if (notify_after) { hipLaunchKernelGGL(k_seq_signal_multi, dim3(1), dim3(64), 0, ks, ctx->notify, ctx->n_notify, (unsigned long long)ctx->notify_seq); LAUNCHCHK("k_seq_signal_multi"); }
   if (pe) { HIPCHK(hipEventRecord(pe[3], ks)); ctx->prof_n++; }
   ctx->nbatch++;
   ctx->rows_ub += n;
@@ -1302,6 +1309,91 @@ int bmx_partition_by_owner_slabs(bmx_ctx* ctx, uint64_t n, const uint64_t* id, c
                                  uint32_t nshards, uint64_t slab_records, bmx_delta_rec* recs_out, uint64_t* counts_out_dev) {
   if (slab_records == 0) return fail(ctx, BMX_ERR_INVALID, "slab_records must be > 0");
   return partition_impl(ctx, n, id, field, ts, val, nshards, slab_records, recs_out, counts_out_dev);
+}
+
+/* ---- direct exchange between processes (one process per GPU): IPC-mapped receive slabs, arrival words, no collective on the data path ---- */
+int bmx_ipc_alloc(bmx_ctx* ctx, uint64_t bytes, void** dev_ptr, uint8_t handle_out[64]) {
+  if (!ctx || !dev_ptr || !handle_out || bytes == 0) return fail(ctx, BMX_ERR_INVALID, "bmx_ipc_alloc: bad arguments");
+  static_assert(sizeof(hipIpcMemHandle_t) <= 64, "IPC handle fits the 64-byte carrier");
+  HIPCHK(hipSetDevice(ctx->device));
+  void* p = nullptr;
+  hipError_t e = hipMalloc(&p, bytes);
+  if (e != hipSuccess) return fail(ctx, e == hipErrorOutOfMemory ? BMX_ERR_NOMEM : BMX_ERR_HIP, std::string("hipMalloc: ") + hipGetErrorString(e));
+  e = hipMemset(p, 0, bytes);
+  hipIpcMemHandle_t h;
+  if (e == hipSuccess) e = hipIpcGetMemHandle(&h, p);
+  if (e != hipSuccess) { (void)hipFree(p); return fail_hip(ctx, e, "hipIpcGetMemHandle"); }
+  std::memset(handle_out, 0, 64);
+  std::memcpy(handle_out, &h, sizeof(h));
+  *dev_ptr = p;
+  return BMX_OK;
+}
+int bmx_ipc_open(bmx_ctx* ctx, const uint8_t handle[64], int peer_device, void** dev_ptr) {
+  if (!ctx || !handle || !dev_ptr) return fail(ctx, BMX_ERR_INVALID, "bmx_ipc_open: bad arguments");
+  HIPCHK(hipSetDevice(ctx->device));
+  if (peer_device >= 0 && peer_device != ctx->device) {       // peer access first: the mapping below is only usable from this GPU with it
+    int can = 0;
+    HIPCHK(hipDeviceCanAccessPeer(&can, ctx->device, peer_device));
+    if (!can) return fail(ctx, BMX_ERR_HIP, "bmx_ipc_open: no peer access between the two GPUs");
+    hipError_t pe = hipDeviceEnablePeerAccess(peer_device, 0);
+    if (pe != hipSuccess && pe != hipErrorPeerAccessAlreadyEnabled) return fail_hip(ctx, pe, "hipDeviceEnablePeerAccess");
+    (void)hipGetLastError();
+  }
+  hipIpcMemHandle_t h;
+  std::memcpy(&h, handle, sizeof(h));
+  void* p = nullptr;
+  HIPCHK(hipIpcOpenMemHandle(&p, h, hipIpcMemLazyEnablePeerAccess));
+  *dev_ptr = p;
+  return BMX_OK;
+}
+int bmx_ipc_close(bmx_ctx* ctx, void* dev_ptr) {
+  if (!ctx) return fail(nullptr, BMX_ERR_INVALID, "null context");
+  if (!dev_ptr) return BMX_OK;
+  HIPCHK(hipSetDevice(ctx->device));
+  HIPCHK(hipStreamSynchronize(ctx->stream));
+  HIPCHK(hipIpcCloseMemHandle(dev_ptr));
+  return BMX_OK;
+}
+int bmx_ipc_free(bmx_ctx* ctx, void* dev_ptr) {
+  if (!ctx) return fail(nullptr, BMX_ERR_INVALID, "null context");
+  if (!dev_ptr) return BMX_OK;
+  HIPCHK(hipSetDevice(ctx->device));
+  HIPCHK(hipStreamSynchronize(ctx->stream));
+  HIPCHK(hipFree(dev_ptr));
+  return BMX_OK;
+}
+
+int bmx_partition_scatter(bmx_ctx* ctx, uint64_t n, const uint64_t* id, const uint32_t* field, const int64_t* ts, const int64_t* val,
+                          uint32_t nshards, uint64_t slab_records, void* const* dst, uint64_t* counts_out_dev, uint64_t* const* arrive_words, uint64_t arrive_value) {
+  if (!ctx || !dst || slab_records == 0 || nshards == 0 || nshards > PART_MAX_SHARDS) return fail(ctx, BMX_ERR_INVALID, "bmx_partition_scatter: bad arguments (1..16 shards, slab_records > 0)");
+  PartOut po; std::memset(&po, 0, sizeof(po));
+  for (uint32_t g = 0; g < nshards; g++) {
+    if (!dst[g]) return fail(ctx, BMX_ERR_INVALID, "bmx_partition_scatter: null destination slab");
+    po.base[g] = static_cast<bmx_delta_rec*>(dst[g]);
+    if (arrive_words) po.arrive[g] = reinterpret_cast<unsigned long long*>(arrive_words[g]);
+  }
+  if (arrive_words) { po.arrive_value = arrive_value; po.done = &ctx->ds->part_done; }
+  return partition_impl(ctx, n, id, field, ts, val, nshards, slab_records, nullptr, counts_out_dev, &po, 0);
+}
+
+int bmx_seq_wait_all(bmx_ctx* ctx, void* hip_stream, const uint64_t* words_dev, uint32_t nwords, uint64_t at_least) {
+  if (!ctx || !words_dev || nwords == 0 || nwords > 64) return fail(ctx, BMX_ERR_INVALID, "bmx_seq_wait_all: 1..64 words");
+  HIPCHK(hipSetDevice(ctx->device));
+  hipStream_t st = hip_stream ? reinterpret_cast<hipStream_t>(hip_stream) : ctx->stream;
+  hipLaunchKernelGGL(k_seq_wait_all, dim3(1), dim3(64), 0, st, reinterpret_cast<const unsigned long long*>(words_dev), nwords, (unsigned long long)at_least,
+                     &ctx->ds->status, ctx->ds->seq_diag);
+  LAUNCHCHK("k_seq_wait_all");
+  return BMX_OK;
+}
+
+int bmx_merge_notify(bmx_ctx* ctx, uint64_t* const* words, uint32_t nwords) {
+  if (!ctx || nwords > PART_MAX_SHARDS || (nwords && !words)) return fail(ctx, BMX_ERR_INVALID, "bmx_merge_notify: at most 16 words");
+  HIPCHK(hipSetDevice(ctx->device));
+  HIPCHK(hipStreamSynchronize(ctx->stream));
+  std::memset(&ctx->notify, 0, sizeof(ctx->notify));
+  for (uint32_t k = 0; k < nwords; k++) ctx->notify.p[k] = reinterpret_cast<unsigned long long*>(words[k]);
+  ctx->n_notify = nwords; ctx->notify_seq = 0;
+  return BMX_OK;
 }
 
 int bmx_timer_start(bmx_ctx* ctx) {

@@ -555,9 +555,34 @@ __global__ void k_seq_wait(const unsigned long long* seq, unsigned long long at_
   }
 }
 
+// Wait until EVERY one of n words (this GPU's memory, written by peers: system-scope loads) has reached `at_least`: lane k polls word k.
+__global__ void k_seq_wait_all(const unsigned long long* words, uint32_t n, unsigned long long at_least, uint32_t* status, unsigned long long* diag) {
+  const uint32_t k = threadIdx.x;
+  if (k >= n) return;
+  const unsigned long long t0 = wall_clock64();            // 100 MHz
+  unsigned long long seen;
+  while ((seen = __hip_atomic_load(words + k, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM)) < at_least) {
+    __builtin_amdgcn_s_sleep(8);
+    if (wall_clock64() - t0 > 6000000000ull) {             // ~60 s: report instead of hanging
+      if (diag) { diag[0] = (unsigned long long)(uintptr_t)(words + k); diag[1] = at_least; diag[2] = seen; }
+      atomicOr(status, ST_SPIN);
+      return;
+    }
+  }
+}
+// One store of `value` into each of n words that may live in other GPUs' memory (lane k -> word k), after everything enqueued before.
+constexpr int PART_MAX_SHARDS = 16;
+struct SeqPtrs { unsigned long long* p[PART_MAX_SHARDS]; };
+__global__ void k_seq_signal_multi(SeqPtrs w, uint32_t n, unsigned long long value) {
+  if (threadIdx.x < n && w.p[threadIdx.x]) {
+    __threadfence_system();
+    __hip_atomic_store(w.p[threadIdx.x], value, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+  }
+}
+
 // K7: stable partition of a delta batch by owner shard into 32-byte records (two launches: count, scatter).
 // Counting and ranking are wave-ballot based (one __ballot per shard per 64 deltas): no LDS or global atomics.
-constexpr int PART_MAX_SHARDS = 16;
+
 constexpr int PART_BLOCKS = 1024;
 constexpr uint32_t PART_TILE = 1024;   // deltas staged in LDS per step of k_part_scatter; per_block is a multiple of it
 // Where the records of each shard go. Default: one buffer, shard g's run (or slab) at its offset. With `split` set, shard g's slab
@@ -567,6 +592,12 @@ struct PartOut {
   bmx_delta_rec* base[PART_MAX_SHARDS];
   uint32_t split;
   uint32_t aux_base;     // added to the origin index carried in `aux` (offset of this originator's slice in a global batch)
+  // Arrival notification (bmx_partition_scatter): when the LAST workgroup of the scatter has finished — every record is in its owner's receive
+  // slab, possibly another GPU's memory — arrive[g] (a word in shard g's memory) is set to arrive_value. The owner's merge waits for the
+  // words of all its origins (bmx_seq_wait_all): no copy kernel, no collective, no second stream. done = a zeroed counter of this context.
+  unsigned long long* arrive[PART_MAX_SHARDS];
+  unsigned long long arrive_value;
+  uint32_t* done;
 };
 
 __device__ __forceinline__ uint32_t owner_of_dev(uint64_t id, uint32_t nshards) { return (uint32_t)__umul64hi(owner_hash(id), (uint64_t)nshards); }
@@ -710,6 +741,21 @@ __global__ __launch_bounds__(256) void k_part_scatter(const uint64_t* id, const 
         uint4* q = reinterpret_cast<uint4*>((po.split ? po.base[g] : out + (size_t)g * slab) + p);
         q[0] = padlo; q[1] = padhi;
       }
+    }
+  }
+  if (po.done) {
+    // every store of this workgroup is performed system-wide before its ticket is taken; the workgroup that draws the last ticket
+    // therefore knows that ALL records are where they belong and tells the owners (release stores at system scope: peer memory)
+    __shared__ uint32_t s_last;
+    __threadfence_system();
+    __syncthreads();
+    if (threadIdx.x == 0) s_last = atomicAdd(po.done, 1u) == gridDim.x - 1;
+    __syncthreads();
+    if (s_last) {
+      __threadfence_system();
+      if (threadIdx.x < nshards && po.arrive[threadIdx.x])
+        __hip_atomic_store(po.arrive[threadIdx.x], po.arrive_value, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+      if (threadIdx.x == 0) *po.done = 0u;      // ready for the next partition on this context (same stream: ordered)
     }
   }
 }

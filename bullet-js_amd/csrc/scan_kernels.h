@@ -247,6 +247,9 @@ struct FinishMerge {  // totals -> caller; fold and clear the sharded per-batch 
   unsigned long long* shard_ctr; unsigned long long* row_count;
   // optional: {rows, batch sequence number} in host memory the GPU can write (the host bounds the row count from it without a sync)
   unsigned long long* host_mirror = nullptr; unsigned long long seq = 0;
+  // optional (bmx_merge_notify): words, possibly in other GPUs' memory, that learn how many merges this context has finished — the origins of the
+  // direct exchange reuse a receive slab set only after the merge that read it (this launch is the merge's last: the table and the slabs are done with)
+  SeqPtrs notify{}; uint32_t n_notify = 0; unsigned long long notify_value = 0;
   __device__ void operator()(uint64_t total, uint32_t* lds4) const {
     static_assert(CTR_SHARDS == SEL_THREADS, "one counter shard per thread");
     unsigned long long* c = shard_ctr + (size_t)threadIdx.x * CTR_STRIDE;
@@ -265,6 +268,7 @@ struct FinishMerge {  // totals -> caller; fold and clear the sharded per-batch 
       if (n_applied) *n_applied = total;
       if (stats) { stats->n_applied = total; stats->n_conflicts = tconf; stats->n_rows = r; stats->reserved = 0; }
     }
+    if (threadIdx.x < n_notify && notify.p[threadIdx.x]) __hip_atomic_store(notify.p[threadIdx.x], notify_value, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
   }
 };
 

@@ -362,6 +362,27 @@ int bmx_vc_merge_batch_dev(bmx_vc* t, uint64_t n, const uint64_t* id, const uint
 int bmx_vc_set_stream(bmx_vc* t, void* hip_stream);
 int bmx_vc_sync(bmx_vc* t);
 
+/* ---- direct exchange between PROCESSES, one per GPU (what `bench.py --gpus N` runs; replaces the gossip fan-out of src/bullet-network.js:378-418
+ * inside a node, like the all-to-all it supersedes): every rank owns receive slabs other ranks write into.
+ *   bmx_ipc_alloc  device memory (zeroed) + a 64-byte handle another process opens with bmx_ipc_open (peer_device: the GPU it lives on as THIS
+ *                  process numbers it, or -1 for "the same GPU"); bmx_ipc_close / bmx_ipc_free undo them (the stream is synchronised first).
+ *   bmx_partition_scatter  bmx_partition_by_owner_slabs with one destination per shard: slab g is written to dst[g] — a pointer into shard g's
+ *                  receive memory, this process's or a mapped one — and, once the LAST record is stored, arrive_words[g] (a word in shard g's
+ *                  memory, may be NULL) is set to arrive_value with a system-scope release. No copy kernel, no collective, no second stream.
+ *   bmx_seq_wait_all  one-wave kernel on the stream: returns once every one of nwords consecutive words (this GPU's memory) is >= at_least;
+ *                  expires like bmx_seq_wait.
+ *   bmx_merge_notify  from now on every merge of this context, as its last act, stores the number of merges finished since this call into each of
+ *                  the given words (other ranks' memory: "your slab set k is free again"). nwords = 0 switches it off. */
+int bmx_ipc_alloc(bmx_ctx* ctx, uint64_t bytes, void** dev_ptr, uint8_t handle_out[64]);
+int bmx_ipc_open(bmx_ctx* ctx, const uint8_t handle[64], int peer_device, void** dev_ptr);
+int bmx_ipc_close(bmx_ctx* ctx, void* dev_ptr);
+int bmx_ipc_free(bmx_ctx* ctx, void* dev_ptr);
+int bmx_partition_scatter(bmx_ctx* ctx, uint64_t n, const uint64_t* id, const uint32_t* field, const int64_t* ts, const int64_t* val,
+                          uint32_t nshards, uint64_t slab_records, void* const* dst, uint64_t* counts_out_dev, uint64_t* const* arrive_words,
+                          uint64_t arrive_value);
+int bmx_seq_wait_all(bmx_ctx* ctx, void* hip_stream, const uint64_t* words_dev, uint32_t nwords, uint64_t at_least);
+int bmx_merge_notify(bmx_ctx* ctx, uint64_t* const* words, uint32_t nwords);
+
 /* ---- timing helpers (HIP events on the context's stream; used by bench.py) ------------------- */
 int bmx_timer_start(bmx_ctx* ctx);
 int bmx_timer_stop(bmx_ctx* ctx, float* ms_out);    /* synchronises on the stop event */
