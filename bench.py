@@ -507,9 +507,13 @@ def main():
                     "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None, "algorithmic_bytes_per_launch": alg_bytes,
                     "kernel_ms": {k: round(v, 5) for k, v in stage_ms.items()}, "launches_averaged": ncalls,
                     "note": "rank 0, launches without a concurrent exchange (second pass); HBM traffic counters are collected on the N=1 run"}
-        extra = {"host_enqueue_ms_per_step": round(t_enq / K * 1e3, 4), "exchange": dict(sg.stats(), mode="fixed slabs of %d records per ordered pair, partition+all-to-all of batch b+1 overlapped with merge of batch b" % sg.slab)}
+        how = ("direct: the owner partition of batch b+1 stores every slab straight into its owner's IPC-mapped receive memory (peer stores over xGMI) and sets arrival words; no collective, one stream"
+               if sg.exchange == "direct" else "rccl: partition + ONE all-to-all of batch b+1 on a second stream under the merge of batch b")
+        extra = {"host_enqueue_ms_per_step": round(t_enq / K * 1e3, 4), "exchange": dict(sg.stats(), kind=sg.exchange, mode="fixed slabs of %d records per ordered pair; %s" % (sg.slab, how))}
         shape = ("config 5 shape: streaming replay with 30%% of every batch on %d global hot keys" % (R_global // 1000)) if CONFIG == 5 else "config 4 shape"
         cfg = {"workload": "%s: %dM-row graph id-hash sharded over %d MI355X, %dM mixed-shard deltas per step routed by RCCL all-to-all" %
+               (shape, R_global // 1_000_000, world, world * D_PER_STEP // 1_000_000) if sg.exchange != "direct" else
+               "%s: %dM-row graph id-hash sharded over %d MI355X, %dM mixed-shard deltas per step routed to their owners by direct peer stores (fallback: RCCL all-to-all)" %
                (shape, R_global // 1_000_000, world, world * D_PER_STEP // 1_000_000),
                "resident_rows_per_gpu": R_PER_GPU, "deltas_per_step_per_gpu": D_PER_STEP, "insert_mode": "reference", "sharding": "owner = hash(node id) mod N"}
 
@@ -530,6 +534,7 @@ def main():
         else:
             out["cpu_baseline"] = None
     if sharded:
+        sg.close()
         sg.ops.close()
     eng.close()
     eng = None

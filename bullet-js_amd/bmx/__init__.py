@@ -120,6 +120,13 @@ def load_library():
     L.bmx_owner_of.argtypes = [u64, u32]; L.bmx_owner_of.restype = u32
     L.bmx_partition_by_owner.argtypes = [vp, u64, vp, vp, vp, vp, u32, vp, vp]; L.bmx_partition_by_owner.restype = i32
     L.bmx_partition_by_owner_slabs.argtypes = [vp, u64, vp, vp, vp, vp, u32, u64, vp, vp]; L.bmx_partition_by_owner_slabs.restype = i32
+    L.bmx_partition_scatter.argtypes = [vp, u64, vp, vp, vp, vp, u32, u64, vp, vp, vp, u64]; L.bmx_partition_scatter.restype = i32
+    L.bmx_ipc_alloc.argtypes = [vp, u64, u32, C.POINTER(vp), C.c_char_p]; L.bmx_ipc_alloc.restype = i32
+    L.bmx_ipc_open.argtypes = [vp, C.c_char_p, i32, C.POINTER(vp)]; L.bmx_ipc_open.restype = i32
+    L.bmx_ipc_close.argtypes = [vp, vp]; L.bmx_ipc_close.restype = i32
+    L.bmx_ipc_free.argtypes = [vp, vp]; L.bmx_ipc_free.restype = i32
+    L.bmx_seq_wait_all.argtypes = [vp, vp, vp, u32, u64]; L.bmx_seq_wait_all.restype = i32
+    L.bmx_merge_notify.argtypes = [vp, vp, u32]; L.bmx_merge_notify.restype = i32
     L.bmx_timer_start.argtypes = [vp]; L.bmx_timer_start.restype = i32
     L.bmx_timer_stop.argtypes = [vp, C.POINTER(C.c_float)]; L.bmx_timer_stop.restype = i32
     L.bmx_profile_enable.argtypes = [vp, i32]; L.bmx_profile_enable.restype = i32
@@ -363,6 +370,50 @@ class Engine:
 
     def partition_by_owner_dev(self, n, id, field, ts, val, nshards, recs_out, counts_out):
         self._chk(self.L.bmx_partition_by_owner(self.h, int(n), _ptr(id), _ptr(field), _ptr(ts), _ptr(val), int(nshards), _ptr(recs_out), _ptr(counts_out)))
+
+    # ---- direct exchange between processes (bmx_ipc_* / bmx_partition_scatter): pointers are plain ints here ----
+    def ipc_alloc(self, nbytes, uncached=True):
+        """-> (device pointer, 64-byte handle another process opens with ipc_open). uncached: never served from this GPU's L2 (peers store into it)"""
+        p = C.c_void_p()
+        h = C.create_string_buffer(64)
+        self._chk(self.L.bmx_ipc_alloc(self.h, int(nbytes), 1 if uncached else 0, C.byref(p), h))
+        return int(p.value), h.raw
+
+    def ipc_open(self, handle, peer_device=-1):
+        p = C.c_void_p()
+        self._chk(self.L.bmx_ipc_open(self.h, C.create_string_buffer(bytes(handle), 64), int(peer_device), C.byref(p)))
+        return int(p.value)
+
+    def ipc_close(self, ptr):
+        self._chk(self.L.bmx_ipc_close(self.h, C.c_void_p(int(ptr))))
+
+    def ipc_free(self, ptr):
+        self._chk(self.L.bmx_ipc_free(self.h, C.c_void_p(int(ptr))))
+
+    def partition_scatter_dev(self, n, id, field, ts, val, nshards, slab_records, dst_ptrs, counts_out, arrive_ptrs=None, arrive_value=0):
+        """owner partition writing slab g straight to dst_ptrs[g] (this GPU's or a peer's memory); arrive_ptrs[g] := arrive_value when all is stored"""
+        dst = (C.c_void_p * int(nshards))(*[C.c_void_p(int(x)) for x in dst_ptrs])
+        arr = (C.c_void_p * int(nshards))(*[C.c_void_p(int(x)) if x else None for x in arrive_ptrs]) if arrive_ptrs is not None else None
+        self._chk(self.L.bmx_partition_scatter(self.h, int(n), _ptr(id), _ptr(field), _ptr(ts), _ptr(val), int(nshards), int(slab_records), dst, _ptr(counts_out),
+                                               arr, int(arrive_value)))
+
+    @staticmethod
+    def ptr_array(ptrs):
+        """a C array of device pointers, built once and reused (partition_scatter_raw): keeps the per-step host cost down"""
+        return (C.c_void_p * max(len(ptrs), 1))(*[C.c_void_p(int(x)) if x else None for x in ptrs])
+
+    def partition_scatter_raw(self, n, id, field, ts, val, nshards, slab_records, dst_arr, counts_out, arrive_arr, arrive_value):
+        self._chk(self.L.bmx_partition_scatter(self.h, int(n), _ptr(id), _ptr(field), _ptr(ts), _ptr(val), int(nshards), int(slab_records), dst_arr, _ptr(counts_out),
+                                               arrive_arr, int(arrive_value)))
+
+    def seq_wait_all(self, stream_ptr, words_ptr, nwords, at_least):
+        self._chk(self.L.bmx_seq_wait_all(self.h, C.c_void_p(stream_ptr) if stream_ptr else None, _ptr(words_ptr), int(nwords), int(at_least)))
+
+    def merge_notify(self, word_ptrs):
+        """every later merge stores the count of merges finished since into these words (peers' memory); [] switches it off"""
+        n = len(word_ptrs)
+        arr = (C.c_void_p * max(n, 1))(*[C.c_void_p(int(x)) if x else None for x in word_ptrs]) if n else None
+        self._chk(self.L.bmx_merge_notify(self.h, arr, n))
 
     def partition_by_owner_slabs_dev(self, n, id, field, ts, val, nshards, slab_records, recs_out, counts_out):
         self._chk(self.L.bmx_partition_by_owner_slabs(self.h, int(n), _ptr(id), _ptr(field), _ptr(ts), _ptr(val), int(nshards), int(slab_records),

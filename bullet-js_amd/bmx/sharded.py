@@ -10,6 +10,14 @@ Order: a shard receives the runs of rank 0, 1, ..., N-1 concatenated, each run i
 the global batch order (rank-major, then index) restricted to the shard is preserved and the sequential
 semantics of the merge (smallest index wins ties / creates absent rows) stay well defined.
 
+Two exchanges for the pipelined mode (setup_pipeline(exchange=...), env BMX_SHARDED_EXCHANGE, default "auto"):
+  direct   every rank owns receive slabs that the other ranks have MAPPED (hipIpc*): the owner partition of a batch writes each shard's
+           slab straight into that shard's memory over xGMI (bmx_partition_scatter) and sets an arrival word there when its last record is
+           stored; the owner's merge waits for the arrival words of all its origins (bmx_seq_wait_all), and its last workgroup tells every
+           origin that the slab set is free again (bmx_merge_notify). One stream, no copy kernel beside the probe kernel, no collective.
+  rccl     fixed slabs through ONE all-to-all on a second, high-priority stream (the round 1-2 path; what "auto" falls back to, on every
+           rank together, when a rank cannot set up or verify the mappings).
+
 Two ways to run a step:
   merge_step()        exact split sizes: the counts go through the host (two small syncs per step). Always safe.
   route() + merge()   pipelined: fixed-size slabs padded with reserved-id records (skipped by the merge), equal
@@ -23,6 +31,8 @@ Two ways to run a step:
 tests inject a CPU implementation to exercise the routing with the gloo backend.
 """
 import contextlib
+import os
+import sys
 import numpy as np
 import torch
 
@@ -57,6 +67,8 @@ class EngineOps:
             self.comm = torch.cuda.Stream(device=self.device, priority=-1)
             self.pe = Engine(capacity_rows=1024, device=self.device.index or 0)   # owns only the partition scratch
             self.pe.set_stream(self.comm.cuda_stream)
+
+    direct_capable = True          # bmx_ipc_* / bmx_partition_scatter are available behind this ops object
 
     def empty_records(self, n):
         return torch.empty((max(int(n), 1), 4), dtype=torch.int64, device=self.device)
@@ -146,6 +158,8 @@ class ShardedGraph:
         self.n_steps = 0
         self.sent_remote = 0
         self.received = 0
+        self._direct = None
+        self.exchange = "exact"
 
     def owned_rows(self, R_global, chunk=4_000_000):
         """row ordinals in [0, R_global) whose node this rank owns."""
@@ -199,7 +213,7 @@ class ShardedGraph:
         return nrecv
 
     # ---- pipelined mode ----------------------------------------------------------------------
-    def setup_pipeline(self, max_deltas, slack=1.03, depth=2, partition_on="merge"):
+    def setup_pipeline(self, max_deltas, slack=1.03, depth=2, partition_on="merge", exchange=None):
         """Allocate `depth` (>= 2) send/receive slab sets for batches of up to max_deltas deltas per rank. Protocol: call
         route(b+1) before merge(b) and merge in route order; at most `depth` routed-but-unmerged batches may exist.
         partition_on: "exchange" = the owner partition of batch b+1 runs on the exchange stream in front of its all-to-all, i.e.
@@ -209,6 +223,16 @@ class ShardedGraph:
         W = self.world
         self.slab = int(max_deltas / W * slack) + 64
         self.partition_on = partition_on
+        exchange = exchange or os.environ.get("BMX_SHARDED_EXCHANGE", "auto")
+        assert exchange in ("auto", "direct", "rccl")
+        self.exchange = "rccl"
+        self._direct = None
+        if exchange != "rccl" and getattr(self.ops, "direct_capable", False):
+            if self._setup_direct(depth):
+                self.exchange = "direct"
+                return
+            if exchange == "direct":
+                raise RuntimeError("direct exchange requested but a rank could not set up or verify the IPC mappings")
         self._pipe = []
         for _ in range(depth):
             self._pipe.append(dict(send=self.ops.empty_records(W * self.slab), recv=self.ops.empty_records(W * self.slab),
@@ -239,6 +263,10 @@ class ShardedGraph:
         p = self._pipe[k % depth]
         self._routed += 1
         p["k"] = k
+        if self._direct is not None:
+            self._route_direct(p, n, id, field, ts, val)
+            self.sent_remote += n - n // self.world
+            return p
         with self.ops.comm_ctx():                             # GPU: a no-op after the first call (streams are set once)
             if self.partition_on == "merge":
                 # merge stream, between merge(k-2) and merge(k-1): the all-to-all that last read these send slabs finished before
@@ -275,6 +303,8 @@ class ShardedGraph:
         """Merge a routed batch on the merge stream (waits for its exchange on the device, not on the host), then issue
         the exchanges of the batches routed meanwhile."""
         p = ticket
+        if self._direct is not None:
+            return self._merge_direct(p)
         if not p["exchanged"]:                                 # first batch of a pipeline: nothing to hide it behind
             self._due.remove(p)
             self._exchange(p)
@@ -290,6 +320,132 @@ class ShardedGraph:
         self.received += nrecv
         return p
 
+    # ---- direct exchange (IPC-mapped receive slabs) ------------------------------------------------
+    def _all_agree(self, ok):
+        flags = [None] * self.world
+        self.dist.all_gather_object(flags, bool(ok))
+        return all(flags)
+
+    def _setup_direct(self, depth):
+        """Allocate this rank's receive slabs + arrival / free words, exchange the IPC handles, map the peers', run one empty batch through the
+        whole hand-off (partition -> peer stores -> arrival words -> merge -> free words) and check it. Every step is agreed on by ALL ranks:
+        either everybody switches to the direct exchange or nobody does. Returns True when it is in use."""
+        from . import BmxError
+        e, W, r, dist = self.ops.e, self.world, self.rank, self.dist
+        rec_bytes = 32
+        own = None
+        try:
+            # uncached: peers store into all three while kernels here poll or read them
+            recv, h_recv = e.ipc_alloc(depth * W * self.slab * rec_bytes, uncached=True)
+            arrived, h_arr = e.ipc_alloc(max(W * 8, 256), uncached=True)
+            freed, h_free = e.ipc_alloc(max(W * 8, 256), uncached=True)
+            own = dict(recv=recv, arrived=arrived, freed=freed)
+            mine = (self.ops.device.index or 0, os.getpid(), h_recv, h_arr, h_free)
+        except BmxError as err:
+            print("bmx sharded: direct exchange unavailable on rank %d (%s)" % (r, err), file=sys.stderr)
+            mine = None
+        infos = [None] * W
+        dist.all_gather_object(infos, mine)
+        if any(x is None for x in infos):
+            self._free_direct(own, [])
+            return False
+        peers, opened, ok = [None] * W, [], True
+        try:
+            for g in range(W):
+                if g == r:
+                    peers[g] = own
+                    continue
+                dev_g = infos[g][0]
+                pd = -1 if dev_g == (self.ops.device.index or 0) else dev_g
+                ptrs = dict(recv=e.ipc_open(infos[g][2], pd), arrived=e.ipc_open(infos[g][3], pd), freed=e.ipc_open(infos[g][4], pd))
+                opened.extend(ptrs.values())
+                peers[g] = ptrs
+        except BmxError as err:
+            print("bmx sharded: rank %d cannot map a peer's receive slabs (%s)" % (r, err), file=sys.stderr)
+            ok = False
+        if not self._all_agree(ok):
+            self._free_direct(own, opened)
+            return False
+        self.ops._pipeline()                                                   # the exchange stream and its partition context
+        pe = self.ops.pe
+        sets = []
+        for q in range(depth):                                                 # pointer arrays per slab set, built once
+            off = (q * W + r) * self.slab * rec_bytes
+            sets.append(dict(dst=pe.ptr_array([peers[g]["recv"] + off for g in range(W)]), arrive=pe.ptr_array([peers[g]["arrived"] + 8 * r for g in range(W)])))
+        self._direct = dict(own=own, peers=peers, opened=opened, depth=depth, sets=sets)
+        self._pipe = [dict(counts=self.ops.zeros_i64(W), applied=self.ops.zeros_i32(W * self.slab), n_applied=self.ops.zeros_i64(1), used=False) for _ in range(depth)]
+        self._routed = self._merged = 0
+        self._due = []
+        e.merge_notify([peers[g]["freed"] + 8 * r for g in range(W)])      # my merges tell origin g: word [me] of ITS free words
+        dist.barrier()                                                        # nobody stores into a peer before every peer has mapped everything
+        # pre-flight: batch 0 is empty (padding only); it travels the whole hand-off on every rank
+        try:
+            p = self.route(0, None, None, None, None)
+            self.merge(p)
+            self.ops.sync()
+            ok = int(p["n_applied"].cpu()[0]) == 0
+        except BmxError as err:
+            print("bmx sharded: rank %d: the direct exchange did not complete its pre-flight batch (%s)" % (r, err), file=sys.stderr)
+            ok = False
+        if not self._all_agree(ok):
+            self._teardown_direct()
+            return False
+        self.n_steps = 0; self.received = 0; self.sent_remote = 0        # the pre-flight batch is not a step
+        return True
+
+    def _route_direct(self, p, n, id, field, ts, val):
+        # on the EXCHANGE stream (a high-priority stream of its own, like the all-to-all it replaces): the scatter of batch k + 1 is bound by the
+        # xGMI links (7/8 of the records leave the GPU) and runs underneath the merge of batch k; the two streams meet only through words in memory
+        d, pe, W, k = self._direct, self.ops.pe, self.world, p["k"]
+        depth = d["depth"]
+        if k >= depth:                     # the slab set is free once EVERY owner has merged batch k - depth (their merges count up my free words)
+            pe.seq_wait_all(0, d["own"]["freed"], W, k - depth + 1)
+        st = d["sets"][k % depth]
+        pe.partition_scatter_raw(n, id, field, ts, val, W, self.slab, st["dst"], p["counts"], st["arrive"], k + 1)
+        p["used"] = True
+
+    def _merge_direct(self, p):
+        d, e, W, k = self._direct, self.ops.e, self.world, p["k"]
+        e.seq_wait_all(0, d["own"]["arrived"], W, k + 1)          # every origin's slab of batch k has arrived
+        nrecv = W * self.slab
+        e.merge_records_dev(nrecv, d["own"]["recv"] + (k % d["depth"]) * nrecv * 32, self.insert_mode, applied=p["applied"], n_applied=p["n_applied"])
+        self._merged += 1
+        self.n_steps += 1
+        self.received += nrecv
+        return p
+
+    def _free_direct(self, own, opened):
+        e = self.ops.e
+        for ptr in opened:
+            try:
+                e.ipc_close(ptr)
+            except Exception:
+                pass
+        self.dist.barrier()                 # peers have unmapped before the owner frees
+        if own:
+            for ptr in own.values():
+                try:
+                    e.ipc_free(ptr)
+                except Exception:
+                    pass
+
+    def _teardown_direct(self):
+        d = self._direct
+        if d is None:
+            return
+        try:
+            self.ops.sync()
+        except Exception:
+            pass
+        self.ops.e.merge_notify([])
+        self.dist.barrier()                 # nobody is storing into a peer any more
+        self._direct = None
+        self._free_direct(d["own"], d["opened"])
+
+    def close(self):
+        """Give the direct exchange's mappings back (collective: every rank calls it)."""
+        self._teardown_direct()
+
     def overflowed(self):
         """True if a slab of ANY batch routed so far was too small for what its origin had to send (host sync). The partition kernel
         raises a sticky error on its context when it drops records, so an overflow of an earlier batch whose counts have been
@@ -301,7 +457,7 @@ class ShardedGraph:
             if e.code != ERR_OVERFLOW:
                 raise
             self._overflowed = True
-        return getattr(self, "_overflowed", False) or any(int(p["counts"].max().item()) > self.slab for p in self._pipe if p["used"])
+        return getattr(self, "_overflowed", False) or any(int(p["counts"].max().item()) > self.slab for p in self._pipe if p.get("used"))
 
     def last_applied(self):
         """(indices into the received batch, received records) of the last step's winners."""

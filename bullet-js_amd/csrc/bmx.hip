@@ -33,8 +33,6 @@ struct DevScalars {  // one small device allocation; zeroed at create
   uint32_t wide;
   unsigned long long seq_diag[3];  // k_seq_wait expiry: {sequence word address, value waited for, value last seen}
   unsigned long long chg_n[2];     // entries in the index change log: batch k reads [k&1], its compaction writes [(k+1)&1]
-  uint32_t part_done;              // bmx_partition_scatter: workgroups of the running scatter that have finished (reset by the last one)
-  uint32_t pad_;
 };
 
 struct Index {
@@ -1312,12 +1310,14 @@ int bmx_partition_by_owner_slabs(bmx_ctx* ctx, uint64_t n, const uint64_t* id, c
 }
 
 /* ---- direct exchange between processes (one process per GPU): IPC-mapped receive slabs, arrival words, no collective on the data path ---- */
-int bmx_ipc_alloc(bmx_ctx* ctx, uint64_t bytes, void** dev_ptr, uint8_t handle_out[64]) {
+int bmx_ipc_alloc(bmx_ctx* ctx, uint64_t bytes, uint32_t flags, void** dev_ptr, uint8_t handle_out[64]) {
   if (!ctx || !dev_ptr || !handle_out || bytes == 0) return fail(ctx, BMX_ERR_INVALID, "bmx_ipc_alloc: bad arguments");
   static_assert(sizeof(hipIpcMemHandle_t) <= 64, "IPC handle fits the 64-byte carrier");
   HIPCHK(hipSetDevice(ctx->device));
   void* p = nullptr;
-  hipError_t e = hipMalloc(&p, bytes);
+  // BMX_IPC_UNCACHED: memory other GPUs store into while kernels here poll or read it must not be served from this GPU's L2 (a line cached
+  // before the peer's store would stay stale: the L2 is only coherent for this GPU's own writes)
+  hipError_t e = (flags & BMX_IPC_UNCACHED) ? hipExtMallocWithFlags(&p, bytes, hipDeviceMallocUncached) : hipMalloc(&p, bytes);
   if (e != hipSuccess) return fail(ctx, e == hipErrorOutOfMemory ? BMX_ERR_NOMEM : BMX_ERR_HIP, std::string("hipMalloc: ") + hipGetErrorString(e));
   e = hipMemset(p, 0, bytes);
   hipIpcMemHandle_t h;
@@ -1370,10 +1370,16 @@ int bmx_partition_scatter(bmx_ctx* ctx, uint64_t n, const uint64_t* id, const ui
   for (uint32_t g = 0; g < nshards; g++) {
     if (!dst[g]) return fail(ctx, BMX_ERR_INVALID, "bmx_partition_scatter: null destination slab");
     po.base[g] = static_cast<bmx_delta_rec*>(dst[g]);
-    if (arrive_words) po.arrive[g] = reinterpret_cast<unsigned long long*>(arrive_words[g]);
   }
-  if (arrive_words) { po.arrive_value = arrive_value; po.done = &ctx->ds->part_done; }
-  return partition_impl(ctx, n, id, field, ts, val, nshards, slab_records, nullptr, counts_out_dev, &po, 0);
+  int rc = partition_impl(ctx, n, id, field, ts, val, nshards, slab_records, nullptr, counts_out_dev, &po, 0);
+  if (rc || !arrive_words) return rc;
+  // the arrival words, from a launch of their own behind the scatter: its kernel boundary is the release (every record is stored and written
+  // back, peer memory included) — fences inside the scatter's 1024 workgroups write the whole L2 back a thousand times (measured: +100 us)
+  SeqPtrs w; std::memset(&w, 0, sizeof(w));
+  for (uint32_t g = 0; g < nshards; g++) w.p[g] = reinterpret_cast<unsigned long long*>(arrive_words[g]);
+  hipLaunchKernelGGL(k_seq_signal_multi, dim3(1), dim3(64), 0, ctx->stream, w, nshards, (unsigned long long)arrive_value);
+  LAUNCHCHK("k_seq_signal_multi");
+  return BMX_OK;
 }
 
 int bmx_seq_wait_all(bmx_ctx* ctx, void* hip_stream, const uint64_t* words_dev, uint32_t nwords, uint64_t at_least) {

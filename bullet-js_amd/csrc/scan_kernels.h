@@ -268,7 +268,8 @@ struct FinishMerge {  // totals -> caller; fold and clear the sharded per-batch 
       if (n_applied) *n_applied = total;
       if (stats) { stats->n_applied = total; stats->n_conflicts = tconf; stats->n_rows = r; stats->reserved = 0; }
     }
-    if (threadIdx.x < n_notify && notify.p[threadIdx.x]) __hip_atomic_store(notify.p[threadIdx.x], notify_value, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    // (relaxed: nothing is published with it — it only says that the launches BEFORE this one are done with their input)
+    if (threadIdx.x < n_notify && notify.p[threadIdx.x]) __hip_atomic_store(notify.p[threadIdx.x], notify_value, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
   }
 };
 

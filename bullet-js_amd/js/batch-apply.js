@@ -33,9 +33,14 @@ function applyBatch(bullet, updates, fromNetwork, wantBroadcast = true) {
   for (let i = 0; i < n; i++) {
     const u = updates[i];
     const path = u.path;
-    const cut = path.lastIndexOf("/");
-    const parentPath = cut < 0 ? "" : path.slice(0, cut);
-    const key = cut < 0 ? path : path.slice(cut + 1);
+    let cut = path.lastIndexOf("/");
+    let parentPath = cut < 0 ? "" : path.slice(0, cut);
+    let key = cut < 0 ? path : path.slice(cut + 1);
+    if (!key || path.indexOf("//") >= 0) {       // trailing or doubled slashes: the key is the last NON-EMPTY segment (src/bullet.js:186 path.split('/').filter(Boolean))
+      const segs = path.split("/").filter(Boolean);
+      key = segs.length ? segs.pop() : "";
+      parentPath = segs.join("/");
+    }
     let node;
     if (parentPath === lastParentPath) node = lastParentNode;
     else {
@@ -43,7 +48,7 @@ function applyBatch(bullet, updates, fromNetwork, wantBroadcast = true) {
       if (parentPath) for (const seg of parentPath.split("/")) { if (!seg) continue; if (!node[seg]) node[seg] = {}; node = node[seg]; }
       lastParentPath = parentPath; lastParentNode = node;
     }
-    if (!key) continue;
+    if (!key) { if (broadcast) broadcast[i] = null; continue; }     // no segment at all: nothing to write (the reference's loop falls through the same way)
     node[key] = u.value;
     const old = bullet.meta[path];
     // {...old, source, vectorClock, lastModified} (src/bullet.js:196-201): the entry keeps whatever else somebody hung on it and gets these
@@ -91,7 +96,7 @@ function applyBatch(bullet, updates, fromNetwork, wantBroadcast = true) {
     clearTimeout(bullet._saveTimeout);
     bullet._saveTimeout = setTimeout(() => { bullet.storage.save(); }, 1000);
   }
-  return broadcast || [];
+  return broadcast ? broadcast.filter((x) => x !== null) : [];
 }
 
 module.exports = { applyBatch, LOG_CAP };

@@ -112,6 +112,7 @@ function batchApplyCase(makeBullet, label, n) {
   let s = 777; const rnd = () => { s ^= s << 13; s >>>= 0; s ^= s >>> 17; s ^= s << 5; s >>>= 0; return s; };
   const updates = [];
   for (let i = 0; i < n; i++) updates.push({ path: "n/k" + (rnd() % 300) + "/" + ["age", "score", "hits"][rnd() % 3], value: (rnd() % 2001) - 1000, vectorClock: { w: 2 + (rnd() % 500) } });
+  for (let i = 50; i < n; i += 97) updates[i].path = i % 2 ? updates[i].path + "/" : updates[i].path.replace("n/", "n//");   // trailing / doubled slashes: the key is the last non-empty segment (src/bullet.js:186)
   const a = makeBullet(), b = makeBullet();
   const seenA = { leaf: [], node: [], root: [] }, seenB = { leaf: [], node: [], root: [] };
   for (const [bb, seen] of [[a, seenA], [b, seenB]]) {

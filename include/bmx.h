@@ -364,16 +364,18 @@ int bmx_vc_sync(bmx_vc* t);
 
 /* ---- direct exchange between PROCESSES, one per GPU (what `bench.py --gpus N` runs; replaces the gossip fan-out of src/bullet-network.js:378-418
  * inside a node, like the all-to-all it supersedes): every rank owns receive slabs other ranks write into.
- *   bmx_ipc_alloc  device memory (zeroed) + a 64-byte handle another process opens with bmx_ipc_open (peer_device: the GPU it lives on as THIS
+ *   bmx_ipc_alloc  device memory (zeroed; flags: BMX_IPC_UNCACHED) + a 64-byte handle another process opens with bmx_ipc_open (peer_device: the GPU it lives on as THIS
  *                  process numbers it, or -1 for "the same GPU"); bmx_ipc_close / bmx_ipc_free undo them (the stream is synchronised first).
  *   bmx_partition_scatter  bmx_partition_by_owner_slabs with one destination per shard: slab g is written to dst[g] — a pointer into shard g's
- *                  receive memory, this process's or a mapped one — and, once the LAST record is stored, arrive_words[g] (a word in shard g's
- *                  memory, may be NULL) is set to arrive_value with a system-scope release. No copy kernel, no collective, no second stream.
+ *                  receive memory, this process's or a mapped one — and, from a one-wave launch behind the scatter (its kernel boundary is the
+ *                  release), arrive_words[g] (a word in shard g's memory, may be NULL) is set to arrive_value. No copy kernel, no collective,
+ *                  no second stream.
  *   bmx_seq_wait_all  one-wave kernel on the stream: returns once every one of nwords consecutive words (this GPU's memory) is >= at_least;
  *                  expires like bmx_seq_wait.
  *   bmx_merge_notify  from now on every merge of this context, as its last act, stores the number of merges finished since this call into each of
  *                  the given words (other ranks' memory: "your slab set k is free again"). nwords = 0 switches it off. */
-int bmx_ipc_alloc(bmx_ctx* ctx, uint64_t bytes, void** dev_ptr, uint8_t handle_out[64]);
+#define BMX_IPC_UNCACHED 1u   /* never cached in this GPU's L2: for memory that peers store into (receive slabs, arrival / free words) */
+int bmx_ipc_alloc(bmx_ctx* ctx, uint64_t bytes, uint32_t flags, void** dev_ptr, uint8_t handle_out[64]);
 int bmx_ipc_open(bmx_ctx* ctx, const uint8_t handle[64], int peer_device, void** dev_ptr);
 int bmx_ipc_close(bmx_ctx* ctx, void* dev_ptr);
 int bmx_ipc_free(bmx_ctx* ctx, void* dev_ptr);

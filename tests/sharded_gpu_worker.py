@@ -32,7 +32,9 @@ def main():
         d = synth.big_deltas(D, R, seed=5 + 100 * rank, T0=1000, DT=1000, insert_pct=15, hot_pct=30, hot_keys=40, unique=False, batch=b)
         batches.append([torch.from_numpy(np.ascontiguousarray(x).view(np.int64 if x.dtype.itemsize == 8 else np.int32)).to(dev) for x in d])
     if mode.startswith("pipelined"):
-        sg.setup_pipeline(D, slack=1.2, partition_on=mode.split("_")[1])
+        parts = mode.split("_")            # pipelined_<where the partition runs>[_rccl]: the direct (IPC) exchange unless "rccl" is asked for
+        sg.setup_pipeline(D, slack=1.2, partition_on=parts[1], exchange="rccl" if parts[-1] == "rccl" else "direct")
+        assert sg.exchange == ("rccl" if parts[-1] == "rccl" else "direct")
         tk = sg.route(D, *batches[0])
         for b in range(NB):
             nxt = sg.route(D, *batches[b + 1]) if b + 1 < NB else None     # route(b+1) before merge(b), as bench.py does
@@ -51,6 +53,7 @@ def main():
     np.savez(os.path.join(out_dir, "rank%d.npz" % rank), id=id, f=f, ts=ts, val=val, nloaded=nloaded, winners=np.array(counts),
              sent=sg.sent_remote, recv=sg.received)
     dist.barrier()
+    sg.close()
     ops.close()
     eng.close()
     dist.destroy_process_group()

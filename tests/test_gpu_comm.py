@@ -162,3 +162,27 @@ def test_put_rows_and_tombstones_over_shards(nshards):
             assert np.array_equal(np.sort(c.scan_range(f, lo, hi)), np.sort(o.scan_range(f, lo, hi))), (lo, hi)
         assert rows_digest(*c.dump_rows()) == o.digest()
     o.close()
+
+
+@pytest.mark.skipif(torch.cuda.device_count() < 2, reason="needs two physical GPUs (the builder's box has one): peer access, cross-device events and peer stores run here first")
+@pytest.mark.parametrize("ndev", [2, 4, 8])
+def test_physical_devices_equal_one_merge(ndev):
+    """The same checks as the logical-shard tests with every shard on its OWN GPU: host batches (device-to-device run copies, the shared winner
+    byte map on shard 0 written by peers), device batches (owner partition storing straight into peer memory), sharded scans, puts."""
+    if torch.cuda.device_count() < ndev:
+        pytest.skip("needs %d GPUs" % ndev)
+    res = synth.big_resident(R, seed=3, F=2)
+    o = Oracle(); o.load_rows(*res)
+    with bmx.Comm(list(range(ndev)), capacity_rows_per_shard=2 * (R + 4 * D) // ndev + 4096) as c:
+        c.load_rows(*res)
+        assert c.row_count() == len(o)
+        for b in range(3):
+            d = synth.big_deltas(D, R, seed=40 + b, insert_pct=10, hot_pct=20, hot_keys=50, unique=False, batch=b)
+            applied, st = c.merge(*d)
+            _, want = o.merge_batch(*d)
+            assert np.array_equal(applied, want), b
+        assert rows_digest(*c.dump_rows()) == o.digest()
+        f = int(res[1][0])
+        lo, hi = -(1 << 28), 1 << 28
+        assert np.array_equal(np.sort(c.scan_range(f, lo, hi)), np.sort(o.scan_range(f, lo, hi)))
+    o.close()

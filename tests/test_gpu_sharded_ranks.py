@@ -1,7 +1,8 @@
-"""GPU, two ranks: the N>1 product path (bmx/sharded.py with EngineOps: device partition into slabs, events between the
-merge and exchange streams, merge of received records with padding) run by two processes that share cuda:0, launched with
-torch.distributed.run exactly as the driver launches bench.py. The union of the two shards must equal ONE oracle fed
-the same batches in global order, bit for bit. (RCCL itself cannot run two ranks on one device; transport here is gloo.)"""
+"""GPU, two and four ranks: the N>1 product path (bmx/sharded.py with EngineOps) run by processes that share cuda:0, launched with
+torch.distributed.run exactly as the driver launches bench.py. The union of the shards must equal ONE oracle fed the same batches in global
+order, bit for bit. Both exchanges: the direct one (every rank's receive slabs are IPC-mapped by the others; the owner partition stores straight
+into them and sets arrival words; merges wait for those and free the slabs through words in the origins' memory — the same code that crosses xGMI
+between GPUs crosses process boundaries here) and the slab all-to-all (RCCL cannot run two ranks on one device: its transport here is gloo)."""
 import os
 import socket
 import subprocess
@@ -20,7 +21,8 @@ def _free_port():
     return p
 
 
-@pytest.mark.parametrize("mode,world", [("exact", 2), ("pipelined_exchange", 2), ("pipelined_merge", 2), ("pipelined_merge", 4)])
+@pytest.mark.parametrize("mode,world", [("exact", 2), ("pipelined_exchange_rccl", 2), ("pipelined_merge_rccl", 2), ("pipelined_merge_rccl", 4),
+                                        ("pipelined_merge", 2), ("pipelined_merge", 4)])   # without _rccl: the direct exchange (IPC-mapped receive slabs, peer stores, arrival words)
 def test_ranks_sharing_one_gpu_equal_single_merge(tmp_path, mode, world):
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world), "--master-addr", "127.0.0.1",
            "--master-port", str(_free_port()), os.path.join(HERE, "sharded_gpu_worker.py"), str(tmp_path), mode]
@@ -43,3 +45,21 @@ def test_ranks_sharing_one_gpu_equal_single_merge(tmp_path, mode, world):
     ts = np.concatenate([p["ts"] for p in parts]); val = np.concatenate([p["val"] for p in parts])
     assert len(ids) == len(o)
     assert rows_digest(ids, f, ts, val) == o.digest()
+
+
+@pytest.mark.skipif(__import__("torch").cuda.device_count() < 2, reason="needs two physical GPUs: the direct exchange across xGMI (peer access + IPC mappings between devices) runs here first")
+@pytest.mark.parametrize("world", [2, 4, 8])
+def test_one_rank_per_physical_gpu_bench_verifies_itself(world):
+    """bench.py exactly as the driver launches it (one process per GPU, RCCL process group, direct exchange with RCCL as the agreed fallback): a short
+    run whose every shard is compared with the oracle replay inside bench.py itself (`verified`)."""
+    import json
+    import torch
+    if torch.cuda.device_count() < world:
+        pytest.skip("needs %d GPUs" % world)
+    root = os.path.dirname(HERE)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world), "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.join(root, "bench.py"), "--gpus", str(world), "--steps", "6", "--warmup", "2"]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    line = json.loads(r.stdout.strip().splitlines()[-1])
+    assert line["n_gpus"] == world and line["verified"]["ok"]
