@@ -324,9 +324,8 @@ def main():
     # ~44M slots (load factor 0.23-0.35); higher load factors lengthen the probe chains faster than the smaller table helps.
     n_profiled = min(K, 12) + min(K, 8)
     cap = int(os.environ.get("BMX_BENCH_CAP", max(22_000_000, R_PER_GPU + (nb + n_profiled + 3) * ins_per_step + 4 * D_PER_STEP)))
-    eng = bmx.Engine(capacity_rows=cap, device=local_rank, flags=(bmx.CTX_BUCKETED_MERGE if os.environ.get("BMX_BENCH_BUCKETED", "0") == "1" else 0),
-                     load_pct=int(os.environ.get("BMX_BENCH_LOAD_PCT", 0)))
-    main_kernel = "k_merge_bins" if os.environ.get("BMX_BENCH_BUCKETED", "0") == "1" else "k_probe_apply"
+    eng = bmx.Engine(capacity_rows=cap, device=local_rank, load_pct=int(os.environ.get("BMX_BENCH_LOAD_PCT", 0)))
+    main_kernel = "k_probe_apply"
     verified = None
 
     if not sharded:

@@ -21,9 +21,7 @@ VAL_DELETED = -(1 << 63)   # BMX_VAL_DELETED: tombstone value of bmx_put_rows
 MERGE_MARK_CREATED, APPLIED_CREATED, APPLIED_INDEX = 0x1000, 0x80000000, 0x00FFFFFF
 MERGE_UNIQUE_KEYS = 0x100
 MERGE_STRICT_FLAGS = 0x200
-MERGE_BUCKETED = 0x800
 CTX_FIXED_CAPACITY = 2
-CTX_BUCKETED_MERGE = 8
 FLAG_INCOMING, FLAG_CURRENT, FLAG_HISTORICAL = 1, 2, 4
 MAX_BATCH = 1 << 24
 
@@ -60,7 +58,7 @@ class Info(C.Structure):
 
 DELTA_REC_DTYPE = np.dtype([("id", "<u8"), ("field", "<u4"), ("aux", "<u4"), ("ts", "<i8"), ("val", "<i8")])
 
-# OR-ed into the flags of every Engine this process creates (tests use it to run the same cases on the bucketed merge path)
+# OR-ed into the flags of every Engine this process creates
 DEFAULT_CTX_FLAGS = int(os.environ.get("BMX_CTX_FLAGS", "0"), 0)
 
 _lib = None
@@ -436,7 +434,7 @@ class Engine:
         ms = (C.c_float * 3)()
         n = C.c_uint32()
         self._chk(self.L.bmx_profile_read(self.h, ms, C.byref(n)))
-        return {"probe_apply": ms[0], "resolve_lists": ms[1], "compact": ms[2]}, n.value   # bucketed path: merge_bins, bucket, count+compact
+        return {"probe_apply": ms[0], "resolve_lists": ms[1], "compact": ms[2]}, n.value
 
     def profile_read_scan(self):
         """-> (dict stage -> average ms per scan call, number of calls)"""

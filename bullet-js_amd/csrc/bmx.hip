@@ -15,7 +15,6 @@
 
 #include "../../include/bmx.h"
 #include "merge_kernels.h"
-#include "bin_kernels.h"
 #include "scan_kernels.h"
 #include "select.h"
 #include "slot.h"
@@ -68,10 +67,6 @@ struct bmx_ctx {
   uint32_t blk_half = 0, blk_par = 0; bool blk_clean[2] = {false, false};   // blk_clean[h]: half h is known to be all zero
   uint32_t* blk_follow = nullptr;     // ws_cap/256 epoch tags: a delta of the block got a follower on its row
   unsigned long long* shard_ctr = nullptr;  // CTR_SHARDS * CTR_STRIDE
-  // default merge path (bin_kernels.h): the batch regrouped by bin, tile by tile
-  uint32_t bin_tiles_cap = 0;
-  uint4* bin_stage = nullptr;         // bin_tiles_cap * BK_TILE records of 32 B
-  uint16_t* bin_toff = nullptr;       // bin_tiles_cap * TOFF_STRIDE offsets
   // staging for BMX_MEM_HOST calls
   // Two staging sets: batch b+1 is uploaded (copy stream) while batch b is merged (main stream); bmx_merge_submit / bmx_merge_collect
   struct Staging {
@@ -126,8 +121,6 @@ struct bmx_ctx {
   std::vector<hipEvent_t> prof_ev;    // 4 events per profiled call
   std::vector<hipEvent_t> scan_ev;    // 3 events per profiled scan call (before the mask pass, after it, after the emit pass)
   uint32_t scan_prof_n = 0;
-  uint8_t prof_path[64] = {0};        // 1 = the call took the bucketed path: stages are bucket / merge_bins / count+compact
-  bool bucketed_default = false;      // BMX_CTX_BUCKETED_MERGE: merges take the bucketed path unless they ask for strict flags / unique keys
   std::string err;
 };
 
@@ -237,19 +230,6 @@ int ensure_workspace(bmx_ctx* ctx, uint64_t n) {
   return BMX_OK;
 }
 
-int ensure_bins(bmx_ctx* ctx, uint64_t n) {
-  const uint32_t tiles = (uint32_t)((n + BK_TILE - 1) / BK_TILE);
-  if (tiles <= ctx->bin_tiles_cap) return BMX_OK;
-  HIPCHK(hipStreamSynchronize(ctx->stream));
-  const uint32_t cap = std::max<uint32_t>(tiles, std::min<uint32_t>(ctx->bin_tiles_cap * 2, MAX_BATCH / BK_TILE));
-  dev_free(ctx->bin_stage); dev_free(ctx->bin_toff);
-  ctx->bin_tiles_cap = 0;
-  int rc;
-  if ((rc = dev_alloc(ctx, &ctx->bin_stage, (uint64_t)cap * BK_TILE * 2)) || (rc = dev_alloc(ctx, &ctx->bin_toff, (uint64_t)cap * TOFF_STRIDE))) return rc;
-  ctx->bin_tiles_cap = cap;
-  return BMX_OK;
-}
-
 // The copy streams exist only once a host batch is submitted: HIP maps streams onto a few hardware queues, and a device-mode caller
 // that overlaps its own streams (the sharded pipeline: exchange beside merge) must not find them sharing a queue with idle ones of ours
 // (measured: with two extra streams per context the exchange kernel serialised behind the merge kernels, 164 vs 125 us per step).
@@ -334,8 +314,7 @@ int merge_core(bmx_ctx* ctx, uint64_t n, const uint64_t* id, const uint32_t* fie
   const bool force = (insert_mode & MERGE_FORCE_INTERNAL) != 0;      // bmx_put_rows: unique keys, stored as given
   const bool unique = (insert_mode & BMX_MERGE_UNIQUE_KEYS) != 0 || force;
   const bool strict = (insert_mode & BMX_MERGE_STRICT_FLAGS) != 0;
-  const bool legacy = strict || unique || mark_created || !((insert_mode & BMX_MERGE_BUCKETED) != 0 || ctx->bucketed_default);   // "legacy" = the one-lane-per-delta kernels
-  insert_mode &= ~(BMX_MERGE_UNIQUE_KEYS | BMX_MERGE_STRICT_FLAGS | BMX_MERGE_BUCKETED | BMX_MERGE_MARK_CREATED | MERGE_FORCE_INTERNAL);
+  insert_mode &= ~(BMX_MERGE_UNIQUE_KEYS | BMX_MERGE_STRICT_FLAGS | BMX_MERGE_MARK_CREATED | MERGE_FORCE_INTERNAL);
   if (force) insert_mode = BMX_INSERT_DELTA;
   if (unique && strict) return fail(ctx, BMX_ERR_INVALID, "BMX_MERGE_STRICT_FLAGS cannot be combined with BMX_MERGE_UNIQUE_KEYS");
   if (insert_mode != BMX_INSERT_REFERENCE && insert_mode != BMX_INSERT_DELTA) return fail(ctx, BMX_ERR_INVALID, "bad insert_mode");
@@ -358,7 +337,6 @@ int merge_core(bmx_ctx* ctx, uint64_t n, const uint64_t* id, const uint32_t* fie
   }
   rc = ensure_workspace(ctx, n);
   if (rc) return rc;
-  if (!legacy && (rc = ensure_bins(ctx, n))) return rc;
   if (++ctx->epoch > EPOCH_MAX) {  // tags wrap: forget every claim
     hipLaunchKernelGGL(k_sweep_heads, dim3(2048), dim3(256), 0, ctx->stream, ctx->slots, ctx->nslots);
     LAUNCHCHK("k_sweep_heads");
@@ -375,7 +353,7 @@ int merge_core(bmx_ctx* ctx, uint64_t n, const uint64_t* id, const uint32_t* fie
   A.next = ctx->next; A.wflag = wflag; A.flags = flags;
   A.slot_of = ctx->slot_of; A.blk_follow = ctx->blk_follow; A.shard_ctr = ctr; A.status = &ctx->ds->status;
   A.blk_info = ctx->blk_info + (size_t)ctx->blk_par * ctx->blk_half; A.blk_next = ctx->blk_info + (size_t)(ctx->blk_par ^ 1u) * ctx->blk_half; A.blk_ents = ctx->blk_half;
-  const bool wave_k1 = legacy && !strict;       // k_probe_apply: adds into its half, zeroes the other one
+  const bool wave_k1 = !strict;       // k_probe_apply: adds into its half, zeroes the other one
   if (wave_k1 && !ctx->blk_clean[ctx->blk_par]) HIPCHK(hipMemsetAsync(A.blk_info, 0, (size_t)ctx->blk_half * sizeof(uint32_t), ctx->stream));   // a batch on another path used this half last
   ctx->blk_clean[ctx->blk_par] = false; if (wave_k1) ctx->blk_clean[ctx->blk_par ^ 1u] = true;
   ctx->blk_par ^= 1u;
@@ -384,26 +362,6 @@ int merge_core(bmx_ctx* ctx, uint64_t n, const uint64_t* id, const uint32_t* fie
   const uint32_t rblocks = blocks;   // one lane per delta
   hipEvent_t* pe = (ctx->prof_on && ctx->prof_n < PROF_MAX_CALLS) ? &ctx->prof_ev[4 * ctx->prof_n] : nullptr;
   if (pe) HIPCHK(hipEventRecord(pe[0], ctx->stream));
-  if (!legacy) {
-    // bucketed path: bucket the batch, merge every bucket inside one workgroup, count the winners per 256-delta block
-    BinArgs B;
-    B.slots = ctx->slots; B.nslots = ctx->nslots;
-    B.id = id; B.field = field; B.ts = ts; B.val = val; B.recs = recs;
-    B.n = (uint32_t)n; B.epoch = ctx->epoch; B.ntiles = (uint32_t)((n + BK_TILE - 1) / BK_TILE);
-    B.stage = ctx->bin_stage; B.toff = ctx->bin_toff; B.wflag = wflag; B.flags = flags;
-    B.shard_ctr = ctr; B.status = &ctx->ds->status;
-    hipLaunchKernelGGL((k_bucket<AOS>), dim3(B.ntiles), dim3(BK_THREADS), 0, ctx->stream, B);
-    LAUNCHCHK("k_bucket");
-    if (pe) HIPCHK(hipEventRecord(pe[1], ctx->stream));
-    if (insert_mode == BMX_INSERT_REFERENCE) hipLaunchKernelGGL((k_merge_bins<BMX_INSERT_REFERENCE>), dim3(NB), dim3(MB_THREADS), 0, ctx->stream, B);
-    else hipLaunchKernelGGL((k_merge_bins<BMX_INSERT_DELTA>), dim3(NB), dim3(MB_THREADS), 0, ctx->stream, B);
-    LAUNCHCHK("k_merge_bins");
-    if (pe) HIPCHK(hipEventRecord(pe[2], ctx->stream));
-    hipLaunchKernelGGL(k_count_winners, dim3((uint32_t)((n + 4095) / 4096)), dim3(256), 0, ctx->stream, (const uint8_t*)wflag, (uint32_t)n, A.blk_info);
-    LAUNCHCHK("k_count_winners");
-    if (pe) ctx->prof_path[ctx->prof_n] = 1;
-  } else {
-  if (pe) ctx->prof_path[ctx->prof_n] = 0;
   if (strict) {
     hipLaunchKernelGGL((k_probe_link_strict<AOS>), dim3(blocks), dim3(256), 0, ctx->stream, A);
   } else {
@@ -433,7 +391,6 @@ int merge_core(bmx_ctx* ctx, uint64_t n, const uint64_t* id, const uint32_t* fie
   }
   LAUNCHCHK("k_resolve_lists");
   if (pe) HIPCHK(hipEventRecord(pe[2], ctx->stream));
-  }
   // K3: ordered compaction of the winner bytes (+ the index change log while an index is being maintained)
   hipStream_t ks = ctx->stream;
   FinishMerge Fin{reinterpret_cast<unsigned long long*>(n_applied), stats, ctr, &ctx->ds->row_count};
@@ -442,7 +399,7 @@ int merge_core(bmx_ctx* ctx, uint64_t n, const uint64_t* id, const uint32_t* fie
   if (ctx->n_notify) { ++ctx->notify_seq; if (!notify_after) { Fin.notify = ctx->notify; Fin.n_notify = ctx->n_notify; Fin.notify_value = ctx->notify_seq; } }
   ChgLog L{};
   if (ctx->chg_valid) {
-    if (legacy && !strict && (!unique || force) && ctx->chg_ub + n <= ctx->chg_cap && ctx->nslots < (1ull << 31)) {
+    if (!strict && (!unique || force) && ctx->chg_ub + n <= ctx->chg_cap && ctx->nslots < (1ull << 31)) {
       L.chg = ctx->chg; L.base = &ctx->ds->chg_n[ctx->chg_par]; L.next = &ctx->ds->chg_n[ctx->chg_par ^ 1u];
       L.slot_of = ctx->slot_of; L.field = field; L.recs = recs; L.cap = ctx->chg_cap;
       ctx->chg_par ^= 1u; ctx->chg_ub += n;
@@ -956,7 +913,6 @@ void bmx_destroy(bmx_ctx* ctx) {
   dev_free(ctx->pr_id); dev_free(ctx->pr_field); dev_free(ctx->pr_ts); dev_free(ctx->pr_val); dev_free(ctx->pr_found);
   if (ctx->copy_stream) (void)hipStreamDestroy(ctx->copy_stream);
   if (ctx->down_stream) { (void)hipStreamSynchronize(ctx->down_stream); (void)hipStreamDestroy(ctx->down_stream); }
-  dev_free(ctx->bin_stage); dev_free(ctx->bin_toff);
   dev_free(ctx->slot_pos); dev_free(ctx->chg);
   if (ctx->host_rows) { (void)hipHostFree(ctx->host_rows); ctx->host_rows = nullptr; }
   if (ctx->pin_in) { (void)hipHostFree(ctx->pin_in); ctx->pin_in = nullptr; }
@@ -1440,9 +1396,7 @@ int bmx_profile_read(bmx_ctx* ctx, float ms_out[3], uint32_t* n_calls) {
     for (int k = 0; k < 3; k++) {
       float ms = 0;
       HIPCHK(hipEventElapsedTime(&ms, ctx->prof_ev[4 * i + k], ctx->prof_ev[4 * i + k + 1]));
-      // bucketed path: events bracket k_bucket | k_merge_bins | count + compaction; reported as [0] main kernel, [1] pre-pass, [2] compaction
-      const int slot = ctx->prof_path[i] ? (k == 0 ? 1 : (k == 1 ? 0 : 2)) : k;
-      acc[slot] += ms;
+      acc[k] += ms;
     }
   for (int k = 0; k < 3; k++) ms_out[k] = ctx->prof_n ? (float)(acc[k] / ctx->prof_n) : 0.f;
   *n_calls = ctx->prof_n;

@@ -339,6 +339,23 @@ __global__ __launch_bounds__(SEL_THREADS) void k_compact_winners(const uint8_t* 
   }
 }
 
+// winners per 256-delta block (what k_compact_winners ranks from) out of a byte map: one 16-byte load per lane, 4096 deltas per workgroup.
+// (The merge kernels leave these counts themselves; this is for byte maps filled otherwise: the winners of a host batch over several shards.)
+__global__ __launch_bounds__(256) void k_count_winners(const uint8_t* __restrict__ wflag, uint32_t n, uint32_t* __restrict__ blk_info) {
+  const uint64_t first = (uint64_t)blockIdx.x * 4096u + (uint64_t)threadIdx.x * 16u;
+  uint32_t c = 0;
+  if (first + 16 <= n) {
+    const uint4 x = *reinterpret_cast<const uint4*>(wflag + first);
+    c = __popc(x.x & 0x01010101u) + __popc(x.y & 0x01010101u) + __popc(x.z & 0x01010101u) + __popc(x.w & 0x01010101u);
+  } else {
+    for (uint32_t e = 0; e < 16 && first + e < n; e++) c += wflag[first + e] & 1u;
+  }
+  // sum over the 16 lanes that share a 256-delta block
+  c += __shfl_xor(c, 1); c += __shfl_xor(c, 2); c += __shfl_xor(c, 4); c += __shfl_xor(c, 8);
+  const uint32_t kb = blockIdx.x * 16u + (threadIdx.x >> 4);
+  if ((threadIdx.x & 15u) == 0 && (uint64_t)kb * 256u < n) blk_info[kb] = c;
+}
+
 __global__ void k_sum_counts(const uint32_t* block_counts, uint32_t nblocks, unsigned long long* n_out) {
   __shared__ uint32_t wsum[4];
   uint32_t part = strided_partial_sum(block_counts, nblocks);

@@ -65,15 +65,9 @@ extern "C" {
  * no delta is applied optimistically. Cannot be combined with BMX_MERGE_UNIQUE_KEYS. */
 #define BMX_MERGE_STRICT_FLAGS 0x200
 
-/* Optional bit OR-ed into `insert_mode`: take the bucketed path (csrc/bin_kernels.h) instead of the default one-lane-per-delta
- * kernels: the batch is regrouped by key range, one workgroup owns each range, duplicate keys meet in LDS, and the table sees one
- * line read and at most one write-back per KEY and no claim atomic. Same results for every batch. Measured slower than the default
- * on unique-key batches (regrouping moves the batch twice: DESIGN.md §5) and robust where the default degrades: thousands of deltas
- * on one key cost LDS hops instead of dependent global loads. Ignored with BMX_MERGE_STRICT_FLAGS / BMX_MERGE_UNIQUE_KEYS. */
-#define BMX_MERGE_BUCKETED 0x800
 /* applied_idx[k] carries bit 31 (BMX_APPLIED_CREATED) when winner k is the delta that CREATED its row: the row then stores the insert rule's
  * clock ({id: 2} with BMX_INSERT_REFERENCE, src/bullet-crt.js:172-185), not the delta's own ts — what the host writes into meta[path].vectorClock
- * (src/bullet.js:196-201) without reading the row back. Mask with BMX_APPLIED_INDEX to get the index. Not with the bucketed path. */
+ * (src/bullet.js:196-201) without reading the row back. Mask with BMX_APPLIED_INDEX to get the index. */
 #define BMX_MERGE_MARK_CREATED 0x1000
 #define BMX_APPLIED_CREATED 0x80000000u
 #define BMX_APPLIED_INDEX   0x00FFFFFFu
@@ -120,7 +114,6 @@ typedef struct bmx_info {
 /* bmx_create flags */
 #define BMX_CTX_FIXED_CAPACITY 2u /* never grow: a batch that would exceed capacity_rows fails with BMX_ERR_FULL.
                                      Default: the table is rehashed into one twice as large (synchronous, on device). */
-#define BMX_CTX_BUCKETED_MERGE 8u /* every merge of this context takes the bucketed path (see BMX_MERGE_BUCKETED) */
 
 /* ---- lifetime -------------------------------------------------------------------------------
  * Replaces `new BulletCRT(bullet)` src/bullet-crt.js:6-16 / `new BulletQuery(bullet)`
@@ -228,7 +221,7 @@ int bmx_reserve(bmx_ctx* ctx, uint64_t capacity_rows);
  * Maintenance (the device-side _updateIndices, src/bullet-query.js:82-110): while an index exists, every merge on the default path
  * logs its winners' rows; the next scan applies that log to the dense columns (created rows appended, changed rows overwritten)
  * instead of rebuilding them from the table. A full rebuild still happens after a table growth, after merges that do not log
- * (BMX_MERGE_UNIQUE_KEYS, BMX_MERGE_STRICT_FLAGS, the bucketed path), when the log outgrows an eighth of the table, with more than 8
+ * (BMX_MERGE_UNIQUE_KEYS, BMX_MERGE_STRICT_FLAGS), when the log outgrows an eighth of the table, with more than 8
  * indexes, or for tables of 2^31 slots and more. bmx_index_refresh_counts reports how often each happened.
  * out_ids may be NULL (count only). *n_out = number of matches even if cap is smaller. */
 int bmx_index_build(bmx_ctx* ctx, uint32_t field);
@@ -390,8 +383,7 @@ int bmx_timer_start(bmx_ctx* ctx);
 int bmx_timer_stop(bmx_ctx* ctx, float* ms_out);    /* synchronises on the stop event */
 /* Per-kernel timing of the merge: while enabled, every merge call brackets its three stages with HIP
  * events (up to 64 calls are kept). bmx_profile_read synchronises and returns the AVERAGE milliseconds
- * per call of: [0] k_probe_apply, [1] k_resolve_lists, [2] winner compaction, and the number of calls averaged
- * (calls that took the bucketed path: [0] k_merge_bins, [1] k_bucket, [2] k_count_winners + compaction). */
+ * per call of: [0] k_probe_apply, [1] k_resolve_lists, [2] winner compaction, and the number of calls averaged */
 int bmx_profile_enable(bmx_ctx* ctx, int on);
 int bmx_profile_read(bmx_ctx* ctx, float ms_out[3], uint32_t* n_calls);
 /* Same for the scans issued while profiling was enabled: AVERAGE milliseconds per scan call of [0] the mask pass (k_scan_mask: the one

@@ -2,7 +2,7 @@
 
 config 2: 10M-row resident graph, 1M-delta batches (90 % hits on unique keys, 10 % inserts) — winners, n_rows and the state digest;
 config 5: the same graph under 10 streaming batches of 1M deltas with 30 % of them on R/1000 hot keys.
-The oracle side is computed once per shape and shared by both merge paths (conftest parametrises `merge_path`)."""
+The oracle side is computed once per shape."""
 import functools
 
 import numpy as np
