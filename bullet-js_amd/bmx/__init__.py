@@ -29,7 +29,7 @@ EXPORTS = [
     "bmx_create", "bmx_create_ex", "bmx_destroy", "bmx_last_error", "bmx_abi_version", "bmx_get_info", "bmx_sync", "bmx_set_stream", "bmx_get_stream", "bmx_seq_signal", "bmx_seq_wait",
     "bmx_load_rows", "bmx_put_rows", "bmx_merge_batch", "bmx_merge_submit", "bmx_merge_collect", "bmx_merge_records", "bmx_get_rows", "bmx_get_row", "bmx_dump_rows", "bmx_row_count", "bmx_reserve",
     "bmx_index_build", "bmx_index_drop", "bmx_index_size", "bmx_index_refresh_counts", "bmx_scan_range", "bmx_scan_equals", "bmx_scan_count", "bmx_scan_filter", "bmx_scan_range_pos", "bmx_index_ids",
-    "bmx_owner_of", "bmx_partition_by_owner", "bmx_partition_by_owner_slabs", "bmx_partition_scatter", "bmx_ipc_alloc", "bmx_ipc_open", "bmx_ipc_close", "bmx_ipc_free", "bmx_seq_wait_all", "bmx_merge_notify", "bmx_timer_start", "bmx_timer_stop", "bmx_profile_enable", "bmx_profile_read", "bmx_profile_read_scan",
+    "bmx_owner_of", "bmx_partition_by_owner", "bmx_partition_by_owner_slabs", "bmx_partition_scatter", "bmx_merge_records_after", "bmx_ipc_alloc", "bmx_ipc_open", "bmx_ipc_close", "bmx_ipc_free", "bmx_seq_wait_all", "bmx_merge_notify", "bmx_timer_start", "bmx_timer_stop", "bmx_profile_enable", "bmx_profile_read", "bmx_profile_read_scan",
     "bmx_comm_create", "bmx_comm_destroy", "bmx_comm_last_error", "bmx_comm_nshards", "bmx_comm_shard", "bmx_comm_sync", "bmx_comm_load_rows", "bmx_comm_put_rows", "bmx_comm_merge",
     "bmx_comm_merge_dev", "bmx_comm_shard_result", "bmx_comm_row_count", "bmx_comm_get_rows", "bmx_comm_dump_rows", "bmx_comm_index_build",
     "bmx_comm_scan_range", "bmx_comm_scan_equals", "bmx_comm_scan_count", "bmx_comm_scan_filter",
@@ -118,7 +118,8 @@ def load_library():
     L.bmx_owner_of.argtypes = [u64, u32]; L.bmx_owner_of.restype = u32
     L.bmx_partition_by_owner.argtypes = [vp, u64, vp, vp, vp, vp, u32, vp, vp]; L.bmx_partition_by_owner.restype = i32
     L.bmx_partition_by_owner_slabs.argtypes = [vp, u64, vp, vp, vp, vp, u32, u64, vp, vp]; L.bmx_partition_by_owner_slabs.restype = i32
-    L.bmx_partition_scatter.argtypes = [vp, u64, vp, vp, vp, vp, u32, u64, vp, vp, vp, u64]; L.bmx_partition_scatter.restype = i32
+    L.bmx_partition_scatter.argtypes = [vp, u64, vp, vp, vp, vp, u32, u64, vp, vp, vp, u64, vp, u32, u64]; L.bmx_partition_scatter.restype = i32
+    L.bmx_merge_records_after.argtypes = [vp, vp, u32, u64, u64, vp, i32, vp, vp, vp, vp]; L.bmx_merge_records_after.restype = i32
     L.bmx_ipc_alloc.argtypes = [vp, u64, u32, C.POINTER(vp), C.c_char_p]; L.bmx_ipc_alloc.restype = i32
     L.bmx_ipc_open.argtypes = [vp, C.c_char_p, i32, C.POINTER(vp)]; L.bmx_ipc_open.restype = i32
     L.bmx_ipc_close.argtypes = [vp, vp]; L.bmx_ipc_close.restype = i32
@@ -400,9 +401,14 @@ class Engine:
         """a C array of device pointers, built once and reused (partition_scatter_raw): keeps the per-step host cost down"""
         return (C.c_void_p * max(len(ptrs), 1))(*[C.c_void_p(int(x)) if x else None for x in ptrs])
 
-    def partition_scatter_raw(self, n, id, field, ts, val, nshards, slab_records, dst_arr, counts_out, arrive_arr, arrive_value):
-        self._chk(self.L.bmx_partition_scatter(self.h, int(n), _ptr(id), _ptr(field), _ptr(ts), _ptr(val), int(nshards), int(slab_records), dst_arr, _ptr(counts_out),
-                                               arrive_arr, int(arrive_value)))
+    def partition_scatter_raw(self, n, id, field, ts, val, nshards, slab_records, dst_arr, counts_out, arrive_arr, arrive_value, wait_ptr=0, n_wait=0, wait_at_least=0):
+        """one host call per route: (optional) wait until n_wait words at wait_ptr are >= wait_at_least, partition + scatter, arrival words"""
+        self._chk(self.L.bmx_partition_scatter(self.h, n, _ptr(id), _ptr(field), _ptr(ts), _ptr(val), nshards, slab_records, dst_arr, _ptr(counts_out),
+                                               arrive_arr, arrive_value, wait_ptr if wait_ptr else None, n_wait, wait_at_least))
+
+    def merge_records_after(self, wait_ptr, n_wait, wait_at_least, n, recs_ptr, insert_mode, applied, n_applied):
+        """one host call per merge: wait for the arrival words, then merge the records"""
+        self._chk(self.L.bmx_merge_records_after(self.h, wait_ptr, n_wait, wait_at_least, n, recs_ptr, insert_mode, _ptr(applied), _ptr(n_applied), None, None))
 
     def seq_wait_all(self, stream_ptr, words_ptr, nwords, at_least):
         self._chk(self.L.bmx_seq_wait_all(self.h, C.c_void_p(stream_ptr) if stream_ptr else None, _ptr(words_ptr), int(nwords), int(at_least)))

@@ -398,17 +398,17 @@ class ShardedGraph:
         # xGMI links (7/8 of the records leave the GPU) and runs underneath the merge of batch k; the two streams meet only through words in memory
         d, pe, W, k = self._direct, self.ops.pe, self.world, p["k"]
         depth = d["depth"]
-        if k >= depth:                     # the slab set is free once EVERY owner has merged batch k - depth (their merges count up my free words)
-            pe.seq_wait_all(0, d["own"]["freed"], W, k - depth + 1)
         st = d["sets"][k % depth]
-        pe.partition_scatter_raw(n, id, field, ts, val, W, self.slab, st["dst"], p["counts"], st["arrive"], k + 1)
+        # the slab set is free once EVERY owner has merged batch k - depth (their merges count up my free words): waited for on the device, same call
+        pe.partition_scatter_raw(n, id, field, ts, val, W, self.slab, st["dst"], p["counts"], st["arrive"], k + 1,
+                                 d["own"]["freed"] if k >= depth else 0, W, k - depth + 1)
         p["used"] = True
 
     def _merge_direct(self, p):
         d, e, W, k = self._direct, self.ops.e, self.world, p["k"]
-        e.seq_wait_all(0, d["own"]["arrived"], W, k + 1)          # every origin's slab of batch k has arrived
         nrecv = W * self.slab
-        e.merge_records_dev(nrecv, d["own"]["recv"] + (k % d["depth"]) * nrecv * 32, self.insert_mode, applied=p["applied"], n_applied=p["n_applied"])
+        # every origin's slab of batch k has arrived (waited for on the device), then the merge: one host call
+        e.merge_records_after(d["own"]["arrived"], W, k + 1, nrecv, d["own"]["recv"] + (k % d["depth"]) * nrecv * 32, self.insert_mode, p["applied"], p["n_applied"])
         self._merged += 1
         self.n_steps += 1
         self.received += nrecv

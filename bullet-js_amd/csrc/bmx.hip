@@ -1018,6 +1018,13 @@ int bmx_merge_records(bmx_ctx* ctx, uint64_t n, const bmx_delta_rec* recs, int i
   return merge_core<true>(ctx, n, nullptr, nullptr, nullptr, nullptr, recs, insert_mode, applied_idx, n_applied, flags, stats);
 }
 
+int bmx_merge_records_after(bmx_ctx* ctx, const uint64_t* wait_words_dev, uint32_t n_wait, uint64_t wait_at_least, uint64_t n, const bmx_delta_rec* recs,
+                            int insert_mode, uint32_t* applied_idx, uint64_t* n_applied, uint8_t* flags, bmx_merge_stats* stats) {
+  if (!ctx) return fail(nullptr, BMX_ERR_INVALID, "null context");
+  if (wait_words_dev && n_wait) { int wrc = bmx_seq_wait_all(ctx, nullptr, wait_words_dev, n_wait, wait_at_least); if (wrc) return wrc; }
+  return bmx_merge_records(ctx, n, recs, insert_mode, applied_idx, n_applied, flags, stats);
+}
+
 int bmx_load_rows(bmx_ctx* ctx, uint64_t n, const uint64_t* id, const uint32_t* field, const int64_t* ts, const int64_t* val, int mem) {
   if (!ctx) return fail(nullptr, BMX_ERR_INVALID, "null context");
   if (n && (!id || !field || !ts || !val)) return fail(ctx, BMX_ERR_INVALID, "null input column");
@@ -1320,8 +1327,10 @@ int bmx_ipc_free(bmx_ctx* ctx, void* dev_ptr) {
 }
 
 int bmx_partition_scatter(bmx_ctx* ctx, uint64_t n, const uint64_t* id, const uint32_t* field, const int64_t* ts, const int64_t* val,
-                          uint32_t nshards, uint64_t slab_records, void* const* dst, uint64_t* counts_out_dev, uint64_t* const* arrive_words, uint64_t arrive_value) {
+                          uint32_t nshards, uint64_t slab_records, void* const* dst, uint64_t* counts_out_dev, uint64_t* const* arrive_words, uint64_t arrive_value,
+                          const uint64_t* wait_words_dev, uint32_t n_wait, uint64_t wait_at_least) {
   if (!ctx || !dst || slab_records == 0 || nshards == 0 || nshards > PART_MAX_SHARDS) return fail(ctx, BMX_ERR_INVALID, "bmx_partition_scatter: bad arguments (1..16 shards, slab_records > 0)");
+  if (wait_words_dev && n_wait) { int wrc = bmx_seq_wait_all(ctx, nullptr, wait_words_dev, n_wait, wait_at_least); if (wrc) return wrc; }
   PartOut po; std::memset(&po, 0, sizeof(po));
   for (uint32_t g = 0; g < nshards; g++) {
     if (!dst[g]) return fail(ctx, BMX_ERR_INVALID, "bmx_partition_scatter: null destination slab");

@@ -77,6 +77,8 @@ class PutQueue {
     sg.cols.set2(sg.n++, lo, hi, field, ts, val);
     this.n++;
   }
+  /* the segment a batch's winners append to, with room for `rows` more rows (one allocation per batch instead of doubling from 64) */
+  uniqueSegment(rows) { return this._seg(false, rows); }
   closeBatch() {                                      // the next batch's rows may name the same keys: they start a new segment
     if (this.segs.length && !this.segs[this.segs.length - 1].dedupe) this.segs.push({ dedupe: true, n: 0, cap: 64, cols: new Columns(64), at: new Map() });
   }
@@ -546,6 +548,38 @@ class GpuCRT {
     const b = this.bullet;
     const q = this._putQueue();
     const updates = mode ? new Array(n) : null;
+    if (!mode && valueRows) {
+      // no store to keep: the winners' integer fields go straight into one pre-sized segment (no tombstones: what a replaced node held is only known
+      // with the store). An eligible entry's own fields are safe integers, the transport tags are not numbers.
+      const keys = this._graph.keys;
+      let sg = q.uniqueSegment(2 * n), lastParent = null, per = null;
+      for (let k = 0; k < n; k++) {
+        const e = entries[applied[k].entry];
+        const path = e.path, cut = path.lastIndexOf("/");
+        const ts = ts32 ? ts32[2 * k + 1] * 4294967296 + ts32[2 * k] : ((appliedIdx[k] >>> 31) && !deltaMode ? 2 : e.vectorClock[writer]);
+        if (!(cut === (lastParent === null ? -2 : lastParent.length) && path.startsWith(lastParent))) {
+          lastParent = cut < 0 ? "" : path.slice(0, cut);
+          per = keys._fieldCache.get(lastParent);
+          if (per === undefined) { keys.fieldOf(lastParent, null); per = keys._fieldCache.get(lastParent); }
+        }
+        const value = e.data, lo = id32[2 * k], hi = id32[2 * k + 1];
+        if (typeof value === "number") {
+          if (sg.n === sg.cap) sg = q.uniqueSegment(n);
+          sg.cols.set2(sg.n++, lo, hi, keys.fieldOf(lastParent, null), ts, value); q.n++;
+          continue;
+        }
+        for (const f in value) {
+          const v = value[f];
+          if (typeof v !== "number") continue;
+          let h = per.get(f);
+          if (h === undefined) h = keys.fieldOf(lastParent, f);
+          if (sg.n === sg.cap) sg = q.uniqueSegment(n);
+          sg.cols.set2(sg.n++, lo, hi, h, ts, v); q.n++;
+        }
+      }
+      q.closeBatch();
+      return [];
+    }
     for (let k = 0; k < n; k++) {
       const e = entries[applied[k].entry];
       const path = e.path, cut = path.lastIndexOf("/");

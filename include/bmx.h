@@ -363,6 +363,8 @@ int bmx_vc_sync(bmx_vc* t);
  *                  receive memory, this process's or a mapped one — and, from a one-wave launch behind the scatter (its kernel boundary is the
  *                  release), arrive_words[g] (a word in shard g's memory, may be NULL) is set to arrive_value. No copy kernel, no collective,
  *                  no second stream.
+ *                  wait_words_dev (may be NULL): bmx_seq_wait_all on these words first (the owners have freed the slab set). One host call per route.
+ *   bmx_merge_records_after  bmx_seq_wait_all on the words (the origins' slabs have arrived), then bmx_merge_records: one host call per merge.
  *   bmx_seq_wait_all  one-wave kernel on the stream: returns once every one of nwords consecutive words (this GPU's memory) is >= at_least;
  *                  expires like bmx_seq_wait.
  *   bmx_merge_notify  from now on every merge of this context, as its last act, stores the number of merges finished since this call into each of
@@ -374,7 +376,9 @@ int bmx_ipc_close(bmx_ctx* ctx, void* dev_ptr);
 int bmx_ipc_free(bmx_ctx* ctx, void* dev_ptr);
 int bmx_partition_scatter(bmx_ctx* ctx, uint64_t n, const uint64_t* id, const uint32_t* field, const int64_t* ts, const int64_t* val,
                           uint32_t nshards, uint64_t slab_records, void* const* dst, uint64_t* counts_out_dev, uint64_t* const* arrive_words,
-                          uint64_t arrive_value);
+                          uint64_t arrive_value, const uint64_t* wait_words_dev, uint32_t n_wait, uint64_t wait_at_least);
+int bmx_merge_records_after(bmx_ctx* ctx, const uint64_t* wait_words_dev, uint32_t n_wait, uint64_t wait_at_least, uint64_t n, const bmx_delta_rec* recs,
+                            int insert_mode, uint32_t* applied_idx, uint64_t* n_applied, uint8_t* flags, bmx_merge_stats* stats);
 int bmx_seq_wait_all(bmx_ctx* ctx, void* hip_stream, const uint64_t* words_dev, uint32_t nwords, uint64_t at_least);
 int bmx_merge_notify(bmx_ctx* ctx, uint64_t* const* words, uint32_t nwords);
 
