@@ -196,11 +196,11 @@ int bmx_put_rows(bmx_ctx* ctx, uint64_t n, const uint64_t* id, const uint32_t* f
 int bmx_get_rows(bmx_ctx* ctx, uint64_t n, const uint64_t* id, const uint32_t* field, int64_t* ts, int64_t* val,
                  uint8_t* found, int mem);
 int bmx_get_row(bmx_ctx* ctx, uint64_t id, uint32_t field, int64_t* ts, int64_t* val); /* 1 found, 0 absent, <0 error */
-/* all resident rows, unordered; *n_out = row count even if cap is smaller (checkpoint hook:
- * src/bullet-network-sync.js:592-664 _collectFullSyncData) */
+/* all resident rows that hold data (tombstones are left out), unordered; *n_out = their number even if cap is smaller (checkpoint hook:
+ * src/bullet-network-sync.js:592-664 _collectFullSyncData, which skips deleted entries the same way) */
 int bmx_dump_rows(bmx_ctx* ctx, uint64_t cap, uint64_t* id, uint32_t* field, int64_t* ts, int64_t* val,
                   uint64_t* n_out, int mem);
-int bmx_row_count(bmx_ctx* ctx, uint64_t* n_out);
+int bmx_row_count(bmx_ctx* ctx, uint64_t* n_out);   /* keys holding a slot: rows + tombstones (what counts against capacity_rows) */
 /* Make room for at least capacity_rows resident rows (no-op if already there): allocates a new table, re-inserts every
  * row on the device, frees the old one. Synchronous. The reference's store is a JS object that simply grows
  * (src/bullet.js:28); this is the device-side equivalent. */
@@ -226,7 +226,7 @@ int bmx_reserve(bmx_ctx* ctx, uint64_t capacity_rows);
  * out_ids may be NULL (count only). *n_out = number of matches even if cap is smaller. */
 int bmx_index_build(bmx_ctx* ctx, uint32_t field);
 int bmx_index_drop(bmx_ctx* ctx, uint32_t field);
-int bmx_index_size(bmx_ctx* ctx, uint32_t field, uint64_t* n_out);
+int bmx_index_size(bmx_ctx* ctx, uint32_t field, uint64_t* n_out);   /* positions in the index columns (rows of the field, tombstoned ones included: they keep their position and match nothing) */
 int bmx_index_refresh_counts(bmx_ctx* ctx, uint64_t* full_builds, uint64_t* incremental_updates);
 int bmx_scan_range(bmx_ctx* ctx, uint32_t field, int64_t lo, int64_t hi, uint64_t* out_ids, uint64_t cap,
                    uint64_t* n_out, int mem);
