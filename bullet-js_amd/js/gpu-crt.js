@@ -53,10 +53,14 @@ function peek(root, path) {
  * keeps the LAST write per key (a Map keyed by the row key: fine for a put at a time); the winners of a batch are unique by construction — one
  * winner per node, one row per field — and are appended to a segment of their own with no look-up at all. */
 class PutQueue {
-  constructor() { this.segs = []; this.n = 0; }
+  constructor() { this.segs = []; this.n = 0; this.hostRows = 0; this._sealed = false; }
   _seg(dedupe, room) {
     let sg = this.segs.length ? this.segs[this.segs.length - 1] : null;
-    if (!sg || sg.dedupe !== dedupe) { sg = { dedupe, n: 0, cap: Math.max(64, room), cols: new Columns(Math.max(64, room)), at: dedupe ? new Map() : null }; this.segs.push(sg); }
+    if (!sg || sg.dedupe !== dedupe || (this._sealed && !dedupe)) {
+      sg = { dedupe, n: 0, cap: Math.max(64, room), cols: new Columns(Math.max(64, room)), at: dedupe ? new Map() : null };
+      this.segs.push(sg);
+      this._sealed = false;
+    }
     if (sg.n + room > sg.cap) {
       let cap = sg.cap; while (sg.n + room > cap) cap *= 2;
       const bigger = new Columns(cap);
@@ -69,7 +73,7 @@ class PutQueue {
     const sg = this._seg(true, 1);
     const key = lo + ":" + hi + ":" + field;
     let i = sg.at.get(key);
-    if (i === undefined) { i = sg.n++; sg.at.set(key, i); this.n++; }
+    if (i === undefined) { i = sg.n++; sg.at.set(key, i); this.n++; this.hostRows++; }
     sg.cols.set2(i, lo, hi, field, ts, val);
   }
   pushUnique(lo, hi, field, ts, val) {                // a batch winner's row: unique within its batch by construction
@@ -79,12 +83,10 @@ class PutQueue {
   }
   /* the segment a batch's winners append to, with room for `rows` more rows (one allocation per batch instead of doubling from 64) */
   uniqueSegment(rows) { return this._seg(false, rows); }
-  closeBatch() {                                      // the next batch's rows may name the same keys: they start a new segment
-    if (this.segs.length && !this.segs[this.segs.length - 1].dedupe) this.segs.push({ dedupe: true, n: 0, cap: 64, cols: new Columns(64), at: new Map() });
-  }
+  closeBatch() { this._sealed = true; }               // the next batch's rows may name the same keys: they start a segment of their own
   /* rows of single host writes are waiting (they may be clock rows: a merge must see them); batch winners' value rows alone can wait for a reader */
-  hasHostRows() { for (const sg of this.segs) if (sg.dedupe && sg.n) return true; return false; }
-  take() { const out = this.segs.filter((sg) => sg.n > 0).map((sg) => sg.cols.slice(sg.n)); this.segs = []; this.n = 0; return out; }
+  hasHostRows() { return this.hostRows > 0; }
+  take() { const out = this.segs.filter((sg) => sg.n > 0).map((sg) => sg.cols.slice(sg.n)); this.segs = []; this.n = 0; this.hostRows = 0; this._sealed = false; return out; }
 }
 
 function verdict(winner, clock, value, reason, extra) {
@@ -430,7 +432,8 @@ class GpuCRT {
    * for the batch (N1, batch-apply.js); "each" = one _applyUpdate per winner. The winners' integer fields are queued as device value rows
    * (and tombstones for the fields the replaced node had: known only when the store is kept, i.e. with opts.apply) for the device-side
    * indexes; they reach the device in front of the next device read (opts.valueRows: false leaves them out: clock rows only).
-   * -> {applied: [{entry, field: null}], nApplied, nConflicts, nRows, host: [entry indices], broadcast: [{path, broadcastData}] when applied}
+   * -> {appliedEntries: Int32Array (winner k is entry appliedEntries[k]), applied: [{entry, field: null}] (the same, built on first read), nApplied, nConflicts,
+   *     nRows, host: [entry indices], broadcast: [{path, broadcastData}] when applied}
    */
   mergeEntries(entries, opts = {}) {
     if (this._opts.writers) return this._mergeEntriesVector(entries, opts);
@@ -497,11 +500,15 @@ class GpuCRT {
   }
 
   _finishEntries(entries, p, r, opts) {
-    const applied = new Array(r.applied.length);
-    for (let k = 0; k < applied.length; k++) applied[k] = { entry: p.rowEntry[r.applied[k] & 0xffffff], field: null };
-    const broadcast = this._applyWinners(entries, p.cols, r.applied, applied, opts.apply, opts.broadcast !== false, !this.graph.comm, opts.insertMode === "delta", p.writer, opts.valueRows !== false);
+    const nw = r.applied.length;
+    const appliedEntries = new Int32Array(nw);                 // winner k is entry appliedEntries[k] (ascending)
+    for (let k = 0; k < nw; k++) appliedEntries[k] = p.rowEntry[r.applied[k] & 0xffffff];
+    const broadcast = this._applyWinners(entries, p.cols, r.applied, appliedEntries, opts.apply, opts.broadcast !== false, !this.graph.comm, opts.insertMode === "delta", p.writer, opts.valueRows !== false);
     if (opts.apply) this._notifyIndexHook(entries, p.host);
-    return { applied, nApplied: r.nApplied, nConflicts: r.nConflicts, nRows: r.nRows, host: p.host, broadcast: opts.apply ? broadcast : undefined };
+    const out = { appliedEntries, nApplied: r.nApplied, nConflicts: r.nConflicts, nRows: r.nRows, host: p.host, broadcast: opts.apply ? broadcast : undefined };
+    let list = null;                                           // `applied` in the older shape, built only if somebody reads it (an object per winner is what the ingestion rate can do without)
+    Object.defineProperty(out, "applied", { enumerable: true, get() { if (!list) { list = new Array(nw); for (let k = 0; k < nw; k++) list[k] = { entry: appliedEntries[k], field: null }; } return list; } });
+    return out;
   }
 
   /*
@@ -554,7 +561,7 @@ class GpuCRT {
       const keys = this._graph.keys;
       let sg = q.uniqueSegment(2 * n), lastParent = null, per = null;
       for (let k = 0; k < n; k++) {
-        const e = entries[applied[k].entry];
+        const e = entries[applied[k]];
         const path = e.path, cut = path.lastIndexOf("/");
         const ts = ts32 ? ts32[2 * k + 1] * 4294967296 + ts32[2 * k] : ((appliedIdx[k] >>> 31) && !deltaMode ? 2 : e.vectorClock[writer]);
         if (!(cut === (lastParent === null ? -2 : lastParent.length) && path.startsWith(lastParent))) {
@@ -581,7 +588,7 @@ class GpuCRT {
       return [];
     }
     for (let k = 0; k < n; k++) {
-      const e = entries[applied[k].entry];
+      const e = entries[applied[k]];
       const path = e.path, cut = path.lastIndexOf("/");
       // the clock the node now stores: read back, or — one context — the entry's own unless this winner CREATED the node (bit 31: the insert rule's {writer: 2})
       const ts = ts32 ? ts32[2 * k + 1] * 4294967296 + ts32[2 * k] : ((appliedIdx[k] >>> 31) && !deltaMode ? 2 : e.vectorClock[writer]);

@@ -186,3 +186,26 @@ def test_physical_devices_equal_one_merge(ndev):
         lo, hi = -(1 << 28), 1 << 28
         assert np.array_equal(np.sort(c.scan_range(f, lo, hi)), np.sort(o.scan_range(f, lo, hi)))
     o.close()
+
+
+@pytest.mark.parametrize("N", [2, 8])
+def test_host_batch_with_every_delta_on_one_shard(N):
+    """A host batch whose node ids all belong to ONE shard: the slab sized for a uniform owner hash is too small, the batch is partitioned once more
+    into slabs of the largest run before anything is merged. Winners and state as one unsharded merge."""
+    from oracle import streams
+    rng = np.random.default_rng(5 + N)
+    cand = streams.splitmix64_np(np.arange(1, 2_000_000, dtype=np.uint64))
+    mine = cand[bmx.owner_of(cand, N) == N - 1][:90_000]
+    assert len(mine) == 90_000
+    f = streams.field_hash(1)
+    o = Oracle()
+    with bmx.Comm([0] * N, capacity_rows_per_shard=400_000) as c:
+        for b in range(2):
+            ids = mine[rng.integers(0, len(mine), 70_000)]
+            d = (ids, np.full(len(ids), f, np.uint32), rng.integers(1, 50, len(ids)).astype(np.int64), rng.integers(-9, 10, len(ids)).astype(np.int64))
+            applied, st = c.merge(*d)
+            _, want = o.merge_batch(*d)
+            assert np.array_equal(applied, want), b
+        assert c.row_count() == len(o)
+        assert rows_digest(*c.dump_rows()) == o.digest()
+    o.close()
