@@ -121,9 +121,9 @@ def js_host_rate():
     if not node:
         return None
     try:
-        r = subprocess.run([node, os.path.join(ROOT, "bullet-js_amd", "js", "test", "e2e_rate.js"), "1000000", "200000", "5"], capture_output=True, text=True, timeout=240)
+        r = subprocess.run([node, os.path.join(ROOT, "bullet-js_amd", "js", "test", "e2e_rate.js"), "1000000", "500000", "8"], capture_output=True, text=True, timeout=240)
         j = json.loads(r.stdout.strip().splitlines()[-1])
-        j["sample"] = "5 batches of 200k sync entries (10 % new nodes) against 1M resident nodes, node-level resolution (one clock-row delta per entry + the winners' value rows); GpuCRT.mergeEntries (synchronous), GpuCRT.mergeEntriesPipelined (mergeEntriesAsync, two chunks in flight) and GpuCRT.mergeBatch (typed columns) over the N-API addon, host buffers"
+        j["sample"] = "8 chunks of 500k sync entries (10 % new nodes) against 1M resident nodes per figure, node-level resolution (one clock-row delta per entry + the winners' value rows); GpuCRT.mergeEntries (synchronous), GpuCRT.mergeEntriesPipelined (mergeEntriesAsync, two chunks in flight) and GpuCRT.mergeBatch (typed columns) over the N-API addon, page-locked host columns"
         return j
     except Exception as e:
         return {"error": str(e)[:200]}

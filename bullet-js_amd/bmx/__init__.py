@@ -27,7 +27,7 @@ MAX_BATCH = 1 << 24
 
 EXPORTS = [
     "bmx_create", "bmx_create_ex", "bmx_destroy", "bmx_last_error", "bmx_abi_version", "bmx_get_info", "bmx_sync", "bmx_set_stream", "bmx_get_stream", "bmx_seq_signal", "bmx_seq_wait",
-    "bmx_load_rows", "bmx_put_rows", "bmx_merge_batch", "bmx_merge_submit", "bmx_merge_collect", "bmx_merge_records", "bmx_get_rows", "bmx_get_row", "bmx_dump_rows", "bmx_row_count", "bmx_reserve",
+    "bmx_load_rows", "bmx_put_rows", "bmx_merge_batch", "bmx_merge_submit", "bmx_merge_collect", "bmx_host_alloc", "bmx_host_free", "bmx_merge_records", "bmx_get_rows", "bmx_get_row", "bmx_dump_rows", "bmx_row_count", "bmx_reserve",
     "bmx_index_build", "bmx_index_drop", "bmx_index_size", "bmx_index_refresh_counts", "bmx_scan_range", "bmx_scan_equals", "bmx_scan_count", "bmx_scan_filter", "bmx_scan_range_pos", "bmx_index_ids",
     "bmx_owner_of", "bmx_partition_by_owner", "bmx_partition_by_owner_slabs", "bmx_partition_scatter", "bmx_merge_records_after", "bmx_ipc_alloc", "bmx_ipc_open", "bmx_ipc_close", "bmx_ipc_free", "bmx_seq_wait_all", "bmx_merge_notify", "bmx_timer_start", "bmx_timer_stop", "bmx_profile_enable", "bmx_profile_read", "bmx_profile_read_scan",
     "bmx_comm_create", "bmx_comm_destroy", "bmx_comm_last_error", "bmx_comm_nshards", "bmx_comm_shard", "bmx_comm_sync", "bmx_comm_load_rows", "bmx_comm_put_rows", "bmx_comm_merge",
@@ -124,6 +124,8 @@ def load_library():
     L.bmx_ipc_open.argtypes = [vp, C.c_char_p, i32, C.POINTER(vp)]; L.bmx_ipc_open.restype = i32
     L.bmx_ipc_close.argtypes = [vp, vp]; L.bmx_ipc_close.restype = i32
     L.bmx_ipc_free.argtypes = [vp, vp]; L.bmx_ipc_free.restype = i32
+    L.bmx_host_alloc.argtypes = [C.c_uint64, C.POINTER(C.c_void_p)]; L.bmx_host_alloc.restype = i32
+    L.bmx_host_free.argtypes = [vp]; L.bmx_host_free.restype = i32
     L.bmx_seq_wait_all.argtypes = [vp, vp, vp, u32, u64]; L.bmx_seq_wait_all.restype = i32
     L.bmx_merge_notify.argtypes = [vp, vp, u32]; L.bmx_merge_notify.restype = i32
     L.bmx_timer_start.argtypes = [vp]; L.bmx_timer_start.restype = i32
@@ -178,6 +180,44 @@ def _ptr(a):
     if isinstance(a, np.ndarray):
         return C.c_void_p(a.ctypes.data)
     return C.c_void_p(a.data_ptr())
+
+
+class HostBuffer:
+    """Page-locked host memory (bmx_host_alloc) seen as a numpy array: inputs and outputs of host-array calls placed here move at the
+    link's rate. Freed by close() or when collected; arrays taken from it must not outlive it."""
+
+    def __init__(self, nbytes):
+        self.L = load_library()
+        p = C.c_void_p()
+        rc = self.L.bmx_host_alloc(int(nbytes), C.byref(p))
+        if rc:
+            raise BmxError(rc, (self.L.bmx_last_error(None) or b"").decode())
+        self.ptr, self.nbytes = p.value, int(nbytes)
+        self._raw = (C.c_uint8 * self.nbytes).from_address(self.ptr)
+
+    def array(self, dtype, count, offset=0):
+        dt = np.dtype(dtype)
+        if offset % dt.itemsize or offset + count * dt.itemsize > self.nbytes:
+            raise ValueError("HostBuffer.array: out of range or misaligned")
+        return np.frombuffer(self._raw, dtype=dt, count=count, offset=offset)
+
+    def close(self):
+        if self.ptr:
+            self._raw = None
+            self.L.bmx_host_free(C.c_void_p(self.ptr))
+            self.ptr = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def host_columns(n):
+    """-> (HostBuffer, id u64[n], field u32[n], ts i64[n], val i64[n]) in page-locked memory, the layout merge_batch() takes."""
+    hb = HostBuffer(max(n, 1) * 28)
+    return hb, hb.array(np.uint64, n), hb.array(np.uint32, n, 24 * n), hb.array(np.int64, n, 8 * n), hb.array(np.int64, n, 16 * n)
 
 
 class Engine:

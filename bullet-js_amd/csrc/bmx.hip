@@ -52,6 +52,8 @@ constexpr int MERGE_FORCE_INTERNAL = 0x4000;   // insert_mode bit used by bmx_pu
 
 }  // namespace
 
+// count, stats and device status of one host batch, written by k_small_tail into mapped host memory
+struct SmallOut { unsigned long long n_applied; bmx_merge_stats stats; uint32_t status; uint32_t pad; };
 struct bmx_ctx {
   int device = 0;
   hipStream_t own_stream = nullptr, stream = nullptr;
@@ -75,12 +77,14 @@ struct bmx_ctx {
     uint64_t* id = nullptr; uint32_t* field = nullptr; int64_t* ts = nullptr; int64_t* val = nullptr;
     uint32_t* applied = nullptr; uint8_t* flags = nullptr;
     unsigned long long* n_out = nullptr; bmx_merge_stats* stats = nullptr;   // device words of this set
+    SmallOut* tail = nullptr;                                                 // the same, in mapped host memory (null: copied down instead)
     hipEvent_t up = nullptr, done = nullptr;                                  // inputs uploaded / kernels of the batch finished
     uint64_t n = 0; bool want_flags = false; bool busy = false; uint64_t ticket = 0;
   } stg[2];
   // small host batches (<= SMALL_HOST_N deltas): inputs are packed into mapped host memory the kernels read directly, results are written
   // straight into mapped host memory: three launches and one stream synchronisation per call, no copies, no second stream
   uint8_t* pin_in = nullptr; uint8_t* pin_out = nullptr;
+  SmallOut* stg_tails = nullptr;       // mapped host memory behind stg[i].tail
   hipStream_t copy_stream = nullptr;   // uploads
   hipStream_t down_stream = nullptr;   // downloads (PCIe is full duplex: results of batch b come back while batch b+1 goes up)
   uint64_t next_ticket = 1;
@@ -422,8 +426,11 @@ int merge_core(bmx_ctx* ctx, uint64_t n, const uint64_t* id, const uint32_t* fie
 // Host batches go through two staging sets. submit: upload on the copy stream, then the merge on the main stream behind an event;
 // collect: results back on the copy stream once the batch's kernels are done. While the host uploads batch b+1 (a pageable
 // hipMemcpyAsync keeps the calling thread busy for the whole transfer) the GPU merges batch b.
+__global__ void k_small_tail(const unsigned long long* n_applied, const bmx_merge_stats* stats, const uint32_t* status, SmallOut* out) {
+  if (threadIdx.x == 0) { out->n_applied = *n_applied; out->stats = *stats; out->status = *status; }
+}
 int submit_host(bmx_ctx* ctx, uint64_t n, const uint64_t* id, const uint32_t* field, const int64_t* ts, const int64_t* val,
-                int insert_mode, bool want_flags, uint64_t* ticket) {
+                int insert_mode, bool want_flags, uint64_t* ticket, bool inputs_free_on_return) {
   int k = -1;
   for (int i = 0; i < 2; i++) if (!ctx->stg[i].busy) { k = i; break; }
   if (k < 0) return fail(ctx, BMX_ERR_INVALID, "two batches are already in flight: collect the oldest first (bmx_merge_collect)");
@@ -438,10 +445,16 @@ int submit_host(bmx_ctx* ctx, uint64_t n, const uint64_t* id, const uint32_t* fi
     HIPCHK(hipMemcpyAsync(S.val, val, n * 8, hipMemcpyHostToDevice, ctx->copy_stream));
     HIPCHK(hipEventRecord(S.up, ctx->copy_stream));
     HIPCHK(hipStreamWaitEvent(ctx->stream, S.up, 0));
+    // a copy from page-locked memory (bmx_host_alloc) is truly asynchronous: bmx_merge_submit promises that the arrays may be reused on return
+    if (inputs_free_on_return) HIPCHK(hipEventSynchronize(S.up));
   }
   rc = merge_core<false>(ctx, n, S.id, S.field, S.ts, S.val, nullptr, insert_mode, S.applied, reinterpret_cast<uint64_t*>(S.n_out),
                          want_flags ? S.flags : nullptr, S.stats);
   if (rc) return rc;
+  if (S.tail) {
+    hipLaunchKernelGGL(k_small_tail, dim3(1), dim3(64), 0, ctx->stream, (const unsigned long long*)S.n_out, (const bmx_merge_stats*)S.stats, (const uint32_t*)&ctx->ds->status, S.tail);
+    LAUNCHCHK("k_small_tail");
+  }
   HIPCHK(hipEventRecord(S.done, ctx->stream));
   S.n = n; S.want_flags = want_flags; S.busy = true; S.ticket = ctx->next_ticket++;
   *ticket = S.ticket;
@@ -456,11 +469,16 @@ int collect_host(bmx_ctx* ctx, uint64_t ticket, uint32_t* applied_idx, uint64_t*
   bmx_ctx::Staging& S = ctx->stg[k];
   S.busy = false;
   bmx_merge_stats hs; std::memset(&hs, 0, sizeof(hs));
-  HIPCHK(hipStreamWaitEvent(ctx->down_stream, S.done, 0));
   uint32_t st = 0;
-  HIPCHK(hipMemcpyAsync(&hs, S.stats, sizeof(hs), hipMemcpyDeviceToHost, ctx->down_stream));
-  HIPCHK(hipMemcpyAsync(&st, &ctx->ds->status, sizeof(st), hipMemcpyDeviceToHost, ctx->down_stream));
-  HIPCHK(hipStreamSynchronize(ctx->down_stream));
+  if (S.tail) {                         // count, stats and status are in mapped host memory once the batch's last launch is done
+    HIPCHK(hipEventSynchronize(S.done));
+    hs = S.tail->stats; st = S.tail->status;
+  } else {
+    HIPCHK(hipStreamWaitEvent(ctx->down_stream, S.done, 0));
+    HIPCHK(hipMemcpyAsync(&hs, S.stats, sizeof(hs), hipMemcpyDeviceToHost, ctx->down_stream));
+    HIPCHK(hipMemcpyAsync(&st, &ctx->ds->status, sizeof(st), hipMemcpyDeviceToHost, ctx->down_stream));
+    HIPCHK(hipStreamSynchronize(ctx->down_stream));
+  }
   if (st) return check_status(ctx);     // sticky device error of this (or an earlier, uncollected) batch
   if (S.n == 0) std::memset(&hs, 0, sizeof(hs));
   if (applied_idx && hs.n_applied) HIPCHK(hipMemcpyAsync(applied_idx, S.applied, hs.n_applied * 4, hipMemcpyDeviceToHost, ctx->down_stream));
@@ -477,7 +495,6 @@ int collect_host(bmx_ctx* ctx, uint64_t ticket, uint32_t* applied_idx, uint64_t*
 // over PCIe, and winners, count, stats and the device status come back through mapped host memory as well.
 constexpr uint64_t SMALL_HOST_N = 32768;
 constexpr int SMALL_PATH_UNAVAILABLE = 1;
-struct SmallOut { unsigned long long n_applied; bmx_merge_stats stats; uint32_t status; uint32_t pad; };
 constexpr size_t SMALL_IN_BYTES = SMALL_HOST_N * 28, SMALL_OUT_APPLIED = 0, SMALL_OUT_FLAGS = SMALL_HOST_N * 4, SMALL_OUT_TAIL = SMALL_HOST_N * 5,
                  SMALL_OUT_BYTES = SMALL_OUT_TAIL + sizeof(SmallOut);
 bool ensure_pinned(bmx_ctx* ctx) {   // the two mapped host buffers of the small-call paths (merge, point reads, scans); false = fall back to copies
@@ -485,14 +502,12 @@ bool ensure_pinned(bmx_ctx* ctx) {   // the two mapped host buffers of the small
   if (hipHostMalloc(reinterpret_cast<void**>(&ctx->pin_in), SMALL_IN_BYTES, hipHostMallocMapped) != hipSuccess ||
       hipHostMalloc(reinterpret_cast<void**>(&ctx->pin_out), SMALL_OUT_BYTES, hipHostMallocMapped) != hipSuccess) {
     (void)hipGetLastError();
-    if (ctx->pin_in) { (void)hipHostFree(ctx->pin_in); ctx->pin_in = nullptr; }
+    if (ctx->stg_tails) { (void)hipHostFree(ctx->stg_tails); ctx->stg_tails = nullptr; }
+  if (ctx->pin_in) { (void)hipHostFree(ctx->pin_in); ctx->pin_in = nullptr; }
     ctx->pin_out = nullptr;
     return false;
   }
   return true;
-}
-__global__ void k_small_tail(const unsigned long long* n_applied, const bmx_merge_stats* stats, const uint32_t* status, SmallOut* out) {
-  if (threadIdx.x == 0) { out->n_applied = *n_applied; out->stats = *stats; out->status = *status; }
 }
 int merge_host_small(bmx_ctx* ctx, uint64_t n, const uint64_t* id, const uint32_t* field, const int64_t* ts, const int64_t* val,
                      int insert_mode, uint32_t* applied_idx, uint64_t* n_applied, uint8_t* flags, bmx_merge_stats* stats) {
@@ -533,7 +548,7 @@ int merge_host(bmx_ctx* ctx, uint64_t n, const uint64_t* id, const uint32_t* fie
     if (src != SMALL_PATH_UNAVAILABLE) return src;
   }
   uint64_t ticket = 0;
-  int rc = submit_host(ctx, n, id, field, ts, val, insert_mode, flags != nullptr, &ticket);
+  int rc = submit_host(ctx, n, id, field, ts, val, insert_mode, flags != nullptr, &ticket, false);   // collect_host waits for the whole batch
   if (rc) return rc;
   return collect_host(ctx, ticket, applied_idx, n_applied, flags, stats);
 }
@@ -888,6 +903,10 @@ int bmx_create_ex(int device, uint64_t capacity_rows, uint32_t max_load_pct, uin
   if (hipHostMalloc(reinterpret_cast<void**>(&ctx->host_rows), 2 * sizeof(unsigned long long), hipHostMallocMapped) == hipSuccess) {
     ctx->host_rows[0] = 0; ctx->host_rows[1] = 0;
   } else { ctx->host_rows = nullptr; (void)hipGetLastError(); }
+  if (hipHostMalloc(reinterpret_cast<void**>(&ctx->stg_tails), 2 * sizeof(SmallOut), hipHostMallocMapped) == hipSuccess) {
+    std::memset(ctx->stg_tails, 0, 2 * sizeof(SmallOut));
+    for (int i = 0; i < 2; i++) ctx->stg[i].tail = ctx->stg_tails + i;
+  } else { ctx->stg_tails = nullptr; (void)hipGetLastError(); }
   ctx->fixed_capacity = (flags & BMX_CTX_FIXED_CAPACITY) != 0;
   CR(hipMemsetAsync(ctx->ds, 0, sizeof(DevScalars), ctx->stream));
   hipLaunchKernelGGL(k_init_slots, dim3(2048), dim3(256), 0, ctx->stream, ctx->slots, nslots);
@@ -1002,7 +1021,7 @@ int bmx_merge_submit(bmx_ctx* ctx, uint64_t n, const uint64_t* id, const uint32_
   if (n && (!id || !field || !ts || !val)) return fail(ctx, BMX_ERR_INVALID, "null input column");
   if (n > MAX_BATCH) return fail(ctx, BMX_ERR_INVALID, "batch larger than 2^24 deltas: split it (sequential semantics are preserved)");
   HIPCHK(hipSetDevice(ctx->device));
-  return submit_host(ctx, n, id, field, ts, val, insert_mode, want_flags != 0, ticket);
+  return submit_host(ctx, n, id, field, ts, val, insert_mode, want_flags != 0, ticket, true);
 }
 
 int bmx_merge_collect(bmx_ctx* ctx, uint64_t ticket, uint32_t* applied_idx, uint64_t* n_applied, uint8_t* flags, bmx_merge_stats* stats) {
@@ -1324,6 +1343,20 @@ int bmx_ipc_free(bmx_ctx* ctx, void* dev_ptr) {
   HIPCHK(hipSetDevice(ctx->device));
   HIPCHK(hipStreamSynchronize(ctx->stream));
   HIPCHK(hipFree(dev_ptr));
+  return BMX_OK;
+}
+
+int bmx_host_alloc(uint64_t bytes, void** host_ptr) {
+  if (!host_ptr || bytes == 0) return fail(nullptr, BMX_ERR_INVALID, "bmx_host_alloc: bad arguments");
+  *host_ptr = nullptr;
+  hipError_t e = hipHostMalloc(host_ptr, bytes, hipHostMallocPortable);
+  if (e != hipSuccess) { (void)hipGetLastError(); *host_ptr = nullptr; return fail(nullptr, e == hipErrorOutOfMemory ? BMX_ERR_NOMEM : BMX_ERR_HIP, std::string("hipHostMalloc: ") + hipGetErrorString(e)); }
+  return BMX_OK;
+}
+int bmx_host_free(void* host_ptr) {
+  if (!host_ptr) return BMX_OK;
+  hipError_t e = hipHostFree(host_ptr);
+  if (e != hipSuccess) { (void)hipGetLastError(); return fail(nullptr, BMX_ERR_HIP, std::string("hipHostFree: ") + hipGetErrorString(e)); }
   return BMX_OK;
 }
 

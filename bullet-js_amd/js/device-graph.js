@@ -7,7 +7,7 @@
  * and are concatenated (src/bullet-query.js:186-261). The methods below behave the same either way.
  */
 const { requireNative } = require("./native");
-const { KeyDictionary } = require("./hash");
+const { KeyDictionary, Columns } = require("./hash");
 
 class DeviceGraph {
   constructor(opts = {}) {
@@ -27,6 +27,28 @@ class DeviceGraph {
     this.keys = new KeyDictionary();
     this.batches = 0;
     this.preOp = null;             // GpuCRT hangs its queue of host-decided rows here: flushed in front of every operation below
+    // column sets of >= 4096 rows are page-locked (bmx_host_alloc) and reused: the runtime neither pins fresh pages per upload nor stages them
+    this._pinned = typeof this.native.hostColumns === "function" && opts.pinnedColumns !== false && process.env.BMX_JS_PINNED !== "0";
+    this._pool = new Map();        // capacity (a power of two) -> idle Columns
+  }
+  /* a Columns of at least n rows to build a batch in; give it back (giveColumns) once the call that read it has returned */
+  takeColumns(n) {
+    if (n < 4096) return new Columns(Math.max(n, 1));
+    let cap = 4096; while (cap < n) cap *= 2;
+    const idle = this._pool.get(cap);
+    if (idle && idle.length) return idle.pop();
+    let backing;
+    if (this._pinned) { try { backing = this.native.hostColumns(cap); } catch (e) { this._pinned = false; } }   // no page-locked memory left: plain arrays
+    const c = new Columns(cap, backing);
+    c._pooled = true;
+    return c;
+  }
+  giveColumns(cols) {
+    const root = cols && (cols._root || cols);
+    if (!root || !root._pooled) return;
+    let idle = this._pool.get(root.n);
+    if (!idle) this._pool.set(root.n, idle = []);
+    if (idle.length < 4 && idle.indexOf(root) < 0) idle.push(root);
   }
   mergeBatch(cols, mode) {          // (merges come from GpuCRT, which decides itself what has to be flushed in front of them)
     this.batches++;

@@ -53,19 +53,23 @@ function peek(root, path) {
  * keeps the LAST write per key (a Map keyed by the row key: fine for a put at a time); the winners of a batch are unique by construction — one
  * winner per node, one row per field — and are appended to a segment of their own with no look-up at all. */
 class PutQueue {
-  constructor() { this.segs = []; this.n = 0; this.hostRows = 0; this._sealed = false; }
+  /* graph: where segments take their columns from and give them back to (DeviceGraph.takeColumns: page-locked, reused); plain Columns without one */
+  constructor(graph) { this.segs = []; this.n = 0; this.hostRows = 0; this._sealed = false; this._graph = graph || null; }
+  _alloc(n) { return this._graph ? this._graph.takeColumns(n) : new Columns(n); }
   _seg(dedupe, room) {
     let sg = this.segs.length ? this.segs[this.segs.length - 1] : null;
     if (!sg || sg.dedupe !== dedupe || (this._sealed && !dedupe)) {
-      sg = { dedupe, n: 0, cap: Math.max(64, room), cols: new Columns(Math.max(64, room)), at: dedupe ? new Map() : null };
+      const cols = this._alloc(Math.max(64, room));
+      sg = { dedupe, n: 0, cap: cols.n, cols, at: dedupe ? new Map() : null };
       this.segs.push(sg);
       this._sealed = false;
     }
     if (sg.n + room > sg.cap) {
       let cap = sg.cap; while (sg.n + room > cap) cap *= 2;
-      const bigger = new Columns(cap);
-      bigger.id.set(sg.cols.id); bigger.field.set(sg.cols.field); bigger.ts.set(sg.cols.ts); bigger.val.set(sg.cols.val);
-      sg.cols = bigger; sg.cap = cap;
+      const bigger = this._alloc(cap), m = sg.n;
+      bigger.id.set(sg.cols.id.subarray(0, m)); bigger.field.set(sg.cols.field.subarray(0, m)); bigger.ts.set(sg.cols.ts.subarray(0, m)); bigger.val.set(sg.cols.val.subarray(0, m));
+      if (this._graph) this._graph.giveColumns(sg.cols);
+      sg.cols = bigger; sg.cap = bigger.n;
     }
     return sg;
   }
@@ -86,7 +90,12 @@ class PutQueue {
   closeBatch() { this._sealed = true; }               // the next batch's rows may name the same keys: they start a segment of their own
   /* rows of single host writes are waiting (they may be clock rows: a merge must see them); batch winners' value rows alone can wait for a reader */
   hasHostRows() { return this.hostRows > 0; }
-  take() { const out = this.segs.filter((sg) => sg.n > 0).map((sg) => sg.cols.slice(sg.n)); this.segs = []; this.n = 0; this.hostRows = 0; this._sealed = false; return out; }
+  take() {
+    const out = [];
+    for (const sg of this.segs) { if (sg.n > 0) out.push(sg.cols.slice(sg.n)); else if (this._graph) this._graph.giveColumns(sg.cols); }
+    this.segs = []; this.n = 0; this.hostRows = 0; this._sealed = false;
+    return out;
+  }
 }
 
 function verdict(winner, clock, value, reason, extra) {
@@ -308,8 +317,8 @@ class GpuCRT {
    * direct readers of the graph (getRows, scans, dumps) never see a table that lags the host's own writes */
   _putQueue() {
     if (!this._puts) {
-      this._puts = new PutQueue();
       const g = this._graph;
+      this._puts = new PutQueue(g);
       if (g && !g.preOp) g.preOp = () => this._flushDeviceWrites();
     }
     return this._puts;
@@ -326,7 +335,7 @@ class GpuCRT {
     const q = this._puts;
     if (!q || q.n === 0) return;
     const g = this.graph;
-    for (const cols of q.take()) g.putRows(cols);
+    for (const cols of q.take()) { g.putRows(cols); g.giveColumns(cols); }   // bmx_put_rows has returned: the columns are free again
   }
 
   /*
@@ -367,11 +376,16 @@ class GpuCRT {
       }
       if (k === 0) return false;
     }
-    if (this._hostOnly.size && this._hostOnly.has(e.path)) return false;
-    if (this._apiClocks.size && this._apiClocks.has(e.path)) {   // createVectorClock / getVectorClock / createUpdate were used on this path
-      const m = this.bullet.meta[e.path];
-      if (m && m.vectorClock) this._apiClocks.delete(e.path);
-      else if (scalarClock(this.vectorClocks.get(e.path), writer) !== 1) return false;   // the reference would store that clock + 1, not {writer: 2}
+    return this._pathEligible(e.path, writer);
+  }
+
+  /* the part of entryEligible that depends on what this peer holds for the path */
+  _pathEligible(path, writer) {
+    if (this._hostOnly.size && this._hostOnly.has(path)) return false;
+    if (this._apiClocks.size && this._apiClocks.has(path)) {     // createVectorClock / getVectorClock / createUpdate were used on this path
+      const m = this.bullet.meta[path];
+      if (m && m.vectorClock) this._apiClocks.delete(path);
+      else if (scalarClock(this.vectorClocks.get(path), writer) !== 1) return false;   // the reference would store that clock + 1, not {writer: 2}
     }
     return true;
   }
@@ -473,42 +487,129 @@ class GpuCRT {
     return total;
   }
 
-  /* entries -> one clock-row delta per eligible entry */
+  /*
+   * entries -> one clock-row delta per eligible entry (entryEligible's rules, checked here in one pass over the entry).
+   * When the store is not kept (no opts.apply) the value rows of EVERY eligible entry are prepared in the same pass — the entry is in cache
+   * now and is not when its chunk comes back from the GPU — as typed rows [rowStart[i], rowStart[i + 1]) of `vcols`; _finishEntries copies the
+   * winners' rows into the put queue without touching an entry again.
+   */
   _packEntries(entries, opts) {
     const writer = opts.writer || this.bullet.id;
     const g = this.graph;
     const keys = g.keys;
     const n = entries.length;
-    const cols = new Columns(Math.max(n, 1));
+    const cols = g.takeColumns(Math.max(n, 1));               // given back by _finishEntries
     const rowEntry = new Int32Array(Math.max(n, 1));
+    const emit = !opts.apply && opts.valueRows !== false;
+    let vcols = emit ? g.takeColumns(Math.max(2 * n, 64)) : null, vn = 0;
+    const rowStart = emit ? new Int32Array(n + 1) : null;
     const host = [];
+    const guarded = this._hostOnly.size > 0 || this._apiClocks.size > 0;
     let i = 0;
-    let lastParent = "";                                    // consecutive entries usually share their collection: reuse the sliced string
+    // consecutive entries usually share their collection: the parent is recognised by the position of the last "/" and the hash of the prefix
+    // (by-products of the id hash), its string is sliced and its field hashes looked up only when it changes
+    let parent = null, pCut = -2, pH1 = 0, pH2 = 0, clockField = 0, per = null;
     for (let ei = 0; ei < n; ei++) {
       const e = entries[ei];
-      if (!this.entryEligible(e, writer, false)) { host.push(ei); continue; }
-      const path = e.path, cut = path.lastIndexOf("/");
-      if (cut < 0) lastParent = "";
-      else if (!(cut === lastParent.length && path.startsWith(lastParent))) lastParent = path.slice(0, cut);
+      if (!e || e.deleted) { host.push(ei); continue; }
+      const ts = scalarClock(e.vectorClock, writer);
+      const d = e.data;
+      const prim = isDeviceInt(d);
+      if (ts < 0 || (!prim && !isMergeable(d)) || (guarded && !this._pathEligible(e.path, writer))) { host.push(ei); continue; }
+      const path = e.path;
       keys.lookup(path);
-      cols.set2(i, keys.lo, keys.hi, keys.fieldOf(lastParent, NODE_CLOCK), e.vectorClock[writer], this._nodeSeq++);
+      const lo = keys.lo, hi = keys.hi;
+      if (keys.cut !== pCut || keys.ph1 !== pH1 || keys.ph2 !== pH2) {
+        pCut = keys.cut; pH1 = keys.ph1; pH2 = keys.ph2;
+        parent = pCut < 0 ? "" : path.slice(0, pCut);
+        clockField = keys.fieldOf(parent, NODE_CLOCK);
+        per = keys._fieldCache.get(parent);
+      }
+      if (prim) {
+        if (emit) {
+          if (vn === vcols.n) vcols = this._growColumns(vcols, vn);
+          vcols.set2(vn++, lo, hi, keys.fieldOf(parent, null), ts, d);
+        }
+      } else {
+        let k = 0, ok = true;
+        const v0 = vn;
+        for (const f in d) {
+          if (f === "__vectorClock" || f === "__fromNetwork" || !Object.prototype.hasOwnProperty.call(d, f)) continue;
+          const v = d[f];
+          if (!isDeviceInt(v)) { ok = false; break; }
+          k++;
+          if (emit) {
+            let h = per.get(f);
+            if (h === undefined) h = keys.fieldOf(parent, f);
+            if (vn === vcols.n) vcols = this._growColumns(vcols, vn);
+            vcols.set2(vn++, lo, hi, h, ts, v);
+          }
+        }
+        if (!ok || k === 0) { vn = v0; host.push(ei); continue; }
+      }
+      if (emit) rowStart[i + 1] = vn;
+      cols.set2(i, lo, hi, clockField, ts, this._nodeSeq++);
       rowEntry[i++] = ei;
     }
     // one context: the winners that created their node are marked (stored clock = the insert rule's, no read-back); shards: read back
     const mergeOpts = g.comm ? opts : Object.assign({}, opts, { markCreated: true });
-    return { cols: cols.slice(i), rowEntry, host, writer, mergeOpts };
+    return { cols: cols.slice(i), rowEntry, host, writer, mergeOpts, vcols, rowStart };
+  }
+
+  _growColumns(cols, used) {
+    const g = this.graph, bigger = g.takeColumns(2 * cols.n);
+    bigger.id.set(cols.id.subarray(0, used)); bigger.field.set(cols.field.subarray(0, used)); bigger.ts.set(cols.ts.subarray(0, used)); bigger.val.set(cols.val.subarray(0, used));
+    g.giveColumns(cols);
+    return bigger;
   }
 
   _finishEntries(entries, p, r, opts) {
     const nw = r.applied.length;
     const appliedEntries = new Int32Array(nw);                 // winner k is entry appliedEntries[k] (ascending)
     for (let k = 0; k < nw; k++) appliedEntries[k] = p.rowEntry[r.applied[k] & 0xffffff];
-    const broadcast = this._applyWinners(entries, p.cols, r.applied, appliedEntries, opts.apply, opts.broadcast !== false, !this.graph.comm, opts.insertMode === "delta", p.writer, opts.valueRows !== false);
+    let broadcast = [];
+    if (p.vcols) this._queueWinnerRows(p, r.applied, !this.graph.comm, opts.insertMode === "delta");
+    else broadcast = this._applyWinners(entries, p.cols, r.applied, appliedEntries, opts.apply, opts.broadcast !== false, !this.graph.comm, opts.insertMode === "delta", p.writer, opts.valueRows !== false);
+    this.graph.giveColumns(p.cols);                           // the merge has returned and the winners' ids are copied
+    if (p.vcols) this.graph.giveColumns(p.vcols);
     if (opts.apply) this._notifyIndexHook(entries, p.host);
     const out = { appliedEntries, nApplied: r.nApplied, nConflicts: r.nConflicts, nRows: r.nRows, host: p.host, broadcast: opts.apply ? broadcast : undefined };
     let list = null;                                           // `applied` in the older shape, built only if somebody reads it (an object per winner is what the ingestion rate can do without)
     Object.defineProperty(out, "applied", { enumerable: true, get() { if (!list) { list = new Array(nw); for (let k = 0; k < nw; k++) list[k] = { entry: appliedEntries[k], field: null }; } return list; } });
     return out;
+  }
+
+  /* the prepared value rows of the winners -> one segment of the put queue, under the clock each node now stores: the entry's own, or — a winner that
+   * CREATED its node, reference insert rule — {writer: 2} (bit 31 of its index on one context; read back from the clock rows on a sharded graph).
+   * No tombstones: what a replaced node held is only known with the store (opts.apply keeps it). Typed copies only. */
+  _queueWinnerRows(p, appliedIdx, marked, deltaMode) {
+    const n = appliedIdx.length;
+    if (n === 0) return;
+    const rs = p.rowStart, v = p.vcols;
+    let total = 0;
+    for (let k = 0; k < n; k++) { const j = appliedIdx[k] & 0xffffff; total += rs[j + 1] - rs[j]; }
+    let ts32 = null;
+    if (!marked) {
+      const ids = new BigUint64Array(n), id32 = new Uint32Array(ids.buffer), fields = new Uint32Array(n), c = p.cols;
+      for (let k = 0; k < n; k++) { const j = appliedIdx[k] & 0xffffff; id32[2 * k] = c._id32[2 * j]; id32[2 * k + 1] = c._id32[2 * j + 1]; fields[k] = c.field[j]; }
+      const rows = this.graph.getRows(ids, fields);
+      ts32 = new Uint32Array(rows.ts.buffer, rows.ts.byteOffset, n * 2);
+    }
+    const q = this._putQueue();
+    const sg = q.uniqueSegment(total), o = sg.cols;
+    const oi = o._id32, ot = o._ts32, ov = o._val32, of = o.field, vi = v._id32, vt = v._ts32, vv = v._val32, vf = v.field;
+    let w = sg.n;
+    for (let k = 0; k < n; k++) {
+      const a = appliedIdx[k], j = a & 0xffffff, created = (a >>> 31) !== 0 && !deltaMode;
+      for (let x = rs[j], end = rs[j + 1]; x < end; x++, w++) {
+        oi[2 * w] = vi[2 * x]; oi[2 * w + 1] = vi[2 * x + 1]; of[w] = vf[x]; ov[2 * w] = vv[2 * x]; ov[2 * w + 1] = vv[2 * x + 1];
+        if (ts32) { ot[2 * w] = ts32[2 * k]; ot[2 * w + 1] = ts32[2 * k + 1]; }
+        else if (created) { ot[2 * w] = 2; ot[2 * w + 1] = 0; }
+        else { ot[2 * w] = vt[2 * x]; ot[2 * w + 1] = vt[2 * x + 1]; }
+      }
+    }
+    q.n += w - sg.n; sg.n = w;
+    q.closeBatch();
   }
 
   /*
@@ -555,38 +656,6 @@ class GpuCRT {
     const b = this.bullet;
     const q = this._putQueue();
     const updates = mode ? new Array(n) : null;
-    if (!mode && valueRows) {
-      // no store to keep: the winners' integer fields go straight into one pre-sized segment (no tombstones: what a replaced node held is only known
-      // with the store). An eligible entry's own fields are safe integers, the transport tags are not numbers.
-      const keys = this._graph.keys;
-      let sg = q.uniqueSegment(2 * n), lastParent = null, per = null;
-      for (let k = 0; k < n; k++) {
-        const e = entries[applied[k]];
-        const path = e.path, cut = path.lastIndexOf("/");
-        const ts = ts32 ? ts32[2 * k + 1] * 4294967296 + ts32[2 * k] : ((appliedIdx[k] >>> 31) && !deltaMode ? 2 : e.vectorClock[writer]);
-        if (!(cut === (lastParent === null ? -2 : lastParent.length) && path.startsWith(lastParent))) {
-          lastParent = cut < 0 ? "" : path.slice(0, cut);
-          per = keys._fieldCache.get(lastParent);
-          if (per === undefined) { keys.fieldOf(lastParent, null); per = keys._fieldCache.get(lastParent); }
-        }
-        const value = e.data, lo = id32[2 * k], hi = id32[2 * k + 1];
-        if (typeof value === "number") {
-          if (sg.n === sg.cap) sg = q.uniqueSegment(n);
-          sg.cols.set2(sg.n++, lo, hi, keys.fieldOf(lastParent, null), ts, value); q.n++;
-          continue;
-        }
-        for (const f in value) {
-          const v = value[f];
-          if (typeof v !== "number") continue;
-          let h = per.get(f);
-          if (h === undefined) h = keys.fieldOf(lastParent, f);
-          if (sg.n === sg.cap) sg = q.uniqueSegment(n);
-          sg.cols.set2(sg.n++, lo, hi, h, ts, v); q.n++;
-        }
-      }
-      q.closeBatch();
-      return [];
-    }
     for (let k = 0; k < n; k++) {
       const e = entries[applied[k]];
       const path = e.path, cut = path.lastIndexOf("/");

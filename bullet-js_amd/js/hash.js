@@ -56,6 +56,7 @@ class KeyDictionary {
     this._fieldCache = new Map();   // collection -> Map(field name -> hash)
     this.paths = [];           // index -> path
     this.lo = 0; this.hi = 0;
+    this.cut = -1; this.ph1 = 0; this.ph2 = 0;   // of the last lookup(): position of the path's last "/" and the 64-bit hash state of its parent prefix
     this._alloc(capacity);
   }
   get size() { return this.paths.length; }
@@ -82,9 +83,11 @@ class KeyDictionary {
    * the collision the device cannot represent, and are refused. */
   lookup(p) {
     let h1 = 0x811c9dc5, h2 = 0x9747b28c, h3 = 0x2f0b4a27;
+    let cut = -1, p1 = 0, p2 = 0;             // by-products for the callers that need the parent: index of the last "/", hash state of the prefix in front of it
     for (let i = 0; i < p.length; i++) {
       const c = p.charCodeAt(i);
       if (c < 0x80) {
+        if (c === 47) { cut = i; p1 = h1; p2 = h2; }
         h1 = Math.imul(h1 ^ c, 0x01000193); h2 = Math.imul(h2 ^ c, 0x01000193); h3 = Math.imul(h3 ^ c, 0x01000193);
       } else {
         const a = c & 0xff, b = c >>> 8;
@@ -97,7 +100,7 @@ class KeyDictionary {
     let hi = fmix32((h2 >>> 0) ^ lo);
     if (lo === 0xffffffff && hi === 0xffffffff) hi = 0xfffffffe;
     const chk = fmix32((h3 >>> 0) ^ p.length);
-    this.lo = lo; this.hi = hi;
+    this.lo = lo; this.hi = hi; this.cut = cut; this.ph1 = p1; this.ph2 = p2;
     const t = this._t, mask = this._mask;
     let s = (lo ^ Math.imul(hi, 0x9E3779B1)) & mask;
     for (;;) {
@@ -152,15 +155,16 @@ class KeyDictionary {
 
 /* typed-column builder: id as BigUint64Array written through a Uint32Array view */
 class Columns {
-  constructor(n) {
+  /* backing: {id, field, ts, val} typed arrays of n rows to build in (page-locked ones from the addon's hostColumns(n)); own arrays otherwise */
+  constructor(n, backing) {
     this.n = n;
-    this.id = new BigUint64Array(n);
-    this._id32 = new Uint32Array(this.id.buffer);
-    this.field = new Uint32Array(n);
-    this.ts = new BigInt64Array(n);
-    this.val = new BigInt64Array(n);
-    this._ts32 = new Uint32Array(this.ts.buffer);
-    this._val32 = new Uint32Array(this.val.buffer);
+    this.id = backing ? backing.id : new BigUint64Array(n);
+    this.field = backing ? backing.field : new Uint32Array(n);
+    this.ts = backing ? backing.ts : new BigInt64Array(n);
+    this.val = backing ? backing.val : new BigInt64Array(n);
+    this._id32 = new Uint32Array(this.id.buffer, this.id.byteOffset, 2 * n);
+    this._ts32 = new Uint32Array(this.ts.buffer, this.ts.byteOffset, 2 * n);
+    this._val32 = new Uint32Array(this.val.buffer, this.val.byteOffset, 2 * n);
   }
   /* ts and val are safe integers (|x| <= 2^53-1): written as two 32-bit halves, no BigInt allocated per element */
   set(i, idPair, field, ts, val) {
@@ -183,6 +187,7 @@ class Columns {
   slice(n) {
     if (n === this.n) return this;
     const c = Object.create(Columns.prototype);
+    c._root = this._root || this;                  // the allocation a pool takes back (DeviceGraph.giveColumns)
     c.n = n; c.id = this.id.subarray(0, n); c._id32 = this._id32.subarray(0, 2 * n);
     c.field = this.field.subarray(0, n); c.ts = this.ts.subarray(0, n); c.val = this.val.subarray(0, n);
     c._ts32 = this._ts32.subarray(0, 2 * n); c._val32 = this._val32.subarray(0, 2 * n);

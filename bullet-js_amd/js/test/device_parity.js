@@ -50,6 +50,41 @@ for (const name of fs.readdirSync(GOLD).filter((f) => f.startsWith("g2_stream_")
   checks += 4;
 }
 
+/* Page-locked column sets from the graph's pool (DeviceGraph.takeColumns -> the addon's hostColumns -> bmx_host_alloc): one allocation behind
+ * four typed arrays at byte offsets, reused after giveColumns; a G2 stream merged from them gives the reference's winners and state. */
+{
+  const name = "g2_stream_mixed_100k_10k.json";
+  const g = load(name);
+  const { resident, deltas, F } = gen.genStream(g.spec);
+  const crt = new GpuCRT({ id: "w", meta: {}, _getData() {} }, { capacityRows: 2 * (g.spec.R + g.spec.D) });
+  const graph = crt.graph;
+  const fill = (rows) => {
+    const cols = graph.takeColumns(rows.length);
+    rows.forEach((r, i) => { const id = gen.rowId(r.row, F); cols.set2(i, Number(id & 0xffffffffn), Number(id >> 32n), gen.rowField(r.row, F), r.ts, r.val); });
+    return cols;
+  };
+  const rc = fill(resident);
+  assert.ok(rc._pooled && rc.n >= resident.length && (rc.n & (rc.n - 1)) === 0, "pooled, power-of-two capacity");
+  if (graph._pinned) assert.ok(rc.id.buffer === rc.field.buffer && rc.ts.byteOffset === 8 * rc.n && rc.field.byteOffset === 24 * rc.n, "one page-locked allocation behind the four columns");
+  graph.loadRows(rc.slice(resident.length));
+  graph.giveColumns(rc.slice(resident.length));
+  assert.strictEqual(graph.takeColumns(resident.length), rc, "an idle column set is reused");
+  graph.giveColumns(rc);
+  graph.giveColumns(rc);                                     // a second give is ignored
+  const dc = fill(deltas);
+  assert.ok(dc !== rc && dc.id.buffer !== rc.id.buffer, "a set of its own for another size");
+  const r = crt.mergeBatch(dc.slice(deltas.length));
+  assert.deepStrictEqual(Array.from(r.applied), g.winners, name + " winners from page-locked columns");
+  assert.strictEqual(r.nRows, g.n_rows_final);
+  const d = graph.dumpRows();
+  let digest = 0n;
+  for (let i = 0; i < d.id.length; i++) digest = (digest + gen.rowDigest(d.id[i], d.field[i], d.ts[i], d.val[i])) & ((1n << 64n) - 1n);
+  assert.strictEqual(digest.toString(16), g.digest, name + " state digest");
+  assert.ok(graph.takeColumns(100)._pooled === undefined, "small sets are plain arrays");
+  crt.close();
+  checks += 8;
+}
+
 /* Sharded graph (bmx_comm_*): one handle owns N shards (logical shards on this box's one GPU). Winners in the caller's index
  * space, row count and state digest must equal the reference's, and so must the queries, which now run on every shard. */
 for (const shards of [2, 4, 8]) {

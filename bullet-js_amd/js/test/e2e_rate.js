@@ -45,6 +45,7 @@ let t0 = process.hrtime.bigint();
 for (const entries of batches) applied += crt.mergeEntries(entries).nApplied;
 const dtEntries = Number(process.hrtime.bigint() - t0) / 1e9;
 (async () => {
+await crt.mergeEntriesAsync(batches[0].slice(1000, 2000));      // the asynchronous path's first call (worker start-up, JIT)
 t0 = process.hrtime.bigint();
 const pr = await crt.mergeEntriesPipelined(batches2);
 applied += pr.nApplied;

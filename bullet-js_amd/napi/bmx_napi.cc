@@ -261,6 +261,29 @@ napi_value MergeBatchAsync(napi_env env, napi_callback_info info) {
   return promise;
 }
 
+// hostColumns(n) -> {id: BigUint64Array, field: Uint32Array, ts: BigInt64Array, val: BigInt64Array} of n rows over ONE page-locked allocation
+// (bmx_host_alloc): batches built in it upload at the link's rate, with no pinning of fresh pages by the runtime. Freed when the buffer is collected.
+void finalize_host_buffer(napi_env, void* data, void*) { (void)bmx_host_free(data); }
+napi_value HostColumns(napi_env env, napi_callback_info info) {
+  ARGS(1);
+  double dn;
+  if (napi_get_value_double(env, argv[0], &dn) != napi_ok || !(dn >= 1) || dn > 16777216) { napi_throw_range_error(env, nullptr, "bmx: hostColumns(n) wants 1 <= n <= 2^24"); return nullptr; }
+  const size_t n = (size_t)dn;
+  void* mem = nullptr;
+  int rc = bmx_host_alloc(28ull * n, &mem);
+  if (rc) return throw_bmx(env, nullptr, rc);
+  napi_value ab, out, id, field, ts, val;
+  if (napi_create_external_arraybuffer(env, mem, 28 * n, finalize_host_buffer, nullptr, &ab) != napi_ok) { (void)bmx_host_free(mem); napi_throw_error(env, nullptr, "bmx: external ArrayBuffer refused"); return nullptr; }
+  NAPI_OK(napi_create_typedarray(env, napi_biguint64_array, n, ab, 0, &id));
+  NAPI_OK(napi_create_typedarray(env, napi_bigint64_array, n, ab, 8 * n, &ts));
+  NAPI_OK(napi_create_typedarray(env, napi_bigint64_array, n, ab, 16 * n, &val));
+  NAPI_OK(napi_create_typedarray(env, napi_uint32_array, n, ab, 24 * n, &field));
+  NAPI_OK(napi_create_object(env, &out));
+  napi_set_named_property(env, out, "id", id); napi_set_named_property(env, out, "field", field);
+  napi_set_named_property(env, out, "ts", ts); napi_set_named_property(env, out, "val", val);
+  return out;
+}
+
 napi_value Reserve(napi_env env, napi_callback_info info) {
   ARGS(2);
   Handle* h; if (!get_handle(env, argv[0], &h)) return nullptr;
@@ -829,7 +852,7 @@ napi_value CommScanFilter(napi_env env, napi_callback_info info) {
 
 napi_value Init(napi_env env, napi_value exports) {
   struct { const char* name; napi_callback fn; } fns[] = {
-      {"abiVersion", AbiVersion}, {"create", Create}, {"destroy", Destroy}, {"mergeBatch", MergeBatch}, {"mergeBatchAsync", MergeBatchAsync}, {"reserve", Reserve}, {"loadRows", LoadRows}, {"putRows", PutRows}, {"scanRangePos", ScanRangePos}, {"indexIds", IndexIds}, {"commPutRows", CommPutRows},
+      {"abiVersion", AbiVersion}, {"create", Create}, {"destroy", Destroy}, {"mergeBatch", MergeBatch}, {"mergeBatchAsync", MergeBatchAsync}, {"reserve", Reserve}, {"loadRows", LoadRows}, {"putRows", PutRows}, {"hostColumns", HostColumns}, {"scanRangePos", ScanRangePos}, {"indexIds", IndexIds}, {"commPutRows", CommPutRows},
       {"getRows", GetRows}, {"rowCount", RowCount}, {"dumpRows", DumpRows}, {"indexBuild", IndexBuild}, {"indexDrop", IndexDrop},
       {"indexSize", IndexSize}, {"indexRefreshCounts", IndexRefreshCounts}, {"scanRange", ScanRange}, {"scanCount", ScanCount}, {"scanFilter", ScanFilter}, {"info", Info},
       {"vcCreate", VcCreate}, {"vcDestroy", VcDestroy}, {"vcLoadRows", VcLoadRows}, {"vcMergeBatch", VcMergeBatch}, {"vcGetRows", VcGetRows}, {"vcRowCount", VcRowCount}, {"vcScanRange", VcScanRange}, {"ownersOf", OwnersOf},

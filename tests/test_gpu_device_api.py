@@ -232,6 +232,45 @@ def test_pipelined_host_batches_submit_collect():
         assert np.array_equal(a2, w2)
 
 
+def test_page_locked_host_columns_are_free_again_when_submit_returns():
+    """bmx_host_alloc: ONE page-locked column set is refilled for every batch — right after bmx_merge_submit returns, while that batch is still
+    in flight (copies from such memory are asynchronous, the call waits for its upload) — and also feeds the synchronous call and bmx_put_rows;
+    winners and final rows equal the oracle's."""
+    R, D, NBATCH = 60_000, 40_000, 5            # above the small-batch limit: the staging path
+    res = synth.big_resident(R, seed=41)
+    bs = [synth.big_deltas(D, R, seed=42, insert_pct=10, hot_pct=20, hot_keys=64, unique=False, batch=b) for b in range(NBATCH)]
+    o = Oracle(); o.load_rows(*res)
+    want = [o.merge_batch(*b)[1] for b in bs]
+    hb, *pin = bmx.host_columns(D)
+    assert all(a.flags["C_CONTIGUOUS"] and len(a) == D for a in pin)
+
+    def fill(b):
+        for dst, src in zip(pin, bs[b]):
+            dst[:] = src
+
+    with bmx.Engine(4 * (R + NBATCH * D)) as e:
+        e.load_rows(*res)
+        fill(0)
+        t_prev = e.merge_submit(*pin)
+        for b in range(1, NBATCH - 1):
+            fill(b)                                           # overwrites what batch b-1 was uploaded from
+            t = e.merge_submit(*pin)
+            applied, _, _ = e.merge_collect(t_prev)
+            assert np.array_equal(applied, want[b - 1]), b
+            t_prev = t
+        for a in pin:
+            a[:] = 0                                          # and scribbled over while the last one is in flight
+        applied, _, _ = e.merge_collect(t_prev)
+        assert np.array_equal(applied, want[NBATCH - 2])
+        fill(NBATCH - 1)
+        applied, _, _ = e.merge_batch(*pin, want_flags=False)
+        assert np.array_equal(applied, want[NBATCH - 1])
+        assert rows_digest(*e.dump_rows()) == o.digest()
+    hb.close()
+    with pytest.raises(bmx.BmxError):
+        bmx.HostBuffer(0)
+
+
 @pytest.mark.parametrize("n", [1, 32767, 32768, 32769])
 def test_host_batches_on_both_sides_of_the_small_batch_limit(n):
     """Host batches of up to 32768 deltas go through mapped host memory, larger ones through the staging copies: same winners, flags, stats,
