@@ -34,6 +34,7 @@ EXPORTS = [
     "bmx_comm_merge_dev", "bmx_comm_shard_result", "bmx_comm_row_count", "bmx_comm_get_rows", "bmx_comm_dump_rows", "bmx_comm_index_build",
     "bmx_comm_scan_range", "bmx_comm_scan_equals", "bmx_comm_scan_count", "bmx_comm_scan_filter",
     "bmx_vc_create", "bmx_vc_destroy", "bmx_vc_last_error", "bmx_vc_load_rows", "bmx_vc_merge_batch", "bmx_vc_get_rows", "bmx_vc_row_count", "bmx_vc_scan_range", "bmx_vc_merge_batch_dev", "bmx_vc_set_stream", "bmx_vc_sync",
+    "bmx_vc_load_rows_ks", "bmx_vc_merge_batch_ks", "bmx_vc_get_rows_ks", "bmx_vc_merge_batch_ks_dev", "bmx_vc_keyset", "bmx_vc_keyset_dense",
 ]
 
 
@@ -161,6 +162,12 @@ def load_library():
     L.bmx_vc_row_count.argtypes = [vp, C.POINTER(u64)]; L.bmx_vc_row_count.restype = i32
     L.bmx_vc_scan_range.argtypes = [vp, u32, i64, i64, vp, u64, C.POINTER(u64)]; L.bmx_vc_scan_range.restype = i32
     L.bmx_vc_merge_batch_dev.argtypes = [vp, u64, vp, vp, vp, vp, vp, vp, vp]; L.bmx_vc_merge_batch_dev.restype = i32
+    L.bmx_vc_load_rows_ks.argtypes = [vp, u64, vp, vp, vp, vp, vp]; L.bmx_vc_load_rows_ks.restype = i32
+    L.bmx_vc_merge_batch_ks.argtypes = [vp, u64, vp, vp, vp, vp, vp, vp, vp, vp]; L.bmx_vc_merge_batch_ks.restype = i32
+    L.bmx_vc_get_rows_ks.argtypes = [vp, u64, vp, vp, vp, vp, vp, vp]; L.bmx_vc_get_rows_ks.restype = i32
+    L.bmx_vc_merge_batch_ks_dev.argtypes = [vp, u64, vp, vp, vp, vp, vp, vp, vp, vp]; L.bmx_vc_merge_batch_ks_dev.restype = i32
+    L.bmx_vc_keyset.argtypes = [vp, C.c_uint32]; L.bmx_vc_keyset.restype = C.c_uint32
+    L.bmx_vc_keyset_dense.argtypes = [C.c_uint32]; L.bmx_vc_keyset_dense.restype = C.c_uint32
     L.bmx_vc_set_stream.argtypes = [vp, vp]; L.bmx_vc_set_stream.restype = i32
     L.bmx_vc_sync.argtypes = [vp]; L.bmx_vc_sync.restype = i32
     _lib = L
@@ -659,24 +666,33 @@ class EngineVC:
             raise ValueError("column lengths differ")
         return id, field, clocks, val
 
-    def load_rows(self, id, field, clocks, val):
+    def load_rows(self, id, field, clocks, val, keysets=None):
+        """keysets (uint32[n], see keyset()): which writers each clock names and in which order; None = all K, in order."""
         id, field, clocks, val = self._cols(id, field, clocks, val)
-        self._chk(self.L.bmx_vc_load_rows(self.h, len(id), _ptr(id), _ptr(field), _ptr(clocks), _ptr(val)))
+        ks = None if keysets is None else _np(keysets, np.uint32)
+        self._chk(self.L.bmx_vc_load_rows_ks(self.h, len(id), _ptr(id), _ptr(field), _ptr(clocks), _ptr(ks), _ptr(val)))
 
-    def merge_batch(self, id, field, clocks, val):
+    def merge_batch(self, id, field, clocks, val, keysets=None):
         """-> (flags uint8[n], updated uint32[]): per-delta resolve() flags; for each touched row that changed, the index of the
         last delta that updated it, ascending."""
         id, field, clocks, val = self._cols(id, field, clocks, val)
         n = len(id)
+        ks = None if keysets is None else _np(keysets, np.uint32)
+        if ks is not None and len(ks) != n:
+            raise ValueError("column lengths differ")
         flags = np.zeros(n, np.uint8); upd = np.zeros(max(n, 1), np.uint32); nu = C.c_uint64()
-        self._chk(self.L.bmx_vc_merge_batch(self.h, n, _ptr(id), _ptr(field), _ptr(clocks), _ptr(val), _ptr(upd), C.byref(nu), _ptr(flags)))
+        self._chk(self.L.bmx_vc_merge_batch_ks(self.h, n, _ptr(id), _ptr(field), _ptr(clocks), _ptr(ks), _ptr(val), _ptr(upd), C.byref(nu), _ptr(flags)))
         return flags, upd[: nu.value].copy()
 
-    def get_rows(self, id, field):
-        """-> (clocks (n,K) uint32, val int64[n], state uint8[n]) with state VC_ABSENT / VC_DENSE / VC_SPARSE."""
+    def get_rows(self, id, field, with_keysets=False):
+        """-> (clocks (n,K) uint32, val int64[n], state uint8[n]) with state VC_ABSENT / VC_DENSE / VC_SPARSE; with_keysets: + keysets uint32[n]."""
         id = _np(id, np.uint64); field = _np(field, np.uint32)
         n = len(id)
         clocks = np.zeros((n, self.K), np.uint32); val = np.zeros(n, np.int64); st = np.zeros(n, np.uint8)
+        if with_keysets:
+            ks = np.zeros(n, np.uint32)
+            self._chk(self.L.bmx_vc_get_rows_ks(self.h, n, _ptr(id), _ptr(field), _ptr(clocks), _ptr(ks), _ptr(val), _ptr(st)))
+            return clocks, val, st, ks
         self._chk(self.L.bmx_vc_get_rows(self.h, n, _ptr(id), _ptr(field), _ptr(clocks), _ptr(val), _ptr(st)))
         return clocks, val, st
 
@@ -697,14 +713,36 @@ class EngineVC:
         return out[:min(m.value, cap)].copy()
 
     # device-pointer form: torch tensors / raw pointers, enqueue-only
-    def merge_batch_dev(self, n, id, field, clocks, val, updated=None, n_updated=None, flags=None):
-        self._chk(self.L.bmx_vc_merge_batch_dev(self.h, int(n), _ptr(id), _ptr(field), _ptr(clocks), _ptr(val), _ptr(updated), _ptr(n_updated), _ptr(flags)))
+    def merge_batch_dev(self, n, id, field, clocks, val, updated=None, n_updated=None, flags=None, keysets=None):
+        self._chk(self.L.bmx_vc_merge_batch_ks_dev(self.h, int(n), _ptr(id), _ptr(field), _ptr(clocks), _ptr(keysets), _ptr(val), _ptr(updated), _ptr(n_updated), _ptr(flags)))
 
     def set_stream(self, stream_ptr):
         self._chk(self.L.bmx_vc_set_stream(self.h, C.c_void_p(stream_ptr) if stream_ptr else None))
 
     def sync(self):
         self._chk(self.L.bmx_vc_sync(self.h))
+
+
+KEYSET_NONE = 0xFFFFFFFF
+
+
+def keyset(writers):
+    """Key-set word of a clock whose keys are the writers with these indices, in this order (include/bmx.h bmx_vc_keyset)."""
+    ks = KEYSET_NONE
+    for i, w in enumerate(writers):
+        ks = (ks & ~(0xF << (4 * i))) | ((int(w) & 0xF) << (4 * i))
+    return ks & 0xFFFFFFFF
+
+
+def keyset_writers(ks):
+    """inverse of keyset(): the writer indices a key-set word names, in order"""
+    out = []
+    for i in range(8):
+        w = (int(ks) >> (4 * i)) & 0xF
+        if w == 0xF:
+            break
+        out.append(w)
+    return out
 
 
 def owner_of(ids, nshards):

@@ -1,5 +1,8 @@
 // vc_kernels.h — N4: K-writer vector-clock rows, gfx950. 64-byte slots:
-//   { id u64 | field u32 | head u32 | val i64 | state u32 | pad u32 | clock u32[8] }
+//   { id u64 | field u32 | head u32 | val i64 | state u32 | keyset u32 | clock u32[8] }
+// keyset = WHICH of the K writers the clock object names and in which order (eight 4-bit writer indices, 0xF = end): the reference's clocks are JS
+// objects, a missing key counts as 0 when clocks are compared (src/bullet-crt.js:76-79) but two clocks are "identical" only if their JSON texts are
+// (:200-203) — same keys, same order —, and a merged clock lists the incoming clock's keys first, then the stored clock's other keys (:103-114).
 // Two launches per batch, no optimistic writes (the outcome for concurrent clocks depends on the order of the deltas):
 //   k_vc_link    every delta finds/creates its row, claims it (one atomicExch) and links into the row's list
 //   k_vc_resolve the LAST claimer of a row applies the row's deltas in index order with the reference's resolve()
@@ -24,12 +27,47 @@ constexpr uint32_t VC_SHORT = 16;        // lists up to this length are ordered 
 constexpr uint32_t VC_LONG_WGS = 64;     // workgroups of k_vc_resolve_long (each owns one bitmap over the batch)
 constexpr uint32_t VC_QUEUED = 0xFFFFFFFEu;
 
+constexpr uint32_t VC_KS_NONE = 0xFFFFFFFFu;     // the clock {}
+__host__ __device__ __forceinline__ uint32_t vc_ks_dense(uint32_t K) {      // all K writers, in the table's order
+  uint32_t ks = VC_KS_NONE;
+  for (uint32_t k = 0; k < K; k++) ks = (ks & ~(0xFu << (4 * k))) | (k << (4 * k));
+  return ks;
+}
+__host__ __device__ __forceinline__ uint32_t vc_ks_single(uint32_t w) { return 0xFFFFFFF0u | w; }
+// key order of mergeVectorClocks(in, cur) = {...in} followed by cur's keys that `in` does not have (src/bullet-crt.js:103-114)
+__device__ __forceinline__ uint32_t vc_ks_merge(uint32_t in, uint32_t cur) {
+  uint32_t have = 0, len = 0;
+#pragma unroll
+  for (int i = 0; i < VC_MAXK; i++) { const uint32_t w = (in >> (4 * i)) & 0xFu; if (w != 0xFu) { have |= 1u << w; len = (uint32_t)i + 1; } }
+  uint32_t out = in;
+#pragma unroll
+  for (int i = 0; i < VC_MAXK; i++) {
+    const uint32_t w = (cur >> (4 * i)) & 0xFu;
+    if (w != 0xFu && !((have >> w) & 1u) && len < (uint32_t)VC_MAXK) { out = (out & ~(0xFu << (4 * len))) | (w << (4 * len)); have |= 1u << w; len++; }
+  }
+  return out;
+}
+// a well-formed key set: writer indices < K, each at most once, nothing behind the first 0xF; components of writers it does not name are zero
+__device__ __forceinline__ bool vc_ks_valid(uint32_t ks, const uint32_t* comps, uint32_t K) {
+  uint32_t have = 0; bool ended = false, ok = true;
+#pragma unroll
+  for (int i = 0; i < VC_MAXK; i++) {
+    const uint32_t w = (ks >> (4 * i)) & 0xFu;
+    if (w == 0xFu) { ended = true; continue; }
+    if (ended || w >= K || ((have >> w) & 1u)) ok = false;
+    have |= 1u << (w & 7u);
+  }
+#pragma unroll
+  for (int k = 0; k < VC_MAXK; k++) if ((uint32_t)k < K && !((have >> k) & 1u) && comps[k] != 0u) ok = false;
+  return ok;
+}
+
 struct VcLongRow { uint32_t slot, head, m, base; };
 struct VcLongCtl { uint32_t n_rows, cursor; };
 
 struct alignas(64) VSlot {
   uint64_t id; uint32_t field; uint32_t head;
-  int64_t val; uint32_t state; uint32_t pad;
+  int64_t val; uint32_t state; uint32_t keyset;
   uint32_t clock[VC_MAXK];
 };
 static_assert(sizeof(VSlot) == 64, "vc slot is 64 bytes");
@@ -37,6 +75,7 @@ static_assert(sizeof(VSlot) == 64, "vc slot is 64 bytes");
 struct VcArgs {
   VSlot* slots; uint64_t nslots;
   const uint64_t* id; const uint32_t* field; const uint32_t* clocks; const int64_t* val;
+  const uint32_t* keysets;   // per delta, or null: every clock names all K writers in the table's order
   uint32_t n, K, local, epoch;
   uint32_t* next; uint32_t* slot_of; uint8_t* wflag; uint8_t* flags; uint32_t* blk_info;
   unsigned long long* row_count; uint32_t* status;
@@ -50,7 +89,7 @@ __global__ __launch_bounds__(256) void k_vc_init(VSlot* slots, uint64_t nslots) 
   for (uint64_t s = (uint64_t)blockIdx.x * 256u + threadIdx.x; s < nslots; s += (uint64_t)gridDim.x * 256u) {
     uint4* q = reinterpret_cast<uint4*>(slots + s);
     q[0] = make_uint4(0xFFFFFFFFu, 0xFFFFFFFFu, FIELD_PENDING, 0u);
-    q[1] = make_uint4(0u, 0u, VC_ABSENT, 0u);
+    q[1] = make_uint4(0u, 0u, VC_ABSENT, VC_KS_NONE);
     q[2] = make_uint4(0u, 0u, 0u, 0u); q[3] = make_uint4(0u, 0u, 0u, 0u);
   }
 }
@@ -92,6 +131,12 @@ __global__ __launch_bounds__(256) void k_vc_link(VcArgs A) {
   if (active) {
     const uint64_t id = A.id[j]; const uint32_t field = A.field[j]; const int64_t v = A.val[j];
     bool valid = id != EMPTY_ID && field != FIELD_PENDING && v >= -VAL_MAX && v <= VAL_MAX;
+    if (valid && A.keysets) {
+      uint32_t in[VC_MAXK];
+#pragma unroll
+      for (int k = 0; k < VC_MAXK; k++) in[k] = ((uint32_t)k < A.K) ? A.clocks[(size_t)j * A.K + k] : 0u;
+      valid = vc_ks_valid(A.keysets[j], in, A.K);
+    }
     if (!valid) atomicOr(A.status, ST_RANGE);
     if (valid) {
       const uint32_t tag = (A.epoch << IDX_BITS) | j;
@@ -167,22 +212,22 @@ __global__ __launch_bounds__(256) void k_vc_link(VcArgs A) {
 }
 
 // resolve() for one delta against the running row state held in registers (static indices only)
-struct VcState { uint32_t c[VC_MAXK]; int64_t val; uint32_t state; };
-__device__ __forceinline__ uint32_t vc_apply(VcState& R, const uint32_t* in, int64_t v, uint32_t K, uint32_t local) {
+struct VcState { uint32_t c[VC_MAXK]; int64_t val; uint32_t state; uint32_t ks; };
+__device__ __forceinline__ uint32_t vc_apply(VcState& R, const uint32_t* in, uint32_t in_ks, int64_t v, uint32_t K, uint32_t local) {
   if (R.state == VC_ABSENT) {                    // "no current state": clock {local: 2}, incoming clock dropped (:172-185)
 #pragma unroll
     for (int k = 0; k < VC_MAXK; k++) R.c[k] = ((uint32_t)k == local) ? 2u : 0u;
-    R.val = v; R.state = VC_SPARSE;
+    R.val = v; R.state = VC_SPARSE; R.ks = vc_ks_single(local);
     return BMX_FLAG_INCOMING;
   }
   bool in_ahead = false, cur_ahead = false, equal = true;
 #pragma unroll
-  for (int k = 0; k < VC_MAXK; k++) if ((uint32_t)k < K) {
+  for (int k = 0; k < VC_MAXK; k++) if ((uint32_t)k < K) {     // a writer a clock does not name holds 0 there: "|| 0" of :76-79
     if (in[k] > R.c[k]) in_ahead = true; else if (R.c[k] > in[k]) cur_ahead = true;
     if (in[k] != R.c[k]) equal = false;
   }
   const int cmp = (in_ahead && cur_ahead) ? 0 : (in_ahead ? 1 : (cur_ahead ? -1 : 0));
-  const bool json_equal = equal && (R.state != VC_SPARSE || K == 1);
+  const bool json_equal = equal && in_ks == R.ks;            // JSON.stringify equality (:200-203): same keys in the same order, same counters
   if (cmp == 0 && json_equal) {                  // identical clocks: value comparison (:200-233)
     if (v == R.val) return 0u;
     if (v > R.val) { R.val = v; return BMX_FLAG_INCOMING; }
@@ -191,6 +236,7 @@ __device__ __forceinline__ uint32_t vc_apply(VcState& R, const uint32_t* in, int
   if (cmp < 0) return BMX_FLAG_CURRENT | BMX_FLAG_HISTORICAL;    // :251-263
 #pragma unroll
   for (int k = 0; k < VC_MAXK; k++) if ((uint32_t)k < K && in[k] > R.c[k]) R.c[k] = in[k];   // merged clock stored with the update
+  R.ks = vc_ks_merge(in_ks, R.ks);
   R.state = VC_DENSE;
   if (cmp > 0) { R.val = v; return BMX_FLAG_INCOMING; }          // :236-248
   if (v >= R.val) R.val = v;                                      // concurrent: mergeValues on non-objects (:266-278, :133-135)
@@ -203,9 +249,10 @@ __device__ __forceinline__ uint32_t vc_resolve_row(const VcArgs& A, VSlot* sl, u
   VcState R;
   {
     const uint4 mid = q[1], c0 = q[2], c1 = q[3];
-    R.val = (int64_t)((uint64_t)mid.x | ((uint64_t)mid.y << 32)); R.state = mid.z;
+    R.val = (int64_t)((uint64_t)mid.x | ((uint64_t)mid.y << 32)); R.state = mid.z; R.ks = mid.w;
     R.c[0] = c0.x; R.c[1] = c0.y; R.c[2] = c0.z; R.c[3] = c0.w; R.c[4] = c1.x; R.c[5] = c1.y; R.c[6] = c1.z; R.c[7] = c1.w;
   }
+  const uint32_t dense_ks = vc_ks_dense(A.K);
   uint32_t last_upd = ~0u;
   if (A.load) {
     // bulk preload: the highest-index delta of the key overwrites the row (dense)
@@ -213,7 +260,7 @@ __device__ __forceinline__ uint32_t vc_resolve_row(const VcArgs& A, VSlot* sl, u
     for (;;) { if (idx > best) best = idx; uint32_t nx = A.next[idx]; if ((nx >> IDX_BITS) != A.epoch) break; idx = nx & IDX_MASK; if (++steps > A.n) break; }
 #pragma unroll
     for (int k = 0; k < VC_MAXK; k++) R.c[k] = ((uint32_t)k < A.K) ? A.clocks[(size_t)best * A.K + k] : 0u;
-    R.val = A.val[best]; R.state = VC_DENSE; last_upd = best;
+    R.val = A.val[best]; R.state = VC_DENSE; R.ks = A.keysets ? A.keysets[best] : dense_ks; last_upd = best;
   } else {
     // how long is the list? (one walk)
     uint32_t m = 1;
@@ -242,7 +289,7 @@ __device__ __forceinline__ uint32_t vc_resolve_row(const VcArgs& A, VSlot* sl, u
       uint32_t in[VC_MAXK];
 #pragma unroll
       for (int k = 0; k < VC_MAXK; k++) in[k] = ((uint32_t)k < A.K) ? A.clocks[(size_t)pick * A.K + k] : 0u;
-      const uint32_t fl = vc_apply(R, in, A.val[pick], A.K, A.local);
+      const uint32_t fl = vc_apply(R, in, A.keysets ? A.keysets[pick] : dense_ks, A.val[pick], A.K, A.local);
       if (A.flags) A.flags[pick] = (uint8_t)fl;
       if (fl & (BMX_FLAG_INCOMING | BMX_FLAG_CONCURRENT)) last_upd = pick;
       prev_idx = pick; first_round = false;
@@ -251,7 +298,7 @@ __device__ __forceinline__ uint32_t vc_resolve_row(const VcArgs& A, VSlot* sl, u
   }
   // one writer per row, after all reads of this launch pair
   uint4* w = reinterpret_cast<uint4*>(sl);
-  w[1] = make_uint4((uint32_t)(uint64_t)R.val, (uint32_t)((uint64_t)R.val >> 32), R.state, 0u);
+  w[1] = make_uint4((uint32_t)(uint64_t)R.val, (uint32_t)((uint64_t)R.val >> 32), R.state, R.ks);
   w[2] = make_uint4(R.c[0], R.c[1], R.c[2], R.c[3]);
   w[3] = make_uint4(R.c[4], R.c[5], R.c[6], R.c[7]);
   return last_upd;
@@ -284,6 +331,7 @@ __global__ __launch_bounds__(256) void k_vc_resolve_long(VcArgs A) {
   __shared__ int64_t s_val[256];
   __shared__ uint32_t s_idx[256];
   __shared__ uint8_t s_fl[256];
+  __shared__ uint32_t s_ks[256];
   __shared__ uint32_t wsum[4];
   const uint32_t nrows = min(A.lctl->n_rows, A.lrows_cap);
   uint32_t* bm = A.bitmap + (size_t)blockIdx.x * A.bitmap_words;
@@ -320,14 +368,14 @@ __global__ __launch_bounds__(256) void k_vc_resolve_long(VcArgs A) {
     if (threadIdx.x == 0) {
       const uint4* q = reinterpret_cast<const uint4*>(sl);
       const uint4 mid = q[1], c0 = q[2], c1 = q[3];
-      R.val = (int64_t)((uint64_t)mid.x | ((uint64_t)mid.y << 32)); R.state = mid.z;
+      R.val = (int64_t)((uint64_t)mid.x | ((uint64_t)mid.y << 32)); R.state = mid.z; R.ks = mid.w;
       R.c[0] = c0.x; R.c[1] = c0.y; R.c[2] = c0.z; R.c[3] = c0.w; R.c[4] = c1.x; R.c[5] = c1.y; R.c[6] = c1.z; R.c[7] = c1.w;
     }
     for (uint32_t c0 = 0; c0 < tot; c0 += 256) {
       const uint32_t i = c0 + threadIdx.x;
       if (i < tot) {
         const uint32_t idx = __builtin_nontemporal_load(&ord[i]);
-        s_idx[threadIdx.x] = idx; s_val[threadIdx.x] = A.val[idx];
+        s_idx[threadIdx.x] = idx; s_val[threadIdx.x] = A.val[idx]; s_ks[threadIdx.x] = A.keysets ? A.keysets[idx] : vc_ks_dense(A.K);
 #pragma unroll
         for (int k = 0; k < VC_MAXK; k++) s_clk[threadIdx.x][k] = ((uint32_t)k < A.K) ? A.clocks[(size_t)idx * A.K + k] : 0u;
       }
@@ -338,7 +386,7 @@ __global__ __launch_bounds__(256) void k_vc_resolve_long(VcArgs A) {
           uint32_t in[VC_MAXK];
 #pragma unroll
           for (int k = 0; k < VC_MAXK; k++) in[k] = s_clk[x][k];
-          const uint32_t fl = vc_apply(R, in, s_val[x], A.K, A.local);
+          const uint32_t fl = vc_apply(R, in, s_ks[x], s_val[x], A.K, A.local);
           s_fl[x] = (uint8_t)fl;
           if (fl & (BMX_FLAG_INCOMING | BMX_FLAG_CONCURRENT)) last_upd = s_idx[x];
         }
@@ -349,7 +397,7 @@ __global__ __launch_bounds__(256) void k_vc_resolve_long(VcArgs A) {
     }
     if (threadIdx.x == 0) {
       uint4* w = reinterpret_cast<uint4*>(sl);
-      w[1] = make_uint4((uint32_t)(uint64_t)R.val, (uint32_t)((uint64_t)R.val >> 32), R.state, 0u);
+      w[1] = make_uint4((uint32_t)(uint64_t)R.val, (uint32_t)((uint64_t)R.val >> 32), R.state, R.ks);
       w[2] = make_uint4(R.c[0], R.c[1], R.c[2], R.c[3]);
       w[3] = make_uint4(R.c[4], R.c[5], R.c[6], R.c[7]);
       if (last_upd != ~0u) { A.wflag[last_upd] = W_WINNER; atomicAdd(&A.blk_info[last_upd >> 8], 1u); }
@@ -359,12 +407,12 @@ __global__ __launch_bounds__(256) void k_vc_resolve_long(VcArgs A) {
 }
 
 __global__ __launch_bounds__(256) void k_vc_get(const VSlot* slots, uint64_t nslots, uint32_t n, uint32_t K, const uint64_t* id, const uint32_t* field,
-                                                uint32_t* clocks, int64_t* val, uint8_t* state) {
+                                                uint32_t* clocks, int64_t* val, uint8_t* state, uint32_t* keysets) {
   uint32_t j = blockIdx.x * 256u + threadIdx.x;
   if (j >= n) return;
   const uint64_t kid = id[j]; const uint32_t kf = field[j];
   ProbeSeq<2> ps(kid, kf, nslots);
-  uint8_t st = VC_ABSENT; int64_t v = 0; uint32_t c[VC_MAXK] = {0, 0, 0, 0, 0, 0, 0, 0};
+  uint8_t st = VC_ABSENT; int64_t v = 0; uint32_t ks = VC_KS_NONE; uint32_t c[VC_MAXK] = {0, 0, 0, 0, 0, 0, 0, 0};
   for (uint64_t p = 0; p < nslots; ++p) {
     const uint4* q = reinterpret_cast<const uint4*>(slots + ps.slot());
     uint4 lo = q[0];
@@ -372,13 +420,14 @@ __global__ __launch_bounds__(256) void k_vc_get(const VSlot* slots, uint64_t nsl
     if (sid == EMPTY_ID) break;
     if (sid == kid && lo.z == kf) {
       uint4 mid = q[1], c0 = q[2], c1 = q[3];
-      v = (int64_t)((uint64_t)mid.x | ((uint64_t)mid.y << 32)); st = (uint8_t)mid.z;
+      v = (int64_t)((uint64_t)mid.x | ((uint64_t)mid.y << 32)); st = (uint8_t)mid.z; ks = mid.w;
       c[0] = c0.x; c[1] = c0.y; c[2] = c0.z; c[3] = c0.w; c[4] = c1.x; c[5] = c1.y; c[6] = c1.z; c[7] = c1.w;
       break;
     }
     ps.next();
   }
   val[j] = v; state[j] = st;
+  if (keysets) keysets[j] = ks;
 #pragma unroll
   for (int k = 0; k < VC_MAXK; k++) if ((uint32_t)k < K) clocks[(size_t)j * K + k] = c[k];
 }

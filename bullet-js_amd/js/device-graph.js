@@ -100,9 +100,17 @@ class DeviceVcTable {
       err.code = "BMX_BAD_WRITERS";
       throw err;
     }
+    if (writers.some((w) => typeof w !== "string" || /^(0|[1-9][0-9]*)$/.test(w)) || new Set(writers).size !== writers.length) {
+      // an integer-like key is moved to the front of a JS object whatever the insertion order: the key ORDER of the reference's merged clocks
+      // (part of their identity: src/bullet-crt.js:200-203) would not be the insertion order the device tracks
+      const err = new Error("bmx: vector-clock mode needs distinct, non-numeric string writer ids");
+      err.code = "BMX_BAD_WRITERS";
+      throw err;
+    }
     this.writers = writers.slice();
     this.K = writers.length;
     this.local = writers.indexOf(local);
+    this.writerIndex = new Map(writers.map((w, k) => [w, k]));
     const devs = Array.isArray(opts.devices) && opts.devices.length ? opts.devices.slice() : new Array(Math.max(1, opts.shards | 0)).fill(opts.device || 0);
     const cap = opts.vcCapacityRows || opts.capacityRows || (1 << 16);
     this.handles = devs.map((d) => this.native.vcCreate(d, Math.max(1024, Math.ceil(cap / devs.length)), this.K, this.local));
@@ -123,48 +131,49 @@ class DeviceVcTable {
   _sub(c, idx) {
     const m = idx.length, K = this.K;
     const id = new BigUint64Array(m), field = new Uint32Array(m), clocks = new Uint32Array(m * K), val = new BigInt64Array(m);
+    const keysets = c.keysets ? new Uint32Array(m) : undefined;
     for (let x = 0; x < m; x++) {
       const j = idx[x];
       id[x] = c.id[j]; field[x] = c.field[j]; val[x] = c.val[j];
+      if (keysets) keysets[x] = c.keysets[j];
       for (let k = 0; k < K; k++) clocks[x * K + k] = c.clocks[j * K + k];
     }
-    return { id, field, clocks, val };
+    return { id, field, clocks, val, keysets };
   }
+  /* c.keysets (optional Uint32Array): which writers each clock names and in which order; without it every clock names all K, in order */
   loadRows(c) {
-    if (this.N === 1) { this.native.vcLoadRows(this.handle, c.id, c.field, c.clocks, c.val); return; }
+    if (this.N === 1) { this.native.vcLoadRows(this.handle, c.id, c.field, c.clocks, c.val, c.keysets); return; }
     const back = this._split(c.id);
-    for (let g = 0; g < this.N; g++) if (back[g].length) { const s = this._sub(c, back[g]); this.native.vcLoadRows(this.handles[g], s.id, s.field, s.clocks, s.val); }
+    for (let g = 0; g < this.N; g++) if (back[g].length) { const s = this._sub(c, back[g]); this.native.vcLoadRows(this.handles[g], s.id, s.field, s.clocks, s.val, s.keysets); }
   }
   mergeBatch(c) {
-    if (this.N === 1) return this.native.vcMergeBatch(this.handle, c.id, c.field, c.clocks, c.val);
+    if (this.N === 1) return this.native.vcMergeBatch(this.handle, c.id, c.field, c.clocks, c.val, c.keysets);
     const n = c.id.length, back = this._split(c.id);
     const flags = new Uint8Array(n), upd = [];
     let nRows = 0;
     for (let g = 0; g < this.N; g++) {
       if (!back[g].length) { nRows += this.native.vcRowCount(this.handles[g]); continue; }
       const s = this._sub(c, back[g]);
-      const r = this.native.vcMergeBatch(this.handles[g], s.id, s.field, s.clocks, s.val);
+      const r = this.native.vcMergeBatch(this.handles[g], s.id, s.field, s.clocks, s.val, s.keysets);
       for (let x = 0; x < r.flags.length; x++) flags[back[g][x]] = r.flags[x];
       for (let x = 0; x < r.updated.length; x++) upd.push(back[g][r.updated[x]]);
       nRows += r.nRows;
     }
     return { updated: Uint32Array.from(upd).sort(), flags, nRows };
   }
-  /* rows decided on the host, stored as given (bmx_put_rows); val === VAL_DELETED leaves a tombstone. Keys unique within one call. */
-  putRows(cols) { return this.comm ? this.native.commPutRows(this.comm, cols.id, cols.field, cols.ts, cols.val) : this.native.putRows(this.handle, cols.id, cols.field, cols.ts, cols.val); }
   getRows(id, field) {
     if (this.N === 1) return this.native.vcGetRows(this.handle, id, field);
     const n = id.length, K = this.K, back = this._split(id);
-    const clocks = new Uint32Array(n * K), val = new BigInt64Array(n), state = new Uint8Array(n);
+    const clocks = new Uint32Array(n * K), val = new BigInt64Array(n), state = new Uint8Array(n), keysets = new Uint32Array(n);
     for (let g = 0; g < this.N; g++) {
       const idx = back[g], m = idx.length;
       if (!m) continue;
       const gi = new BigUint64Array(m), gf = new Uint32Array(m);
       for (let x = 0; x < m; x++) { gi[x] = id[idx[x]]; gf[x] = field[idx[x]]; }
       const r = this.native.vcGetRows(this.handles[g], gi, gf);
-      for (let x = 0; x < m; x++) { const j = idx[x]; val[j] = r.val[x]; state[j] = r.state[x]; for (let k = 0; k < K; k++) clocks[j * K + k] = r.clocks[x * K + k]; }
+      for (let x = 0; x < m; x++) { const j = idx[x]; val[j] = r.val[x]; state[j] = r.state[x]; keysets[j] = r.keysets[x]; for (let k = 0; k < K; k++) clocks[j * K + k] = r.clocks[x * K + k]; }
     }
-    return { clocks, val, state };
+    return { clocks, val, state, keysets };
   }
   rowCount() { let t = 0; for (const h of this.handles) t += this.native.vcRowCount(h); return t; }
   /* node ids (BigUint64Array) of the rows of `field` with lo <= value <= hi: range()/equals() over the K-writer rows (every table scans its own) */

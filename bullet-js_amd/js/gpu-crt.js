@@ -14,7 +14,7 @@
  *   - batches (sync chunks, bulk loads: src/bullet-network-sync.js:551-569) go to the MI355X through
  *     mergeBatch()/mergeEntries(): typed columns -> bmx_merge_batch. That path has no host implementation.
  */
-const { Columns, VcColumns, fieldId, isDeviceInt, scalarClock, denseClock, NODE_CLOCK, VAL_DELETED } = require("./hash");
+const { Columns, VcColumns, fieldId, isDeviceInt, scalarClock, clockKeyset, keysetWriters, NODE_CLOCK, VAL_DELETED } = require("./hash");
 
 const REASON = {
   fresh: "no current state",
@@ -111,8 +111,8 @@ class GpuCRT {
   /**
    * @param {object} bullet  the Bullet instance (needs .id, .meta, ._getData)
    * @param {object} [opts]  { graph: DeviceGraph (shared with GpuQuery), device, capacityRows, writer,
-   *                           writers: [ids] — N4: batch rows carry a vector clock over exactly these (<= 8) writers,
-   *                           this peer's id among them, and mergeEntries() uses the device's vector-clock table }
+   *                           writers: [ids] — N4: clocks may name any of these (<= 8) writers, this peer's id among them, in any order
+   *                           (general vector clocks): the nodes' clocks live in the device's vector-clock table }
    */
   constructor(bullet, opts = {}) {
     this.bullet = bullet;
@@ -124,6 +124,7 @@ class GpuCRT {
     this._hostOnly = new Set();     // paths whose clock the device cannot hold (more than one writer, foreign key sets): their entries stay on the host
     this._nodeSeq = 1;              // arrival number of node writes (val of the clock rows): a tie on the clock goes to the later write
     this._puts = null;              // PutQueue: rows the host decided, not yet on the device
+    this._vcPuts = [];              // writers mode: clock rows of host writes for the vector-clock table [path, parent, keyset, counters...], not yet on the device
   }
 
   /* ---------------------------------------------------------------- clock bookkeeping (host) */
@@ -247,6 +248,9 @@ class GpuCRT {
     }
     const doUpdate = d.incoming || !currentClock || d.concurrent;
     if (doUpdate) this._mirrorWrite(path, currentData, d.value, d.vectorClock);
+    // a local write that is REFUSED has still incremented the stored clock: the clock it incremented was the very object meta[path] holds (that is why it met
+    // "identical clocks" and was decided by value, SURVEY §5) — the device's clock row follows
+    else if (!tagged && currentClock && clock === currentClock) this._mirrorWrite(path, currentData, currentData, currentClock);
     return {
       value: d.value,
       vectorClock: d.vectorClock,
@@ -269,9 +273,12 @@ class GpuCRT {
    * Queued here, sent with ONE bmx_put_rows in front of the next device operation (no device call per put).
    */
   _mirrorWrite(path, oldValue, value, clock) {
-    if (!this._graph || this._opts.writers) return;           // no device table in use (or the K-writer table: its rows are not scalar-clock rows)
+    if (this._opts.writers) return this._mirrorWriteVector(path, oldValue, value, clock);
+    if (!this._graph) return;                                  // no device table in use
     const ts = scalarClock(clock, this._opts.writer || this.bullet.id);
-    if (ts < 0) this._hostOnly.add(path); else this._hostOnly.delete(path);
+    // host-only paths: a clock the device cannot hold, or a STRING value — an object that meets it under an identical clock is compared with it as text
+    // ("[object Object]" < "zebra": src/bullet-crt.js:11-15), the one case where an object entry's fate depends on the stored value
+    if (ts < 0 || typeof value === "string") this._hostOnly.add(path); else this._hostOnly.delete(path);
     const cut = path.lastIndexOf("/");
     const parent = cut < 0 ? "" : path.slice(0, cut);
     const keys = this._graph.keys;
@@ -344,7 +351,7 @@ class GpuCRT {
    * is created (index.js attach(), GpuStorage.restoreDevice()). -> rows queued
    */
   seedDevice() {
-    if (!this._graph || this._opts.writers) return 0;
+    if (!this._graph && !(this._opts.writers && this._vc)) return 0;
     const b = this.bullet, meta = b.meta || {};
     let n = 0;
     for (const p of Object.keys(meta)) {
@@ -353,17 +360,21 @@ class GpuCRT {
       this._mirrorWrite(p, undefined, peek(b.store, p), m.vectorClock);
       n++;
     }
-    this._flushDeviceWrites();
+    if (this._graph) this._flushDeviceWrites();
     return n;
   }
 
   /* May entry e = {path, data, vectorClock} be resolved by the device?  (SURVEY §8(a) contract, node level)
-   *   data: a safe integer, or a plain object with at least one field, all safe integers; clock: the single component {writer: ts};
-   *   the path's stored clock is one the device holds (not host-only), and a first sight of it would store {writer: 2} in the reference too
-   *   (src/bullet-crt.js:172-185 increments whatever crt.vectorClocks already holds for a path that has no meta clock yet). */
+   *   data: a plain object with at least one field — of ANY JSON type: the device resolves the node's CLOCK, the object itself stays on the host and
+   *   replaces the node when its entry wins (two objects under identical clocks: compare() answers +1, src/bullet-crt.js:11-15, so no value is ever
+   *   looked at); only its safe-integer fields additionally become device value rows for the index scans — or a safe integer;
+   *   clock: the single component {writer: ts}; the path's stored clock is one the device holds and its stored value is not a string (not host-only),
+   *   and a first sight of it would store {writer: 2} in the reference too (src/bullet-crt.js:172-185 increments whatever crt.vectorClocks already
+   *   holds for a path that has no meta clock yet). */
   entryEligible(e, writer, objectsOnly) {
     if (!e || e.deleted) return false;
-    if (scalarClock(e.vectorClock, writer) < 0) return false;
+    if (this._opts.writers) { if (clockKeyset(e.vectorClock, this.vcTable.writerIndex, this._vcComps()) < 0) return false; }   // any clock over the table's writers
+    else if (scalarClock(e.vectorClock, writer) < 0) return false;
     const d = e.data;
     if (isDeviceInt(d)) { if (objectsOnly) return false; }
     else {
@@ -371,8 +382,8 @@ class GpuCRT {
       let k = 0;
       for (const f in d) {
         if (f === "__vectorClock" || f === "__fromNetwork" || !Object.prototype.hasOwnProperty.call(d, f)) continue;
-        if (!isDeviceInt(d[f])) return false;
         k++;
+        break;
       }
       if (k === 0) return false;
     }
@@ -503,6 +514,7 @@ class GpuCRT {
     const emit = !opts.apply && opts.valueRows !== false;
     let vcols = emit ? g.takeColumns(Math.max(2 * n, 64)) : null, vn = 0;
     const rowStart = emit ? new Int32Array(n + 1) : null;
+    const rowNode = opts.apply ? new Int32Array(Math.max(n, 1)) : null;   // the node (dictionary number of its path) of every delta: _unaliasLosers
     const host = [];
     const guarded = this._hostOnly.size > 0 || this._apiClocks.size > 0;
     let i = 0;
@@ -531,29 +543,28 @@ class GpuCRT {
           vcols.set2(vn++, lo, hi, keys.fieldOf(parent, null), ts, d);
         }
       } else {
-        let k = 0, ok = true;
-        const v0 = vn;
+        let k = 0;
         for (const f in d) {
           if (f === "__vectorClock" || f === "__fromNetwork" || !Object.prototype.hasOwnProperty.call(d, f)) continue;
-          const v = d[f];
-          if (!isDeviceInt(v)) { ok = false; break; }
           k++;
-          if (emit) {
-            let h = per.get(f);
-            if (h === undefined) h = keys.fieldOf(parent, f);
-            if (vn === vcols.n) vcols = this._growColumns(vcols, vn);
-            vcols.set2(vn++, lo, hi, h, ts, v);
-          }
+          if (!emit) break;
+          const v = d[f];
+          if (!isDeviceInt(v)) continue;                      // strings, nested objects, ...: part of the node on the host, no device row
+          let h = per.get(f);
+          if (h === undefined) h = keys.fieldOf(parent, f);
+          if (vn === vcols.n) vcols = this._growColumns(vcols, vn);
+          vcols.set2(vn++, lo, hi, h, ts, v);
         }
-        if (!ok || k === 0) { vn = v0; host.push(ei); continue; }
+        if (k === 0) { host.push(ei); continue; }              // {} : left to setData
       }
       if (emit) rowStart[i + 1] = vn;
+      if (rowNode) rowNode[i] = keys.idx;
       cols.set2(i, lo, hi, clockField, ts, this._nodeSeq++);
       rowEntry[i++] = ei;
     }
     // one context: the winners that created their node are marked (stored clock = the insert rule's, no read-back); shards: read back
     const mergeOpts = g.comm ? opts : Object.assign({}, opts, { markCreated: true });
-    return { cols: cols.slice(i), rowEntry, host, writer, mergeOpts, vcols, rowStart };
+    return { cols: cols.slice(i), rowEntry, host, writer, mergeOpts, vcols, rowStart, rowNode };
   }
 
   _growColumns(cols, used) {
@@ -570,6 +581,7 @@ class GpuCRT {
     let broadcast = [];
     if (p.vcols) this._queueWinnerRows(p, r.applied, !this.graph.comm, opts.insertMode === "delta");
     else broadcast = this._applyWinners(entries, p.cols, r.applied, appliedEntries, opts.apply, opts.broadcast !== false, !this.graph.comm, opts.insertMode === "delta", p.writer, opts.valueRows !== false);
+    if (opts.apply) this._unaliasLosers(entries, p.rowEntry, p.rowNode, p.cols.n, r.applied, this.graph.keys.size);
     this.graph.giveColumns(p.cols);                           // the merge has returned and the winners' ids are copied
     if (p.vcols) this.graph.giveColumns(p.vcols);
     if (opts.apply) this._notifyIndexHook(entries, p.host);
@@ -577,6 +589,35 @@ class GpuCRT {
     let list = null;                                           // `applied` in the older shape, built only if somebody reads it (an object per winner is what the ingestion rate can do without)
     Object.defineProperty(out, "applied", { enumerable: true, get() { if (!list) { list = new Array(nw); for (let k = 0; k < nw; k++) list[k] = { entry: appliedEntries[k], field: null }; } return list; } });
     return out;
+  }
+
+  /*
+   * What crt.vectorClocks holds after a batch. The reference's resolve() stores the MERGED clock of every entry it resolves in crt.vectorClocks
+   * (src/bullet-crt.js:193-198), applied or not; an applied entry's merged clock is also the object meta[path] gets (one object in both places: a later
+   * local write increments it in place and then meets "identical clocks", SURVEY §5), a losing entry's is a fresh object that only crt.vectorClocks
+   * holds (a later local write increments THAT and dominates). The winners are handled where they are applied; this gives every node whose LAST entry of
+   * the batch lost what the reference would hold: the merge of that entry's clock with the node's stored clock, as a new object — and the store the side
+   * effect of the read every resolution starts with.
+   * rowNode[j]: the node of delta j; winners: delta indices (bits 24..31 may carry marks).
+   */
+  _unaliasLosers(entries, rowEntry, rowNode, nrows, winners, nNodes) {
+    if (!rowNode || nrows === 0) return;
+    if (!this._seen || this._seen.length < nNodes) { this._seen = new Uint32Array(Math.max(1024, 2 * nNodes)); this._seenStamp = 0; }
+    if (++this._seenStamp === 0xffffffff) { this._seen.fill(0); this._seenStamp = 1; }
+    const seen = this._seen, stamp = this._seenStamp, meta = this.bullet.meta || {};
+    const won = new Uint8Array(nrows);
+    for (let k = 0; k < winners.length; k++) won[winners[k] & 0xffffff] = 1;
+    for (let j = nrows - 1; j >= 0; j--) {
+      const node = rowNode[j];
+      if (seen[node] === stamp) continue;
+      seen[node] = stamp;
+      if (won[j]) continue;
+      const e = entries[rowEntry[j]], m = meta[e.path];
+      if (m && m.vectorClock) this.vectorClocks.set(e.path, this.mergeVectorClocks(e.vectorClock, m.vectorClock));
+      // ... and the read the reference's handleUpdate starts with: _getData(path) REPLACES a falsy value on the way (null of a deleted node, 0, "") by {}
+      // (src/bullet.js:115-129), whether the entry then wins or not. A winner overwrites it; behind a loser it stays.
+      if (typeof this.bullet._getData === "function") this.bullet._getData(e.path);
+    }
   }
 
   /* the prepared value rows of the winners -> one segment of the put queue, under the clock each node now stores: the entry's own, or — a winner that
@@ -691,97 +732,181 @@ class GpuCRT {
     if (!this._vc) {
       const { DeviceVcTable } = require("./device-graph");
       this._vc = new DeviceVcTable(this._opts.writers, this.bullet.id, this._opts);   // throws without the addon / a GPU
+      this.seedDevice();                                                              // clocks the facade already holds -> clock rows
     }
     return this._vc;
   }
+  _vcComps() { return this._vcScratch || (this._vcScratch = new Uint32Array(this._opts.writers.length)); }
 
-  /* stored clock of a device row as the reference would hold it: {local: n} after a first write, all K writers otherwise */
-  _clockObject(comps, off, state) {
+  /* stored clock of a device row as the object the reference would hold: the row's counters under the keys its key set names, in that order */
+  _clockObject(comps, off, keyset) {
     const t = this.vcTable, c = {};
-    if (state === t.native.VC_SPARSE) { c[t.writers[t.local]] = comps[off + t.local]; return c; }
-    for (let k = 0; k < t.K; k++) c[t.writers[k]] = comps[off + k];
+    for (const k of keysetWriters(keyset)) c[t.writers[k]] = comps[off + k];
     return c;
   }
 
-  /**
-   * mergeEntries() when the resolver was created with opts.writers (general vector clocks, SURVEY §8(f) N4).
-   * An entry goes to the device when its clock has exactly those writers as keys, in that order, with uint32 counters, and
-   * its data is an integer or an object of integer fields; everything else is returned in `host`.
-   * Device semantics = resolve() applied delta by delta in entry order (src/bullet-crt.js:164-279).
-   * -> {applied: [{entry, field}] (last updating delta of every row that changed, in entry order), flags: Uint8Array per
-   *     device row (1 incoming, 2 current, 4 historical, 8 concurrent), rows: [{entry, field}] per device row,
-   *     nApplied, nConflicts (concurrent merges), nRows, host}
-   */
-  _mergeEntriesVector(entries, opts = {}) {
-    const t = this.vcTable;
-    const plan = [];
-    let rows = 0;
-    for (const e of entries) {
-      const comps = denseClock(e.vectorClock, t.writers);
-      let fields = null;
-      if (comps) {
-        if (isDeviceInt(e.data)) fields = [[null, e.data]];
-        else if (e.data && typeof e.data === "object" && !Array.isArray(e.data)) {
-          fields = [];
-          for (const k of Object.keys(e.data)) {
-            if (k === "__vectorClock" || k === "__fromNetwork") continue;
-            if (!isDeviceInt(e.data[k])) { fields = null; break; }
-            fields.push([k, e.data[k]]);
-          }
-        }
-      }
-      plan.push(fields && fields.length ? { comps, fields } : null);
-      if (fields) rows += fields.length;
-    }
-    const cols = new VcColumns(rows, t.K);
-    const back = new Array(rows);
-    const host = [];
-    let i = 0;
-    entries.forEach((e, ei) => {
-      const p = plan[ei];
-      if (!p) { host.push(ei); return; }
-      const cut = e.path.lastIndexOf("/");
-      const parent = cut < 0 ? "" : e.path.slice(0, cut);
-      const id = t.keys.idOf(e.path);
-      for (const [fname, v] of p.fields) {
-        cols.set(i, id, t.keys.fieldOf(parent, fname), p.comps, v);
-        back[i] = { entry: ei, field: fname };
-        i++;
-      }
-    });
-    const r = t.mergeBatch(cols);
-    const applied = Array.from(r.updated, (j) => back[j]);
-    let nConflicts = 0;
-    for (let j = 0; j < r.flags.length; j++) if (r.flags[j] & t.native.FLAG_CONCURRENT) nConflicts++;
-    if (opts.apply && r.updated.length) {
-      const n = r.updated.length;
-      const ids = new BigUint64Array(n), fields = new Uint32Array(n);
-      for (let k = 0; k < n; k++) { ids[k] = cols.id[r.updated[k]]; fields[k] = cols.field[r.updated[k]]; }
-      const got = t.getRows(ids, fields);
-      for (let k = 0; k < n; k++) {
-        const a = applied[k], e = entries[a.entry];
-        const leaf = a.field === null ? e.path : e.path + "/" + a.field;
-        const clock = this._clockObject(got.clocks, k * t.K, got.state[k]);
-        if (typeof this.bullet._applyUpdate === "function") this.bullet._applyUpdate(leaf, Number(got.val[k]), clock, true);
-        this.vectorClocks.set(leaf, clock);
+  /* _mirrorWrite in writers mode: the node's clock row goes to the vector-clock table (counters + key set; a clock that names a foreign writer or
+   * holds something else than uint32 counters marks the path host-only, and so does a string value: see _mirrorWrite), the value rows to the scalar
+   * table the index scans read, exactly as in scalar mode. Both are queued and sent in front of the next device operation. */
+  _mirrorWriteVector(path, oldValue, value, clock) {
+    if (!this._vc && !this._graph) return;                      // nothing on the device yet: seeded when the tables are created
+    const comps = this._vcComps();
+    const ks = this._vc ? clockKeyset(clock, this._vc.writerIndex, comps) : 0;
+    if (ks < 0 || typeof value === "string") this._hostOnly.add(path); else this._hostOnly.delete(path);
+    const cut = path.lastIndexOf("/");
+    const parent = cut < 0 ? "" : path.slice(0, cut);
+    if (this._vc && ks >= 0) this._vcPuts.push([path, parent, ks, Array.from(comps), this._nodeSeq++]);
+    if (!this._graph) return;
+    const keys = this._graph.keys;
+    const q = this._putQueue();
+    keys.lookup(path);
+    this._queueValueRows(q, path, parent, keys.lo, keys.hi, oldValue, value, 0, false);
+    if (cut > 0) {                                              // the leaf as a field of its parent node
+      const key = path.slice(cut + 1), c2 = parent.lastIndexOf("/");
+      const was = isDeviceInt(oldValue), is = isDeviceInt(value);
+      if (was || is) {
+        keys.lookup(parent);
+        q.push(keys.lo, keys.hi, keys.fieldOf(c2 < 0 ? "" : parent.slice(0, c2), key), 0, is ? value : VAL_DELETED);
       }
     }
-    return { applied, flags: r.flags, rows: back, nApplied: applied.length, nConflicts, nRows: r.nRows, host };
   }
 
-  /** Stored (value, clock) of device rows in vector mode: [{path, field}] -> [{value, vectorClock} | null]. */
-  vcLookup(keys) {
-    const t = this.vcTable, n = keys.length;
+  /* queued clock rows of host writes -> the vector-clock table (a preload: the last row of a key stays) */
+  _flushVcPuts() {
+    const puts = this._vcPuts;
+    if (!puts.length) return;
+    this._vcPuts = [];
+    const t = this.vcTable, cols = new VcColumns(puts.length, t.K);
+    puts.forEach((p, i) => { t.keys.lookup(p[0]); cols.set2(i, t.keys.lo, t.keys.hi, t.keys.fieldOf(p[1], NODE_CLOCK), p[3], p[2], p[4]); });
+    t.loadRows(cols);
+  }
+
+  /**
+   * mergeEntries() when the resolver was created with opts.writers (general vector clocks, SURVEY §8(f) N4), NODE level like the scalar path:
+   * an entry {path, data, vectorClock} whose clock names only the table's writers (any subset, any key order, uint32 counters) is ONE delta on the
+   * node's clock row of the vector-clock table — counters, key set, and its arrival number as the value — and the device runs resolve() over each
+   * node's deltas in entry order (src/bullet-crt.js:164-279): first sight stores {local: 2}; a dominating clock replaces the node; a dominated one is
+   * historical; identical clocks (same keys, same order, same counters) take the later object; everything else is CONCURRENT and the stored clock
+   * becomes the merge, in the reference's key order. What the device cannot hold is the objects: the per-delta flags tell the host what each entry did,
+   * and with opts.apply the host replays just that over the store — INCOMING replaces the node, CONCURRENT is mergeValues(entry, node) (:122-153) —
+   * and applies each changed node once (final value, clock read back with its key order), queueing its integer fields as device value rows.
+   * -> {appliedEntries: Int32Array (the last updating entry of every node that changed, ascending), applied (the same as [{entry, field: null}]),
+   *     flags: Uint8Array per device delta (1 incoming, 2 current, 4 historical, 8 concurrent), rowEntry: Int32Array (delta -> entry index),
+   *     nApplied, nConflicts (concurrent merges), nRows, host: [entry indices], broadcast}
+   */
+  _mergeEntriesVector(entries, opts = {}) {
+    const t = this.vcTable, keys = t.keys, nat = t.native;
+    const writer = opts.writer || this.bullet.id;
+    const n = entries.length;
+    this._flushVcPuts();
+    const cols = new VcColumns(Math.max(n, 1), t.K);
+    const rowEntry = new Int32Array(Math.max(n, 1));
+    const rowNode = opts.apply ? new Int32Array(Math.max(n, 1)) : null;
+    const comps = this._vcComps();
+    const guarded = this._hostOnly.size > 0 || this._apiClocks.size > 0;
+    const host = [];
+    let i = 0, parent = null, pCut = -2, pH1 = 0, pH2 = 0, clockField = 0;
+    for (let ei = 0; ei < n; ei++) {
+      const e = entries[ei];
+      if (!e || e.deleted) { host.push(ei); continue; }
+      const d = e.data;
+      if (!isDeviceInt(d)) {
+        let any = false;
+        if (isMergeable(d)) for (const f in d) { if (f !== "__vectorClock" && f !== "__fromNetwork" && Object.prototype.hasOwnProperty.call(d, f)) { any = true; break; } }
+        if (!any) { host.push(ei); continue; }
+      }
+      const ks = clockKeyset(e.vectorClock, t.writerIndex, comps);
+      if (ks < 0 || (guarded && !this._pathEligible(e.path, writer))) { host.push(ei); continue; }
+      keys.lookup(e.path);
+      if (keys.cut !== pCut || keys.ph1 !== pH1 || keys.ph2 !== pH2) {
+        pCut = keys.cut; pH1 = keys.ph1; pH2 = keys.ph2;
+        parent = pCut < 0 ? "" : e.path.slice(0, pCut);
+        clockField = keys.fieldOf(parent, NODE_CLOCK);
+      }
+      if (rowNode) rowNode[i] = keys.idx;
+      cols.set2(i, keys.lo, keys.hi, clockField, comps, ks, this._nodeSeq++);
+      rowEntry[i++] = ei;
+    }
+    const used = cols.slice(i);
+    const r = i ? t.mergeBatch(used) : { updated: new Uint32Array(0), flags: new Uint8Array(0), nRows: t.rowCount() };
+    const nw = r.updated.length;
+    const appliedEntries = new Int32Array(nw);
+    for (let k = 0; k < nw; k++) appliedEntries[k] = rowEntry[r.updated[k]];
+    let nConflicts = 0;
+    for (let j = 0; j < i; j++) if (r.flags[j] & nat.FLAG_CONCURRENT) nConflicts++;
+    let broadcast;
+    if (opts.apply && nw) broadcast = this._applyVectorWinners(entries, used, rowEntry, r, opts);
+    if (opts.apply) this._unaliasLosers(entries, rowEntry, rowNode, i, r.updated, keys.size);
+    if (opts.apply) this._notifyIndexHook(entries, host);
+    const out = { appliedEntries, flags: r.flags, rowEntry: rowEntry.subarray(0, i), nApplied: nw, nConflicts, nRows: r.nRows, host, broadcast: opts.apply ? broadcast || [] : undefined };
+    let list = null;
+    Object.defineProperty(out, "applied", { enumerable: true, get() { if (!list) list = Array.from(appliedEntries, (ei) => ({ entry: ei, field: null })); return list; } });
+    return out;
+  }
+
+  /* replay of what the device decided, node by node (see _mergeEntriesVector), and ONE application per changed node */
+  _applyVectorWinners(entries, cols, rowEntry, r, opts) {
+    const t = this.vcTable, nat = t.native, b = this.bullet;
+    const working = new Map(), before = new Map();
+    const clean = (d) => {
+      if (!isMergeable(d)) return d;
+      const c = {};
+      for (const f of Object.keys(d)) if (f !== "__vectorClock" && f !== "__fromNetwork") c[f] = d[f];
+      return c;
+    };
+    for (let j = 0; j < r.flags.length; j++) {
+      const fl = r.flags[j];
+      if (!(fl & (nat.FLAG_INCOMING | nat.FLAG_CONCURRENT))) continue;
+      const e = entries[rowEntry[j]], path = e.path;
+      let cur;
+      if (working.has(path)) cur = working.get(path); else { cur = peek(b.store, path); before.set(path, cur); }
+      if (!cur) cur = {};                                       // what handleUpdate's _getData(path) makes of a falsy value (src/bullet.js:115-129)
+      const inc = clean(e.data);
+      working.set(path, (fl & nat.FLAG_CONCURRENT) ? this.mergeValues(inc, cur) : inc);
+    }
+    const nw = r.updated.length;
+    const ids = new BigUint64Array(nw), fields = new Uint32Array(nw);
+    for (let k = 0; k < nw; k++) { ids[k] = cols.id[r.updated[k]]; fields[k] = cols.field[r.updated[k]]; }
+    const got = t.getRows(ids, fields);
+    const valueRows = opts.valueRows !== false;
+    const q = valueRows ? this._putQueue() : null;
+    const gk = valueRows ? this.graph.keys : null;
+    const updates = new Array(nw);
+    for (let k = 0; k < nw; k++) {
+      const path = entries[rowEntry[r.updated[k]]].path;
+      const clock = this._clockObject(got.clocks, k * t.K, got.keysets[k]);
+      const value = working.get(path);
+      updates[k] = { path, value, vectorClock: clock };
+      this.vectorClocks.set(path, clock);
+      if (valueRows) {
+        const cut = path.lastIndexOf("/");
+        gk.lookup(path);
+        this._queueValueRows(q, path, cut < 0 ? "" : path.slice(0, cut), gk.lo, gk.hi, before.get(path), value, 0, true);
+      }
+    }
+    if (q) q.closeBatch();
+    if (opts.apply === "each") {
+      if (typeof b._applyUpdate === "function") for (const u of updates) b._applyUpdate(u.path, u.value, u.vectorClock, true);
+      return opts.broadcast !== false ? updates.map((u) => ({ path: u.path, broadcastData: isMergeable(u.value) ? Object.assign({}, u.value, { __vectorClock: u.vectorClock }) : u.value })) : [];
+    }
+    if (typeof b._applyBatch === "function") return b._applyBatch(updates, true) || [];
+    return require("./batch-apply").applyBatch(b, updates, true, opts.broadcast !== false);
+  }
+
+  /** The clocks the vector-clock table holds for these node paths: [path | {path}] -> [vectorClock object (reference key order) | null]. */
+  vcLookup(paths) {
+    const t = this.vcTable, n = paths.length;
+    this._flushVcPuts();
     const ids = new BigUint64Array(n), id32 = new Uint32Array(ids.buffer), fields = new Uint32Array(n);
-    keys.forEach((k, i) => {
-      const cut = k.path.lastIndexOf("/");
-      const id = t.keys.idOf(k.path);
-      id32[2 * i] = id[0]; id32[2 * i + 1] = id[1];
-      fields[i] = t.keys.fieldOf(cut < 0 ? "" : k.path.slice(0, cut), k.field === undefined ? null : k.field);
+    paths.forEach((k, i) => {
+      const path = typeof k === "string" ? k : k.path;
+      const cut = path.lastIndexOf("/");
+      t.keys.lookup(path);
+      id32[2 * i] = t.keys.lo; id32[2 * i + 1] = t.keys.hi;
+      fields[i] = t.keys.fieldOf(cut < 0 ? "" : path.slice(0, cut), NODE_CLOCK);
     });
     const got = t.getRows(ids, fields);
-    return keys.map((_, i) => (got.state[i] === t.native.VC_ABSENT ? null
-      : { value: Number(got.val[i]), vectorClock: this._clockObject(got.clocks, i * t.K, got.state[i]) }));
+    return paths.map((_, i) => (got.state[i] === t.native.VC_ABSENT ? null : this._clockObject(got.clocks, i * t.K, got.keysets[i])));
   }
 
   /*

@@ -57,6 +57,7 @@ class KeyDictionary {
     this.paths = [];           // index -> path
     this.lo = 0; this.hi = 0;
     this.cut = -1; this.ph1 = 0; this.ph2 = 0;   // of the last lookup(): position of the path's last "/" and the 64-bit hash state of its parent prefix
+    this.idx = -1;                              // ... and the path's number in this dictionary (paths[idx])
     this._alloc(capacity);
   }
   get size() { return this.paths.length; }
@@ -107,7 +108,7 @@ class KeyDictionary {
       const k = t[4 * s + 2];
       if (k === 0) break;
       if (t[4 * s] === lo && t[4 * s + 1] === hi) {
-        if (t[4 * s + 3] === chk) return;
+        if (t[4 * s + 3] === chk) { this.idx = k - 1; return; }
         const err = new Error(`bmx: 64-bit id collision between paths '${this.paths[k - 1]}' and '${p}'`);
         err.code = "BMX_ID_COLLISION";
         throw err;
@@ -115,6 +116,7 @@ class KeyDictionary {
       s = (s + 1) & mask;
     }
     this.paths.push(p);
+    this.idx = this.paths.length - 1;
     t[4 * s] = lo; t[4 * s + 1] = hi; t[4 * s + 2] = this.paths.length; t[4 * s + 3] = chk;
     if (this.paths.length * 2 > this._cap) this._grow();
   }
@@ -221,14 +223,55 @@ class VcColumns {
     this._id32 = new Uint32Array(this.id.buffer);
     this.field = new Uint32Array(n);
     this.clocks = new Uint32Array(n * K);
+    this.keysets = new Uint32Array(n).fill(keysetDense(K));   // which writers each clock names, in which order (include/bmx.h): all K unless set
     this.val = new BigInt64Array(n);
+    this._val32 = new Uint32Array(this.val.buffer);
   }
-  set(i, idPair, field, comps, val) {
+  set(i, idPair, field, comps, val, keyset) {
     this._id32[2 * i] = idPair[0]; this._id32[2 * i + 1] = idPair[1];
     this.field[i] = field;
     this.clocks.set(comps, i * this.K);
+    if (keyset !== undefined) this.keysets[i] = keyset;
     this.val[i] = BigInt(val);
   }
+  /* the id as two numbers, the counters taken from comps[0..K), val a safe integer written as two halves (no BigInt per row) */
+  set2(i, lo, hi32, field, comps, keyset, val) {
+    this._id32[2 * i] = lo; this._id32[2 * i + 1] = hi32;
+    this.field[i] = field;
+    const K = this.K, o = i * K;
+    for (let k = 0; k < K; k++) this.clocks[o + k] = comps[k];
+    this.keysets[i] = keyset;
+    const hi = Math.floor(val / 4294967296);
+    this._val32[2 * i] = val - hi * 4294967296; this._val32[2 * i + 1] = hi;
+  }
+  slice(n) {
+    if (n === this.n) return this;
+    const c = Object.create(VcColumns.prototype);
+    c.n = n; c.K = this.K; c.id = this.id.subarray(0, n); c._id32 = this._id32.subarray(0, 2 * n); c.field = this.field.subarray(0, n);
+    c.clocks = this.clocks.subarray(0, n * this.K); c.keysets = this.keysets.subarray(0, n); c.val = this.val.subarray(0, n); c._val32 = this._val32.subarray(0, 2 * n);
+    return c;
+  }
+}
+
+/* key-set word of the N4 table (include/bmx.h bmx_vc_keyset): eight 4-bit writer indices in the clock object's key order, 0xF = end */
+const KEYSET_NONE = 0xffffffff;
+function keysetDense(K) { let ks = KEYSET_NONE; for (let k = 0; k < K; k++) ks = ((ks & ~(0xf << (4 * k))) | (k << (4 * k))) >>> 0; return ks; }
+function keysetWriters(ks) { const out = []; for (let i = 0; i < 8; i++) { const w = (ks >>> (4 * i)) & 0xf; if (w === 0xf) break; out.push(w); } return out; }
+/* clock object -> key-set word, its counters written into comps[0..K) (zero for writers it does not name); -1 when the clock names somebody outside
+ * `index` (Map writer id -> position) or a counter is not a uint32: such a clock stays on the host */
+function clockKeyset(clock, index, comps) {
+  if (!clock || typeof clock !== "object") return -1;
+  comps.fill(0);
+  let ks = KEYSET_NONE, i = 0;
+  for (const w in clock) {
+    if (!Object.prototype.hasOwnProperty.call(clock, w)) continue;
+    const k = index.get(w), c = clock[w];
+    if (k === undefined || i >= 8 || typeof c !== "number" || !Number.isInteger(c) || c < 0 || c > 0xffffffff) return -1;
+    comps[k] = c;
+    ks = (ks & ~(0xf << (4 * i))) | (k << (4 * i));
+    i++;
+  }
+  return ks >>> 0;
 }
 
 /* a clock the N4 table understands: exactly the K writers as keys, in `writers` order (the reference compares clocks with
@@ -248,4 +291,4 @@ function denseClock(clock, writers) {
   return out;
 }
 
-module.exports = { pathId, fieldId, idKey, KeyDictionary, Columns, VcColumns, isDeviceInt, scalarClock, denseClock, fnv1a32, NODE_CLOCK, VAL_DELETED };
+module.exports = { pathId, fieldId, idKey, KeyDictionary, Columns, VcColumns, isDeviceInt, scalarClock, denseClock, clockKeyset, keysetDense, keysetWriters, KEYSET_NONE, fnv1a32, NODE_CLOCK, VAL_DELETED };

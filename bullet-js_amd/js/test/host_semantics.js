@@ -190,6 +190,7 @@ if (fs.existsSync(path.join(REF, "src", "bullet.js"))) {
   quiet(() => queryExample(() => mk(true), "real-bullet"));
   quiet(() => batchApplyCase(() => mk(false), "real-bullet 2500", 2500));     // against the reference's own _applyUpdate/_notify
   quiet(() => g9OnTheHost(() => mk(false), "real-bullet"));
+  quiet(() => g9OnTheHost(() => mk(false), "real-bullet", "g10_sync_mixed_values.json"));
   {
     // the reference's file storage reads what GpuStorage wrote, and the real facade accepts GpuStorage at its provider hook
     const os = require("os");
@@ -210,8 +211,9 @@ if (fs.existsSync(path.join(REF, "src", "bullet.js"))) {
 
 /* g9 (host side, no GPU): the reference's sync loop entry by entry through GpuCRT.handleUpdate — the host resolver that takes every entry the device
  * contract leaves out — reproduces the reference's node-level outcomes: store and every clock + source after each chunk, then the queries */
-function g9OnTheHost(makeBullet, label) {
-  const g = load("g9_sync_node_semantics.json");
+function g9OnTheHost(makeBullet, label, fixture = "g9_sync_node_semantics.json") {
+  const g = load(fixture);
+  label += " " + fixture.slice(0, fixture.indexOf("_"));
   const b = makeBullet();
   g.chunks.forEach((chunk, ci) => {
     for (const e of JSON.parse(JSON.stringify(chunk))) {              // the loop body of src/bullet-network-sync.js:552-568
@@ -219,17 +221,35 @@ function g9OnTheHost(makeBullet, label) {
       else b.setData(e.path, typeof e.data === "object" && e.data !== null ? Object.assign({}, e.data, { __fromNetwork: true, __vectorClock: e.vectorClock }) : e.data, false);
     }
     const want = g.after[ci];
-    assert.deepStrictEqual(JSON.parse(JSON.stringify(b.store)), want.store, label + ": g9 store after chunk " + (ci + 1));
+    assert.deepStrictEqual(JSON.parse(JSON.stringify(b.store)), want.store, label + ": store after chunk " + (ci + 1));
     assert.deepStrictEqual(Object.keys(b.meta).sort(), Object.keys(want.meta).sort(), label);
     for (const p of Object.keys(want.meta)) {
-      assert.deepStrictEqual(JSON.parse(JSON.stringify(b.meta[p].vectorClock)), want.meta[p].vectorClock, label + ": g9 clock of " + p + " after chunk " + (ci + 1));
-      assert.strictEqual(b.meta[p].source, want.meta[p].source, label + ": g9 source of " + p);
+      assert.deepStrictEqual(JSON.parse(JSON.stringify(b.meta[p].vectorClock)), want.meta[p].vectorClock, label + ": clock of " + p + " after chunk " + (ci + 1));
+      assert.strictEqual(b.meta[p].source, want.meta[p].source, label + ": source of " + p);
       checks++;
     }
   });
   return b;
 }
 g9OnTheHost(() => { const b = new MiniBullet("w"); b.crt = new GpuCRT(b); return b; }, "mini");
+/* g12 (host side): multi-writer clocks, node level — the host resolver alone reproduces the reference's stores and clocks, key ORDER included */
+{
+  const g = load("g12_vc_node_semantics.json");
+  const b = new MiniBullet("w"); b.crt = new GpuCRT(b);
+  g.chunks.forEach((chunk, ci) => {
+    for (const e of JSON.parse(JSON.stringify(chunk))) {
+      if (e.deleted) b.setData(e.path, null, false);
+      else b.setData(e.path, Object.assign({}, e.data, { __fromNetwork: true, __vectorClock: e.vectorClock }), false);
+    }
+    const want = g.after[ci];
+    assert.deepStrictEqual(JSON.parse(JSON.stringify(b.store)), want.store, "g12 (host) store after chunk " + (ci + 1));
+    for (const p of Object.keys(want.meta)) {
+      assert.deepStrictEqual(Object.keys(b.meta[p].vectorClock).map((w) => [w, b.meta[p].vectorClock[w]]), want.meta[p].clock, "g12 (host) clock of " + p + " after chunk " + (ci + 1));
+      checks++;
+    }
+  });
+}
+g9OnTheHost(() => { const b = new MiniBullet("w"); b.crt = new GpuCRT(b); return b; }, "mini", "g10_sync_mixed_values.json");   // fields of every JSON type, ties against stored strings / numbers / null
 
 /* N2 and the wrappers around setData: with put middleware registered nothing is batched (every entry takes setData, one by one);
  * without it the device-eligible run goes to mergeEntries, and the query engine's index hook is told about every batched entry */

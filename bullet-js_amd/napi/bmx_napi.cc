@@ -559,29 +559,47 @@ bool get_vc_cols(napi_env env, napi_value* a, uint32_t K, const uint64_t** id, c
   return true;
 }
 
+// optional trailing argument: keysets Uint32Array[n] (which writers each clock names, in which order: include/bmx.h); absent / undefined = all K, in order
+bool get_keysets(napi_env env, size_t argc, napi_value* argv, size_t at, size_t n, const uint32_t** ks) {
+  *ks = nullptr;
+  if (argc <= at) return true;
+  napi_valuetype t; napi_typeof(env, argv[at], &t);
+  if (t == napi_undefined || t == napi_null) return true;
+  void* p; size_t m;
+  if (!get_ta(env, argv[at], napi_uint32_array, &p, &m)) return false;
+  if (m != n) { napi_throw_range_error(env, nullptr, "bmx: keysets must hold one word per row"); return false; }
+  *ks = (const uint32_t*)p;
+  return true;
+}
+#define ARGS_OPT(MIN, MAX)                                   \
+  size_t argc = MAX; napi_value argv[MAX];                   \
+  NAPI_OK(napi_get_cb_info(env, info, &argc, argv, nullptr, nullptr)); \
+  if (argc < MIN) { napi_throw_type_error(env, nullptr, "bmx: missing arguments"); return nullptr; }
+
+// vcLoadRows(h, id, field, clocks, val[, keysets])
 napi_value VcLoadRows(napi_env env, napi_callback_info info) {
-  ARGS(5);
+  ARGS_OPT(5, 6);
   VcHandle* h; if (!get_vc(env, argv[0], &h)) return nullptr;
-  const uint64_t* id; const uint32_t *field, *clocks; const int64_t* val; size_t n;
-  if (!get_vc_cols(env, argv + 1, h->K, &id, &field, &clocks, &val, &n)) return nullptr;
+  const uint64_t* id; const uint32_t *field, *clocks, *ks; const int64_t* val; size_t n;
+  if (!get_vc_cols(env, argv + 1, h->K, &id, &field, &clocks, &val, &n) || !get_keysets(env, argc, argv, 5, n, &ks)) return nullptr;
   std::lock_guard<std::mutex> g(h->mu);
-  int rc = bmx_vc_load_rows(h->t, n, id, field, clocks, val);
+  int rc = bmx_vc_load_rows_ks(h->t, n, id, field, clocks, ks, val);
   if (rc) return throw_vc(env, h->t, rc);
   return nullptr;
 }
 
-// vcMergeBatch(h, id, field, clocks, val) -> {updated: Uint32Array, flags: Uint8Array, nRows}
+// vcMergeBatch(h, id, field, clocks, val[, keysets]) -> {updated: Uint32Array, flags: Uint8Array, nRows}
 napi_value VcMergeBatch(napi_env env, napi_callback_info info) {
-  ARGS(5);
+  ARGS_OPT(5, 6);
   VcHandle* h; if (!get_vc(env, argv[0], &h)) return nullptr;
-  const uint64_t* id; const uint32_t *field, *clocks; const int64_t* val; size_t n;
-  if (!get_vc_cols(env, argv + 1, h->K, &id, &field, &clocks, &val, &n)) return nullptr;
+  const uint64_t* id; const uint32_t *field, *clocks, *ks; const int64_t* val; size_t n;
+  if (!get_vc_cols(env, argv + 1, h->K, &id, &field, &clocks, &val, &n) || !get_keysets(env, argc, argv, 5, n, &ks)) return nullptr;
   std::vector<uint32_t> upd(n ? n : 1);
   void* fl = nullptr;
   napi_value flags = make_ta(env, napi_uint8_array, 1, n, &fl);
   uint64_t nu = 0, rows = 0;
   std::lock_guard<std::mutex> g(h->mu);
-  int rc = bmx_vc_merge_batch(h->t, n, id, field, clocks, val, upd.data(), &nu, (uint8_t*)fl);
+  int rc = bmx_vc_merge_batch_ks(h->t, n, id, field, clocks, ks, val, upd.data(), &nu, (uint8_t*)fl);
   if (rc) return throw_vc(env, h->t, rc);
   bmx_vc_row_count(h->t, &rows);
   void* up = nullptr;
@@ -594,21 +612,23 @@ napi_value VcMergeBatch(napi_env env, napi_callback_info info) {
   return out;
 }
 
-// vcGetRows(h, id, field) -> {clocks: Uint32Array[n*K], val: BigInt64Array, state: Uint8Array}
+// vcGetRows(h, id, field) -> {clocks: Uint32Array[n*K], val: BigInt64Array, state: Uint8Array, keysets: Uint32Array}
 napi_value VcGetRows(napi_env env, napi_callback_info info) {
   ARGS(3);
   VcHandle* h; if (!get_vc(env, argv[0], &h)) return nullptr;
   void *p0, *p1; size_t n0, n1;
   if (!get_ta(env, argv[1], napi_biguint64_array, &p0, &n0) || !get_ta(env, argv[2], napi_uint32_array, &p1, &n1)) return nullptr;
   if (n0 != n1) { napi_throw_range_error(env, nullptr, "bmx: column lengths differ"); return nullptr; }
-  void *c, *v, *st;
+  void *c, *v, *st, *ks;
   napi_value clocks = make_ta(env, napi_uint32_array, 4, n0 * h->K, &c);
   napi_value val = make_ta(env, napi_bigint64_array, 8, n0, &v);
   napi_value state = make_ta(env, napi_uint8_array, 1, n0, &st);
+  napi_value keysets = make_ta(env, napi_uint32_array, 4, n0, &ks);
   std::lock_guard<std::mutex> g(h->mu);
-  int rc = bmx_vc_get_rows(h->t, n0, (const uint64_t*)p0, (const uint32_t*)p1, (uint32_t*)c, (int64_t*)v, (uint8_t*)st);
+  int rc = bmx_vc_get_rows_ks(h->t, n0, (const uint64_t*)p0, (const uint32_t*)p1, (uint32_t*)c, (uint32_t*)ks, (int64_t*)v, (uint8_t*)st);
   if (rc) return throw_vc(env, h->t, rc);
   napi_value out; NAPI_OK(napi_create_object(env, &out));
+  napi_set_named_property(env, out, "keysets", keysets);
   napi_set_named_property(env, out, "clocks", clocks);
   napi_set_named_property(env, out, "val", val);
   napi_set_named_property(env, out, "state", state);

@@ -329,7 +329,13 @@ int bmx_comm_scan_filter(bmx_comm* comm, uint32_t nterms, const bmx_term* terms,
  * (compareVectorClocks src/bullet-crt.js:68-95, missing component = 0), component-wise max merge (:103-114), the
  * "identical clocks -> value comparison" branch (:200-233), and the "concurrent" branch whose value is
  * compare(in,cur) >= 0 ? in : cur (:266-278, :133-135) — including the quirk that a first write stores the one-key clock
- * {local: 2} (:172-185). Contract: incoming clocks are dense (the host lists all K writers, same order, every time).
+ * {local: 2} (:172-185). Clocks that name all K writers in the table's order need nothing more (the plain entry points); clocks that name
+ * only SOME of them, or in another order — the reference's clocks are JS objects: a missing key counts as 0 in the dominance test (:76-79), two
+ * clocks are "identical" only when their JSON texts are (:200-203: same keys, same order, same counters), a merged clock lists the incoming
+ * clock's keys first and then the stored clock's other keys (:103-114) — carry a KEY SET word per clock (the *_ks entry points): eight 4-bit
+ * writer indices in the object's key order, 0xF = end (BMX_VC_KEYSET_NONE = the clock {}); components of writers a clock does not name must
+ * be 0. A row stores its clock's key set next to the counters and bmx_vc_get_rows_ks returns it, so the host rebuilds the very object the
+ * reference would hold. Writers outside the table's K stay on the host.
  * Deltas of one key are applied in index order (the result is order dependent for concurrent clocks), so batches are
  * exact for any duplication. flags[j] additionally carries BMX_FLAG_CONCURRENT. updated_idx = ascending indices of the
  * last delta per key that caused a store (doUpdate: src/bullet-crt.js:383). These entry points take host buffers (synchronous). capacity_rows
@@ -337,8 +343,12 @@ int bmx_comm_scan_filter(bmx_comm* comm, uint32_t nterms, const bmx_term* terms,
 #define BMX_FLAG_CONCURRENT 8u
 #define BMX_VC_MAX_WRITERS 8
 #define BMX_VC_ABSENT 0
-#define BMX_VC_DENSE  1   /* the row's clock lists all K writers */
+#define BMX_VC_DENSE  1   /* the row's clock was loaded or merged at least once (its keys: the row's key set; all K writers for the plain entry points) */
 #define BMX_VC_SPARSE 2   /* the row still carries the one-key clock {local: 2} of its first write */
+#define BMX_VC_KEYSET_NONE 0xFFFFFFFFu
+/* key set of a clock whose keys are writers w[0..count) in that order; bmx_vc_keyset_dense(K) = all K writers in the table's order (pure functions) */
+uint32_t bmx_vc_keyset(const uint8_t* w, uint32_t count);
+uint32_t bmx_vc_keyset_dense(uint32_t k_writers);
 typedef struct bmx_vc bmx_vc;
 int bmx_vc_create(int device, uint64_t capacity_rows, uint32_t k_writers, uint32_t local_writer, bmx_vc** out);
 void bmx_vc_destroy(bmx_vc* t);
@@ -349,6 +359,14 @@ int bmx_vc_merge_batch(bmx_vc* t, uint64_t n, const uint64_t* id, const uint32_t
                        const int64_t* val, uint32_t* updated_idx, uint64_t* n_updated, uint8_t* flags);
 int bmx_vc_get_rows(bmx_vc* t, uint64_t n, const uint64_t* id, const uint32_t* field, uint32_t* clocks_out /* n*K */,
                     int64_t* val_out, uint8_t* state_out);
+/* The same with a key set per clock (keysets: n words, NULL = every clock names all K writers in order; keysets_out may be NULL).
+ * A malformed key set (index >= K, a writer twice, a non-zero component of an unnamed writer) is BMX_ERR_RANGE. */
+int bmx_vc_load_rows_ks(bmx_vc* t, uint64_t n, const uint64_t* id, const uint32_t* field, const uint32_t* clocks /* n*K */, const uint32_t* keysets,
+                        const int64_t* val);
+int bmx_vc_merge_batch_ks(bmx_vc* t, uint64_t n, const uint64_t* id, const uint32_t* field, const uint32_t* clocks /* n*K */, const uint32_t* keysets,
+                          const int64_t* val, uint32_t* updated_idx, uint64_t* n_updated, uint8_t* flags);
+int bmx_vc_get_rows_ks(bmx_vc* t, uint64_t n, const uint64_t* id, const uint32_t* field, uint32_t* clocks_out /* n*K */, uint32_t* keysets_out,
+                       int64_t* val_out, uint8_t* state_out);
 int bmx_vc_row_count(bmx_vc* t, uint64_t* n_out);
 /* range()/equals()/count() (src/bullet-query.js:186-313) over the rows of this table: node ids of the rows of `field` with lo <= val <= hi, in
  * table order; out_ids may be NULL (count only); *n_out = matches even if cap is smaller. Scans the table itself (64 B per slot), host buffers. */
@@ -358,6 +376,8 @@ int bmx_vc_scan_range(bmx_vc* t, uint32_t field, int64_t lo, int64_t hi, uint64_
  * reported by bmx_vc_sync. bmx_vc_set_stream: run on the caller's hipStream_t (NULL = the table's own). */
 int bmx_vc_merge_batch_dev(bmx_vc* t, uint64_t n, const uint64_t* id, const uint32_t* field, const uint32_t* clocks, const int64_t* val,
                            uint32_t* updated_idx, uint64_t* n_updated, uint8_t* flags);
+int bmx_vc_merge_batch_ks_dev(bmx_vc* t, uint64_t n, const uint64_t* id, const uint32_t* field, const uint32_t* clocks, const uint32_t* keysets,
+                              const int64_t* val, uint32_t* updated_idx, uint64_t* n_updated, uint8_t* flags);
 int bmx_vc_set_stream(bmx_vc* t, void* hip_stream);
 int bmx_vc_sync(bmx_vc* t);
 

@@ -298,15 +298,17 @@ uint64_t orc_mt_batch(orc_t** tables, uint32_t T, uint64_t n, const uint64_t* id
  * N4: fixed-K multi-writer vector clocks, integer values. Restates resolve() for general clocks
  * (src/bullet-crt.js:164-279) with compareVectorClocks :68-95 (missing component = 0), mergeVectorClocks :103-114
  * (component-wise max) and mergeValues :122-153 for non-objects (compare(in,cur) >= 0 ? in : cur).
- * Contract: every incoming clock is "dense" (lists the same K writers in the same order), so JSON equality of two clocks is
- * component equality — except against the ONE-key clock {local: 2} stored by a first write (:172-185), tracked as `sparse`.
- * Pinned by the g6 vc fixtures under tests/golden (real reference, 3 writers).
+ * A clock is K counters plus its KEY SET: which writers the JS object names and in which order (eight 4-bit writer indices, 0xF = end).
+ * A missing key counts as 0 in the dominance test (:76-79); two clocks are "identical" only if JSON.stringify says so (:200-203): same keys,
+ * same order, same counters; a merged clock is {...incoming} followed by the stored clock's other keys (:103-114). The plain entry points
+ * take "dense" clocks (all K writers, in order); a first write stores the ONE-key clock {local: 2} (:172-185), also reported as `sparse`.
+ * Pinned by the g6 vc fixtures (dense clocks) and g11_vc_keysets_*.json (subsets, permutations, {}) under tests/golden (real reference, 3 writers).
  * ====================================================================================================================== */
 #define ORC_VC_MAXK 8
 #define ORC_FLAG_CONCURRENT 8u
 
 typedef struct {
-  uint64_t id; uint32_t field; uint32_t stamp; int64_t val; uint32_t clock[ORC_VC_MAXK]; uint32_t last_j; uint8_t sparse;
+  uint64_t id; uint32_t field; uint32_t stamp; int64_t val; uint32_t clock[ORC_VC_MAXK]; uint32_t last_j; uint32_t ks; uint8_t sparse;
 } orc_vrow;
 typedef struct orc_vc {
   orc_vrow* rows; uint64_t n, cap; uint32_t* slots; uint64_t nslots; uint32_t K, local, stamp;
@@ -352,20 +354,38 @@ static orc_vrow* vc_append(orc_vc_t* t, uint64_t id, uint32_t field) {
   t->slots[s] = (uint32_t)(++t->n);
   return r;
 }
-/* dense preload (harness sets state directly) */
-void orc_vc_load_rows(orc_vc_t* t, uint64_t n, const uint64_t* id, const uint32_t* field, const uint32_t* clocks, const int64_t* val) {
+#define ORC_KS_NONE 0xFFFFFFFFu
+static uint32_t ks_dense(uint32_t K) { uint32_t ks = ORC_KS_NONE; for (uint32_t k = 0; k < K; k++) ks = (ks & ~(0xFu << (4 * k))) | (k << (4 * k)); return ks; }
+/* key order of mergeVectorClocks(in, cur): the spread of `in`, then every key of `cur` that is new (:103-114) */
+static uint32_t ks_merge(uint32_t in, uint32_t cur) {
+  uint32_t keys[2 * ORC_VC_MAXK], nk = 0;
+  for (int i = 0; i < ORC_VC_MAXK; i++) { uint32_t w = (in >> (4 * i)) & 0xFu; if (w == 0xFu) break; keys[nk++] = w; }
+  for (int i = 0; i < ORC_VC_MAXK; i++) {
+    uint32_t w = (cur >> (4 * i)) & 0xFu; if (w == 0xFu) break;
+    int seen = 0; for (uint32_t x = 0; x < nk; x++) if (keys[x] == w) seen = 1;
+    if (!seen) keys[nk++] = w;
+  }
+  uint32_t out = ORC_KS_NONE;
+  for (uint32_t x = 0; x < nk && x < ORC_VC_MAXK; x++) out = (out & ~(0xFu << (4 * x))) | (keys[x] << (4 * x));
+  return out;
+}
+/* preload (harness sets state directly): keysets NULL = dense */
+void orc_vc_load_rows_ks(orc_vc_t* t, uint64_t n, const uint64_t* id, const uint32_t* field, const uint32_t* clocks, const uint32_t* keysets, const int64_t* val) {
   for (uint64_t i = 0; i < n; i++) {
     orc_vrow* r = vc_find(t, id[i], field[i]);
     if (!r) r = vc_append(t, id[i], field[i]);
     for (uint32_t k = 0; k < t->K; k++) r->clock[k] = clocks[i * t->K + k];
-    r->val = val[i]; r->sparse = 0;
+    r->val = val[i]; r->sparse = 0; r->ks = keysets ? keysets[i] : ks_dense(t->K);
   }
 }
-static unsigned vc_resolve(orc_vc_t* t, uint64_t id, uint32_t field, const uint32_t* c, int64_t v, orc_vrow** out) {
+void orc_vc_load_rows(orc_vc_t* t, uint64_t n, const uint64_t* id, const uint32_t* field, const uint32_t* clocks, const int64_t* val) {
+  orc_vc_load_rows_ks(t, n, id, field, clocks, NULL, val);
+}
+static unsigned vc_resolve(orc_vc_t* t, uint64_t id, uint32_t field, const uint32_t* c, uint32_t cks, int64_t v, orc_vrow** out) {
   orc_vrow* r = vc_find(t, id, field);
   if (!r) {                                  /* "no current state": stored clock is {local: 2}, the incoming clock is dropped */
     r = vc_append(t, id, field);
-    r->clock[t->local] = 2; r->sparse = 1; r->val = v;
+    r->clock[t->local] = 2; r->sparse = 1; r->val = v; r->ks = 0xFFFFFFF0u | t->local;
     *out = r;
     return ORC_FLAG_INCOMING;
   }
@@ -376,7 +396,7 @@ static unsigned vc_resolve(orc_vc_t* t, uint64_t id, uint32_t field, const uint3
     if (c[k] != r->clock[k]) equal = 0;
   }
   const int cmp = (in_ahead && cur_ahead) ? 0 : (in_ahead ? 1 : (cur_ahead ? -1 : 0));
-  const int json_equal = equal && (!r->sparse || t->K == 1);   /* {local:2} has one key, a dense clock K keys */
+  const int json_equal = equal && cks == r->ks;                /* same keys, same order, same counters */
   if (cmp == 0 && json_equal) {                                /* identical clocks: value comparison  :200-233 */
     int vc = cmp3(v, r->val);
     if (vc == 0) return 0;
@@ -385,6 +405,7 @@ static unsigned vc_resolve(orc_vc_t* t, uint64_t id, uint32_t field, const uint3
   }
   if (cmp < 0) return ORC_FLAG_CURRENT | ORC_FLAG_HISTORICAL;  /* :251-263 (the row keeps its clock) */
   for (uint32_t k = 0; k < t->K; k++) if (c[k] > r->clock[k]) r->clock[k] = c[k];   /* merged clock is stored with the update */
+  r->ks = ks_merge(cks, r->ks);
   r->sparse = 0;
   if (cmp > 0) { r->val = v; return ORC_FLAG_INCOMING; }       /* :236-248 */
   if (cmp3(v, r->val) >= 0) r->val = v;                        /* concurrent: mergeValues on non-objects  :266-278, :133-135 */
@@ -392,13 +413,13 @@ static unsigned vc_resolve(orc_vc_t* t, uint64_t id, uint32_t field, const uint3
 }
 /* sequential batch; updated (optional, capacity n) = ascending indices of the last delta per key that caused a store
  * (doUpdate = incoming || no current || concurrent: src/bullet-crt.js:383). Returns their number. */
-uint64_t orc_vc_merge_batch(orc_vc_t* t, uint64_t n, const uint64_t* id, const uint32_t* field, const uint32_t* clocks, const int64_t* val,
-                            uint8_t* flags, uint32_t* updated) {
+uint64_t orc_vc_merge_batch_ks(orc_vc_t* t, uint64_t n, const uint64_t* id, const uint32_t* field, const uint32_t* clocks, const uint32_t* keysets,
+                               const int64_t* val, uint8_t* flags, uint32_t* updated) {
   t->stamp++;
   uint8_t* mark = (uint8_t*)calloc(n ? n : 1, 1);
   for (uint64_t j = 0; j < n; j++) {
     orc_vrow* r;
-    unsigned f = vc_resolve(t, id[j], field[j], clocks + j * t->K, val[j], &r);
+    unsigned f = vc_resolve(t, id[j], field[j], clocks + j * t->K, keysets ? keysets[j] : ks_dense(t->K), val[j], &r);
     if (flags) flags[j] = (uint8_t)f;
     if (f & (ORC_FLAG_INCOMING | ORC_FLAG_CONCURRENT)) {
       if (r->stamp == t->stamp) mark[r->last_j] = 0;
@@ -409,6 +430,17 @@ uint64_t orc_vc_merge_batch(orc_vc_t* t, uint64_t n, const uint64_t* id, const u
   for (uint64_t j = 0; j < n; j++) if (mark[j]) { if (updated) updated[w] = (uint32_t)j; w++; }
   free(mark);
   return w;
+}
+uint64_t orc_vc_merge_batch(orc_vc_t* t, uint64_t n, const uint64_t* id, const uint32_t* field, const uint32_t* clocks, const int64_t* val,
+                            uint8_t* flags, uint32_t* updated) {
+  return orc_vc_merge_batch_ks(t, n, id, field, clocks, NULL, val, flags, updated);
+}
+int orc_vc_get_row_ks(orc_vc_t* t, uint64_t id, uint32_t field, uint32_t* clock_out, uint32_t* ks_out, int64_t* val, int* sparse) {
+  orc_vrow* r = vc_find(t, id, field);
+  if (!r) return 0;
+  for (uint32_t k = 0; k < t->K; k++) clock_out[k] = r->clock[k];
+  *val = r->val; if (sparse) *sparse = r->sparse; if (ks_out) *ks_out = r->ks;
+  return 1;
 }
 int orc_vc_get_row(orc_vc_t* t, uint64_t id, uint32_t field, uint32_t* clock_out, int64_t* val, int* sparse) {
   orc_vrow* r = vc_find(t, id, field);

@@ -252,6 +252,58 @@ function runVcStream(spec) {
     flags_b64: flags.toString("base64"), updated: Array.from(last.values()).sort((x, y) => x - y), final_rows: finalRows };
 }
 
+/* N4 with arbitrary KEY SETS: every clock is an object over a random ordered subset of the writers (any order, any number of them, {} included).
+ * What the fixture pins beyond the dense streams: a missing key counts as 0 in the dominance test (src/bullet-crt.js:76-79), clocks with equal
+ * counters but different key sets / key orders are NOT identical (JSON.stringify, :200-203) and fall through to the concurrent branch, and the
+ * stored clock's key order after a merge is the incoming clock's keys followed by the stored clock's other keys (:103-114).
+ * Rows: [row, keys (writer indices in the object's key order), counters (K, 0 for a writer the clock does not name), value]. */
+function runVcKeysetStream(spec) {
+  const rng = xorshift32(spec.seed);
+  const crt = newCrt();
+  const state = new Map();
+  const K = WRITERS.length;
+  const randClock = () => {
+    const order = WRITERS.map((_, i) => i);
+    for (let i = K - 1; i > 0; i--) { const j = rng() % (i + 1); const t = order[i]; order[i] = order[j]; order[j] = t; }
+    const cnt = rng() % 100 < spec.full_pct ? K : rng() % (K + 1);
+    const keys = order.slice(0, cnt), comps = new Array(K).fill(0), obj = {};
+    for (const k of keys) { comps[k] = rng() % spec.CMAX; obj[WRITERS[k]] = comps[k]; }
+    return { keys, comps, obj };
+  };
+  const keysOf = (clock) => Object.keys(clock).map((w) => WRITERS.indexOf(w));
+  const resident = [];
+  for (let r = 0; r < spec.R; r++) {
+    const c = randClock();
+    const val = (rng() % spec.VR) - spec.VOFF;
+    resident.push([r, c.keys, c.comps, val]);
+    state.set("k" + r, { value: val, clock: c.obj, row: r });
+  }
+  const deltas = [];
+  const flags = Buffer.alloc(spec.D);
+  const last = new Map();
+  for (let j = 0; j < spec.D; j++) {
+    const u = rng() % 100;
+    let row;
+    if (u < spec.insert_pct) row = spec.R + (rng() % spec.ins_space);
+    else if (u < spec.insert_pct + spec.hot_pct) row = rng() % spec.H;
+    else row = rng() % Math.max(spec.R, 1);
+    const c = randClock();
+    const val = (rng() % spec.VR) - spec.VOFF;
+    deltas.push([row, c.keys, c.comps, val]);
+    const key = "k" + row;
+    const cur = state.get(key);
+    const r = crt.processUpdate(key, val, c.obj, cur ? cur.value : undefined, cur ? cur.clock : undefined);
+    const d = r.decision;
+    flags[j] = flagsOf(d);
+    if (d.incoming || !cur || d.concurrent) { state.set(key, { value: r.value, clock: r.vectorClock, row }); last.set(key, j); }
+  }
+  const finalRows = [];
+  for (const [, st] of state) finalRows.push([st.row, keysOf(st.clock), compsOf(st.clock), st.value]);
+  finalRows.sort((x, y) => x[0] - y[0]);
+  return { kind: "vc_keyset_stream", source: "reference BulletCRT.processUpdate with clocks over ordered subsets of the writers {a,b,w}, bullet.id = 'w'", writers: WRITERS, spec,
+    resident, deltas, flags_b64: flags.toString("base64"), updated: Array.from(last.values()).sort((x, y) => x - y), final_rows: finalRows };
+}
+
 /* ------------------------------------------------------------------ L1 / query fixtures through the real Bullet facade */
 function quiet(fn) { const l = console.log; console.log = () => {}; try { return fn(); } finally { console.log = l; } }
 function newBullet(extra) {
@@ -522,6 +574,174 @@ function genSyncNodeSemantics() {
     chunks, after, queries };
 }
 
+/* ------------------------------------------------------------------ g10: synced objects with fields of every JSON type
+ * The node-level resolution never looks at an object's fields (two objects under identical clocks: compare() is +1, src/bullet-crt.js:11-15), so the
+ * batch path takes ANY plain object, not only all-integer ones. This fixture pins that on the reference's own loop: strings, nested objects, arrays,
+ * booleans and null as fields; whole-node replacement dropping such fields; the ONE case where an object entry's fate depends on the stored value — an
+ * identical clock against a stored STRING, compared as text ("[object Object]" < "alpha" keeps the string, "ALPHA" loses) —; ties against a stored
+ * number, null (a deleted node), {} and the object an array entry turns into (the loop spreads it: src/bullet-network-sync.js:560-563). */
+function genSyncMixedValues() {
+  const Sync = require(path.join(REF, "src", "bullet-network-sync.js"));
+  const b = newBullet({ enableIndexing: true });
+  const chunks = [
+    [ /* chunk 1: first sight; primitives are local writes */
+      { path: "users/u1", data: { name: "Ann", age: 30, tags: ["a", "b"], addr: { city: "X", zip: 10115 }, active: true, nick: null }, vectorClock: { w: 100 } },
+      { path: "users/u2", data: { name: "Bob", age: 41 }, vectorClock: { w: 100 } },
+      { path: "users/u3", data: { name: "Cy", age: "52" }, vectorClock: { w: 100 } },
+      { path: "cfg/name", data: "alpha", vectorClock: { w: 100 } },
+      { path: "cfg/up", data: "ALPHA", vectorClock: { w: 100 } },
+      { path: "cfg/list", data: [1, 2, 3], vectorClock: { w: 100 } },
+      { path: "cfg/num", data: 7, vectorClock: { w: 100 } },
+      { path: "m/e", data: {}, vectorClock: { w: 100 } },
+    ],
+    [ /* chunk 2: replacement, ties on {w:2} against every kind of stored value, a historical write */
+      { path: "users/u1", data: { name: "Anna", age: 31 }, vectorClock: { w: 150 } },
+      { path: "users/u2", data: { name: "Bobby" }, vectorClock: { w: 2 } },
+      { path: "users/u3", data: { name: "Cyd", age: 53 }, vectorClock: { w: 1 } },
+      { path: "cfg/name", data: { v: 1 }, vectorClock: { w: 3 } },            /* a primitive's local write left {w:3} (create 1, two increments) */
+      { path: "cfg/up", data: { v: 1 }, vectorClock: { w: 3 } },
+      { path: "cfg/num", data: { v: 2 }, vectorClock: { w: 3 } },
+      { path: "cfg/list", data: { v: 3 }, vectorClock: { w: 2 } },
+      { path: "m/e", data: { x: 1, note: "was empty" }, vectorClock: { w: 2 } },
+    ],
+    [ /* chunk 3: a deletion and a tie on the clock it leaves behind, a string where an integer was, a node created and replaced in one chunk,
+         a dominating object over the stored string */
+      { path: "users/u1", deleted: true, vectorClock: { w: 160 } },
+      { path: "users/u1", data: { name: "Zed", age: 9 }, vectorClock: { w: 151 } },
+      { path: "users/u2", data: { name: "B3", age: "x" }, vectorClock: { w: 200 } },
+      { path: "users/u4", data: { name: "Dee", age: 61, addr: { city: "Y" } }, vectorClock: { w: 5 } },
+      { path: "users/u4", data: { age: 62 }, vectorClock: { w: 5 } },
+      { path: "cfg/name", data: { v: 2 }, vectorClock: { w: 4 } },
+    ],
+    [ /* chunk 4: the former string node is an ordinary node now; an integer where a string was */
+      { path: "cfg/name", data: { v: 3, label: "three" }, vectorClock: { w: 4 } },
+      { path: "users/u3", data: { age: 54 }, vectorClock: { w: 2 } },
+      { path: "users/u5", data: { name: "Eve", age: 70, prefs: { theme: "dark", size: 12 } }, vectorClock: { w: 1 } },
+      { path: "cfg/n2", data: 9, vectorClock: { w: 1 } },
+      { path: "cfg/n3", data: 9, vectorClock: { w: 1 } },
+    ],
+    [ /* chunk 5: what a LOSING entry leaves behind. resolve() stores the merged clock of every entry in crt.vectorClocks (src/bullet-crt.js:193-198); for an
+         entry that loses this is a fresh object, no longer the one meta[path] holds — so the next local write (a primitive here) increments the copy and
+         dominates (cfg/n2: 5 is accepted), where without the losing entry it increments meta's own clock in place, meets "identical clocks" and is decided by
+         value (cfg/n3: 5 < 9 is refused) */
+      { path: "cfg/n2", data: { x: 1 }, vectorClock: { w: 1 } },
+      { path: "cfg/n2", data: 5, vectorClock: { w: 1 } },
+      { path: "cfg/n3", data: 5, vectorClock: { w: 1 } },
+      { path: "cfg/n3", data: { x: 2 }, vectorClock: { w: 3 } },      /* the refused write has still moved cfg/n3's clock to {w:4}: {w:3} is historical now */
+      /* ... and in the store: every resolution starts with _getData(path), which replaces a falsy value on the way by {} (src/bullet.js:115-129) — the null
+         of a deleted node becomes {} even though the entry that looked at it loses */
+      { path: "users/u6", deleted: true, vectorClock: { w: 1 } },
+      { path: "users/u6", data: { name: "late" }, vectorClock: { w: 1 } },
+    ],
+  ];
+  const fake = { bullet: b };
+  const after = [];
+  quiet(() => {
+    for (const c of chunks) {
+      Sync.prototype._processSyncEntries.call(fake, JSON.parse(JSON.stringify(c)), "peer-1");
+      const meta = {};
+      for (const k of Object.keys(b.meta)) meta[k] = { vectorClock: JSON.parse(JSON.stringify(b.meta[k].vectorClock)), source: b.meta[k].source };
+      after.push({ store: JSON.parse(JSON.stringify(b.store)), meta });
+    }
+  });
+  const paths = (nodes) => nodes.map((n) => n.path);
+  const queries = [];
+  quiet(() => {
+    queries.push({ op: "range", path: "users", field: "age", args: [0, 100], paths: paths(b.range("users", "age", 0, 100)) });
+    queries.push({ op: "equals", path: "users", field: "age", args: [62], paths: paths(b.equals("users", "age", 62)) });
+    queries.push({ op: "equals", path: "users", field: "age", args: [41], paths: paths(b.equals("users", "age", 41)) });
+    queries.push({ op: "range", path: "cfg", field: "v", args: [0, 10], paths: paths(b.range("cfg", "v", 0, 10)) });
+    queries.push({ op: "range", path: "m", field: "x", args: [0, 10], paths: paths(b.range("m", "x", 0, 10)) });
+    queries.push({ op: "count", path: "users", field: "age", args: [54], count: b.query.count("users", "age", 54) });
+  });
+  return { kind: "sync_mixed_values", source: "reference BulletNetworkSync._processSyncEntries + BulletQuery on a real Bullet (id 'w', network disabled)", id: "w",
+    chunks, after, queries };
+}
+
+/* ------------------------------------------------------------------ g12: NODE-level semantics under multi-writer clocks (N4)
+ * The reference's sync loop on objects whose clocks name several writers ({a, b, w}; this peer is 'w'), in every key order and with keys missing:
+ * dominance with missing keys counted as 0, whole-node replacement, CONCURRENT clocks -> mergeValues (the stored object's fields, overlaid field by
+ * field with compare(in, cur) >= 0 ? in : cur, new fields appended: src/bullet-crt.js:122-153) and the merged clock's key order ({...incoming}, then the
+ * stored clock's other keys: :103-114), equal counters under different key sets (NOT identical: JSON.stringify :200-203 -> concurrent), the {w:2} of a
+ * first sight against multi-writer clocks, several entries for one node in one chunk, deletions (a local write: the stored clock's own component is
+ * incremented in place), strings and nested objects as fields. Store and per-path clock (as an ordered [key, counter] list) + source after every chunk. */
+function genVcNodeSemantics() {
+  const Sync = require(path.join(REF, "src", "bullet-network-sync.js"));
+  const b = newBullet({ enableIndexing: true });
+  const chunks = [
+    [ /* chunk 1: first sight: every node stores {w:2}, whatever clock came with it */
+      { path: "doc/a", data: { title: "A", rev: 1, size: 10 }, vectorClock: { a: 1, b: 0, w: 0 } },
+      { path: "doc/b", data: { title: "B", rev: 1 }, vectorClock: { b: 4 } },
+      { path: "doc/c", data: { rev: 1, tags: ["x"], meta: { k: 1 } }, vectorClock: { w: 1, a: 1 } },
+      { path: "doc/d", data: { rev: 1, size: 5 }, vectorClock: {} },
+      { path: "doc/e", data: { rev: 1 }, vectorClock: { a: 3, b: 3, w: 3 } },
+      { path: "doc/f", data: { rev: 1, size: 1 }, vectorClock: { w: 9 } },
+    ],
+    [ /* chunk 2 against {w:2}: dominating (w >= 2 and something more), concurrent (w < 2 but another writer ahead), historical, equal counters with
+         another key set (concurrent: merged), the identical clock (tie: incoming object) */
+      { path: "doc/a", data: { title: "A2", rev: 2 }, vectorClock: { a: 2, w: 2 } },
+      { path: "doc/b", data: { rev: 2, size: 7 }, vectorClock: { b: 5 } },
+      { path: "doc/c", data: { rev: 0 }, vectorClock: { w: 1 } },
+      { path: "doc/d", data: { rev: 3, extra: 1 }, vectorClock: { w: 2, a: 0 } },
+      { path: "doc/e", data: { rev: 9, note: "tie" }, vectorClock: { w: 2 } },
+      { path: "doc/f", data: { rev: 4 }, vectorClock: { b: 0, w: 2, a: 0 } },
+    ],
+    [ /* chunk 3: several entries per node in one chunk: concurrent after concurrent (the merged clock grows), then a dominating one that replaces the
+         merged node, key orders that differ from the stored one */
+      { path: "doc/b", data: { rev: 1, size: 9, who: "a" }, vectorClock: { a: 7 } },
+      { path: "doc/b", data: { rev: 5, who: "w" }, vectorClock: { w: 3, b: 1 } },
+      { path: "doc/b", data: { rev: 6 }, vectorClock: { w: 3, b: 5, a: 7 } },
+      { path: "doc/b", data: { rev: 7, fin: 1 }, vectorClock: { a: 7, b: 5, w: 3 } },
+      { path: "doc/a", data: { rev: 3, size: 11 }, vectorClock: { b: 1 } },
+      { path: "doc/a", data: { rev: 1, size: 99, title: "old" }, vectorClock: { a: 1 } },
+      { path: "doc/g", data: { rev: 1 }, vectorClock: { b: 2 } },
+      { path: "doc/g", data: { rev: 2, size: 3 }, vectorClock: { b: 2 } },
+      { path: "doc/g", data: { rev: 0, size: 8, name: "g" }, vectorClock: { a: 1 } },
+    ],
+    [ /* chunk 4: a deletion (local write: the stored clock's w component + 1), entries around it, a re-creation */
+      { path: "doc/a", deleted: true, vectorClock: { w: 50 } },
+      { path: "doc/a", data: { rev: 8 }, vectorClock: { a: 2, w: 3, b: 1 } },
+      { path: "doc/a", data: { rev: 9, size: 1 }, vectorClock: { a: 2, b: 1, w: 3 } },
+      { path: "doc/c", data: { rev: 5, size: 2 }, vectorClock: { a: 9, w: 2 } },
+      { path: "doc/c", data: { size: 4, rev: 4 }, vectorClock: { b: 1, w: 2 } },
+      { path: "doc/h", data: { rev: 1, size: 6 }, vectorClock: { a: 1, b: 1 } },
+      { path: "doc/h", data: { rev: 2 }, vectorClock: { a: 1, b: 1, w: 1 } },
+      { path: "doc/h", data: { rev: 3, size: 2 }, vectorClock: { b: 1, w: 2, a: 1 } },
+    ],
+    [ /* chunk 5: what a LOSING entry leaves behind in crt.vectorClocks (the merged clock, a fresh object with the incoming clock's keys first: :193-198):
+         the deletion behind it — a local write — increments that copy, dominates and stores ITS key set; without a losing entry in front (doc/d) the
+         deletion increments meta's own clock in place */
+      { path: "doc/e", data: { rev: 0 }, vectorClock: { a: 0, w: 1 } },
+      { path: "doc/e", deleted: true, vectorClock: { w: 1 } },
+      { path: "doc/g", data: { rev: 9 }, vectorClock: { w: 1, b: 1 } },
+      { path: "doc/g", deleted: true, vectorClock: { w: 1 } },
+      { path: "doc/d", deleted: true, vectorClock: { w: 1 } },
+      { path: "doc/g", data: { rev: 10, back: 1 }, vectorClock: { w: 3, b: 2, a: 1 } },
+      { path: "doc/e", data: { rev: 1 }, vectorClock: { w: 1 } },      /* loses against the deleted node, whose null its _getData has turned into {} by then */
+    ],
+  ];
+  const fake = { bullet: b };
+  const after = [];
+  quiet(() => {
+    for (const c of chunks) {
+      Sync.prototype._processSyncEntries.call(fake, JSON.parse(JSON.stringify(c)), "peer-1");
+      const meta = {};
+      for (const k of Object.keys(b.meta)) meta[k] = { clock: Object.keys(b.meta[k].vectorClock).map((w) => [w, b.meta[k].vectorClock[w]]), source: b.meta[k].source };
+      after.push({ store: JSON.parse(JSON.stringify(b.store)), meta });
+    }
+  });
+  const paths = (nodes) => nodes.map((n) => n.path);
+  const queries = [];
+  quiet(() => {
+    queries.push({ op: "range", path: "doc", field: "rev", args: [0, 100], paths: paths(b.range("doc", "rev", 0, 100)) });
+    queries.push({ op: "range", path: "doc", field: "size", args: [0, 100], paths: paths(b.range("doc", "size", 0, 100)) });
+    queries.push({ op: "equals", path: "doc", field: "rev", args: [7], paths: paths(b.equals("doc", "rev", 7)) });
+    queries.push({ op: "count", path: "doc", field: "size", args: [2], count: b.query.count("doc", "size", 2) });
+  });
+  return { kind: "vc_node_semantics", source: "reference BulletNetworkSync._processSyncEntries + BulletQuery on a real Bullet (id 'w', network disabled), multi-writer clocks", id: "w",
+    writers: ["a", "b", "w"], chunks, after, queries };
+}
+
 /* ------------------------------------------------------------------ g7: a directory written by the reference's file storage (N3)
  * src/bullet-file-storage.js:170-210 writes store.json / meta.json / log.json; the files themselves are the fixture
  * (tests/golden/g7_storage_dir/). */
@@ -573,12 +793,16 @@ function main() {
   write("g6_vc_unique_2k.json", runVcStream({ seed: 61, R: 2000, D: 1500, CMAX: 4, VR: 5, VOFF: 2, insert_pct: 10, hot_pct: 0, H: 1, ins_space: 100000 }));
   write("g6_vc_dups_500.json", runVcStream({ seed: 62, R: 500, D: 4000, CMAX: 3, VR: 3, VOFF: 1, insert_pct: 15, hot_pct: 30, H: 8, ins_space: 60 }));
   write("g6_vc_empty_start.json", runVcStream({ seed: 63, R: 0, D: 1500, CMAX: 3, VR: 3, VOFF: 1, insert_pct: 100, hot_pct: 0, H: 1, ins_space: 200 }));
+  write("g11_vc_keysets_2k.json", runVcKeysetStream({ seed: 111, R: 2000, D: 3000, CMAX: 4, VR: 5, VOFF: 2, insert_pct: 10, hot_pct: 0, H: 1, ins_space: 100000, full_pct: 30 }));
+  write("g11_vc_keysets_hot.json", runVcKeysetStream({ seed: 112, R: 300, D: 3000, CMAX: 40, VR: 3, VOFF: 1, insert_pct: 10, hot_pct: 40, H: 6, ins_space: 40, full_pct: 20 }));
   write("g4_l1_ops.json", genL1());
   write("g5_query_example.json", genQueryExample());
   write("g5_query_seeded_2k.json", genQuerySeeded(2000, 4711, true));
   write("g5_query_seeded_100k.json", genQuerySeeded(100000, 4712, false));
   write("g8_sync_chunk.json", genSyncChunk());
   write("g9_sync_node_semantics.json", genSyncNodeSemantics());
+  write("g10_sync_mixed_values.json", genSyncMixedValues());
+  write("g12_vc_node_semantics.json", genVcNodeSemantics());
   genStorageDir(path.join(OUT, "g7_storage_dir"));
 }
 

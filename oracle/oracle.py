@@ -212,6 +212,9 @@ class OracleVC:
         L.orc_vc_merge_batch.argtypes = [C.c_void_p, C.c_uint64, u64p, u32p, u32p, i64p, u8p, u32p]; L.orc_vc_merge_batch.restype = C.c_uint64
         L.orc_vc_get_row.argtypes = [C.c_void_p, C.c_uint64, C.c_uint32, u32p, C.POINTER(C.c_int64), C.POINTER(C.c_int)]; L.orc_vc_get_row.restype = C.c_int
         L.orc_vc_dump_rows.argtypes = [C.c_void_p, C.c_uint64, u64p, u32p, u32p, i64p]; L.orc_vc_dump_rows.restype = C.c_uint64
+        L.orc_vc_load_rows_ks.argtypes = [C.c_void_p, C.c_uint64, u64p, u32p, u32p, u32p, i64p]
+        L.orc_vc_merge_batch_ks.argtypes = [C.c_void_p, C.c_uint64, u64p, u32p, u32p, u32p, i64p, u8p, u32p]; L.orc_vc_merge_batch_ks.restype = C.c_uint64
+        L.orc_vc_get_row_ks.argtypes = [C.c_void_p, C.c_uint64, C.c_uint32, u32p, u32p, C.POINTER(C.c_int64), C.POINTER(C.c_int)]; L.orc_vc_get_row_ks.restype = C.c_int
         self._L, self.K = L, K
         self._h = C.c_void_p(L.orc_vc_create(K, local))
         assert self._h
@@ -231,23 +234,28 @@ class OracleVC:
         clocks = np.ascontiguousarray(clocks, np.uint32).reshape(len(id), self.K); val = np.ascontiguousarray(val, np.int64)
         return id, field, clocks, val
 
-    def load_rows(self, id, field, clocks, val):
+    def load_rows(self, id, field, clocks, val, keysets=None):
         id, field, clocks, val = self._args(id, field, clocks, val)
-        self._L.orc_vc_load_rows(self._h, len(id), _p(id, C.c_uint64), _p(field, C.c_uint32), _p(clocks, C.c_uint32), _p(val, C.c_int64))
+        ks = None if keysets is None else np.ascontiguousarray(keysets, np.uint32)
+        self._L.orc_vc_load_rows_ks(self._h, len(id), _p(id, C.c_uint64), _p(field, C.c_uint32), _p(clocks, C.c_uint32),
+                                    None if ks is None else _p(ks, C.c_uint32), _p(val, C.c_int64))
 
-    def merge_batch(self, id, field, clocks, val):
-        """-> (flags u8[n] with bit 8 = concurrent, updated u32[w] ascending)"""
+    def merge_batch(self, id, field, clocks, val, keysets=None):
+        """-> (flags u8[n] with bit 8 = concurrent, updated u32[w] ascending). keysets: u32[n] key-set words (None = all K writers, in order)"""
         id, field, clocks, val = self._args(id, field, clocks, val)
         n = len(id)
+        ks = None if keysets is None else np.ascontiguousarray(keysets, np.uint32)
         flags = np.zeros(max(n, 1), np.uint8); upd = np.zeros(max(n, 1), np.uint32)
-        w = self._L.orc_vc_merge_batch(self._h, n, _p(id, C.c_uint64), _p(field, C.c_uint32), _p(clocks, C.c_uint32), _p(val, C.c_int64),
-                                       _p(flags, C.c_uint8), _p(upd, C.c_uint32))
+        w = self._L.orc_vc_merge_batch_ks(self._h, n, _p(id, C.c_uint64), _p(field, C.c_uint32), _p(clocks, C.c_uint32),
+                                          None if ks is None else _p(ks, C.c_uint32), _p(val, C.c_int64), _p(flags, C.c_uint8), _p(upd, C.c_uint32))
         return flags[:n], upd[:w].copy()
 
-    def get_row(self, id, field):
-        c = np.zeros(self.K, np.uint32); v = C.c_int64(); sp = C.c_int()
-        ok = self._L.orc_vc_get_row(self._h, int(id), int(field), _p(c, C.c_uint32), C.byref(v), C.byref(sp))
-        return (c.tolist(), v.value, bool(sp.value)) if ok else None
+    def get_row(self, id, field, with_keyset=False):
+        c = np.zeros(self.K, np.uint32); v = C.c_int64(); sp = C.c_int(); ks = np.zeros(1, np.uint32)
+        ok = self._L.orc_vc_get_row_ks(self._h, int(id), int(field), _p(c, C.c_uint32), _p(ks, C.c_uint32), C.byref(v), C.byref(sp))
+        if not ok:
+            return None
+        return (c.tolist(), v.value, bool(sp.value), int(ks[0])) if with_keyset else (c.tolist(), v.value, bool(sp.value))
 
     def dump_rows(self):
         n = len(self)

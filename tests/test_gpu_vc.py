@@ -51,6 +51,83 @@ def test_vc_device_matches_reference_golden(name):
     e.close()
 
 
+@pytest.mark.parametrize("name", ["g11_vc_keysets_2k.json", "g11_vc_keysets_hot.json"])
+def test_vc_device_matches_reference_on_arbitrary_key_sets(name):
+    """Clocks over ordered subsets of the writers, made by the real reference: flags, updating deltas, and every final row's counters, value and
+    key order (bmx_vc_*_ks)."""
+    g = load_golden(name)
+    K = len(g["writers"]); local = g["writers"].index("w")
+    e = bmx.EngineVC(max(4096, 2 * (len(g["resident"]) + len(g["deltas"]))), K, local)
+    r = g["resident"]
+    if r:
+        e.load_rows([keyid(x[0]) for x in r], [F0] * len(r), [x[2] for x in r], [x[3] for x in r], keysets=[bmx.keyset(x[1]) for x in r])
+    d = g["deltas"]
+    flags, upd = e.merge_batch([keyid(x[0]) for x in d], [F0] * len(d), [x[2] for x in d], [x[3] for x in d], keysets=[bmx.keyset(x[1]) for x in d])
+    assert np.array_equal(flags, np.frombuffer(base64.b64decode(g["flags_b64"]), dtype=np.uint8))
+    assert upd.tolist() == g["updated"]
+    assert e.row_count() == len(g["final_rows"])
+    ids = np.array([keyid(x[0]) for x in g["final_rows"]], np.uint64)
+    clocks, val, st, ks = e.get_rows(ids, np.full(len(ids), F0, np.uint32), with_keysets=True)
+    for k, (row, keys, clock, v) in enumerate(g["final_rows"]):
+        assert clocks[k].tolist() == clock and val[k] == v and bmx.keyset_writers(ks[k]) == keys, (row, clocks[k], clock, val[k], v, hex(ks[k]), keys)
+    e.close()
+
+
+def _rand_keysets(rng, n, K, clocks, full=0.3):
+    """random ordered subsets of the K writers; counters of the writers a clock does not name are zeroed in place"""
+    ks = np.zeros(n, np.uint32)
+    for j in range(n):
+        order = rng.permutation(K)
+        cnt = K if rng.random() < full else int(rng.integers(0, K + 1))
+        keys = order[:cnt].tolist()
+        mask = np.zeros(K, bool); mask[keys] = True
+        clocks[j, ~mask] = 0
+        ks[j] = bmx.keyset(keys)
+    return ks
+
+
+@pytest.mark.parametrize("K,local", [(1, 0), (2, 0), (3, 2), (8, 5)])
+def test_vc_random_key_sets_match_oracle(K, local):
+    """seeded batches with hot keys (lists longer than the in-lane limit go through k_vc_resolve_long), a keyed preload, several batches"""
+    rng = np.random.default_rng(300 + K)
+    e = bmx.EngineVC(40000, K, local); o = OracleVC(K, local)
+    ids, fields, clocks, val = _rand_batch(rng, 3000, 2000, K, 3, 3)
+    ks = _rand_keysets(rng, len(ids), K, clocks)
+    e.load_rows(ids, fields, clocks, val, keysets=ks); o.load_rows(ids, fields, clocks, val, keysets=ks)
+    seen = set(zip(ids.tolist(), fields.tolist()))
+    for b in range(5):
+        ids, fields, clocks, val = _rand_batch(rng, 5000, 3000, K, 3 + 5 * b, 3, hot=0.3 if b % 2 else 0.0)
+        ks = _rand_keysets(rng, len(ids), K, clocks)
+        f1, u1 = e.merge_batch(ids, fields, clocks, val, keysets=ks)
+        f2, u2 = o.merge_batch(ids, fields, clocks, val, keysets=ks)
+        assert np.array_equal(f1, f2), (b, np.nonzero(f1 != f2)[0][:10])
+        assert np.array_equal(u1, u2), b
+        assert e.row_count() == len(o)
+        seen.update(zip(ids.tolist(), fields.tolist()))
+    keys = sorted(seen)
+    kid = np.array([k[0] for k in keys], np.uint64); kf = np.array([k[1] for k in keys], np.uint32)
+    clocks, val, st, ks = e.get_rows(kid, kf, with_keysets=True)
+    for k in range(len(keys)):
+        c, v, sparse, oks = o.get_row(int(kid[k]), int(kf[k]), with_keyset=True)
+        assert clocks[k].tolist() == c and val[k] == v and int(ks[k]) == oks, (k, clocks[k], c, val[k], v, hex(int(ks[k])), hex(oks))
+    e.close()
+
+
+def test_vc_malformed_key_sets_are_refused():
+    K, local = 3, 0
+    ids = np.array([keyid(1)], np.uint64); f = np.array([F0], np.uint32); val = np.array([1], np.int64)
+    for keys, clock in [([3], [0, 0, 0]), ([1, 1], [0, 1, 0]), ([0], [1, 1, 0])]:      # unknown writer, a writer twice, a counter of an unnamed writer
+        e = bmx.EngineVC(4096, K, local)
+        with pytest.raises(bmx.BmxError) as ei:
+            e.merge_batch(ids, f, np.array([clock], np.uint32), val, keysets=[bmx.keyset(keys)])
+        assert ei.value.code == bmx.ERR_RANGE
+        e.close()
+    e = bmx.EngineVC(4096, K, local)
+    with pytest.raises(bmx.BmxError):
+        e.merge_batch(ids, f, np.array([[0, 0, 0]], np.uint32), val, keysets=[0xFFFFF0F1])        # a key behind the end mark
+    e.close()
+
+
 def _rand_batch(rng, n, nkeys, K, cmax, vr, hot=0.0, nfields=2):
     rows = rng.integers(0, nkeys, n)
     if hot > 0:
