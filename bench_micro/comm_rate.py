@@ -28,11 +28,18 @@ for N in (1, 2, 4, 8):
         c.sync()
         dt = (time.perf_counter() - t0) / (NB - 1)
         hb = [synth.big_deltas(D, R, seed=7, insert_pct=10, unique=True, batch=20 + b, drift=62500) for b in range(8)]
-        c.merge(*hb[0])
+        keep, *pin = bmx.host_columns(D)          # the caller's arrays in page-locked memory (bmx_host_alloc), refilled per batch like a host that reuses its buffers
+        keep_out = bmx.HostBuffer(4 * D); out = keep_out.array(np.uint32, D)
+        def fill(h):
+            for d, s in zip(pin, h):
+                d[:] = s
+        fill(hb[0]); c.merge(*pin, applied_out=out)
         ts = []
         for h in hb[1:]:
+            fill(h)
             t0 = time.perf_counter()
-            c.merge(*h)
+            c.merge(*pin, applied_out=out)
             ts.append(time.perf_counter() - t0)
-        dth = sorted(ts)[len(ts) // 2]     # median: the first calls on fresh pageable arrays pay the runtime's pinning
-        print("N=%d logical shards on one GPU: device step (1M deltas in all) %.0f us = %.2f G merges/s | host batch of 1M %.0f us = %.2f G/s" % (N, dt * 1e6, D / dt / 1e9, dth * 1e6, D / dth / 1e9))
+        dth = sorted(ts)[len(ts) // 2]
+        print("N=%d logical shards on one GPU: device step (1M deltas in all) %.0f us = %.2f G merges/s | host batch of 1M (page-locked arrays) %.0f us = %.2f G/s" % (N, dt * 1e6, D / dt / 1e9, dth * 1e6, D / dth / 1e9))
+        keep.close(); keep_out.close()

@@ -551,16 +551,19 @@ class Comm:
         id, field, ts, val = _np(id, np.uint64), _np(field, np.uint32), _np(ts, np.int64), _np(val, np.int64)
         self._chk(self.L.bmx_comm_put_rows(self.h, len(id), _ptr(id), _ptr(field), _ptr(ts), _ptr(val)))
 
-    def merge(self, id, field, ts, val, insert_mode=INSERT_REFERENCE):
-        """host batch -> (applied_idx u32[w] ascending indices into the batch, MergeStats summed over the shards)"""
+    def merge(self, id, field, ts, val, insert_mode=INSERT_REFERENCE, applied_out=None):
+        """host batch -> (applied_idx u32[w] ascending indices into the batch, MergeStats summed over the shards).
+        applied_out: a uint32 array of at least n entries to receive the winners (e.g. page-locked: HostBuffer); the result is then a view of it."""
         id, field, ts, val = _np(id, np.uint64), _np(field, np.uint32), _np(ts, np.int64), _np(val, np.int64)
         n = len(id)
-        applied = np.zeros(max(n, 1), np.uint32)
+        if applied_out is not None and (applied_out.dtype != np.uint32 or len(applied_out) < n or not applied_out.flags["C_CONTIGUOUS"]):
+            raise ValueError("applied_out must be a contiguous uint32 array of at least n entries")
+        applied = applied_out if applied_out is not None else np.zeros(max(n, 1), np.uint32)
         na = C.c_uint64(0)
         st = MergeStats()
         self._chk(self.L.bmx_comm_merge(self.h, n, _ptr(id), _ptr(field), _ptr(ts), _ptr(val), int(insert_mode), _ptr(applied),
                                         C.cast(C.byref(na), C.c_void_p), C.cast(C.byref(st), C.c_void_p)))
-        return applied[:na.value].copy(), st
+        return (applied[:na.value] if applied_out is not None else applied[:na.value].copy()), st
 
     def merge_dev(self, batches, insert_mode=INSERT_REFERENCE, slab_records=0):
         """batches[i] = (n, id, field, ts, val): device tensors on shard i's GPU, the deltas shard i originates. Enqueue-only."""
