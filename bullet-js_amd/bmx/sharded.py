@@ -70,6 +70,17 @@ class EngineOps:
 
     direct_capable = True          # bmx_ipc_* / bmx_partition_scatter are available behind this ops object
 
+    def gpu_identity(self, index=None):
+        """(PCI domain, bus, device) of a GPU this process can see — how two processes find out whether they name the same GPU, whatever each calls it"""
+        try:
+            pr = torch.cuda.get_device_properties(self.device.index or 0 if index is None else index)
+            return (int(pr.pci_domain_id), int(pr.pci_bus_id), int(pr.pci_device_id))
+        except Exception:
+            return None
+
+    def visible_gpus(self):
+        return {self.gpu_identity(i): i for i in range(torch.cuda.device_count())}
+
     def empty_records(self, n):
         return torch.empty((max(int(n), 1), 4), dtype=torch.int64, device=self.device)
 
@@ -340,7 +351,7 @@ class ShardedGraph:
             arrived, h_arr = e.ipc_alloc(max(W * 8, 256), uncached=True)
             freed, h_free = e.ipc_alloc(max(W * 8, 256), uncached=True)
             own = dict(recv=recv, arrived=arrived, freed=freed)
-            mine = (self.ops.device.index or 0, os.getpid(), h_recv, h_arr, h_free)
+            mine = (self.ops.device.index or 0, os.getpid(), h_recv, h_arr, h_free, self.ops.gpu_identity() if hasattr(self.ops, "gpu_identity") else None)
         except BmxError as err:
             print("bmx sharded: direct exchange unavailable on rank %d (%s)" % (r, err), file=sys.stderr)
             mine = None
@@ -355,8 +366,17 @@ class ShardedGraph:
                 if g == r:
                     peers[g] = own
                     continue
-                dev_g = infos[g][0]
-                pd = -1 if dev_g == (self.ops.device.index or 0) else dev_g
+                dev_g, pci_g, pci_me = infos[g][0], infos[g][5], infos[r][5]
+                if pci_g is not None and pci_me is not None:
+                    # the peer's GPU as THIS process numbers it: ranks need not number the GPUs alike (per-rank visibility masks)
+                    if pci_g == pci_me:
+                        pd = -1
+                    else:
+                        pd = self.ops.visible_gpus().get(pci_g)
+                        if pd is None:
+                            raise BmxError(-1, "rank %d's GPU %s is not visible to this process: no peer access" % (g, pci_g))
+                else:
+                    pd = -1 if dev_g == (self.ops.device.index or 0) else dev_g
                 ptrs = dict(recv=e.ipc_open(infos[g][2], pd), arrived=e.ipc_open(infos[g][3], pd), freed=e.ipc_open(infos[g][4], pd))
                 opened.extend(ptrs.values())
                 peers[g] = ptrs
