@@ -97,10 +97,6 @@ struct bmx_ctx {
   uint32_t* scan_mask = nullptr;      // scan scratch: one match bit per index row
   uint32_t* scan_counts = nullptr;    // scan scratch: matches per 8192-row block (+ total)
   uint64_t scan_blocks_cap = 0;
-  unsigned long long* scan_status = nullptr;   // one-launch scans: a status word per 8192-row block (k_scan_fused), never cleared: words carry the launch's epoch
-  uint32_t* scan_ticket = nullptr;             // ... and the ticket counter workgroups number themselves with (zero between launches)
-  uint32_t scan_epoch = 0;
-  bool scan_two_pass = false;                  // BMX_SCAN_TWO_PASS=1: the mask + emit pair of launches instead (kept for A/B runs)
   bool fixed_capacity = false;
   uint64_t nbatch = 0;
   uint32_t* part_counts = nullptr;    // PART_MAX_SHARDS * PART_BLOCKS
@@ -735,29 +731,12 @@ int ensure_scan_scratch(bmx_ctx* ctx, uint64_t n) {
   uint64_t nb = (n + SCAN_BLOCK_ELEMS - 1) / SCAN_BLOCK_ELEMS;
   if (nb <= ctx->scan_blocks_cap) return BMX_OK;
   HIPCHK(hipStreamSynchronize(ctx->stream));
-  dev_free(ctx->scan_mask); dev_free(ctx->scan_counts); dev_free(ctx->scan_status);
+  dev_free(ctx->scan_mask); dev_free(ctx->scan_counts);
   ctx->scan_blocks_cap = 0;
   uint64_t cap = nb + nb / 4 + 16;
   int rc;
-  if ((rc = dev_alloc(ctx, &ctx->scan_mask, cap * (SCAN_BLOCK_ELEMS / 32))) || (rc = dev_alloc(ctx, &ctx->scan_counts, cap + 1)) ||
-      (rc = dev_alloc(ctx, &ctx->scan_status, cap))) return rc;
-  if (!ctx->scan_ticket) {
-    if ((rc = dev_alloc(ctx, &ctx->scan_ticket, 1))) return rc;
-    HIPCHK(hipMemsetAsync(ctx->scan_ticket, 0, sizeof(uint32_t), ctx->stream));
-  }
-  HIPCHK(hipMemsetAsync(ctx->scan_status, 0, cap * sizeof(unsigned long long), ctx->stream));   // epoch 0 is never a launch's epoch
-  ctx->scan_epoch = 0;
+  if ((rc = dev_alloc(ctx, &ctx->scan_mask, cap * (SCAN_BLOCK_ELEMS / 32))) || (rc = dev_alloc(ctx, &ctx->scan_counts, cap + 1))) return rc;
   ctx->scan_blocks_cap = cap;
-  return BMX_OK;
-}
-
-// the look-back state of the next one-launch scan
-int next_scan_look(bmx_ctx* ctx, ScanLook* L) {
-  if (ctx->scan_epoch >= LOOK_EPOCH_MAX) {     // epochs wrap: forget every word once per 4M scans
-    HIPCHK(hipMemsetAsync(ctx->scan_status, 0, ctx->scan_blocks_cap * sizeof(unsigned long long), ctx->stream));
-    ctx->scan_epoch = 0;
-  }
-  L->status = ctx->scan_status; L->ticket = ctx->scan_ticket; L->epoch = ++ctx->scan_epoch;
   return BMX_OK;
 }
 
@@ -788,17 +767,7 @@ int run_scan_t(bmx_ctx* ctx, const Pred& P, const Index* ix, void* out_v, uint64
   const uint32_t nb = (uint32_t)((std::max<uint64_t>(ix->n, 1) + SCAN_BLOCK_ELEMS - 1) / SCAN_BLOCK_ELEMS);
   hipEvent_t* se = (ctx->prof_on && ctx->scan_prof_n < PROF_MAX_CALLS && !ctx->scan_ev.empty()) ? &ctx->scan_ev[3 * ctx->scan_prof_n] : nullptr;
   if (se) HIPCHK(hipEventRecord(se[0], ctx->stream));
-  if (!ctx->scan_two_pass && (d_out || d_n)) {
-    // one launch: the column is read once, matches leave from registers at ranks found by a look-back over the workgroups in front (select.h)
-    typename std::conditional<POS, EmitPos, EmitIds>::type Em;
-    if constexpr (POS) Em = EmitPos{d_out, d_cap}; else Em = EmitIds{ix->ids, d_out, d_cap};   // d_out == nullptr: count only
-    using EmT = decltype(Em);
-    ScanLook L;
-    if ((rc = next_scan_look(ctx, &L))) return rc;
-    hipLaunchKernelGGL((k_scan_fused<Pred, EmT, FinishCount>), dim3(nb), dim3(SEL_THREADS), 0, ctx->stream, P, ix->n, nb, L, Em, FinishCount{d_n});
-    LAUNCHCHK("k_scan_fused");
-    if (se) HIPCHK(hipEventRecord(se[1], ctx->stream));
-  } else if (d_out) {
+  if (d_out) {
     // pass 1: one read of the column -> match mask + block counts; pass 2: ids / positions from the mask
     hipLaunchKernelGGL((k_scan_mask<Pred, true>), dim3(nb), dim3(SEL_THREADS), 0, ctx->stream, P, ix->n, ctx->scan_mask, ctx->scan_counts);
     LAUNCHCHK("k_scan_mask");
@@ -938,7 +907,6 @@ int bmx_create_ex(int device, uint64_t capacity_rows, uint32_t max_load_pct, uin
     std::memset(ctx->stg_tails, 0, 2 * sizeof(SmallOut));
     for (int i = 0; i < 2; i++) ctx->stg[i].tail = ctx->stg_tails + i;
   } else { ctx->stg_tails = nullptr; (void)hipGetLastError(); }
-  { const char* tp = std::getenv("BMX_SCAN_TWO_PASS"); ctx->scan_two_pass = tp && tp[0] == '1'; }
   ctx->fixed_capacity = (flags & BMX_CTX_FIXED_CAPACITY) != 0;
   CR(hipMemsetAsync(ctx->ds, 0, sizeof(DevScalars), ctx->stream));
   hipLaunchKernelGGL(k_init_slots, dim3(2048), dim3(256), 0, ctx->stream, ctx->slots, nslots);
@@ -969,7 +937,7 @@ void bmx_destroy(bmx_ctx* ctx) {
   if (ctx->host_rows) { (void)hipHostFree(ctx->host_rows); ctx->host_rows = nullptr; }
   if (ctx->pin_in) { (void)hipHostFree(ctx->pin_in); ctx->pin_in = nullptr; }
   if (ctx->pin_out) { (void)hipHostFree(ctx->pin_out); ctx->pin_out = nullptr; }
-  dev_free(ctx->scan_out); dev_free(ctx->block_counts); dev_free(ctx->part_counts); dev_free(ctx->part_owner); dev_free(ctx->scan_mask); dev_free(ctx->scan_counts); dev_free(ctx->scan_status); dev_free(ctx->scan_ticket);
+  dev_free(ctx->scan_out); dev_free(ctx->block_counts); dev_free(ctx->part_counts); dev_free(ctx->part_owner); dev_free(ctx->scan_mask); dev_free(ctx->scan_counts);
   for (auto ev : ctx->prof_ev) (void)hipEventDestroy(ev);
   for (auto ev : ctx->scan_ev) (void)hipEventDestroy(ev);
   if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);

@@ -217,101 +217,4 @@ __global__ __launch_bounds__(SEL_THREADS) void k_scan_emit(const uint32_t* __res
   if (blockIdx.x == gridDim.x - 1) Fin(running, wsum);
 }
 
-// ---- one-launch scan: the column is read once and the matches are emitted from registers, ranks through a decoupled look-back ----
-// Workgroup b (numbered by a ticket it draws, so that every workgroup it may wait for is already running) evaluates its 8192 rows, publishes its
-// match count, adds up the counts published by the workgroups in front of it — stopping at the first one that has already published its PREFIX —
-// publishes its own prefix and writes its matches at prefix + local rank. No mask round trip through memory, no second launch: what the two-pass
-// form pays for them (4-7 us of launch boundary, 12.5 MB of mask per 100M rows) is most of a small column's scan.
-// A status word is {launch epoch : 22 | state : 2 | count : 40}: a word of another launch is "nothing published yet", so the array is never cleared
-// (the host restarts the epochs every 4M launches). The last ticket resets the ticket counter for the next launch.
-constexpr unsigned long long LOOK_AGG = 1ull << 40, LOOK_PREFIX = 2ull << 40, LOOK_VAL_MASK = (1ull << 40) - 1;
-constexpr uint32_t LOOK_EPOCH_MAX = (1u << 22) - 1;
-struct ScanLook { unsigned long long* status; uint32_t* ticket; uint32_t epoch; };
-
-template <class Pred, class Emit, class Finish>
-__global__ __launch_bounds__(SEL_THREADS) void k_scan_fused(Pred P, uint64_t n, uint32_t nblocks, ScanLook L, Emit Em, Finish Fin) {
-  constexpr int E = Pred::E;
-  constexpr int TILES = 32 / E;
-  __shared__ uint32_t s_blk;
-  __shared__ uint32_t wtile[SEL_THREADS / 64][TILES];
-  __shared__ unsigned long long s_prefix;
-  __shared__ uint32_t wsum[4];
-  if (threadIdx.x == 0) s_blk = atomicAdd(L.ticket, 1u);
-  __syncthreads();
-  const uint32_t blk = s_blk;
-  const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const uint64_t base = (uint64_t)blk * SCAN_BLOCK_ELEMS;
-  uint32_t m[TILES], ex[TILES];
-#pragma unroll
-  for (int k = 0; k < TILES; k++) {
-    const uint64_t first = base + (uint64_t)k * SEL_THREADS * E + (uint64_t)threadIdx.x * E;
-    m[k] = first < n ? P.mask(first, n) : 0u;
-  }
-  // ranks inside the workgroup, tile after tile (= row order): one wave scan per tile, ONE barrier for all of them
-#pragma unroll
-  for (int k = 0; k < TILES; k++) {
-    const uint32_t c = (uint32_t)__popc(m[k]);
-    const uint32_t inc = wave_incl_scan_u32(c);
-    ex[k] = inc - c;
-    if (lane == 63) wtile[wave][k] = inc;
-  }
-  __syncthreads();
-  uint32_t total = 0;
-#pragma unroll
-  for (int k = 0; k < TILES; k++) {
-    uint32_t before = 0, tile_tot = 0;
-#pragma unroll
-    for (int w = 0; w < SEL_THREADS / 64; w++) { const uint32_t s = wtile[w][k]; if (w < (int)wave) before += s; tile_tot += s; }
-    ex[k] += total + before;
-    total += tile_tot;
-  }
-  // look-back (first wave): lane i reads the status of workgroup look - i
-  if (wave == 0) {
-    const unsigned long long ep = (unsigned long long)L.epoch << 42;
-    unsigned long long pre = 0;
-    if (blk > 0) {
-      if (lane == 0) __hip_atomic_store(&L.status[blk], ep | LOOK_AGG | (unsigned long long)total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      int64_t look = (int64_t)blk - 1;
-      for (uint32_t spins = 0;; ) {
-        const int64_t idx = look - (int64_t)lane;
-        unsigned long long w = ep | LOOK_PREFIX;                                   // in front of workgroup 0: an empty prefix
-        if (idx >= 0) w = __hip_atomic_load(&L.status[idx], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        const bool valid = (w >> 42) == (unsigned long long)L.epoch && (w & (LOOK_AGG | LOOK_PREFIX)) != 0;
-        const bool is_prefix = valid && (w & LOOK_PREFIX) != 0;
-        const unsigned long long bp = __ballot(is_prefix), bi = __ballot(!valid);
-        const int first_p = bp ? __ffsll((long long)bp) - 1 : 64;
-        const unsigned long long upto = first_p >= 63 ? ~0ull : ((2ull << first_p) - 1ull);
-        if (bi & upto) {                                                           // a workgroup in the window has not published yet: look again
-          __builtin_amdgcn_s_sleep(1);
-          if (++spins > (1u << 24)) break;                                         // bounded: a lost workgroup must not hang the GPU (the total comes out wrong, the tests notice)
-          continue;
-        }
-        unsigned long long v = ((int)lane <= first_p) ? (w & LOOK_VAL_MASK) : 0ull;
-#pragma unroll
-        for (int d = 32; d >= 1; d >>= 1) v += __shfl_xor(v, d);
-        pre += v;
-        if (first_p < 64) break;
-        look -= 64;
-      }
-    }
-    if (lane == 0) {
-      __hip_atomic_store(&L.status[blk], ep | LOOK_PREFIX | ((pre + (unsigned long long)total) & LOOK_VAL_MASK), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      s_prefix = pre;
-    }
-  }
-  __syncthreads();
-  const uint64_t pre = s_prefix;
-#pragma unroll
-  for (int k = 0; k < TILES; k++) {
-    const uint64_t first = base + (uint64_t)k * SEL_THREADS * E + (uint64_t)threadIdx.x * E;
-    uint64_t pos = pre + ex[k];
-    uint32_t mm = m[k];
-    while (mm) { const int e = __ffs((int)mm) - 1; mm &= mm - 1; Em(pos++, first + (uint64_t)e); }
-  }
-  if (blk == nblocks - 1) {
-    if (threadIdx.x == 0) *L.ticket = 0u;                                          // every ticket of this launch has been drawn
-    Fin(pre + total, wsum);
-  }
-}
-
 }  // namespace bmx
