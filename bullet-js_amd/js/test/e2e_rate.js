@@ -61,7 +61,21 @@ for (let b = 0; b < B; b++) {
 t0 = process.hrtime.bigint();
 for (const cols of colsB) applied += crt.mergeBatch(cols).nApplied;
 const dtCols = Number(process.hrtime.bigint() - t0) / 1e9;
-console.log(JSON.stringify({ mergeEntries_per_s: (B * D) / dtEntries, mergeEntriesPipelined_per_s: (B * D) / dtPipe, mergeBatch_typed_columns_per_s: (B * D) / dtCols, unit: "deltas/s", resident_keys: R,
+// general vector clocks (N4): the same entries under clocks over ordered subsets of three writers, nodes' clock rows in the vector-clock table
+let vector = null;
+if (process.argv[5] === "vector") {
+  const WR = ["a", "b", "w"];
+  const vcrt = new GpuCRT({ id: "w", meta: {}, _getData() {} }, { writers: WR, capacityRows: 2 * (R + B * D) });
+  const vb = mkBatches(2);
+  for (const entries of vb) for (const e of entries) { const c = {}; const k = rnd() % 4; for (let x = 0; x < k; x++) c[WR[(x + (rnd() % 3)) % 3]] = rnd() % 5; e.vectorClock = c; }
+  vcrt.mergeEntries(vb[0].slice(0, 1000));
+  t0 = process.hrtime.bigint();
+  let conc = 0;
+  for (const entries of vb) conc += vcrt.mergeEntries(entries).nConflicts;
+  vector = { mergeEntries_per_s: (B * D) / (Number(process.hrtime.bigint() - t0) / 1e9), concurrent_merges: conc, writers: 3 };
+  vcrt.close();
+}
+console.log(JSON.stringify({ vector, mergeEntries_per_s: (B * D) / dtEntries, mergeEntriesPipelined_per_s: (B * D) / dtPipe, mergeBatch_typed_columns_per_s: (B * D) / dtCols, unit: "deltas/s", resident_keys: R,
   entries_per_batch: D, batches: B, applied, node: process.version }));
 crt.close();
 })().catch((e) => { console.error(e); process.exit(1); });
