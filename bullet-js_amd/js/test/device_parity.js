@@ -644,6 +644,57 @@ for (const [name, shards] of [["g11_vc_keysets_2k.json", 1], ["g11_vc_keysets_ho
   b.close();
 }
 
+/* N2 (stress): the same differential test in scalar mode — batch adapter on the GPU against the host resolver applied entry by entry: 3 chunks of 2000 entries
+ * on 250 nodes under clocks {w: 0..7} (many ties), objects with integer and string fields, integer and string primitives (local writes in the reference's
+ * loop: refused ones still move the clock), deletions, two-writer clocks (host-only paths), with and without put batching. Store, clocks, sources and the device's
+ * clock rows after every chunk. */
+for (const batchPuts of [false, true]) {
+  const b = new MiniBullet("w");
+  const { crt, sync } = attach(b, { capacityRows: 256, batchSync: { batchPuts } });
+  const twinB = new MiniBullet("w");
+  twinB.crt = new GpuCRT(twinB);
+  const rng = gen.xorshift32(batchPuts ? 4242 : 777);
+  for (let round = 0; round < 3; round++) {
+    const entries = [];
+    for (let j = 0; j < 2000; j++) {
+      const path = "st/n" + (rng() % 250);
+      const u = rng() % 100, clock = { w: rng() % 8 };
+      if (u < 3) entries.push({ path, data: { hits: 1 }, vectorClock: { w: rng() % 8, q: 1 } });
+      else if (u < 8) entries.push({ path, data: rng() % 7, vectorClock: clock });
+      else if (u < 10) entries.push({ path, data: "s" + (rng() % 3), vectorClock: clock });
+      else if (u < 13) entries.push({ path, deleted: true, vectorClock: clock });
+      else entries.push({ path, data: rng() % 3 ? { hits: (rng() % 5) - 2, level: rng() % 3 } : { hits: (rng() % 5) - 2, tag: "t" + (rng() % 3) }, vectorClock: clock });
+    }
+    for (const e of JSON.parse(JSON.stringify(entries))) {             // the loop body of src/bullet-network-sync.js:552-568
+      if (e.deleted) twinB.setData(e.path, null, false);
+      else twinB.setData(e.path, typeof e.data === "object" && e.data !== null ? Object.assign({}, e.data, { __fromNetwork: true, __vectorClock: e.vectorClock }) : e.data, false);
+    }
+    if (batchPuts && round === 1) {                                     // the middle chunk as network puts (objects) and single-entry chunks (the rest)
+      for (const e of JSON.parse(JSON.stringify(entries))) {
+        if (e.deleted || typeof e.data !== "object") sync.processSyncEntries([e], "peer-1");
+        else sync.handlePut("peer-1", { path: e.path, data: Object.assign({}, e.data, { __vectorClock: e.vectorClock }) });
+      }
+      sync.flush();
+    } else sync.processSyncEntries(JSON.parse(JSON.stringify(entries)), "peer-1");
+    for (const k of Object.keys(twinB.store.st)) assert.deepStrictEqual(b.store.st[k], twinB.store.st[k], "scalar stress: node st/" + k + " after chunk " + round + ", clock " + JSON.stringify(twinB.meta["st/" + k].vectorClock) + " vs " + JSON.stringify((b.meta["st/" + k] || {}).vectorClock));
+    const ps = Object.keys(twinB.meta).sort();
+    assert.deepStrictEqual(Object.keys(b.meta).sort(), ps);
+    for (const p of ps) {
+      assert.deepStrictEqual(b.meta[p].vectorClock, twinB.meta[p].vectorClock, "scalar stress: clock of " + p + " after chunk " + round);
+      assert.strictEqual(b.meta[p].source, twinB.meta[p].source, "scalar stress: source of " + p + " after chunk " + round);
+    }
+    // the device's clock rows: ts = the stored clock's w for every path whose clock is {w: n}
+    const held = ps.filter((p) => hash.scalarClock(twinB.meta[p].vectorClock, "w") >= 0);
+    const ids = new BigUint64Array(held.length), fields = new Uint32Array(held.length);
+    held.forEach((p, i) => { const id = crt.graph.keys.idOf(p); ids[i] = BigInt(id[0]) | (BigInt(id[1]) << 32n); fields[i] = crt.graph.keys.fieldOf("st", hash.NODE_CLOCK); });
+    const rows = crt.graph.getRows(ids, fields);
+    held.forEach((p, i) => { assert.ok(rows.found[i], "scalar stress: no clock row for " + p); assert.strictEqual(Number(rows.ts[i]), twinB.meta[p].vectorClock.w, "scalar stress: device clock of " + p + " after chunk " + round); });
+    checks += 3 * ps.length;
+  }
+  assert.ok(sync.stats.deviceEntries > 3000, JSON.stringify(sync.stats));
+  b.close();
+}
+
 /* Promise variant: two batches in flight from the event loop's point of view, serialised inside the addon */
 (async () => {
   const g = load("g2_stream_hot30_10k_10k.json");
