@@ -16,10 +16,20 @@ P = lambda a: C.c_void_p(a.ctypes.data)
 applied = [np.zeros(D, np.uint32), np.zeros(D, np.uint32)]
 na = C.c_uint64(); st = bmx.MergeStats()
 
-def run(label, pipelined, reuse):
+def run(label, pipelined, reuse, pinned=False):
+    global applied
     e = bmx.Engine(22_000_000); e.load_rows(*res)
     L, h = e.L, e.h
-    buf = [tuple(np.empty_like(x) for x in bs[0]) for _ in range(2)]
+    keep = []
+    if pinned:                                             # the host's two array sets and its two winner lists in page-locked memory (bmx_host_alloc)
+        hc = [bmx.host_columns(D) for _ in range(2)]
+        keep = [x[0] for x in hc]
+        buf = [tuple(x[1:]) for x in hc]
+        ho = [bmx.HostBuffer(4 * D) for _ in range(2)]; keep += ho
+        applied = [o.array(np.uint32, D) for o in ho]
+    else:
+        buf = [tuple(np.empty_like(x) for x in bs[0]) for _ in range(2)]
+        applied = [np.zeros(D, np.uint32), np.zeros(D, np.uint32)]
     def cols(b, k):
         if not reuse:
             return bs[b]
@@ -52,9 +62,12 @@ def run(label, pipelined, reuse):
     dt = tot / (NB - 1)
     print("%-78s %5.0f us per 1M-delta batch -> %.2f G merges/s" % (label, dt * 1e6, D / dt / 1e9))
     e.close()
+    for k in keep: k.close()
 
 run("host buffers, synchronous bmx_merge_batch, fresh arrays per batch:", False, False)
 run("host buffers, synchronous bmx_merge_batch, the host's own two reused array sets:", False, True)
 run("host buffers, pipelined bmx_merge_submit/collect, fresh arrays per batch:", True, False)
 run("host buffers, pipelined bmx_merge_submit/collect, two reused array sets:", True, True)
+run("host buffers in page-locked memory (bmx_host_alloc), synchronous bmx_merge_batch:", False, True, True)
+run("host buffers in page-locked memory (bmx_host_alloc), pipelined submit/collect:", True, True, True)
 print("(PCIe ceiling at 52.6 GB/s for 28 B in + 3.4 B out per delta: ~1.67 G merges/s)")
