@@ -46,6 +46,23 @@ int main(void) {
     CHECK(na == nw && st.n_applied == nw && st.n_rows == orc_size(o));
     CHECK(memcmp(applied, want, nw * sizeof(uint32_t)) == 0);
   }
+  /* one more batch from page-locked arrays (bmx_host_alloc): same call, same answer */
+  {
+    void* pin = NULL; uint32_t* papp = NULL;
+    CHECK(bmx_host_alloc(28ull * D, &pin) == BMX_OK && pin != NULL);
+    CHECK(bmx_host_alloc(4ull * D, (void**)&papp) == BMX_OK);
+    uint64_t* pid = (uint64_t*)pin; int64_t* pts = (int64_t*)((char*)pin + 8ull * D); int64_t* pval = (int64_t*)((char*)pin + 16ull * D); uint32_t* pf = (uint32_t*)((char*)pin + 24ull * D);
+    for (int j = 0; j < D; j++) {
+      uint64_t u = sm(7000003ULL + j);
+      pid[j] = sm((u % 100 < 10 ? R + 5000 + (sm(u) % 3000) : sm(u ^ 5) % R) + 1); pf[j] = F; pts[j] = 3000 + (int64_t)(sm(u + 17) % 2000); pval[j] = (int64_t)(sm(u + 31) % 2001) - 1000;
+    }
+    uint64_t na = 0; bmx_merge_stats st;
+    CHECK(bmx_merge_batch(ctx, D, pid, pf, pts, pval, BMX_INSERT_REFERENCE, BMX_MEM_HOST, papp, &na, NULL, &st) == BMX_OK);
+    uint64_t nw = orc_merge_batch(o, D, pid, pf, pts, pval, 0, NULL, want);
+    CHECK(na == nw && st.n_rows == orc_size(o) && memcmp(papp, want, nw * sizeof(uint32_t)) == 0);
+    CHECK(bmx_host_free(pin) == BMX_OK && bmx_host_free(papp) == BMX_OK && bmx_host_free(NULL) == BMX_OK);
+    CHECK(bmx_host_alloc(0, &pin) == BMX_ERR_INVALID);
+  }
   /* point reads */
   for (int i = 0; i < 200; i++) {
     uint64_t k = sm((uint64_t)(i * 37 % (R + 5000)) + 1); int64_t t1, v1, t2, v2;
@@ -65,6 +82,28 @@ int main(void) {
   CHECK(bmx_merge_batch(ctx, 1, &badid, &bf, &bt, &bv, BMX_INSERT_REFERENCE, BMX_MEM_HOST, NULL, NULL, NULL, NULL) == BMX_ERR_RANGE);
   CHECK(strlen(bmx_last_error(ctx)) > 0);
   CHECK(bmx_merge_batch(ctx, 1, &badid, &bf, &bt, &bv, 77, BMX_MEM_HOST, NULL, NULL, NULL, NULL) == BMX_ERR_INVALID);
+  /* K-writer vector clocks with key sets: {b:1,a:2} merges with {w:2} into {b:1,a:2,w:2}; then {a:2,b:1,w:2} — equal counters, another key ORDER: not identical
+     (JSON.stringify) -> concurrent, and the stored clock lists the incoming clock's keys first (src/bullet-crt.js:103-114, 200-203) */
+  {
+    bmx_vc* t = NULL;
+    CHECK(bmx_vc_create(0, 1024, 3, 2, &t) == BMX_OK);
+    const uint8_t ba[2] = {1, 0}, ab[2] = {0, 1};
+    uint64_t vid[3] = {sm(1), sm(1), sm(1)}; uint32_t vf[3] = {F, F, F};
+    uint32_t vclk[9] = {5, 5, 5, /* first sight: dropped, {w:2} stored */ 2, 1, 0, /* {b:1,a:2}: concurrent with {w:2} -> {b:1,a:2,w:2} */ 2, 1, 2 /* {a:2,b:1,w:2}: the same counters */};
+    uint32_t vks[3] = {bmx_vc_keyset_dense(3), bmx_vc_keyset(ba, 2), bmx_vc_keyset_dense(3)};
+    (void)ab;
+    int64_t vval[3] = {10, 11, 12};
+    uint32_t upd[3]; uint64_t nu = 0; uint8_t vfl[3];
+    CHECK(bmx_vc_merge_batch_ks(t, 3, vid, vf, vclk, vks, vval, upd, &nu, vfl) == BMX_OK);
+    CHECK(vfl[0] == BMX_FLAG_INCOMING && vfl[1] == BMX_FLAG_CONCURRENT && vfl[2] == BMX_FLAG_CONCURRENT && nu == 1 && upd[0] == 2);
+    uint32_t oc[3], oks = 0; int64_t ov = 0; uint8_t os = 0;
+    CHECK(bmx_vc_get_rows_ks(t, 1, vid, vf, oc, &oks, &ov, &os) == BMX_OK);
+    const uint8_t abw[3] = {0, 1, 2};
+    CHECK(oc[0] == 2 && oc[1] == 1 && oc[2] == 2 && ov == 12 && oks == bmx_vc_keyset(abw, 3) && os == BMX_VC_DENSE);   /* {a:2, b:1, w:2} */
+    uint32_t bad = bmx_vc_keyset(ba, 2); uint32_t badclk[3] = {0, 0, 7};                                                /* a counter for a writer the key set does not name */
+    CHECK(bmx_vc_merge_batch_ks(t, 1, vid, vf, badclk, &bad, vval, NULL, NULL, NULL) == BMX_ERR_RANGE);
+    bmx_vc_destroy(t);
+  }
   bmx_destroy(ctx); orc_destroy(o);
   printf("cabi_parity ok: %d rows, 3 x %d deltas, scan %llu matches\n", R, D, (unsigned long long)m);
   return 0;
