@@ -697,25 +697,28 @@ class GpuCRT {
     const b = this.bullet;
     const q = this._putQueue();
     const updates = mode ? new Array(n) : null;
+    // consecutive winners usually share their collection: its path string and its object in the store are looked up when it changes
+    let parent = null, pLen = -2, pNode;
     for (let k = 0; k < n; k++) {
       const e = entries[applied[k]];
       const path = e.path, cut = path.lastIndexOf("/");
+      if (cut !== pLen || !path.startsWith(parent)) { parent = cut < 0 ? "" : path.slice(0, cut); pLen = cut; pNode = mode ? peek(b.store, parent) : undefined; }
       // the clock the node now stores: read back, or — one context — the entry's own unless this winner CREATED the node (bit 31: the insert rule's {writer: 2})
       const ts = ts32 ? ts32[2 * k + 1] * 4294967296 + ts32[2 * k] : ((appliedIdx[k] >>> 31) && !deltaMode ? 2 : e.vectorClock[writer]);
       let value = e.data, old;
       if (mode) {
         const clock = {};
         clock[writer] = ts;
-        if (isMergeable(value)) {                                                       // the node's new value: the entry's object without the transport tags
-          const clean = {};
-          for (const f of Object.keys(value)) if (f !== "__vectorClock" && f !== "__fromNetwork") clean[f] = value[f];
-          value = clean;
+        if (isMergeable(value)) {                                                       // the node's new value: a copy of the entry's object without the transport tags
+          if (value.__vectorClock === undefined && value.__fromNetwork === undefined) value = Object.assign({}, value);
+          else { const clean = {}; for (const f of Object.keys(value)) if (f !== "__vectorClock" && f !== "__fromNetwork") clean[f] = value[f]; value = clean; }
         }
         updates[k] = { path, value, vectorClock: clock };
         this.vectorClocks.set(path, clock);                                             // the same object meta will hold: local writes increment it in place, like the reference's (SURVEY §5 aliasing)
-        old = peek(b.store, path);
+        if (cut === path.length - 1 || path.indexOf("//") >= 0) old = peek(b.store, path);   // empty segments: the walk that skips them
+        else if (pNode !== null && typeof pNode === "object") { const key = cut < 0 ? path : path.slice(cut + 1); old = Object.prototype.hasOwnProperty.call(pNode, key) ? pNode[key] : undefined; }
       }
-      if (valueRows) this._queueValueRows(q, path, cut < 0 ? "" : path.slice(0, cut), id32[2 * k], id32[2 * k + 1], old, value, ts, true);
+      if (valueRows) this._queueValueRows(q, path, parent, id32[2 * k], id32[2 * k + 1], old, value, ts, true);
     }
     q.closeBatch();
     if (!mode) return [];

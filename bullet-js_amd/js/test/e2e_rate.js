@@ -61,9 +61,30 @@ for (let b = 0; b < B; b++) {
 t0 = process.hrtime.bigint();
 for (const cols of colsB) applied += crt.mergeBatch(cols).nApplied;
 const dtCols = Number(process.hrtime.bigint() - t0) / 1e9;
+// the whole ingestion seam with the store kept (attach(..., {batchSync}) -> processSyncEntries, apply: true: store, meta, op log, listeners, value rows),
+// against the reference's loop body entry by entry through the host resolver (src/bullet-network-sync.js:551-569)
+let applied_path = null;
+if (process.argv[5] === "apply" || process.argv[6] === "apply") {
+  const { attach } = require("..");
+  const MiniBullet = require("./mini-bullet");
+  const ab = new MiniBullet("w");
+  const h = attach(ab, { capacityRows: 2 * (R + B * D), batchSync: {} });
+  const chunks = mkBatches(3).map((c) => JSON.parse(JSON.stringify(c))), chunks2 = mkBatches(3).map((c) => JSON.parse(JSON.stringify(c)));
+  h.sync.processSyncEntries(chunks[0].slice(0, 1000));
+  t0 = process.hrtime.bigint();
+  for (const c of chunks) h.sync.processSyncEntries(c);
+  const dtA = Number(process.hrtime.bigint() - t0) / 1e9;
+  const tb = new MiniBullet("w"); tb.crt = new GpuCRT(tb);
+  const few = chunks2.slice(0, Math.max(1, B >> 2));
+  t0 = process.hrtime.bigint();
+  for (const c of few) for (const e of c) tb.setData(e.path, Object.assign({}, e.data, { __fromNetwork: true, __vectorClock: e.vectorClock }), false);
+  const dtH = Number(process.hrtime.bigint() - t0) / 1e9;
+  applied_path = { batchSync_apply_entries_per_s: (B * D) / dtA, per_entry_host_loop_entries_per_s: (few.length * D) / dtH, nodes: Object.keys(ab.store.n || {}).length };
+  ab.close();
+}
 // general vector clocks (N4): the same entries under clocks over ordered subsets of three writers, nodes' clock rows in the vector-clock table
 let vector = null;
-if (process.argv[5] === "vector") {
+if (process.argv[5] === "vector" || process.argv[6] === "vector") {
   const WR = ["a", "b", "w"];
   const vcrt = new GpuCRT({ id: "w", meta: {}, _getData() {} }, { writers: WR, capacityRows: 2 * (R + B * D) });
   const vb = mkBatches(2);
@@ -75,7 +96,7 @@ if (process.argv[5] === "vector") {
   vector = { mergeEntries_per_s: (B * D) / (Number(process.hrtime.bigint() - t0) / 1e9), concurrent_merges: conc, writers: 3 };
   vcrt.close();
 }
-console.log(JSON.stringify({ vector, mergeEntries_per_s: (B * D) / dtEntries, mergeEntriesPipelined_per_s: (B * D) / dtPipe, mergeBatch_typed_columns_per_s: (B * D) / dtCols, unit: "deltas/s", resident_keys: R,
+console.log(JSON.stringify({ applied_path, vector, mergeEntries_per_s: (B * D) / dtEntries, mergeEntriesPipelined_per_s: (B * D) / dtPipe, mergeBatch_typed_columns_per_s: (B * D) / dtCols, unit: "deltas/s", resident_keys: R,
   entries_per_batch: D, batches: B, applied, node: process.version }));
 crt.close();
 })().catch((e) => { console.error(e); process.exit(1); });
