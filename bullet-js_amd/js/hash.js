@@ -274,21 +274,4 @@ function clockKeyset(clock, index, comps) {
   return ks >>> 0;
 }
 
-/* a clock the N4 table understands: exactly the K writers as keys, in `writers` order (the reference compares clocks with
- * JSON.stringify, so key set and order are part of a clock's identity: src/bullet-crt.js:200-203), uint32 counters.
- * -> array of K components, or null */
-function denseClock(clock, writers) {
-  if (!clock || typeof clock !== "object") return null;
-  const ks = Object.keys(clock);
-  if (ks.length !== writers.length) return null;
-  const out = new Array(ks.length);
-  for (let k = 0; k < ks.length; k++) {
-    if (ks[k] !== writers[k]) return null;
-    const c = clock[ks[k]];
-    if (typeof c !== "number" || !Number.isInteger(c) || c < 0 || c > 0xffffffff) return null;
-    out[k] = c;
-  }
-  return out;
-}
-
-module.exports = { pathId, fieldId, idKey, KeyDictionary, Columns, VcColumns, isDeviceInt, scalarClock, denseClock, clockKeyset, keysetDense, keysetWriters, KEYSET_NONE, fnv1a32, NODE_CLOCK, VAL_DELETED };
+module.exports = { pathId, fieldId, idKey, KeyDictionary, Columns, VcColumns, isDeviceInt, scalarClock, clockKeyset, keysetDense, keysetWriters, KEYSET_NONE, fnv1a32, NODE_CLOCK, VAL_DELETED };
