@@ -107,6 +107,8 @@ function verdict(winner, clock, value, reason, extra) {
   }, extra || {});
 }
 
+const PACK_BLOCK = 1024;   // entries whose dictionary probes are issued back to back (GpuCRT._packEntries); measured 16..4096: flat from 1024 on
+
 class GpuCRT {
   /**
    * @param {object} bullet  the Bullet instance (needs .id, .meta, ._getData)
@@ -521,46 +523,60 @@ class GpuCRT {
     // consecutive entries usually share their collection: the parent is recognised by the position of the last "/" and the hash of the prefix
     // (by-products of the id hash), its string is sliced and its field hashes looked up only when it changes
     let parent = null, pCut = -2, pH1 = 0, pH2 = 0, clockField = 0, per = null;
-    for (let ei = 0; ei < n; ei++) {
-      const e = entries[ei];
-      if (!e || e.deleted) { host.push(ei); continue; }
-      const ts = scalarClock(e.vectorClock, writer);
-      const d = e.data;
-      const prim = isDeviceInt(d);
-      if (ts < 0 || (!prim && !isMergeable(d)) || (guarded && !this._pathEligible(e.path, writer))) { host.push(ei); continue; }
-      const path = e.path;
-      keys.lookup(path);
-      const lo = keys.lo, hi = keys.hi;
-      if (keys.cut !== pCut || keys.ph1 !== pH1 || keys.ph2 !== pH2) {
-        pCut = keys.cut; pH1 = keys.ph1; pH2 = keys.ph2;
-        parent = pCut < 0 ? "" : path.slice(0, pCut);
-        clockField = keys.fieldOf(parent, NODE_CLOCK);
-        per = keys._fieldCache.get(parent);
+    // Blocks of PACK_BLOCK entries, three passes each: (1) eligibility + the id hash of the path (touches the entry, no table), (2) the dictionary probes of
+    // the whole block back to back — independent cache misses the CPU overlaps —, (3) the rows. One entry at a time the probe's miss stood in the critical path.
+    keys._block(PACK_BLOCK);
+    const bPath = this._bPath || (this._bPath = new Array(PACK_BLOCK)), bEnt = this._bEnt || (this._bEnt = new Int32Array(PACK_BLOCK));
+    const bTs = this._bTs || (this._bTs = new Float64Array(PACK_BLOCK));
+    for (let e0 = 0; e0 < n; e0 += PACK_BLOCK) {
+      const e1 = Math.min(n, e0 + PACK_BLOCK);
+      let m = 0;
+      for (let ei = e0; ei < e1; ei++) {
+        const e = entries[ei];
+        if (!e || e.deleted) { host.push(ei); continue; }
+        const ts = scalarClock(e.vectorClock, writer);
+        const d = e.data;
+        if (ts < 0 || (!isDeviceInt(d) && !isMergeable(d)) || (guarded && !this._pathEligible(e.path, writer))) { host.push(ei); continue; }
+        keys.hashInto(e.path, m);
+        bPath[m] = e.path; bEnt[m] = ei; bTs[m] = ts;
+        m++;
       }
-      if (prim) {
-        if (emit) {
-          if (vn === vcols.n) vcols = this._growColumns(vcols, vn);
-          vcols.set2(vn++, lo, hi, keys.fieldOf(parent, null), ts, d);
+      keys.probeBlock(bPath, m);
+      for (let x = 0; x < m; x++) {
+        const ei = bEnt[x], e = entries[ei], d = e.data, ts = bTs[x];
+        const lo = keys.bLo[x], hi = keys.bHi[x];
+        if (keys.bCut[x] !== pCut || keys.bP1[x] !== pH1 || keys.bP2[x] !== pH2) {
+          pCut = keys.bCut[x]; pH1 = keys.bP1[x]; pH2 = keys.bP2[x];
+          parent = pCut < 0 ? "" : bPath[x].slice(0, pCut);
+          clockField = keys.fieldOf(parent, NODE_CLOCK);
+          per = keys._fieldCache.get(parent);
         }
-      } else {
-        let k = 0;
-        for (const f in d) {
-          if (f === "__vectorClock" || f === "__fromNetwork" || !Object.prototype.hasOwnProperty.call(d, f)) continue;
-          k++;
-          if (!emit) break;
-          const v = d[f];
-          if (!isDeviceInt(v)) continue;                      // strings, nested objects, ...: part of the node on the host, no device row
-          let h = per.get(f);
-          if (h === undefined) h = keys.fieldOf(parent, f);
-          if (vn === vcols.n) vcols = this._growColumns(vcols, vn);
-          vcols.set2(vn++, lo, hi, h, ts, v);
+        if (typeof d === "number") {
+          if (emit) {
+            if (vn === vcols.n) vcols = this._growColumns(vcols, vn);
+            vcols.set2(vn++, lo, hi, keys.fieldOf(parent, null), ts, d);
+          }
+        } else {
+          let k = 0;
+          for (const f in d) {
+            if (f === "__vectorClock" || f === "__fromNetwork" || !Object.prototype.hasOwnProperty.call(d, f)) continue;
+            k++;
+            if (!emit) break;
+            const v = d[f];
+            if (!isDeviceInt(v)) continue;                      // strings, nested objects, ...: part of the node on the host, no device row
+            let h = per.get(f);
+            if (h === undefined) h = keys.fieldOf(parent, f);
+            if (vn === vcols.n) vcols = this._growColumns(vcols, vn);
+            vcols.set2(vn++, lo, hi, h, ts, v);
+          }
+          if (k === 0) { host.push(ei); continue; }              // {} : left to setData
         }
-        if (k === 0) { host.push(ei); continue; }              // {} : left to setData
+        if (emit) rowStart[i + 1] = vn;
+        if (rowNode) rowNode[i] = keys.bIdx[x];
+        cols.set2(i, lo, hi, clockField, ts, this._nodeSeq++);
+        rowEntry[i++] = ei;
       }
-      if (emit) rowStart[i + 1] = vn;
-      if (rowNode) rowNode[i] = keys.idx;
-      cols.set2(i, lo, hi, clockField, ts, this._nodeSeq++);
-      rowEntry[i++] = ei;
+      for (let x = 0; x < m; x++) bPath[x] = undefined;          // no strings kept alive by the scratch array
     }
     // one context: the winners that created their node are marked (stored clock = the insert rule's, no read-back); shards: read back
     const mergeOpts = g.comm ? opts : Object.assign({}, opts, { markCreated: true });

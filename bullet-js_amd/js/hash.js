@@ -120,6 +120,62 @@ class KeyDictionary {
     t[4 * s] = lo; t[4 * s + 1] = hi; t[4 * s + 2] = this.paths.length; t[4 * s + 3] = chk;
     if (this.paths.length * 2 > this._cap) this._grow();
   }
+  /* lookup() in two halves for callers that resolve many paths at once (GpuCRT._packEntries): hashInto(p, i) does the arithmetic for slot i of a block
+   * (no table access), probeBlock(paths, m) then resolves the m slots back to back — m independent table probes the CPU can overlap, where lookup() after
+   * lookup() pays one cache miss at a time (the table of a million paths does not fit the caches). Results per slot: bLo/bHi (the id), bCut/bP1/bP2 (the
+   * parent's by-products, as lookup() leaves them in cut/ph1/ph2), bIdx (the path's number). */
+  _block(m) {
+    if (!this.bLo || this.bLo.length < m) {
+      this.bLo = new Uint32Array(m); this.bHi = new Uint32Array(m); this.bChk = new Uint32Array(m); this.bP1 = new Uint32Array(m); this.bP2 = new Uint32Array(m);
+      this.bCut = new Int32Array(m); this.bIdx = new Int32Array(m);
+    }
+  }
+  hashInto(p, i) {
+    let h1 = 0x811c9dc5, h2 = 0x9747b28c, h3 = 0x2f0b4a27;
+    let cut = -1, p1 = 0, p2 = 0;
+    for (let x = 0; x < p.length; x++) {
+      const c = p.charCodeAt(x);
+      if (c < 0x80) {
+        if (c === 47) { cut = x; p1 = h1; p2 = h2; }
+        h1 = Math.imul(h1 ^ c, 0x01000193); h2 = Math.imul(h2 ^ c, 0x01000193); h3 = Math.imul(h3 ^ c, 0x01000193);
+      } else {
+        const a = c & 0xff, b = c >>> 8;
+        h1 = Math.imul(Math.imul(h1 ^ a, 0x01000193) ^ b, 0x01000193);
+        h2 = Math.imul(Math.imul(h2 ^ a, 0x01000193) ^ b, 0x01000193);
+        h3 = Math.imul(Math.imul(h3 ^ a, 0x01000193) ^ b, 0x01000193);
+      }
+    }
+    const lo = fmix32(h1 >>> 0);
+    let hi = fmix32((h2 >>> 0) ^ lo);
+    if (lo === 0xffffffff && hi === 0xffffffff) hi = 0xfffffffe;
+    this.bLo[i] = lo; this.bHi[i] = hi; this.bChk[i] = fmix32((h3 >>> 0) ^ p.length); this.bCut[i] = cut; this.bP1[i] = p1; this.bP2[i] = p2;
+  }
+  probeBlock(paths, m) {
+    const bLo = this.bLo, bHi = this.bHi, bChk = this.bChk, bIdx = this.bIdx;
+    let t = this._t, mask = this._mask;
+    for (let i = 0; i < m; i++) {
+      const lo = bLo[i], hi = bHi[i];
+      let s = (lo ^ Math.imul(hi, 0x9E3779B1)) & mask;
+      for (;;) {
+        const k = t[4 * s + 2];
+        if (k === 0) {                                         // first sight: register the path (as lookup() does)
+          const p = paths[i];
+          this.paths.push(p);
+          bIdx[i] = this.paths.length - 1;
+          t[4 * s] = lo; t[4 * s + 1] = hi; t[4 * s + 2] = this.paths.length; t[4 * s + 3] = bChk[i];
+          if (this.paths.length * 2 > this._cap) { this._grow(); t = this._t; mask = this._mask; }
+          break;
+        }
+        if (t[4 * s] === lo && t[4 * s + 1] === hi) {
+          if (t[4 * s + 3] === bChk[i]) { bIdx[i] = k - 1; break; }
+          const err = new Error(`bmx: 64-bit id collision between paths '${this.paths[k - 1]}' and '${paths[i]}'`);
+          err.code = "BMX_ID_COLLISION";
+          throw err;
+        }
+        s = (s + 1) & mask;
+      }
+    }
+  }
   idOf(p) { this.lookup(p); return [this.lo, this.hi]; }
   pathOf(lo, hi) {
     const t = this._t, mask = this._mask;
