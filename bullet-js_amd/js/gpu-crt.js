@@ -825,26 +825,45 @@ class GpuCRT {
     const guarded = this._hostOnly.size > 0 || this._apiClocks.size > 0;
     const host = [];
     let i = 0, parent = null, pCut = -2, pH1 = 0, pH2 = 0, clockField = 0;
-    for (let ei = 0; ei < n; ei++) {
-      const e = entries[ei];
-      if (!e || e.deleted) { host.push(ei); continue; }
-      const d = e.data;
-      if (!isDeviceInt(d)) {
-        let any = false;
-        if (isMergeable(d)) for (const f in d) { if (f !== "__vectorClock" && f !== "__fromNetwork" && Object.prototype.hasOwnProperty.call(d, f)) { any = true; break; } }
-        if (!any) { host.push(ei); continue; }
+    // blocks of PACK_BLOCK entries: eligibility + counters + path hash, then the dictionary probes of the block back to back, then the rows (see _packEntries)
+    keys._block(PACK_BLOCK);
+    const bPath = this._bPath || (this._bPath = new Array(PACK_BLOCK));
+    const K = t.K;
+    for (let e0 = 0; e0 < n; e0 += PACK_BLOCK) {
+      const e1 = Math.min(n, e0 + PACK_BLOCK);
+      const first = i;
+      let m = 0;
+      for (let ei = e0; ei < e1; ei++) {
+        const e = entries[ei];
+        if (!e || e.deleted) { host.push(ei); continue; }
+        const d = e.data;
+        if (!isDeviceInt(d)) {
+          let any = false;
+          if (isMergeable(d)) for (const f in d) { if (f !== "__vectorClock" && f !== "__fromNetwork" && Object.prototype.hasOwnProperty.call(d, f)) { any = true; break; } }
+          if (!any) { host.push(ei); continue; }
+        }
+        const ks = clockKeyset(e.vectorClock, t.writerIndex, comps);
+        if (ks < 0 || (guarded && !this._pathEligible(e.path, writer))) { host.push(ei); continue; }
+        keys.hashInto(e.path, m);
+        bPath[m++] = e.path;
+        const o = i * K;                                          // counters, key set and arrival number now; id and field once the path is resolved
+        for (let k = 0; k < K; k++) cols.clocks[o + k] = comps[k];
+        cols.keysets[i] = ks;
+        cols.setVal(i, this._nodeSeq++);
+        rowEntry[i++] = ei;
       }
-      const ks = clockKeyset(e.vectorClock, t.writerIndex, comps);
-      if (ks < 0 || (guarded && !this._pathEligible(e.path, writer))) { host.push(ei); continue; }
-      keys.lookup(e.path);
-      if (keys.cut !== pCut || keys.ph1 !== pH1 || keys.ph2 !== pH2) {
-        pCut = keys.cut; pH1 = keys.ph1; pH2 = keys.ph2;
-        parent = pCut < 0 ? "" : e.path.slice(0, pCut);
-        clockField = keys.fieldOf(parent, NODE_CLOCK);
+      keys.probeBlock(bPath, m);
+      for (let x = 0; x < m; x++) {
+        const j = first + x;
+        if (keys.bCut[x] !== pCut || keys.bP1[x] !== pH1 || keys.bP2[x] !== pH2) {
+          pCut = keys.bCut[x]; pH1 = keys.bP1[x]; pH2 = keys.bP2[x];
+          parent = pCut < 0 ? "" : bPath[x].slice(0, pCut);
+          clockField = keys.fieldOf(parent, NODE_CLOCK);
+        }
+        if (rowNode) rowNode[j] = keys.bIdx[x];
+        cols.setKey(j, keys.bLo[x], keys.bHi[x], clockField);
+        bPath[x] = undefined;
       }
-      if (rowNode) rowNode[i] = keys.idx;
-      cols.set2(i, keys.lo, keys.hi, clockField, comps, ks, this._nodeSeq++);
-      rowEntry[i++] = ei;
     }
     const used = cols.slice(i);
     const r = i ? t.mergeBatch(used) : { updated: new Uint32Array(0), flags: new Uint8Array(0), nRows: t.rowCount() };

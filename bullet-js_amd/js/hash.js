@@ -300,6 +300,8 @@ class VcColumns {
     const hi = Math.floor(val / 4294967296);
     this._val32[2 * i] = val - hi * 4294967296; this._val32[2 * i + 1] = hi;
   }
+  setKey(i, lo, hi32, field) { this._id32[2 * i] = lo; this._id32[2 * i + 1] = hi32; this.field[i] = field; }
+  setVal(i, val) { const hi = Math.floor(val / 4294967296); this._val32[2 * i] = val - hi * 4294967296; this._val32[2 * i + 1] = hi; }
   slice(n) {
     if (n === this.n) return this;
     const c = Object.create(VcColumns.prototype);
