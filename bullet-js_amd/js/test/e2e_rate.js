@@ -39,7 +39,11 @@ const mkBatches = (salt) => {
   return out;
 };
 const batches = mkBatches(0), batches2 = mkBatches(1);
-crt.mergeEntries(batches[0].slice(0, 1000));                     // warm the addon and the JIT
+{ // warm the addon, the JIT and the pool of page-locked column sets with one chunk of the timed size (entries of their own: keys n/w...)
+  const warm = new Array(D);
+  for (let j = 0; j < D; j++) warm[j] = { path: "n/w" + j, data: { f: j & 1023 }, vectorClock: { w: 1000000 + j } };
+  crt.mergeEntries(warm);
+}
 let applied = 0;
 let t0 = process.hrtime.bigint();
 for (const entries of batches) applied += crt.mergeEntries(entries).nApplied;
