@@ -39,10 +39,12 @@ const mkBatches = (salt) => {
   return out;
 };
 const batches = mkBatches(0), batches2 = mkBatches(1);
-{ // warm the addon, the JIT and the pool of page-locked column sets with one chunk of the timed size (entries of their own: keys n/w...)
+{ // warm the addon, the JIT and the pool of page-locked column sets with one chunk of the timed size: resident nodes under a clock below everything stored
+  // (all historical: no row, no dictionary entry and no store state changes)
   const warm = new Array(D);
-  for (let j = 0; j < D; j++) warm[j] = { path: "n/w" + j, data: { f: j & 1023 }, vectorClock: { w: 1000000 + j } };
-  crt.mergeEntries(warm);
+  for (let j = 0; j < D; j++) warm[j] = { path: "n/k" + (j % R), data: { f: j & 1023 }, vectorClock: { w: 1 } };
+  const r0 = crt.mergeEntries(warm);
+  if (r0.nApplied !== 0) throw new Error("warm-up chunk was supposed to be historical");
 }
 let applied = 0;
 let t0 = process.hrtime.bigint();
