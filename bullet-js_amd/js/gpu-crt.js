@@ -537,6 +537,11 @@ class GpuCRT {
         const ts = scalarClock(e.vectorClock, writer);
         const d = e.data;
         if (ts < 0 || (!isDeviceInt(d) && !isMergeable(d)) || (guarded && !this._pathEligible(e.path, writer))) { host.push(ei); continue; }
+        if (typeof d !== "number") {                            // {} (nothing but transport tags): left to setData
+          let any = false;
+          for (const f in d) { if (f !== "__vectorClock" && f !== "__fromNetwork" && Object.prototype.hasOwnProperty.call(d, f)) { any = true; break; } }
+          if (!any) { host.push(ei); continue; }
+        }
         keys.hashInto(e.path, m);
         bPath[m] = e.path; bEnt[m] = ei; bTs[m] = ts;
         m++;
@@ -556,12 +561,9 @@ class GpuCRT {
             if (vn === vcols.n) vcols = this._growColumns(vcols, vn);
             vcols.set2(vn++, lo, hi, keys.fieldOf(parent, null), ts, d);
           }
-        } else {
-          let k = 0;
+        } else if (emit) {
           for (const f in d) {
             if (f === "__vectorClock" || f === "__fromNetwork" || !Object.prototype.hasOwnProperty.call(d, f)) continue;
-            k++;
-            if (!emit) break;
             const v = d[f];
             if (!isDeviceInt(v)) continue;                      // strings, nested objects, ...: part of the node on the host, no device row
             let h = per.get(f);
@@ -569,7 +571,6 @@ class GpuCRT {
             if (vn === vcols.n) vcols = this._growColumns(vcols, vn);
             vcols.set2(vn++, lo, hi, h, ts, v);
           }
-          if (k === 0) { host.push(ei); continue; }              // {} : left to setData
         }
         if (emit) rowStart[i + 1] = vn;
         if (rowNode) rowNode[i] = keys.bIdx[x];

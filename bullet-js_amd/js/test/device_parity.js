@@ -201,9 +201,10 @@ for (const shards of [2, 4, 8]) {
     { path: "s/e", data: ["x"], vectorClock: { w: 4 } },             // an array, a string, an empty object: host path
     { path: "s/f", data: "x", vectorClock: { w: 4 } },
     { path: "s/g", data: {}, vectorClock: { w: 4 } },
+    { path: "s/h", data: { n: 1 }, vectorClock: { q: 4 } },          // somebody else's clock: host path (the list of handed-back entries stays in entry order)
   ];
   const r = crt.mergeEntries(entries, { insertMode: "delta" });
-  assert.deepStrictEqual(r.host, [4, 6, 7, 8]);
+  assert.deepStrictEqual(r.host, [4, 6, 7, 8, 9]);
   assert.deepStrictEqual(r.applied, [{ entry: 1, field: null }, { entry: 3, field: null }, { entry: 5, field: null }]);   // one winner per NODE: the object that is its final value
   assert.strictEqual(r.nRows, 3);                                    // three clock rows (the winners' value rows are still queued)
   const snap = crt.checkpoint();                                     // flushes them: s/a {n:3}, s/b 7, s/c {k:6}
