@@ -742,6 +742,9 @@ int ensure_scan_scratch(bmx_ctx* ctx, uint64_t n) {
 
 // Run one predicate over an index and deliver ids (POS = false: u64 node ids gathered from the id column) or index positions (POS = true: u32,
 // no gather) / the count according to `mem`. `out` is uint64_t* or uint32_t* accordingly.
+// a value column above this size is read with nontemporal loads: it cannot stay in the 256 MiB Infinity Cache between two scans anyway (scan_kernels.h)
+constexpr uint64_t SCAN_NT_BYTES = 256ull << 20;
+
 template <bool POS, class Pred>
 int run_scan_t(bmx_ctx* ctx, const Pred& P, const Index* ix, void* out_v, uint64_t cap, uint64_t* n_out, int mem) {
   using OutT = typename std::conditional<POS, uint32_t, uint64_t>::type;
@@ -836,10 +839,10 @@ int scan_range_impl_t(bmx_ctx* ctx, uint32_t field, int64_t lo, int64_t hi, void
     // tombstone looks like in this column and is never matched (a real -2^31 makes the index wide: scan_kernels.h v32_of)
     int64_t l = std::max<int64_t>(lo, (int64_t)INT32_MIN + 1), h = std::min<int64_t>(hi, INT32_MAX);
     if (lo > INT32_MAX || hi < INT32_MIN) { l = 1; h = 0; }
-    PredRange32 P{ix->v32, (int32_t)l, (int32_t)h};
+    PredRange32 P{ix->v32, (int32_t)l, (int32_t)h, ix->n * sizeof(int32_t) > SCAN_NT_BYTES};
     return run_scan_t<POS>(ctx, P, ix, out, cap, n_out, mem);
   }
-  PredRange64 P{ix->v64, std::max<int64_t>(lo, -VAL_MAX), hi};    // values live in +-(2^53-1): the clamp changes no answer and keeps tombstones (INT64_MIN) out
+  PredRange64 P{ix->v64, std::max<int64_t>(lo, -VAL_MAX), hi, ix->n * sizeof(int64_t) > SCAN_NT_BYTES};    // values live in +-(2^53-1): the clamp changes no answer and keeps tombstones (INT64_MIN) out
   return run_scan_t<POS>(ctx, P, ix, out, cap, n_out, mem);
 }
 int scan_range_impl(bmx_ctx* ctx, uint32_t field, int64_t lo, int64_t hi, uint64_t* out_ids, uint64_t cap, uint64_t* n_out, int mem) {
