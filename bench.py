@@ -65,6 +65,52 @@ def to_dev(cols, dev):
             torch.from_numpy(ts).to(dev), torch.from_numpy(val).to(dev))
 
 
+def exchange_selftest(dev, dist, rank, world):
+    """N>1 only, before the real graph is built: a small graph (20k rows per rank) and six batches of 8192 deltas per rank go through the very pipeline the
+    timed run uses — direct exchange if every rank can set it up — and every rank compares its shard with the oracle. The direct exchange stores into
+    other GPUs' memory; if the data that arrives is not what was sent on THIS machine, every rank switches to the RCCL all-to-all for the timed run
+    instead of finding out in the post-run verification. -> exchange kind to use ("direct" / "rccl")"""
+    import bmx
+    from bmx import synth
+    from bmx.sharded import ShardedGraph, EngineOps
+    from oracle.oracle import Oracle, rows_digest
+    Rs, Ds, NBs = 20_000, 8192, 6
+    e = bmx.Engine(capacity_rows=4 * (Rs + NBs * Ds), device=dev.index or 0)
+    sg = ShardedGraph(EngineOps(e, dev), dist, rank, world)
+    sg.load_owned_resident(Rs, T0=T0, DT=DT)
+    Rg = Rs * world
+    gen = lambda b, src: synth.big_deltas(Ds, Rg, seed=77 + 1000 * src, part=(src, world), T0=T0, DT=DT, insert_pct=10, unique=True, batch=b, drift=DT // 16)
+    sg.setup_pipeline(Ds, slack=1.5)
+    kind = sg.exchange
+    ok = True
+    if kind == "direct":
+        bs = [to_dev(gen(b, rank), dev) for b in range(NBs)]
+        tk = sg.route(Ds, *bs[0], exchange_now=True)
+        for b in range(NBs):
+            nxt = sg.route(Ds, *bs[b + 1]) if b + 1 < NBs else None
+            sg.merge(tk)
+            tk = nxt
+        sg.ops.sync(); torch.cuda.synchronize()
+        o = Oracle()
+        o.load_rows(*sg.owned_resident_host(Rs, T0=T0, DT=DT))
+        for b in range(NBs):
+            for src in range(world):
+                cols = gen(b, src)
+                mine = synth.owner_of_np(cols[0], world) == rank
+                o.merge_batch(*[c[mine] for c in cols])
+        ok = (not sg.overflowed()) and e.row_count() == len(o) and rows_digest(*e.dump_rows()) == o.digest()
+        if os.environ.get("BMX_BENCH_SELFTEST_FAIL") == str(rank): ok = False     # test hook: pretend this rank saw wrong data
+        o.close()
+    okt = torch.tensor([1 if ok else 0], dtype=torch.int64, device=dev)
+    dist.all_reduce(okt, op=dist.ReduceOp.MIN)
+    sg.close(); sg.ops.close(); e.close()
+    if kind == "direct" and int(okt.item()) != 1:
+        if rank == 0:
+            print("bench: the direct exchange failed its self-test on this machine (a shard differed from the oracle): the timed run uses the RCCL all-to-all", file=sys.stderr)
+        return "rccl"
+    return kind
+
+
 def cpu_baseline(n_batches=24):
     """Oracle (C port of the reference merge rule) on ONE host core, same workload shape."""
     from oracle.oracle import Oracle
@@ -409,6 +455,8 @@ def main():
                    "resident_rows_per_gpu": R_PER_GPU, "deltas_per_step_per_gpu": D_PER_STEP, "insert_mode": "reference", "sharding": "none"}
     else:
         from bmx.sharded import ShardedGraph, EngineOps
+        if world > 1 and os.environ.get("BMX_SHARDED_EXCHANGE", "auto") == "auto":
+            os.environ["BMX_SHARDED_EXCHANGE"] = exchange_selftest(dev, dist, rank, world)   # every rank gets the same answer (all-reduce inside)
         sg = ShardedGraph(EngineOps(eng, dev), dist, rank, world)
         sg.load_owned_resident(R_PER_GPU, T0=T0, DT=DT)
         R_global = R_PER_GPU * world
