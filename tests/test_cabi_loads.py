@@ -52,6 +52,25 @@ def test_no_cpu_fallback_without_gpu(lib):
     assert ei.value.code == bmx.ERR_NO_DEVICE
 
 
+def test_key_set_words_and_page_locked_memory_without_a_gpu(lib):
+    """Pure helpers work anywhere (the key-set word of a vector clock: include/bmx.h); page-locked memory comes from the HIP runtime, so without a GPU
+    bmx_host_alloc answers with an error code and a message — it never hands out ordinary memory in its place."""
+    import ctypes as C
+    import numpy as np
+    import torch
+    for keys in ([], [0], [2, 1, 0], [7, 0, 3, 1]):
+        a = np.array(keys, np.uint8)
+        assert lib.bmx_vc_keyset(C.c_void_p(a.ctypes.data) if len(a) else None, len(a)) == bmx.keyset(keys)
+        assert bmx.keyset_writers(bmx.keyset(keys)) == keys
+    assert lib.bmx_vc_keyset_dense(3) == bmx.keyset([0, 1, 2]) and lib.bmx_vc_keyset_dense(8) == bmx.keyset(range(8))
+    p = C.c_void_p()
+    assert lib.bmx_host_alloc(0, C.byref(p)) == bmx.ERR_INVALID and lib.bmx_host_free(None) == 0
+    if not torch.cuda.is_available():
+        with pytest.raises(bmx.BmxError) as ei:
+            bmx.HostBuffer(4096)
+        assert ei.value.code in (bmx.ERR_HIP, bmx.ERR_NOMEM, bmx.ERR_NO_DEVICE) and str(ei.value)
+
+
 def test_oversize_tables_are_refused_before_any_device_work(lib):
     """Slot indices in the per-batch workspace are 32-bit: a table that would need more than 2^32 slots (137 GB of 32-byte slots would
     fit the 288 GB of HBM) is refused with BMX_ERR_INVALID, on any machine, instead of corrupting rows silently."""
