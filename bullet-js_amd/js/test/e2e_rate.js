@@ -59,10 +59,10 @@ const dtPipe = Number(process.hrtime.bigint() - t0) / 1e9;
 // the same amount of work with the keys already hashed (typed columns in, winners out)
 const colsB = [];
 for (let b = 0; b < B; b++) {
-  const cols = new hash.Columns(D);
+  const cols = g.takeColumns(D);                 // page-locked column sets (the way a host builds typed batches: INTEGRATION.md)
   const f = g.keys.fieldOf("n", "f");
   for (let j = 0; j < D; j++) cols.set(j, g.keys.idOf(batches[b][j].path), f, 3000000 + (rnd() % 1000000), (rnd() % 2001) - 1000);
-  colsB.push(cols);
+  colsB.push(cols.slice(D));
 }
 t0 = process.hrtime.bigint();
 for (const cols of colsB) applied += crt.mergeBatch(cols).nApplied;
