@@ -14,6 +14,7 @@ const gen = require(path.join(__dirname, "..", "..", "..", "oracle", "gen_golden
 const GOLD = process.argv[2] || path.join(__dirname, "..", "..", "..", "tests", "golden");
 const load = (n) => JSON.parse(fs.readFileSync(path.join(GOLD, n), "utf8"));
 let checks = 0;
+const STRESS_SALT = parseInt(process.env.BMX_STRESS_SALT || "0", 10);   // other seeds for the differential stress tests (default: the pinned ones)
 
 function columns(rows, F) {
   const n = rows.length;
@@ -604,7 +605,7 @@ for (const [name, shards] of [["g11_vc_keysets_2k.json", 1], ["g11_vc_keysets_ho
   const { crt, sync } = attach(b, { writers: WR, capacityRows: 256, batchSync: {} });
   const twinB = new MiniBullet("w");
   twinB.crt = new GpuCRT(twinB);                                        // host resolver only
-  const rng = gen.xorshift32(99);
+  const rng = gen.xorshift32(99 + STRESS_SALT);
   const randClock = () => {
     const order = [0, 1, 2];
     for (let i = 2; i > 0; i--) { const j = rng() % (i + 1); const t = order[i]; order[i] = order[j]; order[j] = t; }
@@ -654,16 +655,19 @@ for (const batchPuts of [false, true]) {
   const { crt, sync } = attach(b, { capacityRows: 256, batchSync: { batchPuts } });
   const twinB = new MiniBullet("w");
   twinB.crt = new GpuCRT(twinB);
-  const rng = gen.xorshift32(batchPuts ? 4242 : 777);
+  const rng = gen.xorshift32((batchPuts ? 4242 : 777) + STRESS_SALT);
   for (let round = 0; round < 3; round++) {
     const entries = [];
     for (let j = 0; j < 2000; j++) {
       const path = "st/n" + (rng() % 250);
       const u = rng() % 100, clock = { w: rng() % 8 };
       if (u < 3) entries.push({ path, data: { hits: 1 }, vectorClock: { w: rng() % 8, q: 1 } });
-      else if (u < 8) entries.push({ path, data: rng() % 7, vectorClock: clock });
-      else if (u < 10) entries.push({ path, data: "s" + (rng() % 3), vectorClock: clock });
+      else if (u < 8) entries.push({ path, data: rng() % 7, vectorClock: clock });                      // 0 among them: a falsy value _getData turns into {}
+      else if (u < 10) entries.push({ path, data: rng() % 4 ? "s" + (rng() % 3) : "", vectorClock: clock });
       else if (u < 13) entries.push({ path, deleted: true, vectorClock: clock });
+      else if (u < 14) entries.push({ path, data: [rng() % 3, "a"], vectorClock: clock });              // an array: the loop spreads it into an object (host path)
+      else if (u < 15) entries.push({ path, data: {}, vectorClock: clock });
+      else if (u < 17) entries.push({ path, data: { hits: rng() % 3, deep: { a: rng() % 2, b: [1] }, flag: rng() % 2 === 0, none: null }, vectorClock: clock });
       else entries.push({ path, data: rng() % 3 ? { hits: (rng() % 5) - 2, level: rng() % 3 } : { hits: (rng() % 5) - 2, tag: "t" + (rng() % 3) }, vectorClock: clock });
     }
     for (const e of JSON.parse(JSON.stringify(entries))) {             // the loop body of src/bullet-network-sync.js:552-568
