@@ -622,6 +622,8 @@ for (const [name, shards] of [["g11_vc_keysets_2k.json", 1], ["g11_vc_keysets_ho
       if (u < 2) entries.push({ path, data: { hits: 1 }, vectorClock: { a: rng() % 3, zed: 2 } });
       else if (u < 4) entries.push({ path, data: rng() % 7, vectorClock: randClock() });
       else if (u < 5) entries.push({ path, deleted: true, vectorClock: randClock() });
+      else if (u < 6) entries.push({ path, data: rng() % 2 ? [1, "a"] : (rng() % 2 ? "" : {}), vectorClock: randClock() });   // array (spread by the loop), empty string, {}
+      else if (u < 8) entries.push({ path, data: { hits: rng() % 3, deep: { a: rng() % 2 }, none: null }, vectorClock: randClock() });
       else entries.push({ path, data: rng() % 3 ? { hits: (rng() % 5) - 2, level: rng() % 3 } : { hits: (rng() % 5) - 2, tag: "t" + (rng() % 3) }, vectorClock: randClock() });
     }
     for (const e of JSON.parse(JSON.stringify(entries))) {             // the loop body of src/bullet-network-sync.js:552-568
