@@ -302,24 +302,27 @@ class GpuCRT {
   /* value rows of node `path` (id lo:hi) for `value`, tombstones for what `oldValue` had on the device and `value` has not */
   _queueValueRows(q, path, parent, lo, hi, oldValue, value, ts, unique) {
     const keys = this._graph.keys;
-    const put = unique ? (f, v) => q.pushUnique(lo, hi, f, ts, v) : (f, v) => q.push(lo, hi, f, ts, v);
     const newObj = isMergeable(value), oldObj = isMergeable(oldValue);
     if (newObj) {
       for (const f in value) {
         if (f === "__vectorClock" || f === "__fromNetwork" || !Object.prototype.hasOwnProperty.call(value, f)) continue;
         const v = value[f];
-        if (isDeviceInt(v)) put(keys.fieldOf(parent, f), v);
-        else if (oldObj && isDeviceInt(oldValue[f])) put(keys.fieldOf(parent, f), VAL_DELETED);
+        let row;
+        if (isDeviceInt(v)) row = v;
+        else if (oldObj && isDeviceInt(oldValue[f])) row = VAL_DELETED;
+        else continue;
+        if (unique) q.pushUnique(lo, hi, keys.fieldOf(parent, f), ts, row); else q.push(lo, hi, keys.fieldOf(parent, f), ts, row);
       }
     }
     if (oldObj) {
       for (const f in oldValue) {
         if (!Object.prototype.hasOwnProperty.call(oldValue, f) || !isDeviceInt(oldValue[f])) continue;
-        if (!newObj || !Object.prototype.hasOwnProperty.call(value, f)) put(keys.fieldOf(parent, f), VAL_DELETED);
+        if (newObj && Object.prototype.hasOwnProperty.call(value, f)) continue;
+        if (unique) q.pushUnique(lo, hi, keys.fieldOf(parent, f), ts, VAL_DELETED); else q.push(lo, hi, keys.fieldOf(parent, f), ts, VAL_DELETED);
       }
     }
-    if (isDeviceInt(value)) put(keys.fieldOf(parent, null), value);
-    else if (isDeviceInt(oldValue)) put(keys.fieldOf(parent, null), VAL_DELETED);
+    const prim = isDeviceInt(value) ? value : (isDeviceInt(oldValue) ? VAL_DELETED : undefined);
+    if (prim !== undefined) { if (unique) q.pushUnique(lo, hi, keys.fieldOf(parent, null), ts, prim); else q.push(lo, hi, keys.fieldOf(parent, null), ts, prim); }
   }
 
   /* the queue of rows for bmx_put_rows; the graph flushes it in front of every device operation it is asked for (DeviceGraph.preOp), so
@@ -730,7 +733,7 @@ class GpuCRT {
           if (value.__vectorClock === undefined && value.__fromNetwork === undefined) value = Object.assign({}, value);
           else { const clean = {}; for (const f of Object.keys(value)) if (f !== "__vectorClock" && f !== "__fromNetwork") clean[f] = value[f]; value = clean; }
         }
-        updates[k] = { path, value, vectorClock: clock };
+        updates[k] = { path, value, vectorClock: clock, parentHint: parent, cutHint: cut };   // (the hints spare applyBatch the same string work)
         this.vectorClocks.set(path, clock);                                             // the same object meta will hold: local writes increment it in place, like the reference's (SURVEY §5 aliasing)
         if (cut === path.length - 1 || path.indexOf("//") >= 0) old = peek(b.store, path);   // empty segments: the walk that skips them
         else if (pNode !== null && typeof pNode === "object") { const key = cut < 0 ? path : path.slice(cut + 1); old = Object.prototype.hasOwnProperty.call(pNode, key) ? pNode[key] : undefined; }
