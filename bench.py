@@ -111,8 +111,8 @@ def exchange_selftest(dev, dist, rank, world):
     return kind
 
 
-def cpu_baseline(n_batches=24):
-    """Oracle (C port of the reference merge rule) on ONE host core, same workload shape."""
+def cpu_baseline(n_batches=24, extras=True):
+    """Oracle (C port of the reference merge rule) on ONE host core, same workload shape. extras: also the all-cores and the Node.js legs (N=1 line)."""
     from oracle.oracle import Oracle
     o = Oracle()
     o.load_rows(*gen_resident(R_PER_GPU))
@@ -124,6 +124,8 @@ def cpu_baseline(n_batches=24):
     o.close()
     out = {"value": n_batches * D_PER_STEP / dt, "unit": "merges/s", "cores": 1, "kind": "port",
            "sample": "%d x 1M-delta batches of the bench's own stream (config %d) against the 10M-row resident graph (load excluded; %.1f s of timed CPU work), oracle/bmx_oracle.c, 1 thread" % (n_batches, CONFIG, dt)}
+    if not extras:
+        return out
     # extra line: the same port on all host cores, threads owning key shards
     try:
         from oracle.oracle import OracleMT
@@ -315,13 +317,42 @@ def scan_bench(bmx, dev, R, reps=20, wide=False):
     return out
 
 
-def main():
-    global CONFIG
-    # stdout carries exactly ONE JSON line: native libraries (RCCL's version banner) print to fd 1, so fd 1 is pointed
-    # at stderr for the whole run and the JSON goes to a private duplicate of the real stdout.
+def launch_ranks(n_gpus, argv):
+    """`python bench.py --gpus N` with N > 1 and no WORLD_SIZE in the environment: this process is only the LAUNCHER. It starts
+    `python -m torch.distributed.run --nproc-per-node N bench.py <same arguments>` as a CHILD process, hands rank 0's single JSON line through and
+    exits with the child's return code. It never touches the GPU (no HIP call, no torch.cuda.is_available(): a process that has initialised
+    the GPU must neither exec nor be needed for anything here), it does not retry, and a failing child fails the run. -> exit code"""
+    import socket
+    import subprocess
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as sk:      # a free rendezvous port on the loopback interface
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")                  # dmabuf IPC: what RCCL and the direct exchange's mappings need on this driver
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n_gpus), "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + list(argv)
+    print("bench: launching %d ranks: %s" % (n_gpus, " ".join(cmd)), file=sys.stderr)
+    child = subprocess.Popen(cmd, stdout=subprocess.PIPE, env=env, text=True)
+    line = None
+    for ln in child.stdout:                                            # rank 0 prints exactly one JSON line; anything else on stdout goes to stderr
+        t = ln.strip()
+        if t.startswith("{") and t.endswith("}") and '"metric"' in t:
+            line = t
+        elif t:
+            print(t, file=sys.stderr)
+    rc = child.wait()
+    if rc != 0:
+        print("bench: the ranks exited with code %d: no result" % rc, file=sys.stderr)
+        return rc
+    if line is None:
+        print("bench: the ranks finished without printing a result line", file=sys.stderr)
+        return 1
+    sys.stdout.write(line + "\n")
     sys.stdout.flush()
-    real_stdout = os.fdopen(os.dup(1), "w")
-    os.dup2(2, 1)
+    return 0
+
+
+def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=None, help="timed steps (default: 20 for config 2, 90 for config 5)")
@@ -333,7 +364,21 @@ def main():
     ap.add_argument("--scan", action="store_true", help="(kept for compatibility: the scans are on by default)")
     ap.add_argument("--scan-rows", type=str, default="10000000,100000000", help="comma-separated index sizes of the config-3 scans")
     ap.add_argument("--force-sharded", action="store_true", help="run the N>1 code path (partition + all-to-all + merge) even with one rank: rehearsal only")
-    args = ap.parse_args()
+    ap.add_argument("--no-defer", action="store_true", help="A/B switch: keep every batch's winner compaction on the merge stream (bmx_set_deferred_compaction(0))")
+    return ap.parse_args(argv)
+
+
+def main(argv=None):
+    global CONFIG
+    args = parse_args(argv)
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # launcher role: nothing below this line runs in this process (in particular no GPU call)
+        raise SystemExit(launch_ranks(args.gpus, sys.argv[1:] if argv is None else argv))
+    # stdout carries exactly ONE JSON line: native libraries (RCCL's version banner) print to fd 1, so fd 1 is pointed
+    # at stderr for the whole run and the JSON goes to a private duplicate of the real stdout.
+    sys.stdout.flush()
+    real_stdout = os.fdopen(os.dup(1), "w")
+    os.dup2(2, 1)
     CONFIG = args.config
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -372,6 +417,9 @@ def main():
     n_profiled = min(K, 12) + min(K, 8)
     cap = int(os.environ.get("BMX_BENCH_CAP", max(22_000_000, R_PER_GPU + (nb + n_profiled + 3) * ins_per_step + 4 * D_PER_STEP)))
     eng = bmx.Engine(capacity_rows=cap, device=local_rank, load_pct=int(os.environ.get("BMX_BENCH_LOAD_PCT", 0)))
+    # deferred compaction (include/bmx.h): on by default in the library; --no-defer is the A/B switch
+    defer = not args.no_defer and (not (world > 1 or args.force_sharded) or os.environ.get("BMX_SHARDED_DEFER", "1") == "1")
+    eng.set_deferred(defer)
     main_kernel = "k_probe_apply"
     verified = None
 
@@ -456,7 +504,10 @@ def main():
     else:
         from bmx.sharded import ShardedGraph, EngineOps
         if world > 1 and os.environ.get("BMX_SHARDED_EXCHANGE", "auto") == "auto":
-            os.environ["BMX_SHARDED_EXCHANGE"] = exchange_selftest(dev, dist, rank, world)   # every rank gets the same answer (all-reduce inside)
+            # every rank gets the same answer (all-reduce inside). A passed self-test leaves the choice on "auto": should the set-up of the REAL
+            # slabs fail on some rank after all, every rank falls back to the RCCL exchange together instead of raising
+            if exchange_selftest(dev, dist, rank, world) == "rccl":
+                os.environ["BMX_SHARDED_EXCHANGE"] = "rccl"
         sg = ShardedGraph(EngineOps(eng, dev), dist, rank, world)
         sg.load_owned_resident(R_PER_GPU, T0=T0, DT=DT)
         R_global = R_PER_GPU * world
@@ -527,12 +578,12 @@ def main():
                     mine = synth.owner_of_np(cols[0], world) == rank
                     o.merge_batch(*[c[mine] for c in cols])
             ok = eng.row_count() == len(o) and rows_digest(*eng.dump_rows()) == o.digest()
-            okt = torch.tensor([1 if ok else 0], dtype=torch.int64, device=dev)
-            dist.all_reduce(okt, op=dist.ReduceOp.MIN)
-            if int(okt.item()) != 1:
-                raise SystemExit("VERIFICATION FAILED: a shard's rows differ from the oracle replay (rank %d: %s)" % (rank, "ok" if ok else "MISMATCH"))
-            verified = {"against": "oracle/bmx_oracle.c: every rank replays the deltas it owns (all originators, step order) and compares its shard",
-                        "batches": nb * world, "rows_this_rank": len(o), "ok": True, "seconds": round(time.perf_counter() - tv, 2)}
+            per_rank = [None] * world
+            dist.all_gather_object(per_rank, {"rank": rank, "ok": bool(ok), "rows": len(o), "table_digest": "%016x" % o.digest()})
+            if not all(x["ok"] for x in per_rank):
+                raise SystemExit("VERIFICATION FAILED: a shard's rows differ from the oracle replay (ranks: %s)" % ", ".join("%d %s" % (x["rank"], "ok" if x["ok"] else "MISMATCH") for x in per_rank))
+            verified = {"against": "oracle/bmx_oracle.c: every rank replays the deltas it owns (all originators, step order) and compares its shard's row count and digest",
+                        "batches": nb * world, "rows_this_rank": len(o), "ok": True, "per_rank": per_rank, "seconds": round(time.perf_counter() - tv, 2)}
             o.close()
         # second pass (every rank, same number of collectives): a few more steps with the per-kernel HIP-event brackets on, for this
         # rank's live k_probe_apply figure. The brackets are event records, i.e. stream bubbles: never part of the timed region.
@@ -551,10 +602,16 @@ def main():
         alg_bytes = 56.0 * D_PER_STEP + 16.0 * wavg         # same accounting as the N=1 line; padding records move no row bytes
         probe_s = stage_ms["probe_apply"] * 1e-3
         achieved = alg_bytes / probe_s / 1e9 if probe_s > 0 else 0.0
+        traffic = None
+        try:      # the same kernel on the same 1M-record batch shape: HBM bytes per launch of the committed rocprofv3 --pmc passes over the N=1 run
+            traffic = json.load(open(os.path.join(ROOT, "profiles", "traffic_probe_apply.json"))).get("bytes_per_launch")
+        except Exception:
+            traffic = None
         roofline = {"bound": "hbm", "kernel": main_kernel, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                    "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None, "algorithmic_bytes_per_launch": alg_bytes,
+                    "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "algorithmic_bytes_per_launch": alg_bytes,
                     "kernel_ms": {k: round(v, 5) for k, v in stage_ms.items()}, "launches_averaged": ncalls,
-                    "note": "rank 0, launches without a concurrent exchange (second pass); HBM traffic counters are collected on the N=1 run"}
+                    "traffic_source": "profiles/traffic_probe_apply.json: PMC passes over the N=1 run of this kernel (config 2, SoA columns), not re-collected per rank",
+                    "note": "rank 0, launches without a concurrent exchange (second pass, per-kernel HIP events on the merge stream)"}
         how = ("direct: the owner partition of batch b+1 stores every slab straight into its owner's IPC-mapped receive memory (peer stores over xGMI) and sets arrival words; no collective, one stream"
                if sg.exchange == "direct" else "rccl: partition + ONE all-to-all of batch b+1 on a second stream under the merge of batch b")
         extra = {"host_enqueue_ms_per_step": round(t_enq / K * 1e3, 4), "exchange": dict(sg.stats(), kind=sg.exchange, mode="fixed slabs of %d records per ordered pair; %s" % (sg.slab, how))}
@@ -576,9 +633,12 @@ def main():
             for rs in [int(x) for x in args.scan_rows.split(",") if x]:
                 out["scan_config3"]["%dM" % (rs // 1_000_000)] = scan_bench(bmx, dev, R=rs)
                 out["scan_config3"]["%dM_int64" % (rs // 1_000_000)] = scan_bench(bmx, dev, R=rs, wide=True)
-        if not sharded and not args.no_cpu_baseline:
-            out["js_host"] = js_host_rate()
-            out["cpu_baseline"] = cpu_baseline()
+        if not args.no_cpu_baseline:
+            if not sharded:
+                out["js_host"] = js_host_rate()
+                out["cpu_baseline"] = cpu_baseline()
+            else:   # the same one-core leg as the N=1 line, on rank 0, after the timed region (the other ranks wait at the barrier below)
+                out["cpu_baseline"] = cpu_baseline(n_batches=12, extras=False)
         else:
             out["cpu_baseline"] = None
     if sharded:

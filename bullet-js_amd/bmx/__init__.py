@@ -26,7 +26,7 @@ FLAG_INCOMING, FLAG_CURRENT, FLAG_HISTORICAL = 1, 2, 4
 MAX_BATCH = 1 << 24
 
 EXPORTS = [
-    "bmx_create", "bmx_create_ex", "bmx_destroy", "bmx_last_error", "bmx_abi_version", "bmx_get_info", "bmx_sync", "bmx_set_stream", "bmx_get_stream", "bmx_seq_signal", "bmx_seq_wait",
+    "bmx_create", "bmx_create_ex", "bmx_destroy", "bmx_last_error", "bmx_abi_version", "bmx_selfcheck", "bmx_set_deferred_compaction", "bmx_merge_fence", "bmx_get_deferred_counts", "bmx_get_info", "bmx_sync", "bmx_set_stream", "bmx_get_stream", "bmx_seq_signal", "bmx_seq_wait",
     "bmx_load_rows", "bmx_put_rows", "bmx_merge_batch", "bmx_merge_submit", "bmx_merge_collect", "bmx_host_alloc", "bmx_host_free", "bmx_merge_records", "bmx_get_rows", "bmx_get_row", "bmx_dump_rows", "bmx_row_count", "bmx_reserve",
     "bmx_index_build", "bmx_index_drop", "bmx_index_size", "bmx_index_refresh_counts", "bmx_scan_range", "bmx_scan_equals", "bmx_scan_count", "bmx_scan_filter", "bmx_scan_range_pos", "bmx_index_ids",
     "bmx_owner_of", "bmx_partition_by_owner", "bmx_partition_by_owner_slabs", "bmx_partition_scatter", "bmx_merge_records_after", "bmx_ipc_alloc", "bmx_ipc_open", "bmx_ipc_close", "bmx_ipc_free", "bmx_seq_wait_all", "bmx_merge_notify", "bmx_timer_start", "bmx_timer_stop", "bmx_profile_enable", "bmx_profile_read", "bmx_profile_read_scan",
@@ -89,6 +89,10 @@ def load_library():
     L.bmx_destroy.argtypes = [vp]; L.bmx_destroy.restype = None
     L.bmx_last_error.argtypes = [vp]; L.bmx_last_error.restype = C.c_char_p
     L.bmx_abi_version.argtypes = []; L.bmx_abi_version.restype = i32
+    L.bmx_selfcheck.argtypes = [i32, C.POINTER(u64), C.POINTER(u64), C.POINTER(u64)]; L.bmx_selfcheck.restype = i32
+    L.bmx_set_deferred_compaction.argtypes = [vp, i32]; L.bmx_set_deferred_compaction.restype = i32
+    L.bmx_merge_fence.argtypes = [vp]; L.bmx_merge_fence.restype = i32
+    L.bmx_get_deferred_counts.argtypes = [vp, C.POINTER(u64), C.POINTER(u64)]; L.bmx_get_deferred_counts.restype = i32
     L.bmx_get_info.argtypes = [vp, C.POINTER(Info)]; L.bmx_get_info.restype = i32
     L.bmx_sync.argtypes = [vp]; L.bmx_sync.restype = i32
     L.bmx_set_stream.argtypes = [vp, vp]; L.bmx_set_stream.restype = i32
@@ -172,6 +176,16 @@ def load_library():
     L.bmx_vc_sync.argtypes = [vp]; L.bmx_vc_sync.restype = i32
     _lib = L
     return L
+
+
+def selfcheck(device=0):
+    """bmx_selfcheck: (checked 16-byte loads, torn pairs seen, torn pairs of the split-store control). Raises if a pair tore."""
+    L = load_library()
+    r, t, c = C.c_uint64(), C.c_uint64(), C.c_uint64()
+    rc = L.bmx_selfcheck(int(device), C.byref(r), C.byref(t), C.byref(c))
+    if rc:
+        raise BmxError(rc, (L.bmx_last_error(None) or b"").decode())
+    return r.value, t.value, c.value
 
 
 def _np(a, dt):
@@ -396,6 +410,20 @@ class Engine:
     def set_stream(self, stream_ptr):
         self._chk(self.L.bmx_set_stream(self.h, C.c_void_p(stream_ptr) if stream_ptr else None))
 
+    def set_deferred(self, on):
+        """deferred compaction (bmx.h): the winner compaction of a device batch runs under the NEXT batch's probe kernel. On by default."""
+        self._chk(self.L.bmx_set_deferred_compaction(self.h, 1 if on else 0))
+
+    def merge_fence(self):
+        """enqueue-only: the engine's stream is ordered behind every compaction (for work the caller enqueues on that stream itself)"""
+        self._chk(self.L.bmx_merge_fence(self.h))
+
+    def deferred_counts(self):
+        """(merges whose compaction was deferred, of those: run on the side stream under the next probe kernel)"""
+        a, b = C.c_uint64(), C.c_uint64()
+        self._chk(self.L.bmx_get_deferred_counts(self.h, C.byref(a), C.byref(b)))
+        return a.value, b.value
+
     def seq_signal(self, stream_ptr, seq_dev, value):
         """enqueue on the stream (0 = the engine's): *seq_dev = value once everything before it on that stream is done."""
         self._chk(self.L.bmx_seq_signal(self.h, C.c_void_p(stream_ptr) if stream_ptr else None, _ptr(seq_dev), int(value)))
@@ -441,7 +469,7 @@ class Engine:
         dst = (C.c_void_p * int(nshards))(*[C.c_void_p(int(x)) for x in dst_ptrs])
         arr = (C.c_void_p * int(nshards))(*[C.c_void_p(int(x)) if x else None for x in arrive_ptrs]) if arrive_ptrs is not None else None
         self._chk(self.L.bmx_partition_scatter(self.h, int(n), _ptr(id), _ptr(field), _ptr(ts), _ptr(val), int(nshards), int(slab_records), dst, _ptr(counts_out),
-                                               arr, int(arrive_value)))
+                                               arr, int(arrive_value), None, 0, 0))
 
     @staticmethod
     def ptr_array(ptrs):

@@ -206,6 +206,7 @@ class ShardedGraph:
     def merge_step(self, n, id, field, ts, val):
         """Route this rank's n deltas to their owners and merge what arrives here. Returns the number received."""
         ops, dist, W = self.ops, self.dist, self.world
+        # (safe beside the direct exchange: only bmx_merge_records_after — the merges that read a receive slab set — count up the peers' free words)
         if self._recs is None or self._recs.shape[0] < n:
             self._recs = ops.empty_records(n)
         ops.partition(n, id, field, ts, val, W, self._recs, self._counts)
@@ -344,15 +345,14 @@ class ShardedGraph:
         from . import BmxError
         e, W, r, dist = self.ops.e, self.world, self.rank, self.dist
         rec_bytes = 32
-        own = None
+        own = {}                 # every allocation is recorded as it succeeds: whatever fails later, _free_direct gives all of them back
         try:
             # uncached: peers store into all three while kernels here poll or read them
-            recv, h_recv = e.ipc_alloc(depth * W * self.slab * rec_bytes, uncached=True)
-            arrived, h_arr = e.ipc_alloc(max(W * 8, 256), uncached=True)
-            freed, h_free = e.ipc_alloc(max(W * 8, 256), uncached=True)
-            own = dict(recv=recv, arrived=arrived, freed=freed)
+            own["recv"], h_recv = e.ipc_alloc(depth * W * self.slab * rec_bytes, uncached=True)
+            own["arrived"], h_arr = e.ipc_alloc(max(W * 8, 256), uncached=True)
+            own["freed"], h_free = e.ipc_alloc(max(W * 8, 256), uncached=True)
             mine = (self.ops.device.index or 0, os.getpid(), h_recv, h_arr, h_free, self.ops.gpu_identity() if hasattr(self.ops, "gpu_identity") else None)
-        except BmxError as err:
+        except Exception as err:      # anything at all: a rank that left here without an answer would leave the others hanging in the all_gather below
             print("bmx sharded: direct exchange unavailable on rank %d (%s)" % (r, err), file=sys.stderr)
             mine = None
         infos = [None] * W
@@ -380,7 +380,7 @@ class ShardedGraph:
                 ptrs = dict(recv=e.ipc_open(infos[g][2], pd), arrived=e.ipc_open(infos[g][3], pd), freed=e.ipc_open(infos[g][4], pd))
                 opened.extend(ptrs.values())
                 peers[g] = ptrs
-        except BmxError as err:
+        except Exception as err:      # not only BmxError: every rank must reach the agreement below
             print("bmx sharded: rank %d cannot map a peer's receive slabs (%s)" % (r, err), file=sys.stderr)
             ok = False
         if not self._all_agree(ok):
@@ -404,7 +404,7 @@ class ShardedGraph:
             self.merge(p)
             self.ops.sync()
             ok = int(p["n_applied"].cpu()[0]) == 0
-        except BmxError as err:
+        except Exception as err:
             print("bmx sharded: rank %d: the direct exchange did not complete its pre-flight batch (%s)" % (r, err), file=sys.stderr)
             ok = False
         if not self._all_agree(ok):

@@ -2,6 +2,7 @@
 // No CPU fallback exists: every entry point fails with BMX_ERR_NO_DEVICE / BMX_ERR_HIP when there is no GPU.
 #include <hip/hip_runtime.h>
 #include <algorithm>
+#include <atomic>
 #include <chrono>
 #include <climits>
 #include <cmath>
@@ -33,6 +34,7 @@ struct DevScalars {  // one small device allocation; zeroed at create
   uint32_t wide;
   unsigned long long seq_diag[3];  // k_seq_wait expiry: {sequence word address, value waited for, value last seen}
   unsigned long long chg_n[2];     // entries in the index change log: batch k reads [k&1], its compaction writes [(k+1)&1]
+  unsigned long long seqw[2];      // deferred compaction: [0] = number of the latest probe kernel that has started, [1] = of the latest compaction finished on the side stream
 };
 
 struct Index {
@@ -48,7 +50,10 @@ struct Index {
 
 thread_local std::string g_err;
 constexpr uint32_t PROF_MAX_CALLS = 64;
-constexpr int MERGE_FORCE_INTERNAL = 0x4000;   // insert_mode bit used by bmx_put_rows only (not in bmx.h)
+constexpr int MERGE_FORCE_INTERNAL = 0x4000;   // marker carried by the INTERNAL host-batch helpers (merge_host, submit_host) for bmx_put_rows; never accepted from a caller
+inline bool public_mode_ok(int insert_mode) {  // what bmx.h documents: BMX_INSERT_* plus the three optional bits
+  return (insert_mode & ~(BMX_INSERT_DELTA | BMX_MERGE_UNIQUE_KEYS | BMX_MERGE_STRICT_FLAGS | BMX_MERGE_MARK_CREATED)) == 0;
+}
 
 }  // namespace
 
@@ -64,12 +69,18 @@ struct bmx_ctx {
   // per-batch workspace (grown on demand)
   uint32_t ws_cap = 0;
   uint32_t* next = nullptr;
-  uint8_t* wflag = nullptr;
-  uint32_t* slot_of = nullptr;
-  uint32_t* blk_info = nullptr;       // 2 x (ws_cap/256 + 16) block summaries: batch k uses half k & 1, k_probe_apply zeroes the other half for batch k + 1
-  uint32_t blk_half = 0, blk_par = 0; bool blk_clean[2] = {false, false};   // blk_clean[h]: half h is known to be all zero
+  // what the compaction (K3) reads is kept per batch PARITY, so that the compaction of batch b can run on a second stream while the probe
+  // kernel of batch b + 1 fills the other set ("deferred compaction", merge_core): winner bytes, the claimers' slots, the deltas' field
+  // hashes (for the index change log) and the sharded counters
+  uint8_t* wflag[2] = {nullptr, nullptr};
+  uint32_t* slot_of[2] = {nullptr, nullptr};
+  uint32_t* fld_ws[2] = {nullptr, nullptr};
+  uint32_t ws_par = 0;
+  uint32_t* blk_info = nullptr;       // 3 x (ws_cap/256 + 16) block summaries: batch k adds into segment k % 3 and k_probe_apply zeroes segment (k + 1) % 3 for batch k + 1;
+                                      // three, because the compaction of batch k - 1 may still read segment (k - 1) % 3 while batch k is probed
+  uint32_t blk_half = 0, blk_seg = 0; bool blk_clean[3] = {false, false, false};   // blk_clean[h]: segment h is known to be all zero
   uint32_t* blk_follow = nullptr;     // ws_cap/256 epoch tags: a delta of the block got a follower on its row
-  unsigned long long* shard_ctr = nullptr;  // CTR_SHARDS * CTR_STRIDE
+  unsigned long long* shard_ctr = nullptr;  // 2 x CTR_SHARDS * CTR_STRIDE (one set per batch parity)
   // staging for BMX_MEM_HOST calls
   // Two staging sets: batch b+1 is uploaded (copy stream) while batch b is merged (main stream); bmx_merge_submit / bmx_merge_collect
   struct Staging {
@@ -119,7 +130,20 @@ struct bmx_ctx {
   uint64_t ix_full_builds = 0, ix_incremental = 0;
   // bmx_merge_notify: words (possibly in other GPUs' memory) that every merge's last workgroup sets to the number of merges finished since
   SeqPtrs notify{}; uint32_t n_notify = 0; uint64_t notify_seq = 0;
+  bool notify_armed = false;          // set by bmx_merge_records_after around ITS merge: only the merges of the slab protocol count up the peers' free words
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
+  // Deferred compaction (merge_core): the compaction of a device-resident batch is not launched with the batch. If the next call is another such
+  // merge, it goes to a high-priority side stream behind a one-wave wait for that merge's probe kernel to START (= everything of this batch is
+  // done), and runs under that probe kernel; anything else launches it on the context's stream first (flush_pending).
+  struct PendingK3 {
+    bool on = false;
+    const uint8_t* wflag = nullptr; const uint32_t* blk = nullptr; uint32_t n = 0; uint32_t* applied = nullptr;
+    FinishMerge Fin{}; ChgLog L{}; uint32_t mark_created = 0; bool notify_after = false; uint64_t notify_seq = 0; uint64_t seq = 0;
+  } pend;
+  bool defer_enabled = true;
+  hipStream_t side = nullptr;
+  uint64_t dseq = 0;                  // deferred merges so far (the sequence numbers in ds->seqw)
+  uint64_t n_deferred = 0, n_side = 0;   // merges whose compaction was deferred / actually ran on the side stream (bmx_get_deferred_counts)
   // optional per-kernel profiling (bmx_profile_enable)
   bool prof_on = false;
   uint32_t prof_n = 0;
@@ -215,22 +239,27 @@ void tighten_rows_ub(bmx_ctx* ctx) {
   ctx->rows_ub = std::min<uint64_t>(ctx->rows_ub, seen_rows + pending);
 }
 
+int flush_pending(bmx_ctx* ctx);
 int ensure_workspace(bmx_ctx* ctx, uint64_t n) {
   if (n <= ctx->ws_cap) return BMX_OK;
+  if (int frc = flush_pending(ctx)) return frc;      // a compaction not launched yet reads the workspace this call frees
   HIPCHK(hipStreamSynchronize(ctx->stream));
   uint64_t cap = std::max<uint64_t>(n, std::min<uint64_t>((uint64_t)ctx->ws_cap * 2, MAX_BATCH));
   cap = std::max<uint64_t>(cap, 1u << 16);
   cap = (cap + 255) & ~255ull;
-  dev_free(ctx->next); dev_free(ctx->wflag); dev_free(ctx->slot_of); dev_free(ctx->blk_info); dev_free(ctx->blk_follow);
+  dev_free(ctx->next); dev_free(ctx->blk_info); dev_free(ctx->blk_follow);
+  for (int h = 0; h < 2; h++) { dev_free(ctx->wflag[h]); dev_free(ctx->slot_of[h]); dev_free(ctx->fld_ws[h]); }
   ctx->ws_cap = 0;
   int rc;
-  if ((rc = dev_alloc(ctx, &ctx->next, cap)) || (rc = dev_alloc(ctx, &ctx->wflag, cap + 16)) || (rc = dev_alloc(ctx, &ctx->slot_of, cap))) return rc;
-  if ((rc = dev_alloc(ctx, &ctx->blk_info, 2 * ((cap / 256 + 16 + 3) & ~3ull))) || (rc = dev_alloc(ctx, &ctx->blk_follow, cap / 256 + 16))) return rc;
+  if ((rc = dev_alloc(ctx, &ctx->next, cap))) return rc;
+  for (int h = 0; h < 2; h++)
+    if ((rc = dev_alloc(ctx, &ctx->wflag[h], cap + 16)) || (rc = dev_alloc(ctx, &ctx->slot_of[h], cap)) || (rc = dev_alloc(ctx, &ctx->fld_ws[h], cap))) return rc;
+  if ((rc = dev_alloc(ctx, &ctx->blk_info, 3 * ((cap / 256 + 16 + 3) & ~3ull))) || (rc = dev_alloc(ctx, &ctx->blk_follow, cap / 256 + 16))) return rc;
   HIPCHK(hipMemsetAsync(ctx->next, 0, cap * sizeof(uint32_t), ctx->stream));
   HIPCHK(hipMemsetAsync(ctx->blk_follow, 0, (cap / 256 + 16) * sizeof(uint32_t), ctx->stream));
-  ctx->blk_half = (uint32_t)((cap / 256 + 16 + 3) & ~3ull);    // a multiple of four entries: both halves stay 16-byte aligned for the compaction's wide loads
-  HIPCHK(hipMemsetAsync(ctx->blk_info, 0, 2 * (size_t)ctx->blk_half * sizeof(uint32_t), ctx->stream));
-  ctx->blk_clean[0] = ctx->blk_clean[1] = true;
+  ctx->blk_half = (uint32_t)((cap / 256 + 16 + 3) & ~3ull);    // a multiple of four entries: every segment stays 16-byte aligned for the compaction's wide loads
+  HIPCHK(hipMemsetAsync(ctx->blk_info, 0, 3 * (size_t)ctx->blk_half * sizeof(uint32_t), ctx->stream));
+  ctx->blk_clean[0] = ctx->blk_clean[1] = ctx->blk_clean[2] = true;
   ctx->ws_cap = (uint32_t)cap;
   return BMX_OK;
 }
@@ -309,29 +338,67 @@ int grow_table(bmx_ctx* ctx, uint64_t capacity_rows) {
   return check_status(ctx);
 }
 
-// The merge proper: all pointers are device pointers; only enqueues work.
+// ---- deferred compaction ---------------------------------------------------------------------------------------------------------------
+// K3 (k_compact_winners) reads only per-batch workspace — winner bytes, block counts, the claimers' slots — and writes what the CALLER reads
+// after bmx_sync(): applied_idx, n_applied, stats. Nothing the next batch's probe kernel needs. So for a stream of device-resident batches the
+// compaction of batch b runs on a second, high-priority stream UNDER the probe kernel of batch b + 1 (which is bound by memory-side requests in
+// flight, not by CUs), and the context's stream carries K1 -> K2 -> K1 -> K2 ... only. Ordering without command-processor markers (an event
+// record between two kernels holds a stream ~10 us, bmx.h "bmx_seq_signal"):
+//   side stream:  k_seq_wait(seqw[0] >= q + 1)  ->  K3(q)  ->  k_seq_signal(seqw[1] = q)
+//   main stream:  K1(q + 1) [block 0 stores seqw[0] = q + 1 when it starts: K2(q) is done]  ->  K2(q + 1) [block 0 returns once seqw[1] >= q]
+// so K3(q) is complete before K1(q + 2) overwrites the workspace half it read, whatever the side stream's queue does. K3 is launched LATE: a
+// merge only records it (ctx->pend); the next deferring merge puts it on the side stream, anything else (bmx_sync, a scan, a host batch, a
+// merge on another path, ...) launches it on the context's own stream first (flush_pending, called by every entry point) — after which that
+// stream is ordered behind everything, because the K2 in front of it waited for the only compaction that could still be running on the side.
+void launch_k3(bmx_ctx* ctx, const bmx_ctx::PendingK3& P, hipStream_t ks) {
+  hipLaunchKernelGGL((k_compact_winners<FinishMerge>), dim3((uint32_t)(((uint64_t)P.n + 4095) / 4096)), dim3(SEL_THREADS), 0, ks, P.wflag, P.blk, P.n,
+                     P.applied, P.Fin, P.L, P.mark_created);
+  if (P.notify_after) hipLaunchKernelGGL(k_seq_signal_multi, dim3(1), dim3(64), 0, ks, ctx->notify, ctx->n_notify, (unsigned long long)P.notify_seq);
+}
+int flush_pending(bmx_ctx* ctx) {
+  if (!ctx->pend.on) return BMX_OK;
+  ctx->pend.on = false;
+  launch_k3(ctx, ctx->pend, ctx->stream);
+  LAUNCHCHK("k_compact_winners");
+  return BMX_OK;
+}
+// every entry point that is not a deferring merge: bind the device, launch a compaction that is still only recorded
+int enter(bmx_ctx* ctx) {
+  HIPCHK(hipSetDevice(ctx->device));
+  return flush_pending(ctx);
+}
+constexpr uint64_t DEFER_MIN_N = 1u << 16;   // below this a batch is launch-bound: the side stream's three extra launches would cost more than the compaction
+
+// The merge proper: all pointers are device pointers; only enqueues work. `defer`: the caller reads applied_idx / n_applied / stats only after
+// bmx_sync() or another bmx_* call on this context (the BMX_MEM_DEVICE contract), so the compaction may be deferred (above).
 template <bool AOS>
 int merge_core(bmx_ctx* ctx, uint64_t n, const uint64_t* id, const uint32_t* field, const int64_t* ts, const int64_t* val,
                const bmx_delta_rec* recs, int insert_mode, uint32_t* applied_idx, uint64_t* n_applied, uint8_t* flags,
-               bmx_merge_stats* stats) {
+               bmx_merge_stats* stats, bool defer = false, bool force = false) {
   if (n > MAX_BATCH) return fail(ctx, BMX_ERR_INVALID, "batch larger than 2^24 deltas: split it (sequential semantics are preserved)");
   const uint32_t mark_created = (insert_mode & BMX_MERGE_MARK_CREATED) ? 1u : 0u;
-  const bool force = (insert_mode & MERGE_FORCE_INTERNAL) != 0;      // bmx_put_rows: unique keys, stored as given
-  const bool unique = (insert_mode & BMX_MERGE_UNIQUE_KEYS) != 0 || force;
+  const bool unique = (insert_mode & BMX_MERGE_UNIQUE_KEYS) != 0 || force;      // force = bmx_put_rows: unique keys, stored as given
   const bool strict = (insert_mode & BMX_MERGE_STRICT_FLAGS) != 0;
-  insert_mode &= ~(BMX_MERGE_UNIQUE_KEYS | BMX_MERGE_STRICT_FLAGS | BMX_MERGE_MARK_CREATED | MERGE_FORCE_INTERNAL);
+  if (insert_mode & ~(BMX_INSERT_DELTA | BMX_MERGE_UNIQUE_KEYS | BMX_MERGE_STRICT_FLAGS | BMX_MERGE_MARK_CREATED)) return fail(ctx, BMX_ERR_INVALID, "bad insert_mode");
+  insert_mode &= ~(BMX_MERGE_UNIQUE_KEYS | BMX_MERGE_STRICT_FLAGS | BMX_MERGE_MARK_CREATED);
   if (force) insert_mode = BMX_INSERT_DELTA;
   if (unique && strict) return fail(ctx, BMX_ERR_INVALID, "BMX_MERGE_STRICT_FLAGS cannot be combined with BMX_MERGE_UNIQUE_KEYS");
   if (insert_mode != BMX_INSERT_REFERENCE && insert_mode != BMX_INSERT_DELTA) return fail(ctx, BMX_ERR_INVALID, "bad insert_mode");
+  int rc;
+  hipEvent_t* pe = (ctx->prof_on && ctx->prof_n < PROF_MAX_CALLS) ? &ctx->prof_ev[4 * ctx->prof_n] : nullptr;
+  // the compaction of THIS batch is deferred iff the default path runs (K1 + K2) on a batch big enough to hide it behind; per-kernel profiling brackets every launch
+  const bool deferring = defer && ctx->defer_enabled && !strict && !unique && !pe && n >= DEFER_MIN_N;
+  if (!deferring && (rc = flush_pending(ctx))) return rc;     // everything else sees the stream in order
   if (n == 0) {
+    if ((rc = flush_pending(ctx))) return rc;
     if (n_applied) HIPCHK(hipMemsetAsync(n_applied, 0, sizeof(uint64_t), ctx->stream));
     if (stats) HIPCHK(hipMemsetAsync(stats, 0, sizeof(bmx_merge_stats), ctx->stream));
     return BMX_OK;
   }
   // capacity guards: physical (never let probing run out of empty slots) and logical (capacity_rows)
-  int rc;
   if (ctx->rows_ub + n >= ctx->nslots || ctx->rows_ub > ctx->capacity_rows) tighten_rows_ub(ctx);
   if (ctx->rows_ub + n >= ctx->nslots || ctx->rows_ub > ctx->capacity_rows) {
+    if ((rc = flush_pending(ctx))) return rc;                 // the exact row count is the last compaction's
     rc = refresh_rows(ctx);
     if (rc) return rc;
     if (ctx->rows_ub + n >= ctx->nslots || ctx->rows_ub > ctx->capacity_rows) {
@@ -342,6 +409,11 @@ int merge_core(bmx_ctx* ctx, uint64_t n, const uint64_t* id, const uint32_t* fie
   }
   rc = ensure_workspace(ctx, n);
   if (rc) return rc;
+  if (deferring && !ctx->side) {
+    int lo = 0, hi = 0;
+    HIPCHK(hipDeviceGetStreamPriorityRange(&lo, &hi));      // hi = the numerically smallest = highest priority: a hardware queue of its own
+    HIPCHK(hipStreamCreateWithPriority(&ctx->side, hipStreamNonBlocking, hi));
+  }
   if (++ctx->epoch > EPOCH_MAX) {  // tags wrap: forget every claim
     hipLaunchKernelGGL(k_sweep_heads, dim3(2048), dim3(256), 0, ctx->stream, ctx->slots, ctx->nslots);
     LAUNCHCHK("k_sweep_heads");
@@ -349,23 +421,44 @@ int merge_core(bmx_ctx* ctx, uint64_t n, const uint64_t* id, const uint32_t* fie
     HIPCHK(hipMemsetAsync(ctx->blk_follow, 0, ((size_t)ctx->ws_cap / 256 + 16) * sizeof(uint32_t), ctx->stream));
     ctx->epoch = 1;
   }
-  uint8_t* wflag = ctx->wflag;
-  unsigned long long* ctr = ctx->shard_ctr;
+  // this batch's workspace set (parity) and block-summary segment
+  const uint32_t par = (ctx->ws_par ^= 1u);
+  const uint32_t seg = ctx->blk_seg, seg_next = (seg + 1u) % 3u;
+  ctx->blk_seg = seg_next;
+  uint8_t* wflag = ctx->wflag[par];
+  unsigned long long* ctr = ctx->shard_ctr + (size_t)par * CTR_SHARDS * CTR_STRIDE;
   MergeArgs A;
   A.slots = ctx->slots; A.nslots = ctx->nslots;
   A.id = id; A.field = field; A.ts = ts; A.val = val; A.recs = recs;
   A.n = (uint32_t)n; A.epoch = ctx->epoch;
   A.next = ctx->next; A.wflag = wflag; A.flags = flags;
-  A.slot_of = ctx->slot_of; A.blk_follow = ctx->blk_follow; A.shard_ctr = ctr; A.status = &ctx->ds->status;
-  A.blk_info = ctx->blk_info + (size_t)ctx->blk_par * ctx->blk_half; A.blk_next = ctx->blk_info + (size_t)(ctx->blk_par ^ 1u) * ctx->blk_half; A.blk_ents = ctx->blk_half;
-  const bool wave_k1 = !strict;       // k_probe_apply: adds into its half, zeroes the other one
-  if (wave_k1 && !ctx->blk_clean[ctx->blk_par]) HIPCHK(hipMemsetAsync(A.blk_info, 0, (size_t)ctx->blk_half * sizeof(uint32_t), ctx->stream));   // a batch on another path used this half last
-  ctx->blk_clean[ctx->blk_par] = false; if (wave_k1) ctx->blk_clean[ctx->blk_par ^ 1u] = true;
-  ctx->blk_par ^= 1u;
+  A.slot_of = ctx->slot_of[par]; A.blk_follow = ctx->blk_follow; A.shard_ctr = ctr; A.status = &ctx->ds->status;
+  A.blk_info = ctx->blk_info + (size_t)seg * ctx->blk_half; A.blk_next = ctx->blk_info + (size_t)seg_next * ctx->blk_half; A.blk_ents = ctx->blk_half;
+  const bool wave_k1 = !strict;       // k_probe_apply: adds into its segment, zeroes the next one
+  if (wave_k1 && !ctx->blk_clean[seg]) HIPCHK(hipMemsetAsync(A.blk_info, 0, (size_t)ctx->blk_half * sizeof(uint32_t), ctx->stream));   // a batch on another path used this segment last
+  ctx->blk_clean[seg] = false; ctx->blk_clean[seg_next] = wave_k1;
   A.force = force ? 1u : 0u;
+  // the index change log of this batch (written by its compaction): decided here because a deferred compaction reads the deltas' fields from a copy
+  ChgLog L{};
+  if (ctx->chg_valid) {
+    if (!strict && (!unique || force) && ctx->chg_ub + n <= ctx->chg_cap && ctx->nslots < (1ull << 31)) {
+      L.chg = ctx->chg; L.base = &ctx->ds->chg_n[ctx->chg_par]; L.next = &ctx->ds->chg_n[ctx->chg_par ^ 1u];
+      L.slot_of = ctx->slot_of[par]; L.field = field; L.recs = recs; L.cap = ctx->chg_cap;
+      if (deferring) { A.fld_out = ctx->fld_ws[par]; L.field = ctx->fld_ws[par]; L.recs = nullptr; }   // the caller's columns need not outlive this call's kernels
+      ctx->chg_par ^= 1u; ctx->chg_ub += n;
+    } else {
+      ctx->chg_valid = false;   // this batch is not in the log (another merge path, or the log is full): the next scan rebuilds
+    }
+  }
+  A.log_slots = (L.chg != nullptr) ? 1u : 0u;
+  const bool side_k3 = deferring && ctx->pend.on;     // the compaction of the batch before goes to the side stream, under this batch's probe kernel
+  if (deferring) {
+    ++ctx->dseq;
+    A.started = &ctx->ds->seqw[0]; A.started_val = ctx->dseq;
+    if (side_k3) { A.k3_done = &ctx->ds->seqw[1]; A.k3_wait = ctx->pend.seq; }
+  }
   const uint32_t blocks = (uint32_t)((n + 255) / 256);
   const uint32_t rblocks = blocks;   // one lane per delta
-  hipEvent_t* pe = (ctx->prof_on && ctx->prof_n < PROF_MAX_CALLS) ? &ctx->prof_ev[4 * ctx->prof_n] : nullptr;
   if (pe) HIPCHK(hipEventRecord(pe[0], ctx->stream));
   if (strict) {
     hipLaunchKernelGGL((k_probe_link_strict<AOS>), dim3(blocks), dim3(256), 0, ctx->stream, A);
@@ -381,6 +474,15 @@ int merge_core(bmx_ctx* ctx, uint64_t n, const uint64_t* id, const uint32_t* fie
     }
   }
   LAUNCHCHK("k_probe_apply");
+  if (side_k3) {
+    // K1 of this batch is enqueued: the wait below cannot be left without its signal. K3 of the batch before, on the side stream.
+    hipLaunchKernelGGL(k_seq_wait, dim3(1), dim3(64), 0, ctx->side, (const unsigned long long*)&ctx->ds->seqw[0], (unsigned long long)ctx->dseq, &ctx->ds->status, ctx->ds->seq_diag);
+    launch_k3(ctx, ctx->pend, ctx->side);
+    hipLaunchKernelGGL(k_seq_signal, dim3(1), dim3(64), 0, ctx->side, &ctx->ds->seqw[1], (unsigned long long)ctx->pend.seq);
+    ctx->pend.on = false;
+    ctx->n_side++;
+    LAUNCHCHK("deferred k_compact_winners");
+  }
   if (pe) HIPCHK(hipEventRecord(pe[1], ctx->stream));
   if (strict) {   // flags for every delta against the untouched rows, then the final state by the last claimers
     if (insert_mode == BMX_INSERT_REFERENCE) {
@@ -397,30 +499,33 @@ int merge_core(bmx_ctx* ctx, uint64_t n, const uint64_t* id, const uint32_t* fie
   LAUNCHCHK("k_resolve_lists");
   if (pe) HIPCHK(hipEventRecord(pe[2], ctx->stream));
   // K3: ordered compaction of the winner bytes (+ the index change log while an index is being maintained)
-  hipStream_t ks = ctx->stream;
-  FinishMerge Fin{reinterpret_cast<unsigned long long*>(n_applied), stats, ctr, &ctx->ds->row_count};
-  if (ctx->host_rows) { Fin.host_mirror = ctx->host_rows; Fin.seq = ++ctx->batch_seq; ctx->inflight.emplace_back(Fin.seq, n); }
-  const bool notify_after = ctx->n_notify && ctx->chg_valid;   // with an index change log the compaction's workgroups still read the batch: tell the peers from a launch behind it
-  if (ctx->n_notify) { ++ctx->notify_seq; if (!notify_after) { Fin.notify = ctx->notify; Fin.n_notify = ctx->n_notify; Fin.notify_value = ctx->notify_seq; } }
-  ChgLog L{};
-  if (ctx->chg_valid) {
-    if (!strict && (!unique || force) && ctx->chg_ub + n <= ctx->chg_cap && ctx->nslots < (1ull << 31)) {
-      L.chg = ctx->chg; L.base = &ctx->ds->chg_n[ctx->chg_par]; L.next = &ctx->ds->chg_n[ctx->chg_par ^ 1u];
-      L.slot_of = ctx->slot_of; L.field = field; L.recs = recs; L.cap = ctx->chg_cap;
-      ctx->chg_par ^= 1u; ctx->chg_ub += n;
-    } else {
-      ctx->chg_valid = false;   // this batch is not in the log (another merge path, or the log is full): the next scan rebuilds
-    }
+  bmx_ctx::PendingK3 P;
+  P.wflag = wflag; P.blk = A.blk_info; P.n = (uint32_t)n; P.applied = applied_idx; P.L = L; P.mark_created = mark_created;
+  P.Fin = FinishMerge{reinterpret_cast<unsigned long long*>(n_applied), stats, ctr, &ctx->ds->row_count};
+  if (ctx->host_rows) { P.Fin.host_mirror = ctx->host_rows; P.Fin.seq = ++ctx->batch_seq; ctx->inflight.emplace_back(P.Fin.seq, n); }
+  const bool notifying = ctx->n_notify && ctx->notify_armed;
+  P.notify_after = notifying && L.chg && !deferring;   // a change log read from the caller's columns: the compaction's workgroups still read the batch, so the peers are told from a launch behind it
+  if (notifying) { P.notify_seq = ++ctx->notify_seq; if (!P.notify_after) { P.Fin.notify = ctx->notify; P.Fin.n_notify = ctx->n_notify; P.Fin.notify_value = ctx->notify_seq; } }
+  if (deferring) {
+    P.on = true; P.seq = ctx->dseq;
+    ctx->pend = P;
+    ctx->n_deferred++;
+  } else {
+    launch_k3(ctx, P, ctx->stream);
+    LAUNCHCHK("k_compact_winners");
   }
-  hipLaunchKernelGGL((k_compact_winners<FinishMerge>), dim3((uint32_t)((n + 4095) / 4096)), dim3(SEL_THREADS), 0, ks, wflag, A.blk_info, (uint32_t)n,
-                     applied_idx, Fin, L, mark_created);
-  LAUNCHCHK("k_compact_winners");
-  if (notify_after) { hipLaunchKernelGGL(k_seq_signal_multi, dim3(1), dim3(64), 0, ks, ctx->notify, ctx->n_notify, (unsigned long long)ctx->notify_seq); LAUNCHCHK("k_seq_signal_multi"); }
-  if (pe) { HIPCHK(hipEventRecord(pe[3], ks)); ctx->prof_n++; }
+  if (pe) { HIPCHK(hipEventRecord(pe[3], ctx->stream)); ctx->prof_n++; }
   ctx->nbatch++;
   ctx->rows_ub += n;
   ctx->version++;
   return BMX_OK;
+}
+
+// records already on the device, for callers INSIDE the library (the communicator): the put marker is honoured, the compaction is never deferred
+int merge_records_internal(bmx_ctx* ctx, uint64_t n, const bmx_delta_rec* recs, int insert_mode, uint32_t* applied_idx, uint64_t* n_applied, bmx_merge_stats* stats) {
+  HIPCHK(hipSetDevice(ctx->device));
+  return merge_core<true>(ctx, n, nullptr, nullptr, nullptr, nullptr, recs, insert_mode & ~MERGE_FORCE_INTERNAL, applied_idx, n_applied, nullptr, stats, false,
+                          (insert_mode & MERGE_FORCE_INTERNAL) != 0);
 }
 
 // Host batches go through two staging sets. submit: upload on the copy stream, then the merge on the main stream behind an event;
@@ -448,8 +553,8 @@ int submit_host(bmx_ctx* ctx, uint64_t n, const uint64_t* id, const uint32_t* fi
     // a copy from page-locked memory (bmx_host_alloc) is truly asynchronous: bmx_merge_submit promises that the arrays may be reused on return
     if (inputs_free_on_return) HIPCHK(hipEventSynchronize(S.up));
   }
-  rc = merge_core<false>(ctx, n, S.id, S.field, S.ts, S.val, nullptr, insert_mode, S.applied, reinterpret_cast<uint64_t*>(S.n_out),
-                         want_flags ? S.flags : nullptr, S.stats);
+  rc = merge_core<false>(ctx, n, S.id, S.field, S.ts, S.val, nullptr, insert_mode & ~MERGE_FORCE_INTERNAL, S.applied, reinterpret_cast<uint64_t*>(S.n_out),
+                         want_flags ? S.flags : nullptr, S.stats, false, (insert_mode & MERGE_FORCE_INTERNAL) != 0);
   if (rc) return rc;
   if (S.tail) {
     hipLaunchKernelGGL(k_small_tail, dim3(1), dim3(64), 0, ctx->stream, (const unsigned long long*)S.n_out, (const bmx_merge_stats*)S.stats, (const uint32_t*)&ctx->ds->status, S.tail);
@@ -499,11 +604,11 @@ constexpr size_t SMALL_IN_BYTES = SMALL_HOST_N * 28, SMALL_OUT_APPLIED = 0, SMAL
                  SMALL_OUT_BYTES = SMALL_OUT_TAIL + sizeof(SmallOut);
 bool ensure_pinned(bmx_ctx* ctx) {   // the two mapped host buffers of the small-call paths (merge, point reads, scans); false = fall back to copies
   if (ctx->pin_in) return true;
+  { const char* t = std::getenv("BMX_TEST_FAIL_PINNED"); if (t && t[0] == '1') return false; }   // test hook: as if the page-locked allocation had failed
   if (hipHostMalloc(reinterpret_cast<void**>(&ctx->pin_in), SMALL_IN_BYTES, hipHostMallocMapped) != hipSuccess ||
       hipHostMalloc(reinterpret_cast<void**>(&ctx->pin_out), SMALL_OUT_BYTES, hipHostMallocMapped) != hipSuccess) {
     (void)hipGetLastError();
-    if (ctx->stg_tails) { (void)hipHostFree(ctx->stg_tails); ctx->stg_tails = nullptr; }
-  if (ctx->pin_in) { (void)hipHostFree(ctx->pin_in); ctx->pin_in = nullptr; }
+    if (ctx->pin_in) { (void)hipHostFree(ctx->pin_in); ctx->pin_in = nullptr; }
     ctx->pin_out = nullptr;
     return false;
   }
@@ -522,8 +627,8 @@ int merge_host_small(bmx_ctx* ctx, uint64_t n, const uint64_t* id, const uint32_
   uint8_t* o_flags = ctx->pin_out + SMALL_OUT_FLAGS;
   SmallOut* o_tail = reinterpret_cast<SmallOut*>(ctx->pin_out + SMALL_OUT_TAIL);
   // count and stats go through device scalars first (the merge's last workgroup read-modify-writes them), then one thread copies them out
-  int rc = merge_core<false>(ctx, n, p_id, p_field, p_ts, p_val, nullptr, insert_mode, applied_idx ? o_applied : nullptr, reinterpret_cast<uint64_t*>(&ctx->ds->n_out),
-                             flags ? o_flags : nullptr, &ctx->ds->stats);
+  int rc = merge_core<false>(ctx, n, p_id, p_field, p_ts, p_val, nullptr, insert_mode & ~MERGE_FORCE_INTERNAL, applied_idx ? o_applied : nullptr, reinterpret_cast<uint64_t*>(&ctx->ds->n_out),
+                             flags ? o_flags : nullptr, &ctx->ds->stats, false, (insert_mode & MERGE_FORCE_INTERNAL) != 0);
   if (rc) return rc;
   hipLaunchKernelGGL(k_small_tail, dim3(1), dim3(64), 0, ctx->stream, (const unsigned long long*)&ctx->ds->n_out, (const bmx_merge_stats*)&ctx->ds->stats,
                      (const uint32_t*)&ctx->ds->status, o_tail);
@@ -818,7 +923,7 @@ int run_scan(bmx_ctx* ctx, const Pred& P, const Index* ix, uint64_t* out_ids, ui
 
 // second half of a deferred host-mode scan: wait for the scan enqueued with ctx->scan_defer set, deliver the count and up to `cap` ids
 int scan_collect(bmx_ctx* ctx, uint64_t* out_ids, uint64_t cap, uint64_t* n_out) {
-  HIPCHK(hipSetDevice(ctx->device));
+  if (int erc = enter(ctx)) return erc;
   unsigned long long m = 0;
   HIPCHK(hipMemcpyAsync(&m, &ctx->ds->n_out, sizeof(m), hipMemcpyDeviceToHost, ctx->stream));
   HIPCHK(hipStreamSynchronize(ctx->stream));
@@ -859,6 +964,42 @@ const char* bmx_last_error(const bmx_ctx* ctx) { return ctx ? ctx->err.c_str() :
 
 uint32_t bmx_owner_of(uint64_t id, uint32_t nshards) { return (uint32_t)(((unsigned __int128)owner_hash(id) * nshards) >> 64); }
 
+// bmx.h "bmx_selfcheck". Synchronous, on the device's default stream of the calling thread; allocates and frees 128 KB + 4 words.
+int bmx_selfcheck(int device, uint64_t* reads_out, uint64_t* torn_out, uint64_t* control_torn_out) {
+  bmx_ctx* ctx = nullptr;
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) return fail(nullptr, BMX_ERR_NO_DEVICE, "no HIP device: this library has no CPU path");
+  if (device < 0 || device >= ndev) return fail(nullptr, BMX_ERR_INVALID, "bmx_selfcheck: device index out of range");
+  HIPCHK(hipSetDevice(device));
+  constexpr uint32_t NS = 4096, ITERS = 1500, BLOCKS = 1024;     // 4096 hot slots (128 KB: every line is written and read all the time), ~2*10^8 checked loads
+  uint4* slots = nullptr; unsigned long long* d = nullptr;
+  if (hipMalloc(reinterpret_cast<void**>(&slots), (size_t)NS * 32) != hipSuccess || hipMalloc(reinterpret_cast<void**>(&d), 4 * sizeof(unsigned long long)) != hipSuccess) {
+    (void)hipGetLastError(); if (slots) (void)hipFree(slots);
+    return fail(nullptr, BMX_ERR_NOMEM, "bmx_selfcheck: out of device memory");
+  }
+  unsigned long long h[4] = {0, 0, 0, 0};
+  hipError_t e = hipMemset(slots, 0, (size_t)NS * 32);
+  if (e == hipSuccess) e = hipMemset(d, 0, 4 * sizeof(unsigned long long));
+  if (e == hipSuccess) { hipLaunchKernelGGL(k_selfcheck_tear<false>, dim3(BLOCKS), dim3(256), 0, 0, slots, NS, ITERS, d, d + 1); e = hipGetLastError(); }
+  if (e == hipSuccess) e = hipDeviceSynchronize();
+  if (e == hipSuccess) e = hipMemset(slots, 0, (size_t)NS * 32);
+  if (e == hipSuccess) { hipLaunchKernelGGL(k_selfcheck_tear<true>, dim3(BLOCKS), dim3(256), 0, 0, slots, NS, ITERS / 4, d + 2, d + 3); e = hipGetLastError(); }
+  if (e == hipSuccess) e = hipDeviceSynchronize();
+  if (e == hipSuccess) e = hipMemcpy(h, d, sizeof(h), hipMemcpyDeviceToHost);
+  (void)hipFree(slots); (void)hipFree(d);
+  if (e != hipSuccess) return fail_hip(nullptr, e, "bmx_selfcheck");
+  if (reads_out) *reads_out = h[1];
+  if (torn_out) *torn_out = h[0];
+  if (control_torn_out) *control_torn_out = h[2];
+  if (h[0]) {
+    char buf[240];
+    snprintf(buf, sizeof(buf), "self-check failed on device %d: %llu of %llu aligned 16-byte loads saw HALF of an aligned 16-byte store; the merge kernel's exactness needs them indivisible (DESIGN.md section 4)",
+             device, h[0], h[1]);
+    return fail(nullptr, BMX_ERR_INTERNAL, buf);
+  }
+  return BMX_OK;
+}
+
 int bmx_create(int device, uint64_t capacity_rows, uint32_t flags, bmx_ctx** out) {
   return bmx_create_ex(device, capacity_rows, 0, flags, out);
 }
@@ -875,6 +1016,15 @@ int bmx_create_ex(int device, uint64_t capacity_rows, uint32_t max_load_pct, uin
   hipError_t e = hipGetDeviceCount(&ndev);
   if (e != hipSuccess || ndev == 0) return fail(nullptr, BMX_ERR_NO_DEVICE, "no HIP device: this library has no CPU path");
   if (device < 0 || device >= ndev) return fail(nullptr, BMX_ERR_INVALID, "bmx_create: device index out of range");
+  {  // once per device and process: the 16-byte load/store indivisibility the probe kernel relies on is checked on THIS box (BMX_SKIP_SELFCHECK=1 skips it)
+    static std::atomic<unsigned> checked[64];
+    const char* skip = std::getenv("BMX_SKIP_SELFCHECK");
+    if (device < 64 && !(skip && skip[0] == '1') && !checked[device].load()) {
+      int src = bmx_selfcheck(device, nullptr, nullptr, nullptr);
+      if (src) return src;
+      checked[device].store(1u);
+    }
+  }
   bmx_ctx* ctx = new (std::nothrow) bmx_ctx();
   if (!ctx) return fail(nullptr, BMX_ERR_NOMEM, "out of host memory");
   ctx->device = device;
@@ -900,8 +1050,8 @@ int bmx_create_ex(int device, uint64_t capacity_rows, uint32_t max_load_pct, uin
   }
   if ((rc = dev_alloc(ctx, &ctx->block_counts, SEL_MAX_BLOCKS))) return bail(rc);
   if ((rc = dev_alloc(ctx, &ctx->part_counts, PART_MAX_SHARDS * PART_BLOCKS))) return bail(rc);
-  if ((rc = dev_alloc(ctx, &ctx->shard_ctr, CTR_SHARDS * CTR_STRIDE))) return bail(rc);
-  CR(hipMemsetAsync(ctx->shard_ctr, 0, CTR_SHARDS * CTR_STRIDE * sizeof(unsigned long long), ctx->stream));
+  if ((rc = dev_alloc(ctx, &ctx->shard_ctr, 2 * CTR_SHARDS * CTR_STRIDE))) return bail(rc);
+  CR(hipMemsetAsync(ctx->shard_ctr, 0, 2 * CTR_SHARDS * CTR_STRIDE * sizeof(unsigned long long), ctx->stream));
   // the row-count mirror is an optimisation: without mapped host memory the capacity guard simply synchronises as before
   if (hipHostMalloc(reinterpret_cast<void**>(&ctx->host_rows), 2 * sizeof(unsigned long long), hipHostMallocMapped) == hipSuccess) {
     ctx->host_rows[0] = 0; ctx->host_rows[1] = 0;
@@ -923,9 +1073,12 @@ int bmx_create_ex(int device, uint64_t capacity_rows, uint32_t max_load_pct, uin
 void bmx_destroy(bmx_ctx* ctx) {
   if (!ctx) return;
   (void)hipSetDevice(ctx->device);
+  ctx->pend.on = false;     // a compaction that was only recorded is dropped: nobody can read its outputs any more
   if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
+  if (ctx->side) { (void)hipStreamSynchronize(ctx->side); (void)hipStreamDestroy(ctx->side); ctx->side = nullptr; }
   for (auto& ix : ctx->indexes) { dev_free(ix.ids); dev_free(ix.v64); dev_free(ix.v32); }
-  dev_free(ctx->slots); dev_free(ctx->ds); dev_free(ctx->next); dev_free(ctx->wflag); dev_free(ctx->slot_of); dev_free(ctx->blk_info); dev_free(ctx->blk_follow); dev_free(ctx->shard_ctr);
+  dev_free(ctx->slots); dev_free(ctx->ds); dev_free(ctx->next); dev_free(ctx->blk_info); dev_free(ctx->blk_follow); dev_free(ctx->shard_ctr);
+  for (int h = 0; h < 2; h++) { dev_free(ctx->wflag[h]); dev_free(ctx->slot_of[h]); dev_free(ctx->fld_ws[h]); }
   if (ctx->copy_stream) (void)hipStreamSynchronize(ctx->copy_stream);
   for (int i = 0; i < 2; i++) {
     bmx_ctx::Staging& S = ctx->stg[i];
@@ -938,6 +1091,7 @@ void bmx_destroy(bmx_ctx* ctx) {
   if (ctx->down_stream) { (void)hipStreamSynchronize(ctx->down_stream); (void)hipStreamDestroy(ctx->down_stream); }
   dev_free(ctx->slot_pos); dev_free(ctx->chg);
   if (ctx->host_rows) { (void)hipHostFree(ctx->host_rows); ctx->host_rows = nullptr; }
+  if (ctx->stg_tails) { (void)hipHostFree(ctx->stg_tails); ctx->stg_tails = nullptr; ctx->stg[0].tail = ctx->stg[1].tail = nullptr; }
   if (ctx->pin_in) { (void)hipHostFree(ctx->pin_in); ctx->pin_in = nullptr; }
   if (ctx->pin_out) { (void)hipHostFree(ctx->pin_out); ctx->pin_out = nullptr; }
   dev_free(ctx->scan_out); dev_free(ctx->block_counts); dev_free(ctx->part_counts); dev_free(ctx->part_owner); dev_free(ctx->scan_mask); dev_free(ctx->scan_counts);
@@ -951,12 +1105,13 @@ void bmx_destroy(bmx_ctx* ctx) {
 
 int bmx_sync(bmx_ctx* ctx) {
   if (!ctx) return fail(nullptr, BMX_ERR_INVALID, "null context");
-  HIPCHK(hipSetDevice(ctx->device));
+  if (int erc = enter(ctx)) return erc;
   return check_status(ctx);
 }
 
 int bmx_set_stream(bmx_ctx* ctx, void* s) {
   if (!ctx) return fail(nullptr, BMX_ERR_INVALID, "null context");
+  if (int erc = enter(ctx)) return erc;        // a recorded compaction belongs on the old stream
   HIPCHK(hipStreamSynchronize(ctx->stream));   // work already enqueued on the old stream finishes first
   ctx->stream = s ? reinterpret_cast<hipStream_t>(s) : ctx->own_stream;
   return BMX_OK;
@@ -984,7 +1139,7 @@ int bmx_seq_wait(bmx_ctx* ctx, void* hip_stream, const uint64_t* seq_dev, uint64
 
 int bmx_get_info(bmx_ctx* ctx, bmx_info* out) {
   if (!ctx || !out) return fail(ctx, BMX_ERR_INVALID, "bad arguments");
-  HIPCHK(hipSetDevice(ctx->device));
+  if (int erc = enter(ctx)) return erc;
   int rc = refresh_rows(ctx);
   if (rc) return rc;
   out->capacity_rows = ctx->capacity_rows; out->n_slots = ctx->nslots; out->table_bytes = ctx->nslots * sizeof(Slot); out->n_rows = ctx->rows_ub;
@@ -994,7 +1149,7 @@ int bmx_get_info(bmx_ctx* ctx, bmx_info* out) {
 
 int bmx_row_count(bmx_ctx* ctx, uint64_t* n_out) {
   if (!ctx || !n_out) return fail(ctx, BMX_ERR_INVALID, "bad arguments");
-  HIPCHK(hipSetDevice(ctx->device));
+  if (int erc = enter(ctx)) return erc;
   int rc = refresh_rows(ctx);
   if (rc) return rc;
   *n_out = ctx->rows_ub;
@@ -1003,7 +1158,7 @@ int bmx_row_count(bmx_ctx* ctx, uint64_t* n_out) {
 
 int bmx_reserve(bmx_ctx* ctx, uint64_t capacity_rows) {
   if (!ctx || capacity_rows == 0) return fail(ctx, BMX_ERR_INVALID, "bad arguments");
-  HIPCHK(hipSetDevice(ctx->device));
+  if (int erc = enter(ctx)) return erc;
   return grow_table(ctx, capacity_rows);
 }
 
@@ -1011,8 +1166,9 @@ int bmx_merge_batch(bmx_ctx* ctx, uint64_t n, const uint64_t* id, const uint32_t
                     int insert_mode, int mem, uint32_t* applied_idx, uint64_t* n_applied, uint8_t* flags, bmx_merge_stats* stats) {
   if (!ctx) return fail(nullptr, BMX_ERR_INVALID, "null context");
   if (n && (!id || !field || !ts || !val)) return fail(ctx, BMX_ERR_INVALID, "null input column");
+  if (!public_mode_ok(insert_mode)) return fail(ctx, BMX_ERR_INVALID, "bad insert_mode");
   HIPCHK(hipSetDevice(ctx->device));
-  if (mem == BMX_MEM_DEVICE) return merge_core<false>(ctx, n, id, field, ts, val, nullptr, insert_mode, applied_idx, n_applied, flags, stats);
+  if (mem == BMX_MEM_DEVICE) return merge_core<false>(ctx, n, id, field, ts, val, nullptr, insert_mode, applied_idx, n_applied, flags, stats, /*defer=*/true);
   if (mem != BMX_MEM_HOST) return fail(ctx, BMX_ERR_INVALID, "bad mem kind");
   if (n > MAX_BATCH) return fail(ctx, BMX_ERR_INVALID, "batch larger than 2^24 deltas: split it (sequential semantics are preserved)");
   return merge_host(ctx, n, id, field, ts, val, insert_mode, applied_idx, n_applied, flags, stats);
@@ -1023,13 +1179,14 @@ int bmx_merge_submit(bmx_ctx* ctx, uint64_t n, const uint64_t* id, const uint32_
   if (!ctx || !ticket) return fail(ctx, BMX_ERR_INVALID, "bmx_merge_submit: null context or ticket");
   if (n && (!id || !field || !ts || !val)) return fail(ctx, BMX_ERR_INVALID, "null input column");
   if (n > MAX_BATCH) return fail(ctx, BMX_ERR_INVALID, "batch larger than 2^24 deltas: split it (sequential semantics are preserved)");
-  HIPCHK(hipSetDevice(ctx->device));
+  if (!public_mode_ok(insert_mode)) return fail(ctx, BMX_ERR_INVALID, "bad insert_mode");
+  if (int erc = enter(ctx)) return erc;
   return submit_host(ctx, n, id, field, ts, val, insert_mode, want_flags != 0, ticket, true);
 }
 
 int bmx_merge_collect(bmx_ctx* ctx, uint64_t ticket, uint32_t* applied_idx, uint64_t* n_applied, uint8_t* flags, bmx_merge_stats* stats) {
   if (!ctx) return fail(nullptr, BMX_ERR_INVALID, "null context");
-  HIPCHK(hipSetDevice(ctx->device));
+  if (int erc = enter(ctx)) return erc;
   return collect_host(ctx, ticket, applied_idx, n_applied, flags, stats);
 }
 
@@ -1037,22 +1194,26 @@ int bmx_merge_records(bmx_ctx* ctx, uint64_t n, const bmx_delta_rec* recs, int i
                       uint8_t* flags, bmx_merge_stats* stats) {
   if (!ctx) return fail(nullptr, BMX_ERR_INVALID, "null context");
   if (n && !recs) return fail(ctx, BMX_ERR_INVALID, "null records");
+  if (!public_mode_ok(insert_mode)) return fail(ctx, BMX_ERR_INVALID, "bad insert_mode");
   HIPCHK(hipSetDevice(ctx->device));
-  return merge_core<true>(ctx, n, nullptr, nullptr, nullptr, nullptr, recs, insert_mode, applied_idx, n_applied, flags, stats);
+  return merge_core<true>(ctx, n, nullptr, nullptr, nullptr, nullptr, recs, insert_mode, applied_idx, n_applied, flags, stats, /*defer=*/true);
 }
 
 int bmx_merge_records_after(bmx_ctx* ctx, const uint64_t* wait_words_dev, uint32_t n_wait, uint64_t wait_at_least, uint64_t n, const bmx_delta_rec* recs,
                             int insert_mode, uint32_t* applied_idx, uint64_t* n_applied, uint8_t* flags, bmx_merge_stats* stats) {
   if (!ctx) return fail(nullptr, BMX_ERR_INVALID, "null context");
   if (wait_words_dev && n_wait) { int wrc = bmx_seq_wait_all(ctx, nullptr, wait_words_dev, n_wait, wait_at_least); if (wrc) return wrc; }
-  return bmx_merge_records(ctx, n, recs, insert_mode, applied_idx, n_applied, flags, stats);
+  ctx->notify_armed = true;      // THIS merge reads a receive slab set: it (and no other merge of the context) tells the origins when the set is free again
+  const int rc = bmx_merge_records(ctx, n, recs, insert_mode, applied_idx, n_applied, flags, stats);
+  ctx->notify_armed = false;
+  return rc;
 }
 
 int bmx_load_rows(bmx_ctx* ctx, uint64_t n, const uint64_t* id, const uint32_t* field, const int64_t* ts, const int64_t* val, int mem) {
   if (!ctx) return fail(nullptr, BMX_ERR_INVALID, "null context");
   if (n && (!id || !field || !ts || !val)) return fail(ctx, BMX_ERR_INVALID, "null input column");
   if (mem != BMX_MEM_HOST && mem != BMX_MEM_DEVICE) return fail(ctx, BMX_ERR_INVALID, "bad mem kind");
-  HIPCHK(hipSetDevice(ctx->device));
+  if (int erc = enter(ctx)) return erc;
   const uint64_t chunk = 1u << 22;
   for (uint64_t off = 0; off < n; off += chunk) {
     uint64_t m = std::min<uint64_t>(chunk, n - off);
@@ -1070,13 +1231,13 @@ int bmx_put_rows(bmx_ctx* ctx, uint64_t n, const uint64_t* id, const uint32_t* f
   if (!ctx) return fail(nullptr, BMX_ERR_INVALID, "null context");
   if (n && (!id || !field || !ts || !val)) return fail(ctx, BMX_ERR_INVALID, "null input column");
   if (mem != BMX_MEM_HOST && mem != BMX_MEM_DEVICE) return fail(ctx, BMX_ERR_INVALID, "bad mem kind");
-  HIPCHK(hipSetDevice(ctx->device));
+  if (int erc = enter(ctx)) return erc;
   const uint64_t chunk = 1u << 22;
   for (uint64_t off = 0; off < n; off += chunk) {
     const uint64_t m = std::min<uint64_t>(chunk, n - off);
     int rc;
     if (mem == BMX_MEM_DEVICE)
-      rc = merge_core<false>(ctx, m, id + off, field + off, ts + off, val + off, nullptr, MERGE_FORCE_INTERNAL, nullptr, nullptr, nullptr, nullptr);
+      rc = merge_core<false>(ctx, m, id + off, field + off, ts + off, val + off, nullptr, BMX_INSERT_DELTA, nullptr, nullptr, nullptr, nullptr, false, /*force=*/true);
     else
       rc = merge_host(ctx, m, id + off, field + off, ts + off, val + off, MERGE_FORCE_INTERNAL, nullptr, nullptr, nullptr, nullptr);
     if (rc) return rc;
@@ -1088,7 +1249,7 @@ int bmx_get_rows(bmx_ctx* ctx, uint64_t n, const uint64_t* id, const uint32_t* f
   if (!ctx) return fail(nullptr, BMX_ERR_INVALID, "null context");
   if (n == 0) return BMX_OK;
   if (!id || !field || !ts || !val || !found || n > 0xFFFFFFFFull) return fail(ctx, BMX_ERR_INVALID, "bad arguments");
-  HIPCHK(hipSetDevice(ctx->device));
+  if (int erc = enter(ctx)) return erc;
   const uint32_t blocks = (uint32_t)((n + 255) / 256);
   if (mem == BMX_MEM_DEVICE) {
     hipLaunchKernelGGL(k_get_rows, dim3(blocks), dim3(256), 0, ctx->stream, ctx->slots, ctx->nslots, (uint32_t)n, id, field, ts, val, found);
@@ -1135,7 +1296,7 @@ int bmx_dump_rows(bmx_ctx* ctx, uint64_t cap, uint64_t* id, uint32_t* field, int
   if (!ctx) return fail(nullptr, BMX_ERR_INVALID, "null context");
   if (cap && (!id || !field || !ts || !val)) return fail(ctx, BMX_ERR_INVALID, "null output column");
   if (mem != BMX_MEM_HOST && mem != BMX_MEM_DEVICE) return fail(ctx, BMX_ERR_INVALID, "bad mem kind");
-  HIPCHK(hipSetDevice(ctx->device));
+  if (int erc = enter(ctx)) return erc;
   const bool host = mem == BMX_MEM_HOST;
   uint64_t* d_id = id; uint32_t* d_f = field; int64_t* d_ts = ts; int64_t* d_val = val;
   int rc = BMX_OK;
@@ -1170,14 +1331,14 @@ int bmx_dump_rows(bmx_ctx* ctx, uint64_t cap, uint64_t* id, uint32_t* field, int
 
 int bmx_index_build(bmx_ctx* ctx, uint32_t field) {
   if (!ctx) return fail(nullptr, BMX_ERR_INVALID, "null context");
-  HIPCHK(hipSetDevice(ctx->device));
+  if (int erc = enter(ctx)) return erc;
   Index* ix;
   return fresh_index(ctx, field, &ix);
 }
 
 int bmx_index_drop(bmx_ctx* ctx, uint32_t field) {
   if (!ctx) return fail(nullptr, BMX_ERR_INVALID, "null context");
-  HIPCHK(hipSetDevice(ctx->device));
+  if (int erc = enter(ctx)) return erc;
   HIPCHK(hipStreamSynchronize(ctx->stream));
   for (size_t i = 0; i < ctx->indexes.size(); i++)
     if (ctx->indexes[i].field == field) {
@@ -1195,7 +1356,7 @@ int bmx_index_drop(bmx_ctx* ctx, uint32_t field) {
 
 int bmx_index_size(bmx_ctx* ctx, uint32_t field, uint64_t* n_out) {
   if (!ctx || !n_out) return fail(ctx, BMX_ERR_INVALID, "bad arguments");
-  HIPCHK(hipSetDevice(ctx->device));
+  if (int erc = enter(ctx)) return erc;
   Index* ix;
   int rc = fresh_index(ctx, field, &ix);
   if (rc) return rc;
@@ -1212,7 +1373,7 @@ int bmx_index_refresh_counts(bmx_ctx* ctx, uint64_t* full_builds, uint64_t* incr
 
 int bmx_scan_range(bmx_ctx* ctx, uint32_t field, int64_t lo, int64_t hi, uint64_t* out_ids, uint64_t cap, uint64_t* n_out, int mem) {
   if (!ctx) return fail(nullptr, BMX_ERR_INVALID, "null context");
-  HIPCHK(hipSetDevice(ctx->device));
+  if (int erc = enter(ctx)) return erc;
   return scan_range_impl(ctx, field, lo, hi, out_ids, cap, n_out, mem);
 }
 int bmx_scan_equals(bmx_ctx* ctx, uint32_t field, int64_t value, uint64_t* out_ids, uint64_t cap, uint64_t* n_out, int mem) {
@@ -1224,14 +1385,14 @@ int bmx_scan_count(bmx_ctx* ctx, uint32_t field, int64_t lo, int64_t hi, uint64_
 
 int bmx_scan_range_pos(bmx_ctx* ctx, uint32_t field, int64_t lo, int64_t hi, uint32_t* out_pos, uint64_t cap, uint64_t* n_out, int mem) {
   if (!ctx) return fail(nullptr, BMX_ERR_INVALID, "null context");
-  HIPCHK(hipSetDevice(ctx->device));
+  if (int erc = enter(ctx)) return erc;
   return scan_range_impl_t<true>(ctx, field, lo, hi, out_pos, cap, n_out, mem);
 }
 
 int bmx_index_ids(bmx_ctx* ctx, uint32_t field, uint64_t first, uint64_t count, uint64_t* out_ids, int mem) {
   if (!ctx) return fail(nullptr, BMX_ERR_INVALID, "null context");
   if (mem != BMX_MEM_HOST && mem != BMX_MEM_DEVICE) return fail(ctx, BMX_ERR_INVALID, "bad mem kind");
-  HIPCHK(hipSetDevice(ctx->device));
+  if (int erc = enter(ctx)) return erc;
   Index* ix;
   int rc = fresh_index(ctx, field, &ix);
   if (rc) return rc;
@@ -1247,7 +1408,7 @@ int bmx_scan_filter(bmx_ctx* ctx, uint32_t nterms, const bmx_term* terms, uint64
   if (!ctx) return fail(nullptr, BMX_ERR_INVALID, "null context");
   if (nterms == 0 || nterms > MAX_TERMS || !terms) return fail(ctx, BMX_ERR_INVALID, "filter needs 1..8 terms");
   if (mem != BMX_MEM_HOST && mem != BMX_MEM_DEVICE) return fail(ctx, BMX_ERR_INVALID, "bad mem kind");
-  HIPCHK(hipSetDevice(ctx->device));
+  if (int erc = enter(ctx)) return erc;
   Index* ix;
   int rc = fresh_index(ctx, terms[0].field, &ix);
   if (rc) return rc;
@@ -1266,7 +1427,7 @@ static int partition_impl(bmx_ctx* ctx, uint64_t n, const uint64_t* id, const ui
   PartOut po;
   if (split) po = *split; else std::memset(&po, 0, sizeof(po));
   po.split = split ? 1u : 0u; po.aux_base = aux_base;
-  HIPCHK(hipSetDevice(ctx->device));
+  if (int erc = enter(ctx)) return erc;
   uint32_t per_block = (uint32_t)((n + PART_BLOCKS - 1) / PART_BLOCKS);
   per_block = std::max<uint32_t>(PART_TILE, (per_block + PART_TILE - 1) / PART_TILE * PART_TILE);
   if (n > ctx->part_owner_cap) {
@@ -1299,7 +1460,7 @@ int bmx_partition_by_owner_slabs(bmx_ctx* ctx, uint64_t n, const uint64_t* id, c
 int bmx_ipc_alloc(bmx_ctx* ctx, uint64_t bytes, uint32_t flags, void** dev_ptr, uint8_t handle_out[64]) {
   if (!ctx || !dev_ptr || !handle_out || bytes == 0) return fail(ctx, BMX_ERR_INVALID, "bmx_ipc_alloc: bad arguments");
   static_assert(sizeof(hipIpcMemHandle_t) <= 64, "IPC handle fits the 64-byte carrier");
-  HIPCHK(hipSetDevice(ctx->device));
+  if (int erc = enter(ctx)) return erc;
   void* p = nullptr;
   // BMX_IPC_UNCACHED: memory other GPUs store into while kernels here poll or read it must not be served from this GPU's L2 (a line cached
   // before the peer's store would stay stale: the L2 is only coherent for this GPU's own writes)
@@ -1316,7 +1477,7 @@ int bmx_ipc_alloc(bmx_ctx* ctx, uint64_t bytes, uint32_t flags, void** dev_ptr, 
 }
 int bmx_ipc_open(bmx_ctx* ctx, const uint8_t handle[64], int peer_device, void** dev_ptr) {
   if (!ctx || !handle || !dev_ptr) return fail(ctx, BMX_ERR_INVALID, "bmx_ipc_open: bad arguments");
-  HIPCHK(hipSetDevice(ctx->device));
+  if (int erc = enter(ctx)) return erc;
   if (peer_device >= 0 && peer_device != ctx->device) {       // peer access first: the mapping below is only usable from this GPU with it
     int can = 0;
     HIPCHK(hipDeviceCanAccessPeer(&can, ctx->device, peer_device));
@@ -1335,7 +1496,7 @@ int bmx_ipc_open(bmx_ctx* ctx, const uint8_t handle[64], int peer_device, void**
 int bmx_ipc_close(bmx_ctx* ctx, void* dev_ptr) {
   if (!ctx) return fail(nullptr, BMX_ERR_INVALID, "null context");
   if (!dev_ptr) return BMX_OK;
-  HIPCHK(hipSetDevice(ctx->device));
+  if (int erc = enter(ctx)) return erc;
   HIPCHK(hipStreamSynchronize(ctx->stream));
   HIPCHK(hipIpcCloseMemHandle(dev_ptr));
   return BMX_OK;
@@ -1343,7 +1504,7 @@ int bmx_ipc_close(bmx_ctx* ctx, void* dev_ptr) {
 int bmx_ipc_free(bmx_ctx* ctx, void* dev_ptr) {
   if (!ctx) return fail(nullptr, BMX_ERR_INVALID, "null context");
   if (!dev_ptr) return BMX_OK;
-  HIPCHK(hipSetDevice(ctx->device));
+  if (int erc = enter(ctx)) return erc;
   HIPCHK(hipStreamSynchronize(ctx->stream));
   HIPCHK(hipFree(dev_ptr));
   return BMX_OK;
@@ -1386,7 +1547,7 @@ int bmx_partition_scatter(bmx_ctx* ctx, uint64_t n, const uint64_t* id, const ui
 
 int bmx_seq_wait_all(bmx_ctx* ctx, void* hip_stream, const uint64_t* words_dev, uint32_t nwords, uint64_t at_least) {
   if (!ctx || !words_dev || nwords == 0 || nwords > 64) return fail(ctx, BMX_ERR_INVALID, "bmx_seq_wait_all: 1..64 words");
-  HIPCHK(hipSetDevice(ctx->device));
+  HIPCHK(hipSetDevice(ctx->device));      // (no flush: a wait in front of the next merge must not pull the recorded compaction onto this stream)
   hipStream_t st = hip_stream ? reinterpret_cast<hipStream_t>(hip_stream) : ctx->stream;
   hipLaunchKernelGGL(k_seq_wait_all, dim3(1), dim3(64), 0, st, reinterpret_cast<const unsigned long long*>(words_dev), nwords, (unsigned long long)at_least,
                      &ctx->ds->status, ctx->ds->seq_diag);
@@ -1396,7 +1557,7 @@ int bmx_seq_wait_all(bmx_ctx* ctx, void* hip_stream, const uint64_t* words_dev, 
 
 int bmx_merge_notify(bmx_ctx* ctx, uint64_t* const* words, uint32_t nwords) {
   if (!ctx || nwords > PART_MAX_SHARDS || (nwords && !words)) return fail(ctx, BMX_ERR_INVALID, "bmx_merge_notify: at most 16 words");
-  HIPCHK(hipSetDevice(ctx->device));
+  if (int erc = enter(ctx)) return erc;
   HIPCHK(hipStreamSynchronize(ctx->stream));
   std::memset(&ctx->notify, 0, sizeof(ctx->notify));
   for (uint32_t k = 0; k < nwords; k++) ctx->notify.p[k] = reinterpret_cast<unsigned long long*>(words[k]);
@@ -1404,13 +1565,32 @@ int bmx_merge_notify(bmx_ctx* ctx, uint64_t* const* words, uint32_t nwords) {
   return BMX_OK;
 }
 
+int bmx_set_deferred_compaction(bmx_ctx* ctx, int on) {
+  if (!ctx) return fail(nullptr, BMX_ERR_INVALID, "null context");
+  if (int erc = enter(ctx)) return erc;
+  ctx->defer_enabled = on != 0;
+  return BMX_OK;
+}
+int bmx_merge_fence(bmx_ctx* ctx) {
+  if (!ctx) return fail(nullptr, BMX_ERR_INVALID, "null context");
+  return enter(ctx);
+}
+int bmx_get_deferred_counts(bmx_ctx* ctx, uint64_t* deferred, uint64_t* on_side_stream) {
+  if (!ctx) return fail(nullptr, BMX_ERR_INVALID, "null context");
+  if (deferred) *deferred = ctx->n_deferred;
+  if (on_side_stream) *on_side_stream = ctx->n_side;
+  return BMX_OK;
+}
+
 int bmx_timer_start(bmx_ctx* ctx) {
   if (!ctx) return fail(nullptr, BMX_ERR_INVALID, "null context");
+  if (int erc = enter(ctx)) return erc;
   HIPCHK(hipEventRecord(ctx->ev0, ctx->stream));
   return BMX_OK;
 }
 int bmx_timer_stop(bmx_ctx* ctx, float* ms_out) {
   if (!ctx || !ms_out) return fail(ctx, BMX_ERR_INVALID, "bad arguments");
+  if (int erc = enter(ctx)) return erc;          // the last batch's compaction is part of what is timed
   HIPCHK(hipEventRecord(ctx->ev1, ctx->stream));
   HIPCHK(hipEventSynchronize(ctx->ev1));
   HIPCHK(hipEventElapsedTime(ms_out, ctx->ev0, ctx->ev1));
@@ -1419,7 +1599,7 @@ int bmx_timer_stop(bmx_ctx* ctx, float* ms_out) {
 
 int bmx_profile_enable(bmx_ctx* ctx, int on) {
   if (!ctx) return fail(nullptr, BMX_ERR_INVALID, "null context");
-  HIPCHK(hipSetDevice(ctx->device));
+  if (int erc = enter(ctx)) return erc;
   HIPCHK(hipStreamSynchronize(ctx->stream));
   if (on && ctx->prof_ev.empty()) {
     ctx->prof_ev.resize(4 * PROF_MAX_CALLS, nullptr);
@@ -1435,7 +1615,7 @@ int bmx_profile_enable(bmx_ctx* ctx, int on) {
 
 int bmx_profile_read(bmx_ctx* ctx, float ms_out[3], uint32_t* n_calls) {
   if (!ctx || !ms_out || !n_calls) return fail(ctx, BMX_ERR_INVALID, "bad arguments");
-  HIPCHK(hipSetDevice(ctx->device));
+  if (int erc = enter(ctx)) return erc;
   HIPCHK(hipStreamSynchronize(ctx->stream));
   double acc[3] = {0, 0, 0};
   for (uint32_t i = 0; i < ctx->prof_n; i++)
@@ -1451,7 +1631,7 @@ int bmx_profile_read(bmx_ctx* ctx, float ms_out[3], uint32_t* n_calls) {
 
 int bmx_profile_read_scan(bmx_ctx* ctx, float ms_out[2], uint32_t* n_calls) {
   if (!ctx || !ms_out || !n_calls) return fail(ctx, BMX_ERR_INVALID, "bad arguments");
-  HIPCHK(hipSetDevice(ctx->device));
+  if (int erc = enter(ctx)) return erc;
   HIPCHK(hipStreamSynchronize(ctx->stream));
   double acc[2] = {0, 0};
   for (uint32_t i = 0; i < ctx->scan_prof_n; i++)

@@ -44,13 +44,21 @@ struct MergeArgs {
   uint8_t* wflag;             // per delta: W_WINNER = this delta's value is the row's final value,
                               //            W_PENDING = needs k_resolve_lists (duplicate key / reference-mode insert)
   uint8_t* flags;             // optional decision flags
-  uint32_t* slot_of;          // per delta, written by the claimers of a row: the row's slot
+  uint32_t* slot_of;          // per delta: the row's slot — of a first claimer that got a follower (written by that follower: k_resolve_lists starts from it) and,
+                              // while an index change log is kept (log_slots), of every first claimer (the compaction logs the winners' rows)
   uint32_t* blk_info;         // per 256-delta block: winners in the block (this batch's half of the double buffer, zero when the batch starts)
   unsigned long long* shard_ctr;  // CTR_SHARDS x CTR_STRIDE counters: [s][0] rows created, [s][1] conflicts
   uint32_t* status;
   uint32_t* blk_next;         // the block summaries of the NEXT batch (the other half of the double buffer): zeroed by k_probe_apply
   uint32_t blk_ents;          // entries per half
   uint32_t force;             // bmx_put_rows: store every delta as given (unique keys, BMX_INSERT_DELTA); BMX_VAL_DELETED is a legal value then
+  // deferred compaction (bmx.hip, "K3 under the next K1"): the compaction of batch b runs on a second stream while batch b + 1 is probed
+  unsigned long long* started = nullptr;          // k_probe_apply's block 0 stores started_val here when it begins: every launch in front of it on the stream is done
+  unsigned long long started_val = 0;
+  const unsigned long long* k3_done = nullptr;    // k_resolve_lists' block 0 returns only once *k3_done >= k3_wait: the compaction that last read the
+  unsigned long long k3_wait = 0;                 // workspace the NEXT batch writes has finished (it was released when this batch's probe kernel started)
+  uint32_t* fld_out = nullptr;                    // per delta: its field hash, kept for a change log that is written after the caller's columns may be gone
+  uint32_t log_slots = 0;                         // every first claimer records its row's slot (the compaction writes an index change log)
 };
 
 constexpr uint8_t W_NONE = 0, W_WINNER = 1, W_PENDING = 2, W_FIRST = 4;   // W_FIRST (bit): first claimer of its row in this batch; bit 0 is what the compaction reads
@@ -190,8 +198,10 @@ __device__ __forceinline__ void decide_and_claim(const MergeArgs& A, const uint3
   if (!created && !UNIQUE) prev = atomicExch(&sl->head, tag);   // UNIQUE: caller-guaranteed single claimer (prev stays 0)
   if ((prev >> IDX_BITS) != A.epoch) {
     // first claimer of this row in this batch: its snapshot is the pre-batch row
-    if (!UNIQUE) { A.slot_of[j] = (uint32_t)s; wf = W_FIRST; }   // it walks the row's list in k_resolve_lists if anybody follows
-    else if (A.force) A.slot_of[j] = (uint32_t)s;                // a put is logged for the maintained indexes like any other winner
+    // it walks the row's list in k_resolve_lists if anybody follows; its slot is recorded by that follower (a unique-key batch then writes no
+    // slot_of[] at all: 0.8M scattered 4-byte stores = 4 MB of dirty sectors less per 1M-delta launch), or here for the index change log
+    if (!UNIQUE) wf = W_FIRST;
+    if (A.log_slots) A.slot_of[j] = (uint32_t)s;
     if (is_new) {
       // first write of an absent key: the reference stores clock {id:2} (src/bullet-crt.js:172-185);
       // the creation mark keeps later deltas of this key from comparing against this provisional value
@@ -204,6 +214,7 @@ __device__ __forceinline__ void decide_and_claim(const MergeArgs& A, const uint3
   } else {
     // duplicate key inside the batch: link behind the previous claimer; the row's first claimer resolves the list in k_resolve_lists
     A.next[prev & IDX_MASK] = tag;
+    A.slot_of[prev & IDX_MASK] = (uint32_t)s;      // same row as the previous claimer's: this is where the first claimer of the list finds its row
     A.blk_follow[(prev & IDX_MASK) >> 8] = A.epoch;
     wf = W_PENDING; conflict = true;
     fl = c > 0 ? BMX_FLAG_INCOMING : 0u;
@@ -219,10 +230,12 @@ __device__ __forceinline__ void decide_and_claim(const MergeArgs& A, const uint3
 template <bool AOS, int MODE, bool UNIQUE, int NT>
 __global__ __launch_bounds__(NT) void k_probe_apply(MergeArgs A) {
   const uint32_t j = blockIdx.x * (uint32_t)NT + threadIdx.x;
+  if (A.started && j == 0) __hip_atomic_store(A.started, A.started_val, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   for (uint32_t t = j; t < A.blk_ents; t += gridDim.x * (uint32_t)NT) A.blk_next[t] = 0u;
   const bool active = j < A.n;
   uint64_t id = EMPTY_ID; uint32_t field = 0; int64_t a = 0, v = 0;
   if (active) load_delta<AOS>(A, j, id, field, a, v);
+  if (A.fld_out && active) A.fld_out[j] = field;
   const bool pad = AOS && id == EMPTY_ID;
   const bool valid = active && id != EMPTY_ID && field != FIELD_PENDING && a >= 0 && a <= TS_MAX && ((v >= -VAL_MAX && v <= VAL_MAX) || (A.force && v == VAL_DELETED));
   if (active && !valid && !pad) atomicOr(A.status, ST_RANGE);
@@ -357,6 +370,16 @@ template <bool AOS, int MODE>
 __global__ __launch_bounds__(256) void k_resolve_lists(MergeArgs A) {
   // 256-delta blocks none of whose deltas got a follower return after one load
   if (A.blk_follow[blockIdx.x] == A.epoch) resolve_one<AOS, MODE>(A, blockIdx.x * 256u + threadIdx.x);
+  // Deferred compaction: this launch ends only once the compaction of the batch BEFORE this one is done (it was released when this batch's
+  // probe kernel started and takes a tenth of that kernel's time, so the word is there already): the next probe kernel may then overwrite
+  // the workspace half that compaction read. One lane of one block polls; every other block is gone, nothing can starve the compaction.
+  if (A.k3_done && blockIdx.x == 0 && threadIdx.x == 0) {
+    const unsigned long long t0 = wall_clock64();            // 100 MHz
+    while (__hip_atomic_load(A.k3_done, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < A.k3_wait) {
+      __builtin_amdgcn_s_sleep(8);
+      if (wall_clock64() - t0 > 6000000000ull) { atomicOr(A.status, ST_SPIN); break; }   // ~60 s: report instead of hanging
+    }
+  }
 }
 
 // ---- strict mode (BMX_MERGE_STRICT_FLAGS): exact sequential per-delta flags for any batch ----
@@ -461,6 +484,40 @@ __global__ __launch_bounds__(256) void k_resolve_strict(MergeArgs A) {
     }
     A.flags[j] = (uint8_t)fl;
   }
+}
+
+// Self-check of the ONE hardware assumption k_probe_apply's exactness rests on: an aligned 16-byte load never observes half of an
+// aligned 16-byte store to the same address. Even workgroups store (x, ~x ^ K) pairs into the (ts,val) half of random slots of a small table,
+// odd ones load them — alternately with the plain loads the probe uses and with loads that go to L2 every time — and count pairs that do not
+// belong together. SPLIT writes the halves with two 8-byte stores instead: the control, which must show torn pairs for the check to mean anything.
+// Run once per device and process by bmx_create (bmx_selfcheck); a few milliseconds.
+constexpr uint64_t TEAR_K = 0x5DEECE66DA5A5A5Aull;
+template <bool SPLIT>
+__global__ __launch_bounds__(256) void k_selfcheck_tear(uint4* slots, uint32_t nslots, uint32_t iters, unsigned long long* torn, unsigned long long* reads) {
+  typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+  const uint32_t gid = blockIdx.x * 256u + threadIdx.x;
+  const bool writer = (blockIdx.x & 1u) == 0;
+  uint64_t x = (uint64_t)gid * 0x9E3779B97F4A7C15ull + 1;
+  unsigned long long bad = 0, n = 0;
+  for (uint32_t i = 0; i < iters; i++) {
+    x = x * 6364136223846793005ull + 1442695040888963407ull;
+    const uint32_t s = (uint32_t)(x >> 40) % nslots;
+    uint4* p = slots + 2 * (size_t)s + 1;                       // second half of a 32-byte slot: where (ts,val) lives
+    if (writer) {
+      const uint64_t a = x, b = ~x ^ TEAR_K;
+      if (SPLIT) { reinterpret_cast<volatile uint64_t*>(p)[0] = a; reinterpret_cast<volatile uint64_t*>(p)[1] = b; }
+      else *p = make_uint4((uint32_t)a, (uint32_t)(a >> 32), (uint32_t)b, (uint32_t)(b >> 32));
+    } else {
+      u32x4 v;
+      if (blockIdx.x & 2u) v = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(p));
+      else { v = *reinterpret_cast<const u32x4*>(p); asm volatile("" ::: "memory"); }     // the probe's own form: one plain global_load_dwordx4
+      const uint64_t a = (uint64_t)v.x | ((uint64_t)v.y << 32), b = (uint64_t)v.z | ((uint64_t)v.w << 32);
+      if (!(a == 0 && b == 0) && b != (~a ^ TEAR_K)) bad++;
+      n++;
+    }
+  }
+  if (bad) atomicAdd(torn, bad);
+  if (n) atomicAdd(reads, n);
 }
 
 // epoch wrap: forget every claim tag and every creation mark

@@ -3,6 +3,7 @@
 // (reference error policy: the hot path reports, never aborts — src/bullet.js:230-234).
 // Built by bullet-js_amd/Makefile into bullet-js_amd/bmx.node and loaded by js/native.js.
 #include <node_api.h>
+#include <cmath>
 #include <stdint.h>
 #include <math.h>
 #include <string.h>
@@ -446,6 +447,13 @@ napi_value IndexIds(napi_env env, napi_callback_info info) {
   Turn turn(h);
   uint32_t f; NAPI_OK(napi_get_value_uint32(env, argv[1], &f));
   double first, count; NAPI_OK(napi_get_value_double(env, argv[2], &first)); NAPI_OK(napi_get_value_double(env, argv[3], &count));
+  // validated BEFORE anything is allocated: a negative, fractional or NaN count cast to size_t is undefined behaviour or a huge allocation
+  uint64_t size = 0; int src = bmx_index_size(h->ctx, f, &size);
+  if (src) return throw_bmx(env, h->ctx, src);
+  if (!(first >= 0 && count >= 0) || first != std::floor(first) || count != std::floor(count) || first > (double)size || count > (double)size - first) {
+    napi_throw_range_error(env, nullptr, "bmx: indexIds(first, count) reaches outside the index");
+    return nullptr;
+  }
   void* out; napi_value ta = make_ta(env, napi_biguint64_array, 8, (size_t)count, &out);
   int rc = bmx_index_ids(h->ctx, f, (uint64_t)first, (uint64_t)count, (uint64_t*)out, BMX_MEM_HOST);
   if (rc) return throw_bmx(env, h->ctx, rc);

@@ -30,7 +30,10 @@
 extern "C" {
 #endif
 
-#define BMX_ABI_VERSION 1
+/* ABI history. 1: rounds 1-3 (during which BMX_MERGE_BUCKETED 0x800 / BMX_CTX_BUCKETED_MERGE were removed and ~20 entry points added without a bump).
+ * 2: every insert_mode bit that is not documented below is refused with BMX_ERR_INVALID; deferred compaction (bmx_set_deferred_compaction,
+ *    bmx_merge_fence, bmx_get_deferred_counts); bmx_selfcheck. A caller built against 1 that passes only documented bits keeps working. */
+#define BMX_ABI_VERSION 2
 
 /* status codes */
 #define BMX_OK             0
@@ -46,8 +49,10 @@ extern "C" {
 
 /* where the caller's buffers live */
 #define BMX_MEM_HOST   0      /* host pointers: the call copies in/out and is synchronous */
-#define BMX_MEM_DEVICE 1      /* device pointers (same GPU): the call only enqueues work on the context's
-                                 stream; outputs (including counts) are valid after bmx_sync() */
+#define BMX_MEM_DEVICE 1      /* device pointers (same GPU): the call only enqueues work; outputs (including counts) are valid
+                                 after bmx_sync(), or — for work the caller enqueues on the context's stream itself — behind
+                                 bmx_merge_fence() (see "deferred compaction" below). Input arrays may be overwritten in stream
+                                 order as soon as the call returns. */
 
 /* what an absent key's first write stores as its clock */
 #define BMX_INSERT_REFERENCE 0 /* ts := 2, exactly as src/bullet-crt.js:172-185 (+ :33-60) does */
@@ -129,6 +134,13 @@ int bmx_create_ex(int device, uint64_t capacity_rows, uint32_t max_load_pct, uin
 void bmx_destroy(bmx_ctx* ctx);                     /* reference: Bullet.close() src/bullet.js:288-304 */
 const char* bmx_last_error(const bmx_ctx* ctx);     /* ctx may be NULL for bmx_create failures */
 int bmx_abi_version(void);
+/* The merge kernel's exactness argument rests on one property the ISA does not promise: an aligned 16-byte load never
+ * observes half of an aligned 16-byte store to the same address — the (ts,val) pair of a row. bmx_selfcheck hammers exactly that for a few
+ * milliseconds on `device` (writers on half the workgroups, ~2*10^8 checked loads on the others, plain and L2-direct) and returns BMX_ERR_INTERNAL if one
+ * torn pair is seen; *control_torn is the same run with the halves stored separately, which MUST tear (it proves the detector can see one).
+ * bmx_create runs it once per device and process before it builds anything (BMX_SKIP_SELFCHECK=1 in the environment skips that). The reference
+ * needs no counterpart: its writes are single-threaded JS assignments (src/bullet.js:184-201). Outputs may be NULL. */
+int bmx_selfcheck(int device, uint64_t* reads, uint64_t* torn, uint64_t* control_torn);
 int bmx_get_info(bmx_ctx* ctx, bmx_info* out);
 int bmx_sync(bmx_ctx* ctx);                         /* wait for the stream; returns a sticky device error if any */
 int bmx_set_stream(bmx_ctx* ctx, void* hip_stream); /* run on the caller's hipStream_t (NULL = context's own) */
@@ -183,6 +195,20 @@ int bmx_host_free(void* host_ptr);
 /* same, deltas as 32-byte records (device pointers only): the receive side of the sharded exchange */
 int bmx_merge_records(bmx_ctx* ctx, uint64_t n, const bmx_delta_rec* recs, int insert_mode, uint32_t* applied_idx,
                       uint64_t* n_applied, uint8_t* flags, bmx_merge_stats* stats);
+
+/* Deferred compaction (BMX_MEM_DEVICE merges of >= 65536 deltas on the default path; on by default). The reference filters the winners of a
+ * chunk while it applies it (src/bullet-crt.js:383, src/bullet.js:144-146); here that filter is the last of three launches
+ * (k_compact_winners -> applied_idx / n_applied / stats) and reads nothing but per-batch workspace. When batch b + 1 follows batch b directly,
+ * the compaction of b runs on a second, high-priority stream UNDER the probe kernel of b + 1 instead of in front of it (ordering by two words in
+ * device memory, no event markers); with any other bmx_* call in between it runs on the context's stream as before. Consequences for a caller:
+ *   - outputs of a device merge are valid after bmx_sync() (as ever) or after ANY other call on the context other than another device merge;
+ *   - a caller that enqueues its own work on the context's stream (bmx_set_stream) and reads applied_idx / n_applied / stats there without
+ *     bmx_sync() calls bmx_merge_fence() first: it only enqueues, and orders the stream behind every compaction;
+ *   - bmx_set_deferred_compaction(ctx, 0) restores strict stream order for every launch (the communicator does this for its shards).
+ * bmx_get_deferred_counts: merges whose compaction was deferred / of those, how many actually ran on the side stream. */
+int bmx_set_deferred_compaction(bmx_ctx* ctx, int on);
+int bmx_merge_fence(bmx_ctx* ctx);
+int bmx_get_deferred_counts(bmx_ctx* ctx, uint64_t* deferred, uint64_t* on_side_stream);
 
 /* bmx_put_rows: rows whose outcome was decided ELSEWHERE are stored as given (no comparison with the resident row; absent rows are created
  * with the given ts). This is how the host keeps the device table in step with writes it resolved itself — single puts, values or clocks the
@@ -393,8 +419,10 @@ int bmx_vc_sync(bmx_vc* t);
  *   bmx_merge_records_after  bmx_seq_wait_all on the words (the origins' slabs have arrived), then bmx_merge_records: one host call per merge.
  *   bmx_seq_wait_all  one-wave kernel on the stream: returns once every one of nwords consecutive words (this GPU's memory) is >= at_least;
  *                  expires like bmx_seq_wait.
- *   bmx_merge_notify  from now on every merge of this context, as its last act, stores the number of merges finished since this call into each of
- *                  the given words (other ranks' memory: "your slab set k is free again"). nwords = 0 switches it off. */
+ *   bmx_merge_notify  from now on every bmx_merge_records_after of this context — the merges that read a receive slab set, and only those — stores,
+ *                  as its last act, the number of such merges finished since this call into each of the given words (other ranks' memory:
+ *                  "your slab set k is free again"). Other merges on the same context (a bmx_merge_batch in between) do not move the
+ *                  words. nwords = 0 switches it off. */
 #define BMX_IPC_UNCACHED 1u   /* never cached in this GPU's L2: for memory that peers store into (receive slabs, arrival / free words) */
 int bmx_ipc_alloc(bmx_ctx* ctx, uint64_t bytes, uint32_t flags, void** dev_ptr, uint8_t handle_out[64]);
 int bmx_ipc_open(bmx_ctx* ctx, const uint8_t handle[64], int peer_device, void** dev_ptr);

@@ -28,7 +28,7 @@ def test_every_declared_symbol_is_exported(lib):
 
 
 def test_abi_version(lib):
-    assert lib.bmx_abi_version() == 1
+    assert lib.bmx_abi_version() == 2
 
 
 def test_owner_of_matches_oracle(lib):
@@ -50,6 +50,17 @@ def test_no_cpu_fallback_without_gpu(lib):
     with pytest.raises(bmx.BmxError) as ei:
         bmx.Engine(1000)
     assert ei.value.code == bmx.ERR_NO_DEVICE
+
+
+def test_selfcheck_and_deferral_switch_need_a_gpu_or_a_context(lib):
+    import ctypes as C
+    import torch
+    if not torch.cuda.is_available():
+        with pytest.raises(bmx.BmxError) as ei:
+            bmx.selfcheck(0)
+        assert ei.value.code == bmx.ERR_NO_DEVICE
+    assert lib.bmx_set_deferred_compaction(None, 1) == bmx.ERR_INVALID and lib.bmx_merge_fence(None) == bmx.ERR_INVALID
+    assert lib.bmx_get_deferred_counts(None, None, None) == bmx.ERR_INVALID
 
 
 def test_key_set_words_and_page_locked_memory_without_a_gpu(lib):
