@@ -36,8 +36,8 @@ function applyBatch(bullet, updates, fromNetwork, wantBroadcast = true) {
     // u.parentHint / u.cutHint (optional, GpuCRT): the collection's path string shared by consecutive winners and where the path's last "/" is
     let cut = u.cutHint !== undefined ? u.cutHint : path.lastIndexOf("/");
     let parentPath = u.parentHint !== undefined ? u.parentHint : (cut < 0 ? "" : path.slice(0, cut));
-    let key = cut < 0 ? path : path.slice(cut + 1);
-    if (!key || path.indexOf("//") >= 0) {       // trailing or doubled slashes: the key is the last NON-EMPTY segment (src/bullet.js:186 path.split('/').filter(Boolean))
+    let key = u.keyHint !== undefined ? u.keyHint : (cut < 0 ? path : path.slice(cut + 1));
+    if (u.keyHint === undefined && (!key || path.indexOf("//") >= 0)) {       // trailing or doubled slashes: the key is the last NON-EMPTY segment (src/bullet.js:186 path.split('/').filter(Boolean))
       const segs = path.split("/").filter(Boolean);
       key = segs.length ? segs.pop() : "";
       parentPath = segs.join("/");

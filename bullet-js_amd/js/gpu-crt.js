@@ -107,6 +107,27 @@ function verdict(winner, clock, value, reason, extra) {
   }, extra || {});
 }
 
+const KIND_NODE = 1, KIND_INT = 2, KIND_MASK = 3;
+// more bits of GpuCRT._kind[path number] (the store-kept batch path, see ClockMap / _unaliasLosers):
+const P_FALSY = 4;        // the path holds a falsy value (null of a deletion, 0, "", false): _getData replaces it by {} when it is read (src/bullet.js:115-129)
+const P_CLOCK_COPY = 8;   // crt.vectorClocks[path] is a fresh COPY of meta[path].vectorClock (the path's last batch entry LOST), not materialised yet
+const P_CLOCK_META = 16;  // crt.vectorClocks[path] IS meta[path].vectorClock (a batch winner), not materialised yet
+const P_CLOCK_LAZY = P_CLOCK_COPY | P_CLOCK_META;
+
+/* crt.vectorClocks (src/bullet-crt.js:8): a Map path -> clock object. The store-kept batch path would pay one insertion into this million-entry,
+ * string-keyed table per winner and per loser (0.7 us each, cache-cold) for values nobody reads until a LOCAL write touches that very path — so a
+ * batch only marks, in a typed array indexed by the path's dictionary number, what the entry WOULD be (P_CLOCK_META: the object meta[path] holds;
+ * P_CLOCK_COPY: a fresh copy of it), and get()/has() materialise that before they answer. set() and delete() drop the mark: what is stored
+ * explicitly is newer. Observable state through get / has / set is the reference's; size and iteration see only what was materialised. */
+class ClockMap extends Map {
+  constructor(crt) { super(); this._crt = crt; }
+  get(key) { const c = this._crt; if (c !== undefined && c._nLazy > 0) c._materializeClock(key, this); return super.get(key); }
+  has(key) { const c = this._crt; if (c !== undefined && c._nLazy > 0) c._materializeClock(key, this); return super.has(key); }
+  set(key, v) { const c = this._crt; if (c !== undefined && c._nLazy > 0) c._dropLazyClock(key); return super.set(key, v); }
+  delete(key) { const c = this._crt; if (c !== undefined && c._nLazy > 0) c._dropLazyClock(key); return super.delete(key); }
+  _put(key, v) { return super.set(key, v); }
+}
+
 const PACK_BLOCK = 1024;   // entries whose dictionary probes are issued back to back (GpuCRT._packEntries); measured 16..4096: flat from 1024 on
 
 class GpuCRT {
@@ -118,16 +139,78 @@ class GpuCRT {
    */
   constructor(bullet, opts = {}) {
     this.bullet = bullet;
-    this.vectorClocks = new Map();
+    this.vectorClocks = new ClockMap(this);
+    this._nLazy = 0;                // paths whose vectorClocks entry is only marked (P_CLOCK_*)
+    this._nFalsy = 0;               // paths known to hold a falsy value (P_FALSY)
     this.compare = threeWay;
     this._opts = opts;
     this._graph = opts.graph || null;
     this._apiClocks = new Set();    // paths whose clock the public helpers touched before any write gave them a meta entry (entryEligible)
     this._hostOnly = new Set();     // paths whose clock the device cannot hold (more than one writer, foreign key sets): their entries stay on the host
     this._nodeSeq = 1;              // arrival number of node writes (val of the clock rows): a tie on the clock goes to the later write
+    // What a path HOLDS decides what its clock row's val means (see _kindAllows): KIND_NODE — an object, or anything compare() treats like one
+    // against an integer (null, booleans, arrays, floats, the 0 that _getData turns into {}): val = arrival number; KIND_INT — a non-zero safe
+    // integer: val = the integer itself, so that identical clocks are decided BY VALUE exactly as resolve() does (src/bullet-crt.js:200-233).
+    this._kind = new Uint8Array(1024);   // by the path's number in the graph's key dictionary; 0 = nothing known (no entry and no host write seen)
+    // opts.integerEntries === false: integer entries are never the device's (they come back in `host`) and every path is a node path. This is what the
+    // sync adapter sets (attach(..., {batchSync})): a primitive of a sync chunk is a LOCAL write there (src/bullet-network-sync.js:560-563), so no integer
+    // ever needs the device — and an object entry never has to leave it because its path happens to hold an integer.
+    this._intEntries = opts.integerEntries !== false;
+    this._nIntPaths = 0;
+    this.hostOnlyPaths = 0;         // how often a path has left the device path for the host's (monotone; hostOnlyInfo() has the current number)
     this._puts = null;              // PutQueue: rows the host decided, not yet on the device
     this._vcPuts = [];              // writers mode: clock rows of host writes for the vector-clock table [path, parent, keyset, counters...], not yet on the device
   }
+
+  /* Kinds of paths (KIND_*). An INTEGER entry under an identical clock is decided by value against a stored integer — larger wins, equal is a no-op
+   * (src/bullet-crt.js:200-233) — but against a stored OBJECT compare() answers +1 whatever the values (:11-15), and an object entry beats a
+   * stored integer the same way. One row cannot order both ways, so a path is one kind at a time: integer entries are device deltas on integer
+   * paths (val = the integer), object entries on node paths (val = arrival number); an entry of the other kind goes to `host`, whose write flips
+   * the kind (_mirrorWrite). A path nobody has written yet takes the kind of its first entry. */
+  _kindAt(idx) { return idx < this._kind.length ? this._kind[idx] & KIND_MASK : 0; }
+  _kindRoom(idx) { if (idx >= this._kind.length) { const g = new Uint8Array(Math.max(2 * this._kind.length, idx + 1024)); g.set(this._kind); this._kind = g; } }
+  _setKind(idx, k) {
+    this._kindRoom(idx);
+    const b = this._kind[idx], was = b & KIND_MASK;
+    if (was === k) return;
+    if (k === KIND_INT) this._nIntPaths++; else if (was === KIND_INT) this._nIntPaths--;
+    this._kind[idx] = (b & ~KIND_MASK) | k;
+  }
+  _setFalsy(idx, falsy) {
+    this._kindRoom(idx);
+    const b = this._kind[idx];
+    if (falsy) { if (!(b & P_FALSY)) { this._kind[idx] = b | P_FALSY; this._nFalsy++; } }
+    else if (b & P_FALSY) { this._kind[idx] = b & ~P_FALSY; this._nFalsy--; }
+  }
+  /* ClockMap: what a batch left marked for `path` becomes a real entry (meta[path]'s clock object, or a copy of it) */
+  _materializeClock(path, map) {
+    const g = this._graph;
+    if (!g) return;
+    const idx = g.keys.find(path);
+    if (idx < 0 || idx >= this._kind.length) return;
+    const b = this._kind[idx];
+    if (!(b & P_CLOCK_LAZY)) return;
+    this._kind[idx] = b & ~P_CLOCK_LAZY; this._nLazy--;
+    const m = (this.bullet.meta || {})[path];
+    if (m && m.vectorClock) map._put(path, (b & P_CLOCK_META) ? m.vectorClock : Object.assign({}, m.vectorClock));
+  }
+  _dropLazyClock(path) {
+    const g = this._graph;
+    if (!g) return;
+    const idx = g.keys.find(path);
+    if (idx >= 0 && idx < this._kind.length && (this._kind[idx] & P_CLOCK_LAZY)) { this._kind[idx] &= ~P_CLOCK_LAZY; this._nLazy--; }
+  }
+  _markLazyClock(idx, bit) {
+    this._kindRoom(idx);
+    const b = this._kind[idx];
+    if (!(b & P_CLOCK_LAZY)) this._nLazy++;
+    this._kind[idx] = (b & ~P_CLOCK_LAZY) | bit;
+  }
+  _markHostOnly(path) { if (!this._hostOnly.has(path)) { this._hostOnly.add(path); this.hostOnlyPaths++; } }
+  _clearHostOnly(path) { this._hostOnly.delete(path); }
+  /** How much of the graph the device cannot resolve at the moment: paths whose clock names a writer outside the device table (more than 8 peers
+   *  in a gossip mesh, src/bullet-network.js:404-418), or that hold a string; entries on them are resolved by the host path, one by one. */
+  hostOnlyInfo() { return { hostOnlyPaths: this._hostOnly.size, marked: this.hostOnlyPaths, integerPaths: this._nIntPaths }; }
 
   /* ---------------------------------------------------------------- clock bookkeeping (host) */
   setCompare(fn) { this.compare = fn; return this; }
@@ -280,14 +363,17 @@ class GpuCRT {
     const ts = scalarClock(clock, this._opts.writer || this.bullet.id);
     // host-only paths: a clock the device cannot hold, or a STRING value — an object that meets it under an identical clock is compared with it as text
     // ("[object Object]" < "zebra": src/bullet-crt.js:11-15), the one case where an object entry's fate depends on the stored value
-    if (ts < 0 || typeof value === "string") this._hostOnly.add(path); else this._hostOnly.delete(path);
+    if (ts < 0 || typeof value === "string") this._markHostOnly(path); else this._clearHostOnly(path);
     const cut = path.lastIndexOf("/");
     const parent = cut < 0 ? "" : path.slice(0, cut);
     const keys = this._graph.keys;
     const q = this._putQueue();
     keys.lookup(path);
     const lo = keys.lo, hi = keys.hi;
-    if (ts >= 0) q.push(lo, hi, keys.fieldOf(parent, NODE_CLOCK), ts, this._nodeSeq++);
+    const intLeaf = this._intEntries && isDeviceInt(value) && value !== 0;   // (a stored 0 is read back as {}: src/bullet.js:115-129 replaces falsy values on the way)
+    this._setKind(keys.idx, intLeaf ? KIND_INT : KIND_NODE);
+    if (!value || this._nFalsy) this._setFalsy(keys.idx, !value);
+    if (ts >= 0) q.push(lo, hi, keys.fieldOf(parent, NODE_CLOCK), ts, intLeaf ? value : this._nodeSeq++);
     this._queueValueRows(q, path, parent, lo, hi, oldValue, value, ts < 0 ? 0 : ts, false);
     if (cut > 0) {                                             // the leaf as a field of its parent node
       const key = path.slice(cut + 1), c2 = parent.lastIndexOf("/");
@@ -381,7 +467,8 @@ class GpuCRT {
     if (this._opts.writers) { if (clockKeyset(e.vectorClock, this.vcTable.writerIndex, this._vcComps()) < 0) return false; }   // any clock over the table's writers
     else if (scalarClock(e.vectorClock, writer) < 0) return false;
     const d = e.data;
-    if (isDeviceInt(d)) { if (objectsOnly) return false; }
+    const isInt = isDeviceInt(d);
+    if (isInt) { if (objectsOnly || !this._intEntries || d === 0 || this._opts.writers) return false; }
     else {
       if (!isMergeable(d)) return false;
       let k = 0;
@@ -392,7 +479,14 @@ class GpuCRT {
       }
       if (k === 0) return false;
     }
-    return this._pathEligible(e.path, writer);
+    if (!this._pathEligible(e.path, writer)) return false;
+    if (this._graph && !this._opts.writers && (isInt || this._nIntPaths > 0)) {     // the path's kind must be the entry's (or still open)
+      const keys = this._graph.keys;
+      keys.lookup(e.path);
+      const kd = this._kindAt(keys.idx);
+      if (kd !== 0 && kd !== (isInt ? KIND_INT : KIND_NODE)) return false;
+    }
+    return true;
   }
 
   /* the part of entryEligible that depends on what this peer holds for the path */
@@ -468,7 +562,9 @@ class GpuCRT {
   mergeEntries(entries, opts = {}) {
     if (this._opts.writers) return this._mergeEntriesVector(entries, opts);
     const p = this._packEntries(entries, opts);
-    return this._finishEntries(entries, p, this.mergeBatch(p.cols, p.mergeOpts), opts);
+    // (nothing packed — the walk of batch-sync.js stopped at its first entry: no device call)
+    const r = p.cols.n === 0 && opts.stopAtHost ? { applied: new Uint32Array(0), flags: null, nApplied: 0, nConflicts: 0, nRows: undefined } : this.mergeBatch(p.cols, p.mergeOpts);
+    return this._finishEntries(entries, p, r, opts);
   }
 
   /**
@@ -513,16 +609,20 @@ class GpuCRT {
     const writer = opts.writer || this.bullet.id;
     const g = this.graph;
     const keys = g.keys;
-    const n = entries.length;
-    const cols = g.takeColumns(Math.max(n, 1));               // given back by _finishEntries
-    const rowEntry = new Int32Array(Math.max(n, 1));
+    // opts.from / opts.stopAtHost (batch-sync.js): start at entry `from` and STOP at the first entry that is not the device's — the caller resolves that
+    // one on the host and comes back for the rest, so that a chunk is walked once (no separate eligibility pass) and still applied in entry order.
+    // opts.objectsOnly: integer entries are not the device's either (a primitive of a sync chunk is a LOCAL write: src/bullet-network-sync.js:560-563)
+    const from = opts.from | 0, stopAtHost = opts.stopAtHost === true, objectsOnly = opts.objectsOnly === true || !this._intEntries;
+    let n = entries.length, consumed = n;
+    const cols = g.takeColumns(Math.max(n - from, 1));        // given back by _finishEntries
+    const rowEntry = new Int32Array(Math.max(n - from, 1));
     const emit = !opts.apply && opts.valueRows !== false;
-    let vcols = emit ? g.takeColumns(Math.max(2 * n, 64)) : null, vn = 0;
-    const rowStart = emit ? new Int32Array(n + 1) : null;
-    const rowNode = opts.apply ? new Int32Array(Math.max(n, 1)) : null;   // the node (dictionary number of its path) of every delta: _unaliasLosers
+    let vcols = emit ? g.takeColumns(Math.max(2 * (n - from), 64)) : null, vn = 0;
+    const rowStart = emit ? new Int32Array(n - from + 1) : null;
+    const rowNode = opts.apply ? new Int32Array(Math.max(n - from, 1)) : null;   // the node (dictionary number of its path) of every delta: _unaliasLosers
     const host = [];
     const guarded = this._hostOnly.size > 0 || this._apiClocks.size > 0;
-    let i = 0;
+    let i = 0, lateHost = false;
     // consecutive entries usually share their collection: the parent is recognised by the position of the last "/" and the hash of the prefix
     // (by-products of the id hash), its string is sliced and its field hashes looked up only when it changes
     let parent = null, pCut = -2, pH1 = 0, pH2 = 0, clockField = 0, per = null;
@@ -531,19 +631,25 @@ class GpuCRT {
     keys._block(PACK_BLOCK);
     const bPath = this._bPath || (this._bPath = new Array(PACK_BLOCK)), bEnt = this._bEnt || (this._bEnt = new Int32Array(PACK_BLOCK));
     const bTs = this._bTs || (this._bTs = new Float64Array(PACK_BLOCK));
-    for (let e0 = 0; e0 < n; e0 += PACK_BLOCK) {
+    for (let e0 = from; e0 < n; e0 += PACK_BLOCK) {
       const e1 = Math.min(n, e0 + PACK_BLOCK);
       let m = 0;
       for (let ei = e0; ei < e1; ei++) {
         const e = entries[ei];
-        if (!e || e.deleted) { host.push(ei); continue; }
-        const ts = scalarClock(e.vectorClock, writer);
-        const d = e.data;
-        if (ts < 0 || (!isDeviceInt(d) && !isMergeable(d)) || (guarded && !this._pathEligible(e.path, writer))) { host.push(ei); continue; }
-        if (typeof d !== "number") {                            // {} (nothing but transport tags): left to setData
-          let any = false;
-          for (const f in d) { if (f !== "__vectorClock" && f !== "__fromNetwork" && Object.prototype.hasOwnProperty.call(d, f)) { any = true; break; } }
-          if (!any) { host.push(ei); continue; }
+        let mine = !(!e || e.deleted);
+        let ts = 0, d;
+        if (mine) {
+          ts = scalarClock(e.vectorClock, writer);
+          d = e.data;
+          if (ts < 0 || (!isDeviceInt(d) && !isMergeable(d)) || d === 0 || (guarded && !this._pathEligible(e.path, writer))) mine = false;
+          else if (typeof d !== "number") {                     // {} (nothing but transport tags): left to setData
+            mine = false;
+            for (const f in d) { if (f !== "__vectorClock" && f !== "__fromNetwork" && Object.prototype.hasOwnProperty.call(d, f)) { mine = true; break; } }
+          } else if (objectsOnly) mine = false;
+        }
+        if (!mine) {
+          if (stopAtHost) { consumed = ei; n = ei; break; }     // this block's collected entries are still packed below; nothing behind `ei` is looked at
+          host.push(ei); continue;
         }
         keys.hashInto(e.path, m);
         bPath[m] = e.path; bEnt[m] = ei; bTs[m] = ts;
@@ -553,6 +659,15 @@ class GpuCRT {
       for (let x = 0; x < m; x++) {
         const ei = bEnt[x], e = entries[ei], d = e.data, ts = bTs[x];
         const lo = keys.bLo[x], hi = keys.bHi[x];
+        const isInt = typeof d === "number";
+        if (isInt || this._nIntPaths > 0) {                       // the path's kind must be the entry's (_kindAt); a path seen for the first time takes it
+          const want = isInt ? KIND_INT : KIND_NODE, kd = this._kindAt(keys.bIdx[x]);
+          if (kd === 0) this._setKind(keys.bIdx[x], want);
+          else if (kd !== want) {
+            if (stopAtHost) { consumed = ei; n = ei; break; }   // (its successors in this block were only hashed: nothing of them is packed)
+            host.push(ei); lateHost = true; continue;
+          }
+        }
         if (keys.bCut[x] !== pCut || keys.bP1[x] !== pH1 || keys.bP2[x] !== pH2) {
           pCut = keys.bCut[x]; pH1 = keys.bP1[x]; pH2 = keys.bP2[x];
           parent = pCut < 0 ? "" : bPath[x].slice(0, pCut);
@@ -577,14 +692,15 @@ class GpuCRT {
         }
         if (emit) rowStart[i + 1] = vn;
         if (rowNode) rowNode[i] = keys.bIdx[x];
-        cols.set2(i, lo, hi, clockField, ts, this._nodeSeq++);
+        cols.set2(i, lo, hi, clockField, ts, isInt ? d : this._nodeSeq++);     // an integer path's ties are decided by value, a node's by arrival
         rowEntry[i++] = ei;
       }
       for (let x = 0; x < m; x++) bPath[x] = undefined;          // no strings kept alive by the scratch array
     }
+    if (lateHost) host.sort((a, b) => a - b);
     // one context: the winners that created their node are marked (stored clock = the insert rule's, no read-back); shards: read back
     const mergeOpts = g.comm ? opts : Object.assign({}, opts, { markCreated: true });
-    return { cols: cols.slice(i), rowEntry, host, writer, mergeOpts, vcols, rowStart, rowNode };
+    return { cols: cols.slice(i), rowEntry, host, writer, mergeOpts, vcols, rowStart, rowNode, consumed };
   }
 
   _growColumns(cols, used) {
@@ -600,12 +716,12 @@ class GpuCRT {
     for (let k = 0; k < nw; k++) appliedEntries[k] = p.rowEntry[r.applied[k] & 0xffffff];
     let broadcast = [];
     if (p.vcols) this._queueWinnerRows(p, r.applied, !this.graph.comm, opts.insertMode === "delta");
-    else broadcast = this._applyWinners(entries, p.cols, r.applied, appliedEntries, opts.apply, opts.broadcast !== false, !this.graph.comm, opts.insertMode === "delta", p.writer, opts.valueRows !== false);
+    else broadcast = this._applyWinners(entries, p.cols, r.applied, appliedEntries, opts.apply, opts.broadcast !== false, !this.graph.comm, opts.insertMode === "delta", p.writer, opts.valueRows !== false, p.rowNode);
     if (opts.apply) this._unaliasLosers(entries, p.rowEntry, p.rowNode, p.cols.n, r.applied, this.graph.keys.size);
     this.graph.giveColumns(p.cols);                           // the merge has returned and the winners' ids are copied
     if (p.vcols) this.graph.giveColumns(p.vcols);
-    if (opts.apply) this._notifyIndexHook(entries, p.host);
-    const out = { appliedEntries, nApplied: r.nApplied, nConflicts: r.nConflicts, nRows: r.nRows, host: p.host, broadcast: opts.apply ? broadcast : undefined };
+    if (opts.apply) this._notifyIndexHook(entries, p.host, opts.from | 0, p.consumed);
+    const out = { appliedEntries, nApplied: r.nApplied, nConflicts: r.nConflicts, nRows: r.nRows, host: p.host, broadcast: opts.apply ? broadcast : undefined, consumed: p.consumed, packed: p.cols.n };
     let list = null;                                           // `applied` in the older shape, built only if somebody reads it (an object per winner is what the ingestion rate can do without)
     Object.defineProperty(out, "applied", { enumerable: true, get() { if (!list) { list = new Array(nw); for (let k = 0; k < nw; k++) list[k] = { entry: appliedEntries[k], field: null }; } return list; } });
     return out;
@@ -627,11 +743,19 @@ class GpuCRT {
     const seen = this._seen, stamp = this._seenStamp, meta = this.bullet.meta || {};
     const won = new Uint8Array(nrows);
     for (let k = 0; k < winners.length; k++) won[winners[k] & 0xffffff] = 1;
+    const lazy = !this._opts.writers && this._graph;       // single-writer clocks: the loser's merged clock is a copy of the stored one ({w: max(its ts, stored ts)} = stored)
+    const readBack = typeof this.bullet._getData === "function";
     for (let j = nrows - 1; j >= 0; j--) {
       const node = rowNode[j];
       if (seen[node] === stamp) continue;
       seen[node] = stamp;
       if (won[j]) continue;
+      if (lazy) {
+        this._markLazyClock(node, P_CLOCK_COPY);             // what the eager form below stores, when somebody asks for it (ClockMap)
+        // the read below matters only where it replaces a falsy value on the way; none is known anywhere -> nothing to replace
+        if (this._nFalsy > 0 && readBack) this.bullet._getData(entries[rowEntry[j]].path);
+        continue;
+      }
       const e = entries[rowEntry[j]], m = meta[e.path];
       if (m && m.vectorClock) this.vectorClocks.set(e.path, this.mergeVectorClocks(e.vectorClock, m.vectorClock));
       // ... and the read the reference's handleUpdate starts with: _getData(path) REPLACES a falsy value on the way (null of a deleted node, 0, "") by {}
@@ -679,16 +803,16 @@ class GpuCRT {
    * hook is called for it: GpuQuery marks the touched children of its indexed collections (it re-reads them from the store at the next
    * query), a reference BulletQuery gets its own _updateIndices. Entries the batch handed back (`host`) reach the hook through setData.
    */
-  _notifyIndexHook(entries, hostIdx) {
+  _notifyIndexHook(entries, hostIdx, from = 0, to = entries.length) {
     const q = this.bullet.query;
     if (!q) return;
     const skip = hostIdx && hostIdx.length ? new Set(hostIdx) : null;
     if (typeof q._touch === "function") {
       if (!q.indexedPaths || q.indexedPaths.size === 0) return;
-      for (let i = 0; i < entries.length; i++) if (!skip || !skip.has(i)) q._touch(entries[i].path);
+      for (let i = from; i < to; i++) if (!skip || !skip.has(i)) q._touch(entries[i].path);
     } else if (typeof q._updateIndices === "function") {
       if (!q.indexedPaths || q.indexedPaths.size === 0) return;
-      for (let i = 0; i < entries.length; i++) if (!skip || !skip.has(i)) q._updateIndices(entries[i].path, entries[i].data);
+      for (let i = from; i < to; i++) if (!skip || !skip.has(i)) q._updateIndices(entries[i].path, entries[i].data);
     }
   }
 
@@ -700,7 +824,7 @@ class GpuCRT {
    * (src/bullet.js:184-266), the reference's own cost per write; falsy: the store is left alone (the caller applies). In every mode the
    * winners' value rows are queued for the device. Returns what setData would have broadcast per winner (src/bullet-crt.js:371-376).
    */
-  _applyWinners(entries, cols, appliedIdx, applied, mode, wantBroadcast = true, marked = false, deltaMode = false, writerOpt, valueRows = true) {
+  _applyWinners(entries, cols, appliedIdx, applied, mode, wantBroadcast = true, marked = false, deltaMode = false, writerOpt, valueRows = true, rowNode = null) {
     const n = appliedIdx.length;
     if (n === 0) return [];
     const id32 = new Uint32Array(2 * n);
@@ -717,6 +841,7 @@ class GpuCRT {
     const b = this.bullet;
     const q = this._putQueue();
     const updates = mode ? new Array(n) : null;
+    const leaf = this._leafKeys || (this._leafKeys = []);
     // consecutive winners usually share their collection: its path string and its object in the store are looked up when it changes
     let parent = null, pLen = -2, pNode;
     for (let k = 0; k < n; k++) {
@@ -733,10 +858,22 @@ class GpuCRT {
           if (value.__vectorClock === undefined && value.__fromNetwork === undefined) value = Object.assign({}, value);
           else { const clean = {}; for (const f of Object.keys(value)) if (f !== "__vectorClock" && f !== "__fromNetwork") clean[f] = value[f]; value = clean; }
         }
-        updates[k] = { path, value, vectorClock: clock, parentHint: parent, cutHint: cut };   // (the hints spare applyBatch the same string work)
-        this.vectorClocks.set(path, clock);                                             // the same object meta will hold: local writes increment it in place, like the reference's (SURVEY §5 aliasing)
-        if (cut === path.length - 1 || path.indexOf("//") >= 0) old = peek(b.store, path);   // empty segments: the walk that skips them
-        else if (pNode !== null && typeof pNode === "object") { const key = cut < 0 ? path : path.slice(cut + 1); old = Object.prototype.hasOwnProperty.call(pNode, key) ? pNode[key] : undefined; }
+        const plain = cut !== path.length - 1 && path.indexOf("//") < 0;
+        // the node's key in its collection object, ONE string per path for good (by the path's dictionary number): a freshly sliced string has to be
+        // interned by the engine before it can address a property of a million-key object — 0.5 us per winner, twice (old value, store write)
+        let key;
+        if (plain) {
+          if (rowNode) { const idx = rowNode[appliedIdx[k] & 0xffffff]; key = leaf[idx]; if (key === undefined) key = leaf[idx] = (cut < 0 ? path : path.slice(cut + 1)); }
+          else key = cut < 0 ? path : path.slice(cut + 1);
+        }
+        updates[k] = { path, value, vectorClock: clock, parentHint: parent, cutHint: cut, keyHint: key };   // (the hints spare applyBatch the same string work)
+        // crt.vectorClocks[path] = the same object meta will hold: local writes increment it in place, like the reference's (SURVEY §5 aliasing) — as a
+        // MARK where the path's number is at hand (ClockMap), as an entry otherwise
+        if (rowNode) { const idx = rowNode[appliedIdx[k] & 0xffffff]; this._markLazyClock(idx, P_CLOCK_META); if (this._nFalsy) this._setFalsy(idx, !value); }
+        else this.vectorClocks.set(path, clock);
+        if (!plain) old = peek(b.store, path);   // empty segments: the walk that skips them
+        // (one look-up: an inherited property — a segment called "constructor" — is a function, which has neither integer fields nor is one: no rows either way)
+        else if (pNode !== null && typeof pNode === "object") old = pNode[key];
       }
       if (valueRows) this._queueValueRows(q, path, parent, id32[2 * k], id32[2 * k + 1], old, value, ts, true);
     }
@@ -775,7 +912,7 @@ class GpuCRT {
     if (!this._vc && !this._graph) return;                      // nothing on the device yet: seeded when the tables are created
     const comps = this._vcComps();
     const ks = this._vc ? clockKeyset(clock, this._vc.writerIndex, comps) : 0;
-    if (ks < 0 || typeof value === "string") this._hostOnly.add(path); else this._hostOnly.delete(path);
+    if (ks < 0 || typeof value === "string") this._markHostOnly(path); else this._clearHostOnly(path);
     const cut = path.lastIndexOf("/");
     const parent = cut < 0 ? "" : path.slice(0, cut);
     if (this._vc && ks >= 0) this._vcPuts.push([path, parent, ks, Array.from(comps), this._nodeSeq++]);
@@ -841,7 +978,7 @@ class GpuCRT {
         const e = entries[ei];
         if (!e || e.deleted) { host.push(ei); continue; }
         const d = e.data;
-        if (!isDeviceInt(d)) {
+        {   // objects only: under identical clocks two integers are decided by VALUE (src/bullet-crt.js:200-233), which the arrival number of a clock row cannot say
           let any = false;
           if (isMergeable(d)) for (const f in d) { if (f !== "__vectorClock" && f !== "__fromNetwork" && Object.prototype.hasOwnProperty.call(d, f)) { any = true; break; } }
           if (!any) { host.push(ei); continue; }
@@ -973,10 +1110,21 @@ class GpuCRT {
   restore(rows) {
     const g = this.graph;
     const cols = new Columns(rows.length);
+    // a path that holds a (non-zero) integer keeps it as the value of its clock row (ties on an integer path are decided by value, _kindAt)
+    const prim = new Map();
+    for (const r of rows) if (r.field === null && r.path !== null && r.path !== undefined && isDeviceInt(r.val) && r.val !== 0) prim.set(r.path, r.val);
     rows.forEach((r, i) => {
-      const id = r.path !== null && r.path !== undefined ? g.keys.idOf(r.path) : [Number(BigInt("0x" + r.id) & 0xffffffffn), Number(BigInt("0x" + r.id) >> 32n)];
+      const named = r.path !== null && r.path !== undefined;
+      const id = named ? g.keys.idOf(r.path) : [Number(BigInt("0x" + r.id) & 0xffffffffn), Number(BigInt("0x" + r.id) >> 32n)];
+      const pathNo = g.keys.idx;
       const f = r.collection !== null && r.collection !== undefined ? g.keys.fieldOf(r.collection, r.field) : r.fieldHash;
-      cols.set(i, id, f, r.ts, r.field === NODE_CLOCK ? 0 : r.val);      // arrival numbers start over: every write after the restore is later than the restored ones
+      let val = r.val;
+      if (r.field === NODE_CLOCK) {
+        const isInt = named && prim.has(r.path);
+        val = isInt ? prim.get(r.path) : 0;       // nodes: arrival numbers start over — every write after the restore is later than the restored ones
+        if (named) this._setKind(pathNo, isInt ? KIND_INT : KIND_NODE);
+      }
+      cols.set(i, id, f, r.ts, val);
     });
     g.loadRows(cols);
     return rows.length;

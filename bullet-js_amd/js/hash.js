@@ -176,6 +176,34 @@ class KeyDictionary {
       }
     }
   }
+  /* the number of a KNOWN path (paths[number]), -1 for a path this dictionary has never seen; registers nothing */
+  find(p) {
+    const before = this.paths.length;
+    // (the arithmetic of lookup(); a path that is not there is probed to its empty slot and left out)
+    let h1 = 0x811c9dc5, h2 = 0x9747b28c, h3 = 0x2f0b4a27;
+    for (let i = 0; i < p.length; i++) {
+      const c = p.charCodeAt(i);
+      if (c < 0x80) { h1 = Math.imul(h1 ^ c, 0x01000193); h2 = Math.imul(h2 ^ c, 0x01000193); h3 = Math.imul(h3 ^ c, 0x01000193); }
+      else {
+        const a = c & 0xff, b = c >>> 8;
+        h1 = Math.imul(Math.imul(h1 ^ a, 0x01000193) ^ b, 0x01000193);
+        h2 = Math.imul(Math.imul(h2 ^ a, 0x01000193) ^ b, 0x01000193);
+        h3 = Math.imul(Math.imul(h3 ^ a, 0x01000193) ^ b, 0x01000193);
+      }
+    }
+    const lo = fmix32(h1 >>> 0);
+    let hi = fmix32((h2 >>> 0) ^ lo);
+    if (lo === 0xffffffff && hi === 0xffffffff) hi = 0xfffffffe;
+    const chk = fmix32((h3 >>> 0) ^ p.length);
+    const t = this._t, mask = this._mask;
+    let s = (lo ^ Math.imul(hi, 0x9E3779B1)) & mask;
+    for (;;) {
+      const k = t[4 * s + 2];
+      if (k === 0) return -1;
+      if (t[4 * s] === lo && t[4 * s + 1] === hi) return t[4 * s + 3] === chk && before === this.paths.length ? k - 1 : -1;
+      s = (s + 1) & mask;
+    }
+  }
   idOf(p) { this.lookup(p); return [this.lo, this.hi]; }
   pathOf(lo, hi) {
     const t = this._t, mask = this._mask;

@@ -33,7 +33,8 @@ function attach(bullet, opts = {}) {
       return graph;
     },
   };
-  const crt = new GpuCRT(bullet, opts);
+  // with the sync adapter primitives are local writes (batch-sync.js): no integer entry is ever the device's, every path is a node path
+  const crt = new GpuCRT(bullet, opts.batchSync && opts.integerEntries === undefined ? Object.assign({}, opts, { integerEntries: false }) : opts);
   Object.defineProperty(crt, "graph", { get: () => lazy.graph });
   bullet.crt = crt;
   const query = new GpuQuery(bullet, opts);

@@ -702,6 +702,46 @@ for (const batchPuts of [false, true]) {
   b.close();
 }
 
+/* Integer ENTRIES through a DIRECT GpuCRT.mergeEntries call, pinned on tests/golden/g13_entries_integer_ties.json (the reference's processUpdate over
+ * the same entry lists): identical clocks are decided BY VALUE — larger wins, equal is a no-op, also against the {w:2} of a first sight and for
+ * several entries of one path inside one chunk (src/bullet-crt.js:200-233). On the device an integer path's clock row carries the integer itself as
+ * its value. Entries that meet the other kind of value on their path (`mixed`) come back in `host`, exactly those. ADVICE r3 #2: 5 then 3 under one clock. */
+{
+  const g = load("g13_entries_integer_ties.json");
+  const b = new MiniBullet(g.id);
+  const { crt } = attach(b, { capacityRows: 4096 });
+  g.chunks.forEach((chunk, ci) => {
+    const entries = JSON.parse(JSON.stringify(chunk));
+    const r = crt.mergeEntries(entries, { apply: true });
+    const mixed = []; chunk.forEach((e, j) => { if (e.mixed) mixed.push(j); });
+    assert.deepStrictEqual(Array.from(r.host), mixed, "g13 chunk " + (ci + 1) + ": exactly the entries that meet the other kind of value are handed back");
+    const want = g.after[ci];
+    for (const p of Object.keys(want)) {
+      if (p.startsWith("mix/")) continue;               // the host path's business (the caller resolves what comes back in `host`)
+      const seg = p.split("/");
+      assert.strictEqual(b.store[seg[0]][seg[1]], want[p].value, "g13 value of " + p + " after chunk " + (ci + 1));
+      assert.deepStrictEqual(b.meta[p].vectorClock, want[p].clock, "g13 clock of " + p + " after chunk " + (ci + 1));
+      checks++;
+    }
+    // the device rows: clock row (ts = the clock, val = the integer) and the value row the scans read
+    const ps = Object.keys(want).filter((p) => !p.startsWith("mix/"));
+    const snap = crt.checkpoint();
+    for (const p of ps) {
+      const clk = snap.find((x) => x.path === p && x.field === hash.NODE_CLOCK), val = snap.find((x) => x.path === p && x.field === null);
+      assert.ok(clk && val, "g13 device rows of " + p);
+      assert.deepStrictEqual([clk.ts, clk.val, val.val], [want[p].clock.w, want[p].value, want[p].value], "g13 device rows of " + p + " after chunk " + (ci + 1));
+    }
+  });
+  // the advisor's case, on a fresh path and directly: the same path with data 5 then 3 under the same clock keeps 5; then 5 again is a no-op; 6 wins
+  const r2 = crt.mergeEntries([{ path: "adv/x", data: 5, vectorClock: { w: 7 } }, { path: "adv/x", data: 5, vectorClock: { w: 2 } }, { path: "adv/x", data: 3, vectorClock: { w: 2 } }], { apply: true });
+  assert.deepStrictEqual([b.store.adv.x, Array.from(r2.appliedEntries)], [5, [0]]);
+  const r3 = crt.mergeEntries([{ path: "adv/x", data: 6, vectorClock: { w: 2 } }, { path: "adv/x", data: 0, vectorClock: { w: 9 } }], { apply: true });
+  assert.deepStrictEqual([b.store.adv.x, Array.from(r3.appliedEntries), Array.from(r3.host)], [6, [0], [1]]);   // (a 0 is the host's: _getData turns a stored 0 into {})
+  assert.strictEqual(crt.hostOnlyInfo().integerPaths >= 7, true);
+  b.close();
+  checks += 4;
+}
+
 /* Promise variant: two batches in flight from the event loop's point of view, serialised inside the addon */
 (async () => {
   const g = load("g2_stream_hot30_10k_10k.json");

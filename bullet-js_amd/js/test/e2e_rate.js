@@ -25,21 +25,22 @@ const g = crt.graph;
   }
   g.loadRows(cols);
 }
-const mkBatches = (salt) => {
+const mkBatches = (salt, count = B, viaJson = false) => {
   const out = [];
-  for (let b = 0; b < B; b++) {
+  for (let b = 0; b < count; b++) {
     const entries = new Array(D);
     for (let j = 0; j < D; j++) {
       const ins = rnd() % 100 < 10;
       const clock = { w: 1000000 + (rnd() % 2000000) };
       entries[j] = { path: "n/k" + (ins ? R + salt * B * D + b * D + j : rnd() % R), data: { f: (rnd() % 2001) - 1000 }, vectorClock: clock };
     }
-    out.push(entries);
+    out.push(viaJson ? JSON.parse(JSON.stringify(entries)) : entries);      // viaJson: the object shapes a parsed network message has
   }
   return out;
 };
-const batches = mkBatches(0), batches2 = mkBatches(1);
-{ // warm the addon, the JIT and the pool of page-locked column sets with one chunk of the timed size: resident nodes under a clock below everything stored
+const ONLY = process.argv[5] === "only" ? process.argv[6] : null;      // "only apply" / "only vector": just that section (a 4M-entry run of every section does not fit node 12's heap)
+const batches = ONLY ? [] : mkBatches(0), batches2 = ONLY ? [] : mkBatches(1);
+if (!ONLY) { // warm the addon, the JIT and the pool of page-locked column sets with one chunk of the timed size: resident nodes under a clock below everything stored
   // (all historical: no row, no dictionary entry and no store state changes)
   const warm = new Array(D);
   for (let j = 0; j < D; j++) warm[j] = { path: "n/k" + (j % R), data: { f: j & 1023 }, vectorClock: { w: 1 } };
@@ -51,14 +52,17 @@ let t0 = process.hrtime.bigint();
 for (const entries of batches) applied += crt.mergeEntries(entries).nApplied;
 const dtEntries = Number(process.hrtime.bigint() - t0) / 1e9;
 (async () => {
+let dtPipe = 0;
+if (!ONLY) {
 await crt.mergeEntriesAsync(batches[0].slice(1000, 2000));      // the asynchronous path's first call (worker start-up, JIT)
 t0 = process.hrtime.bigint();
 const pr = await crt.mergeEntriesPipelined(batches2);
 applied += pr.nApplied;
-const dtPipe = Number(process.hrtime.bigint() - t0) / 1e9;
+dtPipe = Number(process.hrtime.bigint() - t0) / 1e9;
+}
 // the same amount of work with the keys already hashed (typed columns in, winners out)
 const colsB = [];
-for (let b = 0; b < B; b++) {
+for (let b = 0; b < B && !ONLY; b++) {
   const cols = g.takeColumns(D);                 // page-locked column sets (the way a host builds typed batches: INTEGRATION.md)
   const f = g.keys.fieldOf("n", "f");
   for (let j = 0; j < D; j++) cols.set(j, g.keys.idOf(batches[b][j].path), f, 3000000 + (rnd() % 1000000), (rnd() % 2001) - 1000);
@@ -71,17 +75,18 @@ const dtCols = Number(process.hrtime.bigint() - t0) / 1e9;
 // against the reference's loop body entry by entry through the host resolver (src/bullet-network-sync.js:551-569)
 let applied_path = null;
 if (process.argv[5] === "apply" || process.argv[6] === "apply") {
+  batches.length = 0; batches2.length = 0; colsB.length = 0;
   const { attach } = require("..");
   const MiniBullet = require("./mini-bullet");
   const ab = new MiniBullet("w");
   const h = attach(ab, { capacityRows: 2 * (R + B * D), batchSync: {} });
-  const chunks = mkBatches(3).map((c) => JSON.parse(JSON.stringify(c))), chunks2 = mkBatches(3).map((c) => JSON.parse(JSON.stringify(c)));
+  const chunks = mkBatches(3, B, true), chunks2 = mkBatches(3, Math.max(1, B >> 2), true);
   h.sync.processSyncEntries(chunks[0].slice(0, 1000));
   t0 = process.hrtime.bigint();
   for (const c of chunks) h.sync.processSyncEntries(c);
   const dtA = Number(process.hrtime.bigint() - t0) / 1e9;
   const tb = new MiniBullet("w"); tb.crt = new GpuCRT(tb);
-  const few = chunks2.slice(0, Math.max(1, B >> 2));
+  const few = chunks2;
   t0 = process.hrtime.bigint();
   for (const c of few) for (const e of c) tb.setData(e.path, Object.assign({}, e.data, { __fromNetwork: true, __vectorClock: e.vectorClock }), false);
   const dtH = Number(process.hrtime.bigint() - t0) / 1e9;
@@ -91,6 +96,7 @@ if (process.argv[5] === "apply" || process.argv[6] === "apply") {
 // general vector clocks (N4): the same entries under clocks over ordered subsets of three writers, nodes' clock rows in the vector-clock table
 let vector = null;
 if (process.argv[5] === "vector" || process.argv[6] === "vector") {
+  batches.length = 0; batches2.length = 0; colsB.length = 0;
   const WR = ["a", "b", "w"];
   const vcrt = new GpuCRT({ id: "w", meta: {}, _getData() {} }, { writers: WR, capacityRows: 2 * (R + B * D) });
   const vb = mkBatches(2);
@@ -102,7 +108,7 @@ if (process.argv[5] === "vector" || process.argv[6] === "vector") {
   vector = { mergeEntries_per_s: (B * D) / (Number(process.hrtime.bigint() - t0) / 1e9), concurrent_merges: conc, writers: 3 };
   vcrt.close();
 }
-console.log(JSON.stringify({ applied_path, vector, mergeEntries_per_s: (B * D) / dtEntries, mergeEntriesPipelined_per_s: (B * D) / dtPipe, mergeBatch_typed_columns_per_s: (B * D) / dtCols, unit: "deltas/s", resident_keys: R,
+console.log(JSON.stringify({ applied_path, vector, mergeEntries_per_s: ONLY ? null : (B * D) / dtEntries, mergeEntriesPipelined_per_s: ONLY ? null : (B * D) / dtPipe, mergeBatch_typed_columns_per_s: ONLY ? null : (B * D) / dtCols, unit: "deltas/s", resident_keys: R,
   entries_per_batch: D, batches: B, applied, node: process.version }));
 crt.close();
 })().catch((e) => { console.error(e); process.exit(1); });

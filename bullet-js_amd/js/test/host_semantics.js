@@ -282,4 +282,24 @@ g9OnTheHost(() => { const b = new MiniBullet("w"); b.crt = new GpuCRT(b); return
   checks += 8;
 }
 
+/* g13 (host side): integer ENTRIES resolved against the sender's clock through the host twin's processUpdate — the reference's public resolver on the
+ * same entry list (identical clocks are decided by value; tests/golden/g13_entries_integer_ties.json). The device path of the same fixture: device_parity.js */
+{
+  const g = load("g13_entries_integer_ties.json");
+  const crt = newCrt();
+  const state = new Map();
+  g.chunks.forEach((chunk, ci) => {
+    chunk.forEach((e, j) => {
+      const cur = state.get(e.path);
+      const r = crt.processUpdate(e.path, JSON.parse(JSON.stringify(e.data)), e.vectorClock, cur ? cur.value : undefined, cur ? cur.clock : undefined);
+      assert.strictEqual(flagsOf(r.decision), g.decisions[ci][j], "g13 flags of entry " + j + " of chunk " + (ci + 1));
+      if (r.decision.incoming || !cur || r.decision.concurrent) state.set(e.path, { value: r.value, clock: r.vectorClock });
+      checks++;
+    });
+    const snap = {};
+    for (const [p, v] of state) snap[p] = { value: v.value, clock: v.clock };
+    assert.deepStrictEqual(JSON.parse(JSON.stringify(snap)), g.after[ci], "g13 (host) state after chunk " + (ci + 1));
+  });
+}
+
 console.log("host_semantics ok:", checks, "checks");

@@ -765,6 +765,88 @@ function genStorageDir(outDir) {
   console.log("wrote", outDir, "(store.json, meta.json as written by the reference's BulletFileStorage)");
 }
 
+/* ------------------------------------------------------------------ g13: INTEGER entries resolved against the sender's clock
+ * The reference's sync and put paths never do this (a primitive arrives untagged and becomes a local write, src/bullet-network-sync.js:560-563), but
+ * its public resolver does: crt.processUpdate(path, 5, {w: t}, currentValue, currentClock) — identical clocks are then decided BY VALUE (larger wins,
+ * equal is a no-op: src/bullet-crt.js:200-233), against the {w: 2} a first sight leaves as against any other clock. This is what a direct
+ * GpuCRT.mergeEntries call on integer entries has to reproduce. L0 harness (SURVEY 8(c)): the real BulletCRT, a Map path -> {value, clock}, the caller's
+ * store rule (incoming || no current clock || concurrent). Entries on a path that has held an OBJECT are marked `mixed`: under identical clocks an
+ * object beats any integer and any integer beats an object (compare() answers +1 for unordered pairs, :11-15), which no single row order expresses —
+ * the device hands such entries back (`host`), and the fixture records what the reference does with them. */
+function genIntegerEntryTies() {
+  const crt = newCrt();
+  const state = new Map();
+  const kind = new Map();          // path -> "int" | "node": what the path has held so far (the device's rule for `mixed`)
+  const chunks = [
+    [ /* chunk 1: first sights (stored clock {w:2}, the entry's own clock is discarded), then ties against that {w:2}: larger, smaller, equal */
+      { path: "cnt/a", data: 7, vectorClock: { w: 100 } },
+      { path: "cnt/b", data: 7, vectorClock: { w: 100 } },
+      { path: "cnt/c", data: 7, vectorClock: { w: 100 } },
+      { path: "cnt/d", data: -5, vectorClock: { w: 1 } },
+      { path: "cnt/a", data: 9, vectorClock: { w: 2 } },
+      { path: "cnt/b", data: 3, vectorClock: { w: 2 } },
+      { path: "cnt/c", data: 7, vectorClock: { w: 2 } },
+      { path: "cnt/d", data: -6, vectorClock: { w: 2 } },
+      { path: "cnt/d", data: -4, vectorClock: { w: 2 } },
+    ],
+    [ /* chunk 2: dominating and historical clocks, then ties on the new clock inside ONE chunk (several entries per path), negative and large values */
+      { path: "cnt/a", data: 1, vectorClock: { w: 50 } },
+      { path: "cnt/a", data: 0 - 1, vectorClock: { w: 50 } },
+      { path: "cnt/a", data: 2, vectorClock: { w: 50 } },
+      { path: "cnt/a", data: 2, vectorClock: { w: 50 } },
+      { path: "cnt/b", data: 1000, vectorClock: { w: 1 } },
+      { path: "cnt/c", data: 9007199254740991, vectorClock: { w: 3 } },
+      { path: "cnt/c", data: 9007199254740990, vectorClock: { w: 3 } },
+      { path: "cnt/c", data: -9007199254740991, vectorClock: { w: 4 } },
+      { path: "cnt/e", data: 5, vectorClock: { w: 9 } },
+      { path: "cnt/e", data: 6, vectorClock: { w: 2 } },
+      { path: "cnt/e", data: 4, vectorClock: { w: 2 } },
+    ],
+    [ /* chunk 3: a tie after a tie, an equal value under a newer clock (it wins: the clock decides first), a long run on one path */
+      { path: "cnt/a", data: 3, vectorClock: { w: 50 } },
+      { path: "cnt/a", data: 3, vectorClock: { w: 51 } },
+      { path: "cnt/a", data: 2, vectorClock: { w: 51 } },
+      { path: "cnt/b", data: 8, vectorClock: { w: 2 } },
+      { path: "cnt/b", data: 8, vectorClock: { w: 2 } },
+      { path: "cnt/f", data: 1, vectorClock: { w: 7 } },
+      { path: "cnt/f", data: 5, vectorClock: { w: 2 } },
+      { path: "cnt/f", data: 3, vectorClock: { w: 2 } },
+      { path: "cnt/f", data: 5, vectorClock: { w: 2 } },
+      { path: "cnt/f", data: 6, vectorClock: { w: 1 } },
+      { path: "cnt/f", data: 4, vectorClock: { w: 3 } },
+      { path: "cnt/f", data: 9, vectorClock: { w: 3 } },
+    ],
+    [ /* chunk 4: nodes and integers on one path (`mixed`): handed back by the device; what the reference does with them is recorded all the same */
+      { path: "mix/n", data: { v: 1 }, vectorClock: { w: 5 } },
+      { path: "mix/n", data: 4, vectorClock: { w: 2 } },
+      { path: "mix/i", data: 4, vectorClock: { w: 5 } },
+      { path: "mix/i", data: { v: 2 }, vectorClock: { w: 2 } },
+      { path: "cnt/a", data: 10, vectorClock: { w: 51 } },
+    ],
+  ];
+  const after = [], decisions = [];
+  quiet(() => {
+    for (const c of chunks) {
+      const ds = [];
+      for (const e of c) {
+        const isInt = typeof e.data === "number";
+        const k = kind.get(e.path);
+        if (k !== undefined && k !== (isInt ? "int" : "node")) e.mixed = true;
+        const d = applyDelta(crt, state, e.path, e.vectorClock.w, JSON.parse(JSON.stringify(e.data)));
+        ds.push(flagsOf(d));
+        const held = state.get(e.path).value;
+        kind.set(e.path, typeof held === "number" ? "int" : "node");
+      }
+      decisions.push(ds);
+      const snap = {};
+      for (const [p, v] of state) snap[p] = { value: JSON.parse(JSON.stringify(v.value)), clock: JSON.parse(JSON.stringify(v.clock)) };
+      after.push(snap);
+    }
+  });
+  return { kind: "integer_entry_ties", source: "reference BulletCRT.processUpdate over an entry list (L0 harness: Map path -> {value, clock}, store rule of src/bullet-crt.js:383), id 'w'", id: "w",
+    chunks, decisions, after };
+}
+
 /* ------------------------------------------------------------------ main */
 function write(name, obj) {
   const p = path.join(OUT, name);
@@ -803,6 +885,7 @@ function main() {
   write("g9_sync_node_semantics.json", genSyncNodeSemantics());
   write("g10_sync_mixed_values.json", genSyncMixedValues());
   write("g12_vc_node_semantics.json", genVcNodeSemantics());
+  write("g13_entries_integer_ties.json", genIntegerEntryTies());
   genStorageDir(path.join(OUT, "g7_storage_dir"));
 }
 
