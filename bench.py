@@ -85,6 +85,7 @@ def exchange_selftest(dev, dist, rank, world):
     ok = True
     if kind == "direct":
         bs = [to_dev(gen(b, rank), dev) for b in range(NBs)]
+        torch.cuda.synchronize()                         # uploads run on torch's stream, the partition on the exchange stream
         tk = sg.route(Ds, *bs[0], exchange_now=True)
         for b in range(NBs):
             nxt = sg.route(Ds, *bs[b + 1]) if b + 1 < NBs else None
@@ -249,8 +250,9 @@ def scan_bench(bmx, dev, R, reps=20, wide=False):
         out_ids = torch.zeros(R, dtype=torch.int64, device=dev)
         out_pos = torch.zeros(R, dtype=torch.int32, device=dev)
         id_col = torch.zeros(R, dtype=torch.int64, device=dev)
-        e.index_ids_dev(fa, 0, R, id_col)           # the index's id column: what a position stands for (verification of the position output)
         n_out = torch.zeros(1, dtype=torch.int64, device=dev)
+        torch.cuda.synchronize()                    # torch zero-fills on ITS stream: the fills must have run before the engine writes these buffers on its own
+        e.index_ids_dev(fa, 0, R, id_col)           # the index's id column: what a position stands for (verification of the position output)
         checked = 0
 
         def i64(x):
@@ -275,8 +277,10 @@ def scan_bench(bmx, dev, R, reps=20, wide=False):
                 e.scan_range_pos_dev(fa, lo << sh, hi << sh, out_pos, R, n_out)
             ms_pos = e.timer_stop() / reps
             mp = int(n_out.item())
-            if mp != m or int(id_col[out_pos[:mp].long()].sum().item()) != i64(want[name][1]):
-                raise SystemExit("VERIFICATION FAILED: position scan %s over %d %s rows names other rows than the id scan" % (name, R, out["column"]))
+            got_sum = int(id_col[out_pos[:mp].long()].sum().item()) if mp == m else None
+            if mp != m or got_sum != i64(want[name][1]):
+                raise SystemExit("VERIFICATION FAILED: position scan %s over %d %s rows names other rows than the id scan (%d positions for %d ids; id checksum through the positions %s, expected %d)" %
+                                 (name, R, out["column"], mp, m, got_sum, i64(want[name][1])))
             checked += 2
             # the mask pass alone, un-bracketed: the count-only form of the same query (k_scan_mask without the mask write + a one-workgroup sum), back to back
             e.sync(); e.timer_start()
@@ -316,6 +320,7 @@ def scan_bench(bmx, dev, R, reps=20, wide=False):
         cols = (torch.from_numpy(bid.view(np.int64)).to(dev), torch.full((D_PER_STEP,), int(np.array([fa], np.uint32).view(np.int32)[0]), dtype=torch.int32, device=dev),
                 torch.full((D_PER_STEP,), 9, dtype=torch.int64, device=dev), torch.from_numpy(bval).to(dev))
         full0, inc0 = e.index_refresh_counts()
+        torch.cuda.synchronize()                    # the batch columns were produced on torch's stream
         e.merge_batch_dev(D_PER_STEP, *cols, bmx.INSERT_REFERENCE, applied=None, n_applied=n_out)
         e.sync()
         t0 = time.perf_counter()
