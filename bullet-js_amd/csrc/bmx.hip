@@ -881,7 +881,11 @@ int run_scan_t(bmx_ctx* ctx, const Pred& P, const Index* ix, void* out_v, uint64
     LAUNCHCHK("k_scan_mask");
     if (se) HIPCHK(hipEventRecord(se[1], ctx->stream));
     typename std::conditional<POS, EmitPos, EmitIds>::type Em;
-    if constexpr (POS) Em = EmitPos{d_out, d_cap}; else Em = EmitIds{ix->ids, d_out, d_cap, ix->n * sizeof(uint64_t) > SCAN_NT_BYTES};
+    if constexpr (POS) Em = EmitPos{d_out, d_cap};
+    else {
+      const char* sm = std::getenv("BMX_SCAN_STREAM_MIN");      // measurement switch: matches per block from which the id column is streamed (0xFFFFFFFF: never)
+      Em = EmitIds{ix->ids, d_out, d_cap, ix->n * sizeof(uint64_t) > SCAN_NT_BYTES, sm ? (uint32_t)std::strtoul(sm, nullptr, 0) : SCAN_STREAM_MIN};
+    }
     using EmT = decltype(Em);
     FinishCount Fin{d_n};
     if (nb > SCAN_SUB8_BLOCKS)   // large column: an eighth of the workgroups, each sums the counts in front of it once (no offsets launch)

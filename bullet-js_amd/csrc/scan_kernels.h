@@ -215,6 +215,8 @@ struct PredFilter {
 struct EmitIds {  // index position -> node id (bounded by cap)
   static constexpr bool STREAMABLE = true;     // dense blocks read their part of the id column as a stream (select.h scan_emit_stream_block)
   const uint64_t* ids; uint64_t* out; uint64_t cap; bool nt = false;   // nt: the id column is larger than the Infinity Cache and read once per scan
+  uint32_t stream_min = SCAN_STREAM_MIN;       // matches per 8192-row block from which the block streams (a launch argument so that one process can A/B it)
+  __device__ __forceinline__ uint32_t stream_from() const { return stream_min; }
   __device__ void operator()(uint64_t pos, uint64_t i) const { if (out && pos < cap) out[pos] = ids[i]; }
   __device__ __forceinline__ void load2(uint64_t row, uint64_t& a, uint64_t& b) const {   // ids[row], ids[row + 1]; row is even: 16-byte aligned
     typedef unsigned long long u64x2_t __attribute__((ext_vector_type(2)));
@@ -229,6 +231,7 @@ struct EmitPos {  // index position itself (u32, bounded by cap): no read of the
   static constexpr bool STREAMABLE = false;
   uint32_t* out; uint64_t cap;
   __device__ void operator()(uint64_t pos, uint64_t i) const { if (out && pos < cap) out[pos] = (uint32_t)i; }
+  __device__ __forceinline__ uint32_t stream_from() const { return 0xFFFFFFFFu; }
   __device__ __forceinline__ void load2(uint64_t, uint64_t&, uint64_t&) const {}
   __device__ __forceinline__ uint64_t load1(uint64_t) const { return 0; }
   __device__ __forceinline__ void put(uint64_t, uint64_t) const {}

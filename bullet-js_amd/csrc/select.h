@@ -121,10 +121,12 @@ __global__ __launch_bounds__(SEL_THREADS) void k_sel_write(Pred P, Emit Em, Fini
 // communication between workgroups, any column size, deterministic element order.
 constexpr uint32_t SCAN_BLOCK_ELEMS = 8192;   // elements per block in both passes = 256 mask words
 constexpr uint32_t SCAN_SUB8_BLOCKS = 2048;   // beyond this many blocks (16.78M rows) the emit pass takes eight blocks per workgroup
-// From this many matches in an 8192-row block (6 %) the id output STREAMS the block's 64 KB of the id column instead of gathering one id per match:
-// random matches at that density touch most of the block's 512 lines anyway (81 % at 10 %, profiles/traffic_scan.json) — one 8-byte request per match —
-// while the stream reads every line once with 16 bytes per lane. Below it the gather reads less.
-constexpr uint32_t SCAN_STREAM_MIN = 512;
+// From this many matches in an 8192-row block (37.5 %) the id output STREAMS the block's 64 KB of the id column (16 bytes per lane, coalesced) instead of
+// gathering one id per match. Measured in one process on one index (bench_micro/scan_stream_ab.py, profiles/r04_scan_stream_ab.log, 100M rows, whole scan):
+// 50 % of the rows 334 us streamed against 366 gathered, 100 % 418 against 526 — but 20 % 295 against 281 and 10 % 280 against 222: the gather touches
+// most of the lines from 10 % on (81 %, profiles/traffic_scan.json) yet still moves less, and this kernel's stream only reaches ~4 TB/s (a block's mask
+// load, its rank scan and its stream run one after the other in a workgroup), so the switch sits where the stream wins, not where the traffic curves cross.
+constexpr uint32_t SCAN_STREAM_MIN = 3072;
 
 // One 8192-row block of the id output, streamed (Emit::STREAMABLE): wave w takes rows [2048 w, 2048 (w + 1)) = the 64 mask words its own lanes
 // hold (thread t owns word t), 128 rows per step, two consecutive ids (16 B) per lane. The four mask words of a step and the rank in front of
@@ -133,24 +135,37 @@ constexpr uint32_t SCAN_STREAM_MIN = 512;
 template <class Emit>
 __device__ __forceinline__ void scan_emit_stream_block(const Emit& Em, uint32_t mk, uint32_t r, uint64_t pos0, uint64_t block_row0, uint64_t n) {
   const uint32_t lane = threadIdx.x & 63u, w = threadIdx.x >> 6;
-  const uint64_t row_w = block_row0 + (uint64_t)w * 2048u;
+  const uint64_t row_w = block_row0 + (uint64_t)w * 2048u + 2u * lane;
   const uint32_t sub = lane >> 4, sh = 2u * (lane & 15u);          // which of the step's four words holds this lane's two rows, and where
-#pragma unroll 4
-  for (uint32_t i = 0; i < 16; i++) {
-    const uint32_t w0 = (uint32_t)__builtin_amdgcn_readlane((int)mk, (int)(4 * i)), w1 = (uint32_t)__builtin_amdgcn_readlane((int)mk, (int)(4 * i + 1));
-    const uint32_t w2 = (uint32_t)__builtin_amdgcn_readlane((int)mk, (int)(4 * i + 2)), w3 = (uint32_t)__builtin_amdgcn_readlane((int)mk, (int)(4 * i + 3));
-    const uint32_t rb = (uint32_t)__builtin_amdgcn_readlane((int)r, (int)(4 * i));
-    if ((w0 | w1 | w2 | w3) == 0u) continue;                         // (uniform) nothing in these 128 rows
-    const uint32_t mine = sub == 0 ? w0 : (sub == 1 ? w1 : (sub == 2 ? w2 : w3));
-    const uint32_t before = (sub > 0 ? __popc(w0) : 0u) + (sub > 1 ? __popc(w1) : 0u) + (sub > 2 ? __popc(w2) : 0u) + __popc(mine & ((1u << sh) - 1u));
-    const uint32_t bits = (mine >> sh) & 3u;
-    const uint64_t row = row_w + (uint64_t)i * 128u + 2u * lane;
-    uint64_t id0 = 0, id1 = 0;
-    if (row + 2 <= n) Em.load2(row, id0, id1);                        // one aligned 16-byte load: consecutive lanes on consecutive 16 bytes
-    else if (row < n) id0 = Em.load1(row);
-    const uint64_t pos = pos0 + rb + before;
-    if (bits & 1u) Em.put(pos, id0);
-    if (bits & 2u) Em.put(pos + (bits & 1u), id1);
+  const bool whole = block_row0 + SCAN_BLOCK_ELEMS <= n;             // (uniform) every row of the block exists: loads need no guard
+  constexpr int U = 8;                                                // eight 16-byte loads in flight per lane before the first is used
+#pragma unroll 1
+  for (uint32_t i0 = 0; i0 < 16; i0 += U) {
+    uint64_t a[U], b[U];
+    if (whole) {
+#pragma unroll
+      for (int u = 0; u < U; u++) Em.load2(row_w + (uint64_t)(i0 + u) * 128u, a[u], b[u]);
+    } else {
+#pragma unroll
+      for (int u = 0; u < U; u++) {
+        const uint64_t row = row_w + (uint64_t)(i0 + u) * 128u;
+        a[u] = 0; b[u] = 0;
+        if (row + 2 <= n) Em.load2(row, a[u], b[u]); else if (row < n) a[u] = Em.load1(row);
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < U; u++) {
+      const uint32_t i = i0 + (uint32_t)u;
+      const uint32_t w0 = (uint32_t)__builtin_amdgcn_readlane((int)mk, (int)(4 * i)), w1 = (uint32_t)__builtin_amdgcn_readlane((int)mk, (int)(4 * i + 1));
+      const uint32_t w2 = (uint32_t)__builtin_amdgcn_readlane((int)mk, (int)(4 * i + 2)), w3 = (uint32_t)__builtin_amdgcn_readlane((int)mk, (int)(4 * i + 3));
+      const uint32_t rb = (uint32_t)__builtin_amdgcn_readlane((int)r, (int)(4 * i));
+      const uint32_t mine = sub == 0 ? w0 : (sub == 1 ? w1 : (sub == 2 ? w2 : w3));
+      const uint32_t before = (sub > 0 ? __popc(w0) : 0u) + (sub > 1 ? __popc(w1) : 0u) + (sub > 2 ? __popc(w2) : 0u) + __popc(mine & ((1u << sh) - 1u));
+      const uint32_t bits = (mine >> sh) & 3u;
+      const uint64_t pos = pos0 + rb + before;
+      if (bits & 1u) Em.put(pos, a[u]);
+      if (bits & 2u) Em.put(pos + (bits & 1u), b[u]);
+    }
   }
 }
 
@@ -214,7 +229,7 @@ __global__ __launch_bounds__(SEL_THREADS) void k_scan_emit(const uint32_t* __res
     uint32_t tot;
     uint32_t r = block_excl_scan(cnt, tot, wsum);
     // (dense id output goes block by block below, where every block streams its part of the id column)
-    if (tot <= SCAN_BLOCK_ELEMS && !(Emit::STREAMABLE && tot >= (uint32_t)SUB * SCAN_STREAM_MIN)) {
+    if (tot <= SCAN_BLOCK_ELEMS && !(Emit::STREAMABLE && tot >= (uint32_t)SUB * Em.stream_from())) {
 #pragma unroll
       for (int q = 0; q < SUB; q++) {
         uint32_t m = mk[q];
@@ -235,7 +250,7 @@ __global__ __launch_bounds__(SEL_THREADS) void k_scan_emit(const uint32_t* __res
     uint32_t mk = (w << 5) < n ? mask_words[w] : 0u;
     uint32_t tot;
     uint32_t r = block_excl_scan((uint32_t)__popc(mk), tot, wsum);
-    if (Emit::STREAMABLE && tot >= SCAN_STREAM_MIN) {      // (uniform over the workgroup)
+    if (Emit::STREAMABLE && tot >= Em.stream_from()) {      // (uniform over the workgroup)
       scan_emit_stream_block(Em, mk, r, running, (uint64_t)blk * SCAN_BLOCK_ELEMS, n);
       running += tot;
       continue;

@@ -154,9 +154,9 @@ def test_large_column_scans_match_numpy(wide):
         assert len(col_ids) == R and np.array_equal(np.sort(col_ids), np.sort(ids))
         # selectivity: 0.1 % and 10 % (fast path everywhere), 12.5 % (workgroups on both sides of the 8192-match limit), 20 % and 50 % (fall-through),
         # nothing, everything
-        # ... and around 6.25 % (512 matches per 8192-row block, SCAN_STREAM_MIN): from there on a block's ids are STREAMED from the id column instead of
-        # gathered — 5 % (gather everywhere), 6.2 % / 6.3 % (blocks on both sides of the switch inside one workgroup), 7 % (streamed almost everywhere)
-        for lo, hi in [(42, 42), (100, 199), (100, 224), (300, 499), (0, 499), (2000, 3000), (-5, 5000), (100, 149), (100, 161), (100, 162), (100, 169)]:
+        # ... and around 37.5 % (3072 matches per 8192-row block, SCAN_STREAM_MIN): from there on a block's ids are STREAMED from the id column instead of
+        # gathered — 36 % (gather everywhere), 37.4 % / 37.6 % (blocks on both sides of the switch inside one workgroup), 39 % (streamed almost everywhere)
+        for lo, hi in [(42, 42), (100, 199), (100, 224), (300, 499), (0, 499), (2000, 3000), (-5, 5000), (100, 459), (100, 473), (100, 475), (100, 489)]:
             want = _expected_ids(ids, vals, lo << sh, hi << sh)
             got = e.scan_range(f, lo << sh, hi << sh)
             assert len(got) == len(want), (wide, lo, hi, len(got), len(want))
