@@ -432,8 +432,10 @@ def main(argv=None):
     n_profiled = min(K, 12) + min(K, 8)
     cap = int(os.environ.get("BMX_BENCH_CAP", max(22_000_000, R_PER_GPU + (nb + n_profiled + 3) * ins_per_step + 4 * D_PER_STEP)))
     eng = bmx.Engine(capacity_rows=cap, device=local_rank, load_pct=int(os.environ.get("BMX_BENCH_LOAD_PCT", 0)))
-    # deferred compaction (include/bmx.h): on by default in the library; --no-defer is the A/B switch
-    defer = not args.no_defer and (not (world > 1 or args.force_sharded) or os.environ.get("BMX_SHARDED_DEFER", "1") == "1")
+    # deferred compaction (include/bmx.h): on by default in the library; --no-defer is the A/B switch. The sharded pipeline keeps every compaction on the
+    # merge stream: beside the exchange kernels the deferred form measured SLOWER in the one-rank rehearsal (104-106 against 93-99 us per step,
+    # profiles/r04_sharded_rehearsal_ab.log; BMX_SHARDED_DEFER=1 switches it on)
+    defer = not args.no_defer and (not (world > 1 or args.force_sharded) or os.environ.get("BMX_SHARDED_DEFER", "0") == "1")
     eng.set_deferred(defer)
     main_kernel = "k_probe_apply"
     verified = None
@@ -454,13 +456,19 @@ def main(argv=None):
         for b in range(W):
             step(b)
         eng.sync(); torch.cuda.synchronize()
+        # The timed region: exactly K merge calls between two device-wide synchronisations. Inside the bracket only enqueue calls: the start event, the K
+        # merges, and the stop event (timer_mark launches the last batch's still-pending compaction in front of it); torch.cuda.synchronize() waits for every
+        # stream of the device, the engine's included. The engine's own status check (eng.sync: a device-to-host copy and a second wait) comes after the clock
+        # is read — rounds 1-3 had it, and a blocking event wait, inside the bracket: ~5 us per step of host latency at K = 20 that is not merge time.
         t0 = time.perf_counter()
         eng.timer_start()
         for b in range(W, nb):
             step(b)
-        ev_ms = eng.timer_stop()
-        eng.sync(); torch.cuda.synchronize()
+        eng.timer_mark()
+        torch.cuda.synchronize()
         wall = time.perf_counter() - t0
+        ev_ms = eng.timer_elapsed()
+        eng.sync()
         elapsed = wall
         winners = n_applied[W:nb].cpu().numpy()
 

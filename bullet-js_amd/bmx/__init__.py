@@ -29,7 +29,7 @@ EXPORTS = [
     "bmx_create", "bmx_create_ex", "bmx_destroy", "bmx_last_error", "bmx_abi_version", "bmx_selfcheck", "bmx_set_deferred_compaction", "bmx_merge_fence", "bmx_get_deferred_counts", "bmx_get_info", "bmx_sync", "bmx_set_stream", "bmx_get_stream", "bmx_seq_signal", "bmx_seq_wait",
     "bmx_load_rows", "bmx_put_rows", "bmx_merge_batch", "bmx_merge_submit", "bmx_merge_collect", "bmx_host_alloc", "bmx_host_free", "bmx_merge_records", "bmx_get_rows", "bmx_get_row", "bmx_dump_rows", "bmx_row_count", "bmx_reserve",
     "bmx_index_build", "bmx_index_drop", "bmx_index_size", "bmx_index_refresh_counts", "bmx_scan_range", "bmx_scan_equals", "bmx_scan_count", "bmx_scan_filter", "bmx_scan_range_pos", "bmx_index_ids",
-    "bmx_owner_of", "bmx_partition_by_owner", "bmx_partition_by_owner_slabs", "bmx_partition_scatter", "bmx_merge_records_after", "bmx_ipc_alloc", "bmx_ipc_open", "bmx_ipc_close", "bmx_ipc_free", "bmx_seq_wait_all", "bmx_merge_notify", "bmx_timer_start", "bmx_timer_stop", "bmx_profile_enable", "bmx_profile_read", "bmx_profile_read_scan",
+    "bmx_owner_of", "bmx_partition_by_owner", "bmx_partition_by_owner_slabs", "bmx_partition_scatter", "bmx_merge_records_after", "bmx_ipc_alloc", "bmx_ipc_open", "bmx_ipc_close", "bmx_ipc_free", "bmx_seq_wait_all", "bmx_merge_tail_wait", "bmx_merge_notify", "bmx_timer_start", "bmx_timer_stop", "bmx_timer_mark", "bmx_timer_elapsed", "bmx_profile_enable", "bmx_profile_read", "bmx_profile_read_scan",
     "bmx_comm_create", "bmx_comm_destroy", "bmx_comm_last_error", "bmx_comm_nshards", "bmx_comm_shard", "bmx_comm_sync", "bmx_comm_load_rows", "bmx_comm_put_rows", "bmx_comm_merge",
     "bmx_comm_merge_dev", "bmx_comm_shard_result", "bmx_comm_row_count", "bmx_comm_get_rows", "bmx_comm_dump_rows", "bmx_comm_index_build",
     "bmx_comm_scan_range", "bmx_comm_scan_equals", "bmx_comm_scan_count", "bmx_comm_scan_filter",
@@ -133,8 +133,11 @@ def load_library():
     L.bmx_host_free.argtypes = [vp]; L.bmx_host_free.restype = i32
     L.bmx_seq_wait_all.argtypes = [vp, vp, vp, u32, u64]; L.bmx_seq_wait_all.restype = i32
     L.bmx_merge_notify.argtypes = [vp, vp, u32]; L.bmx_merge_notify.restype = i32
+    L.bmx_merge_tail_wait.argtypes = [vp, vp, u32, u64]; L.bmx_merge_tail_wait.restype = i32
     L.bmx_timer_start.argtypes = [vp]; L.bmx_timer_start.restype = i32
     L.bmx_timer_stop.argtypes = [vp, C.POINTER(C.c_float)]; L.bmx_timer_stop.restype = i32
+    L.bmx_timer_mark.argtypes = [vp]; L.bmx_timer_mark.restype = i32
+    L.bmx_timer_elapsed.argtypes = [vp, C.POINTER(C.c_float)]; L.bmx_timer_elapsed.restype = i32
     L.bmx_profile_enable.argtypes = [vp, i32]; L.bmx_profile_enable.restype = i32
     L.bmx_profile_read.argtypes = [vp, C.POINTER(C.c_float), C.POINTER(u32)]; L.bmx_profile_read.restype = i32
     L.bmx_profile_read_scan.argtypes = [vp, C.POINTER(C.c_float), C.POINTER(u32)]; L.bmx_profile_read_scan.restype = i32
@@ -488,6 +491,10 @@ class Engine:
     def seq_wait_all(self, stream_ptr, words_ptr, nwords, at_least):
         self._chk(self.L.bmx_seq_wait_all(self.h, C.c_void_p(stream_ptr) if stream_ptr else None, _ptr(words_ptr), int(nwords), int(at_least)))
 
+    def merge_tail_wait(self, words_ptr, nwords, at_least):
+        """the NEXT merge's resolve kernel ends only once the words are >= at_least (bmx_merge_tail_wait); 0 words disarms"""
+        self._chk(self.L.bmx_merge_tail_wait(self.h, C.c_void_p(int(words_ptr)) if words_ptr else None, int(nwords), int(at_least)))
+
     def merge_notify(self, word_ptrs):
         """every later merge stores the count of merges finished since into these words (peers' memory); [] switches it off"""
         n = len(word_ptrs)
@@ -530,6 +537,15 @@ class Engine:
     def timer_stop(self):
         ms = C.c_float()
         self._chk(self.L.bmx_timer_stop(self.h, C.byref(ms)))
+        return ms.value
+
+    def timer_mark(self):
+        """record the stop event now (enqueue only; the last batch's deferred compaction is launched in front of it)"""
+        self._chk(self.L.bmx_timer_mark(self.h))
+
+    def timer_elapsed(self):
+        ms = C.c_float()
+        self._chk(self.L.bmx_timer_elapsed(self.h, C.byref(ms)))
         return ms.value
 
 

@@ -170,6 +170,7 @@ class ShardedGraph:
         self.sent_remote = 0
         self.received = 0
         self._direct = None
+        self._tail_wait = os.environ.get("BMX_SHARDED_TAIL_WAIT", "1") == "1"
         self.exchange = "exact"
 
     def owned_rows(self, R_global, chunk=4_000_000):
@@ -427,6 +428,10 @@ class ShardedGraph:
     def _merge_direct(self, p):
         d, e, W, k = self._direct, self.ops.e, self.world, p["k"]
         nrecv = W * self.slab
+        # batch k + 1 is routed already (route(b + 1) comes before merge(b)): THIS merge's resolve kernel waits for its slabs' arrival words as its
+        # last act, and merge(k + 1) then needs no wait launch in front of its probe kernel (bmx_merge_tail_wait)
+        if self._tail_wait and self._routed > k + 1:
+            e.merge_tail_wait(d["own"]["arrived"], W, k + 2)
         # every origin's slab of batch k has arrived (waited for on the device), then the merge: one host call
         e.merge_records_after(d["own"]["arrived"], W, k + 1, nrecv, d["own"]["recv"] + (k % d["depth"]) * nrecv * 32, self.insert_mode, p["applied"], p["n_applied"])
         self._merged += 1

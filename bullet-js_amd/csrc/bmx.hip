@@ -130,6 +130,9 @@ struct bmx_ctx {
   uint64_t ix_full_builds = 0, ix_incremental = 0;
   // bmx_merge_notify: words (possibly in other GPUs' memory) that every merge's last workgroup sets to the number of merges finished since
   SeqPtrs notify{}; uint32_t n_notify = 0; uint64_t notify_seq = 0;
+  // bmx_merge_tail_wait: armed = the next default-path merge's resolve kernel polls these words before it ends; waited = a resolve kernel that did so has
+  // been enqueued (the bmx_merge_records_after that asks for the same wait then launches no wait kernel)
+  struct TailWait { const unsigned long long* words = nullptr; uint32_t n = 0; unsigned long long at_least = 0; } tail_armed, tail_waited;
   bool notify_armed = false;          // set by bmx_merge_records_after around ITS merge: only the merges of the slab protocol count up the peers' free words
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
   // Deferred compaction (merge_core): the compaction of a device-resident batch is not launched with the batch. If the next call is another such
@@ -355,6 +358,13 @@ void launch_k3(bmx_ctx* ctx, const bmx_ctx::PendingK3& P, hipStream_t ks) {
                      P.applied, P.Fin, P.L, P.mark_created);
   if (P.notify_after) hipLaunchKernelGGL(k_seq_signal_multi, dim3(1), dim3(64), 0, ks, ctx->notify, ctx->n_notify, (unsigned long long)P.notify_seq);
 }
+// The deferral protocol lets a one-wave kernel on the side stream wait for a kernel on the context's stream to START. Where the runtime or a tool runs
+// kernels strictly one at a time — rocprofv3 counter collection (--pmc serialises every dispatch of the device), HIP_LAUNCH_BLOCKING,
+// AMD_SERIALIZE_KERNEL — that wait would never end (it expires after ~60 s and raises BMX_ERR_INTERNAL). Such processes keep every launch in stream order.
+bool launches_are_serialized() {
+  auto on = [](const char* name) { const char* v = std::getenv(name); return v && v[0] && !(v[0] == '0' && !v[1]) && std::strcmp(v, "False") && std::strcmp(v, "false"); };
+  return on("ROCPROF_COUNTER_COLLECTION") || on("HIP_LAUNCH_BLOCKING") || on("AMD_SERIALIZE_KERNEL") || on("BMX_NO_DEFERRED_COMPACTION");
+}
 int flush_pending(bmx_ctx* ctx) {
   if (!ctx->pend.on) return BMX_OK;
   ctx->pend.on = false;
@@ -455,7 +465,18 @@ int merge_core(bmx_ctx* ctx, uint64_t n, const uint64_t* id, const uint32_t* fie
   if (deferring) {
     ++ctx->dseq;
     A.started = &ctx->ds->seqw[0]; A.started_val = ctx->dseq;
-    if (side_k3) { A.k3_done = &ctx->ds->seqw[1]; A.k3_wait = ctx->pend.seq; }
+    if (side_k3) {
+      A.k3_done = &ctx->ds->seqw[1]; A.k3_wait = ctx->pend.seq;
+      if (ctx->pend.Fin.n_notify) {   // the slab set of the batch before is free the moment this probe kernel starts: said there, not under it
+        A.notify = ctx->pend.Fin.notify; A.n_notify = ctx->pend.Fin.n_notify; A.notify_value = ctx->pend.Fin.notify_value;
+        ctx->pend.Fin.n_notify = 0;
+      }
+    }
+  }
+  bool tail_used = false;
+  if (ctx->tail_armed.n && !strict && !unique) {     // (paths without a resolve kernel leave it armed for nobody: the later wait launch is then not skipped)
+    A.tail_words = ctx->tail_armed.words; A.tail_n = ctx->tail_armed.n; A.tail_at_least = ctx->tail_armed.at_least; A.tail_diag = ctx->ds->seq_diag;
+    tail_used = true;
   }
   const uint32_t blocks = (uint32_t)((n + 255) / 256);
   const uint32_t rblocks = blocks;   // one lane per delta
@@ -497,6 +518,8 @@ int merge_core(bmx_ctx* ctx, uint64_t n, const uint64_t* id, const uint32_t* fie
     else hipLaunchKernelGGL((k_resolve_lists<AOS, BMX_INSERT_DELTA>), dim3(rblocks), dim3(256), 0, ctx->stream, A);
   }
   LAUNCHCHK("k_resolve_lists");
+  if (tail_used) { ctx->tail_waited = ctx->tail_armed; }
+  ctx->tail_armed = bmx_ctx::TailWait{};
   if (pe) HIPCHK(hipEventRecord(pe[2], ctx->stream));
   // K3: ordered compaction of the winner bytes (+ the index change log while an index is being maintained)
   bmx_ctx::PendingK3 P;
@@ -1065,6 +1088,7 @@ int bmx_create_ex(int device, uint64_t capacity_rows, uint32_t max_load_pct, uin
     for (int i = 0; i < 2; i++) ctx->stg[i].tail = ctx->stg_tails + i;
   } else { ctx->stg_tails = nullptr; (void)hipGetLastError(); }
   ctx->fixed_capacity = (flags & BMX_CTX_FIXED_CAPACITY) != 0;
+  ctx->defer_enabled = !launches_are_serialized();
   CR(hipMemsetAsync(ctx->ds, 0, sizeof(DevScalars), ctx->stream));
   hipLaunchKernelGGL(k_init_slots, dim3(2048), dim3(256), 0, ctx->stream, ctx->slots, nslots);
   CR(hipGetLastError());
@@ -1206,7 +1230,11 @@ int bmx_merge_records(bmx_ctx* ctx, uint64_t n, const bmx_delta_rec* recs, int i
 int bmx_merge_records_after(bmx_ctx* ctx, const uint64_t* wait_words_dev, uint32_t n_wait, uint64_t wait_at_least, uint64_t n, const bmx_delta_rec* recs,
                             int insert_mode, uint32_t* applied_idx, uint64_t* n_applied, uint8_t* flags, bmx_merge_stats* stats) {
   if (!ctx) return fail(nullptr, BMX_ERR_INVALID, "null context");
-  if (wait_words_dev && n_wait) { int wrc = bmx_seq_wait_all(ctx, nullptr, wait_words_dev, n_wait, wait_at_least); if (wrc) return wrc; }
+  if (wait_words_dev && n_wait) {
+    const bool done = ctx->tail_waited.n == n_wait && ctx->tail_waited.words == reinterpret_cast<const unsigned long long*>(wait_words_dev) && ctx->tail_waited.at_least >= wait_at_least;
+    ctx->tail_waited = bmx_ctx::TailWait{};
+    if (!done) { int wrc = bmx_seq_wait_all(ctx, nullptr, wait_words_dev, n_wait, wait_at_least); if (wrc) return wrc; }   // (done: the resolve kernel of the merge before waited for exactly this)
+  }
   ctx->notify_armed = true;      // THIS merge reads a receive slab set: it (and no other merge of the context) tells the origins when the set is free again
   const int rc = bmx_merge_records(ctx, n, recs, insert_mode, applied_idx, n_applied, flags, stats);
   ctx->notify_armed = false;
@@ -1559,6 +1587,12 @@ int bmx_seq_wait_all(bmx_ctx* ctx, void* hip_stream, const uint64_t* words_dev, 
   return BMX_OK;
 }
 
+int bmx_merge_tail_wait(bmx_ctx* ctx, const uint64_t* words_dev, uint32_t nwords, uint64_t at_least) {
+  if (!ctx || nwords > 64 || (nwords && !words_dev)) return fail(ctx, BMX_ERR_INVALID, "bmx_merge_tail_wait: at most 64 words");
+  ctx->tail_armed.words = reinterpret_cast<const unsigned long long*>(words_dev); ctx->tail_armed.n = nwords; ctx->tail_armed.at_least = at_least;
+  return BMX_OK;
+}
+
 int bmx_merge_notify(bmx_ctx* ctx, uint64_t* const* words, uint32_t nwords) {
   if (!ctx || nwords > PART_MAX_SHARDS || (nwords && !words)) return fail(ctx, BMX_ERR_INVALID, "bmx_merge_notify: at most 16 words");
   if (int erc = enter(ctx)) return erc;
@@ -1572,7 +1606,7 @@ int bmx_merge_notify(bmx_ctx* ctx, uint64_t* const* words, uint32_t nwords) {
 int bmx_set_deferred_compaction(bmx_ctx* ctx, int on) {
   if (!ctx) return fail(nullptr, BMX_ERR_INVALID, "null context");
   if (int erc = enter(ctx)) return erc;
-  ctx->defer_enabled = on != 0;
+  ctx->defer_enabled = on != 0 && !launches_are_serialized();    // (never where kernels run one at a time: see launches_are_serialized)
   return BMX_OK;
 }
 int bmx_merge_fence(bmx_ctx* ctx) {
@@ -1596,6 +1630,20 @@ int bmx_timer_stop(bmx_ctx* ctx, float* ms_out) {
   if (!ctx || !ms_out) return fail(ctx, BMX_ERR_INVALID, "bad arguments");
   if (int erc = enter(ctx)) return erc;          // the last batch's compaction is part of what is timed
   HIPCHK(hipEventRecord(ctx->ev1, ctx->stream));
+  HIPCHK(hipEventSynchronize(ctx->ev1));
+  HIPCHK(hipEventElapsedTime(ms_out, ctx->ev0, ctx->ev1));
+  return BMX_OK;
+}
+
+int bmx_timer_mark(bmx_ctx* ctx) {
+  if (!ctx) return fail(nullptr, BMX_ERR_INVALID, "null context");
+  if (int erc = enter(ctx)) return erc;          // the last batch's compaction is part of what is timed
+  HIPCHK(hipEventRecord(ctx->ev1, ctx->stream));
+  return BMX_OK;
+}
+int bmx_timer_elapsed(bmx_ctx* ctx, float* ms_out) {
+  if (!ctx || !ms_out) return fail(ctx, BMX_ERR_INVALID, "bad arguments");
+  HIPCHK(hipSetDevice(ctx->device));
   HIPCHK(hipEventSynchronize(ctx->ev1));
   HIPCHK(hipEventElapsedTime(ms_out, ctx->ev0, ctx->ev1));
   return BMX_OK;

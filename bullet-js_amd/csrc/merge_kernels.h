@@ -28,6 +28,9 @@
 
 namespace bmx {
 
+constexpr int PART_MAX_SHARDS = 16;
+struct SeqPtrs { unsigned long long* p[PART_MAX_SHARDS]; };
+
 struct MergeArgs {
   Slot* slots;
   uint64_t nslots;
@@ -59,6 +62,12 @@ struct MergeArgs {
   unsigned long long k3_wait = 0;                 // workspace the NEXT batch writes has finished (it was released when this batch's probe kernel started)
   uint32_t* fld_out = nullptr;                    // per delta: its field hash, kept for a change log that is written after the caller's columns may be gone
   uint32_t log_slots = 0;                         // every first claimer records its row's slot (the compaction writes an index change log)
+  // bmx_merge_notify with a deferred compaction: the batch BEFORE this one is done with its receive slabs as soon as this launch starts (its probe and
+  // resolve kernels are in front of it on the stream), so block 0 tells the origins here instead of the compaction that runs under this kernel
+  SeqPtrs notify{}; uint32_t n_notify = 0; unsigned long long notify_value = 0;
+  // bmx_merge_tail_wait: k_resolve_lists' block 0 returns only once tail_n words (this GPU's memory, written by peers) are >= tail_at_least — the
+  // arrival words of the NEXT batch's slabs, so that its probe kernel follows without a wait launch in between
+  const unsigned long long* tail_words = nullptr; uint32_t tail_n = 0; unsigned long long tail_at_least = 0; unsigned long long* tail_diag = nullptr;
 };
 
 constexpr uint8_t W_NONE = 0, W_WINNER = 1, W_PENDING = 2, W_FIRST = 4;   // W_FIRST (bit): first claimer of its row in this batch; bit 0 is what the compaction reads
@@ -231,6 +240,7 @@ template <bool AOS, int MODE, bool UNIQUE, int NT>
 __global__ __launch_bounds__(NT) void k_probe_apply(MergeArgs A) {
   const uint32_t j = blockIdx.x * (uint32_t)NT + threadIdx.x;
   if (A.started && j == 0) __hip_atomic_store(A.started, A.started_val, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  if (A.n_notify && j < A.n_notify && A.notify.p[j]) __hip_atomic_store(A.notify.p[j], A.notify_value, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
   for (uint32_t t = j; t < A.blk_ents; t += gridDim.x * (uint32_t)NT) A.blk_next[t] = 0u;
   const bool active = j < A.n;
   uint64_t id = EMPTY_ID; uint32_t field = 0; int64_t a = 0, v = 0;
@@ -378,6 +388,18 @@ __global__ __launch_bounds__(256) void k_resolve_lists(MergeArgs A) {
     while (__hip_atomic_load(A.k3_done, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < A.k3_wait) {
       __builtin_amdgcn_s_sleep(8);
       if (wall_clock64() - t0 > 6000000000ull) { atomicOr(A.status, ST_SPIN); break; }   // ~60 s: report instead of hanging
+    }
+  }
+  if (A.tail_n && blockIdx.x == 0 && threadIdx.x < A.tail_n) {     // lane k polls word k (relaxed, cache-bypassing: the acquire is the boundary behind this launch)
+    const unsigned long long t0 = wall_clock64();
+    unsigned long long seen;
+    while ((seen = __hip_atomic_load(A.tail_words + threadIdx.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM)) < A.tail_at_least) {
+      __builtin_amdgcn_s_sleep(8);
+      if (wall_clock64() - t0 > 6000000000ull) {
+        if (A.tail_diag) { A.tail_diag[0] = (unsigned long long)(uintptr_t)(A.tail_words + threadIdx.x); A.tail_diag[1] = A.tail_at_least; A.tail_diag[2] = seen; }
+        atomicOr(A.status, ST_SPIN);
+        break;
+      }
     }
   }
 }
@@ -630,8 +652,6 @@ __global__ void k_seq_wait_all(const unsigned long long* words, uint32_t n, unsi
   }
 }
 // One store of `value` into each of n words that may live in other GPUs' memory (lane k -> word k), after everything enqueued before.
-constexpr int PART_MAX_SHARDS = 16;
-struct SeqPtrs { unsigned long long* p[PART_MAX_SHARDS]; };
 // The RELEASE is the kernel boundary in front of this launch: everything enqueued before it on the stream is complete and written back.
 __global__ void k_seq_signal_multi(SeqPtrs w, uint32_t n, unsigned long long value) {
   if (threadIdx.x < n && w.p[threadIdx.x]) __hip_atomic_store(w.p[threadIdx.x], value, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);

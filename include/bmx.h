@@ -205,6 +205,10 @@ int bmx_merge_records(bmx_ctx* ctx, uint64_t n, const bmx_delta_rec* recs, int i
  *   - a caller that enqueues its own work on the context's stream (bmx_set_stream) and reads applied_idx / n_applied / stats there without
  *     bmx_sync() calls bmx_merge_fence() first: it only enqueues, and orders the stream behind every compaction;
  *   - bmx_set_deferred_compaction(ctx, 0) restores strict stream order for every launch (the communicator does this for its shards).
+ * The side stream's compaction is released by a one-wave kernel that waits for the next probe kernel to START, so it needs kernels of two
+ * streams to run side by side. A process in which every dispatch is serialised — rocprofv3 counter collection (--pmc; ROCPROF_COUNTER_COLLECTION in
+ * the environment), HIP_LAUNCH_BLOCKING, AMD_SERIALIZE_KERNEL, or BMX_NO_DEFERRED_COMPACTION=1 — never defers (bmx_set_deferred_compaction(ctx, 1)
+ * is ignored there); kernel traces without counters (rocprofv3 --kernel-trace --stats) do not serialise and keep it on.
  * bmx_get_deferred_counts: merges whose compaction was deferred / of those, how many actually ran on the side stream. */
 int bmx_set_deferred_compaction(bmx_ctx* ctx, int on);
 int bmx_merge_fence(bmx_ctx* ctx);
@@ -434,11 +438,19 @@ int bmx_partition_scatter(bmx_ctx* ctx, uint64_t n, const uint64_t* id, const ui
 int bmx_merge_records_after(bmx_ctx* ctx, const uint64_t* wait_words_dev, uint32_t n_wait, uint64_t wait_at_least, uint64_t n, const bmx_delta_rec* recs,
                             int insert_mode, uint32_t* applied_idx, uint64_t* n_applied, uint8_t* flags, bmx_merge_stats* stats);
 int bmx_seq_wait_all(bmx_ctx* ctx, void* hip_stream, const uint64_t* words_dev, uint32_t nwords, uint64_t at_least);
+/* bmx_merge_tail_wait: the wait of the NEXT batch, folded into THIS merge. Armed before a merge call, it makes that merge's resolve kernel (one wave
+ * of it) return only once the nwords words are >= at_least; a following bmx_merge_records_after that asks for the same (or a weaker) wait on the same
+ * words then launches no wait kernel: its probe kernel follows the resolve kernel directly (one launch and its boundary less per step of the
+ * pipeline). Arm it only when the batch those words belong to has been routed already — like every wait here it expires after ~60 s otherwise.
+ * One shot: it applies to the next merge call only (and is dropped by merges on paths that have no resolve kernel). */
+int bmx_merge_tail_wait(bmx_ctx* ctx, const uint64_t* words_dev, uint32_t nwords, uint64_t at_least);
 int bmx_merge_notify(bmx_ctx* ctx, uint64_t* const* words, uint32_t nwords);
 
 /* ---- timing helpers (HIP events on the context's stream; used by bench.py) ------------------- */
 int bmx_timer_start(bmx_ctx* ctx);
 int bmx_timer_stop(bmx_ctx* ctx, float* ms_out);    /* synchronises on the stop event */
+int bmx_timer_mark(bmx_ctx* ctx);                   /* bmx_timer_stop in two halves: record the stop event now (enqueue only) ... */
+int bmx_timer_elapsed(bmx_ctx* ctx, float* ms_out); /* ... and read the time between start and mark later (synchronises on the mark) */
 /* Per-kernel timing of the merge: while enabled, every merge call brackets its three stages with HIP
  * events (up to 64 calls are kept). bmx_profile_read synchronises and returns the AVERAGE milliseconds
  * per call of: [0] k_probe_apply, [1] k_resolve_lists, [2] winner compaction, and the number of calls averaged */
