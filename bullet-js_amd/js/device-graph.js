@@ -161,6 +161,12 @@ class DeviceVcTable {
     }
     return { updated: Uint32Array.from(upd).sort(), flags, nRows };
   }
+  /* mergeBatch off the event loop (one table: a worker thread of the addon, in issue order with every other operation on the table; the clocks of the
+   * updated rows come back with the result as `rows`, read right behind the merge). Several tables: the synchronous form behind a resolved promise. */
+  mergeBatchAsync(c) {
+    if (this.N === 1 && typeof this.native.vcMergeBatchAsync === "function") return this.native.vcMergeBatchAsync(this.handle, c.id, c.field, c.clocks, c.val, c.keysets);
+    return Promise.resolve().then(() => this.mergeBatch(c));
+  }
   getRows(id, field) {
     if (this.N === 1) return this.native.vcGetRows(this.handle, id, field);
     const n = id.length, K = this.K, back = this._split(id);

@@ -574,7 +574,11 @@ class GpuCRT {
    * is the loop this pipelines). Host-path writes issued in between are ordered with the merges through the same queue.
    */
   mergeEntriesAsync(entries, opts = {}) {
-    if (this._opts.writers) return Promise.resolve().then(() => this._mergeEntriesVector(entries, opts));
+    if (this._opts.writers) {          // the same split for the vector-clock table: packed now, merged on a worker thread of the addon, applied when it settles
+      const p = this._packVector(entries, opts);
+      if (!p.used.n) return Promise.resolve(this._finishVector(entries, p, { updated: new Uint32Array(0), flags: new Uint8Array(0), nRows: this.vcTable.rowCount() }, opts));
+      return this.vcTable.mergeBatchAsync(p.used).then((r) => this._finishVector(entries, p, r, opts));
+    }
     const p = this._packEntries(entries, opts);
     return this.mergeBatchAsync(p.cols, p.mergeOpts).then((r) => this._finishEntries(entries, p, r, opts));
   }
@@ -955,7 +959,14 @@ class GpuCRT {
    *     nApplied, nConflicts (concurrent merges), nRows, host: [entry indices], broadcast}
    */
   _mergeEntriesVector(entries, opts = {}) {
-    const t = this.vcTable, keys = t.keys, nat = t.native;
+    const p = this._packVector(entries, opts);
+    const r = p.used.n ? this.vcTable.mergeBatch(p.used) : { updated: new Uint32Array(0), flags: new Uint8Array(0), nRows: this.vcTable.rowCount() };
+    return this._finishVector(entries, p, r, opts);
+  }
+
+  /* entries -> one delta per eligible entry on its node's clock row in the vector-clock table (counters, key set, arrival number) */
+  _packVector(entries, opts = {}) {
+    const t = this.vcTable, keys = t.keys;
     const writer = opts.writer || this.bullet.id;
     const n = entries.length;
     this._flushVcPuts();
@@ -1006,8 +1017,13 @@ class GpuCRT {
         bPath[x] = undefined;
       }
     }
-    const used = cols.slice(i);
-    const r = i ? t.mergeBatch(used) : { updated: new Uint32Array(0), flags: new Uint8Array(0), nRows: t.rowCount() };
+    return { used: cols.slice(i), rowEntry, rowNode, host, n: i };
+  }
+
+  /* what the device decided -> winners, flags, the store (opts.apply) */
+  _finishVector(entries, p, r, opts = {}) {
+    const t = this.vcTable, keys = t.keys, nat = t.native;
+    const { used, rowEntry, rowNode, host } = p, i = p.n;
     const nw = r.updated.length;
     const appliedEntries = new Int32Array(nw);
     for (let k = 0; k < nw; k++) appliedEntries[k] = rowEntry[r.updated[k]];
@@ -1046,7 +1062,7 @@ class GpuCRT {
     const nw = r.updated.length;
     const ids = new BigUint64Array(nw), fields = new Uint32Array(nw);
     for (let k = 0; k < nw; k++) { ids[k] = cols.id[r.updated[k]]; fields[k] = cols.field[r.updated[k]]; }
-    const got = t.getRows(ids, fields);
+    const got = r.rows || t.getRows(ids, fields);       // (the asynchronous merge brings the updated rows' clocks along: read right behind ITS merge, not behind a later one)
     const valueRows = opts.valueRows !== false;
     const q = valueRows ? this._putQueue() : null;
     const gk = valueRows ? this.graph.keys : null;

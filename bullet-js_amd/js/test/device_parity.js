@@ -799,5 +799,52 @@ for (const batchPuts of [false, true]) {
     assert.ok(seq.scan.length > 100 && seq.clocks.length > 2000);
     checks += 5;
   }
+  /* the same for GENERAL vector clocks (N4): mergeEntriesAsync under `writers` is a real asynchronous merge now (vcMergeBatchAsync: a worker thread of the
+   * addon, the updated rows' clocks read right behind the merge) — two chunks in flight leave the store, every clock's key ORDER and the device rows that a
+   * synchronous loop over the same chunks leaves; and a clock that names a writer outside the table shows up in hostOnlyInfo() */
+  {
+    let s = 4242;
+    const rnd = () => { s ^= s << 13; s >>>= 0; s ^= s >>> 17; s ^= s << 5; s >>>= 0; return s; };
+    const WR = ["a", "b", "w"];
+    const chunks = [];
+    for (let c = 0; c < 5; c++) {
+      const entries = [];
+      for (let j = 0; j < 2500; j++) {
+        const clock = {}; const k = 1 + (rnd() % 3);
+        for (let x = 0; x < k; x++) clock[WR[(x + (rnd() % 3)) % 3]] = rnd() % 4;
+        const data = rnd() % 2 ? { a: rnd() % 50, note: "n" + (rnd() % 3) } : { b: rnd() % 9 };
+        entries.push({ path: "v/n" + (rnd() % 1500), data, vectorClock: clock });
+      }
+      chunks.push(entries);
+    }
+    const run = async (pipelined) => {
+      const b = new MiniBullet("w");
+      const { crt: c2 } = attach(b, { capacityRows: 1 << 15, writers: WR });
+      let ticks = 0;
+      const timer = setInterval(() => { ticks++; }, 0);
+      if (pipelined) await c2.mergeEntriesPipelined(chunks.map((c) => JSON.parse(JSON.stringify(c))), { apply: true });
+      else for (const c of chunks) c2.mergeEntries(JSON.parse(JSON.stringify(c)), { apply: true });
+      clearInterval(timer);
+      const paths = Object.keys(b.meta).sort();
+      const out = { store: JSON.parse(JSON.stringify(b.store)), clocks: paths.map((k) => [k, Object.keys(b.meta[k].vectorClock).map((w) => [w, b.meta[k].vectorClock[w]])]),
+        device: c2.vcLookup(paths).map((c) => c && Object.keys(c).map((w) => [w, c[w]])) };
+      // a clock over a writer the table does not know: its entry is the host's, and the caller can see that such paths exist
+      const before = c2.hostOnlyInfo().marked;
+      const r = c2.mergeEntries([{ path: "v/foreign", data: { a: 1 }, vectorClock: { zed: 3 } }], { apply: true });
+      assert.deepStrictEqual(Array.from(r.host), [0]);
+      b.setData("v/foreign", { a: 1, __fromNetwork: true, __vectorClock: { zed: 3 } });      // first sight: stored under {w: 2}, the sender's clock is discarded (src/bullet-crt.js:172-185)
+      b.setData("v/foreign", { a: 2, __fromNetwork: true, __vectorClock: { zed: 3 } });      // concurrent with {w: 2}: the merged clock names `zed`, which the table cannot hold
+      assert.deepStrictEqual(Object.keys(b.meta["v/foreign"].vectorClock).sort(), ["w", "zed"]);
+      assert.ok(c2.hostOnlyInfo().marked > before && c2.hostOnlyInfo().hostOnlyPaths >= 1, JSON.stringify(c2.hostOnlyInfo()));
+      b.close();
+      return out;
+    };
+    const seq = await run(false), pip = await run(true);
+    assert.deepStrictEqual(pip.store, seq.store, "pipelined vector ingestion: store");
+    assert.deepStrictEqual(pip.clocks, seq.clocks, "pipelined vector ingestion: clocks with their key order");
+    assert.deepStrictEqual(pip.device, seq.device, "pipelined vector ingestion: clocks on the device");
+    assert.ok(seq.clocks.length > 1000);
+    checks += 4;
+  }
   console.log("device_parity ok:", checks, "checks");
 })().catch((e) => { console.error(e); process.exit(1); });

@@ -106,6 +106,14 @@ if (process.argv[5] === "vector" || process.argv[6] === "vector") {
   let conc = 0;
   for (const entries of vb) conc += vcrt.mergeEntries(entries).nConflicts;
   vector = { mergeEntries_per_s: (B * D) / (Number(process.hrtime.bigint() - t0) / 1e9), concurrent_merges: conc, writers: 3 };
+  // ... and through mergeEntriesAsync (vcMergeBatchAsync on a worker thread of the addon), two chunks in flight: chunk b + 1 is packed while chunk b is merged
+  const vb2 = mkBatches(5);
+  for (const entries of vb2) for (const e of entries) { const c = {}; const k = rnd() % 4; for (let x = 0; x < k; x++) c[WR[(x + (rnd() % 3)) % 3]] = rnd() % 5; e.vectorClock = c; }
+  await vcrt.mergeEntriesAsync(vb2[0].slice(0, 1000));
+  t0 = process.hrtime.bigint();
+  await vcrt.mergeEntriesPipelined(vb2);
+  vector.mergeEntriesPipelined_per_s = (B * D) / (Number(process.hrtime.bigint() - t0) / 1e9);
+  vector.host_only = vcrt.hostOnlyInfo();
   vcrt.close();
 }
 console.log(JSON.stringify({ applied_path, vector, mergeEntries_per_s: ONLY ? null : (B * D) / dtEntries, mergeEntriesPipelined_per_s: ONLY ? null : (B * D) / dtPipe, mergeBatch_typed_columns_per_s: ONLY ? null : (B * D) / dtCols, unit: "deltas/s", resident_keys: R,

@@ -499,7 +499,19 @@ napi_value Info(napi_env env, napi_callback_info info) {
 }
 
 // ---- N4: vector-clock table (bmx_vc_*) -----------------------------------------------------------------------------
-struct VcHandle { bmx_vc* t; uint32_t K; std::mutex mu; };
+// operations on a table run in the order JS issued them, on whatever thread (the asynchronous merge runs on a libuv worker): tickets, as for the scalar engine
+struct VcHandle {
+  bmx_vc* t; uint32_t K;
+  std::mutex mu; std::condition_variable cv;
+  uint64_t next_ticket = 0, serving = 0;
+  uint64_t take() { std::lock_guard<std::mutex> g(mu); return next_ticket++; }
+};
+struct VcTurn {
+  VcHandle* h; std::unique_lock<std::mutex> lk;
+  VcTurn(VcHandle* hh, uint64_t ticket) : h(hh), lk(hh->mu) { h->cv.wait(lk, [&] { return h->serving == ticket; }); }
+  explicit VcTurn(VcHandle* hh) : h(hh), lk(hh->mu) { const uint64_t t = h->next_ticket++; h->cv.wait(lk, [&] { return h->serving == t; }); }
+  ~VcTurn() { h->serving++; lk.unlock(); h->cv.notify_all(); }
+};
 
 void finalize_vc(napi_env, void* data, void*) {
   VcHandle* h = static_cast<VcHandle*>(data);
@@ -551,7 +563,7 @@ napi_value VcDestroy(napi_env env, napi_callback_info info) {
   void* p = nullptr;
   if (napi_get_value_external(env, argv[0], &p) == napi_ok && p) {
     VcHandle* h = static_cast<VcHandle*>(p);
-    std::lock_guard<std::mutex> g(h->mu);
+    VcTurn turn(h);
     if (h->t) { bmx_vc_destroy(h->t); h->t = nullptr; }
   }
   return nullptr;
@@ -590,7 +602,7 @@ napi_value VcLoadRows(napi_env env, napi_callback_info info) {
   VcHandle* h; if (!get_vc(env, argv[0], &h)) return nullptr;
   const uint64_t* id; const uint32_t *field, *clocks, *ks; const int64_t* val; size_t n;
   if (!get_vc_cols(env, argv + 1, h->K, &id, &field, &clocks, &val, &n) || !get_keysets(env, argc, argv, 5, n, &ks)) return nullptr;
-  std::lock_guard<std::mutex> g(h->mu);
+  VcTurn turn(h);
   int rc = bmx_vc_load_rows_ks(h->t, n, id, field, clocks, ks, val);
   if (rc) return throw_vc(env, h->t, rc);
   return nullptr;
@@ -606,7 +618,7 @@ napi_value VcMergeBatch(napi_env env, napi_callback_info info) {
   void* fl = nullptr;
   napi_value flags = make_ta(env, napi_uint8_array, 1, n, &fl);
   uint64_t nu = 0, rows = 0;
-  std::lock_guard<std::mutex> g(h->mu);
+  VcTurn turn(h);
   int rc = bmx_vc_merge_batch_ks(h->t, n, id, field, clocks, ks, val, upd.data(), &nu, (uint8_t*)fl);
   if (rc) return throw_vc(env, h->t, rc);
   bmx_vc_row_count(h->t, &rows);
@@ -618,6 +630,90 @@ napi_value VcMergeBatch(napi_env env, napi_callback_info info) {
   napi_set_named_property(env, out, "flags", flags);
   set_num(env, out, "nRows", (double)rows);
   return out;
+}
+
+// vcMergeBatchAsync(h, id, field, clocks, val[, keysets]) -> Promise<{updated, flags, nRows, rows: {clocks, keysets} of the updated rows}>: the upload,
+// the kernels and the read-back of the updated rows' clocks run on a libuv worker thread, in issue order with every other operation on the table
+// (reference seam: the sync loop src/bullet-network-sync.js:551-569 under general vector clocks, src/bullet-crt.js:68-153). The rows' clocks come back
+// with the merge because a later merge — already in flight when this one is applied — would have moved them.
+struct VcJob {
+  napi_async_work work = nullptr; napi_deferred deferred = nullptr;
+  napi_ref refs[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+  VcHandle* h = nullptr; uint64_t ticket = 0;
+  const uint64_t* id = nullptr; const uint32_t *field = nullptr, *clocks = nullptr, *ks = nullptr; const int64_t* val = nullptr; size_t n = 0;
+  std::vector<uint32_t> upd, rclocks, rks; std::vector<uint8_t> flags, rstate; std::vector<int64_t> rval;
+  uint64_t nu = 0, rows = 0; int rc = 0; std::string err;
+};
+void vc_execute(napi_env, void* data) {
+  VcJob* j = static_cast<VcJob*>(data);
+  VcTurn turn(j->h, j->ticket);
+  if (!j->h->t) { j->rc = BMX_ERR_INVALID; j->err = "table closed"; return; }
+  j->rc = bmx_vc_merge_batch_ks(j->h->t, j->n, j->id, j->field, j->clocks, j->ks, j->val, j->upd.data(), &j->nu, j->flags.data());
+  if (j->rc) { j->err = bmx_vc_last_error(j->h->t); return; }
+  bmx_vc_row_count(j->h->t, &j->rows);
+  if (j->nu) {
+    std::vector<uint64_t> ids(j->nu); std::vector<uint32_t> fields(j->nu);
+    for (uint64_t k = 0; k < j->nu; k++) { ids[k] = j->id[j->upd[k]]; fields[k] = j->field[j->upd[k]]; }
+    j->rclocks.resize(j->nu * j->h->K); j->rks.resize(j->nu); j->rval.resize(j->nu); j->rstate.resize(j->nu);
+    j->rc = bmx_vc_get_rows_ks(j->h->t, j->nu, ids.data(), fields.data(), j->rclocks.data(), j->rks.data(), j->rval.data(), j->rstate.data());
+    if (j->rc) j->err = bmx_vc_last_error(j->h->t);
+  }
+}
+void vc_complete(napi_env env, napi_status, void* data) {
+  VcJob* j = static_cast<VcJob*>(data);
+  for (auto& r : j->refs) if (r) napi_delete_reference(env, r);
+  if (j->rc) {
+    napi_value msg, err, code;
+    std::string m = "bmx error " + std::to_string(j->rc) + ": " + j->err;
+    napi_create_string_utf8(env, m.c_str(), NAPI_AUTO_LENGTH, &msg);
+    napi_create_error(env, nullptr, msg, &err);
+    napi_create_int32(env, j->rc, &code);
+    napi_set_named_property(env, err, "code", code);
+    napi_reject_deferred(env, j->deferred, err);
+  } else {
+    void *up = nullptr, *fl = nullptr, *c = nullptr, *ks = nullptr;
+    napi_value updated = make_ta(env, napi_uint32_array, 4, (size_t)j->nu, &up);
+    if (j->nu) memcpy(up, j->upd.data(), (size_t)j->nu * 4);
+    napi_value flags = make_ta(env, napi_uint8_array, 1, j->n, &fl);
+    if (j->n) memcpy(fl, j->flags.data(), j->n);
+    napi_value clocks = make_ta(env, napi_uint32_array, 4, (size_t)j->nu * j->h->K, &c);
+    napi_value keysets = make_ta(env, napi_uint32_array, 4, (size_t)j->nu, &ks);
+    if (j->nu) { memcpy(c, j->rclocks.data(), (size_t)j->nu * j->h->K * 4); memcpy(ks, j->rks.data(), (size_t)j->nu * 4); }
+    napi_value out, rows;
+    napi_create_object(env, &out); napi_create_object(env, &rows);
+    napi_set_named_property(env, rows, "clocks", clocks); napi_set_named_property(env, rows, "keysets", keysets);
+    napi_set_named_property(env, out, "updated", updated); napi_set_named_property(env, out, "flags", flags); napi_set_named_property(env, out, "rows", rows);
+    set_num(env, out, "nRows", (double)j->rows);
+    napi_resolve_deferred(env, j->deferred, out);
+  }
+  napi_delete_async_work(env, j->work);
+  delete j;
+}
+napi_value VcMergeBatchAsync(napi_env env, napi_callback_info info) {
+  ARGS_OPT(5, 6);
+  VcHandle* h; if (!get_vc(env, argv[0], &h)) return nullptr;
+  VcJob* j = new VcJob();
+  j->h = h;
+  if (!get_vc_cols(env, argv + 1, h->K, &j->id, &j->field, &j->clocks, &j->val, &j->n) || !get_keysets(env, argc, argv, 5, j->n, &j->ks)) { delete j; return nullptr; }
+  j->upd.resize(j->n ? j->n : 1); j->flags.resize(j->n ? j->n : 1);
+  napi_value promise, name;
+  auto drop = [&](const char* what) {
+    for (auto& r : j->refs) if (r) napi_delete_reference(env, r);
+    if (j->work) napi_delete_async_work(env, j->work);
+    delete j;
+    napi_throw_error(env, nullptr, what);
+    return (napi_value) nullptr;
+  };
+  if (napi_create_promise(env, &j->deferred, &promise) != napi_ok) return drop("bmx: could not create a promise");
+  for (size_t k = 0; k < argc && k < 6; k++) napi_create_reference(env, argv[k], 1, &j->refs[k]);     // the table handle and the columns outlive the job
+  if (napi_create_string_utf8(env, "bmx.vcMergeBatchAsync", NAPI_AUTO_LENGTH, &name) != napi_ok ||
+      napi_create_async_work(env, nullptr, name, vc_execute, vc_complete, j, &j->work) != napi_ok) return drop("bmx: could not create the async work item");
+  j->ticket = h->take();                            // taken last: a ticket that never runs would block every later operation on this table
+  if (napi_queue_async_work(env, j->work) != napi_ok) {
+    { VcTurn skip(h, j->ticket); }
+    return drop("bmx: could not queue the async work item");
+  }
+  return promise;
 }
 
 // vcGetRows(h, id, field) -> {clocks: Uint32Array[n*K], val: BigInt64Array, state: Uint8Array, keysets: Uint32Array}
@@ -632,7 +728,7 @@ napi_value VcGetRows(napi_env env, napi_callback_info info) {
   napi_value val = make_ta(env, napi_bigint64_array, 8, n0, &v);
   napi_value state = make_ta(env, napi_uint8_array, 1, n0, &st);
   napi_value keysets = make_ta(env, napi_uint32_array, 4, n0, &ks);
-  std::lock_guard<std::mutex> g(h->mu);
+  VcTurn turn(h);
   int rc = bmx_vc_get_rows_ks(h->t, n0, (const uint64_t*)p0, (const uint32_t*)p1, (uint32_t*)c, (uint32_t*)ks, (int64_t*)v, (uint8_t*)st);
   if (rc) return throw_vc(env, h->t, rc);
   napi_value out; NAPI_OK(napi_create_object(env, &out));
@@ -649,7 +745,7 @@ napi_value VcScanRange(napi_env env, napi_callback_info info) {
   VcHandle* h; if (!get_vc(env, argv[0], &h)) return nullptr;
   uint32_t f; NAPI_OK(napi_get_value_uint32(env, argv[1], &f));
   int64_t lo, hi; if (!get_i64(env, argv[2], &lo) || !get_i64(env, argv[3], &hi)) return nullptr;
-  std::lock_guard<std::mutex> g(h->mu);
+  VcTurn turn(h);
   uint64_t m = 0; int rc = bmx_vc_scan_range(h->t, f, lo, hi, nullptr, 0, &m);
   if (rc) return throw_vc(env, h->t, rc);
   void* out; napi_value ta = make_ta(env, napi_biguint64_array, 8, m, &out);
@@ -660,7 +756,7 @@ napi_value VcRowCount(napi_env env, napi_callback_info info) {
   ARGS(1);
   VcHandle* h; if (!get_vc(env, argv[0], &h)) return nullptr;
   uint64_t n = 0;
-  std::lock_guard<std::mutex> g(h->mu);
+  VcTurn turn(h);
   int rc = bmx_vc_row_count(h->t, &n);
   if (rc) return throw_vc(env, h->t, rc);
   napi_value v; napi_create_double(env, (double)n, &v);
@@ -883,7 +979,7 @@ napi_value Init(napi_env env, napi_value exports) {
       {"abiVersion", AbiVersion}, {"create", Create}, {"destroy", Destroy}, {"mergeBatch", MergeBatch}, {"mergeBatchAsync", MergeBatchAsync}, {"reserve", Reserve}, {"loadRows", LoadRows}, {"putRows", PutRows}, {"hostColumns", HostColumns}, {"scanRangePos", ScanRangePos}, {"indexIds", IndexIds}, {"commPutRows", CommPutRows},
       {"getRows", GetRows}, {"rowCount", RowCount}, {"dumpRows", DumpRows}, {"indexBuild", IndexBuild}, {"indexDrop", IndexDrop},
       {"indexSize", IndexSize}, {"indexRefreshCounts", IndexRefreshCounts}, {"scanRange", ScanRange}, {"scanCount", ScanCount}, {"scanFilter", ScanFilter}, {"info", Info},
-      {"vcCreate", VcCreate}, {"vcDestroy", VcDestroy}, {"vcLoadRows", VcLoadRows}, {"vcMergeBatch", VcMergeBatch}, {"vcGetRows", VcGetRows}, {"vcRowCount", VcRowCount}, {"vcScanRange", VcScanRange}, {"ownersOf", OwnersOf},
+      {"vcCreate", VcCreate}, {"vcDestroy", VcDestroy}, {"vcLoadRows", VcLoadRows}, {"vcMergeBatch", VcMergeBatch}, {"vcMergeBatchAsync", VcMergeBatchAsync}, {"vcGetRows", VcGetRows}, {"vcRowCount", VcRowCount}, {"vcScanRange", VcScanRange}, {"ownersOf", OwnersOf},
       {"commCreate", CommCreate}, {"commDestroy", CommDestroy}, {"commMergeBatch", CommMergeBatch}, {"commLoadRows", CommLoadRows}, {"commGetRows", CommGetRows},
       {"commRowCount", CommRowCount}, {"commDumpRows", CommDumpRows}, {"commIndexBuild", CommIndexBuild}, {"commIndexDrop", CommIndexDrop}, {"commIndexSize", CommIndexSize},
       {"commScanRange", CommScanRange}, {"commScanCount", CommScanCount}, {"commScanFilter", CommScanFilter}};
