@@ -175,13 +175,13 @@ def js_host_rate():
         j = json.loads(r.stdout.strip().splitlines()[-1])
         for key in ("apply", "vector"):      # one process each: a 4M-entry run of every section at once does not fit node 12's default heap
             try:
-                r2 = subprocess.run([node, script, "1000000", "500000", "8", "only", key], capture_output=True, text=True, timeout=300)
+                r2 = subprocess.run([node, script, "1000000", "200000", "5", "only", key], capture_output=True, text=True, timeout=300)
                 j2 = json.loads(r2.stdout.strip().splitlines()[-1])
                 j["applied_path" if key == "apply" else "vector"] = j2["applied_path" if key == "apply" else "vector"]
             except Exception as e:
                 j["applied_path" if key == "apply" else "vector"] = {"error": str(e)[:200]}
-        j["applied_path_sample"] = "the real ingestion seam with the STORE KEPT: attach(bullet, {batchSync}) -> processSyncEntries over 8 chunks of 500k sync entries: every winner replaces its node in the nested store, meta[path] gets its clock, the op log and the put queue are fed (src/bullet.js:184-266 per batch); beside it the same entries one by one through setData and the host resolver (the reference's loop body)"
-        j["vector_sample"] = "8 chunks of 500k entries under clocks over ordered subsets of three writers (N4): nodes' clock rows in the device's vector-clock table, synchronous GpuCRT.mergeEntries"
+        j["applied_path_sample"] = "the real ingestion seam with the STORE KEPT: attach(bullet, {batchSync}) -> processSyncEntries over 5 chunks of 200k sync entries against 1M resident nodes (90 % updates, 10 % new nodes): every winner replaces its node in the nested store, meta[path] gets its clock, the op log and the put queue are fed (src/bullet.js:184-266 per batch); beside it the same entries one by one through setData and the host resolver (the reference's loop body)"
+        j["vector_sample"] = "5 chunks of 200k entries under clocks over ordered subsets of three writers (N4): nodes' clock rows in the device's vector-clock table, synchronous GpuCRT.mergeEntries"
         j["sample"] = "8 chunks of 500k sync entries (10 % new nodes) against 1M resident nodes per figure, node-level resolution (one clock-row delta per entry + the winners' value rows); GpuCRT.mergeEntries (synchronous), GpuCRT.mergeEntriesPipelined (mergeEntriesAsync, two chunks in flight) and GpuCRT.mergeBatch (typed columns) over the N-API addon, page-locked host columns"
         return j
     except Exception as e:

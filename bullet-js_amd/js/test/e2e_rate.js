@@ -80,12 +80,27 @@ if (process.argv[5] === "apply" || process.argv[6] === "apply") {
   const MiniBullet = require("./mini-bullet");
   const ab = new MiniBullet("w");
   const h = attach(ab, { capacityRows: 2 * (R + B * D), batchSync: {} });
+  // the R resident nodes first, through the seam itself and untimed (first sights: store, meta and device rows of a graph that is already there) — the
+  // timed chunks then are what a running peer sees: 90 % updates of nodes it holds, 10 % new ones
+  for (let r0 = 0; r0 < R; r0 += 250000) {
+    const seed = new Array(Math.min(250000, R - r0));
+    for (let i = 0; i < seed.length; i++) seed[i] = { path: "n/k" + (r0 + i), data: { f: (r0 + i) & 1023 }, vectorClock: { w: 5 } };
+    h.sync.processSyncEntries(seed);
+  }
   const chunks = mkBatches(3, B, true), chunks2 = mkBatches(3, Math.max(1, B >> 2), true);
   h.sync.processSyncEntries(chunks[0].slice(0, 1000));
+  const T = {};
+  if (process.env.E2E_PHASES) {      // where the time of the seam goes (wrappers around the phases of GpuCRT.mergeEntries; ns per entry)
+    const wrap = (obj, name, label) => { const fn = obj[name]; obj[name] = function (...a) { const t = process.hrtime.bigint(); try { return fn.apply(this, a); } finally { T[label] = (T[label] || 0) + Number(process.hrtime.bigint() - t); } }; };
+    wrap(h.crt, "_packEntries", "pack"); wrap(h.crt, "mergeBatch", "merge (addon + GPU)"); wrap(h.crt, "_applyWinners", "apply winners (store, meta, log, value rows)");
+    wrap(h.crt, "_unaliasLosers", "losers"); wrap(h.crt, "_flushDeviceWrites", "put rows"); wrap(h.crt, "mergeEntries", "mergeEntries total");
+  }
   t0 = process.hrtime.bigint();
   for (const c of chunks) h.sync.processSyncEntries(c);
   const dtA = Number(process.hrtime.bigint() - t0) / 1e9;
+  if (process.env.E2E_PHASES) console.error("phases (ns per entry): total " + Math.round(dtA * 1e9 / (B * D)) + "; " + Object.keys(T).map((k) => k + " " + Math.round(T[k] / (B * D))).join("; "));
   const tb = new MiniBullet("w"); tb.crt = new GpuCRT(tb);
+  for (let i = 0; i < R; i++) tb.setData("n/k" + i, { f: i & 1023, __fromNetwork: true, __vectorClock: { w: 5 } }, false);   // the same resident graph for the per-entry loop
   const few = chunks2;
   t0 = process.hrtime.bigint();
   for (const c of few) for (const e of c) tb.setData(e.path, Object.assign({}, e.data, { __fromNetwork: true, __vectorClock: e.vectorClock }), false);
