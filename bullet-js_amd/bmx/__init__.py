@@ -26,7 +26,7 @@ FLAG_INCOMING, FLAG_CURRENT, FLAG_HISTORICAL = 1, 2, 4
 MAX_BATCH = 1 << 24
 
 EXPORTS = [
-    "bmx_create", "bmx_create_ex", "bmx_destroy", "bmx_last_error", "bmx_abi_version", "bmx_selfcheck", "bmx_set_deferred_compaction", "bmx_merge_fence", "bmx_get_deferred_counts", "bmx_get_info", "bmx_sync", "bmx_set_stream", "bmx_get_stream", "bmx_seq_signal", "bmx_seq_wait",
+    "bmx_create", "bmx_create_ex", "bmx_destroy", "bmx_last_error", "bmx_abi_version", "bmx_selfcheck", "bmx_set_deferred_compaction", "bmx_merge_fence", "bmx_get_deferred_counts", "bmx_get_info", "bmx_get_placement", "bmx_set_probe_waves", "bmx_sync", "bmx_set_stream", "bmx_get_stream", "bmx_seq_signal", "bmx_seq_wait",
     "bmx_load_rows", "bmx_put_rows", "bmx_merge_batch", "bmx_merge_submit", "bmx_merge_collect", "bmx_host_alloc", "bmx_host_free", "bmx_merge_records", "bmx_get_rows", "bmx_get_row", "bmx_dump_rows", "bmx_row_count", "bmx_reserve",
     "bmx_index_build", "bmx_index_drop", "bmx_index_size", "bmx_index_refresh_counts", "bmx_scan_range", "bmx_scan_equals", "bmx_scan_count", "bmx_scan_filter", "bmx_scan_range_pos", "bmx_index_ids",
     "bmx_owner_of", "bmx_partition_by_owner", "bmx_partition_by_owner_slabs", "bmx_partition_scatter", "bmx_merge_records_after", "bmx_ipc_alloc", "bmx_ipc_open", "bmx_ipc_close", "bmx_ipc_free", "bmx_seq_wait_all", "bmx_merge_tail_wait", "bmx_merge_notify", "bmx_timer_start", "bmx_timer_stop", "bmx_timer_mark", "bmx_timer_elapsed", "bmx_profile_enable", "bmx_profile_read", "bmx_profile_read_scan",
@@ -94,6 +94,8 @@ def load_library():
     L.bmx_merge_fence.argtypes = [vp]; L.bmx_merge_fence.restype = i32
     L.bmx_get_deferred_counts.argtypes = [vp, C.POINTER(u64), C.POINTER(u64)]; L.bmx_get_deferred_counts.restype = i32
     L.bmx_get_info.argtypes = [vp, C.POINTER(Info)]; L.bmx_get_info.restype = i32
+    L.bmx_set_probe_waves.argtypes = [vp, i32]; L.bmx_set_probe_waves.restype = i32
+    L.bmx_get_placement.argtypes = [vp, C.POINTER(u32), C.POINTER(C.c_float), C.POINTER(C.c_float)]; L.bmx_get_placement.restype = i32
     L.bmx_sync.argtypes = [vp]; L.bmx_sync.restype = i32
     L.bmx_set_stream.argtypes = [vp, vp]; L.bmx_set_stream.restype = i32
     L.bmx_get_stream.argtypes = [vp]; L.bmx_get_stream.restype = vp
@@ -420,6 +422,16 @@ class Engine:
     def merge_fence(self):
         """enqueue-only: the engine's stream is ordered behind every compaction (for work the caller enqueues on that stream itself)"""
         self._chk(self.L.bmx_merge_fence(self.h))
+
+    def set_probe_waves(self, waves_per_simd):
+        """resident waves per SIMD the probe kernel may take (8, 6, 5, 4, 3): fewer leave room for kernels that run beside it (bmx_set_probe_waves)"""
+        self._chk(self.L.bmx_set_probe_waves(self.h, int(waves_per_simd)))
+
+    def placement(self):
+        """table placement tuning at create / growth: {candidates, probe_us_chosen, probe_us_slowest} (candidates 0: not tuned)"""
+        n, a, b = C.c_uint32(), C.c_float(), C.c_float()
+        self._chk(self.L.bmx_get_placement(self.h, C.byref(n), C.byref(a), C.byref(b)))
+        return {"candidates": n.value, "probe_us_chosen": round(a.value, 2), "probe_us_slowest": round(b.value, 2)}
 
     def deferred_counts(self):
         """(merges whose compaction was deferred, of those: run on the side stream under the next probe kernel)"""

@@ -54,6 +54,10 @@ class EngineOps:
         self.main.wait_stream(self._prev_stream)
         torch.cuda.set_stream(self.main)
         engine.set_stream(self.main.cuda_stream)
+        # the probe kernel leaves three of a SIMD's eight wave slots to the exchange stream's partition kernels, which are meant to run under it (they were
+        # starved beside the full-occupancy kernel and finished when it did: profiles/r04_sharded_timeline.log); BMX_K1_WAVES in the environment wins
+        if not os.environ.get("BMX_K1_WAVES"):
+            engine.set_probe_waves(5)
         self.comm = None
         self.pe = None
 

@@ -72,15 +72,17 @@ struct bmx_ctx {
   // what the compaction (K3) reads is kept per batch PARITY, so that the compaction of batch b can run on a second stream while the probe
   // kernel of batch b + 1 fills the other set ("deferred compaction", merge_core): winner bytes, the claimers' slots, the deltas' field
   // hashes (for the index change log) and the sharded counters
-  uint8_t* wflag[2] = {nullptr, nullptr};
-  uint32_t* slot_of[2] = {nullptr, nullptr};
-  uint32_t* fld_ws[2] = {nullptr, nullptr};
+  // THREE sets: while batch k is probed the compactions of batches k - 1 (just released) and k - 2 (not waited for yet) may both still be reading theirs
+  static constexpr uint32_t WS_SETS = 3, BLK_SEGS = 4;
+  uint8_t* wflag[WS_SETS] = {nullptr, nullptr, nullptr};
+  uint32_t* slot_of[WS_SETS] = {nullptr, nullptr, nullptr};
+  uint32_t* fld_ws[WS_SETS] = {nullptr, nullptr, nullptr};
   uint32_t ws_par = 0;
-  uint32_t* blk_info = nullptr;       // 3 x (ws_cap/256 + 16) block summaries: batch k adds into segment k % 3 and k_probe_apply zeroes segment (k + 1) % 3 for batch k + 1;
-                                      // three, because the compaction of batch k - 1 may still read segment (k - 1) % 3 while batch k is probed
-  uint32_t blk_half = 0, blk_seg = 0; bool blk_clean[3] = {false, false, false};   // blk_clean[h]: segment h is known to be all zero
+  uint32_t* blk_info = nullptr;       // 4 x (ws_cap/256 + 16) block summaries: batch k adds into segment k % 4 and k_probe_apply zeroes segment (k + 1) % 4 for batch k + 1;
+                                      // four, because the compactions of batches k - 1 and k - 2 may still read theirs while batch k is probed
+  uint32_t blk_half = 0, blk_seg = 0; bool blk_clean[BLK_SEGS] = {false, false, false, false};   // blk_clean[h]: segment h is known to be all zero
   uint32_t* blk_follow = nullptr;     // ws_cap/256 epoch tags: a delta of the block got a follower on its row
-  unsigned long long* shard_ctr = nullptr;  // 2 x CTR_SHARDS * CTR_STRIDE (one set per batch parity)
+  unsigned long long* shard_ctr = nullptr;  // WS_SETS x CTR_SHARDS * CTR_STRIDE (one per workspace set)
   // staging for BMX_MEM_HOST calls
   // Two staging sets: batch b+1 is uploaded (copy stream) while batch b is merged (main stream); bmx_merge_submit / bmx_merge_collect
   struct Staging {
@@ -144,8 +146,11 @@ struct bmx_ctx {
     FinishMerge Fin{}; ChgLog L{}; uint32_t mark_created = 0; bool notify_after = false; uint64_t notify_seq = 0; uint64_t seq = 0;
   } pend;
   bool defer_enabled = true;
+  uint32_t placement_tries = 0; float placement_us_best = 0, placement_us_worst = 0;   // what alloc_table_tuned saw for the current table
+  int k1_waves = 8;                   // BMX_K1_WAVES (8, 6 or 5): resident waves per SIMD of the probe kernel
   hipStream_t side = nullptr;
   uint64_t dseq = 0;                  // deferred merges so far (the sequence numbers in ds->seqw)
+  uint64_t side_last = 0, side_prev = 0;   // sequence numbers of the last two compactions launched on the side stream (0: none this stream is not ordered behind already)
   uint64_t n_deferred = 0, n_side = 0;   // merges whose compaction was deferred / actually ran on the side stream (bmx_get_deferred_counts)
   // optional per-kernel profiling (bmx_profile_enable)
   bool prof_on = false;
@@ -251,18 +256,18 @@ int ensure_workspace(bmx_ctx* ctx, uint64_t n) {
   cap = std::max<uint64_t>(cap, 1u << 16);
   cap = (cap + 255) & ~255ull;
   dev_free(ctx->next); dev_free(ctx->blk_info); dev_free(ctx->blk_follow);
-  for (int h = 0; h < 2; h++) { dev_free(ctx->wflag[h]); dev_free(ctx->slot_of[h]); dev_free(ctx->fld_ws[h]); }
+  for (uint32_t h = 0; h < bmx_ctx::WS_SETS; h++) { dev_free(ctx->wflag[h]); dev_free(ctx->slot_of[h]); dev_free(ctx->fld_ws[h]); }
   ctx->ws_cap = 0;
   int rc;
   if ((rc = dev_alloc(ctx, &ctx->next, cap))) return rc;
-  for (int h = 0; h < 2; h++)
+  for (uint32_t h = 0; h < bmx_ctx::WS_SETS; h++)
     if ((rc = dev_alloc(ctx, &ctx->wflag[h], cap + 16)) || (rc = dev_alloc(ctx, &ctx->slot_of[h], cap)) || (rc = dev_alloc(ctx, &ctx->fld_ws[h], cap))) return rc;
-  if ((rc = dev_alloc(ctx, &ctx->blk_info, 3 * ((cap / 256 + 16 + 3) & ~3ull))) || (rc = dev_alloc(ctx, &ctx->blk_follow, cap / 256 + 16))) return rc;
+  if ((rc = dev_alloc(ctx, &ctx->blk_info, bmx_ctx::BLK_SEGS * ((cap / 256 + 16 + 3) & ~3ull))) || (rc = dev_alloc(ctx, &ctx->blk_follow, cap / 256 + 16))) return rc;
   HIPCHK(hipMemsetAsync(ctx->next, 0, cap * sizeof(uint32_t), ctx->stream));
   HIPCHK(hipMemsetAsync(ctx->blk_follow, 0, (cap / 256 + 16) * sizeof(uint32_t), ctx->stream));
   ctx->blk_half = (uint32_t)((cap / 256 + 16 + 3) & ~3ull);    // a multiple of four entries: every segment stays 16-byte aligned for the compaction's wide loads
-  HIPCHK(hipMemsetAsync(ctx->blk_info, 0, 3 * (size_t)ctx->blk_half * sizeof(uint32_t), ctx->stream));
-  ctx->blk_clean[0] = ctx->blk_clean[1] = ctx->blk_clean[2] = true;
+  HIPCHK(hipMemsetAsync(ctx->blk_info, 0, bmx_ctx::BLK_SEGS * (size_t)ctx->blk_half * sizeof(uint32_t), ctx->stream));
+  for (uint32_t h = 0; h < bmx_ctx::BLK_SEGS; h++) ctx->blk_clean[h] = true;
   ctx->ws_cap = (uint32_t)cap;
   return BMX_OK;
 }
@@ -317,6 +322,56 @@ uint64_t slots_for(uint64_t capacity_rows, uint32_t load_pct) {
   return nslots >= (1ull << 32) ? 0 : nslots;   // the last 32-bit value is a sentinel (STRICT_NO_ROW)
 }
 
+// Where a table lands matters: the same kernels on the same rows take 68-72 us per 1M-delta launch on some allocations of a 1.4 GB table and 77-80 us on
+// others made in the same process minutes apart — a property of the allocation that stays for its lifetime (profiles/r04_placement_probe.log: six tables alive at
+// once, three passes; which ones are fast changes from run to run). So a large table is allocated up to PLACEMENT_TRIES times, every candidate is timed with
+// the probe kernel's own request mix (k_placement_probe: 2^20 random slot reads + head exchanges + 16-byte stores, best of three launches, ~0.25 ms per
+// candidate), the fastest is kept and the others are freed. Candidates stay allocated while the next one is made (otherwise the allocator hands the same range
+// back); tables too large for that many copies get fewer tries. BMX_TABLE_PLACEMENT_TRIES=1 switches it off. -> the chosen allocation (uninitialised)
+constexpr int PLACEMENT_TRIES = 4;   // (BMX_TABLE_PLACEMENT_TRIES overrides, 1..16)
+constexpr uint64_t PLACEMENT_MIN_BYTES = 256ull << 20;     // below the Infinity Cache's size a table's lines are served on-die wherever they live
+int alloc_table_tuned(bmx_ctx* ctx, uint64_t nslots, Slot** out) {
+  *out = nullptr;
+  int tries = PLACEMENT_TRIES;
+  if (const char* t = std::getenv("BMX_TABLE_PLACEMENT_TRIES")) { const int v = std::atoi(t); if (v >= 1 && v <= 16) tries = v; }
+  const uint64_t bytes = nslots * sizeof(Slot);
+  if (bytes < PLACEMENT_MIN_BYTES) tries = 1;
+  else {
+    size_t free_b = 0, total_b = 0;
+    if (hipMemGetInfo(&free_b, &total_b) == hipSuccess) { while (tries > 1 && (uint64_t)tries * bytes + (2ull << 30) > free_b) tries--; } else (void)hipGetLastError();
+  }
+  int rc;
+  if (tries == 1) return dev_alloc(ctx, out, nslots);
+  std::vector<Slot*> cand;
+  std::vector<float> us;
+  hipEvent_t e0 = nullptr, e1 = nullptr;
+  if (hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess) { (void)hipGetLastError(); if (e0) (void)hipEventDestroy(e0); return dev_alloc(ctx, out, nslots); }
+  constexpr uint32_t PN = 1u << 20;
+  for (int k = 0; k < tries; k++) {
+    Slot* p = nullptr;
+    if ((rc = dev_alloc(ctx, &p, nslots))) { if (cand.empty()) { (void)hipEventDestroy(e0); (void)hipEventDestroy(e1); return rc; } break; }
+    float best = 1e30f;
+    for (int rep = 0; rep < 4; rep++) {                    // (the first launch on a fresh allocation also pays its page-table walk misses: not counted)
+      (void)hipEventRecord(e0, ctx->stream);
+      hipLaunchKernelGGL(k_placement_probe, dim3(PN / 64), dim3(64), 0, ctx->stream, p, nslots, PN, (uint32_t)(k * 16 + rep));
+      (void)hipEventRecord(e1, ctx->stream);
+      float ms = 0;
+      if (hipEventSynchronize(e1) != hipSuccess || hipEventElapsedTime(&ms, e0, e1) != hipSuccess) { (void)hipGetLastError(); ms = 1e9f; }
+      if (rep > 0) best = std::min(best, ms * 1000.f);
+    }
+    cand.push_back(p); us.push_back(best);
+    if (std::getenv("BMX_PLACEMENT_DEBUG")) fprintf(stderr, "bmx placement: candidate %d at %p (%llu MB): probe %.2f us\n", k, (void*)p, (unsigned long long)(bytes >> 20), best);
+  }
+  (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+  size_t pick = 0;
+  for (size_t k = 1; k < cand.size(); k++) if (us[k] < us[pick]) pick = k;
+  for (size_t k = 0; k < cand.size(); k++) if (k != pick) (void)hipFree(cand[k]);
+  ctx->placement_tries = (uint32_t)cand.size(); ctx->placement_us_best = us[pick];
+  ctx->placement_us_worst = *std::max_element(us.begin(), us.end());
+  *out = cand[pick];
+  return BMX_OK;
+}
+
 // Rehash into a table for `capacity_rows` rows. Synchronous.
 int grow_table(bmx_ctx* ctx, uint64_t capacity_rows) {
   if (capacity_rows <= ctx->capacity_rows) return BMX_OK;
@@ -325,7 +380,7 @@ int grow_table(bmx_ctx* ctx, uint64_t capacity_rows) {
   const uint64_t nslots = slots_for(capacity_rows, ctx->load_pct);
   if (!nslots) return fail(ctx, BMX_ERR_INVALID, "table would need more than 2^32 slots (slot indices are 32-bit): shard the graph over more contexts");
   Slot* fresh = nullptr;
-  if ((rc = dev_alloc(ctx, &fresh, nslots))) return rc;
+  if ((rc = alloc_table_tuned(ctx, nslots, &fresh))) return rc;
   hipLaunchKernelGGL(k_init_slots, dim3(2048), dim3(256), 0, ctx->stream, fresh, nslots);
   hipLaunchKernelGGL(k_rehash, dim3(2048), dim3(256), 0, ctx->stream, ctx->slots, ctx->nslots, fresh, nslots, &ctx->ds->status);
   hipError_t e = hipGetLastError();
@@ -366,6 +421,13 @@ bool launches_are_serialized() {
   return on("ROCPROF_COUNTER_COLLECTION") || on("HIP_LAUNCH_BLOCKING") || on("AMD_SERIALIZE_KERNEL") || on("BMX_NO_DEFERRED_COMPACTION");
 }
 int flush_pending(bmx_ctx* ctx) {
+  if (ctx->side_last) {
+    // the resolve kernel at the end of this stream waited for the compaction launched on the side stream TWO batches ago only: the last one may still be
+    // running there (it was released when the last probe kernel started, so this one-wave wait is a formality, and it cannot starve anything)
+    hipLaunchKernelGGL(k_seq_wait, dim3(1), dim3(64), 0, ctx->stream, (const unsigned long long*)&ctx->ds->seqw[1], (unsigned long long)ctx->side_last, &ctx->ds->status, ctx->ds->seq_diag);
+    LAUNCHCHK("k_seq_wait");
+    ctx->side_last = ctx->side_prev = 0;
+  }
   if (!ctx->pend.on) return BMX_OK;
   ctx->pend.on = false;
   launch_k3(ctx, ctx->pend, ctx->stream);
@@ -431,9 +493,9 @@ int merge_core(bmx_ctx* ctx, uint64_t n, const uint64_t* id, const uint32_t* fie
     HIPCHK(hipMemsetAsync(ctx->blk_follow, 0, ((size_t)ctx->ws_cap / 256 + 16) * sizeof(uint32_t), ctx->stream));
     ctx->epoch = 1;
   }
-  // this batch's workspace set (parity) and block-summary segment
-  const uint32_t par = (ctx->ws_par ^= 1u);
-  const uint32_t seg = ctx->blk_seg, seg_next = (seg + 1u) % 3u;
+  // this batch's workspace set and block-summary segment
+  const uint32_t par = (ctx->ws_par = (ctx->ws_par + 1u) % bmx_ctx::WS_SETS);
+  const uint32_t seg = ctx->blk_seg, seg_next = (seg + 1u) % bmx_ctx::BLK_SEGS;
   ctx->blk_seg = seg_next;
   uint8_t* wflag = ctx->wflag[par];
   unsigned long long* ctr = ctx->shard_ctr + (size_t)par * CTR_SHARDS * CTR_STRIDE;
@@ -466,7 +528,9 @@ int merge_core(bmx_ctx* ctx, uint64_t n, const uint64_t* id, const uint32_t* fie
     ++ctx->dseq;
     A.started = &ctx->ds->seqw[0]; A.started_val = ctx->dseq;
     if (side_k3) {
-      A.k3_done = &ctx->ds->seqw[1]; A.k3_wait = ctx->pend.seq;
+      // this batch's resolve kernel ends only once the compaction launched on the side stream BEFORE the one that goes there now is done: the next probe
+      // kernel then reuses nothing a compaction still reads (three workspace sets), and that compaction has had two probe kernels' time
+      if (ctx->side_last) { A.k3_done = &ctx->ds->seqw[1]; A.k3_wait = ctx->side_last; }
       if (ctx->pend.Fin.n_notify) {   // the slab set of the batch before is free the moment this probe kernel starts: said there, not under it
         A.notify = ctx->pend.Fin.notify; A.n_notify = ctx->pend.Fin.n_notify; A.notify_value = ctx->pend.Fin.notify_value;
         ctx->pend.Fin.n_notify = 0;
@@ -486,13 +550,18 @@ int merge_core(bmx_ctx* ctx, uint64_t n, const uint64_t* id, const uint32_t* fie
   } else {
     constexpr int NT = 64;    // every wave its own workgroup (profiles/r03_ab_inserts.log)
     const dim3 grid((uint32_t)((n + NT - 1) / NT));
-    if (insert_mode == BMX_INSERT_REFERENCE) {
-      if (unique) hipLaunchKernelGGL((k_probe_apply<AOS, BMX_INSERT_REFERENCE, true, NT>), grid, dim3(NT), 0, ctx->stream, A);
-      else hipLaunchKernelGGL((k_probe_apply<AOS, BMX_INSERT_REFERENCE, false, NT>), grid, dim3(NT), 0, ctx->stream, A);
-    } else {
-      if (unique) hipLaunchKernelGGL((k_probe_apply<AOS, BMX_INSERT_DELTA, true, NT>), grid, dim3(NT), 0, ctx->stream, A);
-      else hipLaunchKernelGGL((k_probe_apply<AOS, BMX_INSERT_DELTA, false, NT>), grid, dim3(NT), 0, ctx->stream, A);
-    }
+    const int kw = ctx->k1_waves;   // resident waves per SIMD the probe kernel may take (8 = all; 6 / 5 leave room for the kernels that run beside it)
+#define BMX_LAUNCH_K1(KERN) do { \
+      if (insert_mode == BMX_INSERT_REFERENCE) { \
+        if (unique) hipLaunchKernelGGL((KERN<AOS, BMX_INSERT_REFERENCE, true, NT>), grid, dim3(NT), 0, ctx->stream, A); \
+        else hipLaunchKernelGGL((KERN<AOS, BMX_INSERT_REFERENCE, false, NT>), grid, dim3(NT), 0, ctx->stream, A); \
+      } else { \
+        if (unique) hipLaunchKernelGGL((KERN<AOS, BMX_INSERT_DELTA, true, NT>), grid, dim3(NT), 0, ctx->stream, A); \
+        else hipLaunchKernelGGL((KERN<AOS, BMX_INSERT_DELTA, false, NT>), grid, dim3(NT), 0, ctx->stream, A); \
+      } } while (0)
+    if (kw == 6) BMX_LAUNCH_K1(k_probe_apply_w6); else if (kw == 5) BMX_LAUNCH_K1(k_probe_apply_w5); else if (kw == 4) BMX_LAUNCH_K1(k_probe_apply_w4);
+    else if (kw == 3) BMX_LAUNCH_K1(k_probe_apply_w3); else BMX_LAUNCH_K1(k_probe_apply);
+#undef BMX_LAUNCH_K1
   }
   LAUNCHCHK("k_probe_apply");
   if (side_k3) {
@@ -500,6 +569,7 @@ int merge_core(bmx_ctx* ctx, uint64_t n, const uint64_t* id, const uint32_t* fie
     hipLaunchKernelGGL(k_seq_wait, dim3(1), dim3(64), 0, ctx->side, (const unsigned long long*)&ctx->ds->seqw[0], (unsigned long long)ctx->dseq, &ctx->ds->status, ctx->ds->seq_diag);
     launch_k3(ctx, ctx->pend, ctx->side);
     hipLaunchKernelGGL(k_seq_signal, dim3(1), dim3(64), 0, ctx->side, &ctx->ds->seqw[1], (unsigned long long)ctx->pend.seq);
+    ctx->side_prev = ctx->side_last; ctx->side_last = ctx->pend.seq;
     ctx->pend.on = false;
     ctx->n_side++;
     LAUNCHCHK("deferred k_compact_winners");
@@ -1068,7 +1138,7 @@ int bmx_create_ex(int device, uint64_t capacity_rows, uint32_t max_load_pct, uin
   const uint64_t nslots = slots_for(capacity_rows, max_load_pct);
   ctx->nslots = nslots;
   int rc;
-  if ((rc = dev_alloc(ctx, &ctx->slots, nslots))) return bail(rc);
+  if ((rc = alloc_table_tuned(ctx, nslots, &ctx->slots))) return bail(rc);
   if ((rc = dev_alloc(ctx, &ctx->ds, 1))) return bail(rc);
   for (int i = 0; i < 2; i++) {
     if ((rc = dev_alloc(ctx, &ctx->stg[i].n_out, 1)) || (rc = dev_alloc(ctx, &ctx->stg[i].stats, 1))) return bail(rc);
@@ -1077,8 +1147,8 @@ int bmx_create_ex(int device, uint64_t capacity_rows, uint32_t max_load_pct, uin
   }
   if ((rc = dev_alloc(ctx, &ctx->block_counts, SEL_MAX_BLOCKS))) return bail(rc);
   if ((rc = dev_alloc(ctx, &ctx->part_counts, PART_MAX_SHARDS * PART_BLOCKS))) return bail(rc);
-  if ((rc = dev_alloc(ctx, &ctx->shard_ctr, 2 * CTR_SHARDS * CTR_STRIDE))) return bail(rc);
-  CR(hipMemsetAsync(ctx->shard_ctr, 0, 2 * CTR_SHARDS * CTR_STRIDE * sizeof(unsigned long long), ctx->stream));
+  if ((rc = dev_alloc(ctx, &ctx->shard_ctr, bmx_ctx::WS_SETS * CTR_SHARDS * CTR_STRIDE))) return bail(rc);
+  CR(hipMemsetAsync(ctx->shard_ctr, 0, bmx_ctx::WS_SETS * CTR_SHARDS * CTR_STRIDE * sizeof(unsigned long long), ctx->stream));
   // the row-count mirror is an optimisation: without mapped host memory the capacity guard simply synchronises as before
   if (hipHostMalloc(reinterpret_cast<void**>(&ctx->host_rows), 2 * sizeof(unsigned long long), hipHostMallocMapped) == hipSuccess) {
     ctx->host_rows[0] = 0; ctx->host_rows[1] = 0;
@@ -1089,6 +1159,7 @@ int bmx_create_ex(int device, uint64_t capacity_rows, uint32_t max_load_pct, uin
   } else { ctx->stg_tails = nullptr; (void)hipGetLastError(); }
   ctx->fixed_capacity = (flags & BMX_CTX_FIXED_CAPACITY) != 0;
   ctx->defer_enabled = !launches_are_serialized();
+  { const char* kw = std::getenv("BMX_K1_WAVES"); if (kw && kw[0] >= '3' && kw[0] <= '8' && kw[0] != '7' && !kw[1]) ctx->k1_waves = kw[0] - '0'; }
   CR(hipMemsetAsync(ctx->ds, 0, sizeof(DevScalars), ctx->stream));
   hipLaunchKernelGGL(k_init_slots, dim3(2048), dim3(256), 0, ctx->stream, ctx->slots, nslots);
   CR(hipGetLastError());
@@ -1106,7 +1177,7 @@ void bmx_destroy(bmx_ctx* ctx) {
   if (ctx->side) { (void)hipStreamSynchronize(ctx->side); (void)hipStreamDestroy(ctx->side); ctx->side = nullptr; }
   for (auto& ix : ctx->indexes) { dev_free(ix.ids); dev_free(ix.v64); dev_free(ix.v32); }
   dev_free(ctx->slots); dev_free(ctx->ds); dev_free(ctx->next); dev_free(ctx->blk_info); dev_free(ctx->blk_follow); dev_free(ctx->shard_ctr);
-  for (int h = 0; h < 2; h++) { dev_free(ctx->wflag[h]); dev_free(ctx->slot_of[h]); dev_free(ctx->fld_ws[h]); }
+  for (uint32_t h = 0; h < bmx_ctx::WS_SETS; h++) { dev_free(ctx->wflag[h]); dev_free(ctx->slot_of[h]); dev_free(ctx->fld_ws[h]); }
   if (ctx->copy_stream) (void)hipStreamSynchronize(ctx->copy_stream);
   for (int i = 0; i < 2; i++) {
     bmx_ctx::Staging& S = ctx->stg[i];
@@ -1617,6 +1688,20 @@ int bmx_get_deferred_counts(bmx_ctx* ctx, uint64_t* deferred, uint64_t* on_side_
   if (!ctx) return fail(nullptr, BMX_ERR_INVALID, "null context");
   if (deferred) *deferred = ctx->n_deferred;
   if (on_side_stream) *on_side_stream = ctx->n_side;
+  return BMX_OK;
+}
+
+int bmx_set_probe_waves(bmx_ctx* ctx, int waves_per_simd) {
+  if (!ctx || waves_per_simd < 3 || waves_per_simd > 8 || waves_per_simd == 7) return fail(ctx, BMX_ERR_INVALID, "bmx_set_probe_waves: 3, 4, 5, 6 or 8");
+  ctx->k1_waves = waves_per_simd;
+  return BMX_OK;
+}
+
+int bmx_get_placement(bmx_ctx* ctx, uint32_t* candidates, float* probe_us_chosen, float* probe_us_slowest) {
+  if (!ctx) return fail(nullptr, BMX_ERR_INVALID, "null context");
+  if (candidates) *candidates = ctx->placement_tries;
+  if (probe_us_chosen) *probe_us_chosen = ctx->placement_us_best;
+  if (probe_us_slowest) *probe_us_slowest = ctx->placement_us_worst;
   return BMX_OK;
 }
 

@@ -237,7 +237,7 @@ __device__ __forceinline__ void decide_and_claim(const MergeArgs& A, const uint3
 // out of the probing waves (LDS-compacted behind a barrier, by the last wave, by a second launch = SURVEY §2.1 K4): profiles/r03_ab_inserts.log —
 // the barrier cost 2-7 us per 1M-delta launch, every split of the creations cost more than it saved.
 template <bool AOS, int MODE, bool UNIQUE, int NT>
-__global__ __launch_bounds__(NT) void k_probe_apply(MergeArgs A) {
+__device__ __forceinline__ void probe_apply_body(const MergeArgs& A) {
   const uint32_t j = blockIdx.x * (uint32_t)NT + threadIdx.x;
   if (A.started && j == 0) __hip_atomic_store(A.started, A.started_val, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   if (A.n_notify && j < A.n_notify && A.notify.p[j]) __hip_atomic_store(A.notify.p[j], A.notify_value, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
@@ -271,6 +271,22 @@ __global__ __launch_bounds__(NT) void k_probe_apply(MergeArgs A) {
     }
   }
 }
+
+template <bool AOS, int MODE, bool UNIQUE, int NT>
+__global__ __launch_bounds__(NT) void k_probe_apply(MergeArgs A) { probe_apply_body<AOS, MODE, UNIQUE, NT>(A); }
+// The same kernel held to at most SIX (FIVE) resident waves per SIMD instead of eight. The probe kernel is bound by memory-side requests in flight (a CU's 64-entry
+// miss queue is full with far fewer waves), so it loses nothing — and the kernels that are meant to run BESIDE it (the deferred compaction, the owner partition of
+// the next batch on the exchange stream: 256-thread workgroups) find wave slots on every CU at once instead of waiting for four of this kernel's one-wave
+// workgroups to retire on the same CU (kernel trace of the sharded rehearsal: k_part_count 58-72 us and the deferred k_compact_winners 75 us beside the full-occupancy
+// kernel, i.e. they finished when it did).
+template <bool AOS, int MODE, bool UNIQUE, int NT>
+__global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(1, 6))) void k_probe_apply_w6(MergeArgs A) { probe_apply_body<AOS, MODE, UNIQUE, NT>(A); }
+template <bool AOS, int MODE, bool UNIQUE, int NT>
+__global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(1, 5))) void k_probe_apply_w5(MergeArgs A) { probe_apply_body<AOS, MODE, UNIQUE, NT>(A); }
+template <bool AOS, int MODE, bool UNIQUE, int NT>
+__global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(1, 4))) void k_probe_apply_w4(MergeArgs A) { probe_apply_body<AOS, MODE, UNIQUE, NT>(A); }
+template <bool AOS, int MODE, bool UNIQUE, int NT>
+__global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(1, 3))) void k_probe_apply_w3(MergeArgs A) { probe_apply_body<AOS, MODE, UNIQUE, NT>(A); }
 
 // Pending pass (duplicate keys only): one lane per delta, so every walker starts at once (the pass is latency bound:
 // few walkers, each a chain of dependent reads). Only the FIRST claimer of a row that got followers does anything:
@@ -540,6 +556,21 @@ __global__ __launch_bounds__(256) void k_selfcheck_tear(uint4* slots, uint32_t n
   }
   if (bad) atomicAdd(torn, bad);
   if (n) atomicAdd(reads, n);
+}
+
+// Placement probe (bmx_create): the probe kernel's request mix — one random 32-byte slot read, one atomic exchange on its head word, one 16-byte store of its
+// (ts,val) half — over an UNINITIALISED table allocation, n threads. Used to rank candidate allocations of the same size (see tune_table_placement in bmx.hip);
+// k_init_slots runs afterwards, so what it scribbles does not matter.
+__global__ __launch_bounds__(64) void k_placement_probe(Slot* slots, uint64_t nslots, uint32_t n, uint32_t salt) {
+  const uint32_t j = blockIdx.x * 64u + threadIdx.x;
+  if (j >= n) return;
+  const uint64_t h = mix64(((uint64_t)salt << 32) | j);
+  Slot* sl = slots + __umul64hi(h, nslots);
+  const uint4* q = reinterpret_cast<const uint4*>(sl);
+  const uint4 lo = q[0], hi = q[1];
+  const uint32_t prev = atomicExch(&sl->head, j);
+  if (((lo.x ^ hi.x ^ prev) & 7u) != 5u)     // (data dependent: the loads and the exchange cannot be dropped; true for seven slots in eight)
+    reinterpret_cast<uint4*>(sl)[1] = make_uint4(j, lo.y, hi.z, prev);
 }
 
 // epoch wrap: forget every claim tag and every creation mark

@@ -142,6 +142,19 @@ int bmx_abi_version(void);
  * needs no counterpart: its writes are single-threaded JS assignments (src/bullet.js:184-201). Outputs may be NULL. */
 int bmx_selfcheck(int device, uint64_t* reads, uint64_t* torn, uint64_t* control_torn);
 int bmx_get_info(bmx_ctx* ctx, bmx_info* out);
+/* Table placement. Where a large table lands in device memory decides ~10 % of the merge kernel's time (the same kernels on the same rows: 68-72 us per
+ * 1M-delta launch on some allocations of a 1.4 GB table, 77-80 us on others made in the same process — for the allocation's lifetime). bmx_create and every
+ * growth therefore allocate a table of >= 256 MB up to four times, time each candidate with the merge kernel's own request mix (2^20 random slot reads, head
+ * exchanges and 16-byte stores; ~0.25 ms per candidate) and keep the fastest (BMX_TABLE_PLACEMENT_TRIES=1 in the environment: take the first). This call
+ * reports what was seen for the current table: number of candidates (0: not tuned), probe time of the chosen and of the slowest one, in us. The reference has
+ * no counterpart (its store is a JS object, src/bullet.js:28). */
+int bmx_get_placement(bmx_ctx* ctx, uint32_t* candidates, float* probe_us_chosen, float* probe_us_slowest);
+/* Resident waves per SIMD the probe kernel may take: 8 (default: all), 6, 5, 4 or 3. The kernel is bound by memory-side requests in flight — a CU's miss
+ * queue is full with far fewer waves — so fewer cost it nothing measurable, and kernels that are meant to run BESIDE it (the owner partition of the next
+ * batch on the exchange stream, the deferred compaction) find wave slots on every CU at once instead of waiting for its one-wave workgroups to retire:
+ * in the sharded pipeline k_part_count runs 17-33 us beside a 5-wave probe kernel and 58-72 us beside the full one (profiles/r04_sharded_timeline.log).
+ * BMX_K1_WAVES in the environment sets the default of new contexts. */
+int bmx_set_probe_waves(bmx_ctx* ctx, int waves_per_simd);
 int bmx_sync(bmx_ctx* ctx);                         /* wait for the stream; returns a sticky device error if any */
 int bmx_set_stream(bmx_ctx* ctx, void* hip_stream); /* run on the caller's hipStream_t (NULL = context's own) */
 void* bmx_get_stream(bmx_ctx* ctx);
