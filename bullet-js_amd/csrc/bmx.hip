@@ -347,9 +347,15 @@ int alloc_table_tuned(bmx_ctx* ctx, uint64_t nslots, Slot** out) {
   hipEvent_t e0 = nullptr, e1 = nullptr;
   if (hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess) { (void)hipGetLastError(); if (e0) (void)hipEventDestroy(e0); return dev_alloc(ctx, out, nslots); }
   constexpr uint32_t PN = 1u << 20;
+  const char* cenv = std::getenv("BMX_TABLE_CONTIGUOUS");
+  const int n_contig = cenv ? std::atoi(cenv) : 0;         // measurement switch: the first n candidates are asked for as physically contiguous memory
   for (int k = 0; k < tries; k++) {
     Slot* p = nullptr;
-    if ((rc = dev_alloc(ctx, &p, nslots))) { if (cand.empty()) { (void)hipEventDestroy(e0); (void)hipEventDestroy(e1); return rc; } break; }
+    if (k < n_contig) {
+      if (hipExtMallocWithFlags(reinterpret_cast<void**>(&p), bytes, hipDeviceMallocContiguous) != hipSuccess) { (void)hipGetLastError(); p = nullptr; }
+      if (std::getenv("BMX_PLACEMENT_DEBUG")) fprintf(stderr, "bmx placement: candidate %d: contiguous allocation %s\n", k, p ? "granted" : "refused");
+    }
+    if (!p && (rc = dev_alloc(ctx, &p, nslots))) { if (cand.empty()) { (void)hipEventDestroy(e0); (void)hipEventDestroy(e1); return rc; } break; }
     float best = 1e30f;
     for (int rep = 0; rep < 4; rep++) {                    // (the first launch on a fresh allocation also pays its page-table walk misses: not counted)
       (void)hipEventRecord(e0, ctx->stream);
