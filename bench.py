@@ -517,7 +517,9 @@ def main(argv=None):
                     "kernel_ms": {k: round(v, 5) for k, v in stage_ms.items()}, "launches_averaged": ncalls,
                     "whole_merge_achieved_GBs": round((56.0 * D_PER_STEP + 20.0 * wavg) / (elapsed / K) / 1e9, 1)}
         total_units = K * D_PER_STEP
-        extra.update({"event_ms_per_step": round(ev_ms / K, 5), "winners_per_step": round(wavg, 1)})
+        extra.update({"event_ms_per_step": round(ev_ms / K, 5), "winners_per_step": round(wavg, 1),
+                      "table_placement": dict(eng.placement(), note="bmx_create allocates a large table several times and keeps the candidate on which the merge kernel's request mix (2^20 random slot reads + exchanges + stores) runs fastest: include/bmx.h bmx_get_placement"),
+                      "deferred_compaction": dict(zip(("merges_deferred", "compactions_on_side_stream"), eng.deferred_counts()))})
         if CONFIG == 5:
             cfg = {"workload": "config 5: streaming sync replay on 1 MI355X, %d x 1M-delta batches (30%% of a batch on R/1000 = %d hot keys, 70%% uniform), steady state over batches %d..%d" %
                    (nb, R_PER_GPU // 1000, W, nb - 1), "resident_rows_per_gpu": R_PER_GPU, "deltas_per_step_per_gpu": D_PER_STEP, "insert_mode": "reference", "sharding": "none"}

@@ -324,11 +324,12 @@ uint64_t slots_for(uint64_t capacity_rows, uint32_t load_pct) {
 
 // Where a table lands matters: the same kernels on the same rows take 68-72 us per 1M-delta launch on some allocations of a 1.4 GB table and 77-80 us on
 // others made in the same process minutes apart — a property of the allocation that stays for its lifetime (profiles/r04_placement_probe.log: six tables alive at
-// once, three passes; which ones are fast changes from run to run). So a large table is allocated up to PLACEMENT_TRIES times, every candidate is timed with
+// once, three passes; which ones are fast changes from run to run). So a large table is allocated up to PLACEMENT_TRIES times (fewer once a clearly faster candidate has turned up), every candidate is timed with
 // the probe kernel's own request mix (k_placement_probe: 2^20 random slot reads + head exchanges + 16-byte stores, best of three launches, ~0.25 ms per
 // candidate), the fastest is kept and the others are freed. Candidates stay allocated while the next one is made (otherwise the allocator hands the same range
 // back); tables too large for that many copies get fewer tries. BMX_TABLE_PLACEMENT_TRIES=1 switches it off. -> the chosen allocation (uninitialised)
-constexpr int PLACEMENT_TRIES = 4;   // (BMX_TABLE_PLACEMENT_TRIES overrides, 1..16)
+constexpr int PLACEMENT_TRIES = 8;   // at most (BMX_TABLE_PLACEMENT_TRIES overrides, 1..16); from the third candidate on the search stops once the best is 7 % faster than the
+                                     // slowest: both kinds of placement have been seen then (profiles/r04_placement_probe.log: fast ones probe at <= 70 us, slow ones at >= 73.8)
 constexpr uint64_t PLACEMENT_MIN_BYTES = 256ull << 20;     // below the Infinity Cache's size a table's lines are served on-die wherever they live
 int alloc_table_tuned(bmx_ctx* ctx, uint64_t nslots, Slot** out) {
   *out = nullptr;
@@ -366,6 +367,7 @@ int alloc_table_tuned(bmx_ctx* ctx, uint64_t nslots, Slot** out) {
       if (rep > 0) best = std::min(best, ms * 1000.f);
     }
     cand.push_back(p); us.push_back(best);
+    if (cand.size() >= 3 && !std::getenv("BMX_TABLE_PLACEMENT_TRIES") && *std::min_element(us.begin(), us.end()) <= 0.93f * *std::max_element(us.begin(), us.end())) tries = k + 1;
     if (std::getenv("BMX_PLACEMENT_DEBUG")) fprintf(stderr, "bmx placement: candidate %d at %p (%llu MB): probe %.2f us\n", k, (void*)p, (unsigned long long)(bytes >> 20), best);
   }
   (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);

@@ -144,7 +144,7 @@ int bmx_selfcheck(int device, uint64_t* reads, uint64_t* torn, uint64_t* control
 int bmx_get_info(bmx_ctx* ctx, bmx_info* out);
 /* Table placement. Where a large table lands in device memory decides ~10 % of the merge kernel's time (the same kernels on the same rows: 68-72 us per
  * 1M-delta launch on some allocations of a 1.4 GB table, 77-80 us on others made in the same process — for the allocation's lifetime). bmx_create and every
- * growth therefore allocate a table of >= 256 MB up to four times, time each candidate with the merge kernel's own request mix (2^20 random slot reads, head
+ * growth therefore allocate a table of >= 256 MB several times (at most eight; fewer once a clearly faster candidate has turned up), time each candidate with the merge kernel's own request mix (2^20 random slot reads, head
  * exchanges and 16-byte stores; ~0.25 ms per candidate) and keep the fastest (BMX_TABLE_PLACEMENT_TRIES=1 in the environment: take the first). This call
  * reports what was seen for the current table: number of candidates (0: not tuned), probe time of the chosen and of the slowest one, in us. The reference has
  * no counterpart (its store is a JS object, src/bullet.js:28). */
