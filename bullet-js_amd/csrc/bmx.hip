@@ -1180,7 +1180,8 @@ int bmx_create_ex(int device, uint64_t capacity_rows, uint32_t max_load_pct, uin
 void bmx_destroy(bmx_ctx* ctx) {
   if (!ctx) return;
   (void)hipSetDevice(ctx->device);
-  ctx->pend.on = false;     // a compaction that was only recorded is dropped: nobody can read its outputs any more
+  (void)flush_pending(ctx); // a compaction that was only recorded writes the CALLER's winner list and count: it runs before anything is freed
+  (void)hipGetLastError();
   if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
   if (ctx->side) { (void)hipStreamSynchronize(ctx->side); (void)hipStreamDestroy(ctx->side); ctx->side = nullptr; }
   for (auto& ix : ctx->indexes) { dev_free(ix.ids); dev_free(ix.v64); dev_free(ix.v32); }

@@ -214,7 +214,8 @@ int bmx_merge_records(bmx_ctx* ctx, uint64_t n, const bmx_delta_rec* recs, int i
  * (k_compact_winners -> applied_idx / n_applied / stats) and reads nothing but per-batch workspace. When batch b + 1 follows batch b directly,
  * the compaction of b runs on a second, high-priority stream UNDER the probe kernel of b + 1 instead of in front of it (ordering by two words in
  * device memory, no event markers); with any other bmx_* call in between it runs on the context's stream as before. Consequences for a caller:
- *   - outputs of a device merge are valid after bmx_sync() (as ever) or after ANY other call on the context other than another device merge;
+ *   - outputs of a device merge are valid after bmx_sync() (as ever) or after ANY other call on the context other than another device merge
+ *     (bmx_destroy included: it launches a compaction that was only recorded and waits for it);
  *   - a caller that enqueues its own work on the context's stream (bmx_set_stream) and reads applied_idx / n_applied / stats there without
  *     bmx_sync() calls bmx_merge_fence() first: it only enqueues, and orders the stream behind every compaction;
  *   - bmx_set_deferred_compaction(ctx, 0) restores strict stream order for every launch (the communicator does this for its shards).

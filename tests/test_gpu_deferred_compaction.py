@@ -131,6 +131,15 @@ def test_anything_between_two_merges_sees_the_finished_batch():
                 e.sync()
                 _, ow2 = o.merge_batch(*d2)
                 assert np.array_equal(ap2[:len(ow2)].cpu().numpy().view(np.uint32), ow2)
+            elif what == 7 and b == 7:                     # the table grows (every row re-inserted into a new table) while a compaction is only recorded
+                e.reserve(4 * (R + 40 * D))
+            elif what == 7:                                # rows decided elsewhere, stored as given, and the index dropped and built again
+                k = rng.integers(0, R, 2000)
+                pid, pf = res[0][k], res[1][k]
+                pts = np.full(len(k), 9_000_000 + b, dtype=np.int64); pv = rng.integers(-1000, 1000, len(k)).astype(np.int64)
+                _, first = np.unique(pid, return_index=True)     # one row per key
+                e.put_rows(pid[first], pf[first], pts[first], pv[first]); o.put_rows(pid[first], pf[first], pts[first], pv[first])
+                e.index_drop(F); e.index_build(F)
             e.sync()
             na = int(n_applied.item()) if what not in (5, 6) else len(ow)
             assert np.array_equal(applied[:len(ow)].cpu().numpy().view(np.uint32), ow), b
@@ -223,3 +232,26 @@ def test_host_batches_work_when_the_page_locked_buffers_cannot_be_had():
             assert rows_digest(*e.dump_rows()) == o.digest()
     finally:
         del os.environ["BMX_TEST_FAIL_PINNED"]
+
+
+def test_a_context_destroyed_with_a_compaction_pending_finishes_it_first():
+    """bmx_destroy right behind a deferring merge: the recorded compaction still writes the caller's winner list and count (they are the caller's
+    memory, not the context's), and nothing of the context is freed underneath a kernel"""
+    dev = torch.device("cuda", 0)
+    R, D = 200_000, 100_000
+    res = synth.big_resident(R, seed=91)
+    o = Oracle(); o.load_rows(*res)
+    d = synth.big_deltas(D, R, seed=92, insert_pct=10, hot_pct=10, hot_keys=30, unique=False, batch=0, drift=30_000)
+    dd = _dev(d, dev)
+    applied = torch.zeros(D, dtype=torch.int32, device=dev)
+    n_applied = torch.zeros(1, dtype=torch.int64, device=dev)
+    torch.cuda.synchronize()
+    e = bmx.Engine(2 * (R + D))
+    e.load_rows(*res)
+    e.merge_batch_dev(D, *dd, INSERT_REFERENCE, applied=applied, n_applied=n_applied)
+    assert e.deferred_counts()[0] == 1
+    e.close()
+    torch.cuda.synchronize()
+    _, ow = o.merge_batch(*d)
+    assert int(n_applied.item()) == len(ow)
+    assert np.array_equal(applied[:len(ow)].cpu().numpy().view(np.uint32), ow)
