@@ -86,31 +86,53 @@ class DeviceGraph {
 }
 
 /*
- * DeviceVcTable — N4 (SURVEY §8(f)): rows with a K-writer vector clock (a bmx_vc). `writers` fixes the component order;
+ * DeviceVcTable — N4 (SURVEY §8(f)): rows with a K-writer vector clock (a bmx_vc). `writers` fixes the component order of the writers known up
+ * front; opts.maxWriters (<= 8) makes the table that wide and lets unknown writers take the free components as clocks name them;
  * `local` is this peer's id (the reference stores clock {local: 2} for a first write). Host typed arrays in and out.
  */
+/* writer id -> component of the table. With room left (opts.maxWriters > writers given) a writer nobody has named before takes the next free
+ * component the first time a clock names it — a gossip mesh learns its peers as it goes (src/bullet-network.js:404-418), the table does not have to be
+ * told them up front; once all components are taken, clocks naming yet another writer stay on the host (GpuCRT.hostOnlyInfo() counts them).
+ * Integer-like ids never get one: a JS object moves such keys to the front whatever the insertion order, so the key ORDER of the reference's merged
+ * clocks (part of their identity: src/bullet-crt.js:200-203) would not be the order the device tracks. */
+const NUMERIC_ID = /^(0|[1-9][0-9]*)$/;
+class WriterIndex extends Map {
+  constructor(table) { super(); this._t = table; }
+  get(w) {
+    let k = super.get(w);
+    if (k === undefined) {
+      const t = this._t;
+      if (t.writers.length < t.K && typeof w === "string" && w !== "" && !NUMERIC_ID.test(w)) { k = t.writers.length; t.writers.push(w); super.set(w, k); }
+    }
+    return k;
+  }
+}
+
 class DeviceVcTable {
   /** opts: { device, capacityRows | vcCapacityRows, shards: n (logical shards on one GPU) | devices: [..] (one table per GPU) } — with more than one
    *  table, rows are owned by bmx_owner_of(node id): a batch is split on the host in batch order (a key never straddles tables, so the
    *  order-dependent outcome of concurrent clocks is the single-table outcome) and flags / updated indices come back in the caller's index space. */
   constructor(writers, local, opts = {}) {
     this.native = requireNative();
-    if (!Array.isArray(writers) || writers.length < 1 || writers.length > this.native.VC_MAX_WRITERS || writers.indexOf(local) < 0) {
+    const maxW = opts.maxWriters === undefined ? 0 : opts.maxWriters | 0;
+    if (!Array.isArray(writers) || writers.length < 1 || writers.length > this.native.VC_MAX_WRITERS || writers.indexOf(local) < 0 ||
+        (maxW !== 0 && (maxW < writers.length || maxW > this.native.VC_MAX_WRITERS))) {
       const err = new Error("bmx: vector-clock mode needs 1.." + this.native.VC_MAX_WRITERS + " writer ids that include this peer's id");
       err.code = "BMX_BAD_WRITERS";
       throw err;
     }
-    if (writers.some((w) => typeof w !== "string" || /^(0|[1-9][0-9]*)$/.test(w)) || new Set(writers).size !== writers.length) {
+    if (writers.some((w) => typeof w !== "string" || w === "" || NUMERIC_ID.test(w)) || new Set(writers).size !== writers.length) {
       // an integer-like key is moved to the front of a JS object whatever the insertion order: the key ORDER of the reference's merged clocks
       // (part of their identity: src/bullet-crt.js:200-203) would not be the insertion order the device tracks
       const err = new Error("bmx: vector-clock mode needs distinct, non-numeric string writer ids");
       err.code = "BMX_BAD_WRITERS";
       throw err;
     }
-    this.writers = writers.slice();
-    this.K = writers.length;
+    this.writers = writers.slice();                 // grows up to K when opts.maxWriters leaves room (WriterIndex)
+    this.K = maxW || writers.length;
     this.local = writers.indexOf(local);
-    this.writerIndex = new Map(writers.map((w, k) => [w, k]));
+    this.writerIndex = new WriterIndex(this);
+    writers.forEach((w, k) => this.writerIndex.set(w, k));
     const devs = Array.isArray(opts.devices) && opts.devices.length ? opts.devices.slice() : new Array(Math.max(1, opts.shards | 0)).fill(opts.device || 0);
     const cap = opts.vcCapacityRows || opts.capacityRows || (1 << 16);
     this.handles = devs.map((d) => this.native.vcCreate(d, Math.max(1024, Math.ceil(cap / devs.length)), this.K, this.local));

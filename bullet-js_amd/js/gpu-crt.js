@@ -135,7 +135,10 @@ class GpuCRT {
    * @param {object} bullet  the Bullet instance (needs .id, .meta, ._getData)
    * @param {object} [opts]  { graph: DeviceGraph (shared with GpuQuery), device, capacityRows, writer,
    *                           writers: [ids] — N4: clocks may name any of these (<= 8) writers, this peer's id among them, in any order
-   *                           (general vector clocks): the nodes' clocks live in the device's vector-clock table }
+   *                           (general vector clocks): the nodes' clocks live in the device's vector-clock table;
+   *                           writers: "auto" (= [bullet.id] + maxWriters: 8), or maxWriters: n next to a list — the table is n writers wide and a
+   *                           writer nobody named before takes a free component when a clock first names it (a mesh learns its peers as it
+   *                           goes); from the (n + 1)-th distinct writer on, clocks naming it keep their paths on the host: hostOnlyInfo() }
    */
   constructor(bullet, opts = {}) {
     this.bullet = bullet;
@@ -143,6 +146,7 @@ class GpuCRT {
     this._nLazy = 0;                // paths whose vectorClocks entry is only marked (P_CLOCK_*)
     this._nFalsy = 0;               // paths known to hold a falsy value (P_FALSY)
     this.compare = threeWay;
+    if (opts.writers === "auto") opts = Object.assign({}, opts, { writers: [bullet.id], maxWriters: opts.maxWriters || 8 });
     this._opts = opts;
     this._graph = opts.graph || null;
     this._apiClocks = new Set();    // paths whose clock the public helpers touched before any write gave them a meta entry (entryEligible)
@@ -210,7 +214,11 @@ class GpuCRT {
   _clearHostOnly(path) { this._hostOnly.delete(path); }
   /** How much of the graph the device cannot resolve at the moment: paths whose clock names a writer outside the device table (more than 8 peers
    *  in a gossip mesh, src/bullet-network.js:404-418), or that hold a string; entries on them are resolved by the host path, one by one. */
-  hostOnlyInfo() { return { hostOnlyPaths: this._hostOnly.size, marked: this.hostOnlyPaths, integerPaths: this._nIntPaths }; }
+  hostOnlyInfo() {
+    const o = { hostOnlyPaths: this._hostOnly.size, marked: this.hostOnlyPaths, integerPaths: this._nIntPaths };
+    if (this._opts.writers) { o.writers = this._vc ? this._vc.writers.slice() : this._opts.writers.slice(); o.writerSlots = this._vc ? this._vc.K : (this._opts.maxWriters || this._opts.writers.length); }
+    return o;
+  }
 
   /* ---------------------------------------------------------------- clock bookkeeping (host) */
   setCompare(fn) { this.compare = fn; return this; }
@@ -900,7 +908,7 @@ class GpuCRT {
     }
     return this._vc;
   }
-  _vcComps() { return this._vcScratch || (this._vcScratch = new Uint32Array(this._opts.writers.length)); }
+  _vcComps() { return this._vcScratch || (this._vcScratch = new Uint32Array(this._vc ? this._vc.K : (this._opts.maxWriters || this._opts.writers.length))); }
 
   /* stored clock of a device row as the object the reference would hold: the row's counters under the keys its key set names, in that order */
   _clockObject(comps, off, keyset) {

@@ -648,6 +648,53 @@ for (const [name, shards] of [["g11_vc_keysets_2k.json", 1], ["g11_vc_keysets_ho
   b.close();
 }
 
+/* N4 (d): the same differential test with NOBODY named up front (writers: "auto"): the table is eight writers wide, this peer holds the first component and
+ * every other writer takes a free one when a clock first names it. Ten writers send: the eight seen first are the device's, clocks naming the ninth and
+ * tenth keep their paths on the host (hostOnlyInfo), and store, clocks (key order included) and the device's clock rows equal the host resolver's. */
+{
+  const POOL = ["w", "p1", "p2", "p3", "p4", "p5", "p6", "p7", "p8", "p9"];
+  const b = new MiniBullet("w");
+  const { crt, sync } = attach(b, { writers: "auto", capacityRows: 256, batchSync: {} });
+  const twinB = new MiniBullet("w");
+  twinB.crt = new GpuCRT(twinB);
+  const rng = gen.xorshift32(4242 + STRESS_SALT);
+  const ordered = (c) => Object.keys(c).map((w) => [w, c[w]]);
+  for (let round = 0; round < 3; round++) {
+    const live = Math.min(POOL.length, 4 + 3 * round);                 // the mesh grows: 4, 7, 10 writers are heard of
+    const randClock = () => { const c = {}; const n = rng() % 4; for (let x = 0; x < n; x++) c[POOL[rng() % live]] = rng() % 4; return c; };
+    const entries = [];
+    for (let j = 0; j < 1200; j++) {
+      const path = "au/n" + (rng() % 200);
+      const u = rng() % 100;
+      if (u < 3) entries.push({ path, data: rng() % 7, vectorClock: randClock() });
+      else if (u < 4) entries.push({ path, deleted: true, vectorClock: randClock() });
+      else entries.push({ path, data: rng() % 3 ? { hits: (rng() % 5) - 2, level: rng() % 3 } : { hits: (rng() % 5) - 2, tag: "t" + (rng() % 3) }, vectorClock: randClock() });
+    }
+    for (const e of JSON.parse(JSON.stringify(entries))) {
+      if (e.deleted) twinB.setData(e.path, null, false);
+      else twinB.setData(e.path, typeof e.data === "object" && e.data !== null ? Object.assign({}, e.data, { __fromNetwork: true, __vectorClock: e.vectorClock }) : e.data, false);
+    }
+    sync.processSyncEntries(JSON.parse(JSON.stringify(entries)), "peer-1");
+    assert.deepStrictEqual(JSON.parse(JSON.stringify(b.store)), JSON.parse(JSON.stringify(twinB.store)), "auto writers: store after chunk " + round);
+    const ps = Object.keys(twinB.meta).sort();
+    assert.deepStrictEqual(Object.keys(b.meta).sort(), ps);
+    for (const p of ps) assert.deepStrictEqual(ordered(b.meta[p].vectorClock), ordered(twinB.meta[p].vectorClock), "auto writers: clock of " + p + " after chunk " + round);
+    const known = crt.hostOnlyInfo().writers;
+    const held = ps.filter((p) => Object.keys(twinB.meta[p].vectorClock).every((w) => known.includes(w)) && !crt._hostOnly.has(p));
+    crt.vcLookup(held).forEach((c, i) => assert.deepStrictEqual(c && ordered(c), ordered(twinB.meta[held[i]].vectorClock), "auto writers: device clock of " + held[i]));
+    checks += 2 * ps.length;
+  }
+  const info = crt.hostOnlyInfo();
+  assert.strictEqual(info.writerSlots, 8);
+  assert.strictEqual(info.writers.length, 8, JSON.stringify(info));
+  assert.strictEqual(info.writers[0], "w");
+  assert.ok(info.hostOnlyPaths > 0 && info.marked >= info.hostOnlyPaths, JSON.stringify(info));   // the ninth and tenth writer
+  assert.ok(sync.stats.deviceEntries > 2000 && sync.stats.hostEntries > 100, JSON.stringify(sync.stats));
+  assert.throws(() => new GpuCRT(new MiniBullet("w"), { writers: ["w"], maxWriters: 9 }).vcTable, (e) => e.code === "BMX_BAD_WRITERS");
+  checks += 5;
+  b.close();
+}
+
 /* N2 (stress): the same differential test in scalar mode — batch adapter on the GPU against the host resolver applied entry by entry: 3 chunks of 2000 entries
  * on 250 nodes under clocks {w: 0..7} (many ties), objects with integer and string fields, integer and string primitives (local writes in the reference's
  * loop: refused ones still move the clock), deletions, two-writer clocks (host-only paths), with and without put batching. Store, clocks, sources and the device's
