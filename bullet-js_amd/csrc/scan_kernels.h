@@ -226,6 +226,13 @@ struct EmitIds {  // index position -> node id (bounded by cap)
   }
   __device__ __forceinline__ uint64_t load1(uint64_t row) const { return ids[row]; }
   __device__ __forceinline__ void put(uint64_t pos, uint64_t id) const { if (out && pos < cap) out[pos] = id; }
+  __device__ __forceinline__ uint32_t odd(uint64_t pos) const { return (uint32_t)((reinterpret_cast<uintptr_t>(out + pos) >> 3) & 1u); }
+  __device__ __forceinline__ void put2(uint64_t pos, uint64_t a, uint64_t b) const {       // out[pos], out[pos + 1]; &out[pos] is 16-byte aligned (odd(pos) == 0): one store
+    typedef unsigned long long u64x2_t __attribute__((ext_vector_type(2)));
+    if (!out) return;
+    if (pos + 1 < cap) { u64x2_t v; v.x = a; v.y = b; *reinterpret_cast<u64x2_t*>(out + pos) = v; }
+    else if (pos < cap) out[pos] = a;
+  }
 };
 struct EmitPos {  // index position itself (u32, bounded by cap): no read of the id column — the caller maps positions to whatever it mirrors per index row
   static constexpr bool STREAMABLE = false;
@@ -235,6 +242,8 @@ struct EmitPos {  // index position itself (u32, bounded by cap): no read of the
   __device__ __forceinline__ void load2(uint64_t, uint64_t&, uint64_t&) const {}
   __device__ __forceinline__ uint64_t load1(uint64_t) const { return 0; }
   __device__ __forceinline__ void put(uint64_t, uint64_t) const {}
+  __device__ __forceinline__ void put2(uint64_t, uint64_t, uint64_t) const {}
+  __device__ __forceinline__ uint32_t odd(uint64_t) const { return 0; }
 };
 struct FinishCount {  // total -> *n_out (device), optional
   unsigned long long* n_out;

@@ -121,24 +121,29 @@ __global__ __launch_bounds__(SEL_THREADS) void k_sel_write(Pred P, Emit Em, Fini
 // communication between workgroups, any column size, deterministic element order.
 constexpr uint32_t SCAN_BLOCK_ELEMS = 8192;   // elements per block in both passes = 256 mask words
 constexpr uint32_t SCAN_SUB8_BLOCKS = 2048;   // beyond this many blocks (16.78M rows) the emit pass takes eight blocks per workgroup
-// From this many matches in an 8192-row block (37.5 %) the id output STREAMS the block's 64 KB of the id column (16 bytes per lane, coalesced) instead of
-// gathering one id per match. Measured in one process on one index (bench_micro/scan_stream_ab.py, profiles/r04_scan_stream_ab.log, 100M rows, whole scan):
-// 50 % of the rows 334 us streamed against 366 gathered, 100 % 418 against 526 — but 20 % 295 against 281 and 10 % 280 against 222: the gather touches
-// most of the lines from 10 % on (81 %, profiles/traffic_scan.json) yet still moves less, and this kernel's stream only reaches ~4 TB/s (a block's mask
-// load, its rank scan and its stream run one after the other in a workgroup), so the switch sits where the stream wins, not where the traffic curves cross.
-constexpr uint32_t SCAN_STREAM_MIN = 3072;
+// From this many matches in an 8192-row block (29 %) the id output STREAMS the block's 64 KB of the id column (16 bytes per lane, coalesced) instead of
+// gathering one id per match, packs the matches in LDS and writes them as 16-byte stores. Measured in one process on one index
+// (bench_micro/scan_stream_ab.py, profiles/r04_scan_stream_ab.log, 100M rows, whole scan, two boxes): 20 % of the rows 266 / 286 us streamed against
+// 262 / 275 gathered, 50 % 315 / 328 against 338 / 362, 100 % 372 against 514-531 — but 10 % 245-269 against 217-220: the gather touches most of the lines
+// from 10 % on (81 %, profiles/traffic_scan.json) yet still moves less than the whole column, so the switch sits where the stream wins, not where the
+// traffic curves cross. (The first form of the round stored each lane's matches with 8-byte stores straight from registers: 334 us at 50 %, 418 at
+// 100 %, and won only from 40 %.)
+constexpr uint32_t SCAN_STREAM_MIN = 2400;
 
 // One 8192-row block of the id output, streamed (Emit::STREAMABLE): wave w takes rows [2048 w, 2048 (w + 1)) = the 64 mask words its own lanes
 // hold (thread t owns word t), 128 rows per step, two consecutive ids (16 B) per lane. The four mask words of a step and the rank in front of
-// them come from the lanes that own them (readlane: no LDS, no barrier); a lane's rank = that base + the set bits below its two. `r` = exclusive
-// rank of the thread's own word inside the block, `pos0` = rank of the block's first match in the whole answer.
+// them come from the lanes that own them (readlane: no barrier); a lane's rank = that base + the set bits below its two. `r` = exclusive
+// rank of the thread's own word inside the block, `pos0` = rank of the block's first match in the whole answer. Every 512 rows the wave's matches,
+// packed in rank order in ITS 4 KB of LDS (`stg`; nobody else touches it: wave-level ordering only), go out as 16-byte stores.
 template <class Emit>
-__device__ __forceinline__ void scan_emit_stream_block(const Emit& Em, uint32_t mk, uint32_t r, uint64_t pos0, uint64_t block_row0, uint64_t n) {
+__device__ __forceinline__ void scan_emit_stream_block(const Emit& Em, uint32_t mk, uint32_t r, uint64_t pos0, uint64_t block_row0, uint64_t n, uint64_t* stg) {
   const uint32_t lane = threadIdx.x & 63u, w = threadIdx.x >> 6;
   const uint64_t row_w = block_row0 + (uint64_t)w * 2048u + 2u * lane;
   const uint32_t sub = lane >> 4, sh = 2u * (lane & 15u);          // which of the step's four words holds this lane's two rows, and where
   const bool whole = block_row0 + SCAN_BLOCK_ELEMS <= n;             // (uniform) every row of the block exists: loads need no guard
   constexpr int U = 8;                                                // eight 16-byte loads in flight per lane before the first is used
+  constexpr int F = 4;                                                // steps (of 128 rows) per flush of the wave's LDS
+  const uint32_t r_end = (uint32_t)__builtin_amdgcn_readlane((int)r, 63) + (uint32_t)__popc((uint32_t)__builtin_amdgcn_readlane((int)mk, 63));   // rank behind the wave's last row
 #pragma unroll 1
   for (uint32_t i0 = 0; i0 < 16; i0 += U) {
     uint64_t a[U], b[U];
@@ -153,18 +158,36 @@ __device__ __forceinline__ void scan_emit_stream_block(const Emit& Em, uint32_t 
         if (row + 2 <= n) Em.load2(row, a[u], b[u]); else if (row < n) a[u] = Em.load1(row);
       }
     }
+    // the matches of 512 rows at a time are packed into the wave's 4 KB of LDS in rank order ...
 #pragma unroll
-    for (int u = 0; u < U; u++) {
-      const uint32_t i = i0 + (uint32_t)u;
-      const uint32_t w0 = (uint32_t)__builtin_amdgcn_readlane((int)mk, (int)(4 * i)), w1 = (uint32_t)__builtin_amdgcn_readlane((int)mk, (int)(4 * i + 1));
-      const uint32_t w2 = (uint32_t)__builtin_amdgcn_readlane((int)mk, (int)(4 * i + 2)), w3 = (uint32_t)__builtin_amdgcn_readlane((int)mk, (int)(4 * i + 3));
-      const uint32_t rb = (uint32_t)__builtin_amdgcn_readlane((int)r, (int)(4 * i));
-      const uint32_t mine = sub == 0 ? w0 : (sub == 1 ? w1 : (sub == 2 ? w2 : w3));
-      const uint32_t before = (sub > 0 ? __popc(w0) : 0u) + (sub > 1 ? __popc(w1) : 0u) + (sub > 2 ? __popc(w2) : 0u) + __popc(mine & ((1u << sh) - 1u));
-      const uint32_t bits = (mine >> sh) & 3u;
-      const uint64_t pos = pos0 + rb + before;
-      if (bits & 1u) Em.put(pos, a[u]);
-      if (bits & 2u) Em.put(pos + (bits & 1u), b[u]);
+    for (int h = 0; h < U; h += F) {
+      const uint32_t ih = i0 + (uint32_t)h;
+      const uint32_t rb0 = (uint32_t)__builtin_amdgcn_readlane((int)r, (int)(4 * ih));
+#pragma unroll
+      for (int u = h; u < h + F; u++) {
+        const uint32_t i = i0 + (uint32_t)u;
+        const uint32_t w0 = (uint32_t)__builtin_amdgcn_readlane((int)mk, (int)(4 * i)), w1 = (uint32_t)__builtin_amdgcn_readlane((int)mk, (int)(4 * i + 1));
+        const uint32_t w2 = (uint32_t)__builtin_amdgcn_readlane((int)mk, (int)(4 * i + 2)), w3 = (uint32_t)__builtin_amdgcn_readlane((int)mk, (int)(4 * i + 3));
+        const uint32_t rb = (uint32_t)__builtin_amdgcn_readlane((int)r, (int)(4 * i));
+        const uint32_t mine = sub == 0 ? w0 : (sub == 1 ? w1 : (sub == 2 ? w2 : w3));
+        const uint32_t before = (sub > 0 ? __popc(w0) : 0u) + (sub > 1 ? __popc(w1) : 0u) + (sub > 2 ? __popc(w2) : 0u) + __popc(mine & ((1u << sh) - 1u));
+        const uint32_t bits = (mine >> sh) & 3u;
+        const uint32_t loc = rb - rb0 + before;
+        if (bits & 1u) stg[loc] = a[u];
+        if (bits & 2u) stg[loc + (bits & 1u)] = b[u];
+      }
+      // ... and leave it as 16-byte stores, consecutive lanes on consecutive pairs (a first id in the upper half of a 16-byte unit goes on its own)
+      const uint32_t T = (ih + F < 16 ? (uint32_t)__builtin_amdgcn_readlane((int)r, (int)(4 * ((ih + F) & 15u))) : r_end) - rb0;
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      const uint64_t p0 = pos0 + rb0;
+      const uint32_t head = T ? Em.odd(p0) : 0u;
+      if (head && lane == 0) Em.put(p0, stg[0]);
+      const uint32_t rest = T - head, npairs = rest >> 1;
+      for (uint32_t q = lane; q < npairs; q += 64) { const uint32_t e = head + 2u * q; Em.put2(p0 + e, stg[e], stg[e + 1]); }
+      if ((rest & 1u) && lane == 1) Em.put(p0 + T - 1, stg[T - 1]);
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
     }
   }
 }
@@ -207,7 +230,9 @@ template <class Emit, class Finish, int SUB>
 __global__ __launch_bounds__(SEL_THREADS) void k_scan_emit(const uint32_t* __restrict__ mask_words, const uint32_t* __restrict__ counts,
                                                             uint64_t n, uint32_t nblocks, Emit Em, Finish Fin) {
   __shared__ uint32_t wsum[4];
-  __shared__ uint16_t loc[SCAN_BLOCK_ELEMS];   // block-local row offsets of the matches, in rank order (16 KB)
+  // block-local row offsets of the matches, in rank order (16 KB) — or, while a dense block streams, the packed ids of 512 rows per wave (4 x 4 KB)
+  __shared__ __attribute__((aligned(16))) unsigned char lds_raw[2 * SCAN_BLOCK_ELEMS];
+  uint16_t* loc = reinterpret_cast<uint16_t*>(lds_raw);
   const uint32_t b0 = blockIdx.x * (uint32_t)SUB;
   uint32_t offset;
   {
@@ -251,7 +276,7 @@ __global__ __launch_bounds__(SEL_THREADS) void k_scan_emit(const uint32_t* __res
     uint32_t tot;
     uint32_t r = block_excl_scan((uint32_t)__popc(mk), tot, wsum);
     if (Emit::STREAMABLE && tot >= Em.stream_from()) {      // (uniform over the workgroup)
-      scan_emit_stream_block(Em, mk, r, running, (uint64_t)blk * SCAN_BLOCK_ELEMS, n);
+      scan_emit_stream_block(Em, mk, r, running, (uint64_t)blk * SCAN_BLOCK_ELEMS, n, reinterpret_cast<uint64_t*>(lds_raw) + (threadIdx.x >> 6) * 512u);
       running += tot;
       continue;
     }

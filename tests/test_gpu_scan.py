@@ -154,9 +154,10 @@ def test_large_column_scans_match_numpy(wide):
         assert len(col_ids) == R and np.array_equal(np.sort(col_ids), np.sort(ids))
         # selectivity: 0.1 % and 10 % (fast path everywhere), 12.5 % (workgroups on both sides of the 8192-match limit), 20 % and 50 % (fall-through),
         # nothing, everything
-        # ... and around 37.5 % (3072 matches per 8192-row block, SCAN_STREAM_MIN): from there on a block's ids are STREAMED from the id column instead of
-        # gathered — 36 % (gather everywhere), 37.4 % / 37.6 % (blocks on both sides of the switch inside one workgroup), 39 % (streamed almost everywhere)
-        for lo, hi in [(42, 42), (100, 199), (100, 224), (300, 499), (0, 499), (2000, 3000), (-5, 5000), (100, 459), (100, 473), (100, 475), (100, 489)]:
+        # ... and around 29.3 % (2400 matches per 8192-row block, SCAN_STREAM_MIN): from there on a block's ids are STREAMED from the id column instead of
+        # gathered — 28 % (gather everywhere), 29.2 % / 29.4 % (blocks on both sides of the switch inside one workgroup), 31 % and more (streamed
+        # almost everywhere; every wave's packed matches leave LDS as 16-byte stores, odd first ranks included)
+        for lo, hi in [(42, 42), (100, 199), (100, 224), (300, 499), (0, 499), (2000, 3000), (-5, 5000), (100, 379), (100, 391), (100, 393), (100, 409), (100, 459), (100, 489)]:
             want = _expected_ids(ids, vals, lo << sh, hi << sh)
             got = e.scan_range(f, lo << sh, hi << sh)
             assert len(got) == len(want), (wide, lo, hi, len(got), len(want))
@@ -168,6 +169,20 @@ def test_large_column_scans_match_numpy(wide):
         # truncated outputs keep the full count
         got = e.scan_range(f, 0, 499 << sh, cap=1000); pos = e.scan_range_pos(f, 0, 499 << sh, cap=1000)
         assert len(got) == 1000 and np.array_equal(col_ids[pos], got)
+        # a device output buffer that starts in the UPPER half of a 16-byte unit (the streamed blocks pair their stores by address, not by rank),
+        # truncated in the middle of a streamed block
+        import torch
+        dev = torch.device("cuda", 0)
+        want = e.scan_range(f, 0, 499 << sh)
+        buf = torch.zeros(len(want) + 8, dtype=torch.int64, device=dev); n_out = torch.zeros(1, dtype=torch.int64, device=dev)
+        torch.cuda.synchronize()
+        for off, cap in ((1, len(want)), (0, len(want)), (1, 123_457), (2, 123_456)):
+            buf.zero_(); torch.cuda.synchronize()
+            e.scan_range_dev(f, 0, 499 << sh, buf[off:], cap, n_out)
+            e.sync()
+            assert int(n_out.item()) == len(want)
+            assert np.array_equal(buf[off:off + cap].cpu().numpy().view(np.uint64), want[:cap]), (wide, off, cap)
+            assert int(buf[off + cap:].abs().sum().item()) == 0 and (off == 0 or int(buf[:off].abs().sum().item()) == 0), "nothing outside [0, cap) is written"
 
 
 def test_positions_on_small_and_maintained_indexes():
