@@ -558,7 +558,7 @@ def main(argv=None):
         sg.ops.sync(); torch.cuda.synchronize(); dist.barrier()
         t0 = time.perf_counter()
         if os.environ.get("BMX_BENCH_HOSTPROF"):      # where the host's enqueue time goes (stderr): wall time inside each call
-            acc = {}
+            acc, each = {}, {}
 
             def timed(obj, name):
                 fn = getattr(obj, name)
@@ -566,14 +566,21 @@ def main(argv=None):
                 def w(*a, **k):
                     t = time.perf_counter()
                     r = fn(*a, **k)
-                    acc[name] = acc.get(name, 0.0) + time.perf_counter() - t
+                    dt = time.perf_counter() - t
+                    acc[name] = acc.get(name, 0.0) + dt
+                    each.setdefault(name, []).append(dt)
                     return r
                 setattr(obj, name, w)
             for nm in ("partition_slabs", "partition_slabs_on_comm", "merge_records", "signal", "wait_seq"):
                 timed(sg.ops, nm)
             timed(dist, "all_to_all_single")
+            if sg.exchange == "direct":       # the direct exchange's three calls per step
+                timed(sg.ops.pe, "partition_scatter_raw"); timed(sg.ops.e, "merge_tail_wait"); timed(sg.ops.e, "merge_records_after")
+            ttot = time.perf_counter()
             run(W, nb)
+            acc["(whole loop)"] = time.perf_counter() - ttot
             print("host us/step: " + ", ".join("%s %.1f" % (k, v / K * 1e6) for k, v in sorted(acc.items())), file=sys.stderr)
+            print("host us per call (median / max): " + ", ".join("%s %.1f / %.1f" % (k, float(np.median(v)) * 1e6, max(v) * 1e6) for k, v in sorted(each.items())), file=sys.stderr)
         else:
             run(W, nb)
         t_enq = time.perf_counter() - t0

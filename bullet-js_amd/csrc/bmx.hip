@@ -9,6 +9,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <thread>
 #include <deque>
 #include <new>
 #include <string>
@@ -147,6 +148,7 @@ struct bmx_ctx {
   } pend;
   bool defer_enabled = true;
   uint32_t placement_tries = 0; float placement_us_best = 0, placement_us_worst = 0;   // what alloc_table_tuned saw for the current table
+  uint64_t n_row_waits = 0;           // merges that waited for a batch in flight to report its row count (wait_for_row_reports)
   int k1_waves = 8;                   // BMX_K1_WAVES (8, 6 or 5): resident waves per SIMD of the probe kernel
   hipStream_t side = nullptr;
   uint64_t dseq = 0;                  // deferred merges so far (the sequence numbers in ds->seqw)
@@ -248,6 +250,26 @@ void tighten_rows_ub(bmx_ctx* ctx) {
 }
 
 int flush_pending(bmx_ctx* ctx);
+// (merge_core's capacity guard) Blocks the CALLER, not the device: until the row reports of enough batches in flight have arrived for the bound to clear,
+// or none is left. A report that does not come within two seconds (a wedged queue) leaves the decision to the synchronising path.
+int wait_for_row_reports(bmx_ctx* ctx, uint64_t n) {
+  if (!ctx->host_rows) return BMX_OK;
+  const auto t0 = std::chrono::steady_clock::now();
+  while ((ctx->rows_ub + n >= ctx->nslots || ctx->rows_ub > ctx->capacity_rows) && !ctx->inflight.empty()) {
+    if (ctx->inflight.size() == 1 && ctx->pend.on) { if (int frc = flush_pending(ctx)) return frc; }   // the only report outstanding is that of a compaction not launched yet
+    const uint64_t want = ctx->inflight.front().first;
+    uint32_t spins = 0;
+    while (__atomic_load_n(ctx->host_rows + 1, __ATOMIC_ACQUIRE) < want) {
+      if ((++spins & 1023u) == 0) {
+        if (std::chrono::steady_clock::now() - t0 > std::chrono::seconds(2)) return BMX_OK;
+        std::this_thread::yield();
+      }
+    }
+    tighten_rows_ub(ctx);
+    ctx->n_row_waits++;
+  }
+  return BMX_OK;
+}
 int ensure_workspace(bmx_ctx* ctx, uint64_t n) {
   if (n <= ctx->ws_cap) return BMX_OK;
   if (int frc = flush_pending(ctx)) return frc;      // a compaction not launched yet reads the workspace this call frees
@@ -477,6 +499,13 @@ int merge_core(bmx_ctx* ctx, uint64_t n, const uint64_t* id, const uint32_t* fie
   }
   // capacity guards: physical (never let probing run out of empty slots) and logical (capacity_rows)
   if (ctx->rows_ub + n >= ctx->nslots || ctx->rows_ub > ctx->capacity_rows) tighten_rows_ub(ctx);
+  if (ctx->rows_ub + n >= ctx->nslots || ctx->rows_ub > ctx->capacity_rows) {
+    // The bound counts every delta of every batch still in flight as a new row. A host that runs many batches ahead of the device (a stream of
+    // device batches: ~10 us per call against ~80 us per batch) reaches it long before the table is full: wait for the OLDEST batch in flight to
+    // report its row count (its compaction writes the host-visible mirror) and look again — the device keeps its queue, nothing drains. Only when
+    // nothing is left in flight does the exact count decide (below).
+    if ((rc = wait_for_row_reports(ctx, n))) return rc;
+  }
   if (ctx->rows_ub + n >= ctx->nslots || ctx->rows_ub > ctx->capacity_rows) {
     if ((rc = flush_pending(ctx))) return rc;                 // the exact row count is the last compaction's
     rc = refresh_rows(ctx);
