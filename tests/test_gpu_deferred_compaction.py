@@ -255,3 +255,29 @@ def test_a_context_destroyed_with_a_compaction_pending_finishes_it_first():
     _, ow = o.merge_batch(*d)
     assert int(n_applied.item()) == len(ow)
     assert np.array_equal(applied[:len(ow)].cpu().numpy().view(np.uint32), ow)
+
+
+@pytest.mark.parametrize("defer", [True, False])
+def test_a_caller_far_ahead_of_the_device_waits_for_row_reports_and_neither_drains_nor_grows(defer):
+    """a table with head room for TWO batches' worth of new rows and a stream of 24 batches that create none: the capacity guard counts every delta in
+    flight as a possible new row, so from the third call on it has to wait for the oldest batch in flight to report its row count (the compaction
+    writes the host-visible mirror) — with the deferral that report may belong to a compaction that is only recorded. Same answers, same table."""
+    dev = torch.device("cuda", 0)
+    R, D, NB = 400_000, 150_000, 24
+    res = synth.big_resident(R, seed=93)
+    o = Oracle(); o.load_rows(*res)
+    hb = [synth.big_deltas(D, R, seed=94, insert_pct=0, hot_pct=20, hot_keys=64, unique=False, batch=b, drift=40_000) for b in range(NB)]
+    db = [_dev(d, dev) for d in hb]
+    applied = torch.zeros((NB, D), dtype=torch.int32, device=dev)
+    n_applied = torch.zeros(NB, dtype=torch.int64, device=dev)
+    torch.cuda.synchronize()
+    with bmx.Engine(R + 2 * D) as e:
+        e.set_deferred(defer)
+        e.load_rows(*res)
+        slots0 = e.info().n_slots
+        for b in range(NB):
+            e.merge_batch_dev(D, *db[b], INSERT_REFERENCE, applied=applied[b], n_applied=n_applied[b:b + 1])
+        e.sync()
+        assert e.info().n_slots == slots0, "the table did not have to grow: no batch created a row"
+        _check_batches(o, hb, applied, n_applied)
+        assert e.row_count() == len(o) == R and rows_digest(*e.dump_rows()) == o.digest()
