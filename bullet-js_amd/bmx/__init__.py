@@ -28,7 +28,7 @@ MAX_BATCH = 1 << 24
 EXPORTS = [
     "bmx_create", "bmx_create_ex", "bmx_destroy", "bmx_last_error", "bmx_abi_version", "bmx_selfcheck", "bmx_set_deferred_compaction", "bmx_merge_fence", "bmx_get_deferred_counts", "bmx_get_info", "bmx_get_placement", "bmx_set_probe_waves", "bmx_sync", "bmx_set_stream", "bmx_get_stream", "bmx_seq_signal", "bmx_seq_wait",
     "bmx_load_rows", "bmx_put_rows", "bmx_merge_batch", "bmx_merge_submit", "bmx_merge_collect", "bmx_host_alloc", "bmx_host_free", "bmx_merge_records", "bmx_get_rows", "bmx_get_row", "bmx_dump_rows", "bmx_row_count", "bmx_reserve",
-    "bmx_index_build", "bmx_index_drop", "bmx_index_size", "bmx_index_refresh_counts", "bmx_scan_range", "bmx_scan_equals", "bmx_scan_count", "bmx_scan_filter", "bmx_scan_range_pos", "bmx_index_ids",
+    "bmx_index_build", "bmx_index_drop", "bmx_index_size", "bmx_index_refresh_counts", "bmx_index_set_ordered", "bmx_index_ordered_info", "bmx_scan_range", "bmx_scan_equals", "bmx_scan_count", "bmx_scan_filter", "bmx_scan_range_pos", "bmx_index_ids",
     "bmx_owner_of", "bmx_partition_by_owner", "bmx_partition_by_owner_slabs", "bmx_partition_scatter", "bmx_merge_records_after", "bmx_ipc_alloc", "bmx_ipc_open", "bmx_ipc_close", "bmx_ipc_free", "bmx_seq_wait_all", "bmx_merge_tail_wait", "bmx_merge_notify", "bmx_timer_start", "bmx_timer_stop", "bmx_timer_mark", "bmx_timer_elapsed", "bmx_profile_enable", "bmx_profile_read", "bmx_profile_read_scan",
     "bmx_comm_create", "bmx_comm_destroy", "bmx_comm_last_error", "bmx_comm_nshards", "bmx_comm_shard", "bmx_comm_sync", "bmx_comm_load_rows", "bmx_comm_put_rows", "bmx_comm_merge",
     "bmx_comm_merge_dev", "bmx_comm_shard_result", "bmx_comm_row_count", "bmx_comm_get_rows", "bmx_comm_dump_rows", "bmx_comm_index_build",
@@ -116,6 +116,8 @@ def load_library():
     L.bmx_index_drop.argtypes = [vp, u32]; L.bmx_index_drop.restype = i32
     L.bmx_index_size.argtypes = [vp, u32, C.POINTER(u64)]; L.bmx_index_size.restype = i32
     L.bmx_index_refresh_counts.argtypes = [vp, C.POINTER(u64), C.POINTER(u64)]; L.bmx_index_refresh_counts.restype = i32
+    L.bmx_index_set_ordered.argtypes = [vp, u32, u32]; L.bmx_index_set_ordered.restype = i32
+    L.bmx_index_ordered_info.argtypes = [vp, u32, C.POINTER(u32), C.POINTER(i32), C.POINTER(u64)]; L.bmx_index_ordered_info.restype = i32
     L.bmx_scan_range.argtypes = [vp, u32, i64, i64, vp, u64, vp, i32]; L.bmx_scan_range.restype = i32
     L.bmx_scan_equals.argtypes = [vp, u32, i64, vp, u64, vp, i32]; L.bmx_scan_equals.restype = i32
     L.bmx_scan_count.argtypes = [vp, u32, i64, i64, vp, i32]; L.bmx_scan_count.restype = i32
@@ -365,6 +367,16 @@ class Engine:
         a, b = C.c_uint64(), C.c_uint64()
         self._chk(self.L.bmx_index_refresh_counts(self.h, C.byref(a), C.byref(b)))
         return a.value, b.value
+
+    def index_set_ordered(self, field, after_queries=1):
+        """value-ordered view of the index (bmx_index_set_ordered): sorted again by the after_queries-th query since the field last changed; 0 = off"""
+        self._chk(self.L.bmx_index_set_ordered(self.h, int(field), int(after_queries)))
+
+    def index_ordered_info(self, field):
+        """-> (after_queries, would the view answer the next query, sorts so far)"""
+        a, v, n = C.c_uint32(), C.c_int32(), C.c_uint64()
+        self._chk(self.L.bmx_index_ordered_info(self.h, int(field), C.byref(a), C.byref(v), C.byref(n)))
+        return a.value, bool(v.value), n.value
 
     def scan_range(self, field, lo, hi, cap=None):
         cap = self.index_size(field) if cap is None else cap

@@ -22,6 +22,11 @@
 #include "select.h"
 #include "slot.h"
 
+namespace bmx {   // csrc/ordered_sort.hip (rocPRIM's radix sort, an object of its own)
+hipError_t sort_pairs_i32(void* tmp, size_t* tmp_bytes, const int32_t* kin, int32_t* kout, const uint32_t* vin, uint32_t* vout, size_t n, hipStream_t s);
+hipError_t sort_pairs_i64(void* tmp, size_t* tmp_bytes, const int64_t* kin, int64_t* kout, const uint32_t* vin, uint32_t* vout, size_t n, hipStream_t s);
+}
+
 using namespace bmx;
 
 namespace {
@@ -35,6 +40,7 @@ struct DevScalars {  // one small device allocation; zeroed at create
   uint32_t wide;
   unsigned long long seq_diag[3];  // k_seq_wait expiry: {sequence word address, value waited for, value last seen}
   unsigned long long chg_n[2];     // entries in the index change log: batch k reads [k&1], its compaction writes [(k+1)&1]
+  unsigned long long ord_ab[2];    // value-ordered view: [first match, one past the last) of the query being answered
   unsigned long long seqw[2];      // deferred compaction: [0] = number of the latest probe kernel that has started, [1] = of the latest compaction finished on the side stream
 };
 
@@ -47,7 +53,23 @@ struct Index {
   bool fits32 = false;
   uint64_t version = ~0ull;  // table version it was built from
   bool has_pos = false;      // its rows' positions are in ctx->slot_pos (it can be maintained from the change log)
+  uint64_t content = 0;      // counts the refreshes that really changed something in the columns (a value, a new row, a rebuild)
+  // value-ordered view (bmx.h bmx_index_set_ordered): the columns once more, sorted by (value, position)
+  uint32_t ordered_after = 0;     // 0 = off; N: a stale view is sorted again by the N-th query since the columns last changed
+  uint32_t stale_queries = 0;
+  uint64_t ord_content = ~0ull;   // `content` the view was sorted from
+  uint64_t ord_n = 0, ord_cap = 0, ord_sorts = 0;
+  bool ord_fits32 = false;
+  void* s_val = nullptr;          // int32_t[ord_n] or int64_t[ord_n], ascending
+  uint32_t* s_pos = nullptr;      // position in the index columns
+  uint64_t* s_ids = nullptr;      // node id
 };
+void free_ordered_view(Index& ix) {
+  if (ix.s_val) (void)hipFree(ix.s_val);
+  if (ix.s_pos) (void)hipFree(ix.s_pos);
+  if (ix.s_ids) (void)hipFree(ix.s_ids);
+  ix.s_val = nullptr; ix.s_pos = nullptr; ix.s_ids = nullptr; ix.ord_cap = 0; ix.ord_n = 0; ix.ord_content = ~0ull;
+}
 
 thread_local std::string g_err;
 constexpr uint32_t PROF_MAX_CALLS = 64;
@@ -859,6 +881,7 @@ int build_index(bmx_ctx* ctx, Index* ix) {
   HIPCHK(hipStreamSynchronize(ctx->stream));
   ix->n = n;
   ix->fits32 = wide == 0;
+  ix->content++;             // every position may be another row's now
   ix->version = ctx->version;
   ix->has_pos = ctx->slot_pos != nullptr;
   ctx->ix_full_builds++;
@@ -876,7 +899,7 @@ int build_index(bmx_ctx* ctx, Index* ix) {
 int refresh_from_log(bmx_ctx* ctx) {
   const unsigned long long* n_dev = &ctx->ds->chg_n[ctx->chg_par];
   const uint64_t ub = ctx->chg_ub;
-  struct Res { unsigned long long added; uint32_t wide; };
+  struct Res { unsigned long long added; uint32_t wide; uint32_t changed; };     // (wide, changed: the two halves of one result word)
   std::vector<Res> res(ctx->indexes.size());
   // results of index k live in its own scratch words: part_totals[] is free between partitions (k < PART_MAX_SHARDS indexes are maintained)
   if (ctx->indexes.size() > IX_MAINTAINED_MAX) return fail(ctx, BMX_ERR_INTERNAL, "index maintenance with more indexes than result words");
@@ -902,7 +925,7 @@ int refresh_from_log(bmx_ctx* ctx) {
     }
     for (size_t k = 0; k < ctx->indexes.size(); k++) {
       HIPCHK(hipMemcpyAsync(&res[k].added, &ctx->ds->part_totals[2 * k], sizeof(unsigned long long), hipMemcpyDeviceToHost, ctx->stream));
-      HIPCHK(hipMemcpyAsync(&res[k].wide, &ctx->ds->part_totals[2 * k + 1], sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
+      HIPCHK(hipMemcpyAsync(&res[k].wide, &ctx->ds->part_totals[2 * k + 1], 2 * sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
     }
     HIPCHK(hipStreamSynchronize(ctx->stream));
   }
@@ -916,7 +939,7 @@ int refresh_from_log(bmx_ctx* ctx) {
       ix.version = ~0ull; ix.has_pos = false; ctx->chg_valid = false;
       continue;
     }
-    if (ub) { ix.n += res[k].added; if (res[k].wide) ix.fits32 = false; }
+    if (ub) { ix.n += res[k].added; if (res[k].wide) ix.fits32 = false; if (res[k].added || res[k].changed) ix.content++; }
     ix.version = ctx->version;
   }
   ctx->ix_incremental++;
@@ -980,8 +1003,57 @@ int ensure_scan_scratch(bmx_ctx* ctx, uint64_t n) {
 // a value column above this size is read with nontemporal loads: it cannot stay in the 256 MiB Infinity Cache between two scans anyway (scan_kernels.h)
 constexpr uint64_t SCAN_NT_BYTES = 256ull << 20;
 
+// ---- value-ordered view (bmx.h bmx_index_set_ordered) ----
+// Is the view of `ix` usable for the query at hand? A stale one is sorted again by the ordered_after-th query since the columns last changed — the
+// queries in front of that one scan the column as ever (one sort of a 100M-row column costs what ~20 scans cost) —, and never while it cannot be had
+// (no memory: the index goes on without it). Synchronous where it sorts.
+bool ensure_ordered_view(bmx_ctx* ctx, Index* ix) {
+  if (!ix->ordered_after || ix->n == 0 || ix->n > 0xFFFFFFFFull) return false;
+  if (ix->ord_content == ix->content && ix->s_val) return true;
+  if (++ix->stale_queries < ix->ordered_after) return false;
+  const uint64_t n = ix->n;
+  const size_t vb = ix->fits32 ? sizeof(int32_t) : sizeof(int64_t);
+  auto give_up = [&]() { (void)hipGetLastError(); free_ordered_view(*ix); ix->stale_queries = 0; return false; };
+  if (n > ix->ord_cap || ix->ord_fits32 != ix->fits32) {
+    free_ordered_view(*ix);
+    const uint64_t cap = n + n / 8 + 1024;
+    if (hipMalloc(&ix->s_val, cap * vb) != hipSuccess || hipMalloc(reinterpret_cast<void**>(&ix->s_pos), cap * sizeof(uint32_t)) != hipSuccess ||
+        hipMalloc(reinterpret_cast<void**>(&ix->s_ids), cap * sizeof(uint64_t)) != hipSuccess) return give_up();
+    ix->ord_cap = cap; ix->ord_fits32 = ix->fits32;
+  }
+  uint32_t* iota = nullptr; void* tmp = nullptr; size_t tmp_bytes = 0;
+  hipError_t e = ix->fits32 ? sort_pairs_i32(nullptr, &tmp_bytes, nullptr, nullptr, nullptr, nullptr, n, ctx->stream)
+                            : sort_pairs_i64(nullptr, &tmp_bytes, nullptr, nullptr, nullptr, nullptr, n, ctx->stream);
+  if (e != hipSuccess || hipMalloc(reinterpret_cast<void**>(&iota), n * sizeof(uint32_t)) != hipSuccess || hipMalloc(&tmp, std::max<size_t>(tmp_bytes, 16)) != hipSuccess) {
+    if (iota) (void)hipFree(iota);
+    return give_up();
+  }
+  const uint32_t gb = (uint32_t)std::min<uint64_t>((n + 255) / 256, 8192);
+  hipLaunchKernelGGL(k_iota_u32, dim3(gb), dim3(256), 0, ctx->stream, iota, n);
+  e = ix->fits32 ? sort_pairs_i32(tmp, &tmp_bytes, ix->v32, static_cast<int32_t*>(ix->s_val), iota, ix->s_pos, n, ctx->stream)
+                 : sort_pairs_i64(tmp, &tmp_bytes, ix->v64, static_cast<int64_t*>(ix->s_val), iota, ix->s_pos, n, ctx->stream);
+  if (e == hipSuccess) { hipLaunchKernelGGL(k_gather_ids, dim3(gb), dim3(256), 0, ctx->stream, (const uint64_t*)ix->ids, (const uint32_t*)ix->s_pos, ix->s_ids, n); e = hipGetLastError(); }
+  if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);       // the scratch goes back below
+  (void)hipFree(iota); (void)hipFree(tmp);
+  if (e != hipSuccess) return give_up();
+  ix->ord_n = n; ix->ord_content = ix->content; ix->stale_queries = 0; ix->ord_sorts++;
+  return true;
+}
+// the query itself: two searches + one contiguous copy; lo/hi are already clamped like the scans' (tombstones sort in front of every legal value)
+template <bool POS, class OutT>
+void launch_ordered(bmx_ctx* ctx, const Index* ix, int64_t lo, int64_t hi, OutT* d_out, uint64_t d_cap, unsigned long long* d_n) {
+  unsigned long long* ab = ctx->ds->ord_ab;
+  if (ix->ord_fits32) hipLaunchKernelGGL((k_ordered_bounds<int32_t>), dim3(1), dim3(128), 0, ctx->stream, static_cast<const int32_t*>(ix->s_val), ix->ord_n, (int32_t)lo, (int32_t)hi, ab, d_n);
+  else hipLaunchKernelGGL((k_ordered_bounds<int64_t>), dim3(1), dim3(128), 0, ctx->stream, static_cast<const int64_t*>(ix->s_val), ix->ord_n, lo, hi, ab, d_n);
+  if (!d_out || !d_cap) return;
+  // the match count is the device's: a grid for the most the caller can take, whose workgroups beyond the matches leave at once
+  const uint32_t blocks = (uint32_t)std::min<uint64_t>((std::min<uint64_t>(d_cap, ix->ord_n) + 2047) / 2048, 8192);
+  if constexpr (POS) hipLaunchKernelGGL((k_ordered_copy<uint32_t>), dim3(blocks), dim3(256), 0, ctx->stream, (const uint32_t*)ix->s_pos, (const unsigned long long*)ab, d_out, d_cap);
+  else hipLaunchKernelGGL((k_ordered_copy<uint64_t>), dim3(blocks), dim3(256), 0, ctx->stream, (const uint64_t*)ix->s_ids, (const unsigned long long*)ab, d_out, d_cap);
+}
+
 template <bool POS, class Pred>
-int run_scan_t(bmx_ctx* ctx, const Pred& P, const Index* ix, void* out_v, uint64_t cap, uint64_t* n_out, int mem) {
+int run_scan_t(bmx_ctx* ctx, const Pred& P, const Index* ix, void* out_v, uint64_t cap, uint64_t* n_out, int mem, bool ordered = false, int64_t olo = 0, int64_t ohi = 0) {
   using OutT = typename std::conditional<POS, uint32_t, uint64_t>::type;
   OutT* out_ids = static_cast<OutT*>(out_v);
   const bool host = mem == BMX_MEM_HOST;
@@ -1005,7 +1077,11 @@ int run_scan_t(bmx_ctx* ctx, const Pred& P, const Index* ix, void* out_v, uint64
   const uint32_t nb = (uint32_t)((std::max<uint64_t>(ix->n, 1) + SCAN_BLOCK_ELEMS - 1) / SCAN_BLOCK_ELEMS);
   hipEvent_t* se = (ctx->prof_on && ctx->scan_prof_n < PROF_MAX_CALLS && !ctx->scan_ev.empty()) ? &ctx->scan_ev[3 * ctx->scan_prof_n] : nullptr;
   if (se) HIPCHK(hipEventRecord(se[0], ctx->stream));
-  if (d_out) {
+  if (ordered) {
+    launch_ordered<POS>(ctx, ix, olo, ohi, d_out, d_cap, d_n);
+    LAUNCHCHK("k_ordered_bounds / k_ordered_copy");
+    if (se) HIPCHK(hipEventRecord(se[1], ctx->stream));
+  } else if (d_out) {
     // pass 1: one read of the column -> match mask + block counts; pass 2: ids / positions from the mask
     hipLaunchKernelGGL((k_scan_mask<Pred, true>), dim3(nb), dim3(SEL_THREADS), 0, ctx->stream, P, ix->n, ctx->scan_mask, ctx->scan_counts);
     LAUNCHCHK("k_scan_mask");
@@ -1073,16 +1149,17 @@ int scan_range_impl_t(bmx_ctx* ctx, uint32_t field, int64_t lo, int64_t hi, void
   Index* ix;
   int rc = fresh_index(ctx, field, &ix);
   if (rc) return rc;
+  const bool ordered = (n_out || out) && ensure_ordered_view(ctx, ix);     // (it was sorted from columns of the width they have now: a widened index has a new `content`)
   if (ix->fits32) {
     // every value fits int32: scan the 4-byte column with bounds clamped into int32 (an empty range stays empty). INT32_MIN itself is what a
     // tombstone looks like in this column and is never matched (a real -2^31 makes the index wide: scan_kernels.h v32_of)
     int64_t l = std::max<int64_t>(lo, (int64_t)INT32_MIN + 1), h = std::min<int64_t>(hi, INT32_MAX);
     if (lo > INT32_MAX || hi < INT32_MIN) { l = 1; h = 0; }
     PredRange32 P{ix->v32, (int32_t)l, (int32_t)h, ix->n * sizeof(int32_t) > SCAN_NT_BYTES};
-    return run_scan_t<POS>(ctx, P, ix, out, cap, n_out, mem);
+    return run_scan_t<POS>(ctx, P, ix, out, cap, n_out, mem, ordered, l, h);
   }
   PredRange64 P{ix->v64, std::max<int64_t>(lo, -VAL_MAX), hi, ix->n * sizeof(int64_t) > SCAN_NT_BYTES};    // values live in +-(2^53-1): the clamp changes no answer and keeps tombstones (INT64_MIN) out
-  return run_scan_t<POS>(ctx, P, ix, out, cap, n_out, mem);
+  return run_scan_t<POS>(ctx, P, ix, out, cap, n_out, mem, ordered, P.lo, P.hi);
 }
 int scan_range_impl(bmx_ctx* ctx, uint32_t field, int64_t lo, int64_t hi, uint64_t* out_ids, uint64_t cap, uint64_t* n_out, int mem) {
   return scan_range_impl_t<false>(ctx, field, lo, hi, out_ids, cap, n_out, mem);
@@ -1213,7 +1290,7 @@ void bmx_destroy(bmx_ctx* ctx) {
   (void)hipGetLastError();
   if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
   if (ctx->side) { (void)hipStreamSynchronize(ctx->side); (void)hipStreamDestroy(ctx->side); ctx->side = nullptr; }
-  for (auto& ix : ctx->indexes) { dev_free(ix.ids); dev_free(ix.v64); dev_free(ix.v32); }
+  for (auto& ix : ctx->indexes) { dev_free(ix.ids); dev_free(ix.v64); dev_free(ix.v32); free_ordered_view(ix); }
   dev_free(ctx->slots); dev_free(ctx->ds); dev_free(ctx->next); dev_free(ctx->blk_info); dev_free(ctx->blk_follow); dev_free(ctx->shard_ctr);
   for (uint32_t h = 0; h < bmx_ctx::WS_SETS; h++) { dev_free(ctx->wflag[h]); dev_free(ctx->slot_of[h]); dev_free(ctx->fld_ws[h]); }
   if (ctx->copy_stream) (void)hipStreamSynchronize(ctx->copy_stream);
@@ -1483,7 +1560,7 @@ int bmx_index_drop(bmx_ctx* ctx, uint32_t field) {
   HIPCHK(hipStreamSynchronize(ctx->stream));
   for (size_t i = 0; i < ctx->indexes.size(); i++)
     if (ctx->indexes[i].field == field) {
-      dev_free(ctx->indexes[i].ids); dev_free(ctx->indexes[i].v64); dev_free(ctx->indexes[i].v32);
+      dev_free(ctx->indexes[i].ids); dev_free(ctx->indexes[i].v64); dev_free(ctx->indexes[i].v32); free_ordered_view(ctx->indexes[i]);
       ctx->indexes.erase(ctx->indexes.begin() + (long)i);
       if (ctx->indexes.empty()) {   // nothing left to maintain: the merges stop logging and the maintenance memory goes back
         ctx->chg_valid = false; ctx->chg_ub = 0;
@@ -1509,6 +1586,27 @@ int bmx_index_refresh_counts(bmx_ctx* ctx, uint64_t* full_builds, uint64_t* incr
   if (!ctx) return fail(nullptr, BMX_ERR_INVALID, "null context");
   if (full_builds) *full_builds = ctx->ix_full_builds;
   if (incremental_updates) *incremental_updates = ctx->ix_incremental;
+  return BMX_OK;
+}
+
+int bmx_index_set_ordered(bmx_ctx* ctx, uint32_t field, uint32_t after_queries) {
+  if (!ctx) return fail(nullptr, BMX_ERR_INVALID, "null context");
+  if (int erc = enter(ctx)) return erc;
+  Index* ix;
+  int rc = fresh_index(ctx, field, &ix);      // (creates the index like a first query would)
+  if (rc) return rc;
+  ix->ordered_after = after_queries;
+  ix->stale_queries = 0;
+  if (!after_queries) { HIPCHK(hipStreamSynchronize(ctx->stream)); free_ordered_view(*ix); }
+  return BMX_OK;
+}
+int bmx_index_ordered_info(bmx_ctx* ctx, uint32_t field, uint32_t* after_queries, int* valid_now, uint64_t* sorts) {
+  if (!ctx) return fail(nullptr, BMX_ERR_INVALID, "null context");
+  Index* ix = find_index(ctx, field);
+  if (!ix) return fail(ctx, BMX_ERR_INVALID, "bmx_index_ordered_info: no index on this field");
+  if (after_queries) *after_queries = ix->ordered_after;
+  if (valid_now) *valid_now = ix->ordered_after && ix->s_val && ix->ord_content == ix->content && ix->version == ctx->version;
+  if (sorts) *sorts = ix->ord_sorts;
   return BMX_OK;
 }
 

@@ -111,7 +111,7 @@ struct EmitAppend {   // created row -> the end of the index columns, in log ord
 // filter reads the int64 one whatever the range scans use). Entries that created their row were appended with the current value already.
 __global__ __launch_bounds__(256) void k_ix_update(const uint2* __restrict__ chg, const unsigned long long* __restrict__ n_dev, const Slot* __restrict__ slots,
                                                    uint32_t field, const uint32_t* __restrict__ slot_pos, int64_t* __restrict__ v64, int32_t* __restrict__ v32,
-                                                   uint32_t* wide) {
+                                                   uint32_t* wide /* wide[1]: set when a value in the index really changed */) {
   const uint64_t n = *n_dev;
   for (uint64_t i = (uint64_t)blockIdx.x * 256u + threadIdx.x; i < n; i += (uint64_t)gridDim.x * 256u) {
     const uint2 x = chg[i];
@@ -121,6 +121,7 @@ __global__ __launch_bounds__(256) void k_ix_update(const uint2* __restrict__ chg
     if (p == POS_NONE) continue;
     const uint4 hi = reinterpret_cast<const uint4*>(slots + s)[1];
     const int64_t v = (int64_t)((uint64_t)hi.z | ((uint64_t)hi.w << 32));
+    if (v64[p] != v) wide[1] = 1u;       // (the value-ordered view of the index is stale only then)
     v64[p] = v; v32[p] = v32_of(v);
     if (is_wide(v)) *wide = 1u;
   }
@@ -245,6 +246,60 @@ struct EmitPos {  // index position itself (u32, bounded by cap): no read of the
   __device__ __forceinline__ void put2(uint64_t, uint64_t, uint64_t) const {}
   __device__ __forceinline__ uint32_t odd(uint64_t) const { return 0; }
 };
+// ---- value-ordered view of an index (bmx.h bmx_index_set_ordered): columns sorted by (value, position) ----
+// src/bullet-query.js keeps an index as a Map keyed by VALUE (:30-73): equals() is one lookup, range() walks the distinct values. The view gives the
+// device index the same shape: a query is two k-ary searches on the sorted value column + one contiguous copy, O(log R + matches).
+__global__ __launch_bounds__(256) void k_iota_u32(uint32_t* __restrict__ p, uint64_t n) {
+  for (uint64_t i = (uint64_t)blockIdx.x * 256u + threadIdx.x; i < n; i += (uint64_t)gridDim.x * 256u) p[i] = (uint32_t)i;
+}
+__global__ __launch_bounds__(256) void k_gather_ids(const uint64_t* __restrict__ ids, const uint32_t* __restrict__ pos, uint64_t* __restrict__ out, uint64_t n) {
+  for (uint64_t i = (uint64_t)blockIdx.x * 256u + threadIdx.x; i < n; i += (uint64_t)gridDim.x * 256u) out[i] = ids[pos[i]];
+}
+// One wave per bound, 64-ary search: every round 63 lanes probe evenly spaced keys of [L, R) and the ballot says between which two the bound lies
+// (a 100M-row column: five dependent rounds instead of the 27 of a binary search). UPPER = false: first index with v >= key; true: first with v > key.
+template <class T, bool UPPER>
+__device__ __forceinline__ uint64_t ordered_bound(const T* __restrict__ v, uint64_t n, T key) {
+  const uint32_t lane = threadIdx.x & 63u;
+  uint64_t L = 0, R = n;                         // invariant: every index < L is in front of the bound, every index >= R behind it
+  while (R - L > 64) {
+    const uint64_t step = (R - L + 63) / 64;
+    const uint64_t c = L + (uint64_t)lane * step;        // lane 0 probes nothing (c == L)
+    bool before = false;
+    if (lane > 0 && c < R) { const T x = v[c]; before = UPPER ? x <= key : x < key; }
+    const uint32_t t = (uint32_t)__popcll(__ballot(before));        // sorted column: lanes 1..t are in front of the bound
+    const uint64_t nl = t ? L + (uint64_t)t * step + 1 : L;
+    const uint64_t cr = L + (uint64_t)(t + 1) * step;
+    R = (t < 63 && cr < R) ? cr : R;
+    L = nl;
+  }
+  bool before = false;
+  if (L + lane < R) { const T x = v[L + lane]; before = UPPER ? x <= key : x < key; }
+  return L + (uint64_t)__popcll(__ballot(before));
+}
+// ab[0] = first match, ab[1] = one past the last; *n_out = matches (optional). An empty range (lo > hi) matches nothing.
+template <class T>
+__global__ __launch_bounds__(128) void k_ordered_bounds(const T* __restrict__ v, uint64_t n, T lo, T hi, unsigned long long* __restrict__ ab, unsigned long long* __restrict__ n_out) {
+  __shared__ unsigned long long sh[2];
+  const uint32_t w = threadIdx.x >> 6;
+  uint64_t r = 0;
+  if (lo <= hi) r = w == 0 ? ordered_bound<T, false>(v, n, lo) : ordered_bound<T, true>(v, n, hi);
+  if ((threadIdx.x & 63u) == 0) sh[w] = r;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const unsigned long long a = sh[0], b = sh[1] < sh[0] ? sh[0] : sh[1];
+    ab[0] = a; ab[1] = b;
+    if (n_out) *n_out = b - a;
+  }
+}
+// out[k] = src[a + k] for k < min(b - a, cap): the matches are one contiguous run of the sorted id (or position) column
+template <class OutT>
+__global__ __launch_bounds__(256) void k_ordered_copy(const OutT* __restrict__ src, const unsigned long long* __restrict__ ab, OutT* __restrict__ out, uint64_t cap) {
+  const uint64_t a = ab[0];
+  uint64_t m = ab[1] - a;
+  if (m > cap) m = cap;
+  for (uint64_t i = (uint64_t)blockIdx.x * 256u + threadIdx.x; i < m; i += (uint64_t)gridDim.x * 256u) out[i] = __builtin_nontemporal_load(src + a + i);
+}
+
 struct FinishCount {  // total -> *n_out (device), optional
   unsigned long long* n_out;
   __device__ void operator()(uint64_t total, uint32_t*) const { if (n_out && threadIdx.x == 0) *n_out = total; }

@@ -86,7 +86,7 @@ class GpuQuery {
   index(path, field = null, opts = {}) {
     const key = GpuQuery.keyOf(path, field);
     if (this.indices[key]) return this;
-    this.indices[key] = { path, field, stale: true, dirty: null, kind: null, source: opts.source === "device" ? "device" : "store" };
+    this.indices[key] = { path, field, stale: true, dirty: null, kind: null, source: opts.source === "device" ? "device" : "store", ordered: opts.ordered >>> 0 };
     this.indexedPaths.add(path);
     if (!this._byBase.has(path)) this._byBase.set(path, []);
     this._byBase.get(path).push(this.indices[key]);
@@ -100,6 +100,7 @@ class GpuQuery {
     ix.kind = "device";
     ix.deviceField = g.keys.fieldOf(ix.path, ix.field);
     g.indexBuild(ix.deviceField);
+    if (ix.ordered && typeof g.indexSetOrdered === "function") g.indexSetOrdered(ix.deviceField, ix.ordered);   // opts.ordered: the device keeps a value-ordered view too
     ix.paths = null; ix.values = null; ix.stale = false; ix.dirty = null; ix.rank = null; ix._posByPath = null;
   }
 

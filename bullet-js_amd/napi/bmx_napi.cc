@@ -374,6 +374,28 @@ napi_value IndexBuild(napi_env env, napi_callback_info info) {
   if (rc) return throw_bmx(env, h->ctx, rc);
   return nullptr;
 }
+/* indexSetOrdered(handle, field, afterQueries): value-ordered view of the index (bmx_index_set_ordered); 0 = off. -> {afterQueries, valid, sorts} */
+napi_value IndexSetOrdered(napi_env env, napi_callback_info info) {
+  ARGS(3);
+  Handle* h; if (!get_handle(env, argv[0], &h)) return nullptr;
+  Turn turn(h);   // runs in issue order with the asynchronous merges
+  uint32_t f, n; NAPI_OK(napi_get_value_uint32(env, argv[1], &f)); NAPI_OK(napi_get_value_uint32(env, argv[2], &n));
+  int rc = bmx_index_set_ordered(h->ctx, f, n);
+  if (rc) return throw_bmx(env, h->ctx, rc);
+  return nullptr;
+}
+napi_value IndexOrderedInfo(napi_env env, napi_callback_info info) {
+  ARGS(2);
+  Handle* h; if (!get_handle(env, argv[0], &h)) return nullptr;
+  Turn turn(h);
+  uint32_t f; NAPI_OK(napi_get_value_uint32(env, argv[1], &f));
+  uint32_t after = 0; int valid = 0; uint64_t sorts = 0;
+  int rc = bmx_index_ordered_info(h->ctx, f, &after, &valid, &sorts);
+  if (rc) return throw_bmx(env, h->ctx, rc);
+  napi_value out; NAPI_OK(napi_create_object(env, &out));
+  set_num(env, out, "afterQueries", after); set_num(env, out, "valid", valid); set_num(env, out, "sorts", (double)sorts);
+  return out;
+}
 napi_value IndexDrop(napi_env env, napi_callback_info info) {
   ARGS(2);
   Handle* h; if (!get_handle(env, argv[0], &h)) return nullptr;
@@ -977,7 +999,7 @@ napi_value CommScanFilter(napi_env env, napi_callback_info info) {
 napi_value Init(napi_env env, napi_value exports) {
   struct { const char* name; napi_callback fn; } fns[] = {
       {"abiVersion", AbiVersion}, {"create", Create}, {"destroy", Destroy}, {"mergeBatch", MergeBatch}, {"mergeBatchAsync", MergeBatchAsync}, {"reserve", Reserve}, {"loadRows", LoadRows}, {"putRows", PutRows}, {"hostColumns", HostColumns}, {"scanRangePos", ScanRangePos}, {"indexIds", IndexIds}, {"commPutRows", CommPutRows},
-      {"getRows", GetRows}, {"rowCount", RowCount}, {"dumpRows", DumpRows}, {"indexBuild", IndexBuild}, {"indexDrop", IndexDrop},
+      {"getRows", GetRows}, {"rowCount", RowCount}, {"dumpRows", DumpRows}, {"indexBuild", IndexBuild}, {"indexDrop", IndexDrop}, {"indexSetOrdered", IndexSetOrdered}, {"indexOrderedInfo", IndexOrderedInfo},
       {"indexSize", IndexSize}, {"indexRefreshCounts", IndexRefreshCounts}, {"scanRange", ScanRange}, {"scanCount", ScanCount}, {"scanFilter", ScanFilter}, {"info", Info},
       {"vcCreate", VcCreate}, {"vcDestroy", VcDestroy}, {"vcLoadRows", VcLoadRows}, {"vcMergeBatch", VcMergeBatch}, {"vcMergeBatchAsync", VcMergeBatchAsync}, {"vcGetRows", VcGetRows}, {"vcRowCount", VcRowCount}, {"vcScanRange", VcScanRange}, {"ownersOf", OwnersOf},
       {"commCreate", CommCreate}, {"commDestroy", CommDestroy}, {"commMergeBatch", CommMergeBatch}, {"commLoadRows", CommLoadRows}, {"commGetRows", CommGetRows},

@@ -32,8 +32,9 @@ extern "C" {
 
 /* ABI history. 1: rounds 1-3 (during which BMX_MERGE_BUCKETED 0x800 / BMX_CTX_BUCKETED_MERGE were removed and ~20 entry points added without a bump).
  * 2: every insert_mode bit that is not documented below is refused with BMX_ERR_INVALID; deferred compaction (bmx_set_deferred_compaction,
- *    bmx_merge_fence, bmx_get_deferred_counts); bmx_selfcheck. A caller built against 1 that passes only documented bits keeps working. */
-#define BMX_ABI_VERSION 2
+ *    bmx_merge_fence, bmx_get_deferred_counts); bmx_selfcheck. A caller built against 1 that passes only documented bits keeps working.
+ * 3: value-ordered index views (bmx_index_set_ordered, bmx_index_ordered_info): additions only; nothing a caller built against 2 uses has changed. */
+#define BMX_ABI_VERSION 3
 
 /* status codes */
 #define BMX_OK             0
@@ -264,7 +265,7 @@ int bmx_reserve(bmx_ctx* ctx, uint64_t capacity_rows);
  *
  * bmx_scan_range replaces range(path, field, min, max) src/bullet-query.js:221-261: lo <= val <= hi,
  * both inclusive. bmx_scan_equals replaces equals() :186-210, bmx_scan_count replaces count() :293-313.
- * Results are node ids in index-column order (deterministic for a given history of calls: table order for the rows
+ * Results are node ids in index-column order unless the index has a value-ordered view (below) (deterministic for a given history of calls: table order for the rows
  * present at the last full build, then creation order); the host mirror maps ids back to paths and can reproduce the
  * reference's first-seen-value order.
  *
@@ -278,6 +279,19 @@ int bmx_index_build(bmx_ctx* ctx, uint32_t field);
 int bmx_index_drop(bmx_ctx* ctx, uint32_t field);
 int bmx_index_size(bmx_ctx* ctx, uint32_t field, uint64_t* n_out);   /* positions in the index columns (rows of the field, tombstoned ones included: they keep their position and match nothing) */
 int bmx_index_refresh_counts(bmx_ctx* ctx, uint64_t* full_builds, uint64_t* incremental_updates);
+/* Value-ordered view of an index (opt-in per index; ABI 3). The reference keeps an index as a Map keyed by VALUE (src/bullet-query.js:30-73): equals() is one
+ * lookup (:186-210), range() walks the distinct values (:221-261) — neither ever touches a child that does not match. The dense columns above cost one pass
+ * over ALL rows per query instead. bmx_index_set_ordered(ctx, field, N >= 1) gives the index the reference's shape: a second copy of its columns sorted by
+ * (value, position). While that view is current, bmx_scan_range / _equals / _count / _range_pos on the field are two k-ary searches plus one contiguous copy —
+ * O(log R + matches), nothing read that is not part of the answer — and deliver the matches in (value, position) order instead of position order (the set
+ * is the same; the host mirror can reproduce the reference's first-seen-value order from either). The view is current as long as no merge, put or rebuild
+ * changed a value or added a row of the field (merges on other fields do not touch it). A stale view is sorted again (one radix sort of the column + one
+ * gather: milliseconds for 10^8 rows, csrc/ordered_sort.hip) by the N-th query since the change; the N - 1 queries before it scan the column as ever, so a
+ * field that is written between any two queries never pays for a sort with N >= 2. N = 0 switches the view off and frees it (3 columns: 16 or 20 bytes per
+ * row). If the memory cannot be had the index silently goes on without the view. bmx_index_ordered_info: N, whether the view would answer the next query,
+ * and how many sorts have run. */
+int bmx_index_set_ordered(bmx_ctx* ctx, uint32_t field, uint32_t after_queries);
+int bmx_index_ordered_info(bmx_ctx* ctx, uint32_t field, uint32_t* after_queries, int* valid_now, uint64_t* sorts);
 int bmx_scan_range(bmx_ctx* ctx, uint32_t field, int64_t lo, int64_t hi, uint64_t* out_ids, uint64_t cap,
                    uint64_t* n_out, int mem);
 int bmx_scan_equals(bmx_ctx* ctx, uint32_t field, int64_t value, uint64_t* out_ids, uint64_t cap, uint64_t* n_out,

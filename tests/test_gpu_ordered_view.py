@@ -1,0 +1,150 @@
+"""GPU: value-ordered view of an index (include/bmx.h bmx_index_set_ordered). The reference's index is a Map keyed by value (src/bullet-query.js:30-73):
+equals() is one lookup (:186-210), range() walks distinct values (:221-261). With the view the device answers the same queries by two searches on a
+sorted copy of the column and one contiguous copy; the SET of matches must equal a ground-truth scan of the same rows whatever path answered, positions
+and ids must name the same rows in the same order, and the view must notice every change of the field and nothing else."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+import bmx
+from oracle import streams
+from oracle.oracle import VAL_DELETED
+
+FA, FS, FO = streams.fnv1a32("age"), streams.fnv1a32("score"), streams.fnv1a32("other")
+
+
+def _want(ids, vals, lo, hi, alive=None):
+    m = (vals >= lo) & (vals <= hi)
+    if alive is not None:
+        m &= alive
+    return np.sort(ids[m])
+
+
+def _q(e, f, ids, vals, lo, hi, alive=None):
+    """ONE query (the re-sort policy counts queries), compared as a set"""
+    want = _want(ids, vals, lo, hi, alive)
+    got = e.scan_range(f, lo, hi)
+    assert len(got) == len(want) and np.array_equal(np.sort(got), want), (lo, hi, len(got), len(want))
+
+
+def _check(e, f, ids, vals, lo, hi, alive=None):
+    want = _want(ids, vals, lo, hi, alive)
+    got = e.scan_range(f, lo, hi)
+    assert len(got) == len(want) and np.array_equal(np.sort(got), want), (lo, hi, len(got), len(want))
+    assert e.scan_count(f, lo, hi) == len(want)
+    pos = e.scan_range_pos(f, lo, hi)
+    col = e.index_ids(f)
+    assert len(pos) == len(want) and np.array_equal(col[pos], got), (lo, hi, "positions and ids name the same rows in the same order")
+    return got
+
+
+@pytest.mark.parametrize("wide", [False, True])
+def test_queries_through_the_view_equal_a_scan(wide):
+    R = 3_000_017
+    f = FS if wide else FA
+    sh = 33 if wide else 0
+    ids = streams.splitmix64_np(np.arange(1, R + 1, dtype=np.uint64))
+    with np.errstate(over="ignore"):
+        vals = ((streams.splitmix64_np(ids ^ np.uint64(0x5151)) % np.uint64(5000)).astype(np.int64) - 2500) << sh
+    with bmx.Engine(R + 1000) as e:
+        e.load_rows(ids, np.full(R, f, np.uint32), np.full(R, 5, np.int64), vals)
+        e.index_build(f)
+        before = {(lo, hi): np.sort(e.scan_range(f, lo << sh, hi << sh)) for lo, hi in [(7, 7), (-100, 100)]}      # answered by the column scan
+        e.index_set_ordered(f, 1)
+        assert e.index_ordered_info(f) == (1, False, 0)
+        rng = np.random.default_rng(3)
+        qs = [(7, 7), (-100, 100), (-2500, 2499), (-2500, -2500), (2499, 2499), (2500, 9000), (-9000, -2501), (10, 9), (0, 0), (-1, 1), (-(1 << 20), 1 << 20)]
+        qs += [tuple(sorted(rng.integers(-2600, 2600, 2).tolist())) for _ in range(60)]
+        for lo, hi in qs:
+            got = _check(e, f, ids, vals, lo << sh, hi << sh)
+            if (lo, hi) in before:
+                assert np.array_equal(np.sort(got), before[(lo, hi)])
+        a, valid, sorts = e.index_ordered_info(f)
+        assert valid and sorts == 1, "one sort served every query: nothing was written in between"
+        # (value, position) order: values ascend, positions ascend inside one value
+        pos = e.scan_range_pos(f, -50 << sh, 50 << sh)
+        col = e.index_ids(f)
+        order = np.argsort(ids, kind="stable"); vv = vals[order][np.searchsorted(ids[order], col[pos])]
+        assert np.all(np.diff(vv) >= 0) and np.all((np.diff(vv) > 0) | (np.diff(pos.astype(np.int64)) > 0))
+        # truncated answers keep the full count; a device buffer gets the same answer
+        got = e.scan_range(f, -100 << sh, 100 << sh, cap=777); full = e.scan_range(f, -100 << sh, 100 << sh)
+        assert len(got) == 777 and np.array_equal(got, full[:777])
+        dev = torch.device("cuda", 0)
+        buf = torch.zeros(len(full) + 4, dtype=torch.int64, device=dev); n_out = torch.zeros(1, dtype=torch.int64, device=dev)
+        torch.cuda.synchronize()
+        e.scan_range_dev(f, -100 << sh, 100 << sh, buf, len(full), n_out); e.sync()
+        assert int(n_out.item()) == len(full) and np.array_equal(buf[:len(full)].cpu().numpy().view(np.uint64), full) and int(buf[len(full):].abs().sum().item()) == 0
+        e.index_set_ordered(f, 0)       # off: the column scan answers again, in position order
+        assert e.index_ordered_info(f)[:2] == (0, False)
+        pos = e.scan_range_pos(f, -50 << sh, 50 << sh)
+        assert np.all(np.diff(pos.astype(np.int64)) > 0)
+        _check(e, f, ids, vals, -50 << sh, 50 << sh)
+
+
+def test_the_view_follows_every_change_of_its_field_and_nothing_else():
+    R = 400_000
+    rng = np.random.default_rng(11)
+    ids = streams.splitmix64_np(np.arange(1, R + 1, dtype=np.uint64))
+    vals = rng.integers(0, 300, R).astype(np.int64)
+    ts = np.full(R, 10, np.int64)
+    alive = np.ones(R, bool)
+    with bmx.Engine(4 * R) as e:
+        e.load_rows(ids, np.full(R, FA, np.uint32), ts, vals)
+        e.load_rows(ids, np.full(R, FO, np.uint32), ts, vals + 7)
+        e.index_build(FA)
+        e.index_set_ordered(FA, 2)                      # a stale view is sorted again by the SECOND query after a change
+        _q(e, FA, ids, vals, 10, 20); assert e.index_ordered_info(FA) == (2, False, 0)       # first query: scanned
+        _q(e, FA, ids, vals, 10, 20); assert e.index_ordered_info(FA) == (2, True, 1)        # second: sorted
+        _check(e, FA, ids, vals, 0, 299); assert e.index_ordered_info(FA) == (2, True, 1)
+        # a merge on ANOTHER field: the view stays
+        k = rng.choice(R, 50_000, replace=False)
+        e.merge_batch(ids[k], np.full(len(k), FO, np.uint32), np.full(len(k), 20, np.int64), rng.integers(0, 300, len(k)).astype(np.int64))
+        _check(e, FA, ids, vals, 100, 110); assert e.index_ordered_info(FA) == (2, True, 1)
+        # a merge that rewrites the SAME values under a newer clock: rows win, no value changes, the view stays
+        e.merge_batch(ids[k], np.full(len(k), FA, np.uint32), np.full(len(k), 20, np.int64), vals[k])
+        _check(e, FA, ids, vals, 100, 110); assert e.index_ordered_info(FA) == (2, True, 1)
+        # values change, rows are created, rows are tombstoned
+        for rnd in range(3):
+            k = rng.choice(R, 30_000, replace=False)
+            nv = rng.integers(0, 300, len(k)).astype(np.int64)
+            e.merge_batch(ids[k], np.full(len(k), FA, np.uint32), np.full(len(k), 1000 * (rnd + 1), np.int64), nv)     # (above every clock stored so far, tombstones included)
+            vals[k] = nv; alive[k] = True
+            new_ids = streams.splitmix64_np(np.arange(10_000_000 + rnd * 1000, 10_000_000 + rnd * 1000 + 500, dtype=np.uint64))
+            new_vals = rng.integers(0, 300, 500).astype(np.int64)
+            e.merge_batch(new_ids, np.full(500, FA, np.uint32), np.full(500, 5, np.int64), new_vals)
+            ids = np.concatenate([ids, new_ids]); vals = np.concatenate([vals, new_vals]); alive = np.concatenate([alive, np.ones(500, bool)])
+            d = rng.choice(R, 2_000, replace=False)
+            e.put_rows(ids[d], np.full(len(d), FA, np.uint32), np.full(len(d), 1000 * (rnd + 1) + 1, np.int64), np.full(len(d), VAL_DELETED, np.int64))
+            alive[d] = False
+            s0 = e.index_ordered_info(FA)[2]
+            _q(e, FA, ids, vals, 50, 60, alive); assert e.index_ordered_info(FA) == (2, False, s0)       # scanned: the view is stale
+            _q(e, FA, ids, vals, 50, 60, alive); assert e.index_ordered_info(FA) == (2, True, s0 + 1)    # sorted again
+            for lo, hi in [(0, 0), (0, 299), (299, 299), (120, 180), (-5, 3)]:
+                _check(e, FA, ids, vals, lo, hi, alive)
+            assert e.index_ordered_info(FA) == (2, True, s0 + 1)
+        # a table growth rebuilds the index (positions renumbered): the view goes with it
+        e.reserve(16 * R)
+        s0 = e.index_ordered_info(FA)[2]
+        _q(e, FA, ids, vals, 7, 9, alive); _q(e, FA, ids, vals, 7, 9, alive)
+        assert e.index_ordered_info(FA) == (2, True, s0 + 1)
+        _check(e, FA, ids, vals, 7, 9, alive)
+        e.index_drop(FA)
+        _check(e, FA, ids, vals, 7, 9, alive)           # a query re-creates the index, without a view
+
+
+def test_small_and_degenerate_columns():
+    with bmx.Engine(10_000) as e:
+        ids = streams.splitmix64_np(np.arange(1, 201, dtype=np.uint64))
+        vals = np.full(200, 42, np.int64)                  # one value, 200 times
+        e.load_rows(ids, np.full(200, FA, np.uint32), np.full(200, 5, np.int64), vals)
+        e.index_build(FA); e.index_set_ordered(FA, 1)
+        for lo, hi in [(42, 42), (41, 43), (43, 50), (0, 41), (-1 << 40, 1 << 40)]:
+            _check(e, FA, ids, vals, lo, hi)
+        one = streams.splitmix64_np(np.arange(900, 901, dtype=np.uint64))
+        e.load_rows(one, np.full(1, FS, np.uint32), np.full(1, 5, np.int64), np.array([-(1 << 40)], np.int64))      # a single wide row
+        e.index_build(FS); e.index_set_ordered(FS, 1)
+        _check(e, FS, one, np.array([-(1 << 40)], np.int64), -(1 << 41), 0)
+        _check(e, FS, one, np.array([-(1 << 40)], np.int64), 0, 5)
+        assert e.index_ordered_info(FS)[1]
