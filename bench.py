@@ -308,6 +308,48 @@ def scan_bench(bmx, dev, R, reps=20, wide=False):
                                                   "kernel_us_between_events": {"scan_mask": round(kms["scan_mask"] * 1e3, 2), "offsets_and_emit": round(kms["emit"] * 1e3, 2)}}}
         out["verified"] = {"against": "numpy over the generated rows: match count and wrap-around sum of the matching ids, id output and position output (ids gathered through the index's id column)",
                            "scans_checked": checked, "ok": True}
+        # The same queries through the VALUE-ORDERED VIEW of the index (bmx_index_set_ordered: the reference's index is a Map keyed by value,
+        # src/bullet-query.js:30-73): two k-ary searches + one contiguous copy. Bytes moved are 16 / 8 per match (ids / positions), not the column.
+        ov = {}
+        e.index_set_ordered(fa, 1)
+        e.sync(); t0 = time.perf_counter()
+        e.scan_range_dev(fa, 42 << sh, 42 << sh, None, 0, n_out); e.sync()          # the first query sorts the view
+        ov["sort_ms"] = round((time.perf_counter() - t0) * 1e3, 3)
+        if not e.index_ordered_info(fa)[1]:
+            raise SystemExit("the value-ordered view of the %d-row %s index was not built" % (R, out["column"]))
+        for name, lo, hi in QUERIES:
+            for _ in range(3):
+                e.scan_range_dev(fa, lo << sh, hi << sh, out_ids, R, n_out)
+            e.sync(); e.timer_start()
+            for _ in range(reps):
+                e.scan_range_dev(fa, lo << sh, hi << sh, out_ids, R, n_out)
+            ms = e.timer_stop() / reps
+            m = int(n_out.item())
+            if m != want[name][0] or int(out_ids[:m].sum().item()) != i64(want[name][1]):
+                raise SystemExit("VERIFICATION FAILED: ordered-view scan %s over %d %s rows: %d matches (numpy: %d) or a different id checksum" % (name, R, out["column"], m, want[name][0]))
+            for _ in range(3):
+                e.scan_range_pos_dev(fa, lo << sh, hi << sh, out_pos, R, n_out)
+            e.sync(); e.timer_start()
+            for _ in range(reps):
+                e.scan_range_pos_dev(fa, lo << sh, hi << sh, out_pos, R, n_out)
+            ms_pos = e.timer_stop() / reps
+            mp = int(n_out.item())
+            got_sum = int(id_col[out_pos[:mp].long()].sum().item()) if mp == m else None
+            if mp != m or got_sum != i64(want[name][1]):
+                raise SystemExit("VERIFICATION FAILED: ordered-view position scan %s over %d %s rows names other rows than numpy" % (name, R, out["column"]))
+            e.sync(); e.timer_start()
+            for _ in range(reps):
+                e.scan_range_dev(fa, lo << sh, hi << sh, None, 0, n_out)
+            ms_cnt = e.timer_stop() / reps
+            checked += 2
+            ov[name] = {"matches": m, "us": round(ms * 1e3, 2), "bytes_moved": 16 * m, "moved_GBs": round(16.0 * m / (ms * 1e-3) / 1e9, 1),
+                        "position_output_us": round(ms_pos * 1e3, 2), "count_only_us": round(ms_cnt * 1e3, 2),
+                        "speedup_over_the_column_scan": round(out[name]["us"] / (ms * 1e3), 2)}
+        ov["note"] = ("opt-in per index; current while the field is not written (a change makes the next queries scan the column again until the view is re-sorted); "
+                      "matches come in (value, position) order; every timed query verified against numpy like the scans above")
+        out["ordered_view"] = ov
+        out["verified"]["scans_checked"] = checked
+        e.index_set_ordered(fa, 0)                  # off again: what follows measures the maintenance of the plain columns
         del out_pos, id_col
         # index maintenance: a 1M-delta merge on the indexed field (90 % updates of existing nodes, 10 % new nodes), then the first scan — which brings
         # the index up to date from the merge's change log instead of rebuilding it from the table (include/bmx.h "Maintenance")
