@@ -82,6 +82,9 @@ class GpuQuery {
    * index(path, field) as in the reference. opts.source === 'device' indexes the rows that already live on the GPU
    * (ingested through GpuCRT.mergeEntries / mergeBatch under the same (collection, field) hash) instead of uploading the
    * children found in the JS store: the sync -> device -> query flow then never re-sends values.
+   * opts.ordered = N >= 1: the device also keeps a VALUE-ORDERED view of the index — the shape of the reference's own index, a Map keyed by value
+   * (src/bullet-query.js:30-73) —, so equals / range / count cost O(log R + matches) instead of one pass over the column while the field is not written;
+   * a stale view is sorted again by the N-th query after a write (bmx_index_set_ordered). One context only; ignored on a sharded graph.
    */
   index(path, field = null, opts = {}) {
     const key = GpuQuery.keyOf(path, field);
@@ -100,7 +103,7 @@ class GpuQuery {
     ix.kind = "device";
     ix.deviceField = g.keys.fieldOf(ix.path, ix.field);
     g.indexBuild(ix.deviceField);
-    if (ix.ordered && typeof g.indexSetOrdered === "function") g.indexSetOrdered(ix.deviceField, ix.ordered);   // opts.ordered: the device keeps a value-ordered view too
+    if (ix.ordered && typeof g.indexSetOrdered === "function") g.indexSetOrdered(ix.deviceField, 2 * ix.ordered);   // opts.ordered: the device keeps a value-ordered view too (a query here = a count + a fetch on the device)
     ix.paths = null; ix.values = null; ix.stale = false; ix.dirty = null; ix.rank = null; ix._posByPath = null;
   }
 
@@ -158,6 +161,7 @@ class GpuQuery {
     for (let i = 0; i < n; i++) cols.set(i, g.keys.idOf(ix.paths[i]), ix.deviceField, 1, ix.values[i]);
     g.loadRows(cols);
     g.indexBuild(ix.deviceField);
+    if (ix.ordered && typeof g.indexSetOrdered === "function") g.indexSetOrdered(ix.deviceField, 2 * ix.ordered);   // opts.ordered: value-ordered view on the device (bmx_index_set_ordered)
     ix.seq = 1;                                 // ts of the device rows of this build; patches use 2, 3, ...
   }
 

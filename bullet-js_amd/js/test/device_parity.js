@@ -402,6 +402,44 @@ for (const [fixture, batchPuts, minDevice, minHost] of [["g9_sync_node_semantics
   checks += 9;
 }
 
+/* the same device-sourced index with a VALUE-ORDERED VIEW on the device (opts.ordered: bmx_index_set_ordered — the reference's index is a Map keyed by
+ * value, src/bullet-query.js:30-73): equals / range / count answer from a sorted copy of the column while nobody writes the field, scan again right after a
+ * write, and re-sort by the second query after it. Same answers as the plain index whichever path replied; both store-sourced and device-sourced kinds. */
+{
+  const b = new MiniBullet("w");
+  const { crt, query } = attach(b, { capacityRows: 8192 });
+  const entries = [];
+  for (let i = 0; i < 2000; i++) entries.push({ path: "ov/n" + i, data: { age: (i * 7) % 90, score: 3000 - i }, vectorClock: { w: 10 } });
+  crt.mergeEntries(entries, { insertMode: "delta", apply: true });
+  query.index("ov", "age", { source: "device", ordered: 2 });
+  const f = crt.graph.keys.fieldOf("ov", "age");
+  const keys = (nodes) => nodes.map((n) => n.path.split("/").pop()).sort();
+  const wantAge = (lo, hi) => { const o = []; for (let i = 0; i < 2000; i++) { const a = b.store.ov["n" + i] && b.store.ov["n" + i].age; if (a >= lo && a <= hi) o.push("n" + i); } if (b.store.ov.extra && b.store.ov.extra.age >= lo && b.store.ov.extra.age <= hi) o.push("extra"); return o.sort(); };
+  assert.deepStrictEqual(keys(query.equals("ov", "age", 35)), wantAge(35, 35));          // query 1 since the build: the column scan
+  assert.strictEqual(crt.graph.indexOrderedInfo(f).valid, 0);
+  assert.deepStrictEqual(keys(query.range("ov", "age", 10, 12)), wantAge(10, 12));       // query 2: the view is sorted
+  let info = crt.graph.indexOrderedInfo(f);
+  assert.ok(info.valid === 1 && info.sorts === 1 && info.afterQueries === 4, JSON.stringify(info));   // (a query here is a count + a fetch on the device)
+  for (const [lo, hi] of [[0, 0], [0, 89], [89, 89], [40, 60], [-5, 2], [90, 200]]) assert.deepStrictEqual(keys(query.range("ov", "age", lo, hi)), wantAge(lo, hi));
+  assert.strictEqual(query.count("ov", "age", 35), wantAge(35, 35).length);
+  assert.strictEqual(crt.graph.indexOrderedInfo(f).sorts, 1);                            // all from the one sort
+  crt.mergeEntries([{ path: "ov/n5", data: { age: 88 }, vectorClock: { w: 12 } }, { path: "ov/extra", data: { age: 35 }, vectorClock: { w: 12 } }], { insertMode: "delta", apply: true });
+  assert.deepStrictEqual(keys(query.equals("ov", "age", 35)), wantAge(35, 35));          // right after the write: scanned (the view is stale), and "extra" is there
+  assert.strictEqual(crt.graph.indexOrderedInfo(f).valid, 0);
+  assert.deepStrictEqual(keys(query.equals("ov", "age", 88)), wantAge(88, 88));          // second query after the write: sorted again
+  info = crt.graph.indexOrderedInfo(f);
+  assert.ok(info.valid === 1 && info.sorts === 2, JSON.stringify(info));
+  assert.deepStrictEqual(keys(query.range("ov", "age", 30, 40)), wantAge(30, 40));
+  crt.graph.indexSetOrdered(f, 0);
+  assert.deepStrictEqual(keys(query.range("ov", "age", 30, 40)), wantAge(30, 40));
+  // a store-sourced index (position output) over the same rows, ordered view on: the reference's result ORDER is rebuilt on the host from any order
+  query.index("ov", "score", { ordered: 1 });
+  const want = []; for (let i = 0; i < 2000; i++) { const n = b.store.ov["n" + i]; if (n && n.score >= 2900 && n.score <= 2950) want.push("ov/n" + i); }
+  assert.deepStrictEqual(query.range("ov", "score", 2900, 2950).map((n) => n.path).sort(), want.sort());
+  b.close();
+  checks += 20;
+}
+
 /* write-through: what the host path decides (local puts, deletions) reaches the device before the next batch is resolved — node level */
 {
   const b = new MiniBullet("w");
