@@ -31,7 +31,7 @@ EXPORTS = [
     "bmx_index_build", "bmx_index_drop", "bmx_index_size", "bmx_index_refresh_counts", "bmx_index_set_ordered", "bmx_index_ordered_info", "bmx_scan_range", "bmx_scan_equals", "bmx_scan_count", "bmx_scan_filter", "bmx_scan_range_pos", "bmx_index_ids",
     "bmx_owner_of", "bmx_partition_by_owner", "bmx_partition_by_owner_slabs", "bmx_partition_scatter", "bmx_merge_records_after", "bmx_ipc_alloc", "bmx_ipc_open", "bmx_ipc_close", "bmx_ipc_free", "bmx_seq_wait_all", "bmx_merge_tail_wait", "bmx_merge_notify", "bmx_timer_start", "bmx_timer_stop", "bmx_timer_mark", "bmx_timer_elapsed", "bmx_profile_enable", "bmx_profile_read", "bmx_profile_read_scan",
     "bmx_comm_create", "bmx_comm_destroy", "bmx_comm_last_error", "bmx_comm_nshards", "bmx_comm_shard", "bmx_comm_sync", "bmx_comm_load_rows", "bmx_comm_put_rows", "bmx_comm_merge",
-    "bmx_comm_merge_dev", "bmx_comm_shard_result", "bmx_comm_row_count", "bmx_comm_get_rows", "bmx_comm_dump_rows", "bmx_comm_index_build",
+    "bmx_comm_merge_dev", "bmx_comm_shard_result", "bmx_comm_row_count", "bmx_comm_get_rows", "bmx_comm_dump_rows", "bmx_comm_index_build", "bmx_comm_index_set_ordered",
     "bmx_comm_scan_range", "bmx_comm_scan_equals", "bmx_comm_scan_count", "bmx_comm_scan_filter",
     "bmx_vc_create", "bmx_vc_destroy", "bmx_vc_last_error", "bmx_vc_load_rows", "bmx_vc_merge_batch", "bmx_vc_get_rows", "bmx_vc_row_count", "bmx_vc_scan_range", "bmx_vc_merge_batch_dev", "bmx_vc_set_stream", "bmx_vc_sync",
     "bmx_vc_load_rows_ks", "bmx_vc_merge_batch_ks", "bmx_vc_get_rows_ks", "bmx_vc_merge_batch_ks_dev", "bmx_vc_keyset", "bmx_vc_keyset_dense",
@@ -160,6 +160,7 @@ def load_library():
     L.bmx_comm_get_rows.argtypes = [vp, u64, vp, vp, vp, vp, vp]; L.bmx_comm_get_rows.restype = i32
     L.bmx_comm_dump_rows.argtypes = [vp, u64, vp, vp, vp, vp, C.POINTER(u64)]; L.bmx_comm_dump_rows.restype = i32
     L.bmx_comm_index_build.argtypes = [vp, u32]; L.bmx_comm_index_build.restype = i32
+    L.bmx_comm_index_set_ordered.argtypes = [vp, u32, u32]; L.bmx_comm_index_set_ordered.restype = i32
     L.bmx_comm_scan_range.argtypes = [vp, u32, i64, i64, vp, u64, C.POINTER(u64)]; L.bmx_comm_scan_range.restype = i32
     L.bmx_comm_scan_equals.argtypes = [vp, u32, i64, vp, u64, C.POINTER(u64)]; L.bmx_comm_scan_equals.restype = i32
     L.bmx_comm_scan_count.argtypes = [vp, u32, i64, i64, C.POINTER(u64)]; L.bmx_comm_scan_count.restype = i32
@@ -671,6 +672,9 @@ class Comm:
 
     def index_build(self, field):
         self._chk(self.L.bmx_comm_index_build(self.h, int(field)))
+
+    def index_set_ordered(self, field, after_queries=1):
+        self._chk(self.L.bmx_comm_index_set_ordered(self.h, int(field), int(after_queries)))
 
     def scan_count(self, field, lo, hi):
         m = C.c_uint64()

@@ -70,8 +70,12 @@ class DeviceGraph {
   indexBuild(f) { if (this.preOp) this.preOp(); return this.comm ? this.native.commIndexBuild(this.comm, f) : this.native.indexBuild(this.handle, f); }
   indexDrop(f) { return this.comm ? this.native.commIndexDrop(this.comm, f) : this.native.indexDrop(this.handle, f); }
   /* value-ordered view of the index on field f (bmx_index_set_ordered): equals / range answer in O(log R + matches) while the field is not written;
-   * afterQueries: the view is sorted again by that many queries after a change (0 = off). One context only: a sharded graph keeps scanning. */
-  indexSetOrdered(f, afterQueries = 2) { if (this.comm) return false; if (this.preOp) this.preOp(); this.native.indexSetOrdered(this.handle, f, afterQueries >>> 0); return true; }
+   * afterQueries: the view is sorted again by that many queries after a change (0 = off). On a sharded graph every shard keeps its own view. */
+  indexSetOrdered(f, afterQueries = 2) {
+    if (this.preOp) this.preOp();
+    if (this.comm) this.native.commIndexSetOrdered(this.comm, f, afterQueries >>> 0); else this.native.indexSetOrdered(this.handle, f, afterQueries >>> 0);
+    return true;
+  }
   indexOrderedInfo(f) { return this.comm ? null : this.native.indexOrderedInfo(this.handle, f); }
   indexSize(f) { if (this.preOp) this.preOp(); return this.comm ? this.native.commIndexSize(this.comm, f) : this.native.indexSize(this.handle, f); }
   /* {fullBuilds, incremental}: index rebuilds from the table vs updates from the merges' change log (one context only) */

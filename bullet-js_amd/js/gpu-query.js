@@ -84,7 +84,7 @@ class GpuQuery {
    * children found in the JS store: the sync -> device -> query flow then never re-sends values.
    * opts.ordered = N >= 1: the device also keeps a VALUE-ORDERED view of the index — the shape of the reference's own index, a Map keyed by value
    * (src/bullet-query.js:30-73) —, so equals / range / count cost O(log R + matches) instead of one pass over the column while the field is not written;
-   * a stale view is sorted again by the N-th query after a write (bmx_index_set_ordered). One context only; ignored on a sharded graph.
+   * a stale view is sorted again by the N-th query after a write (bmx_index_set_ordered); on a sharded graph every shard keeps its own.
    */
   index(path, field = null, opts = {}) {
     const key = GpuQuery.keyOf(path, field);

@@ -922,6 +922,15 @@ napi_value CommDumpRows(napi_env env, napi_callback_info info) {
   napi_set_named_property(env, out, "ts", c); napi_set_named_property(env, out, "val", d);
   return out;
 }
+napi_value CommIndexSetOrdered(napi_env env, napi_callback_info info) {
+  ARGS(3);
+  CommHandle* h; if (!get_comm(env, argv[0], &h)) return nullptr;
+  std::lock_guard<std::mutex> g(h->mu);
+  uint32_t f, n; NAPI_OK(napi_get_value_uint32(env, argv[1], &f)); NAPI_OK(napi_get_value_uint32(env, argv[2], &n));
+  int rc = bmx_comm_index_set_ordered(h->c, f, n);
+  if (rc) return throw_comm(env, h->c, rc);
+  return nullptr;
+}
 napi_value CommIndexBuild(napi_env env, napi_callback_info info) {
   ARGS(2);
   CommHandle* h; if (!get_comm(env, argv[0], &h)) return nullptr;
@@ -1003,7 +1012,7 @@ napi_value Init(napi_env env, napi_value exports) {
       {"indexSize", IndexSize}, {"indexRefreshCounts", IndexRefreshCounts}, {"scanRange", ScanRange}, {"scanCount", ScanCount}, {"scanFilter", ScanFilter}, {"info", Info},
       {"vcCreate", VcCreate}, {"vcDestroy", VcDestroy}, {"vcLoadRows", VcLoadRows}, {"vcMergeBatch", VcMergeBatch}, {"vcMergeBatchAsync", VcMergeBatchAsync}, {"vcGetRows", VcGetRows}, {"vcRowCount", VcRowCount}, {"vcScanRange", VcScanRange}, {"ownersOf", OwnersOf},
       {"commCreate", CommCreate}, {"commDestroy", CommDestroy}, {"commMergeBatch", CommMergeBatch}, {"commLoadRows", CommLoadRows}, {"commGetRows", CommGetRows},
-      {"commRowCount", CommRowCount}, {"commDumpRows", CommDumpRows}, {"commIndexBuild", CommIndexBuild}, {"commIndexDrop", CommIndexDrop}, {"commIndexSize", CommIndexSize},
+      {"commRowCount", CommRowCount}, {"commDumpRows", CommDumpRows}, {"commIndexBuild", CommIndexBuild}, {"commIndexSetOrdered", CommIndexSetOrdered}, {"commIndexDrop", CommIndexDrop}, {"commIndexSize", CommIndexSize},
       {"commScanRange", CommScanRange}, {"commScanCount", CommScanCount}, {"commScanFilter", CommScanFilter}};
   for (auto& f : fns) {
     napi_value v;

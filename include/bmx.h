@@ -376,6 +376,7 @@ int bmx_comm_row_count(bmx_comm* comm, uint64_t* n_out);
 int bmx_comm_get_rows(bmx_comm* comm, uint64_t n, const uint64_t* id, const uint32_t* field, int64_t* ts, int64_t* val, uint8_t* found);
 int bmx_comm_dump_rows(bmx_comm* comm, uint64_t cap, uint64_t* id, uint32_t* field, int64_t* ts, int64_t* val, uint64_t* n_out);
 int bmx_comm_index_build(bmx_comm* comm, uint32_t field);
+int bmx_comm_index_set_ordered(bmx_comm* comm, uint32_t field, uint32_t after_queries);   /* bmx_index_set_ordered on every shard (results: shard by shard, each in (value, position) order) */
 int bmx_comm_scan_range(bmx_comm* comm, uint32_t field, int64_t lo, int64_t hi, uint64_t* out_ids, uint64_t cap, uint64_t* n_out);
 int bmx_comm_scan_equals(bmx_comm* comm, uint32_t field, int64_t value, uint64_t* out_ids, uint64_t cap, uint64_t* n_out);
 int bmx_comm_scan_count(bmx_comm* comm, uint32_t field, int64_t lo, int64_t hi, uint64_t* n_out);

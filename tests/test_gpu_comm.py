@@ -121,6 +121,28 @@ def test_shards_grow_and_keep_indexes_fresh():
         assert rows_digest(*c.dump_rows()) == o.digest()
 
 
+@pytest.mark.parametrize("N", [1, 3])
+def test_value_ordered_views_on_every_shard(N):
+    """bmx_comm_index_set_ordered: every shard answers from its own sorted copy of the index; the union equals the oracle's scan before and after merges
+    that change the field (the queries right after a merge scan the columns, the later ones sort again)."""
+    o = Oracle()
+    with bmx.Comm([0] * N, capacity_rows_per_shard=200_000) as c:
+        f0 = int(synth.field_hash(0))
+        res = synth.big_resident(120_000, seed=5)
+        c.merge(*res); o.merge_batch(*res)
+        c.index_build(f0)
+        c.index_set_ordered(f0, 2)
+        for b in range(3):
+            for lo, hi in [(-(1 << 28), 1 << 28), (0, 1 << 30), (-(1 << 40), 1 << 40), (5, 4), (12345, 12345)] * 2:
+                got = np.sort(c.scan_range(f0, lo, hi)); want = np.sort(o.scan_range(f0, lo, hi))
+                assert np.array_equal(got, want), (b, lo, hi)
+                assert c.scan_count(f0, lo, hi) == len(want)
+            d = synth.big_deltas(30_000, 120_000, seed=6, insert_pct=20, hot_pct=10, hot_keys=50, unique=False, batch=b)
+            applied, st = c.merge(*d)
+            _, ow = o.merge_batch(*d)
+            assert np.array_equal(applied, ow), b
+
+
 @pytest.mark.parametrize("N", [1, 3, 8])
 def test_small_host_batches_are_routed_on_the_host(N):
     """Batches of up to 32768 deltas take the host-routed path (owner per delta on the CPU, each shard's small-batch merge): same winners, in the
