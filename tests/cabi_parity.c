@@ -77,6 +77,20 @@ int main(void) {
   qsort(a, m, 8, cmp_u64); qsort(b2, mw, 8, cmp_u64);
   CHECK(memcmp(a, b2, 8 * m) == 0);
   uint64_t c = 0; CHECK(bmx_scan_count(ctx, F, 7, 7, &c, BMX_MEM_HOST) == BMX_OK && c == orc_scan_range(o, F, 7, 7, NULL, 0));
+  /* the same queries through the value-ordered view of the index (bmx_index_set_ordered): same sets, same counts */
+  {
+    uint32_t after = 0; int valid = 0; uint64_t sorts = 0;
+    CHECK(bmx_index_set_ordered(ctx, F, 1) == BMX_OK);
+    CHECK(bmx_scan_range(ctx, F, -100, 250, a, cap, &m, BMX_MEM_HOST) == BMX_OK && m == mw);
+    qsort(a, m, 8, cmp_u64);
+    CHECK(memcmp(a, b2, 8 * m) == 0);
+    CHECK(bmx_index_ordered_info(ctx, F, &after, &valid, &sorts) == BMX_OK && after == 1 && valid == 1 && sorts == 1);
+    CHECK(bmx_scan_count(ctx, F, 7, 7, &c, BMX_MEM_HOST) == BMX_OK && c == orc_scan_range(o, F, 7, 7, NULL, 0));
+    CHECK(bmx_scan_count(ctx, F, 5, 4, &c, BMX_MEM_HOST) == BMX_OK && c == 0);
+    CHECK(bmx_index_set_ordered(ctx, F, 0) == BMX_OK);
+    CHECK(bmx_index_ordered_info(ctx, F, &after, &valid, &sorts) == BMX_OK && after == 0 && valid == 0);
+    CHECK(bmx_index_ordered_info(ctx, F + 12345, &after, &valid, &sorts) == BMX_ERR_INVALID);
+  }
   /* errors are codes + text, never aborts */
   uint64_t badid = ~0ULL; uint32_t bf = F; int64_t bt = 1, bv = 1;
   CHECK(bmx_merge_batch(ctx, 1, &badid, &bf, &bt, &bv, BMX_INSERT_REFERENCE, BMX_MEM_HOST, NULL, NULL, NULL, NULL) == BMX_ERR_RANGE);

@@ -124,6 +124,15 @@ def test_the_view_follows_every_change_of_its_field_and_nothing_else():
             for lo, hi in [(0, 0), (0, 299), (299, 299), (120, 180), (-5, 3)]:
                 _check(e, FA, ids, vals, lo, hi, alive)
             assert e.index_ordered_info(FA) == (2, True, s0 + 1)
+        # a value that does not fit int32 arrives: the index switches to its 8-byte column, and the view is sorted from THAT
+        k = rng.choice(R, 3, replace=False)
+        wide = np.array([1 << 40, -(1 << 41), (1 << 31)], np.int64)
+        e.merge_batch(ids[k], np.full(3, FA, np.uint32), np.full(3, 50_000, np.int64), wide)
+        vals[k] = wide; alive[k] = True
+        _q(e, FA, ids, vals, 0, 299, alive); _q(e, FA, ids, vals, 0, 299, alive)
+        assert e.index_ordered_info(FA)[1]
+        for lo, hi in [(1 << 40, 1 << 40), (-(1 << 42), -1), (1 << 31, 1 << 31), (250, 1 << 41), (0, 10)]:
+            _check(e, FA, ids, vals, lo, hi, alive)
         # a table growth rebuilds the index (positions renumbered): the view goes with it
         e.reserve(16 * R)
         s0 = e.index_ordered_info(FA)[2]
