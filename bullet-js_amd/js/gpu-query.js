@@ -85,11 +85,12 @@ class GpuQuery {
    * opts.ordered = N >= 1: the device also keeps a VALUE-ORDERED view of the index — the shape of the reference's own index, a Map keyed by value
    * (src/bullet-query.js:30-73) —, so equals / range / count cost O(log R + matches) instead of one pass over the column while the field is not written;
    * a stale view is sorted again by the N-th query after a write (bmx_index_set_ordered); on a sharded graph every shard keeps its own.
+   * attach(bullet, {orderedIndexes: N}) makes N the default for every index of this engine (the reference's own calls pass no options).
    */
   index(path, field = null, opts = {}) {
     const key = GpuQuery.keyOf(path, field);
     if (this.indices[key]) return this;
-    this.indices[key] = { path, field, stale: true, dirty: null, kind: null, source: opts.source === "device" ? "device" : "store", ordered: opts.ordered >>> 0 };
+    this.indices[key] = { path, field, stale: true, dirty: null, kind: null, source: opts.source === "device" ? "device" : "store", ordered: (opts.ordered !== undefined ? opts.ordered : this._opts.orderedIndexes) >>> 0 };
     this.indexedPaths.add(path);
     if (!this._byBase.has(path)) this._byBase.set(path, []);
     this._byBase.get(path).push(this.indices[key]);

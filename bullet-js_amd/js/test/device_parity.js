@@ -433,9 +433,11 @@ for (const [fixture, batchPuts, minDevice, minHost] of [["g9_sync_node_semantics
   crt.graph.indexSetOrdered(f, 0);
   assert.deepStrictEqual(keys(query.range("ov", "age", 30, 40)), wantAge(30, 40));
   // a store-sourced index (position output) over the same rows, ordered view on: the reference's result ORDER is rebuilt on the host from any order
-  query.index("ov", "score", { ordered: 1 });
+  query._opts.orderedIndexes = 1;                               // what attach(bullet, {orderedIndexes: 1}) sets: the default of every index built from here on
+  query.index("ov", "score");
   const want = []; for (let i = 0; i < 2000; i++) { const n = b.store.ov["n" + i]; if (n && n.score >= 2900 && n.score <= 2950) want.push("ov/n" + i); }
   assert.deepStrictEqual(query.range("ov", "score", 2900, 2950).map((n) => n.path).sort(), want.sort());
+  assert.strictEqual(crt.graph.indexOrderedInfo(query.indices["ov:score"].deviceField).afterQueries, 2);
   b.close();
   checks += 20;
 }
