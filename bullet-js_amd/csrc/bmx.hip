@@ -57,6 +57,7 @@ struct Index {
   // value-ordered view (bmx.h bmx_index_set_ordered): the columns once more, sorted by (value, position)
   uint32_t ordered_after = 0;     // 0 = off; N: a stale view is sorted again by the N-th query since the columns last changed
   uint32_t stale_queries = 0;
+  double last_sort_us = 0;        // what the last sort of the view cost the caller (BMX_INDEX_ORDERED_AUTO weighs it against the scans it saves)
   uint64_t ord_content = ~0ull;   // `content` the view was sorted from
   uint64_t ord_n = 0, ord_cap = 0, ord_sorts = 0;
   bool ord_fits32 = false;
@@ -1010,7 +1011,16 @@ constexpr uint64_t SCAN_NT_BYTES = 256ull << 20;
 bool ensure_ordered_view(bmx_ctx* ctx, Index* ix) {
   if (!ix->ordered_after || ix->n == 0 || ix->n > 0xFFFFFFFFull) return false;
   if (ix->ord_content == ix->content && ix->s_val) return true;
-  if (++ix->stale_queries < ix->ordered_after) return false;
+  uint32_t after = ix->ordered_after;
+  if (after == BMX_INDEX_ORDERED_AUTO) {
+    // rent or buy: sort once the scans answered since the change have cost what a sort costs — then whatever the caller does next, at most twice
+    // the best possible was spent. A scan moves the value column at ~6 TB/s (+ two launches); a sort costs what the last one cost (first time: 60 us per 10^6 rows).
+    const double scan_us = 8.0 + (double)ix->n * (ix->fits32 ? 4.0 : 8.0) / 6.0e6;
+    const double sort_us = ix->last_sort_us > 0 ? ix->last_sort_us : 200.0 + (double)ix->n * 0.00006;
+    after = (uint32_t)std::min<double>(1.0e6, std::max<double>(2.0, std::ceil(sort_us / scan_us)));
+  }
+  if (++ix->stale_queries < after) return false;
+  const auto t_sort = std::chrono::steady_clock::now();
   const uint64_t n = ix->n;
   const size_t vb = ix->fits32 ? sizeof(int32_t) : sizeof(int64_t);
   auto give_up = [&]() { (void)hipGetLastError(); free_ordered_view(*ix); ix->stale_queries = 0; return false; };
@@ -1037,6 +1047,7 @@ bool ensure_ordered_view(bmx_ctx* ctx, Index* ix) {
   (void)hipFree(iota); (void)hipFree(tmp);
   if (e != hipSuccess) return give_up();
   ix->ord_n = n; ix->ord_content = ix->content; ix->stale_queries = 0; ix->ord_sorts++;
+  ix->last_sort_us = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t_sort).count();
   return true;
 }
 // the query itself: two searches + one contiguous copy; lo/hi are already clamped like the scans' (tombstones sort in front of every legal value)

@@ -27,6 +27,9 @@ const { Columns, fieldId, isDeviceInt } = require("./hash");
 
 function bucketKey(v) { return (typeof v === "object" && v !== null) ? JSON.stringify(v) : String(v); }
 
+const ORDERED_AUTO = 0xffffffff;      // BMX_INDEX_ORDERED_AUTO: the engine weighs a sort against the scans it saves
+const orderedOpt = (v) => (v === "auto" ? ORDERED_AUTO : v >>> 0);
+
 class GpuQuery {
   /** @param {object} bullet @param {object} [opts] { graph: DeviceGraph shared with GpuCRT, device, capacityRows } */
   constructor(bullet, opts = {}) {
@@ -82,7 +85,7 @@ class GpuQuery {
    * index(path, field) as in the reference. opts.source === 'device' indexes the rows that already live on the GPU
    * (ingested through GpuCRT.mergeEntries / mergeBatch under the same (collection, field) hash) instead of uploading the
    * children found in the JS store: the sync -> device -> query flow then never re-sends values.
-   * opts.ordered = N >= 1: the device also keeps a VALUE-ORDERED view of the index — the shape of the reference's own index, a Map keyed by value
+   * opts.ordered = N >= 1 or "auto" (the engine sorts once the scans since the last write have cost what a sort costs): the device also keeps a VALUE-ORDERED view of the index — the shape of the reference's own index, a Map keyed by value
    * (src/bullet-query.js:30-73) —, so equals / range / count cost O(log R + matches) instead of one pass over the column while the field is not written;
    * a stale view is sorted again by the N-th query after a write (bmx_index_set_ordered); on a sharded graph every shard keeps its own.
    * attach(bullet, {orderedIndexes: N}) makes N the default for every index of this engine (the reference's own calls pass no options).
@@ -90,7 +93,7 @@ class GpuQuery {
   index(path, field = null, opts = {}) {
     const key = GpuQuery.keyOf(path, field);
     if (this.indices[key]) return this;
-    this.indices[key] = { path, field, stale: true, dirty: null, kind: null, source: opts.source === "device" ? "device" : "store", ordered: (opts.ordered !== undefined ? opts.ordered : this._opts.orderedIndexes) >>> 0 };
+    this.indices[key] = { path, field, stale: true, dirty: null, kind: null, source: opts.source === "device" ? "device" : "store", ordered: orderedOpt(opts.ordered !== undefined ? opts.ordered : this._opts.orderedIndexes) };
     this.indexedPaths.add(path);
     if (!this._byBase.has(path)) this._byBase.set(path, []);
     this._byBase.get(path).push(this.indices[key]);
@@ -104,7 +107,7 @@ class GpuQuery {
     ix.kind = "device";
     ix.deviceField = g.keys.fieldOf(ix.path, ix.field);
     g.indexBuild(ix.deviceField);
-    if (ix.ordered && typeof g.indexSetOrdered === "function") g.indexSetOrdered(ix.deviceField, 2 * ix.ordered);   // opts.ordered: the device keeps a value-ordered view too (a query here = a count + a fetch on the device)
+    if (ix.ordered && typeof g.indexSetOrdered === "function") g.indexSetOrdered(ix.deviceField, ix.ordered === ORDERED_AUTO ? ORDERED_AUTO : 2 * ix.ordered);   // opts.ordered: the device keeps a value-ordered view too (a query here = a count + a fetch on the device)
     ix.paths = null; ix.values = null; ix.stale = false; ix.dirty = null; ix.rank = null; ix._posByPath = null;
   }
 
@@ -162,7 +165,7 @@ class GpuQuery {
     for (let i = 0; i < n; i++) cols.set(i, g.keys.idOf(ix.paths[i]), ix.deviceField, 1, ix.values[i]);
     g.loadRows(cols);
     g.indexBuild(ix.deviceField);
-    if (ix.ordered && typeof g.indexSetOrdered === "function") g.indexSetOrdered(ix.deviceField, 2 * ix.ordered);   // opts.ordered: value-ordered view on the device (bmx_index_set_ordered)
+    if (ix.ordered && typeof g.indexSetOrdered === "function") g.indexSetOrdered(ix.deviceField, ix.ordered === ORDERED_AUTO ? ORDERED_AUTO : 2 * ix.ordered);   // opts.ordered: value-ordered view on the device (bmx_index_set_ordered)
     ix.seq = 1;                                 // ts of the device rows of this build; patches use 2, 3, ...
   }
 

@@ -157,3 +157,21 @@ def test_small_and_degenerate_columns():
         _check(e, FS, one, np.array([-(1 << 40)], np.int64), -(1 << 41), 0)
         _check(e, FS, one, np.array([-(1 << 40)], np.int64), 0, 5)
         assert e.index_ordered_info(FS)[1]
+
+
+def test_auto_policy_sorts_once_the_scans_have_cost_a_sort():
+    """BMX_INDEX_ORDERED_AUTO: rent or buy — a 400k-row int32 column scans in ~8.3 us, its first sort is priced at 224 us: the 28th query since the change sorts"""
+    R = 400_000
+    rng = np.random.default_rng(5)
+    ids = streams.splitmix64_np(np.arange(1, R + 1, dtype=np.uint64))
+    vals = rng.integers(0, 1000, R).astype(np.int64)
+    with bmx.Engine(2 * R) as e:
+        e.load_rows(ids, np.full(R, FA, np.uint32), np.full(R, 5, np.int64), vals)
+        e.index_build(FA)
+        e.index_set_ordered(FA, 0xFFFFFFFF)
+        for i in range(27):
+            _q(e, FA, ids, vals, i, i + 10)
+        assert e.index_ordered_info(FA) == (0xFFFFFFFF, False, 0)
+        _q(e, FA, ids, vals, 5, 50)
+        assert e.index_ordered_info(FA) == (0xFFFFFFFF, True, 1)
+        _check(e, FA, ids, vals, 100, 300)
