@@ -175,3 +175,24 @@ def test_auto_policy_sorts_once_the_scans_have_cost_a_sort():
         _q(e, FA, ids, vals, 5, 50)
         assert e.index_ordered_info(FA) == (0xFFFFFFFF, True, 1)
         _check(e, FA, ids, vals, 100, 300)
+
+
+@pytest.mark.parametrize("n", [1, 2, 63, 64, 65, 66, 4095, 4096, 4097, 4161, 262143, 262144, 262145, 266305])
+def test_search_rounds_at_their_boundaries(n):
+    """the 64-ary search narrows [L, R) by a factor of 64 per round and finishes with one wave over <= 64 keys: column sizes on both sides of every
+    round count, values with long runs of duplicates, every bound from below the smallest to above the largest value"""
+    rng = np.random.default_rng(n)
+    ids = streams.splitmix64_np(np.arange(1, n + 1, dtype=np.uint64))
+    vals = (rng.integers(0, max(2, n // 50), n) * 3).astype(np.int64)           # multiples of 3: keys between the values exist too
+    with bmx.Engine(max(4096, 2 * n)) as e:
+        e.load_rows(ids, np.full(n, FA, np.uint32), np.full(n, 5, np.int64), vals)
+        e.index_build(FA); e.index_set_ordered(FA, 1)
+        top = int(vals.max())
+        keys = sorted(set([-4, -1, 0, 1, 2, 3, top - 1, top, top + 1, top + 7] + rng.integers(-3, top + 4, 24).tolist()))
+        for lo in keys[::3]:
+            for hi in keys[::2]:
+                want = int(((vals >= lo) & (vals <= hi)).sum())
+                assert e.scan_count(FA, lo, hi) == want, (n, lo, hi)
+        for lo, hi in [(0, top), (3, 3), (top, top), (1, 2), (top + 1, top + 9)]:
+            _q(e, FA, ids, vals, lo, hi)
+        assert e.index_ordered_info(FA)[1:] == (True, 1)
