@@ -169,17 +169,37 @@ def js_host_rate():
     node = shutil.which("node")
     if not node:
         return None
+    # The host-bound figures depend on where the one node thread and its memory sit: on a two-socket box the scheduler moves it between the sockets and
+    # the store-kept seam swings between 0.46 and 0.66 M entries/s; kept on the cores of ONE NUMA node (the one this process runs on) it stays at
+    # 0.62-0.69 (profiles/r04_e2e_apply.log). taskset only, and only when the topology can be read; said in the line (`cpus`).
+    pin, cpus = [], None
+    try:
+        here = int(open("/proc/self/stat").read().rsplit(")", 1)[1].split()[36])      # field 39: the CPU this thread last ran on
+        if shutil.which("taskset") and here is not None:
+            import glob
+            for d in sorted(glob.glob("/sys/devices/system/node/node[0-9]*")):
+                cl = open(os.path.join(d, "cpulist")).read().strip()
+                ids = set()
+                for part in cl.split(","):
+                    lo, _, hi = part.partition("-")
+                    ids.update(range(int(lo), int(hi or lo) + 1))
+                if here in ids and len(ids) < (os.cpu_count() or 0):      # (one node = the whole machine: nothing to pin)
+                    pin, cpus = ["taskset", "-c", cl], "%s: CPUs %s" % (os.path.basename(d), cl)
+                    break
+    except Exception:
+        pin, cpus = [], None
     try:
         script = os.path.join(ROOT, "bullet-js_amd", "js", "test", "e2e_rate.js")
-        r = subprocess.run([node, script, "1000000", "500000", "8"], capture_output=True, text=True, timeout=240)
+        r = subprocess.run(pin + [node, script, "1000000", "500000", "8"], capture_output=True, text=True, timeout=240)
         j = json.loads(r.stdout.strip().splitlines()[-1])
         for key in ("apply", "vector"):      # one process each: a 4M-entry run of every section at once does not fit node 12's default heap
             try:
-                r2 = subprocess.run([node, script, "1000000", "200000", "5", "only", key], capture_output=True, text=True, timeout=300)
+                r2 = subprocess.run(pin + [node, script, "1000000", "200000", "5", "only", key], capture_output=True, text=True, timeout=300)
                 j2 = json.loads(r2.stdout.strip().splitlines()[-1])
                 j["applied_path" if key == "apply" else "vector"] = j2["applied_path" if key == "apply" else "vector"]
             except Exception as e:
                 j["applied_path" if key == "apply" else "vector"] = {"error": str(e)[:200]}
+        j["cpus"] = cpus or "not pinned"
         j["applied_path_sample"] = "the real ingestion seam with the STORE KEPT: attach(bullet, {batchSync}) -> processSyncEntries over 5 chunks of 200k sync entries against 1M resident nodes (90 % updates, 10 % new nodes): every winner replaces its node in the nested store, meta[path] gets its clock, the op log and the put queue are fed (src/bullet.js:184-266 per batch); beside it the same entries one by one through setData and the host resolver (the reference's loop body)"
         j["vector_sample"] = "5 chunks of 200k entries under clocks over ordered subsets of three writers (N4): nodes' clock rows in the device's vector-clock table, synchronous GpuCRT.mergeEntries"
         j["sample"] = "8 chunks of 500k sync entries (10 % new nodes) against 1M resident nodes per figure, node-level resolution (one clock-row delta per entry + the winners' value rows); GpuCRT.mergeEntries (synchronous), GpuCRT.mergeEntriesPipelined (mergeEntriesAsync, two chunks in flight) and GpuCRT.mergeBatch (typed columns) over the N-API addon, page-locked host columns"
