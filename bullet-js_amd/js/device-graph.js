@@ -228,3 +228,4 @@ class DeviceVcTable {
 
 module.exports = DeviceGraph;
 module.exports.DeviceVcTable = DeviceVcTable;
+module.exports.WriterIndex = WriterIndex;

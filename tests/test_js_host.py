@@ -35,6 +35,22 @@ def test_addon_builds_and_refuses_without_gpu():
     assert out.returncode == 0 and "addon ok" in out.stdout, out.stdout + out.stderr
 
 
+@needs_node
+def test_writer_index_hands_out_free_components_in_order_of_appearance():
+    """vector-clock mode without a writer list (writers: "auto"): the table's writer index gives a writer nobody named before the next free component,
+    never an integer-like id (a JS object reorders such keys: src/bullet-crt.js:200-203 compares clocks with their key ORDER), never more than the width"""
+    code = ("const { WriterIndex } = require(%r); const { clockKeyset } = require(%r);"
+            "const t = { writers: ['w'], K: 4 }; const ix = new WriterIndex(t); ix.set('w', 0);"
+            "const a = require('assert'); const comps = new Uint32Array(4);"
+            "a.strictEqual(ix.get('w'), 0); a.strictEqual(ix.get('p1'), 1); a.strictEqual(ix.get('p1'), 1); a.strictEqual(ix.get('42'), undefined); a.strictEqual(ix.get(''), undefined);"
+            "a.strictEqual(ix.get('p2'), 2); a.strictEqual(ix.get('p3'), 3); a.strictEqual(ix.get('p4'), undefined); a.deepStrictEqual(t.writers, ['w', 'p1', 'p2', 'p3']);"
+            "const ks = clockKeyset({ p3: 5, w: 2 }, ix, comps); a.ok(ks >= 0); a.deepStrictEqual(Array.from(comps), [2, 0, 0, 5]); a.strictEqual(ks & 0xff, 0x03);"   # key order p3 (3), w (0)
+            "a.strictEqual(clockKeyset({ p9: 1 }, ix, comps), -1); a.strictEqual(clockKeyset({ w: -1 }, ix, comps), -1); console.log('writer index ok');"
+            % (os.path.join(ROOT, "bullet-js_amd", "js", "device-graph.js"), os.path.join(ROOT, "bullet-js_amd", "js", "hash.js")))
+    out = subprocess.run([NODE, "-e", code], capture_output=True, text=True, timeout=60)
+    assert out.returncode == 0 and "writer index ok" in out.stdout, out.stdout + out.stderr
+
+
 @pytest.mark.gpu
 @needs_node
 def test_device_parity_through_napi():
