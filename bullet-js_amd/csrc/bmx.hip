@@ -1052,10 +1052,21 @@ bool ensure_ordered_view(bmx_ctx* ctx, Index* ix) {
 }
 // the query itself: two searches + one contiguous copy; lo/hi are already clamped like the scans' (tombstones sort in front of every legal value)
 template <bool POS, class OutT>
-void launch_ordered(bmx_ctx* ctx, const Index* ix, int64_t lo, int64_t hi, OutT* d_out, uint64_t d_cap, unsigned long long* d_n) {
+void launch_ordered(bmx_ctx* ctx, const Index* ix, int64_t lo, int64_t hi, OutT* d_out, uint64_t d_cap, unsigned long long* d_n, const PredFilter* filter = nullptr) {
   unsigned long long* ab = ctx->ds->ord_ab;
-  if (ix->ord_fits32) hipLaunchKernelGGL((k_ordered_bounds<int32_t>), dim3(1), dim3(128), 0, ctx->stream, static_cast<const int32_t*>(ix->s_val), ix->ord_n, (int32_t)lo, (int32_t)hi, ab, d_n);
-  else hipLaunchKernelGGL((k_ordered_bounds<int64_t>), dim3(1), dim3(128), 0, ctx->stream, static_cast<const int64_t*>(ix->s_val), ix->ord_n, lo, hi, ab, d_n);
+  if (filter && !d_n) d_n = &ctx->ds->n_out;       // (the filter appends through a counter even when nobody asked for the count)
+  if (ix->ord_fits32) {     // the view was sorted from the 4-byte column: bounds clamped into int32 like the scans' (an empty range stays empty)
+    int64_t l = std::max<int64_t>(lo, (int64_t)INT32_MIN + 1), h = std::min<int64_t>(hi, INT32_MAX);
+    if (lo > INT32_MAX || hi < INT32_MIN) { l = 1; h = 0; }
+    hipLaunchKernelGGL((k_ordered_bounds<int32_t>), dim3(1), dim3(128), 0, ctx->stream, static_cast<const int32_t*>(ix->s_val), ix->ord_n, (int32_t)l, (int32_t)h, ab, d_n, filter ? 1u : 0u);
+  } else hipLaunchKernelGGL((k_ordered_bounds<int64_t>), dim3(1), dim3(128), 0, ctx->stream, static_cast<const int64_t*>(ix->s_val), ix->ord_n, lo, hi, ab, d_n, filter ? 1u : 0u);
+  if (filter) {             // every candidate of the run is looked at whatever the caller can take: the count is the number of survivors
+    if constexpr (!POS) {
+      const uint32_t fb = (uint32_t)std::min<uint64_t>((ix->ord_n + 2047) / 2048, 4096);
+      hipLaunchKernelGGL((k_ordered_filter<PredFilter>), dim3(fb), dim3(256), 0, ctx->stream, (const uint64_t*)ix->s_ids, (const unsigned long long*)ab, *filter, d_out, d_out ? d_cap : 0, d_n);
+    }
+    return;
+  }
   if (!d_out || !d_cap) return;
   // the match count is the device's: a grid for the most the caller can take, whose workgroups beyond the matches leave at once
   const uint32_t blocks = (uint32_t)std::min<uint64_t>((std::min<uint64_t>(d_cap, ix->ord_n) + 2047) / 2048, 8192);
@@ -1089,7 +1100,8 @@ int run_scan_t(bmx_ctx* ctx, const Pred& P, const Index* ix, void* out_v, uint64
   hipEvent_t* se = (ctx->prof_on && ctx->scan_prof_n < PROF_MAX_CALLS && !ctx->scan_ev.empty()) ? &ctx->scan_ev[3 * ctx->scan_prof_n] : nullptr;
   if (se) HIPCHK(hipEventRecord(se[0], ctx->stream));
   if (ordered) {
-    launch_ordered<POS>(ctx, ix, olo, ohi, d_out, d_cap, d_n);
+    if constexpr (std::is_same<Pred, PredFilter>::value) launch_ordered<POS>(ctx, ix, olo, ohi, d_out, d_cap, d_n, &P);
+    else launch_ordered<POS>(ctx, ix, olo, ohi, d_out, d_cap, d_n);
     LAUNCHCHK("k_ordered_bounds / k_ordered_copy");
     if (se) HIPCHK(hipEventRecord(se[1], ctx->stream));
   } else if (d_out) {
@@ -1665,6 +1677,8 @@ int bmx_scan_filter(bmx_ctx* ctx, uint32_t nterms, const bmx_term* terms, uint64
   PredFilter P;
   P.v = ix->v64; P.ids = ix->ids; P.slots = ctx->slots; P.nslots = ctx->nslots; P.nterms = nterms;
   for (uint32_t k = 0; k < nterms; k++) { P.t[k] = terms[k]; P.t[k].lo = std::max<int64_t>(terms[k].lo, -VAL_MAX); }   // tombstones (INT64_MIN) match no term
+  // with a value-ordered view of the first term's index: its run is the candidate list, the other terms are probed for those ids only (no order)
+  if ((n_out || out_ids) && ensure_ordered_view(ctx, ix)) return run_scan_t<false>(ctx, P, ix, out_ids, cap, n_out, mem, true, P.t[0].lo, P.t[0].hi);
   return run_scan(ctx, P, ix, out_ids, cap, n_out, mem);
 }
 

@@ -213,6 +213,27 @@ struct PredFilter {
   }
 };
 
+// Declarative filter through the value-ordered view: term 0 selects ONE run of the sorted columns (k_ordered_bounds), the other terms are probed for its ids only —
+// O(log R + candidates) instead of one pass over the column. Survivors are appended as they are found (wave ballot + one atomic per wave): no order.
+template <class PF>
+__global__ __launch_bounds__(256) void k_ordered_filter(const uint64_t* __restrict__ s_ids, const unsigned long long* __restrict__ ab, PF P, uint64_t* __restrict__ out, uint64_t cap,
+                                                        unsigned long long* __restrict__ n_out) {
+  const uint64_t a = ab[0], m = ab[1] - a;
+  const uint64_t rounds = (m + (uint64_t)gridDim.x * 256u - 1) / ((uint64_t)gridDim.x * 256u);
+  for (uint64_t r = 0; r < rounds; r++) {          // (uniform trip count per wave: the ballot below wants every lane there)
+    const uint64_t i = (r * gridDim.x + blockIdx.x) * 256u + threadIdx.x;
+    uint64_t id = 0; bool ok = false;
+    if (i < m) { id = s_ids[a + i]; ok = P.rest(id); }
+    const unsigned long long bal = __ballot(ok);
+    if (bal) {
+      unsigned long long base = 0;
+      if ((threadIdx.x & 63u) == 0) base = atomicAdd(n_out, (unsigned long long)__popcll(bal));
+      base = __shfl(base, 0);
+      if (ok) { const uint64_t pos = base + (uint64_t)__popcll(bal & ((1ull << (threadIdx.x & 63u)) - 1ull)); if (out && pos < cap) out[pos] = id; }
+    }
+  }
+}
+
 struct EmitIds {  // index position -> node id (bounded by cap)
   static constexpr bool STREAMABLE = true;     // dense blocks read their part of the id column as a stream (select.h scan_emit_stream_block)
   const uint64_t* ids; uint64_t* out; uint64_t cap; bool nt = false;   // nt: the id column is larger than the Infinity Cache and read once per scan
@@ -278,7 +299,8 @@ __device__ __forceinline__ uint64_t ordered_bound(const T* __restrict__ v, uint6
 }
 // ab[0] = first match, ab[1] = one past the last; *n_out = matches (optional). An empty range (lo > hi) matches nothing.
 template <class T>
-__global__ __launch_bounds__(128) void k_ordered_bounds(const T* __restrict__ v, uint64_t n, T lo, T hi, unsigned long long* __restrict__ ab, unsigned long long* __restrict__ n_out) {
+__global__ __launch_bounds__(128) void k_ordered_bounds(const T* __restrict__ v, uint64_t n, T lo, T hi, unsigned long long* __restrict__ ab, unsigned long long* __restrict__ n_out,
+                                                        uint32_t zero_count /* the run is only a candidate list (k_ordered_filter counts the matches itself) */) {
   __shared__ unsigned long long sh[2];
   const uint32_t w = threadIdx.x >> 6;
   uint64_t r = 0;
@@ -288,7 +310,7 @@ __global__ __launch_bounds__(128) void k_ordered_bounds(const T* __restrict__ v,
   if (threadIdx.x == 0) {
     const unsigned long long a = sh[0], b = sh[1] < sh[0] ? sh[0] : sh[1];
     ab[0] = a; ab[1] = b;
-    if (n_out) *n_out = b - a;
+    if (n_out) *n_out = zero_count ? 0ull : b - a;
   }
 }
 // out[k] = src[a + k] for k < min(b - a, cap): the matches are one contiguous run of the sorted id (or position) column

@@ -288,7 +288,8 @@ int bmx_index_refresh_counts(bmx_ctx* ctx, uint64_t* full_builds, uint64_t* incr
  * changed a value or added a row of the field (merges on other fields do not touch it). A stale view is sorted again (one radix sort of the column + one
  * gather: milliseconds for 10^8 rows, csrc/ordered_sort.hip) by the N-th query since the change; the N - 1 queries before it scan the column as ever, so a
  * field that is written between any two queries never pays for a sort with N >= 2. N = 0 switches the view off and frees it (3 columns: 16 or 20 bytes per
- * row). If the memory cannot be had the index silently goes on without the view. bmx_index_ordered_info: N, whether the view would answer the next query,
+ * row). bmx_scan_filter takes its candidates from the view of its FIRST term's index when there is one: the other terms are probed for the ids of one run only
+ * (survivors then come in no particular order). If the memory cannot be had the index silently goes on without the view. bmx_index_ordered_info: N, whether the view would answer the next query,
  * and how many sorts have run. */
 #define BMX_INDEX_ORDERED_AUTO 0xFFFFFFFFu   /* after_queries chosen by the engine: sort once the scans since the change have cost what the sort costs (rent-or-buy:
                                                * never more than twice the cheapest schedule, whatever comes next): ~70 queries on 10^8 int32 rows, ~25 on 10^7 */

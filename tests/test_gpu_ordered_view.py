@@ -196,3 +196,37 @@ def test_search_rounds_at_their_boundaries(n):
         for lo, hi in [(0, top), (3, 3), (top, top), (1, 2), (top + 1, top + 9)]:
             _q(e, FA, ids, vals, lo, hi)
         assert e.index_ordered_info(FA)[1:] == (True, 1)
+
+
+def test_declarative_filter_takes_its_candidates_from_the_view():
+    """bmx_scan_filter (AND of range terms over fields of one node, subset of src/bullet-query.js:270-283): with a view on the first term's index the
+    other terms are probed for the ids of ONE run only; same set as the column form, count-only and truncated forms included"""
+    R = 300_000
+    rng = np.random.default_rng(9)
+    ids = streams.splitmix64_np(np.arange(1, R + 1, dtype=np.uint64))
+    age = rng.integers(0, 100, R).astype(np.int64); score = rng.integers(-500, 500, R).astype(np.int64); other = rng.integers(0, 10, R).astype(np.int64)
+    with bmx.Engine(4 * R) as e:
+        for f, v in ((FA, age), (FS, score), (FO, other)):
+            e.load_rows(ids, np.full(R, f, np.uint32), np.full(R, 5, np.int64), v)
+        some = rng.choice(R, 5000, replace=False)                      # nodes without a score row at all: they can match no term on it
+        e.put_rows(ids[some], np.full(len(some), FS, np.uint32), np.full(len(some), 9, np.int64), np.full(len(some), VAL_DELETED, np.int64))
+        has_score = np.ones(R, bool); has_score[some] = False
+        e.index_build(FA)
+        qs = [[(FA, 30, 40), (FS, 0, 100)], [(FA, 0, 99), (FS, -10, 10), (FO, 3, 5)], [(FA, 50, 50)], [(FA, 98, 200), (FO, 0, 0)], [(FA, 5, 4), (FS, 0, 1)]]
+
+        def want(q):
+            m = np.ones(R, bool)
+            for f, lo, hi in q:
+                v = {FA: age, FS: score, FO: other}[f]
+                m &= (v >= lo) & (v <= hi)
+                if f == FS:
+                    m &= has_score
+            return np.sort(ids[m])
+        plain = [np.sort(e.scan_filter(q)) for q in qs]
+        e.index_set_ordered(FA, 1)
+        for q, p0 in zip(qs, plain):
+            got = e.scan_filter(q)
+            assert np.array_equal(np.sort(got), want(q)) and np.array_equal(np.sort(got), p0), q
+            few = e.scan_filter(q, cap=7)
+            assert len(few) == min(7, len(p0)) and np.all(np.isin(few, p0))
+        assert e.index_ordered_info(FA)[1:] == (True, 1)
