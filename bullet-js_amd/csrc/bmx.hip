@@ -412,7 +412,8 @@ int alloc_table_tuned(bmx_ctx* ctx, uint64_t nslots, Slot** out) {
       if (rep > 0) best = std::min(best, ms * 1000.f);
     }
     cand.push_back(p); us.push_back(best);
-    if (cand.size() >= 3 && !std::getenv("BMX_TABLE_PLACEMENT_TRIES") && *std::min_element(us.begin(), us.end()) <= 0.93f * *std::max_element(us.begin(), us.end())) tries = k + 1;
+    // early exit: five candidates seen and the best 7 % under the worst (three were not enough: one capture stopped at 76 us because its first candidate took 82)
+    if (cand.size() >= 5 && !std::getenv("BMX_TABLE_PLACEMENT_TRIES") && *std::min_element(us.begin(), us.end()) <= 0.93f * *std::max_element(us.begin(), us.end())) tries = k + 1;
     if (std::getenv("BMX_PLACEMENT_DEBUG")) fprintf(stderr, "bmx placement: candidate %d at %p (%llu MB): probe %.2f us\n", k, (void*)p, (unsigned long long)(bytes >> 20), best);
   }
   (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
