@@ -922,7 +922,7 @@ int refresh_from_log(bmx_ctx* ctx) {
       LAUNCHCHK("k_sel_write(log)");
       const uint32_t ublocks = (uint32_t)std::min<uint64_t>((ub + 255) / 256, 4096);
       hipLaunchKernelGGL(k_ix_update, dim3(ublocks), dim3(256), 0, ctx->stream, (const uint2*)ctx->chg, n_dev, (const Slot*)ctx->slots, ix.field, (const uint32_t*)ctx->slot_pos,
-                         ix.v64, ix.v32, d_wide);
+                         ix.v64, ix.v32, d_wide, ix.ordered_after ? 1u : 0u);
       LAUNCHCHK("k_ix_update");
     }
     for (size_t k = 0; k < ctx->indexes.size(); k++) {
@@ -941,7 +941,7 @@ int refresh_from_log(bmx_ctx* ctx) {
       ix.version = ~0ull; ix.has_pos = false; ctx->chg_valid = false;
       continue;
     }
-    if (ub) { ix.n += res[k].added; if (res[k].wide) ix.fits32 = false; if (res[k].added || res[k].changed) ix.content++; }
+    if (ub) { ix.n += res[k].added; if (res[k].wide) ix.fits32 = false; if (res[k].added || res[k].changed || !ix.ordered_after) ix.content++; }   // (no view: nobody compared, nobody cares)
     ix.version = ctx->version;
   }
   ctx->ix_incremental++;

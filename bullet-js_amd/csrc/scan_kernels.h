@@ -111,7 +111,8 @@ struct EmitAppend {   // created row -> the end of the index columns, in log ord
 // filter reads the int64 one whatever the range scans use). Entries that created their row were appended with the current value already.
 __global__ __launch_bounds__(256) void k_ix_update(const uint2* __restrict__ chg, const unsigned long long* __restrict__ n_dev, const Slot* __restrict__ slots,
                                                    uint32_t field, const uint32_t* __restrict__ slot_pos, int64_t* __restrict__ v64, int32_t* __restrict__ v32,
-                                                   uint32_t* wide /* wide[1]: set when a value in the index really changed */) {
+                                                   uint32_t* wide /* wide[1]: set when a value in the index really changed */,
+                                                   uint32_t track /* compare before writing (only an index with a value-ordered view cares: the compare is one more read per entry) */) {
   const uint64_t n = *n_dev;
   for (uint64_t i = (uint64_t)blockIdx.x * 256u + threadIdx.x; i < n; i += (uint64_t)gridDim.x * 256u) {
     const uint2 x = chg[i];
@@ -121,7 +122,7 @@ __global__ __launch_bounds__(256) void k_ix_update(const uint2* __restrict__ chg
     if (p == POS_NONE) continue;
     const uint4 hi = reinterpret_cast<const uint4*>(slots + s)[1];
     const int64_t v = (int64_t)((uint64_t)hi.z | ((uint64_t)hi.w << 32));
-    if (v64[p] != v) wide[1] = 1u;       // (the value-ordered view of the index is stale only then)
+    if (track && v64[p] != v) wide[1] = 1u;       // (the value-ordered view of the index is stale only then)
     v64[p] = v; v32[p] = v32_of(v);
     if (is_wide(v)) *wide = 1u;
   }
