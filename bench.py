@@ -161,6 +161,21 @@ def cpu_baseline(n_batches=24, extras=True):
     return out
 
 
+def numa_node_of_cpu(cpu, sysfs="/sys/devices/system/node", n_cpus=None):
+    """(node name, its cpulist string) of the NUMA node that holds `cpu`, or None when the topology cannot be read or has one node only."""
+    import glob
+    n_cpus = (os.cpu_count() or 0) if n_cpus is None else n_cpus
+    for d in sorted(glob.glob(os.path.join(sysfs, "node[0-9]*"))):
+        cl = open(os.path.join(d, "cpulist")).read().strip()
+        ids = set()
+        for part in cl.split(","):
+            lo, _, hi = part.partition("-")
+            ids.update(range(int(lo), int(hi or lo) + 1))
+        if cpu in ids:
+            return (os.path.basename(d), cl) if len(ids) < n_cpus else None      # (one node = the whole machine: nothing to pin)
+    return None
+
+
 def js_host_rate():
     """End-to-end rate of the JS host on this box (extra key, N=1 only): sync-chunk entries -> path hashing -> typed columns -> N-API ->
     GPU merge -> winners, one thread; and the same with the keys already hashed. bullet-js_amd/js/test/e2e_rate.js, bounded sample."""
@@ -175,17 +190,9 @@ def js_host_rate():
     pin, cpus = [], None
     try:
         here = int(open("/proc/self/stat").read().rsplit(")", 1)[1].split()[36])      # field 39: the CPU this thread last ran on
-        if shutil.which("taskset") and here is not None:
-            import glob
-            for d in sorted(glob.glob("/sys/devices/system/node/node[0-9]*")):
-                cl = open(os.path.join(d, "cpulist")).read().strip()
-                ids = set()
-                for part in cl.split(","):
-                    lo, _, hi = part.partition("-")
-                    ids.update(range(int(lo), int(hi or lo) + 1))
-                if here in ids and len(ids) < (os.cpu_count() or 0):      # (one node = the whole machine: nothing to pin)
-                    pin, cpus = ["taskset", "-c", cl], "%s: CPUs %s" % (os.path.basename(d), cl)
-                    break
+        found = numa_node_of_cpu(here) if shutil.which("taskset") else None
+        if found:
+            pin, cpus = ["taskset", "-c", found[1]], "%s: CPUs %s" % found
     except Exception:
         pin, cpus = [], None
     try:

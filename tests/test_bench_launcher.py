@@ -100,3 +100,16 @@ def test_real_launch_without_a_gpu_exits_nonzero_and_prints_no_json():
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1"], capture_output=True, text=True, timeout=300, env=env)
     assert r.returncode != 0 and r.stdout.strip() == ""
     assert "launching 2 ranks" in r.stderr and "needs a GPU" in r.stderr
+
+
+def test_numa_node_lookup_for_the_js_children(tmp_path):
+    """bench.py keeps its node children on the cores of ONE NUMA node (taskset): the node that holds the CPU the bench runs on, read from sysfs cpulists"""
+    import bench
+    for name, cl in (("node0", "0-63,128-191"), ("node1", "64-127,192-255")):
+        d = tmp_path / name; d.mkdir(); (d / "cpulist").write_text(cl + "\n")
+    assert bench.numa_node_of_cpu(5, str(tmp_path), 256) == ("node0", "0-63,128-191")
+    assert bench.numa_node_of_cpu(130, str(tmp_path), 256) == ("node0", "0-63,128-191")
+    assert bench.numa_node_of_cpu(200, str(tmp_path), 256) == ("node1", "64-127,192-255")
+    assert bench.numa_node_of_cpu(300, str(tmp_path), 256) is None
+    one = tmp_path / "single"; (one / "node0").mkdir(parents=True); (one / "node0" / "cpulist").write_text("0-7\n")
+    assert bench.numa_node_of_cpu(3, str(one), 8) is None          # one node = the whole machine: nothing to pin
