@@ -23,8 +23,8 @@
 #include "slot.h"
 
 namespace bmx {   // csrc/ordered_sort.hip (rocPRIM's radix sort, an object of its own)
-hipError_t sort_pairs_i32(void* tmp, size_t* tmp_bytes, const int32_t* kin, int32_t* kout, const uint32_t* vin, uint32_t* vout, size_t n, hipStream_t s);
-hipError_t sort_pairs_i64(void* tmp, size_t* tmp_bytes, const int64_t* kin, int64_t* kout, const uint32_t* vin, uint32_t* vout, size_t n, hipStream_t s);
+hipError_t sort_pairs_i32(void* tmp, size_t* tmp_bytes, const int32_t* kin, int32_t lo, unsigned bits, uint32_t* kout, const uint32_t* vin, uint32_t* vout, size_t n, hipStream_t s);
+hipError_t sort_pairs_i64(void* tmp, size_t* tmp_bytes, const int64_t* kin, int64_t lo, unsigned bits, uint64_t* kout, const uint32_t* vin, uint32_t* vout, size_t n, hipStream_t s);
 }
 
 using namespace bmx;
@@ -1032,18 +1032,37 @@ bool ensure_ordered_view(bmx_ctx* ctx, Index* ix) {
         hipMalloc(reinterpret_cast<void**>(&ix->s_ids), cap * sizeof(uint64_t)) != hipSuccess) return give_up();
     ix->ord_cap = cap; ix->ord_fits32 = ix->fits32;
   }
+  // the column's value range decides how many bits the sort has to look at (csrc/ordered_sort.hip: keys rebased to min = 1, tombstones = 0)
+  const uint32_t gb = (uint32_t)std::min<uint64_t>((n + 255) / 256, 8192);
+  long long mm[2] = {INT64_MAX, INT64_MIN};
+  long long* d_mm = reinterpret_cast<long long*>(ctx->ds->ord_ab);
+  hipError_t e = hipMemcpyAsync(d_mm, mm, sizeof(mm), hipMemcpyHostToDevice, ctx->stream);
+  if (e == hipSuccess) {
+    if (ix->fits32) hipLaunchKernelGGL((k_col_minmax<int32_t>), dim3(std::min<uint32_t>(gb, 2048)), dim3(256), 0, ctx->stream, (const int32_t*)ix->v32, n, d_mm);
+    else hipLaunchKernelGGL((k_col_minmax<int64_t>), dim3(std::min<uint32_t>(gb, 2048)), dim3(256), 0, ctx->stream, (const int64_t*)ix->v64, n, d_mm);
+    e = hipMemcpyAsync(mm, d_mm, sizeof(mm), hipMemcpyDeviceToHost, ctx->stream);
+  }
+  if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+  if (e != hipSuccess) return give_up();
+  if (mm[0] > mm[1]) { mm[0] = 0; mm[1] = 0; }                   // nothing but tombstones
+  const unsigned long long span = (unsigned long long)mm[1] - (unsigned long long)mm[0] + 1ull;     // largest rebased key
+  unsigned bits = 1; while (bits < 64 && (span >> bits)) bits++;
+  bits = std::min<unsigned>(bits, ix->fits32 ? 32u : 64u);
   uint32_t* iota = nullptr; void* tmp = nullptr; size_t tmp_bytes = 0;
-  hipError_t e = ix->fits32 ? sort_pairs_i32(nullptr, &tmp_bytes, nullptr, nullptr, nullptr, nullptr, n, ctx->stream)
-                            : sort_pairs_i64(nullptr, &tmp_bytes, nullptr, nullptr, nullptr, nullptr, n, ctx->stream);
+  e = ix->fits32 ? sort_pairs_i32(nullptr, &tmp_bytes, nullptr, 0, bits, nullptr, nullptr, nullptr, n, ctx->stream)
+                 : sort_pairs_i64(nullptr, &tmp_bytes, nullptr, 0, bits, nullptr, nullptr, nullptr, n, ctx->stream);
   if (e != hipSuccess || hipMalloc(reinterpret_cast<void**>(&iota), n * sizeof(uint32_t)) != hipSuccess || hipMalloc(&tmp, std::max<size_t>(tmp_bytes, 16)) != hipSuccess) {
     if (iota) (void)hipFree(iota);
     return give_up();
   }
-  const uint32_t gb = (uint32_t)std::min<uint64_t>((n + 255) / 256, 8192);
   hipLaunchKernelGGL(k_iota_u32, dim3(gb), dim3(256), 0, ctx->stream, iota, n);
-  e = ix->fits32 ? sort_pairs_i32(tmp, &tmp_bytes, ix->v32, static_cast<int32_t*>(ix->s_val), iota, ix->s_pos, n, ctx->stream)
-                 : sort_pairs_i64(tmp, &tmp_bytes, ix->v64, static_cast<int64_t*>(ix->s_val), iota, ix->s_pos, n, ctx->stream);
-  if (e == hipSuccess) { hipLaunchKernelGGL(k_gather_ids, dim3(gb), dim3(256), 0, ctx->stream, (const uint64_t*)ix->ids, (const uint32_t*)ix->s_pos, ix->s_ids, n); e = hipGetLastError(); }
+  e = ix->fits32 ? sort_pairs_i32(tmp, &tmp_bytes, ix->v32, (int32_t)mm[0], bits, static_cast<uint32_t*>(ix->s_val), iota, ix->s_pos, n, ctx->stream)
+                 : sort_pairs_i64(tmp, &tmp_bytes, ix->v64, (int64_t)mm[0], bits, static_cast<uint64_t*>(ix->s_val), iota, ix->s_pos, n, ctx->stream);
+  if (e == hipSuccess) {
+    if (ix->fits32) hipLaunchKernelGGL((k_gather_ids<int32_t, uint32_t>), dim3(gb), dim3(256), 0, ctx->stream, (const uint64_t*)ix->ids, (const uint32_t*)ix->s_pos, ix->s_ids, n, static_cast<uint32_t*>(ix->s_val), (int32_t)mm[0]);
+    else hipLaunchKernelGGL((k_gather_ids<int64_t, uint64_t>), dim3(gb), dim3(256), 0, ctx->stream, (const uint64_t*)ix->ids, (const uint32_t*)ix->s_pos, ix->s_ids, n, static_cast<uint64_t*>(ix->s_val), (int64_t)mm[0]);
+    e = hipGetLastError();
+  }
   if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);       // the scratch goes back below
   (void)hipFree(iota); (void)hipFree(tmp);
   if (e != hipSuccess) return give_up();

@@ -274,8 +274,27 @@ struct EmitPos {  // index position itself (u32, bounded by cap): no read of the
 __global__ __launch_bounds__(256) void k_iota_u32(uint32_t* __restrict__ p, uint64_t n) {
   for (uint64_t i = (uint64_t)blockIdx.x * 256u + threadIdx.x; i < n; i += (uint64_t)gridDim.x * 256u) p[i] = (uint32_t)i;
 }
-__global__ __launch_bounds__(256) void k_gather_ids(const uint64_t* __restrict__ ids, const uint32_t* __restrict__ pos, uint64_t* __restrict__ out, uint64_t n) {
-  for (uint64_t i = (uint64_t)blockIdx.x * 256u + threadIdx.x; i < n; i += (uint64_t)gridDim.x * 256u) out[i] = ids[pos[i]];
+// smallest and largest value of a column, tombstones (the type's minimum) aside: mm[0] = min, mm[1] = max (caller: INT64_MAX / INT64_MIN before the launch)
+template <class T>
+__global__ __launch_bounds__(256) void k_col_minmax(const T* __restrict__ v, uint64_t n, long long* __restrict__ mm) {
+  constexpr T TOMB = sizeof(T) == 4 ? (T)INT32_MIN : (T)INT64_MIN;
+  long long lo = INT64_MAX, hi = INT64_MIN;
+  for (uint64_t i = (uint64_t)blockIdx.x * 256u + threadIdx.x; i < n; i += (uint64_t)gridDim.x * 256u) {
+    const T x = v[i];
+    if (x != TOMB) { lo = x < lo ? (long long)x : lo; hi = x > hi ? (long long)x : hi; }
+  }
+  for (int d = 32; d >= 1; d >>= 1) { const long long l2 = __shfl_xor(lo, d), h2 = __shfl_xor(hi, d); lo = l2 < lo ? l2 : lo; hi = h2 > hi ? h2 : hi; }
+  if ((threadIdx.x & 63u) == 0) { if (lo != INT64_MAX) atomicMin(mm, lo); if (hi != INT64_MIN) atomicMax(mm + 1, hi); }
+}
+// ids in sorted order, and the sorted keys (rebased by the sort: csrc/ordered_sort.hip) turned back into values in place
+template <class T, class U>
+__global__ __launch_bounds__(256) void k_gather_ids(const uint64_t* __restrict__ ids, const uint32_t* __restrict__ pos, uint64_t* __restrict__ out, uint64_t n, U* keys, T lo) {
+  constexpr T TOMB = sizeof(T) == 4 ? (T)INT32_MIN : (T)INT64_MIN;
+  for (uint64_t i = (uint64_t)blockIdx.x * 256u + threadIdx.x; i < n; i += (uint64_t)gridDim.x * 256u) {
+    out[i] = ids[pos[i]];
+    const U k = keys[i];
+    reinterpret_cast<T*>(keys)[i] = k == 0 ? TOMB : (T)((U)(k - 1) + (U)lo);
+  }
 }
 // One wave per bound, 64-ary search: every round 63 lanes probe evenly spaced keys of [L, R) and the ballot says between which two the bound lies
 // (a 100M-row column: five dependent rounds instead of the 27 of a binary search). UPPER = false: first index with v >= key; true: first with v > key.
