@@ -278,11 +278,17 @@ __global__ __launch_bounds__(256) void k_iota_u32(uint32_t* __restrict__ p, uint
 template <class T>
 __global__ __launch_bounds__(256) void k_col_minmax(const T* __restrict__ v, uint64_t n, long long* __restrict__ mm) {
   constexpr T TOMB = sizeof(T) == 4 ? (T)INT32_MIN : (T)INT64_MIN;
+  constexpr int E = 16 / sizeof(T);                       // elements per 16-byte load
+  typedef T vec_t __attribute__((ext_vector_type(E)));
   long long lo = INT64_MAX, hi = INT64_MIN;
-  for (uint64_t i = (uint64_t)blockIdx.x * 256u + threadIdx.x; i < n; i += (uint64_t)gridDim.x * 256u) {
-    const T x = v[i];
-    if (x != TOMB) { lo = x < lo ? (long long)x : lo; hi = x > hi ? (long long)x : hi; }
+  auto take = [&](T x) { if (x != TOMB) { lo = x < lo ? (long long)x : lo; hi = x > hi ? (long long)x : hi; } };
+  const uint64_t nv = n / E;
+  for (uint64_t i = (uint64_t)blockIdx.x * 256u + threadIdx.x; i < nv; i += (uint64_t)gridDim.x * 256u) {
+    const vec_t x = reinterpret_cast<const vec_t*>(v)[i];
+#pragma unroll
+    for (int e = 0; e < E; e++) take(x[e]);
   }
+  if (blockIdx.x == 0 && threadIdx.x < n - nv * E) take(v[nv * E + threadIdx.x]);      // the ragged tail
   for (int d = 32; d >= 1; d >>= 1) { const long long l2 = __shfl_xor(lo, d), h2 = __shfl_xor(hi, d); lo = l2 < lo ? l2 : lo; hi = h2 > hi ? h2 : hi; }
   if ((threadIdx.x & 63u) == 0) { if (lo != INT64_MAX) atomicMin(mm, lo); if (hi != INT64_MIN) atomicMax(mm + 1, hi); }
 }
