@@ -46,6 +46,16 @@ HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec
 CONFIG = 2             # set by --config
 
 
+def say(msg, rank=None):
+    """progress line on stderr, stamped with the seconds since the launcher started (or since this process did): what a killed run leaves behind"""
+    t0 = float(os.environ.get("BMX_BENCH_LAUNCHED_AT", 0) or 0) or _T_IMPORT
+    r = os.environ.get("RANK", "0") if rank is None else rank
+    print("bench[rank %s] +%.1fs: %s" % (r, time.time() - t0, msg), file=sys.stderr, flush=True)
+
+
+_T_IMPORT = time.time()
+
+
 def gen_resident(R, row0=0):
     from bmx import synth
     return synth.big_resident(R, seed=1, T0=T0, DT=DT, row0=row0)
@@ -68,48 +78,73 @@ def to_dev(cols, dev):
 def exchange_selftest(dev, dist, rank, world):
     """N>1 only, before the real graph is built: a small graph (20k rows per rank) and six batches of 8192 deltas per rank go through the very pipeline the
     timed run uses — direct exchange if every rank can set it up — and every rank compares its shard with the oracle. The direct exchange stores into
-    other GPUs' memory; if the data that arrives is not what was sent on THIS machine, every rank switches to the RCCL all-to-all for the timed run
-    instead of finding out in the post-run verification. -> exchange kind to use ("direct" / "rccl")"""
+    other GPUs' memory; if the data that arrives is not what was sent on THIS machine — or any rank fails any step of it: an IPC open, the set-up,
+    a device-side wait that expires (60 s), an exception of any kind — every rank switches to the RCCL all-to-all for the timed run, inside the same
+    processes, instead of finding out in the post-run verification. -> (exchange kind to use: "direct" / "rccl", why direct was refused or None)"""
     import bmx
     from bmx import synth
     from bmx.sharded import ShardedGraph, EngineOps
     from oracle.oracle import Oracle, rows_digest
     Rs, Ds, NBs = 20_000, 8192, 6
-    e = bmx.Engine(capacity_rows=4 * (Rs + NBs * Ds), device=dev.index or 0)
-    sg = ShardedGraph(EngineOps(e, dev), dist, rank, world)
-    sg.load_owned_resident(Rs, T0=T0, DT=DT)
-    Rg = Rs * world
-    gen = lambda b, src: synth.big_deltas(Ds, Rg, seed=77 + 1000 * src, part=(src, world), T0=T0, DT=DT, insert_pct=10, unique=True, batch=b, drift=DT // 16)
-    sg.setup_pipeline(Ds, slack=1.5)
-    kind = sg.exchange
-    ok = True
-    if kind == "direct":
-        bs = [to_dev(gen(b, rank), dev) for b in range(NBs)]
-        torch.cuda.synchronize()                         # uploads run on torch's stream, the partition on the exchange stream
-        tk = sg.route(Ds, *bs[0], exchange_now=True)
-        for b in range(NBs):
-            nxt = sg.route(Ds, *bs[b + 1]) if b + 1 < NBs else None
-            sg.merge(tk)
-            tk = nxt
-        sg.ops.sync(); torch.cuda.synchronize()
-        o = Oracle()
-        o.load_rows(*sg.owned_resident_host(Rs, T0=T0, DT=DT))
-        for b in range(NBs):
-            for src in range(world):
-                cols = gen(b, src)
-                mine = synth.owner_of_np(cols[0], world) == rank
-                o.merge_batch(*[c[mine] for c in cols])
-        ok = (not sg.overflowed()) and e.row_count() == len(o) and rows_digest(*e.dump_rows()) == o.digest()
-        if os.environ.get("BMX_BENCH_SELFTEST_FAIL") == str(rank): ok = False     # test hook: pretend this rank saw wrong data
-        o.close()
-    okt = torch.tensor([1 if ok else 0], dtype=torch.int64, device=dev)
+    kind, ok, why = "rccl", True, None
+    e = sg = o = None
+    try:      # ANY failure on ANY rank (an IPC open, a set-up step, a device-side wait that expired, wrong data) must end in the agreement below, never in a rank that left
+        e = bmx.Engine(capacity_rows=4 * (Rs + NBs * Ds), device=dev.index or 0)
+        sg = ShardedGraph(EngineOps(e, dev), dist, rank, world)
+        sg.load_owned_resident(Rs, T0=T0, DT=DT)
+        Rg = Rs * world
+        gen = lambda b, src: synth.big_deltas(Ds, Rg, seed=77 + 1000 * src, part=(src, world), T0=T0, DT=DT, insert_pct=10, unique=True, batch=b, drift=DT // 16)
+        sg.setup_pipeline(Ds, slack=1.5)
+        kind = sg.exchange
+        if kind != "direct":
+            why = getattr(sg, "direct_refused", None) or "a rank could not set up or verify the IPC mappings"
+    except Exception as err:
+        ok, why = False, "self-test set-up raised on rank %d: %s" % (rank, str(err)[:200])
+    if kind == "direct" and ok:
+        try:
+            if os.environ.get("BMX_BENCH_SELFTEST_RAISE") == str(rank):      # test hook: this rank's pipeline raises in the middle of the self-test
+                raise RuntimeError("injected failure (BMX_BENCH_SELFTEST_RAISE)")
+            bs = [to_dev(gen(b, rank), dev) for b in range(NBs)]
+            torch.cuda.synchronize()                         # uploads run on torch's stream, the partition on the exchange stream
+            tk = sg.route(Ds, *bs[0], exchange_now=True)
+            for b in range(NBs):
+                nxt = sg.route(Ds, *bs[b + 1]) if b + 1 < NBs else None
+                sg.merge(tk)
+                tk = nxt
+            sg.ops.sync(); torch.cuda.synchronize()
+            o = Oracle()
+            o.load_rows(*sg.owned_resident_host(Rs, T0=T0, DT=DT))
+            for b in range(NBs):
+                for src in range(world):
+                    cols = gen(b, src)
+                    mine = synth.owner_of_np(cols[0], world) == rank
+                    o.merge_batch(*[c[mine] for c in cols])
+            ok = (not sg.overflowed()) and e.row_count() == len(o) and rows_digest(*e.dump_rows()) == o.digest()
+            if not ok:
+                why = "rank %d: the shard differs from the oracle after six batches through peer stores" % rank
+            if os.environ.get("BMX_BENCH_SELFTEST_FAIL") == str(rank):     # test hook: pretend this rank saw wrong data
+                ok, why = False, "injected mismatch (BMX_BENCH_SELFTEST_FAIL)"
+        except Exception as err:
+            ok, why = False, "rank %d: the direct exchange raised in the self-test: %s" % (rank, str(err)[:200])
+        finally:
+            if o is not None:
+                o.close()
+    okt = torch.tensor([1 if ok else 0], dtype=torch.int64, device=dev if dist.get_backend() != "gloo" else "cpu")
     dist.all_reduce(okt, op=dist.ReduceOp.MIN)
-    sg.close(); sg.ops.close(); e.close()
-    if kind == "direct" and int(okt.item()) != 1:
+    whys = [None] * world
+    dist.all_gather_object(whys, why)
+    for closer in ((lambda: sg.close()) if sg is not None else None, (lambda: sg.ops.close()) if sg is not None else None, (lambda: e.close()) if e is not None else None):
+        if closer is not None:
+            try:
+                closer()
+            except Exception as err:      # a context whose device-side wait expired carries a sticky error: it is being thrown away anyway
+                print("bench[rank %d]: closing the self-test's context: %s" % (rank, str(err)[:160]), file=sys.stderr)
+    reason = next((w for w in whys if w), None)
+    if int(okt.item()) != 1:
         if rank == 0:
-            print("bench: the direct exchange failed its self-test on this machine (a shard differed from the oracle): the timed run uses the RCCL all-to-all", file=sys.stderr)
-        return "rccl"
-    return kind
+            print("bench: the direct exchange is refused on this machine (%s): the timed run uses the RCCL all-to-all" % reason, file=sys.stderr)
+        return "rccl", reason
+    return kind, (reason if kind != "direct" else None)
 
 
 def cpu_baseline(n_batches=24, extras=True):
@@ -401,37 +436,256 @@ def scan_bench(bmx, dev, R, reps=20, wide=False):
     return out
 
 
-def launch_ranks(n_gpus, argv):
+LINE_LIMIT = 4000      # bytes: the driver keeps an ~8 KB tail of stdout; the line stays under half of that whatever sections a run adds
+
+
+def _r(x, nd=4):
+    return round(x, nd) if isinstance(x, float) else x
+
+
+def compact_line(out, detail_path=None):
+    """The ONE stdout line (round 4's 21 KB line was cut by the driver and parsed as nothing). Contract fields first, then
+    `roofline`, `cpu_baseline`, `verified`, then one-number summaries of the optional sections; tables, prose and per-rank digests live in
+    `bench_detail.json` (named in the line) and on stderr. Sections are dropped from the end, never the contract fields, should a run ever exceed LINE_LIMIT."""
+    g = out.get
+    line = {k: g(k) for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data")}
+    line["value"] = _r(line["value"], 1); line["ms_per_step"] = _r(line["ms_per_step"], 6)
+    cfg = dict(g("config") or {})
+    cfg["workload"] = str(cfg.get("workload", ""))[:260]
+    line["config"] = cfg
+    rf = g("roofline") or {}
+    line["roofline"] = {k: rf.get(k) for k in ("bound", "kernel", "achieved", "peak", "unit", "frac", "traffic", "algorithmic_bytes_per_launch", "kernel_ms",
+                                                "launches_averaged", "requests_per_launch", "whole_merge_achieved_GBs", "traffic_source") if k in rf}
+    if isinstance(line["roofline"].get("requests_per_launch"), dict):
+        line["roofline"]["requests_per_launch"] = line["roofline"]["requests_per_launch"].get("total")
+    if "traffic_source" in line["roofline"]:
+        line["roofline"]["traffic_source"] = "N=1 PMC passes (profiles/traffic_probe_apply.json)"
+    cb = g("cpu_baseline")
+    if isinstance(cb, dict):
+        c = {k: _r(cb.get(k), 1) for k in ("value", "unit", "cores", "kind")}
+        c["sample"] = str(cb.get("sample", ""))[:200]
+        for leg in ("all_cores", "js_twin"):
+            if isinstance(cb.get(leg), dict) and "value" in cb[leg]:
+                c[leg] = {"value": _r(cb[leg]["value"], 1), "cores": cb[leg].get("cores")}
+        line["cpu_baseline"] = c
+    else:
+        line["cpu_baseline"] = None
+    v = g("verified")
+    if isinstance(v, dict):
+        line["verified"] = {k: v[k] for k in ("ok", "batches", "winner_indices_compared", "rows", "table_digest") if k in v}
+        if "per_rank" in v:
+            line["verified"]["ranks_ok"] = sum(1 for x in v["per_rank"] if x.get("ok"))
+    else:
+        line["verified"] = None
+    optional = []      # (key, value) in the order they are given up if the line grows too long: last first
+    for k in ("event_ms_per_step", "winners_per_step", "host_enqueue_ms_per_step"):
+        if g(k) is not None:
+            optional.append((k, g(k)))
+    ex = g("exchange")
+    if isinstance(ex, dict):
+        optional.append(("exchange", {k: (str(ex[k])[:160] if isinstance(ex[k], str) else ex[k]) for k in ("kind", "refused", "why", "records_sent_to_other_shards", "bytes_per_record", "steps") if k in ex}))
+    sc = g("scan_config3")
+    if isinstance(sc, dict):
+        s3 = {}
+        for size, e in sc.items():
+            if not isinstance(e, dict):
+                continue
+            one = {}
+            q10 = e.get("range_10pct") or {}
+            fr = sorted(f for f in ((e.get(q) or {}).get("roofline_mask_kernel", {}).get("frac") for q in ("equals_0.1pct", "range_1pct", "range_10pct", "range_50pct")) if f is not None)
+            if fr:
+                one["mask_frac"] = fr[len(fr) // 2] if len(fr) % 2 else round((fr[len(fr) // 2 - 1] + fr[len(fr) // 2]) / 2, 4)      # median over the four queries
+            if q10:
+                one["range10_ids_us"] = q10.get("us")
+                one["range10_pos_us"] = (q10.get("position_output") or {}).get("us")
+            q50 = e.get("range_50pct") or {}
+            if q50:
+                one["range50_ids_us"] = q50.get("us")
+            eq = e.get("equals_0.1pct") or {}
+            if eq:
+                one["equals_us"] = eq.get("us")
+            ov = e.get("ordered_view") or {}
+            if ov:
+                one["view_equals_us"] = (ov.get("equals_0.1pct") or {}).get("us")
+                one["view_range10_ids_us"] = (ov.get("range_10pct") or {}).get("us")
+                one["view_sort_ms"] = ov.get("sort_ms")
+                for k in ("view_first_equals_after_merge_us", "view_next_equals_us", "view_kept_current_by"):
+                    if k in ov:
+                        one[k] = ov[k]
+            fs = e.get("first_scan_after_a_1M_delta_merge") or {}
+            if fs:
+                one["first_scan_after_merge_us"] = fs.get("us")
+            one["ok"] = bool((e.get("verified") or {}).get("ok"))
+            s3[size] = one
+        optional.append(("scan_config3", s3))
+    jh = g("js_host")
+    if isinstance(jh, dict):
+        ap, vc = jh.get("applied_path") or {}, jh.get("vector") or {}
+        j = {"mergeEntries_per_s": jh.get("mergeEntries_per_s"), "mergeEntriesPipelined_per_s": jh.get("mergeEntriesPipelined_per_s"),
+             "store_kept_entries_per_s": ap.get("batchSync_apply_entries_per_s"), "vector_pipelined_per_s": vc.get("mergeEntriesPipelined_per_s")}
+        if "error" in jh:
+            j = {"error": str(jh["error"])[:120]}
+        optional.append(("js_host", {k: _r(x, 0) for k, x in j.items()}))
+    um = g("unique_keys_mode")
+    if isinstance(um, dict):
+        optional.append(("unique_keys_probe_ms", (um.get("kernel_ms") or {}).get("probe_apply")))
+    tp = g("table_placement")
+    if isinstance(tp, dict):
+        optional.append(("table_placement", {k: tp[k] for k in ("candidates", "probe_us_chosen", "probe_us_slowest", "policy") if k in tp}))
+    if detail_path:
+        line["detail"] = os.path.basename(detail_path)
+    for k, val in optional:
+        line[k] = val
+    text = json.dumps(line, separators=(", ", ": "))
+    drop = [k for k, _ in optional][::-1]
+    while len(text) >= LINE_LIMIT and drop:
+        line.pop(drop.pop(0), None)
+        text = json.dumps(line, separators=(", ", ": "))
+    if len(text) >= LINE_LIMIT:          # cannot happen with the bounded fields above; never print a line the driver would cut
+        line["config"] = {"workload": cfg["workload"][:120]}
+        text = json.dumps(line, separators=(", ", ": "))
+    return text
+
+
+def emit(out, real_stdout, detail_path=None):
+    """full record -> bench_detail.json (+ stderr), short line -> stdout"""
+    detail_path = detail_path or os.environ.get("BMX_BENCH_DETAIL", os.path.join(ROOT, "bench_detail.json"))
+    full = json.dumps(out)
+    try:
+        with open(detail_path, "w") as f:
+            f.write(full + "\n")
+    except OSError as e:
+        print("bench: could not write %s: %s" % (detail_path, e), file=sys.stderr)
+        detail_path = None
+    print("bench detail: " + full, file=sys.stderr)
+    real_stdout.write(compact_line(out, detail_path) + "\n")
+    real_stdout.flush()
+
+
+COLL_TIMEOUT_S = 150.0       # per collective / barrier / rendezvous inside the ranks
+RANK_TIMEOUT_S = 420.0      # --rank-timeout: wall-clock limit of the launcher on its child (the N ranks), first contact with 8 GPUs included
+
+
+def _tail_lines(path, n=12):
+    try:
+        with open(path, "rb") as f:
+            f.seek(0, 2)
+            f.seek(max(0, f.tell() - 16384))
+            return f.read().decode("utf-8", "replace").splitlines()[-n:]
+    except OSError:
+        return []
+
+
+def launch_ranks(n_gpus, argv, timeout_s=None):
     """`python bench.py --gpus N` with N > 1 and no WORLD_SIZE in the environment: this process is only the LAUNCHER. It starts
-    `python -m torch.distributed.run --nproc-per-node N bench.py <same arguments>` as a CHILD process, hands rank 0's single JSON line through and
-    exits with the child's return code. It never touches the GPU (no HIP call, no torch.cuda.is_available(): a process that has initialised
-    the GPU must neither exec nor be needed for anything here), it does not retry, and a failing child fails the run. -> exit code"""
+    `python -m torch.distributed.run --nproc-per-node N bench.py <same arguments>` as a CHILD process (its own process group), hands rank 0's single
+    JSON line through and exits with the child's return code. It never touches the GPU (no HIP call, no torch.cuda.is_available(): a process that
+    has initialised the GPU must neither exec nor be needed for anything here), it does not retry, and a failing child fails the run.
+    BOUNDED: after `timeout_s` seconds of wall clock the child's whole process group is terminated (SIGTERM, SIGKILL 10 s later),
+    the last stderr lines of every rank are printed (torch.distributed.run tees each rank's stderr into a log directory) and the launcher exits
+    with 124 — a hung rendezvous, IPC open or barrier then costs the limit, not the driver's whole slot. A result line that has ALREADY arrived is
+    still delivered if the ranks only hang while shutting down. -> exit code"""
+    import shutil
+    import signal
     import socket
     import subprocess
+    import tempfile
+    import threading
+    timeout_s = RANK_TIMEOUT_S if timeout_s is None else float(timeout_s)
     with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as sk:      # a free rendezvous port on the loopback interface
         sk.bind(("127.0.0.1", 0))
         port = sk.getsockname()[1]
     env = dict(os.environ)
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")                  # dmabuf IPC: what RCCL and the direct exchange's mappings need on this driver
+    env["BMX_BENCH_LAUNCHED_AT"] = repr(time.time())                   # the ranks stamp their progress lines relative to this
+    logdir = tempfile.mkdtemp(prefix="bmx_bench_ranks_")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n_gpus), "--master-addr", "127.0.0.1",
-           "--master-port", str(port), os.path.abspath(__file__)] + list(argv)
-    print("bench: launching %d ranks: %s" % (n_gpus, " ".join(cmd)), file=sys.stderr)
-    child = subprocess.Popen(cmd, stdout=subprocess.PIPE, env=env, text=True)
-    line = None
-    for ln in child.stdout:                                            # rank 0 prints exactly one JSON line; anything else on stdout goes to stderr
-        t = ln.strip()
-        if t.startswith("{") and t.endswith("}") and '"metric"' in t:
-            line = t
-        elif t:
-            print(t, file=sys.stderr)
-    rc = child.wait()
+           "--master-port", str(port), "--log-dir", logdir, "--tee", "2", os.path.abspath(__file__)] + list(argv)
+    print("bench: launching %d ranks (limit %.0f s): %s" % (n_gpus, timeout_s, " ".join(cmd)), file=sys.stderr)
+    child = subprocess.Popen(cmd, stdout=subprocess.PIPE, env=env, text=True, start_new_session=True)
+    got = {"line": None}
+
+    def pump():
+        for ln in child.stdout:                                        # rank 0 prints exactly one JSON line; anything else on stdout goes to stderr
+            t = ln.strip()
+            if t.startswith("{") and t.endswith("}") and '"metric"' in t:
+                got["line"] = t
+            elif t:
+                print(t, file=sys.stderr)
+    th = threading.Thread(target=pump, daemon=True)
+    th.start()
+
+    def forward(signum, frame):                                        # the ranks live in their own session: a signal to the launcher must reach them too
+        try:
+            os.killpg(child.pid, signal.SIGTERM)
+        except Exception:
+            pass
+        raise SystemExit(128 + signum)
+    for sg_ in (signal.SIGTERM, signal.SIGINT, signal.SIGHUP):
+        try:
+            signal.signal(sg_, forward)
+        except (ValueError, OSError):                                  # not the main thread (tests): nothing to forward
+            pass
+
+    def stop_group():
+        for sig, grace in ((signal.SIGTERM, 10.0), (signal.SIGKILL, 5.0)):
+            try:
+                os.killpg(child.pid, sig)                              # exactly the process group this launcher started
+            except (ProcessLookupError, PermissionError, AttributeError, OSError):
+                try:
+                    child.kill()
+                except Exception:
+                    pass
+            try:
+                child.wait(timeout=grace)
+                return
+            except subprocess.TimeoutExpired:
+                continue
+
+    def rank_tails():
+        import glob
+        logs = sorted(glob.glob(os.path.join(logdir, "**", "stderr.log"), recursive=True))
+        for lg in logs:
+            print("bench: last stderr lines of %s" % os.path.relpath(lg, logdir), file=sys.stderr)
+            for ln in _tail_lines(lg):
+                print("    " + ln, file=sys.stderr)
+        if not logs:
+            print("bench: no per-rank logs under %s" % logdir, file=sys.stderr)
+
+    deadline = time.monotonic() + timeout_s
+    rc = None
+    timed_out = False
+    while rc is None:
+        try:
+            rc = child.wait(timeout=max(0.05, min(1.0, deadline - time.monotonic())))
+        except subprocess.TimeoutExpired:
+            if time.monotonic() >= deadline:
+                timed_out = True
+                break
+            if got["line"] is not None and deadline - time.monotonic() > 45.0:
+                deadline = time.monotonic() + 45.0                     # the result is in: the ranks get 45 s to shut down, not the rest of the limit
+    if timed_out:
+        print("bench: the ranks did not finish within %.0f s: terminating process group %d" % (timeout_s, child.pid), file=sys.stderr)
+        stop_group()
+        th.join(timeout=5.0)
+        rank_tails()
+        shutil.rmtree(logdir, ignore_errors=True)
+        if got["line"] is not None:                                   # measured, verified and printed; only the shutdown hung
+            print("bench: the result line had arrived before the limit: delivering it", file=sys.stderr)
+            sys.stdout.write(got["line"] + "\n"); sys.stdout.flush()
+            return 0
+        return 124
+    th.join(timeout=10.0)
     if rc != 0:
         print("bench: the ranks exited with code %d: no result" % rc, file=sys.stderr)
+        rank_tails()
+        shutil.rmtree(logdir, ignore_errors=True)
         return rc
-    if line is None:
+    shutil.rmtree(logdir, ignore_errors=True)
+    if got["line"] is None:
         print("bench: the ranks finished without printing a result line", file=sys.stderr)
         return 1
-    sys.stdout.write(line + "\n")
+    sys.stdout.write(got["line"] + "\n")
     sys.stdout.flush()
     return 0
 
@@ -448,6 +702,7 @@ def parse_args(argv=None):
     ap.add_argument("--scan", action="store_true", help="(kept for compatibility: the scans are on by default)")
     ap.add_argument("--scan-rows", type=str, default="10000000,100000000", help="comma-separated index sizes of the config-3 scans")
     ap.add_argument("--force-sharded", action="store_true", help="run the N>1 code path (partition + all-to-all + merge) even with one rank: rehearsal only")
+    ap.add_argument("--rank-timeout", type=float, default=RANK_TIMEOUT_S, help="launcher role (--gpus N > 1 without WORLD_SIZE): seconds after which the ranks' process group is terminated and the run fails")
     ap.add_argument("--no-defer", action="store_true", help="A/B switch: keep every batch's winner compaction on the merge stream (bmx_set_deferred_compaction(0))")
     return ap.parse_args(argv)
 
@@ -457,7 +712,7 @@ def main(argv=None):
     args = parse_args(argv)
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         # launcher role: nothing below this line runs in this process (in particular no GPU call)
-        raise SystemExit(launch_ranks(args.gpus, sys.argv[1:] if argv is None else argv))
+        raise SystemExit(launch_ranks(args.gpus, sys.argv[1:] if argv is None else argv, timeout_s=args.rank_timeout))
     # stdout carries exactly ONE JSON line: native libraries (RCCL's version banner) print to fd 1, so fd 1 is pointed
     # at stderr for the whole run and the JSON goes to a private duplicate of the real stdout.
     sys.stdout.flush()
@@ -489,10 +744,16 @@ def main(argv=None):
     if sharded:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1"); os.environ.setdefault("MASTER_PORT", "29544")
+        # every rendezvous, collective and barrier of the run is time-limited: a rank that never arrives fails the others after COLL_TIMEOUT_S
+        # (the process group's watchdog aborts the process), well inside the launcher's limit, instead of holding them for ever
+        import datetime
+        tmo = datetime.timedelta(seconds=float(os.environ.get("BMX_BENCH_COLL_TIMEOUT", COLL_TIMEOUT_S)))
+        say("joining the process group (%s, world %d, collective timeout %.0f s)" % ("gloo rehearsal" if rehearsal else "nccl", world, tmo.total_seconds()))
         if rehearsal:
-            dist.init_process_group(backend="gloo", rank=rank, world_size=world)
+            dist.init_process_group(backend="gloo", rank=rank, world_size=world, timeout=tmo)
         else:
-            dist.init_process_group(backend="nccl", rank=rank, world_size=world, device_id=dev)
+            dist.init_process_group(backend="nccl", rank=rank, world_size=world, device_id=dev, timeout=tmo)
+        say("process group up")
 
     nb = K + W
     ins_per_step = 0 if CONFIG == 5 else D_PER_STEP // 10
@@ -501,13 +762,13 @@ def main(argv=None):
     n_profiled = min(K, 12) + min(K, 8)
     cap = int(os.environ.get("BMX_BENCH_CAP", max(22_000_000, R_PER_GPU + (nb + n_profiled + 3) * ins_per_step + 4 * D_PER_STEP)))
     eng = bmx.Engine(capacity_rows=cap, device=local_rank, load_pct=int(os.environ.get("BMX_BENCH_LOAD_PCT", 0)))
-    # deferred compaction (include/bmx.h): on by default in the library; --no-defer is the A/B switch. The sharded pipeline keeps every compaction on the
-    # merge stream: beside the exchange kernels the deferred form measured SLOWER in the one-rank rehearsal (104-106 against 93-99 us per step,
-    # profiles/r04_sharded_rehearsal_ab.log; BMX_SHARDED_DEFER=1 switches it on)
-    defer = not args.no_defer and (not (world > 1 or args.force_sharded) or os.environ.get("BMX_SHARDED_DEFER", "0") == "1")
-    eng.set_deferred(defer)
+    # deferred compaction (include/bmx.h): on by default in the library; --no-defer is the A/B switch of the unsharded run. The sharded pipeline's choice is
+    # bmx.sharded.EngineOps' (off unless BMX_SHARDED_DEFER=1: measured slower beside the exchange kernels); the bench only reports it.
+    if not (world > 1 or args.force_sharded):
+        eng.set_deferred(not args.no_defer)
     main_kernel = "k_probe_apply"
     verified = None
+    refused_why = None
 
     if not sharded:
         rid = gen_resident(R_PER_GPU)
@@ -600,14 +861,22 @@ def main(argv=None):
         if world > 1 and os.environ.get("BMX_SHARDED_EXCHANGE", "auto") == "auto":
             # every rank gets the same answer (all-reduce inside). A passed self-test leaves the choice on "auto": should the set-up of the REAL
             # slabs fail on some rank after all, every rank falls back to the RCCL exchange together instead of raising
-            if exchange_selftest(dev, dist, rank, world) == "rccl":
+            say("exchange self-test")
+            st_kind, refused_why = exchange_selftest(dev, dist, rank, world)
+            say("exchange self-test -> %s%s" % (st_kind, (" (direct refused: %s)" % refused_why) if refused_why else ""))
+            if st_kind == "rccl":
                 os.environ["BMX_SHARDED_EXCHANGE"] = "rccl"
         sg = ShardedGraph(EngineOps(eng, dev), dist, rank, world)
+        if args.no_defer:
+            eng.set_deferred(False)
+        say("loading this rank's shard (%d of %d rows)" % (R_PER_GPU, R_PER_GPU * world))
         sg.load_owned_resident(R_PER_GPU, T0=T0, DT=DT)
         R_global = R_PER_GPU * world
         batches = [to_dev(gen_batch(b, R_global, seed=2 + 1000 * rank, part=(rank, world)), dev) for b in range(nb)]   # config 2: disjoint rows per originator
+        say("%d batches generated; setting up the exchange" % nb)
         sg.setup_pipeline(D_PER_STEP, partition_on=os.environ.get("BMX_BENCH_PARTITION", "merge"), slack=1.25 if CONFIG == 5 else 1.03)
         torch.cuda.synchronize()
+        say("exchange: %s; warm-up (%d steps)" % (sg.exchange, W))
 
         step_events = [] if os.environ.get("BMX_BENCH_STEPTIMES") else None   # debugging aid: when each step's merge finished (stderr)
 
@@ -625,6 +894,7 @@ def main(argv=None):
         if W:
             run(0, W)
         sg.ops.sync(); torch.cuda.synchronize(); dist.barrier()
+        say("timed region (%d steps)" % K)
         t0 = time.perf_counter()
         if os.environ.get("BMX_BENCH_HOSTPROF"):      # where the host's enqueue time goes (stderr): wall time inside each call
             acc, each = {}, {}
@@ -664,6 +934,7 @@ def main(argv=None):
         tmax = torch.tensor([wall], dtype=torch.float64, device=dev)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed = float(tmax.item())
+        say("timed region done: %.1f us per step here, %.1f max over ranks; verifying" % (wall / K * 1e6, elapsed / K * 1e6))
         total_units = K * D_PER_STEP * world
         if not args.no_verify and world * nb <= 256:
             # every rank replays, through the CPU oracle, the deltas of ALL originators that it owns (same generator, same order:
@@ -715,7 +986,9 @@ def main(argv=None):
                     "note": "rank 0, launches without a concurrent exchange (second pass, per-kernel HIP events on the merge stream)"}
         how = ("direct: the owner partition of batch b+1 stores every slab straight into its owner's IPC-mapped receive memory (peer stores over xGMI) and sets arrival words; no collective, one stream"
                if sg.exchange == "direct" else "rccl: partition + ONE all-to-all of batch b+1 on a second stream under the merge of batch b")
-        extra = {"host_enqueue_ms_per_step": round(t_enq / K * 1e3, 4), "exchange": dict(sg.stats(), kind=sg.exchange, mode="fixed slabs of %d records per ordered pair; %s" % (sg.slab, how))}
+        if sg.exchange != "direct" and refused_why is None:
+            refused_why = getattr(sg, "direct_refused", None) or ("BMX_SHARDED_EXCHANGE=rccl" if os.environ.get("BMX_SHARDED_EXCHANGE") == "rccl" else None)
+        extra = {"host_enqueue_ms_per_step": round(t_enq / K * 1e3, 4), "exchange": dict(sg.stats(), kind=sg.exchange, refused=(None if sg.exchange == "direct" else "direct"), why=refused_why, mode="fixed slabs of %d records per ordered pair; %s" % (sg.slab, how))}
         shape = ("config 5 shape: streaming replay with 30%% of every batch on %d global hot keys" % (R_global // 1000)) if CONFIG == 5 else "config 4 shape"
         cfg = {"workload": "%s: %dM-row graph id-hash sharded over %d MI355X, %dM mixed-shard deltas per step routed by RCCL all-to-all" %
                (shape, R_global // 1_000_000, world, world * D_PER_STEP // 1_000_000) if sg.exchange != "direct" else
@@ -751,8 +1024,7 @@ def main(argv=None):
         dist.barrier()
         dist.destroy_process_group()
     if out is not None:
-        real_stdout.write(json.dumps(out) + "\n")
-        real_stdout.flush()
+        emit(out, real_stdout)
 
 
 if __name__ == "__main__":

@@ -58,6 +58,13 @@ class EngineOps:
         # starved beside the full-occupancy kernel and finished when it did: profiles/r04_sharded_timeline.log); BMX_K1_WAVES in the environment wins
         if not os.environ.get("BMX_K1_WAVES"):
             engine.set_probe_waves(5)
+        # The sharded pipeline keeps every batch's compaction on the merge stream: beside the exchange kernels the deferred form measured SLOWER (104-106 against
+        # 93-99 us per step, profiles/r04_sharded_rehearsal_ab.log). Decided HERE, not by the bench, so that ShardedGraph users run what was measured;
+        # BMX_SHARDED_DEFER=1 switches the deferral on for A/Bs. Queue-sharing note: the deferral's side stream and the exchange stream are both
+        # high-priority streams; with the deferral off only ONE high-priority stream exists per process, so it cannot share a hardware queue with a waiting kernel.
+        self.deferred = os.environ.get("BMX_SHARDED_DEFER", "0") == "1"
+        if hasattr(engine, "set_deferred"):
+            engine.set_deferred(self.deferred)
         self.comm = None
         self.pe = None
 
@@ -176,6 +183,7 @@ class ShardedGraph:
         self._direct = None
         self._tail_wait = os.environ.get("BMX_SHARDED_TAIL_WAIT", "1") == "1"
         self.exchange = "exact"
+        self.direct_refused = None      # why the direct exchange was not taken (the first reason any rank gave), for the bench line
 
     def owned_rows(self, R_global, chunk=4_000_000):
         """row ordinals in [0, R_global) whose node this rank owns."""
@@ -363,6 +371,7 @@ class ShardedGraph:
         infos = [None] * W
         dist.all_gather_object(infos, mine)
         if any(x is None for x in infos):
+            self.direct_refused = "rank %d could not allocate or export its receive slabs" % [i for i, x in enumerate(infos) if x is None][0]
             self._free_direct(own, [])
             return False
         peers, opened, ok = [None] * W, [], True
@@ -388,7 +397,10 @@ class ShardedGraph:
         except Exception as err:      # not only BmxError: every rank must reach the agreement below
             print("bmx sharded: rank %d cannot map a peer's receive slabs (%s)" % (r, err), file=sys.stderr)
             ok = False
+        if os.environ.get("BMX_SHARDED_FAIL_SETUP") == str(r):     # test hook: this rank's mapping step fails
+            ok = False
         if not self._all_agree(ok):
+            self.direct_refused = "a rank could not map a peer's receive slabs (hipIpcOpenMemHandle / peer access)"
             self._free_direct(own, opened)
             return False
         self.ops._pipeline()                                                   # the exchange stream and its partition context
@@ -413,6 +425,7 @@ class ShardedGraph:
             print("bmx sharded: rank %d: the direct exchange did not complete its pre-flight batch (%s)" % (r, err), file=sys.stderr)
             ok = False
         if not self._all_agree(ok):
+            self.direct_refused = "the pre-flight batch did not complete its hand-off on some rank (a device-side wait expired or raised)"
             self._teardown_direct()
             return False
         self.n_steps = 0; self.received = 0; self.sent_remote = 0        # the pre-flight batch is not a step

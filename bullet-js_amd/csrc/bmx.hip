@@ -56,7 +56,8 @@ struct Index {
   uint64_t content = 0;      // counts the refreshes that really changed something in the columns (a value, a new row, a rebuild)
   // value-ordered view (bmx.h bmx_index_set_ordered): the columns once more, sorted by (value, position)
   uint32_t ordered_after = 0;     // 0 = off; N: a stale view is sorted again by the N-th query since the columns last changed
-  uint32_t stale_queries = 0;
+  uint32_t stale_queries = 0;     // queries answered by the column scan since the columns last CHANGED (not: since the last sort)
+  uint64_t stale_content = ~0ull; // the `content` value that count belongs to: a new change starts it again
   double last_sort_us = 0;        // what the last sort of the view cost the caller (BMX_INDEX_ORDERED_AUTO weighs it against the scans it saves)
   uint64_t ord_content = ~0ull;   // `content` the view was sorted from
   uint64_t ord_n = 0, ord_cap = 0, ord_sorts = 0;
@@ -170,7 +171,7 @@ struct bmx_ctx {
     FinishMerge Fin{}; ChgLog L{}; uint32_t mark_created = 0; bool notify_after = false; uint64_t notify_seq = 0; uint64_t seq = 0;
   } pend;
   bool defer_enabled = true;
-  uint32_t placement_tries = 0; float placement_us_best = 0, placement_us_worst = 0;   // what alloc_table_tuned saw for the current table
+  uint32_t placement_tries = 0, placement_tries_asked = 0; float placement_us_best = 0, placement_us_worst = 0;   // what alloc_table_tuned saw for the current table
   uint64_t n_row_waits = 0;           // merges that waited for a batch in flight to report its row count (wait_for_row_reports)
   int k1_waves = 8;                   // BMX_K1_WAVES (8, 6 or 5): resident waves per SIMD of the probe kernel
   hipStream_t side = nullptr;
@@ -373,18 +374,22 @@ uint64_t slots_for(uint64_t capacity_rows, uint32_t load_pct) {
 // the probe kernel's own request mix (k_placement_probe: 2^20 random slot reads + head exchanges + 16-byte stores, best of three launches, ~0.25 ms per
 // candidate), the fastest is kept and the others are freed. Candidates stay allocated while the next one is made (otherwise the allocator hands the same range
 // back); tables too large for that many copies get fewer tries. BMX_TABLE_PLACEMENT_TRIES=1 switches it off. -> the chosen allocation (uninitialised)
-constexpr int PLACEMENT_TRIES = 8;   // at most (BMX_TABLE_PLACEMENT_TRIES overrides, 1..16); from the third candidate on the search stops once the best is 7 % faster than the
-                                     // slowest: both kinds of placement have been seen then (profiles/r04_placement_probe.log: fast ones probe at <= 70 us, slow ones at >= 73.8)
+constexpr int PLACEMENT_TRIES = 4;   // at create (BMX_CTX_PLACEMENT_TRIES(n) in bmx_create_ex's flags, then BMX_TABLE_PLACEMENT_TRIES in the environment, override: 1..8);
+                                     // round 4 tried up to eight: the transient footprint (8 x 1.4 GB) bought ~1 us over four (profiles/r04_placement_probe.log)
+constexpr int PLACEMENT_TRIES_GROW = 3;  // while the old table is alive as well: old + 3 candidates = 4 x the table at the peak
 constexpr uint64_t PLACEMENT_MIN_BYTES = 256ull << 20;     // below the Infinity Cache's size a table's lines are served on-die wherever they live
-int alloc_table_tuned(bmx_ctx* ctx, uint64_t nslots, Slot** out) {
+int alloc_table_tuned(bmx_ctx* ctx, uint64_t nslots, Slot** out, bool growing = false) {
   *out = nullptr;
-  int tries = PLACEMENT_TRIES;
-  if (const char* t = std::getenv("BMX_TABLE_PLACEMENT_TRIES")) { const int v = std::atoi(t); if (v >= 1 && v <= 16) tries = v; }
+  int tries = growing ? PLACEMENT_TRIES_GROW : PLACEMENT_TRIES;
+  if (ctx->placement_tries_asked) tries = growing ? std::min<int>(ctx->placement_tries_asked, PLACEMENT_TRIES_GROW) : (int)ctx->placement_tries_asked;
+  if (const char* t = std::getenv("BMX_TABLE_PLACEMENT_TRIES")) { const int v = std::atoi(t); if (v >= 1 && v <= 8) tries = v; }
   const uint64_t bytes = nslots * sizeof(Slot);
   if (bytes < PLACEMENT_MIN_BYTES) tries = 1;
   else {
+    // never more than HALF of what is free right now for the candidates together (other contexts, torch's allocator and other processes share the
+    // device: ADVICE r4), and never without 2 GB to spare
     size_t free_b = 0, total_b = 0;
-    if (hipMemGetInfo(&free_b, &total_b) == hipSuccess) { while (tries > 1 && (uint64_t)tries * bytes + (2ull << 30) > free_b) tries--; } else (void)hipGetLastError();
+    if (hipMemGetInfo(&free_b, &total_b) == hipSuccess) { while (tries > 1 && ((uint64_t)tries * bytes > free_b / 2 || (uint64_t)tries * bytes + (2ull << 30) > free_b)) tries--; } else (void)hipGetLastError();
   }
   int rc;
   if (tries == 1) return dev_alloc(ctx, out, nslots);
@@ -412,8 +417,6 @@ int alloc_table_tuned(bmx_ctx* ctx, uint64_t nslots, Slot** out) {
       if (rep > 0) best = std::min(best, ms * 1000.f);
     }
     cand.push_back(p); us.push_back(best);
-    // early exit: five candidates seen and the best 7 % under the worst (three were not enough: one capture stopped at 76 us because its first candidate took 82)
-    if (cand.size() >= 5 && !std::getenv("BMX_TABLE_PLACEMENT_TRIES") && *std::min_element(us.begin(), us.end()) <= 0.93f * *std::max_element(us.begin(), us.end())) tries = k + 1;
     if (std::getenv("BMX_PLACEMENT_DEBUG")) fprintf(stderr, "bmx placement: candidate %d at %p (%llu MB): probe %.2f us\n", k, (void*)p, (unsigned long long)(bytes >> 20), best);
   }
   (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
@@ -434,7 +437,7 @@ int grow_table(bmx_ctx* ctx, uint64_t capacity_rows) {
   const uint64_t nslots = slots_for(capacity_rows, ctx->load_pct);
   if (!nslots) return fail(ctx, BMX_ERR_INVALID, "table would need more than 2^32 slots (slot indices are 32-bit): shard the graph over more contexts");
   Slot* fresh = nullptr;
-  if ((rc = alloc_table_tuned(ctx, nslots, &fresh))) return rc;
+  if ((rc = alloc_table_tuned(ctx, nslots, &fresh, /*growing=*/true))) return rc;
   hipLaunchKernelGGL(k_init_slots, dim3(2048), dim3(256), 0, ctx->stream, fresh, nslots);
   hipLaunchKernelGGL(k_rehash, dim3(2048), dim3(256), 0, ctx->stream, ctx->slots, ctx->nslots, fresh, nslots, &ctx->ds->status);
   hipError_t e = hipGetLastError();
@@ -1020,6 +1023,7 @@ bool ensure_ordered_view(bmx_ctx* ctx, Index* ix) {
     const double sort_us = ix->last_sort_us > 0 ? ix->last_sort_us : 200.0 + (double)ix->n * 0.00006;
     after = (uint32_t)std::min<double>(1.0e6, std::max<double>(2.0, std::ceil(sort_us / scan_us)));
   }
+  if (ix->stale_content != ix->content) { ix->stale_content = ix->content; ix->stale_queries = 0; }   // the count starts with every change of the columns
   if (++ix->stale_queries < after) return false;
   const auto t_sort = std::chrono::steady_clock::now();
   const uint64_t n = ix->n;
@@ -1218,7 +1222,7 @@ const char* bmx_last_error(const bmx_ctx* ctx) { return ctx ? ctx->err.c_str() :
 
 uint32_t bmx_owner_of(uint64_t id, uint32_t nshards) { return (uint32_t)(((unsigned __int128)owner_hash(id) * nshards) >> 64); }
 
-// bmx.h "bmx_selfcheck". Synchronous, on the device's default stream of the calling thread; allocates and frees 128 KB + 4 words.
+// bmx.h "bmx_selfcheck". Synchronous for the caller, on a stream of its own (nothing else on the device is waited for); allocates and frees 128 KB + 4 words.
 int bmx_selfcheck(int device, uint64_t* reads_out, uint64_t* torn_out, uint64_t* control_torn_out) {
   bmx_ctx* ctx = nullptr;
   int ndev = 0;
@@ -1232,14 +1236,16 @@ int bmx_selfcheck(int device, uint64_t* reads_out, uint64_t* torn_out, uint64_t*
     return fail(nullptr, BMX_ERR_NOMEM, "bmx_selfcheck: out of device memory");
   }
   unsigned long long h[4] = {0, 0, 0, 0};
-  hipError_t e = hipMemset(slots, 0, (size_t)NS * 32);
-  if (e == hipSuccess) e = hipMemset(d, 0, 4 * sizeof(unsigned long long));
-  if (e == hipSuccess) { hipLaunchKernelGGL(k_selfcheck_tear<false>, dim3(BLOCKS), dim3(256), 0, 0, slots, NS, ITERS, d, d + 1); e = hipGetLastError(); }
-  if (e == hipSuccess) e = hipDeviceSynchronize();
-  if (e == hipSuccess) e = hipMemset(slots, 0, (size_t)NS * 32);
-  if (e == hipSuccess) { hipLaunchKernelGGL(k_selfcheck_tear<true>, dim3(BLOCKS), dim3(256), 0, 0, slots, NS, ITERS / 4, d + 2, d + 3); e = hipGetLastError(); }
-  if (e == hipSuccess) e = hipDeviceSynchronize();
-  if (e == hipSuccess) e = hipMemcpy(h, d, sizeof(h), hipMemcpyDeviceToHost);
+  hipStream_t cs = nullptr;       // a stream of its own: no device-wide synchronisation, nothing of another context or library is waited for
+  hipError_t e = hipStreamCreateWithFlags(&cs, hipStreamNonBlocking);
+  if (e == hipSuccess) e = hipMemsetAsync(slots, 0, (size_t)NS * 32, cs);
+  if (e == hipSuccess) e = hipMemsetAsync(d, 0, 4 * sizeof(unsigned long long), cs);
+  if (e == hipSuccess) { hipLaunchKernelGGL(k_selfcheck_tear<false>, dim3(BLOCKS), dim3(256), 0, cs, slots, NS, ITERS, d, d + 1); e = hipGetLastError(); }
+  if (e == hipSuccess) e = hipMemsetAsync(slots, 0, (size_t)NS * 32, cs);
+  if (e == hipSuccess) { hipLaunchKernelGGL(k_selfcheck_tear<true>, dim3(BLOCKS), dim3(256), 0, cs, slots, NS, ITERS / 4, d + 2, d + 3); e = hipGetLastError(); }
+  if (e == hipSuccess) e = hipMemcpyAsync(h, d, sizeof(h), hipMemcpyDeviceToHost, cs);
+  if (e == hipSuccess) e = hipStreamSynchronize(cs);
+  if (cs) (void)hipStreamDestroy(cs);
   (void)hipFree(slots); (void)hipFree(d);
   if (e != hipSuccess) return fail_hip(nullptr, e, "bmx_selfcheck");
   if (reads_out) *reads_out = h[1];
@@ -1294,6 +1300,8 @@ int bmx_create_ex(int device, uint64_t capacity_rows, uint32_t max_load_pct, uin
   for (int i = 0; i < 2; i++) { CR(hipEventCreateWithFlags(&ctx->stg[i].up, hipEventDisableTiming)); CR(hipEventCreateWithFlags(&ctx->stg[i].done, hipEventDisableTiming)); }
   const uint64_t nslots = slots_for(capacity_rows, max_load_pct);
   ctx->nslots = nslots;
+  ctx->placement_tries_asked = (flags >> 8) & 0xFu;         // BMX_CTX_PLACEMENT_TRIES(n): 0 = the default
+  if (ctx->placement_tries_asked > 8) ctx->placement_tries_asked = 8;
   int rc;
   if ((rc = alloc_table_tuned(ctx, nslots, &ctx->slots))) return bail(rc);
   if ((rc = dev_alloc(ctx, &ctx->ds, 1))) return bail(rc);
@@ -1379,6 +1387,9 @@ int bmx_seq_signal(bmx_ctx* ctx, void* hip_stream, uint64_t* seq_dev, uint64_t v
   if (!ctx || !seq_dev) return fail(ctx, BMX_ERR_INVALID, "bmx_seq_signal: null context or sequence word");
   HIPCHK(hipSetDevice(ctx->device));
   hipStream_t st = hip_stream ? reinterpret_cast<hipStream_t>(hip_stream) : ctx->stream;
+  // a signal on the context's own stream says "every merge enqueued before this is done, outputs included": a compaction that is only recorded
+  // (or still on the side stream) is ordered in front of it (a consumer stream woken by the word read a stale n_applied)
+  if (st == ctx->stream) { if (int frc = flush_pending(ctx)) return frc; }
   hipLaunchKernelGGL(k_seq_signal, dim3(1), dim3(64), 0, st, reinterpret_cast<unsigned long long*>(seq_dev), (unsigned long long)value);
   LAUNCHCHK("k_seq_signal");
   return BMX_OK;

@@ -121,6 +121,11 @@ typedef struct bmx_info {
 #define BMX_CTX_FIXED_CAPACITY 2u /* never grow: a batch that would exceed capacity_rows fails with BMX_ERR_FULL.
                                      Default: the table is rehashed into one twice as large (synchronous, on device). */
 
+/* Table placement tries (see bmx_get_placement): OR BMX_CTX_PLACEMENT_TRIES(n), n = 1..8, into the flags; 0 / absent = the default (4 at create,
+ * 3 at a growth). Peak device memory of bmx_create: tries x the table (at most half of the free memory, whatever was asked); of a growth: the old table + tries x
+ * the new one. 1 = take the first allocation (no transient memory, no timing). */
+#define BMX_CTX_PLACEMENT_TRIES(n) (((uint32_t)(n) & 0xFu) << 8)
+
 /* ---- lifetime -------------------------------------------------------------------------------
  * Replaces `new BulletCRT(bullet)` src/bullet-crt.js:6-16 / `new BulletQuery(bullet)`
  * src/bullet-query.js:2-7 for the device-resident part of the state (reference state:
@@ -145,7 +150,7 @@ int bmx_selfcheck(int device, uint64_t* reads, uint64_t* torn, uint64_t* control
 int bmx_get_info(bmx_ctx* ctx, bmx_info* out);
 /* Table placement. Where a large table lands in device memory decides ~10 % of the merge kernel's time (the same kernels on the same rows: 68-72 us per
  * 1M-delta launch on some allocations of a 1.4 GB table, 77-80 us on others made in the same process — for the allocation's lifetime). bmx_create and every
- * growth therefore allocate a table of >= 256 MB several times (at most eight; fewer once a clearly faster candidate has turned up), time each candidate with the merge kernel's own request mix (2^20 random slot reads, head
+ * growth therefore allocate a table of >= 256 MB several times (four at create, three at a growth — BMX_CTX_PLACEMENT_TRIES —, and never more than half of the free device memory together), time each candidate with the merge kernel's own request mix (2^20 random slot reads, head
  * exchanges and 16-byte stores; ~0.25 ms per candidate) and keep the fastest (BMX_TABLE_PLACEMENT_TRIES=1 in the environment: take the first). This call
  * reports what was seen for the current table: number of candidates (0: not tuned), probe time of the chosen and of the slowest one, in us. The reference has
  * no counterpart (its store is a JS object, src/bullet.js:28). */
@@ -215,8 +220,12 @@ int bmx_merge_records(bmx_ctx* ctx, uint64_t n, const bmx_delta_rec* recs, int i
  * (k_compact_winners -> applied_idx / n_applied / stats) and reads nothing but per-batch workspace. When batch b + 1 follows batch b directly,
  * the compaction of b runs on a second, high-priority stream UNDER the probe kernel of b + 1 instead of in front of it (ordering by two words in
  * device memory, no event markers); with any other bmx_* call in between it runs on the context's stream as before. Consequences for a caller:
- *   - outputs of a device merge are valid after bmx_sync() (as ever) or after ANY other call on the context other than another device merge
- *     (bmx_destroy included: it launches a compaction that was only recorded and waits for it);
+ *   - outputs of a device merge are valid after bmx_sync() (as ever) or, in stream order, behind any other call on the context that enqueues
+ *     or reads something — every entry point except the ones listed next (bmx_destroy included: it launches a compaction that was only recorded and
+ *     waits for it). bmx_seq_signal on the context's own stream counts: it publishes "everything before this is done", so it orders the compaction
+ *     in front of the signal. NOT ordering points, because they neither publish nor read a merge's outputs: another device merge, bmx_seq_wait,
+ *     bmx_seq_wait_all, bmx_seq_signal on a stream that is not the context's, bmx_merge_tail_wait, bmx_set_probe_waves, bmx_timer_elapsed,
+ *     bmx_get_deferred_counts, bmx_get_placement, bmx_index_refresh_counts, bmx_index_ordered_info, bmx_last_error;
  *   - a caller that enqueues its own work on the context's stream (bmx_set_stream) and reads applied_idx / n_applied / stats there without
  *     bmx_sync() calls bmx_merge_fence() first: it only enqueues, and orders the stream behind every compaction;
  *   - bmx_set_deferred_compaction(ctx, 0) restores strict stream order for every launch (the communicator does this for its shards).

@@ -190,6 +190,42 @@ def test_inputs_may_be_overwritten_in_stream_order_and_the_fence_orders_the_outp
         assert np.array_equal(np.sort(e.scan_range(F, -(1 << 40), 1 << 40)), np.sort(o.scan_range(F, -(1 << 40), 1 << 40)))
 
 
+def test_a_signal_on_the_contexts_stream_publishes_the_merge_outputs():
+    """bmx_seq_signal on the context's own stream says "everything before this is done". With the deferral on, the last merge's compaction is
+    only RECORDED when the call returns: the signal must order it in front of itself, so that a consumer stream woken by the word reads this batch's
+    n_applied / applied_idx / stats, not stale ones. (Before the fix the word was set while k_compact_winners had not even been launched.)"""
+    dev = torch.device("cuda", 0)
+    R, D, NB = 250_000, 131_072, 4
+    res = synth.big_resident(R, seed=91)
+    o = Oracle(); o.load_rows(*res)
+    hb = [synth.big_deltas(D, R, seed=92, insert_pct=10, hot_pct=10, hot_keys=30, unique=False, batch=b, drift=30_000) for b in range(NB)]
+    consumer = torch.cuda.Stream(device=dev)
+    with bmx.Engine(2 * (R + NB * D)) as e:
+        e.load_rows(*res)
+        db = [_dev(d, dev) for d in hb]
+        applied = torch.zeros((NB, D), dtype=torch.int32, device=dev)
+        n_applied = torch.full((NB,), -1, dtype=torch.int64, device=dev)
+        stats = torch.zeros((NB, 8), dtype=torch.int64, device=dev)
+        seen_n = torch.full((NB,), -7, dtype=torch.int64, device=dev)
+        seen_applied = torch.zeros((NB, D), dtype=torch.int32, device=dev)
+        word = torch.zeros(1, dtype=torch.int64, device=dev)
+        torch.cuda.synchronize()
+        d0, _ = e.deferred_counts()
+        for b in range(NB):
+            e.merge_batch_dev(D, *db[b], INSERT_REFERENCE, applied=applied[b], n_applied=n_applied[b:b + 1], stats=stats[b])
+            e.seq_signal(0, word, b + 1)                               # on the engine's own stream
+            e.seq_wait(consumer.cuda_stream, word, b + 1)              # the consumer wakes on the word alone: no host sync, no fence
+            with torch.cuda.stream(consumer):
+                seen_n[b:b + 1].copy_(n_applied[b:b + 1])
+                seen_applied[b].copy_(applied[b])
+        consumer.synchronize()
+        e.sync()
+        assert e.deferred_counts()[0] - d0 == NB                       # every merge WAS deferred: the signal, not a switched-off deferral, ordered the outputs
+        _check_batches(o, hb, seen_applied, seen_n)
+        assert torch.equal(seen_n, n_applied)
+        assert rows_digest(*e.dump_rows()) == o.digest()
+
+
 def test_undocumented_insert_mode_bits_are_refused():
     dev = torch.device("cuda", 0)
     d = synth.big_deltas(1000, 5000, seed=3, insert_pct=10, unique=True)

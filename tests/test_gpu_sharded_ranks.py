@@ -47,6 +47,27 @@ def test_ranks_sharing_one_gpu_equal_single_merge(tmp_path, mode, world):
     assert rows_digest(ids, f, ts, val) == o.digest()
 
 
+@pytest.mark.parametrize("hook", ["BMX_BENCH_SELFTEST_RAISE", "BMX_SHARDED_FAIL_SETUP"])
+def test_a_rank_that_fails_in_the_direct_exchange_sends_every_rank_to_the_fallback(hook):
+    """bench.py launched by ITSELF (`--gpus 2`: launcher -> torch.distributed.run -> two ranks sharing this GPU over gloo); rank 1 raises in the middle
+    of the direct exchange's self-test, or fails its mapping step in the set-up. Every rank must fall back to the all-to-all INSIDE the same processes: one short
+    line, exchange kind "rccl", the refused path and the reason named, every shard verified against the oracle."""
+    import json
+    root = os.path.dirname(HERE)
+    env = dict(os.environ, BMX_BENCH_ONE_GPU_REHEARSAL="1")
+    env[hook] = "1"
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "4", "--warmup", "2", "--rank-timeout", "500"],
+                       capture_output=True, text=True, timeout=560, env=env)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-6000:]
+    assert len(r.stdout.strip().splitlines()) == 1 and len(r.stdout) < 4096
+    line = json.loads(r.stdout)
+    assert line["n_gpus"] == 2 and line["verified"]["ok"] and line["verified"]["ranks_ok"] == 2
+    assert line["exchange"]["kind"] == "rccl" and line["exchange"]["refused"] == "direct" and line["exchange"]["why"]
+    assert line["roofline"]["frac"] > 0 and line["cpu_baseline"]["value"] > 0
+
+
 @pytest.mark.skipif(__import__("torch").cuda.device_count() < 2, reason="needs two physical GPUs: the direct exchange across xGMI (peer access + IPC mappings between devices) runs here first")
 @pytest.mark.parametrize("world", [2, 4, 8])
 def test_one_rank_per_physical_gpu_bench_verifies_itself(world):

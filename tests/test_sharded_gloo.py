@@ -85,13 +85,51 @@ class OracleOps:
         pass
 
 
+class _FakeIpcEngine:
+    """the bmx_ipc_* surface of an engine whose peer mapping FAILS on one rank (what a machine without peer access between two GPUs, or a
+    refused hipIpcOpenMemHandle, looks like from bmx/sharded.py)"""
+
+    def __init__(self, rank, fail_open_on):
+        self.rank, self.fail_open_on, self.live, self.opened = rank, fail_open_on, set(), 0
+
+    def ipc_alloc(self, nbytes, uncached=False):
+        ptr = 0x1000000 * (len(self.live) + 1)
+        self.live.add(ptr)
+        return ptr, b"handle-%d-%d" % (self.rank, ptr)
+
+    def ipc_open(self, handle, device):
+        if self.rank == self.fail_open_on:
+            raise RuntimeError("hipIpcOpenMemHandle: invalid argument (injected)")
+        self.opened += 1
+        return 0x7000000 + self.opened
+
+    def ipc_close(self, ptr):
+        self.opened -= 1
+
+    def ipc_free(self, ptr):
+        self.live.discard(ptr)
+
+
+class DirectRefusingOps(OracleOps):
+    """an ops object that SAYS it can do the direct exchange and whose rank 1 cannot map its peer's slabs: every rank must end on the all-to-all"""
+    direct_capable = True
+
+    def __init__(self, rank):
+        super().__init__()
+        self.e = _FakeIpcEngine(rank, fail_open_on=1)
+        self.device = torch.device("cpu")
+
+
 def _worker(rank, world, port, tmp, pipelined=False):
     sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "bullet-js_amd"))
     os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     from bmx import synth
     from bmx.sharded import ShardedGraph
-    ops = OracleOps()
+    refuse = pipelined == "direct_refused"
+    if refuse:
+        pipelined = "merge"
+    ops = DirectRefusingOps(rank) if refuse else OracleOps()
     sg = ShardedGraph(ops, dist, rank, world)
     R = 20000
     nloaded = sg.load_owned_resident(R // world * world // world, T0=1000, DT=1000)   # R/world per rank
@@ -102,6 +140,9 @@ def _worker(rank, world, port, tmp, pipelined=False):
         if pipelined:
             if b == 0:
                 sg.setup_pipeline(3000, slack=1.2, partition_on=pipelined)
+                if refuse:      # a set-up step failed on ONE rank: BOTH ranks are on the all-to-all, know why, and hold no mapping or allocation of the attempt
+                    assert sg.exchange == "rccl" and sg._direct is None and "map a peer" in sg.direct_refused
+                    assert not ops.e.live and ops.e.opened == 0
             p = sg.merge(sg.route(3000, *t))
             assert not sg.overflowed()
             digests.append(int(p["n_applied"][0]))
@@ -121,7 +162,7 @@ def _free_port():
     return p
 
 
-@pytest.mark.parametrize("pipelined", [False, "exchange", "merge"])
+@pytest.mark.parametrize("pipelined", [False, "exchange", "merge", "direct_refused"])
 def test_two_rank_routing_equals_single_merge(tmp_path, pipelined):
     world = 2
     mp.spawn(_worker, args=(world, _free_port(), str(tmp_path), pipelined), nprocs=world, join=True)
