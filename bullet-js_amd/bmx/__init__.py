@@ -26,9 +26,9 @@ FLAG_INCOMING, FLAG_CURRENT, FLAG_HISTORICAL = 1, 2, 4
 MAX_BATCH = 1 << 24
 
 EXPORTS = [
-    "bmx_create", "bmx_create_ex", "bmx_destroy", "bmx_last_error", "bmx_abi_version", "bmx_selfcheck", "bmx_set_deferred_compaction", "bmx_merge_fence", "bmx_get_deferred_counts", "bmx_get_info", "bmx_get_placement", "bmx_set_probe_waves", "bmx_sync", "bmx_set_stream", "bmx_get_stream", "bmx_seq_signal", "bmx_seq_wait",
+    "bmx_create", "bmx_create_ex", "bmx_destroy", "bmx_last_error", "bmx_abi_version", "bmx_selfcheck", "bmx_set_deferred_compaction", "bmx_set_side_stream", "bmx_set_wait_limit", "bmx_merge_fence", "bmx_get_deferred_counts", "bmx_get_info", "bmx_get_placement", "bmx_set_probe_waves", "bmx_sync", "bmx_set_stream", "bmx_get_stream", "bmx_seq_signal", "bmx_seq_wait",
     "bmx_load_rows", "bmx_put_rows", "bmx_merge_batch", "bmx_merge_submit", "bmx_merge_collect", "bmx_host_alloc", "bmx_host_free", "bmx_merge_records", "bmx_get_rows", "bmx_get_row", "bmx_dump_rows", "bmx_row_count", "bmx_reserve",
-    "bmx_index_build", "bmx_index_drop", "bmx_index_size", "bmx_index_refresh_counts", "bmx_index_set_ordered", "bmx_index_ordered_info", "bmx_scan_range", "bmx_scan_equals", "bmx_scan_count", "bmx_scan_filter", "bmx_scan_range_pos", "bmx_index_ids",
+    "bmx_index_build", "bmx_index_drop", "bmx_index_size", "bmx_index_refresh_counts", "bmx_index_set_ordered", "bmx_index_ordered_info", "bmx_index_ordered_stats", "bmx_scan_range", "bmx_scan_equals", "bmx_scan_count", "bmx_scan_filter", "bmx_scan_range_pos", "bmx_index_ids",
     "bmx_owner_of", "bmx_partition_by_owner", "bmx_partition_by_owner_slabs", "bmx_partition_scatter", "bmx_merge_records_after", "bmx_ipc_alloc", "bmx_ipc_open", "bmx_ipc_close", "bmx_ipc_free", "bmx_seq_wait_all", "bmx_merge_tail_wait", "bmx_merge_notify", "bmx_timer_start", "bmx_timer_stop", "bmx_timer_mark", "bmx_timer_elapsed", "bmx_profile_enable", "bmx_profile_read", "bmx_profile_read_scan",
     "bmx_comm_create", "bmx_comm_destroy", "bmx_comm_last_error", "bmx_comm_nshards", "bmx_comm_shard", "bmx_comm_sync", "bmx_comm_load_rows", "bmx_comm_put_rows", "bmx_comm_merge",
     "bmx_comm_merge_dev", "bmx_comm_shard_result", "bmx_comm_row_count", "bmx_comm_get_rows", "bmx_comm_dump_rows", "bmx_comm_index_build", "bmx_comm_index_set_ordered",
@@ -91,6 +91,8 @@ def load_library():
     L.bmx_abi_version.argtypes = []; L.bmx_abi_version.restype = i32
     L.bmx_selfcheck.argtypes = [i32, C.POINTER(u64), C.POINTER(u64), C.POINTER(u64)]; L.bmx_selfcheck.restype = i32
     L.bmx_set_deferred_compaction.argtypes = [vp, i32]; L.bmx_set_deferred_compaction.restype = i32
+    L.bmx_set_side_stream.argtypes = [vp, vp]; L.bmx_set_side_stream.restype = i32
+    L.bmx_set_wait_limit.argtypes = [vp, C.c_double]; L.bmx_set_wait_limit.restype = i32
     L.bmx_merge_fence.argtypes = [vp]; L.bmx_merge_fence.restype = i32
     L.bmx_get_deferred_counts.argtypes = [vp, C.POINTER(u64), C.POINTER(u64)]; L.bmx_get_deferred_counts.restype = i32
     L.bmx_get_info.argtypes = [vp, C.POINTER(Info)]; L.bmx_get_info.restype = i32
@@ -118,6 +120,7 @@ def load_library():
     L.bmx_index_refresh_counts.argtypes = [vp, C.POINTER(u64), C.POINTER(u64)]; L.bmx_index_refresh_counts.restype = i32
     L.bmx_index_set_ordered.argtypes = [vp, u32, u32]; L.bmx_index_set_ordered.restype = i32
     L.bmx_index_ordered_info.argtypes = [vp, u32, C.POINTER(u32), C.POINTER(i32), C.POINTER(u64)]; L.bmx_index_ordered_info.restype = i32
+    L.bmx_index_ordered_stats.argtypes = [vp, u32, C.POINTER(u64), C.POINTER(u64), C.POINTER(u64), C.POINTER(C.c_double), C.POINTER(C.c_double)]; L.bmx_index_ordered_stats.restype = i32
     L.bmx_scan_range.argtypes = [vp, u32, i64, i64, vp, u64, vp, i32]; L.bmx_scan_range.restype = i32
     L.bmx_scan_equals.argtypes = [vp, u32, i64, vp, u64, vp, i32]; L.bmx_scan_equals.restype = i32
     L.bmx_scan_count.argtypes = [vp, u32, i64, i64, vp, i32]; L.bmx_scan_count.restype = i32
@@ -379,6 +382,13 @@ class Engine:
         self._chk(self.L.bmx_index_ordered_info(self.h, int(field), C.byref(a), C.byref(v), C.byref(n)))
         return a.value, bool(v.value), n.value
 
+    def index_ordered_stats(self, field):
+        """{sorts, patches, keys_patched, last_sort_us, last_patch_us} of the value-ordered view (bmx_index_ordered_stats)"""
+        a, b, c = C.c_uint64(), C.c_uint64(), C.c_uint64()
+        d, e = C.c_double(), C.c_double()
+        self._chk(self.L.bmx_index_ordered_stats(self.h, int(field), C.byref(a), C.byref(b), C.byref(c), C.byref(d), C.byref(e)))
+        return {"sorts": a.value, "patches": b.value, "keys_patched": c.value, "last_sort_us": d.value, "last_patch_us": e.value}
+
     def scan_range(self, field, lo, hi, cap=None):
         cap = self.index_size(field) if cap is None else cap
         out = np.zeros(max(cap, 1), np.uint64)
@@ -431,6 +441,14 @@ class Engine:
     def set_deferred(self, on):
         """deferred compaction (bmx.h): the winner compaction of a device batch runs under the NEXT batch's probe kernel. On by default."""
         self._chk(self.L.bmx_set_deferred_compaction(self.h, 1 if on else 0))
+
+    def set_side_stream(self, stream_ptr):
+        """the stream the deferred compactions run on (0 / None: the context's own high-priority stream)"""
+        self._chk(self.L.bmx_set_side_stream(self.h, C.c_void_p(stream_ptr) if stream_ptr else None))
+
+    def set_wait_limit(self, seconds):
+        """device-side waits on this context's GPU give up after this long (default ~60 s): bmx_set_wait_limit"""
+        self._chk(self.L.bmx_set_wait_limit(self.h, float(seconds)))
 
     def merge_fence(self):
         """enqueue-only: the engine's stream is ordered behind every compaction (for work the caller enqueues on that stream itself)"""

@@ -62,7 +62,9 @@ class EngineOps:
         # 93-99 us per step, profiles/r04_sharded_rehearsal_ab.log). Decided HERE, not by the bench, so that ShardedGraph users run what was measured;
         # BMX_SHARDED_DEFER=1 switches the deferral on for A/Bs. Queue-sharing note: the deferral's side stream and the exchange stream are both
         # high-priority streams; with the deferral off only ONE high-priority stream exists per process, so it cannot share a hardware queue with a waiting kernel.
-        self.deferred = os.environ.get("BMX_SHARDED_DEFER", "0") == "1"
+        # BMX_SHARDED_DEFER=2: deferred, and the compactions run on the EXCHANGE stream (bmx_set_side_stream) instead of a third stream.
+        self.defer_mode = os.environ.get("BMX_SHARDED_DEFER", "0")
+        self.deferred = self.defer_mode in ("1", "2")
         if hasattr(engine, "set_deferred"):
             engine.set_deferred(self.deferred)
         self.comm = None
@@ -78,6 +80,8 @@ class EngineOps:
             self.comm = torch.cuda.Stream(device=self.device, priority=-1)
             self.pe = Engine(capacity_rows=1024, device=self.device.index or 0)   # owns only the partition scratch
             self.pe.set_stream(self.comm.cuda_stream)
+            if getattr(self, "defer_mode", "0") == "2":
+                self.e.set_side_stream(self.comm.cuda_stream)
 
     direct_capable = True          # bmx_ipc_* / bmx_partition_scatter are available behind this ops object
 
@@ -160,6 +164,8 @@ class EngineOps:
     def close(self):
         self.leave_pipeline()
         self.sync()
+        if getattr(self, "defer_mode", "0") == "2" and self.comm is not None:
+            self.e.set_side_stream(0)
         self.e.set_stream(0)                       # back to the engine's own stream
         torch.cuda.set_stream(self._prev_stream)
         if self.pe is not None:

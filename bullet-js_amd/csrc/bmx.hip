@@ -21,6 +21,7 @@
 #include "scan_kernels.h"
 #include "select.h"
 #include "slot.h"
+#include "view_kernels.h"
 
 namespace bmx {   // csrc/ordered_sort.hip (rocPRIM's radix sort, an object of its own)
 hipError_t sort_pairs_i32(void* tmp, size_t* tmp_bytes, const int32_t* kin, int32_t lo, unsigned bits, uint32_t* kout, const uint32_t* vin, uint32_t* vout, size_t n, hipStream_t s);
@@ -41,6 +42,8 @@ struct DevScalars {  // one small device allocation; zeroed at create
   unsigned long long seq_diag[3];  // k_seq_wait expiry: {sequence word address, value waited for, value last seen}
   unsigned long long chg_n[2];     // entries in the index change log: batch k reads [k&1], its compaction writes [(k+1)&1]
   unsigned long long ord_ab[2];    // value-ordered view: [first match, one past the last) of the query being answered
+  unsigned long long view_cl_n[8]; // keys in the change run of maintained index k (k_ix_update capture mode: view_kernels.h)
+  uint32_t view_err, view_pad;     // a deleted key was not found in the view it is patched into
   unsigned long long seqw[2];      // deferred compaction: [0] = number of the latest probe kernel that has started, [1] = of the latest compaction finished on the side stream
 };
 
@@ -65,12 +68,24 @@ struct Index {
   void* s_val = nullptr;          // int32_t[ord_n] or int64_t[ord_n], ascending
   uint32_t* s_pos = nullptr;      // position in the index columns
   uint64_t* s_ids = nullptr;      // node id
+  // kept current under writes (view_kernels.h): the second set of columns a patch merges into (allocated by the first patch, then the two sets swap),
+  // the change run k_ix_update captures, and what the patches did
+  void* s_val2 = nullptr; uint32_t* s_pos2 = nullptr; uint64_t* s_ids2 = nullptr; uint64_t ord_cap2 = 0;
+  uint32_t* cl_pos = nullptr; int64_t* cl_old = nullptr; uint64_t cl_cap = 0;
+  uint64_t ord_patches = 0, ord_patched_keys = 0; double last_patch_us = 0;
 };
 void free_ordered_view(Index& ix) {
   if (ix.s_val) (void)hipFree(ix.s_val);
   if (ix.s_pos) (void)hipFree(ix.s_pos);
   if (ix.s_ids) (void)hipFree(ix.s_ids);
+  if (ix.s_val2) (void)hipFree(ix.s_val2);
+  if (ix.s_pos2) (void)hipFree(ix.s_pos2);
+  if (ix.s_ids2) (void)hipFree(ix.s_ids2);
+  if (ix.cl_pos) (void)hipFree(ix.cl_pos);
+  if (ix.cl_old) (void)hipFree(ix.cl_old);
   ix.s_val = nullptr; ix.s_pos = nullptr; ix.s_ids = nullptr; ix.ord_cap = 0; ix.ord_n = 0; ix.ord_content = ~0ull;
+  ix.s_val2 = nullptr; ix.s_pos2 = nullptr; ix.s_ids2 = nullptr; ix.ord_cap2 = 0;
+  ix.cl_pos = nullptr; ix.cl_old = nullptr; ix.cl_cap = 0;
 }
 
 thread_local std::string g_err;
@@ -155,6 +170,9 @@ struct bmx_ctx {
   uint2* chg = nullptr; uint64_t chg_cap = 0, chg_ub = 0;
   bool chg_valid = false; uint32_t chg_par = 0;
   uint64_t ix_full_builds = 0, ix_incremental = 0;
+  // sort scratch of the view patches (view_kernels.h): two key arrays (value 8 B, position 4 B) the merge sort ping-pongs between + the deleted keys' places
+  void* vk_v[2] = {nullptr, nullptr}; uint32_t* vk_p[2] = {nullptr, nullptr}; uint32_t* vk_dx = nullptr; uint64_t vk_cap = 0;
+  bool view_patching = true;          // BMX_VIEW_PATCH=0 in the environment: a change makes the view stale as in round 4 (A/B switch)
   // bmx_merge_notify: words (possibly in other GPUs' memory) that every merge's last workgroup sets to the number of merges finished since
   SeqPtrs notify{}; uint32_t n_notify = 0; uint64_t notify_seq = 0;
   // bmx_merge_tail_wait: armed = the next default-path merge's resolve kernel polls these words before it ends; waited = a resolve kernel that did so has
@@ -175,6 +193,7 @@ struct bmx_ctx {
   uint64_t n_row_waits = 0;           // merges that waited for a batch in flight to report its row count (wait_for_row_reports)
   int k1_waves = 8;                   // BMX_K1_WAVES (8, 6 or 5): resident waves per SIMD of the probe kernel
   hipStream_t side = nullptr;
+  bool side_is_callers = false;       // bmx_set_side_stream: the deferred compactions run on a stream the caller owns (the sharded pipeline's exchange stream)
   uint64_t dseq = 0;                  // deferred merges so far (the sequence numbers in ds->seqw)
   uint64_t side_last = 0, side_prev = 0;   // sequence numbers of the last two compactions launched on the side stream (0: none this stream is not ordered behind already)
   uint64_t n_deferred = 0, n_side = 0;   // merges whose compaction was deferred / actually ran on the side stream (bmx_get_deferred_counts)
@@ -899,18 +918,106 @@ int build_index(bmx_ctx* ctx, Index* ix) {
   return BMX_OK;
 }
 
+// ---- the value-ordered view kept current (view_kernels.h) ----
+constexpr uint64_t VIEW_PATCH_MAX_LOG = 1ull << 24;     // a longer change log is not captured: the view goes stale and is sorted again (a sort of 10^8 rows costs less than a patch that large)
+int ensure_view_scratch(bmx_ctx* ctx, uint64_t keys) {
+  if (keys <= ctx->vk_cap) return BMX_OK;
+  HIPCHK(hipStreamSynchronize(ctx->stream));
+  for (int i = 0; i < 2; i++) { if (ctx->vk_v[i]) (void)hipFree(ctx->vk_v[i]); ctx->vk_v[i] = nullptr; dev_free(ctx->vk_p[i]); }
+  dev_free(ctx->vk_dx); ctx->vk_cap = 0;
+  const uint64_t cap = (keys + keys / 4 + (1u << 16) + 255) & ~255ull;
+  for (int i = 0; i < 2; i++) {
+    if (hipMalloc(&ctx->vk_v[i], cap * 8) != hipSuccess) { (void)hipGetLastError(); ctx->vk_v[i] = nullptr; return fail(ctx, BMX_ERR_NOMEM, "view patch: out of device memory"); }
+    if (int rc = dev_alloc(ctx, &ctx->vk_p[i], cap)) return rc;
+  }
+  if (int rc = dev_alloc(ctx, &ctx->vk_dx, cap)) return rc;
+  ctx->vk_cap = cap;
+  return BMX_OK;
+}
+// Patch the view of `ix` with the change run k_ix_update captured (c changed rows: ix.cl_pos / ix.cl_old) and the rows appended at positions
+// [n0, n0 + added). 0 = the view equals a fresh sort of the columns again; 1 = it could not be patched (no memory, or a deleted key was not where it
+// should be): the caller leaves it stale and the next queries scan / re-sort as ever. Synchronous at its end (one word comes back).
+template <class T>
+int patch_view_t(bmx_ctx* ctx, Index& ix, uint64_t c, uint64_t n0, uint64_t added) {
+  const auto t0 = std::chrono::steady_clock::now();
+  const uint64_t m = c + added, ktot = c + m, nx = ix.ord_n, nz = nx - c + m;
+  if (nz >= 0xFFFFFFFFull || ktot >= 0xFFFFFFFFull || c > nx) return 1;
+  auto soft = [&](int) { g_err.clear(); ctx->err.clear(); (void)hipGetLastError(); return 1; };
+  if (ensure_view_scratch(ctx, ktot)) return soft(0);
+  if (nz > ix.ord_cap2 || !ix.s_val2) {
+    if (ix.s_val2) { (void)hipStreamSynchronize(ctx->stream); (void)hipFree(ix.s_val2); (void)hipFree(ix.s_pos2); (void)hipFree(ix.s_ids2); }
+    ix.s_val2 = nullptr; ix.s_pos2 = nullptr; ix.s_ids2 = nullptr; ix.ord_cap2 = 0;
+    const uint64_t cap = std::max<uint64_t>(ix.ord_cap, nz + nz / 8 + 1024);
+    if (hipMalloc(&ix.s_val2, cap * sizeof(T)) != hipSuccess || hipMalloc(reinterpret_cast<void**>(&ix.s_pos2), cap * sizeof(uint32_t)) != hipSuccess ||
+        hipMalloc(reinterpret_cast<void**>(&ix.s_ids2), cap * sizeof(uint64_t)) != hipSuccess) {
+      if (ix.s_val2) (void)hipFree(ix.s_val2); if (ix.s_pos2) (void)hipFree(ix.s_pos2); if (ix.s_ids2) (void)hipFree(ix.s_ids2);
+      ix.s_val2 = nullptr; ix.s_pos2 = nullptr; ix.s_ids2 = nullptr;
+      return soft(0);
+    }
+    ix.ord_cap2 = cap;
+  }
+  hipStream_t st = ctx->stream;
+  T* kv[2] = {static_cast<T*>(ctx->vk_v[0]), static_cast<T*>(ctx->vk_v[1])};
+  uint32_t* kp[2] = {ctx->vk_p[0], ctx->vk_p[1]};
+  const T* col = sizeof(T) == 4 ? reinterpret_cast<const T*>(ix.v32) : reinterpret_cast<const T*>(ix.v64);
+  hipLaunchKernelGGL((k_view_keys<T>), dim3((uint32_t)std::min<uint64_t>((ktot + 255) / 256, 4096)), dim3(256), 0, st, (const uint32_t*)ix.cl_pos, (const int64_t*)ix.cl_old, (uint32_t)c, col,
+                     (uint32_t)n0, (uint32_t)added, kv[0], kp[0]);
+  // sort the deleted keys [0, c) and the inserted keys [c, c + m): tiles in LDS, then rank-merge passes
+  ViewSegs S{}; S.base[0] = 0; S.len[0] = (uint32_t)c; S.base[1] = (uint32_t)c; S.len[1] = (uint32_t)m;
+  const uint32_t t0b = (uint32_t)((c + VIEW_TILE - 1) / VIEW_TILE), t1b = (uint32_t)((m + VIEW_TILE - 1) / VIEW_TILE);
+  S.blk0[0] = 0; S.blk0[1] = t0b; S.blk0[2] = t0b + t1b;
+  hipLaunchKernelGGL((k_view_tile_sort<T>), dim3(t0b + t1b), dim3(256), 0, st, (const T*)kv[0], (const uint32_t*)kp[0], kv[1], kp[1], S);
+  int cur = 1;
+  ViewSegs P = S; P.blk0[1] = (uint32_t)((c + 255) / 256); P.blk0[2] = P.blk0[1] + (uint32_t)((m + 255) / 256);
+  for (uint64_t L = VIEW_TILE; L < std::max<uint64_t>(c, m); L *= 2) {
+    hipLaunchKernelGGL((k_view_merge_pass<T>), dim3(P.blk0[2]), dim3(256), 0, st, (const T*)kv[cur], (const uint32_t*)kp[cur], kv[cur ^ 1], kp[cur ^ 1], P, (uint32_t)L);
+    cur ^= 1;
+  }
+  (void)hipMemsetAsync(&ctx->ds->view_err, 0, sizeof(uint32_t), st);
+  if (c) hipLaunchKernelGGL((k_view_find<T>), dim3((uint32_t)((c + 255) / 256)), dim3(256), 0, st, static_cast<const T*>(ix.s_val), (const uint32_t*)ix.s_pos, (uint32_t)nx, (const T*)kv[cur],
+                            (const uint32_t*)kp[cur], (uint32_t)c, ctx->vk_dx, &ctx->ds->view_err);
+  ViewRun<T> X{static_cast<T*>(ix.s_val), ix.s_pos, ix.s_ids}, Z{static_cast<T*>(ix.s_val2), ix.s_pos2, ix.s_ids2};
+  const uint32_t nbx = (uint32_t)((nx + VIEW_TILE - 1) / VIEW_TILE), nby = (uint32_t)((m + 255) / 256);
+  hipLaunchKernelGGL((k_view_merge<T>), dim3(nbx + nby), dim3(256), 0, st, X, (uint32_t)nx, (const uint32_t*)ctx->vk_dx, (uint32_t)c, (const T*)(kv[cur] + c), (const uint32_t*)(kp[cur] + c), (uint32_t)m,
+                     (const uint64_t*)ix.ids, Z, nbx);
+  uint32_t err = 0;
+  hipError_t e = hipGetLastError();
+  if (e == hipSuccess) e = hipMemcpyAsync(&err, &ctx->ds->view_err, sizeof(err), hipMemcpyDeviceToHost, st);
+  if (e == hipSuccess) e = hipStreamSynchronize(st);
+  if (e != hipSuccess || err) return soft(0);
+  std::swap(ix.s_val, ix.s_val2); std::swap(ix.s_pos, ix.s_pos2); std::swap(ix.s_ids, ix.s_ids2); std::swap(ix.ord_cap, ix.ord_cap2);
+  ix.ord_n = nz; ix.ord_patches++; ix.ord_patched_keys += ktot;
+  ix.last_patch_us = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count();
+  return 0;
+}
+
 // Bring EVERY maintained index up to date from the change log (they share it), then forget the log. Per index: created rows of its field are
 // appended in log order, then every logged row of the field gets its current value. One host sync at the end (appended counts, wide flags).
+// An index whose value-ordered view is current goes on being current: the refresh captures the change run and the view is patched with it.
 int refresh_from_log(bmx_ctx* ctx) {
   const unsigned long long* n_dev = &ctx->ds->chg_n[ctx->chg_par];
   const uint64_t ub = ctx->chg_ub;
-  struct Res { unsigned long long added; uint32_t wide; uint32_t changed; };     // (wide, changed: the two halves of one result word)
+  struct Res { unsigned long long added; uint32_t wide; uint32_t changed; unsigned long long run; };     // (wide, changed: the two halves of one result word)
   std::vector<Res> res(ctx->indexes.size());
+  std::vector<char> capture(ctx->indexes.size(), 0);
   // results of index k live in its own scratch words: part_totals[] is free between partitions (k < PART_MAX_SHARDS indexes are maintained)
   if (ctx->indexes.size() > IX_MAINTAINED_MAX) return fail(ctx, BMX_ERR_INTERNAL, "index maintenance with more indexes than result words");
   if (ub) {
+    HIPCHK(hipMemsetAsync(ctx->ds->view_cl_n, 0, sizeof(ctx->ds->view_cl_n), ctx->stream));
     for (size_t k = 0; k < ctx->indexes.size(); k++) {
       Index& ix = ctx->indexes[k];
+      // the view is current and can stay so: capture the change run (needs room for one entry per log entry)
+      if (ctx->view_patching && ix.ordered_after && ix.s_val && ix.ord_content == ix.content && ix.ord_fits32 == ix.fits32 && ix.n && ix.n < 0xFFFFFFFFull && ub <= VIEW_PATCH_MAX_LOG) {
+        if (ix.cl_cap < ub) {
+          HIPCHK(hipStreamSynchronize(ctx->stream));
+          if (ix.cl_pos) (void)hipFree(ix.cl_pos); if (ix.cl_old) (void)hipFree(ix.cl_old);
+          ix.cl_pos = nullptr; ix.cl_old = nullptr; ix.cl_cap = 0;
+          const uint64_t cap = (ub + ub / 2 + (1u << 16) + 255) & ~255ull;
+          if (hipMalloc(reinterpret_cast<void**>(&ix.cl_pos), cap * sizeof(uint32_t)) == hipSuccess && hipMalloc(reinterpret_cast<void**>(&ix.cl_old), cap * sizeof(int64_t)) == hipSuccess) ix.cl_cap = cap;
+          else { (void)hipGetLastError(); if (ix.cl_pos) (void)hipFree(ix.cl_pos); ix.cl_pos = nullptr; ix.cl_old = nullptr; }
+        }
+        capture[k] = ix.cl_cap >= ub;
+      }
       unsigned long long* d_added = &ctx->ds->part_totals[2 * k];
       uint32_t* d_wide = reinterpret_cast<uint32_t*>(&ctx->ds->part_totals[2 * k + 1]);
       HIPCHK(hipMemsetAsync(d_added, 0, 2 * sizeof(unsigned long long), ctx->stream));
@@ -925,12 +1032,13 @@ int refresh_from_log(bmx_ctx* ctx) {
       LAUNCHCHK("k_sel_write(log)");
       const uint32_t ublocks = (uint32_t)std::min<uint64_t>((ub + 255) / 256, 4096);
       hipLaunchKernelGGL(k_ix_update, dim3(ublocks), dim3(256), 0, ctx->stream, (const uint2*)ctx->chg, n_dev, (const Slot*)ctx->slots, ix.field, (const uint32_t*)ctx->slot_pos,
-                         ix.v64, ix.v32, d_wide, ix.ordered_after ? 1u : 0u);
+                         ix.v64, ix.v32, d_wide, capture[k] ? 2u : (ix.ordered_after ? 1u : 0u), ix.cl_pos, ix.cl_old, &ctx->ds->view_cl_n[k], (uint32_t)std::min<uint64_t>(ix.cl_cap, 0xFFFFFFFFull));
       LAUNCHCHK("k_ix_update");
     }
     for (size_t k = 0; k < ctx->indexes.size(); k++) {
       HIPCHK(hipMemcpyAsync(&res[k].added, &ctx->ds->part_totals[2 * k], sizeof(unsigned long long), hipMemcpyDeviceToHost, ctx->stream));
       HIPCHK(hipMemcpyAsync(&res[k].wide, &ctx->ds->part_totals[2 * k + 1], 2 * sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
+      if (capture[k]) HIPCHK(hipMemcpyAsync(&res[k].run, &ctx->ds->view_cl_n[k], sizeof(unsigned long long), hipMemcpyDeviceToHost, ctx->stream));
     }
     HIPCHK(hipStreamSynchronize(ctx->stream));
   }
@@ -944,7 +1052,16 @@ int refresh_from_log(bmx_ctx* ctx) {
       ix.version = ~0ull; ix.has_pos = false; ctx->chg_valid = false;
       continue;
     }
-    if (ub) { ix.n += res[k].added; if (res[k].wide) ix.fits32 = false; if (res[k].added || res[k].changed || !ix.ordered_after) ix.content++; }   // (no view: nobody compared, nobody cares)
+    if (ub) {
+      const uint64_t n0 = ix.n;
+      ix.n += res[k].added; if (res[k].wide) ix.fits32 = false;
+      const bool moved = res[k].added || res[k].changed || !ix.ordered_after;     // (no view: nobody compared, nobody cares)
+      if (moved) ix.content++;
+      if (moved && capture[k] && ix.fits32 == ix.ord_fits32 && res[k].run <= ix.cl_cap && ix.n < 0xFFFFFFFFull) {
+        const int prc = ix.ord_fits32 ? patch_view_t<int32_t>(ctx, ix, res[k].run, n0, res[k].added) : patch_view_t<int64_t>(ctx, ix, res[k].run, n0, res[k].added);
+        if (prc == 0) ix.ord_content = ix.content;       // the view equals a fresh sort of the columns as they are now
+      }
+    }
     ix.version = ctx->version;
   }
   ctx->ix_incremental++;
@@ -1324,6 +1441,7 @@ int bmx_create_ex(int device, uint64_t capacity_rows, uint32_t max_load_pct, uin
   } else { ctx->stg_tails = nullptr; (void)hipGetLastError(); }
   ctx->fixed_capacity = (flags & BMX_CTX_FIXED_CAPACITY) != 0;
   ctx->defer_enabled = !launches_are_serialized();
+  { const char* vp = std::getenv("BMX_VIEW_PATCH"); if (vp && vp[0] == '0' && !vp[1]) ctx->view_patching = false; }
   { const char* kw = std::getenv("BMX_K1_WAVES"); if (kw && kw[0] >= '3' && kw[0] <= '8' && kw[0] != '7' && !kw[1]) ctx->k1_waves = kw[0] - '0'; }
   CR(hipMemsetAsync(ctx->ds, 0, sizeof(DevScalars), ctx->stream));
   hipLaunchKernelGGL(k_init_slots, dim3(2048), dim3(256), 0, ctx->stream, ctx->slots, nslots);
@@ -1340,7 +1458,7 @@ void bmx_destroy(bmx_ctx* ctx) {
   (void)flush_pending(ctx); // a compaction that was only recorded writes the CALLER's winner list and count: it runs before anything is freed
   (void)hipGetLastError();
   if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
-  if (ctx->side) { (void)hipStreamSynchronize(ctx->side); (void)hipStreamDestroy(ctx->side); ctx->side = nullptr; }
+  if (ctx->side) { (void)hipStreamSynchronize(ctx->side); if (!ctx->side_is_callers) (void)hipStreamDestroy(ctx->side); ctx->side = nullptr; }
   for (auto& ix : ctx->indexes) { dev_free(ix.ids); dev_free(ix.v64); dev_free(ix.v32); free_ordered_view(ix); }
   dev_free(ctx->slots); dev_free(ctx->ds); dev_free(ctx->next); dev_free(ctx->blk_info); dev_free(ctx->blk_follow); dev_free(ctx->shard_ctr);
   for (uint32_t h = 0; h < bmx_ctx::WS_SETS; h++) { dev_free(ctx->wflag[h]); dev_free(ctx->slot_of[h]); dev_free(ctx->fld_ws[h]); }
@@ -1355,6 +1473,8 @@ void bmx_destroy(bmx_ctx* ctx) {
   if (ctx->copy_stream) (void)hipStreamDestroy(ctx->copy_stream);
   if (ctx->down_stream) { (void)hipStreamSynchronize(ctx->down_stream); (void)hipStreamDestroy(ctx->down_stream); }
   dev_free(ctx->slot_pos); dev_free(ctx->chg);
+  for (int i = 0; i < 2; i++) { if (ctx->vk_v[i]) (void)hipFree(ctx->vk_v[i]); dev_free(ctx->vk_p[i]); }
+  dev_free(ctx->vk_dx);
   if (ctx->host_rows) { (void)hipHostFree(ctx->host_rows); ctx->host_rows = nullptr; }
   if (ctx->stg_tails) { (void)hipHostFree(ctx->stg_tails); ctx->stg_tails = nullptr; ctx->stg[0].tail = ctx->stg[1].tail = nullptr; }
   if (ctx->pin_in) { (void)hipHostFree(ctx->pin_in); ctx->pin_in = nullptr; }
@@ -1664,6 +1784,18 @@ int bmx_index_ordered_info(bmx_ctx* ctx, uint32_t field, uint32_t* after_queries
   return BMX_OK;
 }
 
+int bmx_index_ordered_stats(bmx_ctx* ctx, uint32_t field, uint64_t* sorts, uint64_t* patches, uint64_t* keys_patched, double* last_sort_us, double* last_patch_us) {
+  if (!ctx) return fail(nullptr, BMX_ERR_INVALID, "null context");
+  Index* ix = find_index(ctx, field);
+  if (!ix) return fail(ctx, BMX_ERR_INVALID, "bmx_index_ordered_stats: no index on this field");
+  if (sorts) *sorts = ix->ord_sorts;
+  if (patches) *patches = ix->ord_patches;
+  if (keys_patched) *keys_patched = ix->ord_patched_keys;
+  if (last_sort_us) *last_sort_us = ix->last_sort_us;
+  if (last_patch_us) *last_patch_us = ix->last_patch_us;
+  return BMX_OK;
+}
+
 int bmx_scan_range(bmx_ctx* ctx, uint32_t field, int64_t lo, int64_t hi, uint64_t* out_ids, uint64_t cap, uint64_t* n_out, int mem) {
   if (!ctx) return fail(nullptr, BMX_ERR_INVALID, "null context");
   if (int erc = enter(ctx)) return erc;
@@ -1870,6 +2002,22 @@ int bmx_set_deferred_compaction(bmx_ctx* ctx, int on) {
   if (!ctx) return fail(nullptr, BMX_ERR_INVALID, "null context");
   if (int erc = enter(ctx)) return erc;
   ctx->defer_enabled = on != 0 && !launches_are_serialized();    // (never where kernels run one at a time: see launches_are_serialized)
+  return BMX_OK;
+}
+int bmx_set_wait_limit(bmx_ctx* ctx, double seconds) {
+  if (!ctx || !(seconds >= 0.001) || seconds > 3600.0) return fail(ctx, BMX_ERR_INVALID, "bmx_set_wait_limit: 0.001 .. 3600 seconds");
+  HIPCHK(hipSetDevice(ctx->device));
+  const unsigned long long ticks = (unsigned long long)(seconds * 1.0e8);      // wall_clock64(): 100 MHz
+  HIPCHK(hipMemcpyToSymbol(HIP_SYMBOL(g_wait_ticks), &ticks, sizeof(ticks), 0, hipMemcpyHostToDevice));
+  return BMX_OK;
+}
+int bmx_set_side_stream(bmx_ctx* ctx, void* hip_stream) {
+  if (!ctx) return fail(nullptr, BMX_ERR_INVALID, "null context");
+  if (int erc = enter(ctx)) return erc;            // whatever is recorded or still on the old side stream is ordered into the context's stream first
+  HIPCHK(hipStreamSynchronize(ctx->stream));
+  if (ctx->side) { HIPCHK(hipStreamSynchronize(ctx->side)); if (!ctx->side_is_callers) (void)hipStreamDestroy(ctx->side); }
+  ctx->side = hip_stream ? reinterpret_cast<hipStream_t>(hip_stream) : nullptr;    // nullptr: the next deferring merge creates the context's own again
+  ctx->side_is_callers = hip_stream != nullptr;
   return BMX_OK;
 }
 int bmx_merge_fence(bmx_ctx* ctx) {

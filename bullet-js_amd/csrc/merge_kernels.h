@@ -28,6 +28,14 @@
 
 namespace bmx {
 
+// How long a device-side wait (a sequence word, arrival words, the deferred compaction's hand-off) polls before it gives up, sets the context's sticky
+// ST_SPIN status and returns: 100 MHz ticks, ~60 s by default, bmx_set_wait_limit() changes it for the device. A wait also gives up AT ONCE when the
+// context's status already carries ST_SPIN: after one hand-off has failed every wait still queued behind it drains immediately instead of taking its
+// own full limit (round 5: a rank that raised in the middle of the direct exchange left its peer six queued waits = six minutes).
+__device__ unsigned long long g_wait_ticks = 6000000000ull;
+__device__ __forceinline__ bool wait_gave_up(unsigned long long t0, const uint32_t* status) {
+  return wall_clock64() - t0 > g_wait_ticks || (__hip_atomic_load(status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & ST_SPIN) != 0;
+}
 constexpr int PART_MAX_SHARDS = 16;
 struct SeqPtrs { unsigned long long* p[PART_MAX_SHARDS]; };
 
@@ -403,7 +411,7 @@ __global__ __launch_bounds__(256) void k_resolve_lists(MergeArgs A) {
     const unsigned long long t0 = wall_clock64();            // 100 MHz
     while (__hip_atomic_load(A.k3_done, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < A.k3_wait) {
       __builtin_amdgcn_s_sleep(8);
-      if (wall_clock64() - t0 > 6000000000ull) { atomicOr(A.status, ST_SPIN); break; }   // ~60 s: report instead of hanging
+      if (wait_gave_up(t0, A.status)) { atomicOr(A.status, ST_SPIN); break; }   // ~60 s (g_wait_ticks): report instead of hanging
     }
   }
   if (A.tail_n && blockIdx.x == 0 && threadIdx.x < A.tail_n) {     // lane k polls word k (relaxed, cache-bypassing: the acquire is the boundary behind this launch)
@@ -411,8 +419,8 @@ __global__ __launch_bounds__(256) void k_resolve_lists(MergeArgs A) {
     unsigned long long seen;
     while ((seen = __hip_atomic_load(A.tail_words + threadIdx.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM)) < A.tail_at_least) {
       __builtin_amdgcn_s_sleep(8);
-      if (wall_clock64() - t0 > 6000000000ull) {
-        if (A.tail_diag) { A.tail_diag[0] = (unsigned long long)(uintptr_t)(A.tail_words + threadIdx.x); A.tail_diag[1] = A.tail_at_least; A.tail_diag[2] = seen; }
+      if (wait_gave_up(t0, A.status)) {
+        if (A.tail_diag && !A.tail_diag[0]) { A.tail_diag[0] = (unsigned long long)(uintptr_t)(A.tail_words + threadIdx.x); A.tail_diag[1] = A.tail_at_least; A.tail_diag[2] = seen; }
         atomicOr(A.status, ST_SPIN);
         break;
       }
@@ -657,8 +665,8 @@ __global__ void k_seq_wait(const unsigned long long* seq, unsigned long long at_
   unsigned long long seen;
   while ((seen = __hip_atomic_load(seq, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT)) < at_least) {
     __builtin_amdgcn_s_sleep(8);
-    if (wall_clock64() - t0 > 6000000000ull) {             // ~60 s: report instead of hanging
-      if (diag) { diag[0] = (unsigned long long)(uintptr_t)seq; diag[1] = at_least; diag[2] = seen; }
+    if (wait_gave_up(t0, status)) {                        // ~60 s (g_wait_ticks), or an earlier wait of this context failed already: report instead of hanging
+      if (diag && !diag[0]) { diag[0] = (unsigned long long)(uintptr_t)seq; diag[1] = at_least; diag[2] = seen; }
       atomicOr(status, ST_SPIN);
       return;
     }
@@ -675,8 +683,8 @@ __global__ void k_seq_wait_all(const unsigned long long* words, uint32_t n, unsi
   // invalidate the L2 under everything else that runs; measured: +100 us per step with fences inside the kernels)
   while ((seen = __hip_atomic_load(words + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM)) < at_least) {
     __builtin_amdgcn_s_sleep(8);
-    if (wall_clock64() - t0 > 6000000000ull) {             // ~60 s: report instead of hanging
-      if (diag) { diag[0] = (unsigned long long)(uintptr_t)(words + k); diag[1] = at_least; diag[2] = seen; }
+    if (wait_gave_up(t0, status)) {                        // ~60 s (g_wait_ticks), or an earlier wait of this context failed already
+      if (diag && !diag[0]) { diag[0] = (unsigned long long)(uintptr_t)(words + k); diag[1] = at_least; diag[2] = seen; }
       atomicOr(status, ST_SPIN);
       return;
     }

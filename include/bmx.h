@@ -33,8 +33,10 @@ extern "C" {
 /* ABI history. 1: rounds 1-3 (during which BMX_MERGE_BUCKETED 0x800 / BMX_CTX_BUCKETED_MERGE were removed and ~20 entry points added without a bump).
  * 2: every insert_mode bit that is not documented below is refused with BMX_ERR_INVALID; deferred compaction (bmx_set_deferred_compaction,
  *    bmx_merge_fence, bmx_get_deferred_counts); bmx_selfcheck. A caller built against 1 that passes only documented bits keeps working.
- * 3: value-ordered index views (bmx_index_set_ordered, bmx_index_ordered_info): additions only; nothing a caller built against 2 uses has changed. */
-#define BMX_ABI_VERSION 3
+ * 3: value-ordered index views (bmx_index_set_ordered, bmx_index_ordered_info): additions only; nothing a caller built against 2 uses has changed.
+ * 4: a current view stays current under writes (patched from the change log; bmx_index_ordered_stats), BMX_CTX_PLACEMENT_TRIES, bmx_seq_signal on the context's
+ *    stream orders a recorded compaction in front of it: additions and one strengthening; nothing a caller built against 3 uses has changed. */
+#define BMX_ABI_VERSION 4
 
 /* status codes */
 #define BMX_OK             0
@@ -174,6 +176,10 @@ void* bmx_get_stream(bmx_ctx* ctx);
  *                   must already be enqueued (on any stream) when this is called, otherwise the wait can never be satisfied; it
  *                   gives up after ~60 s and raises the context's sticky device error (bmx_sync then reports it).
  * seq_dev is 8-byte aligned device memory owned by the caller, zeroed before first use. Same GPU only. */
+/* bmx_set_wait_limit: how long every device-side wait of this library on the context's DEVICE (all contexts of the process on that GPU) polls before it gives up:
+ * default ~60 s. Once one wait of a context has given up, the waits still queued on that context return at once (the sticky error is reported by bmx_sync as ever).
+ * The sharded bench sets 20 s: a peer that is 20 s late for a 100-us step is gone, and the ranks must reach their agreed fallback inside the collective time-out. */
+int bmx_set_wait_limit(bmx_ctx* ctx, double seconds);
 int bmx_seq_signal(bmx_ctx* ctx, void* hip_stream, uint64_t* seq_dev, uint64_t value);
 int bmx_seq_wait(bmx_ctx* ctx, void* hip_stream, const uint64_t* seq_dev, uint64_t at_least);
 
@@ -235,6 +241,10 @@ int bmx_merge_records(bmx_ctx* ctx, uint64_t n, const bmx_delta_rec* recs, int i
  * is ignored there); kernel traces without counters (rocprofv3 --kernel-trace --stats) do not serialise and keep it on.
  * bmx_get_deferred_counts: merges whose compaction was deferred / of those, how many actually ran on the side stream. */
 int bmx_set_deferred_compaction(bmx_ctx* ctx, int on);
+/* The stream the deferred compactions run on. Default (NULL): a high-priority stream the context creates. A caller that already drives a second stream beside
+ * the merges (the sharded pipeline's exchange stream: bullet-js_amd/bmx/sharded.py) may hand that one in, so that no third hardware queue competes with the two
+ * it has; the compaction of batch b then runs on it behind whatever the caller enqueued there before the merge of batch b + 1. Synchronises both streams once. */
+int bmx_set_side_stream(bmx_ctx* ctx, void* hip_stream);
 int bmx_merge_fence(bmx_ctx* ctx);
 int bmx_get_deferred_counts(bmx_ctx* ctx, uint64_t* deferred, uint64_t* on_side_stream);
 
@@ -293,17 +303,27 @@ int bmx_index_refresh_counts(bmx_ctx* ctx, uint64_t* full_builds, uint64_t* incr
  * over ALL rows per query instead. bmx_index_set_ordered(ctx, field, N >= 1) gives the index the reference's shape: a second copy of its columns sorted by
  * (value, position). While that view is current, bmx_scan_range / _equals / _count / _range_pos on the field are two k-ary searches plus one contiguous copy —
  * O(log R + matches), nothing read that is not part of the answer — and deliver the matches in (value, position) order instead of position order (the set
- * is the same; the host mirror can reproduce the reference's first-seen-value order from either). The view is current as long as no merge, put or rebuild
- * changed a value or added a row of the field (merges on other fields do not touch it). A stale view is sorted again (one radix sort of the column + one
- * gather: milliseconds for 10^8 rows, csrc/ordered_sort.hip) by the N-th query since the change; the N - 1 queries before it scan the column as ever, so a
- * field that is written between any two queries never pays for a sort with N >= 2. N = 0 switches the view off and frees it (3 columns: 16 or 20 bytes per
- * row). bmx_scan_filter takes its candidates from the view of its FIRST term's index when there is one: the other terms are probed for the ids of one run only
- * (survivors then come in no particular order). If the memory cannot be had the index silently goes on without the view. bmx_index_ordered_info: N, whether the view would answer the next query,
- * and how many sorts have run. */
+ * is the same; the host mirror can reproduce the reference's first-seen-value order from either).
+ * Currency (ABI 4: the device-side _updateIndices, src/bullet-query.js:139-176 — the reference moves a path from the bucket of its old value to the bucket of
+ * its new one on every write): a view that is current STAYS current under writes. The refresh that brings the dense columns up to date from the merges' change
+ * log also captures the change run — (position, old value) of every row whose value really changed, plus the appended rows —, sorts it (hand-written LDS tile
+ * sort + rank-merge passes, csrc/view_kernels.h) and merges it into the view in one streaming pass over the sorted columns: n * (w + 12) bytes read and written
+ * (w = 4 or 8), ~0.1 ms at 10^7 rows, under a millisecond at 10^8 — paid once by the first query after any number of merges on the field, never by the merges;
+ * merges on other fields, merges that lose and rewrites of the same value cost nothing. Memory: a second set of the view's columns from the first patch on (the
+ * two sets swap), i.e. 32 or 40 bytes per row in all, + 12 bytes per logged winner for the change run. The view goes STALE (and is sorted again from scratch,
+ * below) only when it cannot be patched: after an index rebuild (table growth, merges that do not log, a log longer than an eighth of the table or 2^24 entries),
+ * when a value stops fitting int32 (the index switches columns), without memory for the second set, or with BMX_VIEW_PATCH=0 in the environment (A/B switch).
+ * A stale (or new) view is sorted (one radix sort of the column + one gather: milliseconds for 10^8 rows, csrc/ordered_sort.hip) by the N-th query since the
+ * columns last changed; the N - 1 queries before it scan the column as ever. N = 0 switches the view off and frees it. bmx_scan_filter takes its candidates from
+ * the view of its FIRST term's index when there is one: the other terms are probed for the ids of one run only (survivors then come in no particular order).
+ * If the memory cannot be had the index silently goes on without the view. bmx_index_ordered_info: N, whether the view would answer the next query, and how many
+ * sorts have run; bmx_index_ordered_stats: sorts, patches, keys moved by the patches (deleted + inserted), and what the last sort / the last patch cost the
+ * caller in microseconds (outputs may be NULL). */
 #define BMX_INDEX_ORDERED_AUTO 0xFFFFFFFFu   /* after_queries chosen by the engine: sort once the scans since the change have cost what the sort costs (rent-or-buy:
                                                * never more than twice the cheapest schedule, whatever comes next): ~70 queries on 10^8 int32 rows, ~25 on 10^7 */
 int bmx_index_set_ordered(bmx_ctx* ctx, uint32_t field, uint32_t after_queries);
 int bmx_index_ordered_info(bmx_ctx* ctx, uint32_t field, uint32_t* after_queries, int* valid_now, uint64_t* sorts);
+int bmx_index_ordered_stats(bmx_ctx* ctx, uint32_t field, uint64_t* sorts, uint64_t* patches, uint64_t* keys_patched, double* last_sort_us, double* last_patch_us);
 int bmx_scan_range(bmx_ctx* ctx, uint32_t field, int64_t lo, int64_t hi, uint64_t* out_ids, uint64_t cap,
                    uint64_t* n_out, int mem);
 int bmx_scan_equals(bmx_ctx* ctx, uint32_t field, int64_t value, uint64_t* out_ids, uint64_t cap, uint64_t* n_out,

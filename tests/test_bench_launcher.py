@@ -188,7 +188,7 @@ def _full_out():
     size = lambda: {"rows": 100000000, "column": "int32", "index_first_build_ms": 3.9, "index_build_ms": 3.9, "equals_0.1pct": q(79.3), "range_1pct": q(91.3), "range_10pct": q(225.7),
                     "range_50pct": q(337.7), "verified": {"against": "numpy " * 30, "scans_checked": 16, "ok": True},
                     "ordered_view": {"sort_ms": 4.6, "equals_0.1pct": ovq, "range_1pct": ovq, "range_10pct": ovq, "range_50pct": ovq, "note": "n" * 300,
-                                     "view_first_equals_after_merge_us": 812.5, "view_next_equals_us": 7.1, "view_kept_current_by": "sorted change run merged into the view"},
+                                     "first_equals_after_a_1M_delta_merge_us": 812.5, "next_equals_us": 7.1, "view_kept_current_by": "patch", "patch_us": 700.1, "patch_keys": 2100000},
                     "first_scan_after_a_1M_delta_merge": {"us": 293.9, "index_brought_up_to_date_by": "change log", "matches": 100096, "index_rows": 100100000}}
     return {"metric": "CRDT field-merges/s", "value": 12872332136.121153, "unit": "merges/s", "n_gpus": 8, "steps": 20, "warmup": 3, "ms_per_step": 0.07768600044073537,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "int64", "data": "synthetic",
@@ -236,6 +236,7 @@ def test_the_stdout_line_stays_short_whatever_sections_a_run_adds(tmp_path):
     assert j["exchange"]["kind"] == "rccl" and j["exchange"]["refused"] == "direct" and "cannot map" in j["exchange"]["why"]
     assert j["scan_config3"]["100M"]["mask_frac"] == 0.7654 and j["scan_config3"]["100M"]["range10_ids_us"] == 225.7
     assert j["js_host"]["store_kept_entries_per_s"] == 698754.0 and j["detail"] == "bench_detail.json"
+    assert j["scan_config3"]["100M"]["view_first_equals_after_merge_us"] == 812.5 and j["scan_config3"]["100M"]["view_kept_current_by"] == "patch"
     # sections are given up from the end, never the contract: a record that cannot fit still yields a parseable short line
     huge = _full_out()
     huge["scan_config3"] = {"%dM" % i: huge["scan_config3"]["100M"] for i in range(60)}

@@ -28,7 +28,7 @@ def test_every_declared_symbol_is_exported(lib):
 
 
 def test_abi_version(lib):
-    assert lib.bmx_abi_version() == 3
+    assert lib.bmx_abi_version() == 4
 
 
 def test_owner_of_matches_oracle(lib):

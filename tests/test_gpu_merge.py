@@ -35,7 +35,7 @@ def _assert_same_state(e, o):
 def test_library_reports_abi_and_device():
     with bmx.Engine(1000) as e:
         i = e.info()
-        assert i.abi_version == 3 and i.n_rows == 0 and i.n_slots >= 2000 and i.table_bytes == i.n_slots * 32
+        assert i.abi_version == 4 and i.n_rows == 0 and i.n_slots >= 2000 and i.table_bytes == i.n_slots * 32
 
 
 def test_decision_table_golden():

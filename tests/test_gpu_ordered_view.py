@@ -119,11 +119,12 @@ def test_the_view_follows_every_change_of_its_field_and_nothing_else():
             e.put_rows(ids[d], np.full(len(d), FA, np.uint32), np.full(len(d), 1000 * (rnd + 1) + 1, np.int64), np.full(len(d), VAL_DELETED, np.int64))
             alive[d] = False
             s0 = e.index_ordered_info(FA)[2]
-            _q(e, FA, ids, vals, 50, 60, alive); assert e.index_ordered_info(FA) == (2, False, s0)       # scanned: the view is stale
-            _q(e, FA, ids, vals, 50, 60, alive); assert e.index_ordered_info(FA) == (2, True, s0 + 1)    # sorted again
+            p0 = e.index_ordered_stats(FA)["patches"]
+            _q(e, FA, ids, vals, 50, 60, alive); assert e.index_ordered_info(FA) == (2, True, s0)        # round 5: the refresh patched the view, nothing was sorted
+            assert e.index_ordered_stats(FA)["patches"] == p0 + 1
             for lo, hi in [(0, 0), (0, 299), (299, 299), (120, 180), (-5, 3)]:
                 _check(e, FA, ids, vals, lo, hi, alive)
-            assert e.index_ordered_info(FA) == (2, True, s0 + 1)
+            assert e.index_ordered_info(FA) == (2, True, s0) and e.index_ordered_stats(FA)["patches"] == p0 + 1
         # a value that does not fit int32 arrives: the index switches to its 8-byte column, and the view is sorted from THAT
         k = rng.choice(R, 3, replace=False)
         wide = np.array([1 << 40, -(1 << 41), (1 << 31)], np.int64)
@@ -141,6 +142,141 @@ def test_the_view_follows_every_change_of_its_field_and_nothing_else():
         _check(e, FA, ids, vals, 7, 9, alive)
         e.index_drop(FA)
         _check(e, FA, ids, vals, 7, 9, alive)           # a query re-creates the index, without a view
+
+
+def _merge(e, f, k_ids, ts, nv):
+    e.merge_batch(k_ids, np.full(len(k_ids), f, np.uint32), np.full(len(k_ids), ts, np.int64), nv)
+
+
+@pytest.mark.parametrize("wide", [False, True])
+def test_a_current_view_stays_current_under_interleaved_merges_and_queries(wide):
+    """VERDICT r4 item 4 (src/bullet-query.js:139-176: the reference moves a path between value buckets on every write): merges, puts, creations and
+    tombstones on the indexed field interleaved with queries — every query is answered from the view (ids, positions, counts equal numpy over the
+    model), NOTHING is ever sorted again, every refresh that changed something patched the view once. Rows changed twice between two queries, rows
+    changed back to the value they had, duplicate keys inside a batch, revived tombstones, appended rows that sort in front of / behind everything."""
+    R = 600_000
+    sh = 34 if wide else 0
+    rng = np.random.default_rng(21 + wide)
+    ids = streams.splitmix64_np(np.arange(1, R + 1, dtype=np.uint64))
+    vals = rng.integers(0, 500, R).astype(np.int64) << sh
+    alive = np.ones(R, bool)
+    F = FS if wide else FA
+    clock = 10
+    with bmx.Engine(4 * R) as e:
+        e.load_rows(ids, np.full(R, F, np.uint32), np.full(R, clock, np.int64), vals)
+        e.index_build(F); e.index_set_ordered(F, 1)
+        _q(e, F, ids, vals, 3 << sh, 9 << sh)
+        assert e.index_ordered_info(F) == (1, True, 1)
+        patches = 0
+        for rnd in range(8):
+            n_now = len(ids)
+            snap = vals.copy()
+            # (a) a merge that changes values (duplicate keys inside the batch: the last-writer rule picks one)
+            k = rng.choice(n_now, 40_000, replace=True)
+            nv = rng.integers(0, 500, len(k)).astype(np.int64) << sh
+            clock += 10
+            tsb = np.full(len(k), clock, np.int64)
+            e.merge_batch(ids[k], np.full(len(k), F, np.uint32), tsb, nv)
+            best = {}
+            for j in range(len(k)):          # equal clocks inside the batch: the larger value wins (src/bullet-crt.js:200-233)
+                if int(k[j]) not in best or int(nv[j]) > best[int(k[j])]:
+                    best[int(k[j])] = int(nv[j])
+            kk = np.fromiter(best.keys(), np.int64); vv = np.fromiter(best.values(), np.int64)
+            vals[kk] = vv; alive[kk] = True
+            if rnd % 2 == 1:
+                # (b) a SECOND merge before any query: some of the same rows change again, some go back to the value the view still holds
+                k2 = kk[: len(kk) // 3]
+                clock += 10
+                nv2 = rng.integers(0, 500, len(k2)).astype(np.int64) << sh
+                nv2[::2] = snap[k2[::2]]                         # ... back to what the view holds: no key moves for these rows after all
+                _merge(e, F, ids[k2], clock, nv2); vals[k2] = nv2
+            # (c) new rows: below every value, above every value, in the middle
+            newn = 700
+            new_ids = streams.splitmix64_np(np.arange(50_000_000 + rnd * 10_000, 50_000_000 + rnd * 10_000 + newn, dtype=np.uint64))
+            new_vals = np.concatenate([np.full(100, -5 - rnd, np.int64) << sh, np.full(100, 900 + rnd, np.int64) << sh, rng.integers(0, 500, newn - 200).astype(np.int64) << sh])
+            clock += 10
+            _merge(e, F, new_ids, 5, new_vals)
+            ids = np.concatenate([ids, new_ids]); vals = np.concatenate([vals, new_vals]); alive = np.concatenate([alive, np.ones(newn, bool)])
+            # (d) tombstones, some on rows that (a) just changed
+            d = np.concatenate([rng.choice(n_now, 1_500, replace=False), kk[:200]])
+            d = np.unique(d)
+            clock += 10
+            e.put_rows(ids[d], np.full(len(d), F, np.uint32), np.full(len(d), clock, np.int64), np.full(len(d), VAL_DELETED, np.int64))
+            alive[d] = False
+            # the first query after the writes: patched, current, nothing sorted
+            _q(e, F, ids, vals, 40 << sh, 60 << sh, alive)
+            patches += 1
+            st = e.index_ordered_stats(F)
+            assert e.index_ordered_info(F) == (1, True, 1) and st["sorts"] == 1 and st["patches"] == patches, (rnd, st)
+            top = int(vals.max())
+            for lo, hi in [(0, 0), (0, 499 << sh), (-(1 << 50), 1 << 50), ((-5 - rnd) << sh, (-5 - rnd) << sh), (top, top), (250 << sh, 251 << sh), (7 << sh, 6 << sh)]:
+                _check(e, F, ids, vals, lo, hi, alive)
+            assert e.index_ordered_stats(F)["patches"] == patches           # queries do not patch
+            # a merge on this field that LOSES everywhere (old clock): the view is left alone
+            k3 = rng.choice(len(ids), 5_000, replace=False)
+            _merge(e, F, ids[k3], 1, (vals[k3] + (1 << sh)))
+            _check(e, F, ids, vals, 100 << sh, 130 << sh, alive)
+            assert e.index_ordered_stats(F)["patches"] == patches
+        # the view equals what a fresh sort of the same columns gives: drop it, sort again, compare a whole-range position listing
+        pos_patched = e.scan_range_pos(F, -(1 << 50), 1 << 50)
+        e.index_set_ordered(F, 0); e.index_set_ordered(F, 1)
+        pos_sorted = e.scan_range_pos(F, -(1 << 50), 1 << 50)
+        assert e.index_ordered_stats(F)["sorts"] == 2 and e.index_ordered_info(F)[1]       # (a new view: sorted from the columns as they are now)
+        assert np.array_equal(pos_patched, pos_sorted)
+
+
+def test_patch_of_a_large_view_with_a_skewed_change_run():
+    """20M rows, a 1M-delta batch whose new values all land in ONE narrow stretch of the value domain (every inserted key falls into a few tiles of the
+    view: the LDS window of the streaming merge overflows there and the global-memory search takes over), plus rows appended behind everything"""
+    R = 20_000_000
+    rng = np.random.default_rng(33)
+    ids = streams.splitmix64_np(np.arange(1, R + 1, dtype=np.uint64))
+    vals = rng.integers(0, 1000, R).astype(np.int64)
+    with bmx.Engine(R + 4_000_000) as e:
+        e.load_rows(ids, np.full(R, FA, np.uint32), np.full(R, 5, np.int64), vals)
+        e.index_build(FA); e.index_set_ordered(FA, 1)
+        assert e.scan_count(FA, 10, 19) == int(((vals >= 10) & (vals <= 19)).sum())
+        k = rng.choice(R, 1_000_000, replace=False)
+        nv = np.full(len(k), 777, np.int64); nv[::3] = 778
+        _merge(e, FA, ids[k], 50, nv); vals[k] = nv
+        new_ids = streams.splitmix64_np(np.arange(900_000_000, 900_000_000 + 300_000, dtype=np.uint64))
+        new_vals = np.full(300_000, 5000, np.int64)
+        _merge(e, FA, new_ids, 5, new_vals)
+        ids = np.concatenate([ids, new_ids]); vals = np.concatenate([vals, new_vals])
+        for lo, hi in [(777, 777), (778, 778), (0, 776), (779, 999), (5000, 5000), (0, 1 << 40)]:
+            assert e.scan_count(FA, lo, hi) == int(((vals >= lo) & (vals <= hi)).sum()), (lo, hi)
+        st = e.index_ordered_stats(FA)
+        assert st["sorts"] == 1 and st["patches"] == 1, st
+        got = e.scan_range(FA, 777, 778)
+        assert np.array_equal(np.sort(got), np.sort(ids[(vals >= 777) & (vals <= 778)]))
+        pos = e.scan_range_pos(FA, 5000, 5000)
+        assert np.array_equal(np.sort(e.index_ids(FA)[pos]), np.sort(new_ids))
+
+
+def test_without_patching_a_field_written_between_any_two_queries_never_pays_for_a_sort(monkeypatch):
+    """ADVICE r4 (bmx.hip stale_queries): with N = 2 and write / query / write / query ... the stale-query count belongs to ONE change of the columns
+    and starts again with the next; it used to count since the last SORT, so every second query sorted a view the next write threw away. Patching is
+    switched off for this context (BMX_VIEW_PATCH=0, read at create): this is the policy for views that cannot be patched."""
+    monkeypatch.setenv("BMX_VIEW_PATCH", "0")
+    R = 300_000
+    rng = np.random.default_rng(13)
+    ids = streams.splitmix64_np(np.arange(1, R + 1, dtype=np.uint64))
+    vals = rng.integers(0, 300, R).astype(np.int64)
+    with bmx.Engine(4 * R) as e:
+        monkeypatch.delenv("BMX_VIEW_PATCH")
+        e.load_rows(ids, np.full(R, FA, np.uint32), np.full(R, 5, np.int64), vals)
+        e.index_build(FA); e.index_set_ordered(FA, 2)
+        _q(e, FA, ids, vals, 1, 2); _q(e, FA, ids, vals, 1, 2)
+        assert e.index_ordered_info(FA) == (2, True, 1)
+        for rnd in range(6):
+            k = rng.choice(R, 10_000, replace=False)
+            nv = rng.integers(0, 300, len(k)).astype(np.int64)
+            _merge(e, FA, ids[k], 100 + rnd, nv); vals[k] = nv
+            _q(e, FA, ids, vals, 10, 40)
+            assert e.index_ordered_info(FA) == (2, False, 1), rnd           # one query per change: scanned every time, never sorted
+        assert e.index_ordered_stats(FA)["patches"] == 0
+        _q(e, FA, ids, vals, 10, 40)                                        # the SECOND query since the last change sorts
+        assert e.index_ordered_info(FA) == (2, True, 2)
 
 
 def test_small_and_degenerate_columns():
