@@ -826,6 +826,7 @@ def main(argv=None):
         for b in range(W, nb):
             step(b)
         eng.timer_mark()
+        t_enq = time.perf_counter() - t0             # the host's share: K enqueue calls (a host-bound run shows here, not in the kernels)
         torch.cuda.synchronize()
         wall = time.perf_counter() - t0
         ev_ms = eng.timer_elapsed()
@@ -878,7 +879,7 @@ def main(argv=None):
                     "kernel_ms": {k: round(v, 5) for k, v in stage_ms.items()}, "launches_averaged": ncalls,
                     "whole_merge_achieved_GBs": round((56.0 * D_PER_STEP + 20.0 * wavg) / (elapsed / K) / 1e9, 1)}
         total_units = K * D_PER_STEP
-        extra.update({"event_ms_per_step": round(ev_ms / K, 5), "winners_per_step": round(wavg, 1),
+        extra.update({"event_ms_per_step": round(ev_ms / K, 5), "host_enqueue_ms_per_step": round(t_enq / K * 1e3, 5), "winners_per_step": round(wavg, 1),
                       "table_placement": dict(eng.placement(), note="bmx_create allocates a large table several times and keeps the candidate on which the merge kernel's request mix (2^20 random slot reads + exchanges + stores) runs fastest: include/bmx.h bmx_get_placement"),
                       "deferred_compaction": dict(zip(("merges_deferred", "compactions_on_side_stream"), eng.deferred_counts()))})
         if CONFIG == 5:

@@ -707,6 +707,7 @@ int merge_records_internal(bmx_ctx* ctx, uint64_t n, const bmx_delta_rec* recs, 
 // Host batches go through two staging sets. submit: upload on the copy stream, then the merge on the main stream behind an event;
 // collect: results back on the copy stream once the batch's kernels are done. While the host uploads batch b+1 (a pageable
 // hipMemcpyAsync keeps the calling thread busy for the whole transfer) the GPU merges batch b.
+__global__ void k_noop() {}
 __global__ void k_small_tail(const unsigned long long* n_applied, const bmx_merge_stats* stats, const uint32_t* status, SmallOut* out) {
   if (threadIdx.x == 0) { out->n_applied = *n_applied; out->stats = *stats; out->status = *status; }
 }
@@ -1124,6 +1125,7 @@ int ensure_scan_scratch(bmx_ctx* ctx, uint64_t n) {
 // no gather) / the count according to `mem`. `out` is uint64_t* or uint32_t* accordingly.
 // a value column above this size is read with nontemporal loads: it cannot stay in the 256 MiB Infinity Cache between two scans anyway (scan_kernels.h)
 constexpr uint64_t SCAN_NT_BYTES = 256ull << 20;
+constexpr uint32_t SCAN_NTX_DEFAULT = 0;      // EmitIds::ntx (profiles/r05_scan_nt_emit_ab.log)
 
 // ---- value-ordered view (bmx.h bmx_index_set_ordered) ----
 // Is the view of `ix` usable for the query at hand? A stale one is sorted again by the ordered_after-th query since the columns last changed — the
@@ -1254,7 +1256,8 @@ int run_scan_t(bmx_ctx* ctx, const Pred& P, const Index* ix, void* out_v, uint64
     if constexpr (POS) Em = EmitPos{d_out, d_cap};
     else {
       const char* sm = std::getenv("BMX_SCAN_STREAM_MIN");      // measurement switch: matches per block from which the id column is streamed (0xFFFFFFFF: never)
-      Em = EmitIds{ix->ids, d_out, d_cap, ix->n * sizeof(uint64_t) > SCAN_NT_BYTES, sm ? (uint32_t)std::strtoul(sm, nullptr, 0) : SCAN_STREAM_MIN};
+      const char* nx = std::getenv("BMX_SCAN_NT");               // measurement switch: EmitIds::ntx
+      Em = EmitIds{ix->ids, d_out, d_cap, ix->n * sizeof(uint64_t) > SCAN_NT_BYTES, sm ? (uint32_t)std::strtoul(sm, nullptr, 0) : SCAN_STREAM_MIN, nx ? (uint32_t)std::strtoul(nx, nullptr, 0) : SCAN_NTX_DEFAULT};
     }
     using EmT = decltype(Em);
     FinishCount Fin{d_n};
@@ -1354,7 +1357,8 @@ int bmx_selfcheck(int device, uint64_t* reads_out, uint64_t* torn_out, uint64_t*
   }
   unsigned long long h[4] = {0, 0, 0, 0};
   hipStream_t cs = nullptr;       // a stream of its own: no device-wide synchronisation, nothing of another context or library is waited for
-  hipError_t e = hipStreamCreateWithFlags(&cs, hipStreamNonBlocking);
+  const char* nul = std::getenv("BMX_SELFCHECK_NULL_STREAM");     // measurement switch (round 5): the device's null stream, as rounds 1-4 used
+  hipError_t e = (nul && nul[0] == '1') ? hipSuccess : hipStreamCreateWithFlags(&cs, hipStreamNonBlocking);
   if (e == hipSuccess) e = hipMemsetAsync(slots, 0, (size_t)NS * 32, cs);
   if (e == hipSuccess) e = hipMemsetAsync(d, 0, 4 * sizeof(unsigned long long), cs);
   if (e == hipSuccess) { hipLaunchKernelGGL(k_selfcheck_tear<false>, dim3(BLOCKS), dim3(256), 0, cs, slots, NS, ITERS, d, d + 1); e = hipGetLastError(); }
@@ -1393,6 +1397,22 @@ int bmx_create_ex(int device, uint64_t capacity_rows, uint32_t max_load_pct, uin
   hipError_t e = hipGetDeviceCount(&ndev);
   if (e != hipSuccess || ndev == 0) return fail(nullptr, BMX_ERR_NO_DEVICE, "no HIP device: this library has no CPU path");
   if (device < 0 || device >= ndev) return fail(nullptr, BMX_ERR_INVALID, "bmx_create: device index out of range");
+  {  // Once per device and process, BEFORE any stream of this library exists: one empty launch on the device's NULL stream. Measured (profiles/r05_defer_timeline_*.txt,
+     // r05_step_regression.log): the runtime gives the first stream that is USED in a process its first hardware queue, and a context stream that lands there does not
+     // yield wave slots to the high-priority side stream — the deferred compaction then waits ~50 us per step for slots (k_seq_signal, one wave, 54 us; k_resolve_lists
+     // 54 instead of 5 us; 141-147 us per step instead of 77-84). Rounds 1-4 used the null stream by accident (the self-check ran there), which is why the deferral
+     // worked; with BMX_SKIP_SELFCHECK=1 it never did (round-4 tree, same box: 76.8 -> 140.9 us). The null stream takes that first queue and keeps it.
+    static std::atomic<unsigned> touched[64];
+    const char* no = std::getenv("BMX_NO_NULL_STREAM_TOUCH");
+    if (device < 64 && !(no && no[0] == '1') && !touched[device].load()) {
+      if (hipSetDevice(device) == hipSuccess) {
+        hipLaunchKernelGGL(k_noop, dim3(1), dim3(64), 0, nullptr);
+        (void)hipStreamSynchronize(nullptr);
+      }
+      (void)hipGetLastError();
+      touched[device].store(1u);
+    }
+  }
   {  // once per device and process: the 16-byte load/store indivisibility the probe kernel relies on is checked on THIS box (BMX_SKIP_SELFCHECK=1 skips it)
     static std::atomic<unsigned> checked[64];
     const char* skip = std::getenv("BMX_SKIP_SELFCHECK");

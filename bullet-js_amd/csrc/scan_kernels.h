@@ -268,8 +268,12 @@ struct EmitIds {  // index position -> node id (bounded by cap)
   static constexpr bool STREAMABLE = true;     // dense blocks read their part of the id column as a stream (select.h scan_emit_stream_block)
   const uint64_t* ids; uint64_t* out; uint64_t cap; bool nt = false;   // nt: the id column is larger than the Infinity Cache and read once per scan
   uint32_t stream_min = SCAN_STREAM_MIN;       // matches per 8192-row block from which the block streams (a launch argument so that one process can A/B it)
+  uint32_t ntx = 0;                            // round 5 A/B (BMX_SCAN_NT): bit 0 = the gathered ids are loaded nontemporally too, bit 1 = the output is stored nontemporally
   __device__ __forceinline__ uint32_t stream_from() const { return stream_min; }
-  __device__ void operator()(uint64_t pos, uint64_t i) const { if (out && pos < cap) out[pos] = ids[i]; }
+  __device__ __forceinline__ void st1(uint64_t pos, uint64_t id) const { if (ntx & 2u) __builtin_nontemporal_store((unsigned long long)id, reinterpret_cast<unsigned long long*>(out + pos)); else out[pos] = id; }
+  __device__ void operator()(uint64_t pos, uint64_t i) const {
+    if (out && pos < cap) st1(pos, (nt && (ntx & 1u)) ? (uint64_t)__builtin_nontemporal_load(reinterpret_cast<const unsigned long long*>(ids + i)) : ids[i]);
+  }
   __device__ __forceinline__ void load2(uint64_t row, uint64_t& a, uint64_t& b) const {   // ids[row], ids[row + 1]; row is even: 16-byte aligned
     typedef unsigned long long u64x2_t __attribute__((ext_vector_type(2)));
     u64x2_t v;
@@ -277,13 +281,13 @@ struct EmitIds {  // index position -> node id (bounded by cap)
     a = v.x; b = v.y;
   }
   __device__ __forceinline__ uint64_t load1(uint64_t row) const { return ids[row]; }
-  __device__ __forceinline__ void put(uint64_t pos, uint64_t id) const { if (out && pos < cap) out[pos] = id; }
+  __device__ __forceinline__ void put(uint64_t pos, uint64_t id) const { if (out && pos < cap) st1(pos, id); }
   __device__ __forceinline__ uint32_t odd(uint64_t pos) const { return (uint32_t)((reinterpret_cast<uintptr_t>(out + pos) >> 3) & 1u); }
   __device__ __forceinline__ void put2(uint64_t pos, uint64_t a, uint64_t b) const {       // out[pos], out[pos + 1]; &out[pos] is 16-byte aligned (odd(pos) == 0): one store
     typedef unsigned long long u64x2_t __attribute__((ext_vector_type(2)));
     if (!out) return;
-    if (pos + 1 < cap) { u64x2_t v; v.x = a; v.y = b; *reinterpret_cast<u64x2_t*>(out + pos) = v; }
-    else if (pos < cap) out[pos] = a;
+    if (pos + 1 < cap) { u64x2_t v; v.x = a; v.y = b; if (ntx & 2u) __builtin_nontemporal_store(v, reinterpret_cast<u64x2_t*>(out + pos)); else *reinterpret_cast<u64x2_t*>(out + pos) = v; }
+    else if (pos < cap) st1(pos, a);
   }
 };
 struct EmitPos {  // index position itself (u32, bounded by cap): no read of the id column — the caller maps positions to whatever it mirrors per index row

@@ -39,6 +39,42 @@ __device__ __forceinline__ uint32_t u32_lower_bound(const uint32_t* __restrict__
   while (lo < hi) { const uint32_t mid = lo + ((hi - lo) >> 1); if (a[mid] < key) lo = mid + 1; else hi = mid; }
   return lo;
 }
+// The same bounds found by a whole WAVE (every lane calls it with the same arguments and gets the answer): 64-ary search like ordered_bound — every round
+// 63 lanes probe evenly spaced keys of [L, R) and a ballot says between which two the bound lies. A binary search over a run of a million keys is a chain of
+// 20 dependent loads (10-15 us of latency that every workgroup of a merge pass paid before its first key moved); this is four rounds.
+template <class T, bool UPPER = false>
+__device__ __forceinline__ uint64_t vk_bound_wave(const T* __restrict__ v, const uint32_t* __restrict__ p, uint64_t L, uint64_t R, T kv, uint32_t kp) {
+  const uint32_t lane = threadIdx.x & 63u;
+  while (R - L > 64) {
+    const uint64_t step = (R - L + 63) / 64;
+    const uint64_t c = L + (uint64_t)lane * step;        // lane 0 probes nothing (c == L)
+    bool before = false;
+    if (lane > 0 && c < R) { const T x = v[c]; const uint32_t xp = p[c]; before = UPPER ? !vk_less<T>(kv, kp, x, xp) : vk_less<T>(x, xp, kv, kp); }
+    const uint32_t t = (uint32_t)__popcll(__ballot(before));        // sorted keys: lanes 1..t are in front of the bound
+    const uint64_t nl = t ? L + (uint64_t)t * step + 1 : L;
+    const uint64_t cr = L + (uint64_t)(t + 1) * step;
+    R = (t < 63 && cr < R) ? cr : R;
+    L = nl;
+  }
+  bool before = false;
+  if (L + lane < R) { const T x = v[L + lane]; const uint32_t xp = p[L + lane]; before = UPPER ? !vk_less<T>(kv, kp, x, xp) : vk_less<T>(x, xp, kv, kp); }
+  return L + (uint64_t)__popcll(__ballot(before));
+}
+__device__ __forceinline__ uint32_t u32_lower_bound_wave(const uint32_t* __restrict__ a, uint32_t L, uint32_t R, uint32_t key) {
+  const uint32_t lane = threadIdx.x & 63u;
+  while (R - L > 64) {
+    const uint32_t step = (R - L + 63) / 64;
+    const uint32_t c = L + lane * step;
+    const bool before = lane > 0 && c < R && a[c] < key;
+    const uint32_t t = (uint32_t)__popcll(__ballot(before));
+    const uint32_t nl = t ? L + t * step + 1 : L;
+    const uint32_t cr = L + (t + 1) * step;
+    R = (t < 63 && cr < R) ? cr : R;
+    L = nl;
+  }
+  const bool before = L + lane < R && a[L + lane] < key;
+  return L + (uint32_t)__popcll(__ballot(before));
+}
 
 // Up to two independent key arrays sorted by the same launches (the deleted keys and the inserted keys of one patch): segment s occupies
 // [base[s], base[s] + len[s]) of the key arrays and blocks [blk0[s], blk0[s + 1]) of the grid.
@@ -118,8 +154,12 @@ __global__ __launch_bounds__(256) void k_view_merge_pass(const T* __restrict__ v
   const uint32_t e = e0 + threadIdx.x;
   const uint32_t last = (e0 + 255u < len ? e0 + 255u : len - 1u);
   const T* V = vin + base; const uint32_t* P = pin + base;
-  if (threadIdx.x == 0) win[0] = q0 == q1 ? q0 : (uint32_t)(left ? vk_bound<T, false>(V, P, q0, q1, V[e0], P[e0]) : vk_bound<T, true>(V, P, q0, q1, V[e0], P[e0]));
-  if (threadIdx.x == 64) win[1] = q0 == q1 ? q0 : (uint32_t)(left ? vk_bound<T, false>(V, P, q0, q1, V[last], P[last]) : vk_bound<T, true>(V, P, q0, q1, V[last], P[last]));
+  const uint32_t w = threadIdx.x >> 6;
+  if (w < 2) {           // wave 0: where the workgroup's first key stands in the partner run, wave 1: where its last key does
+    const uint32_t k = w == 0 ? e0 : last;
+    const uint32_t b = q0 == q1 ? q0 : (uint32_t)(left ? vk_bound_wave<T, false>(V, P, q0, q1, V[k], P[k]) : vk_bound_wave<T, true>(V, P, q0, q1, V[k], P[k]));
+    if ((threadIdx.x & 63u) == 0) win[w] = b;
+  }
   __syncthreads();
   if (e >= len) return;
   const T kv = V[e]; const uint32_t kp = P[e];
@@ -137,8 +177,12 @@ __global__ __launch_bounds__(256) void k_view_find(const T* __restrict__ xv, con
   const uint32_t i0 = blockIdx.x * 256u;
   if (i0 >= nd) return;
   const uint32_t last = i0 + 255u < nd ? i0 + 255u : nd - 1u;
-  if (threadIdx.x == 0) win[0] = (uint32_t)vk_bound<T>(xv, xp, 0, nx, dv[i0], dp[i0]);
-  if (threadIdx.x == 64) win[1] = (uint32_t)vk_bound<T>(xv, xp, 0, nx, dv[last], dp[last]);
+  const uint32_t w = threadIdx.x >> 6;
+  if (w < 2) {
+    const uint32_t k = w == 0 ? i0 : last;
+    const uint32_t b = (uint32_t)vk_bound_wave<T>(xv, xp, 0, nx, dv[k], dp[k]);
+    if ((threadIdx.x & 63u) == 0) win[w] = b;
+  }
   __syncthreads();
   const uint32_t i = i0 + threadIdx.x;
   if (i >= nd) return;
@@ -173,10 +217,15 @@ __global__ __launch_bounds__(256) void k_view_merge(ViewRun<T> X, uint32_t nx, c
       const uint32_t i = lo + u * 256u + threadIdx.x;
       if (i < hi) { xv[u] = __builtin_nontemporal_load(X.v + i); xp[u] = __builtin_nontemporal_load(X.p + i); xi[u] = __builtin_nontemporal_load(X.ids + i); }
     }
-    if (threadIdx.x == 0) win[0] = u32_lower_bound(dx, 0, ndx, lo);
-    if (threadIdx.x == 64) win[1] = u32_lower_bound(dx, 0, ndx, hi);
-    if (threadIdx.x == 128) win[2] = (uint32_t)vk_bound<T>(yv, yp, 0, ny, X.v[lo], X.p[lo]);
-    if (threadIdx.x == 192) win[3] = (uint32_t)vk_bound<T>(yv, yp, 0, ny, X.v[hi - 1], X.p[hi - 1]);
+    {   // one wave per window end: the deleted indices in [lo, hi), the keys of Y between the tile's first and last key
+      const uint32_t w = threadIdx.x >> 6;
+      uint32_t b;
+      if (w == 0) b = u32_lower_bound_wave(dx, 0, ndx, lo);
+      else if (w == 1) b = u32_lower_bound_wave(dx, 0, ndx, hi);
+      else if (w == 2) b = (uint32_t)vk_bound_wave<T>(yv, yp, 0, ny, X.v[lo], X.p[lo]);
+      else b = (uint32_t)vk_bound_wave<T>(yv, yp, 0, ny, X.v[hi - 1], X.p[hi - 1]);
+      if ((threadIdx.x & 63u) == 0) win[w] = b;
+    }
     __syncthreads();
     const uint32_t d0 = win[0], d1 = win[1], y0 = win[2], y1 = win[3];
     const bool in_lds = d1 - d0 <= VIEW_WIN && y1 - y0 <= VIEW_WIN;       // (uniform)
@@ -210,8 +259,14 @@ __global__ __launch_bounds__(256) void k_view_merge(ViewRun<T> X, uint32_t nx, c
   const uint32_t j0 = (blockIdx.x - nbx) * 256u;
   if (j0 >= ny) return;
   const uint32_t jl = j0 + 255u < ny ? j0 + 255u : ny - 1u;
-  if (threadIdx.x == 0) win[0] = (uint32_t)vk_bound<T>(X.v, X.p, 0, nx, yv[j0], yp[j0]);
-  if (threadIdx.x == 64) win[1] = (uint32_t)vk_bound<T>(X.v, X.p, 0, nx, yv[jl], yp[jl]);
+  {
+    const uint32_t w = threadIdx.x >> 6;
+    if (w < 2) {
+      const uint32_t k = w == 0 ? j0 : jl;
+      const uint32_t b = (uint32_t)vk_bound_wave<T>(X.v, X.p, 0, nx, yv[k], yp[k]);
+      if ((threadIdx.x & 63u) == 0) win[w] = b;
+    }
+  }
   __syncthreads();
   const uint32_t j = j0 + threadIdx.x;
   if (j >= ny) return;

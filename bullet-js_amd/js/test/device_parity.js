@@ -403,8 +403,8 @@ for (const [fixture, batchPuts, minDevice, minHost] of [["g9_sync_node_semantics
 }
 
 /* the same device-sourced index with a VALUE-ORDERED VIEW on the device (opts.ordered: bmx_index_set_ordered — the reference's index is a Map keyed by
- * value, src/bullet-query.js:30-73): equals / range / count answer from a sorted copy of the column while nobody writes the field, scan again right after a
- * write, and re-sort by the second query after it. Same answers as the plain index whichever path replied; both store-sourced and device-sourced kinds. */
+ * value, src/bullet-query.js:30-73): equals / range / count answer from a sorted copy of the column, which a write to the field patches (the first query
+ * after it) instead of throwing it away. Same answers as the plain index whichever path replied; both store-sourced and device-sourced kinds. */
 {
   const b = new MiniBullet("w");
   const { crt, query } = attach(b, { capacityRows: 8192 });
@@ -424,11 +424,11 @@ for (const [fixture, batchPuts, minDevice, minHost] of [["g9_sync_node_semantics
   assert.strictEqual(query.count("ov", "age", 35), wantAge(35, 35).length);
   assert.strictEqual(crt.graph.indexOrderedInfo(f).sorts, 1);                            // all from the one sort
   crt.mergeEntries([{ path: "ov/n5", data: { age: 88 }, vectorClock: { w: 12 } }, { path: "ov/extra", data: { age: 35 }, vectorClock: { w: 12 } }], { insertMode: "delta", apply: true });
-  assert.deepStrictEqual(keys(query.equals("ov", "age", 35)), wantAge(35, 35));          // right after the write: scanned (the view is stale), and "extra" is there
-  assert.strictEqual(crt.graph.indexOrderedInfo(f).valid, 0);
-  assert.deepStrictEqual(keys(query.equals("ov", "age", 88)), wantAge(88, 88));          // second query after the write: sorted again
+  assert.deepStrictEqual(keys(query.equals("ov", "age", 35)), wantAge(35, 35));          // right after the write: the refresh PATCHED the view (round 5: the reference moves the path between value buckets on the write, src/bullet-query.js:139-176), "extra" is there
+  assert.strictEqual(crt.graph.indexOrderedInfo(f).valid, 1);
+  assert.deepStrictEqual(keys(query.equals("ov", "age", 88)), wantAge(88, 88));
   info = crt.graph.indexOrderedInfo(f);
-  assert.ok(info.valid === 1 && info.sorts === 2, JSON.stringify(info));
+  assert.ok(info.valid === 1 && info.sorts === 1, JSON.stringify(info));                 // still the one sort: nothing was sorted again
   assert.deepStrictEqual(keys(query.range("ov", "age", 30, 40)), wantAge(30, 40));
   crt.graph.indexSetOrdered(f, 0);
   assert.deepStrictEqual(keys(query.range("ov", "age", 30, 40)), wantAge(30, 40));
