@@ -71,7 +71,8 @@ struct Index {
   // kept current under writes (view_kernels.h): the second set of columns a patch merges into (allocated by the first patch, then the two sets swap),
   // the change run k_ix_update captures, and what the patches did
   void* s_val2 = nullptr; uint32_t* s_pos2 = nullptr; uint64_t* s_ids2 = nullptr; uint64_t ord_cap2 = 0;
-  uint32_t* cl_pos = nullptr; int64_t* cl_old = nullptr; uint64_t cl_cap = 0;
+  uint32_t* cl_pos = nullptr; int64_t* cl_old = nullptr; uint64_t cl_cap = 0;      // the captured change run, one entry per log entry (holes: POS_NONE)
+  uint32_t* cl2_pos = nullptr; int64_t* cl2_old = nullptr;                          // ... and without the holes
   uint64_t ord_patches = 0, ord_patched_keys = 0; double last_patch_us = 0;
 };
 void free_ordered_view(Index& ix) {
@@ -83,6 +84,9 @@ void free_ordered_view(Index& ix) {
   if (ix.s_ids2) (void)hipFree(ix.s_ids2);
   if (ix.cl_pos) (void)hipFree(ix.cl_pos);
   if (ix.cl_old) (void)hipFree(ix.cl_old);
+  if (ix.cl2_pos) (void)hipFree(ix.cl2_pos);
+  if (ix.cl2_old) (void)hipFree(ix.cl2_old);
+  ix.cl2_pos = nullptr; ix.cl2_old = nullptr;
   ix.s_val = nullptr; ix.s_pos = nullptr; ix.s_ids = nullptr; ix.ord_cap = 0; ix.ord_n = 0; ix.ord_content = ~0ull;
   ix.s_val2 = nullptr; ix.s_pos2 = nullptr; ix.s_ids2 = nullptr; ix.ord_cap2 = 0;
   ix.cl_pos = nullptr; ix.cl_old = nullptr; ix.cl_cap = 0;
@@ -170,8 +174,9 @@ struct bmx_ctx {
   uint2* chg = nullptr; uint64_t chg_cap = 0, chg_ub = 0;
   bool chg_valid = false; uint32_t chg_par = 0;
   uint64_t ix_full_builds = 0, ix_incremental = 0;
-  // sort scratch of the view patches (view_kernels.h): two key arrays (value 8 B, position 4 B) the merge sort ping-pongs between + the deleted keys' places
-  void* vk_v[2] = {nullptr, nullptr}; uint32_t* vk_p[2] = {nullptr, nullptr}; uint32_t* vk_dx = nullptr; uint64_t vk_cap = 0;
+  // sort scratch of the view patches (view_kernels.h): two key arrays (value 8 B, position 4 B) the merge sort ping-pongs between
+  void* vk_v[2] = {nullptr, nullptr}; uint32_t* vk_p[2] = {nullptr, nullptr}; uint64_t vk_cap = 0;
+  void* vk_sv = nullptr; uint32_t* vk_sp = nullptr; uint32_t* vk_d0 = nullptr; uint32_t* vk_y0 = nullptr; uint64_t vk_tiles_cap = 0;   // per tile of the view: its first key (the sample), deleted indices / inserted keys in front of it
   bool view_patching = true;          // BMX_VIEW_PATCH=0 in the environment: a change makes the view stale as in round 4 (A/B switch)
   // bmx_merge_notify: words (possibly in other GPUs' memory) that every merge's last workgroup sets to the number of merges finished since
   SeqPtrs notify{}; uint32_t n_notify = 0; uint64_t notify_seq = 0;
@@ -921,18 +926,27 @@ int build_index(bmx_ctx* ctx, Index* ix) {
 
 // ---- the value-ordered view kept current (view_kernels.h) ----
 constexpr uint64_t VIEW_PATCH_MAX_LOG = 1ull << 24;     // a longer change log is not captured: the view goes stale and is sorted again (a sort of 10^8 rows costs less than a patch that large)
-int ensure_view_scratch(bmx_ctx* ctx, uint64_t keys) {
-  if (keys <= ctx->vk_cap) return BMX_OK;
-  HIPCHK(hipStreamSynchronize(ctx->stream));
-  for (int i = 0; i < 2; i++) { if (ctx->vk_v[i]) (void)hipFree(ctx->vk_v[i]); ctx->vk_v[i] = nullptr; dev_free(ctx->vk_p[i]); }
-  dev_free(ctx->vk_dx); ctx->vk_cap = 0;
-  const uint64_t cap = (keys + keys / 4 + (1u << 16) + 255) & ~255ull;
-  for (int i = 0; i < 2; i++) {
-    if (hipMalloc(&ctx->vk_v[i], cap * 8) != hipSuccess) { (void)hipGetLastError(); ctx->vk_v[i] = nullptr; return fail(ctx, BMX_ERR_NOMEM, "view patch: out of device memory"); }
-    if (int rc = dev_alloc(ctx, &ctx->vk_p[i], cap)) return rc;
+int ensure_view_scratch(bmx_ctx* ctx, uint64_t keys, uint64_t tiles) {
+  if (keys > ctx->vk_cap) {
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    for (int i = 0; i < 2; i++) { if (ctx->vk_v[i]) (void)hipFree(ctx->vk_v[i]); ctx->vk_v[i] = nullptr; dev_free(ctx->vk_p[i]); }
+    ctx->vk_cap = 0;
+    const uint64_t cap = (keys + keys / 4 + (1u << 16) + 255) & ~255ull;
+    for (int i = 0; i < 2; i++) {
+      if (hipMalloc(&ctx->vk_v[i], cap * 8) != hipSuccess) { (void)hipGetLastError(); ctx->vk_v[i] = nullptr; return fail(ctx, BMX_ERR_NOMEM, "view patch: out of device memory"); }
+      if (int rc = dev_alloc(ctx, &ctx->vk_p[i], cap)) return rc;
+    }
+    ctx->vk_cap = cap;
   }
-  if (int rc = dev_alloc(ctx, &ctx->vk_dx, cap)) return rc;
-  ctx->vk_cap = cap;
+  if (tiles + 1 > ctx->vk_tiles_cap) {
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    if (ctx->vk_sv) (void)hipFree(ctx->vk_sv); ctx->vk_sv = nullptr; dev_free(ctx->vk_sp); dev_free(ctx->vk_d0); dev_free(ctx->vk_y0); ctx->vk_tiles_cap = 0;
+    const uint64_t cap = tiles + tiles / 4 + 1024;
+    if (hipMalloc(&ctx->vk_sv, cap * 8) != hipSuccess) { (void)hipGetLastError(); ctx->vk_sv = nullptr; return fail(ctx, BMX_ERR_NOMEM, "view patch: out of device memory"); }
+    int rc;
+    if ((rc = dev_alloc(ctx, &ctx->vk_sp, cap)) || (rc = dev_alloc(ctx, &ctx->vk_d0, cap)) || (rc = dev_alloc(ctx, &ctx->vk_y0, cap))) return rc;
+    ctx->vk_tiles_cap = cap;
+  }
   return BMX_OK;
 }
 // Patch the view of `ix` with the change run k_ix_update captured (c changed rows: ix.cl_pos / ix.cl_old) and the rows appended at positions
@@ -944,7 +958,8 @@ int patch_view_t(bmx_ctx* ctx, Index& ix, uint64_t c, uint64_t n0, uint64_t adde
   const uint64_t m = c + added, ktot = c + m, nx = ix.ord_n, nz = nx - c + m;
   if (nz >= 0xFFFFFFFFull || ktot >= 0xFFFFFFFFull || c > nx) return 1;
   auto soft = [&](int) { g_err.clear(); ctx->err.clear(); (void)hipGetLastError(); return 1; };
-  if (ensure_view_scratch(ctx, ktot)) return soft(0);
+  const uint32_t ntiles = (uint32_t)((nx + VIEW_TILE - 1) / VIEW_TILE);
+  if (ensure_view_scratch(ctx, ktot, ntiles)) return soft(0);
   if (nz > ix.ord_cap2 || !ix.s_val2) {
     if (ix.s_val2) { (void)hipStreamSynchronize(ctx->stream); (void)hipFree(ix.s_val2); (void)hipFree(ix.s_pos2); (void)hipFree(ix.s_ids2); }
     ix.s_val2 = nullptr; ix.s_pos2 = nullptr; ix.s_ids2 = nullptr; ix.ord_cap2 = 0;
@@ -961,7 +976,7 @@ int patch_view_t(bmx_ctx* ctx, Index& ix, uint64_t c, uint64_t n0, uint64_t adde
   T* kv[2] = {static_cast<T*>(ctx->vk_v[0]), static_cast<T*>(ctx->vk_v[1])};
   uint32_t* kp[2] = {ctx->vk_p[0], ctx->vk_p[1]};
   const T* col = sizeof(T) == 4 ? reinterpret_cast<const T*>(ix.v32) : reinterpret_cast<const T*>(ix.v64);
-  hipLaunchKernelGGL((k_view_keys<T>), dim3((uint32_t)std::min<uint64_t>((ktot + 255) / 256, 4096)), dim3(256), 0, st, (const uint32_t*)ix.cl_pos, (const int64_t*)ix.cl_old, (uint32_t)c, col,
+  hipLaunchKernelGGL((k_view_keys<T>), dim3((uint32_t)std::min<uint64_t>((ktot + 255) / 256, 4096)), dim3(256), 0, st, (const uint32_t*)ix.cl2_pos, (const int64_t*)ix.cl2_old, (uint32_t)c, col,
                      (uint32_t)n0, (uint32_t)added, kv[0], kp[0]);
   // sort the deleted keys [0, c) and the inserted keys [c, c + m): tiles in LDS, then rank-merge passes
   ViewSegs S{}; S.base[0] = 0; S.len[0] = (uint32_t)c; S.base[1] = (uint32_t)c; S.len[1] = (uint32_t)m;
@@ -969,18 +984,19 @@ int patch_view_t(bmx_ctx* ctx, Index& ix, uint64_t c, uint64_t n0, uint64_t adde
   S.blk0[0] = 0; S.blk0[1] = t0b; S.blk0[2] = t0b + t1b;
   hipLaunchKernelGGL((k_view_tile_sort<T>), dim3(t0b + t1b), dim3(256), 0, st, (const T*)kv[0], (const uint32_t*)kp[0], kv[1], kp[1], S);
   int cur = 1;
-  ViewSegs P = S; P.blk0[1] = (uint32_t)((c + 255) / 256); P.blk0[2] = P.blk0[1] + (uint32_t)((m + 255) / 256);
+  ViewSegs P = S; P.blk0[1] = (uint32_t)((c + VIEW_PASS_KEYS - 1) / VIEW_PASS_KEYS); P.blk0[2] = P.blk0[1] + (uint32_t)((m + VIEW_PASS_KEYS - 1) / VIEW_PASS_KEYS);
   for (uint64_t L = VIEW_TILE; L < std::max<uint64_t>(c, m); L *= 2) {
     hipLaunchKernelGGL((k_view_merge_pass<T>), dim3(P.blk0[2]), dim3(256), 0, st, (const T*)kv[cur], (const uint32_t*)kp[cur], kv[cur ^ 1], kp[cur ^ 1], P, (uint32_t)L);
     cur ^= 1;
   }
   (void)hipMemsetAsync(&ctx->ds->view_err, 0, sizeof(uint32_t), st);
-  if (c) hipLaunchKernelGGL((k_view_find<T>), dim3((uint32_t)((c + 255) / 256)), dim3(256), 0, st, static_cast<const T*>(ix.s_val), (const uint32_t*)ix.s_pos, (uint32_t)nx, (const T*)kv[cur],
-                            (const uint32_t*)kp[cur], (uint32_t)c, ctx->vk_dx, &ctx->ds->view_err);
+  T* sv = static_cast<T*>(ctx->vk_sv);
+  hipLaunchKernelGGL((k_view_sample<T>), dim3((ntiles + 255) / 256), dim3(256), 0, st, static_cast<const T*>(ix.s_val), (const uint32_t*)ix.s_pos, ntiles, sv, ctx->vk_sp);
+  hipLaunchKernelGGL((k_view_tile_offsets<T>), dim3((ntiles + 1 + 255) / 256), dim3(256), 0, st, (const T*)sv, (const uint32_t*)ctx->vk_sp, ntiles, (const T*)kv[cur], (const uint32_t*)kp[cur], (uint32_t)c,
+                     (const T*)(kv[cur] + c), (const uint32_t*)(kp[cur] + c), (uint32_t)m, ctx->vk_d0, ctx->vk_y0);
   ViewRun<T> X{static_cast<T*>(ix.s_val), ix.s_pos, ix.s_ids}, Z{static_cast<T*>(ix.s_val2), ix.s_pos2, ix.s_ids2};
-  const uint32_t nbx = (uint32_t)((nx + VIEW_TILE - 1) / VIEW_TILE), nby = (uint32_t)((m + 255) / 256);
-  hipLaunchKernelGGL((k_view_merge<T>), dim3(nbx + nby), dim3(256), 0, st, X, (uint32_t)nx, (const uint32_t*)ctx->vk_dx, (uint32_t)c, (const T*)(kv[cur] + c), (const uint32_t*)(kp[cur] + c), (uint32_t)m,
-                     (const uint64_t*)ix.ids, Z, nbx);
+  hipLaunchKernelGGL((k_view_merge<T>), dim3(ntiles), dim3(256), 0, st, X, (uint32_t)nx, (const T*)kv[cur], (const uint32_t*)kp[cur], (const T*)(kv[cur] + c), (const uint32_t*)(kp[cur] + c),
+                     (const uint64_t*)ix.ids, Z, (const uint32_t*)ctx->vk_d0, (const uint32_t*)ctx->vk_y0, &ctx->ds->view_err);
   uint32_t err = 0;
   hipError_t e = hipGetLastError();
   if (e == hipSuccess) e = hipMemcpyAsync(&err, &ctx->ds->view_err, sizeof(err), hipMemcpyDeviceToHost, st);
@@ -1011,11 +1027,16 @@ int refresh_from_log(bmx_ctx* ctx) {
       if (ctx->view_patching && ix.ordered_after && ix.s_val && ix.ord_content == ix.content && ix.ord_fits32 == ix.fits32 && ix.n && ix.n < 0xFFFFFFFFull && ub <= VIEW_PATCH_MAX_LOG) {
         if (ix.cl_cap < ub) {
           HIPCHK(hipStreamSynchronize(ctx->stream));
-          if (ix.cl_pos) (void)hipFree(ix.cl_pos); if (ix.cl_old) (void)hipFree(ix.cl_old);
-          ix.cl_pos = nullptr; ix.cl_old = nullptr; ix.cl_cap = 0;
+          for (void* q : {(void*)ix.cl_pos, (void*)ix.cl_old, (void*)ix.cl2_pos, (void*)ix.cl2_old}) if (q) (void)hipFree(q);
+          ix.cl_pos = nullptr; ix.cl_old = nullptr; ix.cl2_pos = nullptr; ix.cl2_old = nullptr; ix.cl_cap = 0;
           const uint64_t cap = (ub + ub / 2 + (1u << 16) + 255) & ~255ull;
-          if (hipMalloc(reinterpret_cast<void**>(&ix.cl_pos), cap * sizeof(uint32_t)) == hipSuccess && hipMalloc(reinterpret_cast<void**>(&ix.cl_old), cap * sizeof(int64_t)) == hipSuccess) ix.cl_cap = cap;
-          else { (void)hipGetLastError(); if (ix.cl_pos) (void)hipFree(ix.cl_pos); ix.cl_pos = nullptr; ix.cl_old = nullptr; }
+          if (hipMalloc(reinterpret_cast<void**>(&ix.cl_pos), cap * sizeof(uint32_t)) == hipSuccess && hipMalloc(reinterpret_cast<void**>(&ix.cl_old), cap * sizeof(int64_t)) == hipSuccess &&
+              hipMalloc(reinterpret_cast<void**>(&ix.cl2_pos), cap * sizeof(uint32_t)) == hipSuccess && hipMalloc(reinterpret_cast<void**>(&ix.cl2_old), cap * sizeof(int64_t)) == hipSuccess) ix.cl_cap = cap;
+          else {
+            (void)hipGetLastError();
+            for (void* q : {(void*)ix.cl_pos, (void*)ix.cl_old, (void*)ix.cl2_pos, (void*)ix.cl2_old}) if (q) (void)hipFree(q);
+            ix.cl_pos = nullptr; ix.cl_old = nullptr; ix.cl2_pos = nullptr; ix.cl2_old = nullptr;
+          }
         }
         capture[k] = ix.cl_cap >= ub;
       }
@@ -1033,8 +1054,17 @@ int refresh_from_log(bmx_ctx* ctx) {
       LAUNCHCHK("k_sel_write(log)");
       const uint32_t ublocks = (uint32_t)std::min<uint64_t>((ub + 255) / 256, 4096);
       hipLaunchKernelGGL(k_ix_update, dim3(ublocks), dim3(256), 0, ctx->stream, (const uint2*)ctx->chg, n_dev, (const Slot*)ctx->slots, ix.field, (const uint32_t*)ctx->slot_pos,
-                         ix.v64, ix.v32, d_wide, capture[k] ? 2u : (ix.ordered_after ? 1u : 0u), ix.cl_pos, ix.cl_old, &ctx->ds->view_cl_n[k], (uint32_t)std::min<uint64_t>(ix.cl_cap, 0xFFFFFFFFull));
+                         ix.v64, ix.v32, d_wide, capture[k] ? 2u : (ix.ordered_after ? 1u : 0u), ix.cl_pos, ix.cl_old, (uint64_t)ix.cl_cap);
       LAUNCHCHK("k_ix_update");
+      if (capture[k]) {      // the change run without its holes, in log order (ordered select: no atomics), and its length
+        PredChanged PC{ix.cl_pos, n_dev};
+        SelGeom gc = sel_geom<PredChanged::E>(ub);
+        hipLaunchKernelGGL((k_sel_count<PredChanged>), dim3(gc.blocks), dim3(SEL_THREADS), 0, ctx->stream, PC, ub, gc.tiles_per_block, ctx->block_counts);
+        EmitChanged EC{ix.cl_pos, ix.cl_old, ix.cl2_pos, ix.cl2_old};
+        FinishCount FC{&ctx->ds->view_cl_n[k]};
+        hipLaunchKernelGGL((k_sel_write<PredChanged, EmitChanged, FinishCount>), dim3(gc.blocks), dim3(SEL_THREADS), 0, ctx->stream, PC, EC, FC, ub, gc.tiles_per_block, ctx->block_counts);
+        LAUNCHCHK("k_sel_write(change run)");
+      }
     }
     for (size_t k = 0; k < ctx->indexes.size(); k++) {
       HIPCHK(hipMemcpyAsync(&res[k].added, &ctx->ds->part_totals[2 * k], sizeof(unsigned long long), hipMemcpyDeviceToHost, ctx->stream));
@@ -1494,7 +1524,7 @@ void bmx_destroy(bmx_ctx* ctx) {
   if (ctx->down_stream) { (void)hipStreamSynchronize(ctx->down_stream); (void)hipStreamDestroy(ctx->down_stream); }
   dev_free(ctx->slot_pos); dev_free(ctx->chg);
   for (int i = 0; i < 2; i++) { if (ctx->vk_v[i]) (void)hipFree(ctx->vk_v[i]); dev_free(ctx->vk_p[i]); }
-  dev_free(ctx->vk_dx);
+  if (ctx->vk_sv) (void)hipFree(ctx->vk_sv); dev_free(ctx->vk_sp); dev_free(ctx->vk_d0); dev_free(ctx->vk_y0);
   if (ctx->host_rows) { (void)hipHostFree(ctx->host_rows); ctx->host_rows = nullptr; }
   if (ctx->stg_tails) { (void)hipHostFree(ctx->stg_tails); ctx->stg_tails = nullptr; ctx->stg[0].tail = ctx->stg[1].tail = nullptr; }
   if (ctx->pin_in) { (void)hipHostFree(ctx->pin_in); ctx->pin_in = nullptr; }

@@ -111,51 +111,52 @@ struct EmitAppend {   // created row -> the end of the index columns, in log ord
 // filter reads the int64 one whatever the range scans use). Entries that created their row were appended with the current value already.
 // track = 1: compare before writing, wide[1] says whether any value really changed (the index has a value-ordered view that is not current anyway).
 // track = 2: CAPTURE (the view is current and will be patched, view_kernels.h): the new value is EXCHANGED into the int64 column, so of several log
-//            entries of one row exactly one sees the value the view still holds; every real change appends (position, old value) to the change run
-//            — one memory-side atomic per wave for the slot in the run, order irrelevant: the run is sorted afterwards.
+//            entries of one row exactly one sees the value the view still holds; log entry i leaves (position, old value) of a real change in cl[i] and
+//            (POS_NONE, -) otherwise — no counter, no shared atomic (a first version appended through one counter: 15 600 same-address atomics of 17 ns
+//            each made this a 228-us kernel); the holes are taken out by an ordered select afterwards (PredChanged / EmitChanged).
 __global__ __launch_bounds__(256) void k_ix_update(const uint2* __restrict__ chg, const unsigned long long* __restrict__ n_dev, const Slot* __restrict__ slots,
                                                    uint32_t field, const uint32_t* __restrict__ slot_pos, int64_t* __restrict__ v64, int32_t* __restrict__ v32,
                                                    uint32_t* wide /* wide[1]: set when a value in the index really changed */, uint32_t track,
-                                                   uint32_t* __restrict__ cl_pos, int64_t* __restrict__ cl_old, unsigned long long* __restrict__ cl_n, uint32_t cl_cap) {
+                                                   uint32_t* __restrict__ cl_pos, int64_t* __restrict__ cl_old, uint64_t cl_cap) {
   const uint64_t n = *n_dev;
-  for (uint64_t b = (uint64_t)blockIdx.x * 256u; b < n; b += (uint64_t)gridDim.x * 256u) {      // (uniform per workgroup: the ballot below wants every lane there)
-    const uint64_t i = b + threadIdx.x;
-    bool emit = false; uint32_t p = POS_NONE; int64_t old = 0;
-    if (i < n) {
-      const uint2 x = chg[i];
-      if (x.y == field && !(x.x & CHG_CREATED)) {
-        const uint32_t s = x.x;
-        p = slot_pos[s];
-        if (p != POS_NONE) {
-          const uint4 hi = reinterpret_cast<const uint4*>(slots + s)[1];
-          const int64_t v = (int64_t)((uint64_t)hi.z | ((uint64_t)hi.w << 32));
-          if (track == 2u) {
-            old = (int64_t)atomicExch(reinterpret_cast<unsigned long long*>(v64 + p), (unsigned long long)v);
-            emit = old != v;
-            if (emit) wide[1] = 1u;
-          } else {
-            if (track && v64[p] != v) wide[1] = 1u;     // (the value-ordered view of the index is stale only then)
-            v64[p] = v;
-          }
-          v32[p] = v32_of(v);
-          if (is_wide(v)) *wide = 1u;
+  for (uint64_t i = (uint64_t)blockIdx.x * 256u + threadIdx.x; i < n; i += (uint64_t)gridDim.x * 256u) {
+    const uint2 x = chg[i];
+    uint32_t hole = POS_NONE; int64_t old = 0;
+    if (x.y == field && !(x.x & CHG_CREATED)) {
+      const uint32_t s = x.x;
+      const uint32_t p = slot_pos[s];
+      if (p != POS_NONE) {
+        const uint4 hi = reinterpret_cast<const uint4*>(slots + s)[1];
+        const int64_t v = (int64_t)((uint64_t)hi.z | ((uint64_t)hi.w << 32));
+        if (track == 2u) {
+          old = (int64_t)atomicExch(reinterpret_cast<unsigned long long*>(v64 + p), (unsigned long long)v);
+          if (old != v) { hole = p; wide[1] = 1u; }
+        } else {
+          if (track && v64[p] != v) wide[1] = 1u;     // (the value-ordered view of the index is stale only then)
+          v64[p] = v;
         }
+        v32[p] = v32_of(v);
+        if (is_wide(v)) *wide = 1u;
       }
     }
-    if (track == 2u) {
-      const unsigned long long bal = __ballot(emit);
-      if (bal) {
-        unsigned long long base = 0;
-        if ((threadIdx.x & 63u) == 0) base = atomicAdd(cl_n, (unsigned long long)__popcll(bal));
-        base = __shfl(base, 0);
-        if (emit) {
-          const unsigned long long k = base + (unsigned long long)__popcll(bal & ((1ull << (threadIdx.x & 63u)) - 1ull));
-          if (k < cl_cap) { cl_pos[k] = p; cl_old[k] = old; }
-        }
-      }
-    }
+    if (track == 2u && i < cl_cap) { cl_pos[i] = hole; cl_old[i] = old; }
   }
 }
+struct PredChanged {   // entries of the captured change run that are not holes
+  static constexpr int E = 4;
+  const uint32_t* cl_pos; const unsigned long long* n_dev;
+  __device__ uint32_t mask(uint64_t first, uint64_t) const {
+    const uint64_t n = *n_dev;
+    uint32_t m = 0;
+    if (first + 4 <= n) { const uint4 x = *reinterpret_cast<const uint4*>(cl_pos + first); m = (uint32_t)(x.x != POS_NONE) | ((uint32_t)(x.y != POS_NONE) << 1) | ((uint32_t)(x.z != POS_NONE) << 2) | ((uint32_t)(x.w != POS_NONE) << 3); }
+    else for (int e = 0; e < 4 && first + e < n; e++) m |= (uint32_t)(cl_pos[first + e] != POS_NONE) << e;
+    return m;
+  }
+};
+struct EmitChanged {
+  const uint32_t* cl_pos; const int64_t* cl_old; uint32_t* out_pos; int64_t* out_old;
+  __device__ void operator()(uint64_t rank, uint64_t i) const { out_pos[rank] = cl_pos[i]; out_old[rank] = cl_old[i]; }
+};
 struct EmitRows {  // slot -> dumped row columns (bounded by cap)
   const Slot* slots; uint64_t cap; uint64_t* id; uint32_t* field; int64_t* ts; int64_t* val;
   __device__ void operator()(uint64_t pos, uint64_t s) const {

@@ -80,6 +80,7 @@ __device__ __forceinline__ uint32_t u32_lower_bound_wave(const uint32_t* __restr
 // [base[s], base[s] + len[s]) of the key arrays and blocks [blk0[s], blk0[s + 1]) of the grid.
 struct ViewSegs {
   uint32_t base[2], len[2], blk0[3];
+  uint32_t dbg = 0;        // measurement switches of bench_micro/view_merge_micro.hip (1: no merge-path search, 2: no rank search in LDS): wrong output, never set by the engine
   __device__ __forceinline__ uint32_t seg_of(uint32_t block) const { return block >= blk0[1] ? 1u : 0u; }
 };
 
@@ -137,144 +138,264 @@ __global__ __launch_bounds__(256) void k_view_tile_sort(const T* __restrict__ vi
   }
 }
 
-// One pass of the merge sort: inside every segment, sorted runs of L keys (L a multiple of 2048) are merged pairwise into runs of 2L. Rank merge: a key's
-// place in the merged run = its index in its own run + the keys of the partner run in front of it (strictly smaller for the left run, smaller or equal
-// for the right one: stable), found by a binary search that the workgroup's first and last key bound for all 256 (the keys of a workgroup are
-// consecutive in one sorted run, so their ranks lie between those two).
+// One pass of the merge sort: inside every segment, sorted runs of L keys (L a multiple of 2048) are merged pairwise into runs of 2L — merge path: a
+// workgroup OWNS 1024 consecutive keys of the OUTPUT. Two waves find, 64-ary, where the diagonals through its first and last output key cut the two input
+// runs (a few rounds of dependent reads instead of a binary search's twenty); the two input pieces (1024 keys together) are staged in LDS, every key finds its
+// rank in the other piece there, and the workgroup writes its own contiguous stretch. (The first version let every INPUT key compute its output place and
+// store it there: two workgroups on different XCDs then fill every 32-byte sector of the output together, the memory side merges byte-masked partial writes,
+// and a pass over 1.9M keys took 27 us however the searches were arranged.)
+constexpr uint32_t VIEW_PASS_KEYS = 1024;
+// keys of run A that the merged sequence holds in front of diagonal d (A: la keys at a0, B: lb keys at b0; ties: A first). Whole wave, same arguments.
+template <class T>
+__device__ __forceinline__ uint32_t merge_path_wave(const T* __restrict__ V, const uint32_t* __restrict__ P, uint32_t a0, uint32_t la, uint32_t b0, uint32_t lb, uint32_t d) {
+  const uint32_t lane = threadIdx.x & 63u;
+  uint32_t Lo = d > lb ? d - lb : 0u, Hi = d < la ? d : la;          // the answer i lies in [Lo, Hi]; predicate pred(i) = "A[i] is in front of the diagonal" = !(B[d-1-i] < A[i]), true for i < answer
+  while (Hi - Lo > 63u) {
+    const uint32_t step = (Hi - Lo + 63u) / 64u;
+    const uint32_t i = Lo + lane * step;                              // probes Lo, Lo + step, ...; pred is monotone (true ... true false ... false)
+    bool pr = false;
+    if (i < Hi) pr = !vk_less<T>(V[b0 + d - 1u - i], P[b0 + d - 1u - i], V[a0 + i], P[a0 + i]);
+    const uint32_t tcount = (uint32_t)__popcll(__ballot(pr));         // probes 0 .. tcount-1 true
+    const uint32_t nLo = tcount ? Lo + (tcount - 1u) * step + 1u : Lo;
+    const uint32_t nHi = Lo + tcount * step < Hi ? Lo + tcount * step : Hi;
+    Lo = nLo; Hi = tcount == 0 ? Lo : nHi;
+  }
+  bool pr = false;
+  const uint32_t i = Lo + lane;
+  if (i < Hi) pr = !vk_less<T>(V[b0 + d - 1u - i], P[b0 + d - 1u - i], V[a0 + i], P[a0 + i]);
+  return Lo + (uint32_t)__popcll(__ballot(pr));
+}
 template <class T>
 __global__ __launch_bounds__(256) void k_view_merge_pass(const T* __restrict__ vin, const uint32_t* __restrict__ pin, T* __restrict__ vout, uint32_t* __restrict__ pout, ViewSegs S, uint32_t L) {
-  __shared__ uint32_t win[2];
+  __shared__ uint32_t cut[2];
+  __shared__ T sv[VIEW_PASS_KEYS];
+  __shared__ uint32_t sp[VIEW_PASS_KEYS];
   const uint32_t s = S.seg_of(blockIdx.x);
   const uint32_t len = S.len[s], base = S.base[s];
-  const uint32_t e0 = (blockIdx.x - S.blk0[s]) * 256u;             // first key of this workgroup inside the segment
-  if (e0 >= len) return;
-  const uint32_t r = e0 / L, q = r ^ 1u;                             // own run, partner run
-  const bool left = (r & 1u) == 0;
-  const uint32_t q0 = q * L < len ? q * L : len, q1 = (q + 1u) * L < len ? (q + 1u) * L : len;       // partner run [q0, q1): may be empty (odd run count)
-  const uint32_t e = e0 + threadIdx.x;
-  const uint32_t last = (e0 + 255u < len ? e0 + 255u : len - 1u);
+  const uint32_t o0 = (blockIdx.x - S.blk0[s]) * VIEW_PASS_KEYS;     // first output key of this workgroup inside the segment
+  if (o0 >= len) return;
+  const uint32_t o1 = o0 + VIEW_PASS_KEYS < len ? o0 + VIEW_PASS_KEYS : len;
+  const uint32_t pb = o0 / (2u * L) * (2u * L);                        // the pair of runs this stretch of the output belongs to: A = [pb, pb + la), B = [pb + la, pb + la + lb)
+  const uint32_t la = pb + L < len ? L : len - pb, lb = pb + 2u * L <= len ? L : (pb + L < len ? len - pb - L : 0u);
   const T* V = vin + base; const uint32_t* P = pin + base;
   const uint32_t w = threadIdx.x >> 6;
-  if (w < 2) {           // wave 0: where the workgroup's first key stands in the partner run, wave 1: where its last key does
-    const uint32_t k = w == 0 ? e0 : last;
-    const uint32_t b = q0 == q1 ? q0 : (uint32_t)(left ? vk_bound_wave<T, false>(V, P, q0, q1, V[k], P[k]) : vk_bound_wave<T, true>(V, P, q0, q1, V[k], P[k]));
-    if ((threadIdx.x & 63u) == 0) win[w] = b;
+  if (w < 2) {
+    const uint32_t d = (w == 0 ? o0 : o1) - pb;
+    const uint32_t i = lb == 0 ? d : ((S.dbg & 1u) ? (uint32_t)((uint64_t)d * la / (la + lb)) : merge_path_wave<T>(V, P, pb, la, pb + la, lb, d));
+    if ((threadIdx.x & 63u) == 0) cut[w] = i;
   }
   __syncthreads();
-  if (e >= len) return;
-  const T kv = V[e]; const uint32_t kp = P[e];
-  const uint32_t rank = (uint32_t)(left ? vk_bound<T, false>(V, P, win[0], win[1], kv, kp) : vk_bound<T, true>(V, P, win[0], win[1], kv, kp)) - q0;
-  const uint32_t out = (r >> 1) * 2u * L + (e - r * L) + rank;
-  vout[base + out] = kv; pout[base + out] = kp;
+  const uint32_t i0 = cut[0], i1 = cut[1], j0 = (o0 - pb) - i0, j1 = (o1 - pb) - i1;
+  const uint32_t na = i1 - i0, nb = j1 - j0;                            // na + nb = o1 - o0
+  for (uint32_t k = threadIdx.x; k < na + nb; k += 256u) { const uint32_t src = k < na ? pb + i0 + k : pb + la + j0 + (k - na); sv[k] = V[src]; sp[k] = P[src]; }
+  __syncthreads();
+  // every thread merges FOUR consecutive keys of the output: one merge-path search in LDS for its diagonal (ten steps), then four sequential picks — instead of
+  // four rank searches (bench_micro/view_merge_micro.hip: the rank searches were 9 of a pass's 24-34 us)
+  const uint32_t tot = na + nb, dd = threadIdx.x * 4u;
+  if (dd < tot) {
+    uint32_t lo = dd > nb ? dd - nb : 0u, hi = dd < na ? dd : na;     // keys of A among the first dd of the merged piece
+    if (S.dbg & 2u) lo = hi = (uint32_t)((uint64_t)dd * na / tot);
+    while (lo < hi) {
+      const uint32_t mid = lo + ((hi - lo) >> 1);
+      const uint32_t bj = na + (dd - 1u - mid);
+      if (!vk_less<T>(sv[bj], sp[bj], sv[mid], sp[mid])) lo = mid + 1u; else hi = mid;      // A[mid] is in front of the diagonal (ties: A first)
+    }
+    uint32_t ia = lo, ib = na + (dd - lo);
+    T ov[4]; uint32_t op[4];
+    uint32_t cnt = 0;
+#pragma unroll
+    for (uint32_t k = 0; k < 4; k++) {
+      if (dd + k >= tot) break;
+      const bool hasA = ia < na, hasB = ib < tot;
+      const T av = hasA ? sv[ia] : (T)0, bv = hasB ? sv[ib] : (T)0; const uint32_t ap = hasA ? sp[ia] : 0u, bp = hasB ? sp[ib] : 0u;
+      const bool takeA = hasA && (!hasB || !vk_less<T>(bv, bp, av, ap));
+      ov[k] = takeA ? av : bv; op[k] = takeA ? ap : bp; ia += takeA ? 1u : 0u; ib += takeA ? 0u : 1u; cnt++;
+    }
+    T* dv = vout + base + o0 + dd; uint32_t* dp = pout + base + o0 + dd;
+    if (cnt == 4u) {
+      typedef T tvec __attribute__((ext_vector_type(4)));
+      typedef uint32_t uvec __attribute__((ext_vector_type(4)));
+      tvec v4; uvec p4;
+#pragma unroll
+      for (uint32_t k = 0; k < 4; k++) { v4[k] = ov[k]; p4[k] = op[k]; }
+      __builtin_memcpy(dv, &v4, sizeof(v4)); __builtin_memcpy(dp, &p4, sizeof(p4));          // (4-byte aligned destination: unaligned multi-dword stores)
+    } else for (uint32_t k = 0; k < cnt; k++) { dv[k] = ov[k]; dp[k] = op[k]; }
+  }
 }
 
-// Where the deleted keys stand in the view: dx[i] = index of sorted deleted key i in (xv, xp), ascending because both are sorted. A key that is not there
-// means the view and the index columns have drifted apart: *err is set and the caller sorts the view from scratch.
+// A sample of the view: the key every tile of 2048 starts with (48 828 keys for 10^8 rows: L2-resident).
 template <class T>
-__global__ __launch_bounds__(256) void k_view_find(const T* __restrict__ xv, const uint32_t* __restrict__ xp, uint32_t nx, const T* __restrict__ dv, const uint32_t* __restrict__ dp, uint32_t nd,
-                                                   uint32_t* __restrict__ dx, uint32_t* __restrict__ err) {
-  __shared__ uint32_t win[2];
-  const uint32_t i0 = blockIdx.x * 256u;
-  if (i0 >= nd) return;
-  const uint32_t last = i0 + 255u < nd ? i0 + 255u : nd - 1u;
-  const uint32_t w = threadIdx.x >> 6;
-  if (w < 2) {
-    const uint32_t k = w == 0 ? i0 : last;
-    const uint32_t b = (uint32_t)vk_bound_wave<T>(xv, xp, 0, nx, dv[k], dp[k]);
-    if ((threadIdx.x & 63u) == 0) win[w] = b;
-  }
-  __syncthreads();
-  const uint32_t i = i0 + threadIdx.x;
-  if (i >= nd) return;
-  const T kv = dv[i]; const uint32_t kp = dp[i];
-  const uint32_t at = (uint32_t)vk_bound<T>(xv, xp, win[0], win[1] < nx ? win[1] + 1u : nx, kv, kp);
-  const bool found = at < nx && xv[at] == kv && xp[at] == kp;
-  dx[i] = at;
-  if (!found) *err = 1u;
+__global__ __launch_bounds__(256) void k_view_sample(const T* __restrict__ xv, const uint32_t* __restrict__ xp, uint32_t ntiles, T* __restrict__ sv, uint32_t* __restrict__ sp) {
+  const uint32_t t = blockIdx.x * 256u + threadIdx.x;
+  if (t < ntiles) { sv[t] = xv[(uint64_t)t * VIEW_TILE]; sp[t] = xp[(uint64_t)t * VIEW_TILE]; }
+}
+// per tile of the view: how many deleted keys (d0) and how many inserted keys (y0) sort in front of its first key; entry [ntiles] = the totals. Tile t's
+// windows are [d0[t], d0[t + 1]) of D and [y0[t], y0[t + 1]) of Y: the deleted keys ARE keys of the tile, the inserted ones fall between its keys or behind its last.
+template <class T>
+__global__ __launch_bounds__(256) void k_view_tile_offsets(const T* __restrict__ sv, const uint32_t* __restrict__ sp, uint32_t ntiles, const T* __restrict__ dv, const uint32_t* __restrict__ dp, uint32_t nd,
+                                                           const T* __restrict__ yv, const uint32_t* __restrict__ yp, uint32_t ny, uint32_t* __restrict__ d0, uint32_t* __restrict__ y0) {
+  const uint32_t t = blockIdx.x * 256u + threadIdx.x;
+  if (t > ntiles) return;
+  if (t == ntiles) { d0[t] = nd; y0[t] = ny; return; }
+  if (t == 0) { d0[0] = 0; y0[0] = 0; return; }                        // (an inserted key in front of the view's first key belongs to tile 0 too)
+  d0[t] = (uint32_t)vk_bound<T>(dv, dp, 0, nd, sv[t], sp[t]);
+  y0[t] = (uint32_t)vk_bound<T>(yv, yp, 0, ny, sv[t], sp[t]);
 }
 
 template <class T>
 struct ViewRun { T* v; uint32_t* p; uint64_t* ids; };
+template <class V, class P>
+__device__ __forceinline__ void st_vec(P* dst, const V& v) { __builtin_memcpy(dst, &v, sizeof(V)); }
+__device__ __forceinline__ int32_t rdlane(int32_t v, uint32_t l) { return __builtin_amdgcn_readlane(v, (int)l); }
+__device__ __forceinline__ uint32_t rdlane(uint32_t v, uint32_t l) { return (uint32_t)__builtin_amdgcn_readlane((int)v, (int)l); }
+__device__ __forceinline__ int64_t rdlane(int64_t v, uint32_t l) {
+  return (int64_t)(((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)((uint64_t)v >> 32), (int)l) << 32) | (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(uint64_t)v, (int)l));
+}
 
-// The streaming merge: Z = (X without the keys at the sorted indices dx[0..ndx)) merged with the sorted keys Y; ids travel with the keys of X and are
-// gathered from the index's id column for the keys of Y. Workgroups [0, nbx) take one 2048-key tile of X each, the others 256 keys of Y each.
-//   key i of X (alive):  Z[i - (deleted indices < i) + (keys of Y < key)]      key j of Y:  Z[j + p - (deleted indices < p)],  p = keys of X < key
-// A tile's deleted indices and inserted keys are a window of dx / Y that its first and last key bound; up to VIEW_WIN of each are searched in LDS
-// (a patch of 1M keys into 10^8 puts ~20 into a tile), beyond that in global memory. Loads of X are issued eight deep per lane before the first use.
+// The streaming merge: Z = (X without the sorted keys D, which are keys of X) merged with the sorted keys Y; ids travel with the keys of X and are gathered from
+// the index's id column for the keys of Y. One workgroup per 2048-key tile of X; it also places the keys of Y that fall between its keys or behind its last.
+//   key i of X (alive):   Z[i - (keys of D < key) + (keys of Y < key)]
+//   key j of Y:           right behind the last key of X in front of it:  Z[j + (i + 1) - (keys of D <= key_i)],  i = that key's index
+// A lane owns FOUR consecutive keys of X: 16-byte loads of values and positions, 2 x 16 bytes of ids, all issued before the first use (two groups per lane).
+// A tile's deleted and inserted keys are the windows [d0[t], d0[t + 1]) of D and [y0[t], y0[t + 1]) of Y (k_view_tile_offsets), staged in LDS up to VIEW_WIN
+// of each; nine threads rank the tile's 256-key chunk boundaries in them. A wave then takes ITS chunk's window entries into registers — one per lane; a patch of 1M
+// keys puts ~5 deleted and ~3 inserted keys into a chunk — and every lane counts, entry by entry (readlane: scalar broadcasts, no memory, no divergence), how many
+// sort in front of each of its four keys and whether one IS its key. A group with no deleted key and one rank for all four moves as 16-byte stores (the destination is
+// only 4- / 8-byte aligned: gfx950 takes unaligned multi-dword stores), the others key by key. Measured on 10^8 rows (bench_micro/view_merge_micro.hip,
+// profiles/r05_view_merge_micro.log): a plain 16-byte copy of the three columns 543 us = 5.89 TB/s; this kernel with an empty patch 552 us.
+// Earlier forms, same box class: one key per lane with two LDS window searches per key 931 us; lanes WALKING from the chunk's rank to their own (dependent LDS
+// reads, the wave waits for its slowest lane) 847 us + 270 us for the keys of Y placed by workgroups of their own at the end of the grid.
+// *err is set when the tile's deleted keys were not all found among its keys (the view and the index columns have drifted apart: the caller sorts from scratch).
 template <class T>
-__global__ __launch_bounds__(256) void k_view_merge(ViewRun<T> X, uint32_t nx, const uint32_t* __restrict__ dx, uint32_t ndx, const T* __restrict__ yv, const uint32_t* __restrict__ yp, uint32_t ny,
-                                                    const uint64_t* __restrict__ ix_ids, ViewRun<T> Z, uint32_t nbx) {
-  __shared__ uint32_t win[4];
-  __shared__ uint32_t s_dx[VIEW_WIN];
+__global__ __launch_bounds__(256) void k_view_merge(ViewRun<T> X, uint32_t nx, const T* __restrict__ dv, const uint32_t* __restrict__ dp, const T* __restrict__ yv, const uint32_t* __restrict__ yp,
+                                                    const uint64_t* __restrict__ ix_ids, ViewRun<T> Z, const uint32_t* __restrict__ d0s, const uint32_t* __restrict__ y0s, uint32_t* __restrict__ err) {
+  typedef T tvec __attribute__((ext_vector_type(4)));
+  typedef uint32_t uvec __attribute__((ext_vector_type(4)));
+  typedef unsigned long long lvec __attribute__((ext_vector_type(2)));
+  constexpr uint32_t CH = 256u, NCH = VIEW_TILE / CH;             // a chunk = the 256 consecutive keys one wave handles per iteration
+  constexpr uint32_t IT = VIEW_TILE / 1024u;
+  __shared__ T s_dv[VIEW_WIN];
+  __shared__ uint32_t s_dp[VIEW_WIN];
   __shared__ T s_yv[VIEW_WIN];
   __shared__ uint32_t s_yp[VIEW_WIN];
-  if (blockIdx.x < nbx) {
-    const uint32_t lo = blockIdx.x * VIEW_TILE, hi = lo + VIEW_TILE < nx ? lo + VIEW_TILE : nx;     // tile [lo, hi) of X, hi > lo
-    constexpr uint32_t U = VIEW_TILE / 256u;
-    T xv[U]; uint32_t xp[U]; uint64_t xi[U];
+  __shared__ uint32_t rB[NCH + 1], yB[NCH + 1];
+  __shared__ uint32_t n_gone;
+  const uint32_t t = blockIdx.x;
+  const uint32_t lo = t * VIEW_TILE, hi = lo + VIEW_TILE < nx ? lo + VIEW_TILE : nx;     // tile [lo, hi) of X, hi > lo
+  const uint32_t lane = threadIdx.x & 63u, w = threadIdx.x >> 6;
+  tvec xv[IT]; uvec xp[IT]; lvec xa[IT], xb[IT];
 #pragma unroll
-    for (uint32_t u = 0; u < U; u++) {
-      const uint32_t i = lo + u * 256u + threadIdx.x;
-      if (i < hi) { xv[u] = __builtin_nontemporal_load(X.v + i); xp[u] = __builtin_nontemporal_load(X.p + i); xi[u] = __builtin_nontemporal_load(X.ids + i); }
-    }
-    {   // one wave per window end: the deleted indices in [lo, hi), the keys of Y between the tile's first and last key
-      const uint32_t w = threadIdx.x >> 6;
-      uint32_t b;
-      if (w == 0) b = u32_lower_bound_wave(dx, 0, ndx, lo);
-      else if (w == 1) b = u32_lower_bound_wave(dx, 0, ndx, hi);
-      else if (w == 2) b = (uint32_t)vk_bound_wave<T>(yv, yp, 0, ny, X.v[lo], X.p[lo]);
-      else b = (uint32_t)vk_bound_wave<T>(yv, yp, 0, ny, X.v[hi - 1], X.p[hi - 1]);
-      if ((threadIdx.x & 63u) == 0) win[w] = b;
-    }
-    __syncthreads();
-    const uint32_t d0 = win[0], d1 = win[1], y0 = win[2], y1 = win[3];
-    const bool in_lds = d1 - d0 <= VIEW_WIN && y1 - y0 <= VIEW_WIN;       // (uniform)
-    if (in_lds) {
-      for (uint32_t k = threadIdx.x; k < d1 - d0; k += 256u) s_dx[k] = dx[d0 + k];
-      for (uint32_t k = threadIdx.x; k < y1 - y0; k += 256u) { s_yv[k] = yv[y0 + k]; s_yp[k] = yp[y0 + k]; }
-      __syncthreads();
-    }
+  for (uint32_t it = 0; it < IT; it++) {
+    const uint32_t e = lo + it * 1024u + w * CH + lane * 4u;        // this lane's group [e, e + 4)
+    if (e + 4u <= hi) {
+      xv[it] = __builtin_nontemporal_load(reinterpret_cast<const tvec*>(X.v + e)); xp[it] = __builtin_nontemporal_load(reinterpret_cast<const uvec*>(X.p + e));
+      xa[it] = __builtin_nontemporal_load(reinterpret_cast<const lvec*>(X.ids + e)); xb[it] = __builtin_nontemporal_load(reinterpret_cast<const lvec*>(X.ids + e + 2));
+    } else {
 #pragma unroll
-    for (uint32_t u = 0; u < U; u++) {
-      const uint32_t i = lo + u * 256u + threadIdx.x;
-      if (i >= hi) continue;
-      uint32_t r, y; bool gone;
-      if (in_lds) {
-        const uint32_t rl = u32_lower_bound(s_dx, 0, d1 - d0, i);
-        gone = rl < d1 - d0 && s_dx[rl] == i;
-        r = d0 + rl;
-        y = y0 + (uint32_t)vk_bound<T>(s_yv, s_yp, 0, y1 - y0, xv[u], xp[u]);
-      } else {
-        r = u32_lower_bound(dx, d0, d1, i);
-        gone = r < d1 && dx[r] == i;
-        y = (uint32_t)vk_bound<T>(yv, yp, y0, y1, xv[u], xp[u]);
-      }
-      if (gone) continue;
-      const uint64_t o = (uint64_t)i - r + y;
-      Z.v[o] = xv[u]; Z.p[o] = xp[u]; Z.ids[o] = xi[u];
+      for (uint32_t k = 0; k < 4; k++) { const bool ok = e + k < hi; xv[it][k] = ok ? X.v[e + k] : (T)0; xp[it][k] = ok ? X.p[e + k] : 0u; const unsigned long long id = ok ? X.ids[e + k] : 0ull; if (k < 2) xa[it][k] = id; else xb[it][k - 2] = id; }
+    }
+  }
+  const uint32_t d0 = d0s[t], d1 = d0s[t + 1], y0 = y0s[t], y1 = y0s[t + 1];
+  const uint32_t nd = d1 - d0, nyw = y1 - y0;
+  if (nd == 0 && nyw == 0) {                                           // (uniform) nothing of the patch touches this tile: it moves as it is
+#pragma unroll
+    for (uint32_t it = 0; it < IT; it++) {
+      const uint32_t e = lo + it * 1024u + w * CH + lane * 4u;
+      const uint64_t o = (uint64_t)e - d0 + y0;
+      if (e + 4u <= hi) { st_vec(Z.v + o, xv[it]); st_vec(Z.p + o, xp[it]); st_vec(Z.ids + o, xa[it]); st_vec(Z.ids + o + 2, xb[it]); }
+      else for (uint32_t k = 0; k < 4 && e + k < hi; k++) { Z.v[o + k] = xv[it][k]; Z.p[o + k] = xp[it][k]; Z.ids[o + k] = k < 2 ? xa[it][k] : xb[it][k - 2]; }
     }
     return;
   }
-  // keys of Y: 256 consecutive ones; their places in X lie between the places of the first and the last
-  const uint32_t j0 = (blockIdx.x - nbx) * 256u;
-  if (j0 >= ny) return;
-  const uint32_t jl = j0 + 255u < ny ? j0 + 255u : ny - 1u;
-  {
-    const uint32_t w = threadIdx.x >> 6;
-    if (w < 2) {
-      const uint32_t k = w == 0 ? j0 : jl;
-      const uint32_t b = (uint32_t)vk_bound_wave<T>(X.v, X.p, 0, nx, yv[k], yp[k]);
-      if ((threadIdx.x & 63u) == 0) win[w] = b;
-    }
+  const bool in_lds = nd <= VIEW_WIN && nyw <= VIEW_WIN;              // (uniform)
+  if (threadIdx.x == 0) n_gone = 0;
+  if (in_lds) {
+    for (uint32_t k = threadIdx.x; k < nd; k += 256u) { s_dv[k] = dv[d0 + k]; s_dp[k] = dp[d0 + k]; }
+    for (uint32_t k = threadIdx.x; k < nyw; k += 256u) { s_yv[k] = yv[y0 + k]; s_yp[k] = yp[y0 + k]; }
   }
   __syncthreads();
-  const uint32_t j = j0 + threadIdx.x;
-  if (j >= ny) return;
-  const T kv = yv[j]; const uint32_t kp = yp[j];
-  const uint32_t p = (uint32_t)vk_bound<T>(X.v, X.p, win[0], win[1], kv, kp);
-  const uint32_t r = u32_lower_bound(dx, 0, ndx, p);
-  const uint64_t o = (uint64_t)j + p - r;
-  Z.v[o] = kv; Z.p[o] = kp; Z.ids[o] = ix_ids[kp];
+  // the windows, wherever they are: entry k of the tile's deleted / inserted keys
+  const T* dwv = in_lds ? s_dv : dv + d0; const uint32_t* dwp = in_lds ? s_dp : dp + d0;
+  const T* ywv = in_lds ? s_yv : yv + y0; const uint32_t* ywp = in_lds ? s_yp : yp + y0;
+  if (threadIdx.x <= NCH) {      // ranks (inside the windows) of the chunk boundaries lo, lo + 256, ..., the tile's end
+    const uint32_t b = lo + threadIdx.x * CH;
+    uint32_t r = nd, y = nyw;
+    if (threadIdx.x < NCH && b < hi) { const T bv = X.v[b]; const uint32_t bp = X.p[b]; r = (uint32_t)vk_bound<T>(dwv, dwp, 0, nd, bv, bp); y = (uint32_t)vk_bound<T>(ywv, ywp, 0, nyw, bv, bp); }
+    if (threadIdx.x == 0) y = 0;                                       // (inserted keys in front of the tile's first key — only tile 0 has any — are placed by its first lane, below)
+    rB[threadIdx.x] = r; yB[threadIdx.x] = y;
+  }
+  __syncthreads();
+  uint32_t gone_cnt = 0;
+#pragma unroll
+  for (uint32_t it = 0; it < IT; it++) {
+    const uint32_t c = it * 4u + w;
+    const uint32_t e = lo + c * CH + lane * 4u;
+    const uint32_t ra = rB[c], rb = rB[c + 1], ya = yB[c], yb = yB[c + 1];
+    const uint32_t nD = rb - ra, nY = yb - ya;                          // (wave-uniform) this chunk's deleted / inserted keys
+    uint32_t r[4], y[4]; bool gone[4];
+#pragma unroll
+    for (uint32_t k = 0; k < 4; k++) { r[k] = ra; y[k] = ya; gone[k] = false; }
+    if (nD <= 64u && nY <= 64u) {
+      // the chunk's entries, one per lane, then broadcast one by one: every lane counts how many sort in front of each of its keys
+      T ev = (T)0; uint32_t ep = 0;
+      if (lane < nD) { ev = dwv[ra + lane]; ep = dwp[ra + lane]; }
+      for (uint32_t j = 0; j < nD; j++) {
+        const T jv = rdlane(ev, j); const uint32_t jp = rdlane(ep, j);
+#pragma unroll
+        for (uint32_t k = 0; k < 4; k++) { const T kv = xv[it][k]; const uint32_t kp = xp[it][k]; r[k] += vk_less<T>(jv, jp, kv, kp) ? 1u : 0u; gone[k] = gone[k] || (jv == kv && jp == kp); }
+      }
+      if (lane < nY) { ev = ywv[ya + lane]; ep = ywp[ya + lane]; }
+      for (uint32_t j = 0; j < nY; j++) {
+        const T jv = rdlane(ev, j); const uint32_t jp = rdlane(ep, j);
+#pragma unroll
+        for (uint32_t k = 0; k < 4; k++) y[k] += vk_less<T>(jv, jp, xv[it][k], xp[it][k]) ? 1u : 0u;
+      }
+    } else {
+      // a chunk crowded with entries (a skewed patch): every key searches the chunk's stretch of the windows
+#pragma unroll
+      for (uint32_t k = 0; k < 4; k++) {
+        const T kv = xv[it][k]; const uint32_t kp = xp[it][k];
+        r[k] = (uint32_t)vk_bound<T>(dwv, dwp, ra, rb, kv, kp); gone[k] = r[k] < rb && dwv[r[k]] == kv && dwp[r[k]] == kp;
+        y[k] = (uint32_t)vk_bound<T>(ywv, ywp, ya, yb, kv, kp);
+      }
+    }
+#pragma unroll
+    for (uint32_t k = 0; k < 4; k++) if (e + k >= hi) { r[k] = rb; y[k] = yb; gone[k] = false; }     // behind the tile's end: what the last real key sees behind itself
+    // the inserted keys BEHIND key k (in front of the next key of X): ranks [y[k], yn[k])
+    uint32_t ynx = (uint32_t)__shfl_down((int)y[0], 1);
+    if (lane == 63u) ynx = yb;
+    const uint32_t yn[4] = {y[1], y[2], y[3], ynx};
+    const uint64_t ob = (uint64_t)y0 - d0;                               // output index of key i = i + ob - r + y
+    const bool clean = !gone[0] && !gone[1] && !gone[2] && !gone[3] && r[3] == r[0] && y[3] == y[0] && e + 4u <= hi;
+    if (e < hi) {
+      if (clean) { const uint64_t o = e + ob - r[0] + y[0]; st_vec(Z.v + o, xv[it]); st_vec(Z.p + o, xp[it]); st_vec(Z.ids + o, xa[it]); st_vec(Z.ids + o + 2, xb[it]); }
+      else {
+#pragma unroll
+        for (uint32_t k = 0; k < 4; k++) {
+          if (e + k < hi && !gone[k]) { const uint64_t o = (uint64_t)(e + k) + ob - r[k] + y[k]; Z.v[o] = xv[it][k]; Z.p[o] = xp[it][k]; Z.ids[o] = k < 2 ? xa[it][k] : xb[it][k - 2]; }
+          gone_cnt += gone[k] ? 1u : 0u;
+        }
+      }
+#pragma unroll
+      for (uint32_t k = 0; k < 4; k++) {
+        if (e + k >= hi) break;
+        for (uint32_t j = y[k]; j < yn[k]; j++) {                          // (rare: 1 % of the keys have one behind them)
+          const uint64_t o = (uint64_t)(e + k + 1u) + ob - (r[k] + (gone[k] ? 1u : 0u)) + j;
+          const uint32_t jp = ywp[j];
+          Z.v[o] = ywv[j]; Z.p[o] = jp; Z.ids[o] = ix_ids[jp];
+        }
+      }
+      if (e == lo) for (uint32_t j = 0; j < y[0]; j++) {                 // tile 0 only: inserted keys in front of the view's first key
+        const uint32_t jp = ywp[j];
+        Z.v[j] = ywv[j]; Z.p[j] = jp; Z.ids[j] = ix_ids[jp];
+      }
+    }
+  }
+  // every deleted key of the tile's window must have been met
+  for (int d = 32; d >= 1; d >>= 1) gone_cnt += (uint32_t)__shfl_xor((int)gone_cnt, d);
+  if (lane == 0 && gone_cnt) atomicAdd(&n_gone, gone_cnt);
+  __syncthreads();
+  if (threadIdx.x == 0 && n_gone != nd) *err = 1u;
 }
 
 }  // namespace bmx
