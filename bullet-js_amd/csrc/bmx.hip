@@ -2005,8 +2005,15 @@ int bmx_partition_scatter(bmx_ctx* ctx, uint64_t n, const uint64_t* id, const ui
                           uint32_t nshards, uint64_t slab_records, void* const* dst, uint64_t* counts_out_dev, uint64_t* const* arrive_words, uint64_t arrive_value,
                           const uint64_t* wait_words_dev, uint32_t n_wait, uint64_t wait_at_least) {
   if (!ctx || !dst || slab_records == 0 || nshards == 0 || nshards > PART_MAX_SHARDS) return fail(ctx, BMX_ERR_INVALID, "bmx_partition_scatter: bad arguments (1..16 shards, slab_records > 0)");
-  if (wait_words_dev && n_wait) { int wrc = bmx_seq_wait_all(ctx, nullptr, wait_words_dev, n_wait, wait_at_least); if (wrc) return wrc; }
+  // A/B switch, OFF by default: BMX_PART_WAIT_FOLD=1 folds the wait into the scatter pass (every workgroup polls before its first store) instead of a one-wave launch in
+  // front of the count pass. Measured (profiles/r05_sharded_ab.log): 95.0 / 96.9 against 102.1 / 96.4 us per step — inside the run-to-run spread — and one run with the
+  // deferred compaction beside it took 75 ms per step: 1024 spinning workgroups hold the LDS and wave slots the kernel that frees the slabs needs. A one-wave wait cannot do that.
+  static const bool fold_wait = [] { const char* v = std::getenv("BMX_PART_WAIT_FOLD"); return v && v[0] == '1' && !v[1]; }();
+  if (wait_words_dev && n_wait && (!fold_wait || n_wait > 64)) { int wrc = bmx_seq_wait_all(ctx, nullptr, wait_words_dev, n_wait, wait_at_least); if (wrc) return wrc; }
   PartOut po; std::memset(&po, 0, sizeof(po));
+  if (wait_words_dev && n_wait && fold_wait && n_wait <= 64) {
+    po.wait_words = reinterpret_cast<const unsigned long long*>(wait_words_dev); po.n_wait = n_wait; po.wait_at_least = wait_at_least; po.wait_diag = ctx->ds->seq_diag;
+  }
   for (uint32_t g = 0; g < nshards; g++) {
     if (!dst[g]) return fail(ctx, BMX_ERR_INVALID, "bmx_partition_scatter: null destination slab");
     po.base[g] = static_cast<bmx_delta_rec*>(dst[g]);

@@ -708,6 +708,10 @@ struct PartOut {
   bmx_delta_rec* base[PART_MAX_SHARDS];
   uint32_t split;
   uint32_t aux_base;     // added to the origin index carried in `aux` (offset of this originator's slice in a global batch)
+  // round 5: the wait for the destination slabs to be free again (bmx_partition_scatter's wait words) folded into the scatter pass itself — every workgroup polls
+  // the (<= 16) words before its first store — instead of a one-wave launch of its own in front of the count pass: that launch was 5-6 us of the exchange
+  // stream's 90-us chain per step (profiles/r04_sharded_timeline.log), and the count pass, which writes nothing into the slabs, had to wait behind it
+  const unsigned long long* wait_words = nullptr; uint32_t n_wait = 0; unsigned long long wait_at_least = 0; unsigned long long* wait_diag = nullptr;
 };
 
 __device__ __forceinline__ uint32_t owner_of_dev(uint64_t id, uint32_t nshards) { return (uint32_t)__umul64hi(owner_hash(id), (uint64_t)nshards); }
@@ -758,6 +762,25 @@ __global__ __launch_bounds__(256) void k_part_scatter(const uint64_t* id, const 
     }
   };
   if (lo < hi) load_tile(lo);                      // in flight under the prologue
+  if (po.n_wait) {                                   // the slabs this launch stores into are free once every word has reached wait_at_least (lane k polls word k)
+    __shared__ uint32_t gave_up;
+    if (threadIdx.x == 0) gave_up = 0;
+    __syncthreads();
+    if (threadIdx.x < po.n_wait) {
+      const unsigned long long t0 = wall_clock64();
+      unsigned long long seen;
+      while ((seen = __hip_atomic_load(po.wait_words + threadIdx.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM)) < po.wait_at_least) {
+        __builtin_amdgcn_s_sleep(8);
+        if (wait_gave_up(t0, status)) {
+          if (po.wait_diag && !po.wait_diag[0]) { po.wait_diag[0] = (unsigned long long)(uintptr_t)(po.wait_words + threadIdx.x); po.wait_diag[1] = po.wait_at_least; po.wait_diag[2] = seen; }
+          atomicOr(status, ST_SPIN); gave_up = 1u;
+          break;
+        }
+      }
+    }
+    __syncthreads();
+    if (gave_up) return;                             // (uniform) never store into slabs somebody may still read: the sticky error says the batch was not routed
+  }
   // prologue: per shard, before = sum of counts[g][b] over the blocks before this one, all = sum over every block.
   // Wave w reduces shards w, w+4, ...; a lane reads 4 consecutive blocks per 16-byte load.
   for (uint32_t gs = w; gs < nshards; gs += 4) {
