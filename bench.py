@@ -235,13 +235,13 @@ def js_host_rate():
         script = os.path.join(ROOT, "bullet-js_amd", "js", "test", "e2e_rate.js")
         r = subprocess.run(pin + [node, script, "1000000", "500000", "8"], capture_output=True, text=True, timeout=240)
         j = json.loads(r.stdout.strip().splitlines()[-1])
-        for key in ("apply", "vector"):      # one process each: a 4M-entry run of every section at once does not fit node 12's default heap
+        for key, out_key in (("apply", "applied_path"), ("lazy", "lazy_path"), ("vector", "vector")):      # one process each: a 4M-entry run of every section at once does not fit node 12's default heap
             try:
                 r2 = subprocess.run(pin + [node, script, "1000000", "200000", "5", "only", key], capture_output=True, text=True, timeout=300)
                 j2 = json.loads(r2.stdout.strip().splitlines()[-1])
-                j["applied_path" if key == "apply" else "vector"] = j2["applied_path" if key == "apply" else "vector"]
+                j[out_key] = j2[out_key]
             except Exception as e:
-                j["applied_path" if key == "apply" else "vector"] = {"error": str(e)[:200]}
+                j[out_key] = {"error": str(e)[:200]}
         j["cpus"] = cpus or "not pinned"
         j["applied_path_sample"] = "the real ingestion seam with the STORE KEPT: attach(bullet, {batchSync}) -> processSyncEntries over 5 chunks of 200k sync entries against 1M resident nodes (90 % updates, 10 % new nodes): every winner replaces its node in the nested store, meta[path] gets its clock, the op log and the put queue are fed (src/bullet.js:184-266 per batch); beside it the same entries one by one through setData and the host resolver (the reference's loop body)"
         j["vector_sample"] = "5 chunks of 200k entries under clocks over ordered subsets of three writers (N4): nodes' clock rows in the device's vector-clock table, synchronous GpuCRT.mergeEntries"
@@ -550,9 +550,10 @@ def compact_line(out, detail_path=None):
         optional.append(("scan_config3", s3))
     jh = g("js_host")
     if isinstance(jh, dict):
-        ap, vc = jh.get("applied_path") or {}, jh.get("vector") or {}
+        ap, vc, lz = jh.get("applied_path") or {}, jh.get("vector") or {}, jh.get("lazy_path") or {}
         j = {"mergeEntries_per_s": jh.get("mergeEntries_per_s"), "mergeEntriesPipelined_per_s": jh.get("mergeEntriesPipelined_per_s"),
-             "store_kept_entries_per_s": ap.get("batchSync_apply_entries_per_s"), "vector_pipelined_per_s": vc.get("mergeEntriesPipelined_per_s")}
+             "store_kept_entries_per_s": ap.get("batchSync_apply_entries_per_s"), "store_kept_lazy_entries_per_s": lz.get("batchSync_lazy_entries_per_s"),
+             "store_kept_lazy_incl_fold_entries_per_s": lz.get("incl_the_fold_entries_per_s"), "vector_pipelined_per_s": vc.get("mergeEntriesPipelined_per_s")}
         if "error" in jh:
             j = {"error": str(jh["error"])[:120]}
         optional.append(("js_host", {k: _r(x, 0) for k, x in j.items()}))

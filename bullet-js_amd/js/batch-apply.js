@@ -18,10 +18,10 @@
  */
 const LOG_CAP = 1000;   // src/bullet.js:213-215
 
-function applyBatch(bullet, updates, fromNetwork, wantBroadcast = true) {
+function applyBatch(bullet, updates, fromNetwork, wantBroadcast = true, at) {
   const n = updates.length;
   if (n === 0) return [];
-  const now = Date.now();
+  const now = at === undefined ? Date.now() : at;      // `at`: when the batch ARRIVED (a deferred fold, lazy-store.js, applies it later with its own time)
   const source = fromNetwork ? "network" : "local";
   const listeners = bullet.listeners || {};
   const hasListeners = Object.keys(listeners).length > 0;

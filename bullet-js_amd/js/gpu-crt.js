@@ -425,7 +425,7 @@ class GpuCRT {
     if (!this._puts) {
       const g = this._graph;
       this._puts = new PutQueue(g);
-      if (g && !g.preOp) g.preOp = () => this._flushDeviceWrites();
+      if (g && !g.preOp) g.preOp = () => { if (this._lazy && this._lazy.n) this._lazy.foldAll(); this._flushDeviceWrites(); };   // (recorded winners first: their integer fields become rows in the fold)
     }
     return this._puts;
   }
@@ -752,7 +752,8 @@ class GpuCRT {
     if (!rowNode || nrows === 0) return;
     if (!this._seen || this._seen.length < nNodes) { this._seen = new Uint32Array(Math.max(1024, 2 * nNodes)); this._seenStamp = 0; }
     if (++this._seenStamp === 0xffffffff) { this._seen.fill(0); this._seenStamp = 1; }
-    const seen = this._seen, stamp = this._seenStamp, meta = this.bullet.meta || {};
+    const seen = this._seen, stamp = this._seenStamp;
+    let meta = null;                                       // (read only where it is needed: with a lazy store the property is an accessor that folds)
     const won = new Uint8Array(nrows);
     for (let k = 0; k < winners.length; k++) won[winners[k] & 0xffffff] = 1;
     const lazy = !this._opts.writers && this._graph;       // single-writer clocks: the loser's merged clock is a copy of the stored one ({w: max(its ts, stored ts)} = stored)
@@ -768,6 +769,7 @@ class GpuCRT {
         if (this._nFalsy > 0 && readBack) this.bullet._getData(entries[rowEntry[j]].path);
         continue;
       }
+      if (meta === null) meta = this.bullet.meta || {};
       const e = entries[rowEntry[j]], m = meta[e.path];
       if (m && m.vectorClock) this.vectorClocks.set(e.path, this.mergeVectorClocks(e.vectorClock, m.vectorClock));
       // ... and the read the reference's handleUpdate starts with: _getData(path) REPLACES a falsy value on the way (null of a deleted node, 0, "") by {}
@@ -852,6 +854,22 @@ class GpuCRT {
     const writer = writerOpt || this._opts.writer || this.bullet.id;
     const b = this.bullet;
     const q = this._putQueue();
+    const lz = this._lazy;
+    if (lz && mode === true && !wantBroadcast && rowNode && lz.usable()) {
+      // lazy-store.js: RECORD the winners (entry, path number, node id, stored clock); store, meta, op log and the winners' value rows follow when somebody
+      // looks (_foldRecords). What the next chunk's resolution needs is already in place: the clock rows on the device, the path dictionary, the marks below.
+      lz.beginBatch(writer, valueRows);
+      for (let k = 0; k < n; k++) {
+        const a = appliedIdx[k], e = entries[applied[k]], idx = rowNode[a & 0xffffff];
+        const ts = ts32 ? ts32[2 * k + 1] * 4294967296 + ts32[2 * k] : ((a >>> 31) && !deltaMode ? 2 : e.vectorClock[writer]);
+        lz.push(e, idx, id32[2 * k], id32[2 * k + 1], ts);
+        this._markLazyClock(idx, P_CLOCK_META);
+        if (this._nFalsy) this._setFalsy(idx, !e.data);
+      }
+      lz.endBatch();
+      return [];
+    }
+    if (lz && lz.n) lz.foldAll();               // anything applied at once comes BEHIND what was recorded earlier
     const updates = mode ? new Array(n) : null;
     const leaf = this._leafKeys || (this._leafKeys = []);
     // consecutive winners usually share their collection: its path string and its object in the store are looked up when it changes
@@ -897,6 +915,38 @@ class GpuCRT {
     }
     if (typeof b._applyBatch === "function") return b._applyBatch(updates, true) || [];
     return require("./batch-apply").applyBatch(b, updates, true, wantBroadcast);
+  }
+
+  /* lazy-store.js: the recorded winners [from, to) of ONE batch -> store, meta, op log (batch-apply.js, with the batch's arrival time) and the device's value rows;
+   * the same per-winner work, in the same order, as the eager loop of _applyWinners above. */
+  _foldRecords(ent, idxs, los, his, tss, from, to, at, writer, valueRows) {
+    const n = to - from;
+    if (n <= 0) return;
+    const b = this.bullet, q = this._putQueue();
+    const updates = new Array(n);
+    const leaf = this._leafKeys || (this._leafKeys = []);
+    let parent = null, pLen = -2, pNode;
+    for (let k = 0; k < n; k++) {
+      const e = ent[from + k], idx = idxs[from + k], ts = tss[from + k];
+      const path = e.path, cut = path.lastIndexOf("/");
+      if (cut !== pLen || !path.startsWith(parent)) { parent = cut < 0 ? "" : path.slice(0, cut); pLen = cut; pNode = peek(b.store, parent); }
+      let value = e.data, old;
+      const clock = {};
+      clock[writer] = ts;
+      if (isMergeable(value)) {
+        if (value.__vectorClock === undefined && value.__fromNetwork === undefined) value = Object.assign({}, value);
+        else { const clean = {}; for (const f of Object.keys(value)) if (f !== "__vectorClock" && f !== "__fromNetwork") clean[f] = value[f]; value = clean; }
+      }
+      const plain = cut !== path.length - 1 && path.indexOf("//") < 0;
+      let key;
+      if (plain) { key = leaf[idx]; if (key === undefined) key = leaf[idx] = (cut < 0 ? path : path.slice(cut + 1)); }
+      updates[k] = { path, value, vectorClock: clock, parentHint: parent, cutHint: cut, keyHint: key };
+      if (!plain) old = peek(b.store, path);
+      else if (pNode !== null && typeof pNode === "object") old = pNode[key];
+      if (valueRows) this._queueValueRows(q, path, parent, los[from + k], his[from + k], old, value, ts, true);
+    }
+    q.closeBatch();
+    require("./batch-apply").applyBatch(b, updates, true, false, at);
   }
 
   /* ---------------------------------------------------------------- N4: K-writer vector clocks on the device */

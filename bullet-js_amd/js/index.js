@@ -42,15 +42,19 @@ function attach(bullet, opts = {}) {
   bullet.query = query;
   Object.defineProperty(crt, "_graph", { get: () => graph, set: (g) => { graph = g; }, configurable: true });
   const sync = opts.batchSync ? installBatchSync(bullet, crt, typeof opts.batchSync === "object" ? opts.batchSync : {}) : null;
+  // opt-in: store, meta and op log follow the batches lazily (lazy-store.js; one documented difference: live objects handed out before a batch)
+  const lazyStore = opts.batchSync && typeof opts.batchSync === "object" && opts.batchSync.lazyStore ? new (require("./lazy-store"))(bullet, crt, typeof opts.batchSync.lazyStore === "object" ? opts.batchSync.lazyStore : {}) : null;
+  if (lazyStore) crt._lazy = lazyStore;
   const close = bullet.close ? bullet.close.bind(bullet) : null;
   bullet.close = async function () {
     if (sync) sync.uninstall();
+    if (lazyStore) { lazyStore.uninstall(); crt._lazy = null; }
     let r;
     if (close) r = await close();          // storage.close() saves first: it may still need the device rows
     if (graph) { graph.close(); graph = null; }
     return r;
   };
-  return { crt, query, sync };
+  return { crt, query, sync, lazyStore };
 }
 
 module.exports = { GpuCRT, GpuQuery, GpuStorage, attach, installBatchSync, applyBatch, hash, nativeAvailable: native.available };

@@ -286,12 +286,13 @@ for (const shards of [2, 4, 8]) {
 /* ... and on tests/golden/g10_sync_mixed_values.json: objects with string / nested / array / boolean / null fields take the same device path (the node's
  * clock is resolved on the GPU, the object stays on the host, only its integer fields become device rows); an object that meets a stored STRING under
  * an identical clock is the host's (compared as text by the reference). */
-for (const [fixture, batchPuts, minDevice, minHost] of [["g9_sync_node_semantics.json", false, 23, 6], ["g9_sync_node_semantics.json", true, 23, 6],
-  ["g10_sync_mixed_values.json", false, 16, 9], ["g10_sync_mixed_values.json", true, 15, 8]]) {
+for (const [fixture, batchPuts, minDevice, minHost, lazyStore] of [["g9_sync_node_semantics.json", false, 23, 6], ["g9_sync_node_semantics.json", true, 23, 6],
+  ["g10_sync_mixed_values.json", false, 16, 9], ["g10_sync_mixed_values.json", true, 15, 8],
+  ["g9_sync_node_semantics.json", false, 23, 6, true], ["g10_sync_mixed_values.json", false, 16, 9, true], ["g10_sync_mixed_values.json", true, 15, 8, { idleSlice: 0 }]]) {   // ... and with the store following lazily (lazy-store.js)
   const g = load(fixture);
-  const g9 = fixture.slice(0, fixture.indexOf("_"));
+  const g9 = fixture.slice(0, fixture.indexOf("_")) + (lazyStore ? " (lazy store)" : "");
   const b = new MiniBullet(g.id);
-  const { crt, query, sync } = attach(b, { capacityRows: 4096, batchSync: { batchPuts } });
+  const { crt, query, sync } = attach(b, { capacityRows: 4096, batchSync: { batchPuts, lazyStore } });
   g.chunks.forEach((chunk, ci) => {
     if (batchPuts && ci === 2) {     // the same entries as network puts: queued, merged when the queue is flushed (here: by the next chunk's first use)
       for (const e of chunk) {
@@ -739,12 +740,12 @@ for (const [name, shards] of [["g11_vc_keysets_2k.json", 1], ["g11_vc_keysets_ho
  * on 250 nodes under clocks {w: 0..7} (many ties), objects with integer and string fields, integer and string primitives (local writes in the reference's
  * loop: refused ones still move the clock), deletions, two-writer clocks (host-only paths), with and without put batching. Store, clocks, sources and the device's
  * clock rows after every chunk. */
-for (const batchPuts of [false, true]) {
+for (const [batchPuts, lazyStore] of [[false, false], [true, false], [false, { idleSlice: 0 }], [true, true]]) {
   const b = new MiniBullet("w");
-  const { crt, sync } = attach(b, { capacityRows: 256, batchSync: { batchPuts } });
+  const { crt, sync } = attach(b, { capacityRows: 256, batchSync: { batchPuts, lazyStore } });
   const twinB = new MiniBullet("w");
   twinB.crt = new GpuCRT(twinB);
-  const rng = gen.xorshift32((batchPuts ? 4242 : 777) + STRESS_SALT);
+  const rng = gen.xorshift32((batchPuts ? 4242 : 777) + (lazyStore ? 31 : 0) + STRESS_SALT);
   for (let round = 0; round < 3; round++) {
     const entries = [];
     for (let j = 0; j < 2000; j++) {
@@ -787,6 +788,55 @@ for (const batchPuts of [false, true]) {
   }
   assert.ok(sync.stats.deviceEntries > 3000, JSON.stringify(sync.stats));
   b.close();
+}
+
+/* lazy-store.js (opt-in, VERDICT r4 item 5): the winners of device batches are recorded and the facade's store / meta / op log follow when they are read. Against a
+ * twin that applies the same chunks eagerly: nothing is folded while only batches arrive; ANY read through the facade (store, meta, log, _getData, a node's value(), a
+ * host-path write, a device scan) sees exactly the eager state, op-log order and per-batch timestamps included; a registered listener switches the deferral off. */
+{
+  const mk = (lazyStore) => { const b = new MiniBullet("w"); const h = attach(b, { capacityRows: 8192, batchSync: { lazyStore } }); return { b, h }; };
+  const L = mk({ idleSlice: 0 }), E = mk(false);
+  const chunkOf = (c, n, base) => { const es = []; for (let i = 0; i < n; i++) es.push({ path: "lz/n" + ((i * 7 + base) % 900), data: { v: c * 1000 + i, tag: "t" + (i % 3) }, vectorClock: { w: 10 + c } }); return es; };
+  for (let c = 0; c < 4; c++) for (const x of [L, E]) x.h.sync.processSyncEntries(chunkOf(c, 700, c * 13), "peer");
+  assert.ok(L.h.lazyStore.n > 0 && L.h.lazyStore.folds === 0, "four chunks in, nothing folded yet: " + L.h.lazyStore.n);
+  const pend = L.h.lazyStore.n;
+  assert.strictEqual(Object.keys(L.h.lazyStore.real.store).length, 0);                         // the real store object has not been touched
+  assert.deepStrictEqual(JSON.parse(JSON.stringify(L.b.store)), JSON.parse(JSON.stringify(E.b.store)));   // reading it folds everything
+  assert.ok(L.h.lazyStore.n === 0 && L.h.lazyStore.folded === pend);
+  assert.deepStrictEqual(Object.keys(L.b.meta).sort(), Object.keys(E.b.meta).sort());
+  for (const p of Object.keys(E.b.meta)) { assert.deepStrictEqual(L.b.meta[p].vectorClock, E.b.meta[p].vectorClock, p); assert.strictEqual(L.b.meta[p].source, E.b.meta[p].source); }
+  assert.deepStrictEqual(L.b.log.map((r) => [r.path, r.data.v]), E.b.log.map((r) => [r.path, r.data.v]));                    // the last 1000 operations, in arrival order
+  // one more chunk, then different kinds of readers, each on a fresh pending set
+  const readers = [
+    (x) => x.b._getData("lz/n5"), (x) => x.b.get("lz/n6").value(), (x) => x.b.meta["lz/n7"].vectorClock, (x) => x.b.log.length,
+    (x) => { x.b.setData("lz/n8", { v: -1, __fromNetwork: true, __vectorClock: { w: 500 } }); return x.b.store.lz.n8; },        // a host-path write lands BEHIND the recorded batch
+    (x) => { x.h.query.index("lz", "v", { source: "device" }); return x.h.query.range("lz", "v", 4000, 4100).map((n) => n.path).sort(); },   // a device scan: the winners' value rows are there
+    (x) => x.h.crt.getVectorClock("lz/n9"),
+  ];
+  readers.forEach((read, ri) => {
+    for (const x of [L, E]) x.h.sync.processSyncEntries(chunkOf(4 + ri, 300, ri * 31), "peer");
+    assert.ok(L.h.lazyStore.n > 0, "reader " + ri + ": something pending");
+    const gotL = read(L), gotE = read(E);
+    assert.strictEqual(L.h.lazyStore.n, 0, "reader " + ri + " folded what was pending");
+    assert.deepStrictEqual(JSON.parse(JSON.stringify(gotL === undefined ? null : gotL)), JSON.parse(JSON.stringify(gotE === undefined ? null : gotE)), "reader " + ri);
+    assert.deepStrictEqual(JSON.parse(JSON.stringify(L.b.store)), JSON.parse(JSON.stringify(E.b.store)), "store after reader " + ri);
+    checks += 2;
+  });
+  // a listener wants its callback AT the write: nothing is deferred while one is registered
+  L.b.listeners = { "lz/n1": [() => {}] };
+  L.h.sync.processSyncEntries(chunkOf(40, 50, 0), "peer"); E.h.sync.processSyncEntries(chunkOf(40, 50, 0), "peer");
+  assert.strictEqual(L.h.lazyStore.n, 0);
+  assert.deepStrictEqual(JSON.parse(JSON.stringify(L.h.lazyStore.real.store)), JSON.parse(JSON.stringify(E.b.store)));
+  L.b.listeners = {};
+  // the documented difference: a live object handed out before a batch shows the batch once the store has been read through the facade (or the idle fold ran)
+  const held = L.b.get("lz").value();
+  L.h.sync.processSyncEntries([{ path: "lz/brandnew", data: { v: 1 }, vectorClock: { w: 5 } }], "peer");
+  assert.strictEqual(held.brandnew, undefined);
+  assert.deepStrictEqual(L.b.store.lz.brandnew, { v: 1 });
+  assert.deepStrictEqual(held.brandnew, { v: 1 });                                           // the same object: the fold wrote into it
+  L.b.close(); E.b.close();
+  assert.ok(Object.getOwnPropertyDescriptor(L.b, "store").writable, "close() gives the plain properties back");
+  checks += 12;
 }
 
 /* Integer ENTRIES through a DIRECT GpuCRT.mergeEntries call, pinned on tests/golden/g13_entries_integer_ties.json (the reference's processUpdate over

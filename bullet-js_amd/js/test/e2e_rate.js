@@ -73,7 +73,33 @@ for (const cols of colsB) applied += crt.mergeBatch(cols).nApplied;
 const dtCols = Number(process.hrtime.bigint() - t0) / 1e9;
 // the whole ingestion seam with the store kept (attach(..., {batchSync}) -> processSyncEntries, apply: true: store, meta, op log, listeners, value rows),
 // against the reference's loop body entry by entry through the host resolver (src/bullet-network-sync.js:551-569)
-let applied_path = null;
+let applied_path = null, lazy_path = null;
+if (process.argv[5] === "lazy" || process.argv[6] === "lazy") {
+  // the same seam with the store following LAZILY (attach(..., {batchSync: {lazyStore}}), lazy-store.js): what the chunks cost while they arrive, and what the fold
+  // that any read of the store triggers costs afterwards (here: all at once, right behind the last chunk)
+  batches.length = 0; batches2.length = 0; colsB.length = 0;
+  const { attach } = require("..");
+  const MiniBullet = require("./mini-bullet");
+  const ab = new MiniBullet("w");
+  const h = attach(ab, { capacityRows: 2 * (R + B * D), batchSync: { lazyStore: { idleSlice: 0 } } });
+  for (let r0 = 0; r0 < R; r0 += 250000) {
+    const seed = new Array(Math.min(250000, R - r0));
+    for (let i = 0; i < seed.length; i++) seed[i] = { path: "n/k" + (r0 + i), data: { f: (r0 + i) & 1023 }, vectorClock: { w: 5 } };
+    h.sync.processSyncEntries(seed);
+  }
+  void ab.store;                                                   // the resident graph is in the store before the clock starts
+  const chunks = mkBatches(3, B, true);
+  h.sync.processSyncEntries(chunks[0].slice(0, 1000)); void ab.store;
+  t0 = process.hrtime.bigint();
+  for (const c of chunks) h.sync.processSyncEntries(c);
+  const dtL = Number(process.hrtime.bigint() - t0) / 1e9;
+  const pending = h.lazyStore.n;
+  t0 = process.hrtime.bigint();
+  const nodes = Object.keys(ab.store.n || {}).length;              // the first read folds every recorded winner in
+  const dtF = Number(process.hrtime.bigint() - t0) / 1e9;
+  lazy_path = { batchSync_lazy_entries_per_s: (B * D) / dtL, incl_the_fold_entries_per_s: (B * D) / (dtL + dtF), winners_recorded: pending, fold_s: dtF, nodes };
+  ab.close();
+}
 if (process.argv[5] === "apply" || process.argv[6] === "apply") {
   batches.length = 0; batches2.length = 0; colsB.length = 0;
   const { attach } = require("..");
@@ -131,7 +157,7 @@ if (process.argv[5] === "vector" || process.argv[6] === "vector") {
   vector.host_only = vcrt.hostOnlyInfo();
   vcrt.close();
 }
-console.log(JSON.stringify({ applied_path, vector, mergeEntries_per_s: ONLY ? null : (B * D) / dtEntries, mergeEntriesPipelined_per_s: ONLY ? null : (B * D) / dtPipe, mergeBatch_typed_columns_per_s: ONLY ? null : (B * D) / dtCols, unit: "deltas/s", resident_keys: R,
+console.log(JSON.stringify({ applied_path, lazy_path, vector, mergeEntries_per_s: ONLY ? null : (B * D) / dtEntries, mergeEntriesPipelined_per_s: ONLY ? null : (B * D) / dtPipe, mergeBatch_typed_columns_per_s: ONLY ? null : (B * D) / dtCols, unit: "deltas/s", resident_keys: R,
   entries_per_batch: D, batches: B, applied, node: process.version }));
 crt.close();
 })().catch((e) => { console.error(e); process.exit(1); });
