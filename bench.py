@@ -296,7 +296,7 @@ def scan_bench(bmx, dev, R, reps=20, wide=False):
         tscan = {}
     QUERIES = [("equals_0.1pct", 42, 42), ("range_1pct", 100, 109), ("range_10pct", 100, 199), ("range_50pct", 0, 499)]
     want = {name: [0, 0] for name, _, _ in QUERIES}     # per query: match count and the wrap-around sum of the matching ids, from numpy while the rows are generated
-    with bmx.Engine(capacity_rows=R + 1024 + 2 * D_PER_STEP, device=dev.index or 0) as e:
+    with bmx.Engine(capacity_rows=R + 1024 + 3 * D_PER_STEP, device=dev.index or 0) as e:
         for r0 in range(0, R, 10_000_000):          # load in 10M-row pieces: bounded host memory
             m = min(10_000_000, R - r0)
             ids = synth.splitmix64_np(np.arange(r0 + 1, r0 + m + 1, dtype=np.uint64))
@@ -424,7 +424,12 @@ def scan_bench(bmx, dev, R, reps=20, wide=False):
 
         # the view UNDER WRITES (the reference moves a path between value buckets on every write, src/bullet-query.js:139-176): a 1M-delta merge on
         # the indexed field, then the first equals (refresh of the columns from the change log + sort of the change run + one streaming merge into the view), then more
-        cols = delta_batch(7, R)
+        # (one cycle first, untimed: the first patch of an index allocates the view's second set of columns and the sort scratch — once in the index's life)
+        cols = delta_batch(6, R)
+        torch.cuda.synchronize()
+        e.merge_batch_dev(D_PER_STEP, *cols, bmx.INSERT_REFERENCE, applied=None, n_applied=n_out)
+        e.scan_range_dev(fa, 42 << sh, 42 << sh, out_ids, R, n_out); e.sync()
+        cols = delta_batch(7, R + D_PER_STEP)
         torch.cuda.synchronize()
         s0 = e.index_ordered_stats(fa)
         e.merge_batch_dev(D_PER_STEP, *cols, bmx.INSERT_REFERENCE, applied=None, n_applied=n_out)
@@ -436,6 +441,7 @@ def scan_bench(bmx, dev, R, reps=20, wide=False):
         s1 = e.index_ordered_stats(fa)
         ov["view_kept_current_by"] = "patch" if s1["patches"] > s0["patches"] and s1["sorts"] == s0["sorts"] and e.index_ordered_info(fa)[1] else ("sort" if s1["sorts"] > s0["sorts"] else "column scan (view stale)")
         ov["patch_us"] = round(s1["last_patch_us"], 1); ov["patch_keys"] = s1["keys_patched"] - s0["keys_patched"]
+        ov["pending_keys_after"] = s1["pending_keys"]; ov["main_rewritten_in_this_patch"] = s1["rewrites"] - s0["rewrites"]
         e.sync(); e.timer_start()
         for _ in range(reps):
             e.scan_range_dev(fa, 42 << sh, 42 << sh, out_ids, R, n_out)
@@ -452,7 +458,7 @@ def scan_bench(bmx, dev, R, reps=20, wide=False):
         del out_pos, id_col
         # index maintenance WITHOUT a view: another 1M-delta merge on the indexed field (90 % updates of existing nodes, 10 % new nodes), then the first scan — which brings
         # the index up to date from the merge's change log instead of rebuilding it from the table (include/bmx.h "Maintenance")
-        cols = delta_batch(8, R + D_PER_STEP)
+        cols = delta_batch(8, R + 2 * D_PER_STEP)
         full0, inc0 = e.index_refresh_counts()
         torch.cuda.synchronize()                    # the batch columns were produced on torch's stream
         e.merge_batch_dev(D_PER_STEP, *cols, bmx.INSERT_REFERENCE, applied=None, n_applied=n_out)

@@ -9,7 +9,7 @@ import numpy as np, torch, bmx
 from bmx import synth
 R = int(sys.argv[1]) if len(sys.argv) > 1 else 100_000_000
 wide = len(sys.argv) > 2 and sys.argv[2] == "wide"
-ROUNDS = int(sys.argv[3]) if len(sys.argv) > 3 else 4
+ROUNDS = int(sys.argv[3]) if len(sys.argv) > 3 else 8
 D = 1_000_000
 sh = 33 if wide else 0
 dev = torch.device("cuda", 0)
@@ -46,5 +46,5 @@ with bmx.Engine(capacity_rows=R + 1024 + (ROUNDS + 1) * D, device=0) as e:
         for _ in range(10):
             e.scan_range_dev(fa, 42 << sh, 42 << sh, out_ids, out_ids.numel(), n_out)
         nxt = e.timer_stop() / 10 * 1e3
-        print("round %d: first equals after the merge %.0f us (patch %.0f us, %d keys, patches +%d, sorts +%d), then %.1f us per equals; %d matches" %
-              (rnd, first, s1["last_patch_us"], s1["keys_patched"] - s0["keys_patched"], s1["patches"] - s0["patches"], s1["sorts"] - s0["sorts"], nxt, int(n_out.item())), flush=True)
+        print("round %d: first equals after the merge %.0f us (patch %.0f us, %d keys, patches +%d, sorts +%d, main rewritten +%d, %d keys pending), then %.1f us per equals; %d matches" %
+              (rnd, first, s1["last_patch_us"], s1["keys_patched"] - s0["keys_patched"], s1["patches"] - s0["patches"], s1["sorts"] - s0["sorts"], s1["rewrites"] - s0["rewrites"], s1["pending_keys"], nxt, int(n_out.item())), flush=True)

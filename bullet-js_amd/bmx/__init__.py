@@ -120,7 +120,7 @@ def load_library():
     L.bmx_index_refresh_counts.argtypes = [vp, C.POINTER(u64), C.POINTER(u64)]; L.bmx_index_refresh_counts.restype = i32
     L.bmx_index_set_ordered.argtypes = [vp, u32, u32]; L.bmx_index_set_ordered.restype = i32
     L.bmx_index_ordered_info.argtypes = [vp, u32, C.POINTER(u32), C.POINTER(i32), C.POINTER(u64)]; L.bmx_index_ordered_info.restype = i32
-    L.bmx_index_ordered_stats.argtypes = [vp, u32, C.POINTER(u64), C.POINTER(u64), C.POINTER(u64), C.POINTER(C.c_double), C.POINTER(C.c_double)]; L.bmx_index_ordered_stats.restype = i32
+    L.bmx_index_ordered_stats.argtypes = [vp, u32, C.POINTER(u64), C.POINTER(u64), C.POINTER(u64), C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(u64), C.POINTER(u64)]; L.bmx_index_ordered_stats.restype = i32
     L.bmx_scan_range.argtypes = [vp, u32, i64, i64, vp, u64, vp, i32]; L.bmx_scan_range.restype = i32
     L.bmx_scan_equals.argtypes = [vp, u32, i64, vp, u64, vp, i32]; L.bmx_scan_equals.restype = i32
     L.bmx_scan_count.argtypes = [vp, u32, i64, i64, vp, i32]; L.bmx_scan_count.restype = i32
@@ -383,11 +383,11 @@ class Engine:
         return a.value, bool(v.value), n.value
 
     def index_ordered_stats(self, field):
-        """{sorts, patches, keys_patched, last_sort_us, last_patch_us} of the value-ordered view (bmx_index_ordered_stats)"""
-        a, b, c = C.c_uint64(), C.c_uint64(), C.c_uint64()
+        """{sorts, patches, keys_patched, last_sort_us, last_patch_us, rewrites (streaming merges into the view's main run), pending_keys} of the value-ordered view"""
+        a, b, c, f, g = C.c_uint64(), C.c_uint64(), C.c_uint64(), C.c_uint64(), C.c_uint64()
         d, e = C.c_double(), C.c_double()
-        self._chk(self.L.bmx_index_ordered_stats(self.h, int(field), C.byref(a), C.byref(b), C.byref(c), C.byref(d), C.byref(e)))
-        return {"sorts": a.value, "patches": b.value, "keys_patched": c.value, "last_sort_us": d.value, "last_patch_us": e.value}
+        self._chk(self.L.bmx_index_ordered_stats(self.h, int(field), C.byref(a), C.byref(b), C.byref(c), C.byref(d), C.byref(e), C.byref(f), C.byref(g)))
+        return {"sorts": a.value, "patches": b.value, "keys_patched": c.value, "last_sort_us": d.value, "last_patch_us": e.value, "rewrites": f.value, "pending_keys": g.value}
 
     def scan_range(self, field, lo, hi, cap=None):
         cap = self.index_size(field) if cap is None else cap

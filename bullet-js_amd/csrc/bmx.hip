@@ -41,9 +41,10 @@ struct DevScalars {  // one small device allocation; zeroed at create
   uint32_t wide;
   unsigned long long seq_diag[3];  // k_seq_wait expiry: {sequence word address, value waited for, value last seen}
   unsigned long long chg_n[2];     // entries in the index change log: batch k reads [k&1], its compaction writes [(k+1)&1]
-  unsigned long long ord_ab[2];    // value-ordered view: [first match, one past the last) of the query being answered
+  unsigned long long ord_ab[6];    // value-ordered view: [first match, one past the last) of the query being answered in the view's main run, its pending deleted keys, its pending inserted keys
   unsigned long long view_cl_n[8]; // keys in the change run of maintained index k (k_ix_update capture mode: view_kernels.h)
   uint32_t view_err, view_pad;     // a deleted key was not found in the view it is patched into
+  unsigned long long view_tmp[2];  // how a change run's deleted keys split: keys of main / pending inserted keys
   unsigned long long seqw[2];      // deferred compaction: [0] = number of the latest probe kernel that has started, [1] = of the latest compaction finished on the side stream
 };
 
@@ -73,9 +74,23 @@ struct Index {
   void* s_val2 = nullptr; uint32_t* s_pos2 = nullptr; uint64_t* s_ids2 = nullptr; uint64_t ord_cap2 = 0;
   uint32_t* cl_pos = nullptr; int64_t* cl_old = nullptr; uint64_t cl_cap = 0;      // the captured change run, one entry per log entry (holes: POS_NONE)
   uint32_t* cl2_pos = nullptr; int64_t* cl2_old = nullptr;                          // ... and without the holes
-  uint64_t ord_patches = 0, ord_patched_keys = 0; double last_patch_us = 0;
+  uint64_t ord_patches = 0, ord_patched_keys = 0, ord_merges = 0; double last_patch_us = 0;
+  // the view's PENDING patch: logical view = main - pd + pi (both sorted by (value, position); pi carries ids). A refresh merges its change run into these small
+  // runs; the streaming merge into main runs when they have grown past ord_n / 16 keys. Two sets: a merge writes the other one.
+  void* pd_v[2] = {nullptr, nullptr}; uint32_t* pd_p[2] = {nullptr, nullptr};
+  void* pi_v[2] = {nullptr, nullptr}; uint32_t* pi_p[2] = {nullptr, nullptr}; uint64_t* pi_ids[2] = {nullptr, nullptr};
+  uint64_t npd = 0, npi = 0, pend_cap = 0; int pcur = 0;
 };
+void free_pending(Index& ix) {
+  for (int i = 0; i < 2; i++) {
+    if (ix.pd_v[i]) (void)hipFree(ix.pd_v[i]); if (ix.pd_p[i]) (void)hipFree(ix.pd_p[i]);
+    if (ix.pi_v[i]) (void)hipFree(ix.pi_v[i]); if (ix.pi_p[i]) (void)hipFree(ix.pi_p[i]); if (ix.pi_ids[i]) (void)hipFree(ix.pi_ids[i]);
+    ix.pd_v[i] = nullptr; ix.pd_p[i] = nullptr; ix.pi_v[i] = nullptr; ix.pi_p[i] = nullptr; ix.pi_ids[i] = nullptr;
+  }
+  ix.npd = ix.npi = 0; ix.pend_cap = 0; ix.pcur = 0;
+}
 void free_ordered_view(Index& ix) {
+  free_pending(ix);
   if (ix.s_val) (void)hipFree(ix.s_val);
   if (ix.s_pos) (void)hipFree(ix.s_pos);
   if (ix.s_ids) (void)hipFree(ix.s_ids);
@@ -178,6 +193,7 @@ struct bmx_ctx {
   void* vk_v[2] = {nullptr, nullptr}; uint32_t* vk_p[2] = {nullptr, nullptr}; uint64_t vk_cap = 0;
   void* vk_sv = nullptr; uint32_t* vk_sp = nullptr; uint32_t* vk_d0 = nullptr; uint32_t* vk_y0 = nullptr; uint64_t vk_tiles_cap = 0;   // per tile of the view: its first key (the sample), deleted indices / inserted keys in front of it
   bool view_patching = true;          // BMX_VIEW_PATCH=0 in the environment: a change makes the view stale as in round 4 (A/B switch)
+  bool view_pending = true;           // BMX_VIEW_PENDING=0: every patch rewrites the view's main run at once (no pending patch; A/B switch)
   // bmx_merge_notify: words (possibly in other GPUs' memory) that every merge's last workgroup sets to the number of merges finished since
   SeqPtrs notify{}; uint32_t n_notify = 0; uint64_t notify_seq = 0;
   // bmx_merge_tail_wait: armed = the next default-path merge's resolve kernel polls these words before it ends; waited = a resolve kernel that did so has
@@ -949,36 +965,91 @@ int ensure_view_scratch(bmx_ctx* ctx, uint64_t keys, uint64_t tiles) {
   }
   return BMX_OK;
 }
-// Patch the view of `ix` with the change run k_ix_update captured (c changed rows: ix.cl_pos / ix.cl_old) and the rows appended at positions
-// [n0, n0 + added). 0 = the view equals a fresh sort of the columns again; 1 = it could not be patched (no memory, or a deleted key was not where it
-// should be): the caller leaves it stale and the next queries scan / re-sort as ever. Synchronous at its end (one word comes back).
+// Z = (X without the sorted keys D, all of which are keys of X) merged with the sorted keys Y — k_view_merge over the tiles of X, with its sample and tile offsets
+// in the context's scratch. X may be empty (then D is, and Z = Y). Enqueue only; a deleted key that is not in X raises ds->view_err.
+template <class T, bool HAS_IDS>
+void launch_run_merge(bmx_ctx* ctx, ViewRun<T> X, uint64_t nx, const T* dv, const uint32_t* dp, uint64_t nd, const T* yv, const uint32_t* yp, uint64_t ny, const uint64_t* ix_ids, ViewRun<T> Z) {
+  hipStream_t st = ctx->stream;
+  if (nx == 0) {
+    if (ny) {
+      (void)hipMemcpyAsync(Z.v, yv, ny * sizeof(T), hipMemcpyDeviceToDevice, st); (void)hipMemcpyAsync(Z.p, yp, ny * sizeof(uint32_t), hipMemcpyDeviceToDevice, st);
+      if (HAS_IDS) hipLaunchKernelGGL(k_view_gather_ids, dim3((uint32_t)std::min<uint64_t>((ny + 255) / 256, 4096)), dim3(256), 0, st, yp, (uint32_t)ny, ix_ids, Z.ids);
+    }
+    return;
+  }
+  const uint32_t ntiles = (uint32_t)((nx + VIEW_TILE - 1) / VIEW_TILE);
+  T* sv = static_cast<T*>(ctx->vk_sv);
+  hipLaunchKernelGGL((k_view_sample<T>), dim3((ntiles + 255) / 256), dim3(256), 0, st, (const T*)X.v, (const uint32_t*)X.p, ntiles, sv, ctx->vk_sp);
+  hipLaunchKernelGGL((k_view_tile_offsets<T>), dim3((ntiles + 1 + 255) / 256), dim3(256), 0, st, (const T*)sv, (const uint32_t*)ctx->vk_sp, ntiles, dv, dp, (uint32_t)nd, yv, yp, (uint32_t)ny, ctx->vk_d0, ctx->vk_y0);
+  hipLaunchKernelGGL((k_view_merge<T, HAS_IDS>), dim3(ntiles), dim3(256), 0, st, X, (uint32_t)nx, dv, dp, yv, yp, ix_ids, Z, (const uint32_t*)ctx->vk_d0, (const uint32_t*)ctx->vk_y0, &ctx->ds->view_err);
+}
+// the pending patch's buffers for at least `need` keys in each run (what is there is kept)
+template <class T>
+int ensure_pending(bmx_ctx* ctx, Index& ix, uint64_t need) {
+  if (need <= ix.pend_cap) return BMX_OK;
+  HIPCHK(hipStreamSynchronize(ctx->stream));
+  const uint64_t cap = need + need / 2 + (1u << 16);
+  void* nv[2][2] = {{nullptr, nullptr}, {nullptr, nullptr}}; uint32_t* np[2][2] = {{nullptr, nullptr}, {nullptr, nullptr}}; uint64_t* ni[2] = {nullptr, nullptr};
+  bool ok = true;
+  for (int i = 0; i < 2 && ok; i++)
+    ok = hipMalloc(&nv[0][i], cap * sizeof(T)) == hipSuccess && hipMalloc(reinterpret_cast<void**>(&np[0][i]), cap * 4) == hipSuccess && hipMalloc(&nv[1][i], cap * sizeof(T)) == hipSuccess &&
+         hipMalloc(reinterpret_cast<void**>(&np[1][i]), cap * 4) == hipSuccess && hipMalloc(reinterpret_cast<void**>(&ni[i]), cap * 8) == hipSuccess;
+  if (!ok) {
+    (void)hipGetLastError();
+    for (int i = 0; i < 2; i++) { for (int k = 0; k < 2; k++) { if (nv[k][i]) (void)hipFree(nv[k][i]); if (np[k][i]) (void)hipFree(np[k][i]); } if (ni[i]) (void)hipFree(ni[i]); }
+    return fail(ctx, BMX_ERR_NOMEM, "view patch: out of device memory");
+  }
+  const int c = ix.pcur;
+  if (ix.npd) { HIPCHK(hipMemcpy(nv[0][c], ix.pd_v[c], ix.npd * sizeof(T), hipMemcpyDeviceToDevice)); HIPCHK(hipMemcpy(np[0][c], ix.pd_p[c], ix.npd * 4, hipMemcpyDeviceToDevice)); }
+  if (ix.npi) { HIPCHK(hipMemcpy(nv[1][c], ix.pi_v[c], ix.npi * sizeof(T), hipMemcpyDeviceToDevice)); HIPCHK(hipMemcpy(np[1][c], ix.pi_p[c], ix.npi * 4, hipMemcpyDeviceToDevice));
+                HIPCHK(hipMemcpy(ni[c], ix.pi_ids[c], ix.npi * 8, hipMemcpyDeviceToDevice)); }
+  const uint64_t kd = ix.npd, ki = ix.npi;
+  free_pending(ix);
+  for (int i = 0; i < 2; i++) { ix.pd_v[i] = nv[0][i]; ix.pd_p[i] = np[0][i]; ix.pi_v[i] = nv[1][i]; ix.pi_p[i] = np[1][i]; ix.pi_ids[i] = ni[i]; }
+  ix.npd = kd; ix.npi = ki; ix.pend_cap = cap; ix.pcur = c;
+  return BMX_OK;
+}
+// the second set of the view's columns, for `nz` rows
+template <class T>
+bool ensure_view_spare(bmx_ctx* ctx, Index& ix, uint64_t nz) {
+  if (nz <= ix.ord_cap2 && ix.s_val2) return true;
+  if (ix.s_val2) { (void)hipStreamSynchronize(ctx->stream); (void)hipFree(ix.s_val2); (void)hipFree(ix.s_pos2); (void)hipFree(ix.s_ids2); }
+  ix.s_val2 = nullptr; ix.s_pos2 = nullptr; ix.s_ids2 = nullptr; ix.ord_cap2 = 0;
+  const uint64_t cap = std::max<uint64_t>(ix.ord_cap, nz + nz / 8 + 1024);
+  if (hipMalloc(&ix.s_val2, cap * sizeof(T)) != hipSuccess || hipMalloc(reinterpret_cast<void**>(&ix.s_pos2), cap * sizeof(uint32_t)) != hipSuccess ||
+      hipMalloc(reinterpret_cast<void**>(&ix.s_ids2), cap * sizeof(uint64_t)) != hipSuccess) {
+    (void)hipGetLastError();
+    if (ix.s_val2) (void)hipFree(ix.s_val2); if (ix.s_pos2) (void)hipFree(ix.s_pos2); if (ix.s_ids2) (void)hipFree(ix.s_ids2);
+    ix.s_val2 = nullptr; ix.s_pos2 = nullptr; ix.s_ids2 = nullptr;
+    return false;
+  }
+  ix.ord_cap2 = cap;
+  return true;
+}
+// Patch the view of `ix` with the change run k_ix_update captured (c changed rows: ix.cl2_pos / ix.cl2_old) and the rows appended at positions [n0, n0 + added).
+// 0 = the (logical) view equals a fresh sort of the columns again; 1 = it could not be patched (no memory, or a deleted key was not where it should be): the caller
+// leaves it stale and the next queries scan / re-sort as ever. Synchronous at its end (one or two words come back).
+//   1. the run's deleted keys (old value, position) and inserted keys (value, position) are sorted;
+//   2. they join the view's PENDING patch (pd, pi): a deleted key that is a pending inserted key cancels it, the others are deleted keys of main; the inserted keys are
+//      merged into pi. All on runs of a few million keys: L2 / Infinity-Cache traffic;
+//   3. once the pending patch holds more than ord_n / 16 keys (or at once, when the run alone does), main is rewritten: one streaming pass, main - pd + pi.
+// A 1M-delta merge into a 10^8-row index: steps 1-2 on every refresh, step 3 on every third or fourth.
 template <class T>
 int patch_view_t(bmx_ctx* ctx, Index& ix, uint64_t c, uint64_t n0, uint64_t added) {
   const auto t0 = std::chrono::steady_clock::now();
-  const uint64_t m = c + added, ktot = c + m, nx = ix.ord_n, nz = nx - c + m;
-  if (nz >= 0xFFFFFFFFull || ktot >= 0xFFFFFFFFull || c > nx) return 1;
+  const uint64_t m = c + added, ktot = c + m, nx = ix.ord_n;
+  if (nx + m >= 0xFFFFFFFFull || ktot >= 0xFFFFFFFFull) return 1;
   auto soft = [&](int) { g_err.clear(); ctx->err.clear(); (void)hipGetLastError(); return 1; };
-  const uint32_t ntiles = (uint32_t)((nx + VIEW_TILE - 1) / VIEW_TILE);
-  if (ensure_view_scratch(ctx, ktot, ntiles)) return soft(0);
-  if (nz > ix.ord_cap2 || !ix.s_val2) {
-    if (ix.s_val2) { (void)hipStreamSynchronize(ctx->stream); (void)hipFree(ix.s_val2); (void)hipFree(ix.s_pos2); (void)hipFree(ix.s_ids2); }
-    ix.s_val2 = nullptr; ix.s_pos2 = nullptr; ix.s_ids2 = nullptr; ix.ord_cap2 = 0;
-    const uint64_t cap = std::max<uint64_t>(ix.ord_cap, nz + nz / 8 + 1024);
-    if (hipMalloc(&ix.s_val2, cap * sizeof(T)) != hipSuccess || hipMalloc(reinterpret_cast<void**>(&ix.s_pos2), cap * sizeof(uint32_t)) != hipSuccess ||
-        hipMalloc(reinterpret_cast<void**>(&ix.s_ids2), cap * sizeof(uint64_t)) != hipSuccess) {
-      if (ix.s_val2) (void)hipFree(ix.s_val2); if (ix.s_pos2) (void)hipFree(ix.s_pos2); if (ix.s_ids2) (void)hipFree(ix.s_ids2);
-      ix.s_val2 = nullptr; ix.s_pos2 = nullptr; ix.s_ids2 = nullptr;
-      return soft(0);
-    }
-    ix.ord_cap2 = cap;
-  }
+  const uint64_t thr = std::max<uint64_t>(nx / 16, 1u << 16);
+  const uint32_t ntiles_main = (uint32_t)((nx + VIEW_TILE - 1) / VIEW_TILE);
+  if (ensure_view_scratch(ctx, ktot, std::max<uint64_t>(ntiles_main, (ix.npi + ix.npd + VIEW_TILE) / VIEW_TILE + 2))) return soft(0);
   hipStream_t st = ctx->stream;
   T* kv[2] = {static_cast<T*>(ctx->vk_v[0]), static_cast<T*>(ctx->vk_v[1])};
   uint32_t* kp[2] = {ctx->vk_p[0], ctx->vk_p[1]};
   const T* col = sizeof(T) == 4 ? reinterpret_cast<const T*>(ix.v32) : reinterpret_cast<const T*>(ix.v64);
   hipLaunchKernelGGL((k_view_keys<T>), dim3((uint32_t)std::min<uint64_t>((ktot + 255) / 256, 4096)), dim3(256), 0, st, (const uint32_t*)ix.cl2_pos, (const int64_t*)ix.cl2_old, (uint32_t)c, col,
                      (uint32_t)n0, (uint32_t)added, kv[0], kp[0]);
-  // sort the deleted keys [0, c) and the inserted keys [c, c + m): tiles in LDS, then rank-merge passes
+  // 1. sort the deleted keys [0, c) and the inserted keys [c, c + m): tiles in LDS, then merge-path passes
   ViewSegs S{}; S.base[0] = 0; S.len[0] = (uint32_t)c; S.base[1] = (uint32_t)c; S.len[1] = (uint32_t)m;
   const uint32_t t0b = (uint32_t)((c + VIEW_TILE - 1) / VIEW_TILE), t1b = (uint32_t)((m + VIEW_TILE - 1) / VIEW_TILE);
   S.blk0[0] = 0; S.blk0[1] = t0b; S.blk0[2] = t0b + t1b;
@@ -989,21 +1060,74 @@ int patch_view_t(bmx_ctx* ctx, Index& ix, uint64_t c, uint64_t n0, uint64_t adde
     hipLaunchKernelGGL((k_view_merge_pass<T>), dim3(P.blk0[2]), dim3(256), 0, st, (const T*)kv[cur], (const uint32_t*)kp[cur], kv[cur ^ 1], kp[cur ^ 1], P, (uint32_t)L);
     cur ^= 1;
   }
+  const T* Dv = kv[cur]; const uint32_t* Dp = kp[cur]; const T* Iv = kv[cur] + c; const uint32_t* Ip = kp[cur] + c;
   (void)hipMemsetAsync(&ctx->ds->view_err, 0, sizeof(uint32_t), st);
-  T* sv = static_cast<T*>(ctx->vk_sv);
-  hipLaunchKernelGGL((k_view_sample<T>), dim3((ntiles + 255) / 256), dim3(256), 0, st, static_cast<const T*>(ix.s_val), (const uint32_t*)ix.s_pos, ntiles, sv, ctx->vk_sp);
-  hipLaunchKernelGGL((k_view_tile_offsets<T>), dim3((ntiles + 1 + 255) / 256), dim3(256), 0, st, (const T*)sv, (const uint32_t*)ctx->vk_sp, ntiles, (const T*)kv[cur], (const uint32_t*)kp[cur], (uint32_t)c,
-                     (const T*)(kv[cur] + c), (const uint32_t*)(kp[cur] + c), (uint32_t)m, ctx->vk_d0, ctx->vk_y0);
-  ViewRun<T> X{static_cast<T*>(ix.s_val), ix.s_pos, ix.s_ids}, Z{static_cast<T*>(ix.s_val2), ix.s_pos2, ix.s_ids2};
-  hipLaunchKernelGGL((k_view_merge<T>), dim3(ntiles), dim3(256), 0, st, X, (uint32_t)nx, (const T*)kv[cur], (const uint32_t*)kp[cur], (const T*)(kv[cur] + c), (const uint32_t*)(kp[cur] + c),
-                     (const uint64_t*)ix.ids, Z, (const uint32_t*)ctx->vk_d0, (const uint32_t*)ctx->vk_y0, &ctx->ds->view_err);
-  uint32_t err = 0;
-  hipError_t e = hipGetLastError();
-  if (e == hipSuccess) e = hipMemcpyAsync(&err, &ctx->ds->view_err, sizeof(err), hipMemcpyDeviceToHost, st);
-  if (e == hipSuccess) e = hipStreamSynchronize(st);
-  if (e != hipSuccess || err) return soft(0);
-  std::swap(ix.s_val, ix.s_val2); std::swap(ix.s_pos, ix.s_pos2); std::swap(ix.s_ids, ix.s_ids2); std::swap(ix.ord_cap, ix.ord_cap2);
-  ix.ord_n = nz; ix.ord_patches++; ix.ord_patched_keys += ktot;
+  ViewRun<T> X{static_cast<T*>(ix.s_val), ix.s_pos, ix.s_ids};
+  auto finish = [&]() -> int {       // the error word comes back; 0 = everything enqueued above did what it should
+    uint32_t err = 0;
+    hipError_t e = hipGetLastError();
+    if (e == hipSuccess) e = hipMemcpyAsync(&err, &ctx->ds->view_err, sizeof(err), hipMemcpyDeviceToHost, st);
+    if (e == hipSuccess) e = hipStreamSynchronize(st);
+    return (e != hipSuccess || err) ? 1 : 0;
+  };
+  auto rewrite_main = [&](const T* dv, const uint32_t* dp, uint64_t nd, const T* yv, const uint32_t* yp, uint64_t ny) -> bool {   // step 3
+    const uint64_t nz = nx - nd + ny;
+    if (!ensure_view_spare<T>(ctx, ix, nz)) return false;
+    ViewRun<T> Z{static_cast<T*>(ix.s_val2), ix.s_pos2, ix.s_ids2};
+    launch_run_merge<T, true>(ctx, X, nx, dv, dp, nd, yv, yp, ny, (const uint64_t*)ix.ids, Z);
+    if (finish()) return false;
+    std::swap(ix.s_val, ix.s_val2); std::swap(ix.s_pos, ix.s_pos2); std::swap(ix.s_ids, ix.s_ids2); std::swap(ix.ord_cap, ix.ord_cap2);
+    ix.ord_n = nz; ix.ord_merges++;
+    return true;
+  };
+  const bool have = ix.npd + ix.npi > 0;
+  if (!ctx->view_pending || (!have && ktot > thr)) {
+    // the run alone is worth a rewrite of main (small indexes: always), or the pending patch is switched off (BMX_VIEW_PENDING=0)
+    if (have) return soft(0);
+    if (c > nx || !rewrite_main(Dv, Dp, c, Iv, Ip, m)) return soft(0);
+  } else {
+    if (ensure_pending<T>(ctx, ix, std::max<uint64_t>(ix.npd + c, ix.npi + m))) return soft(0);
+    const int pc = ix.pcur, pn = pc ^ 1;
+    T* pdv[2] = {static_cast<T*>(ix.pd_v[0]), static_cast<T*>(ix.pd_v[1])}; T* piv[2] = {static_cast<T*>(ix.pi_v[0]), static_cast<T*>(ix.pi_v[1])};
+    if (!have) {
+      (void)hipMemcpyAsync(pdv[pc], Dv, c * sizeof(T), hipMemcpyDeviceToDevice, st); (void)hipMemcpyAsync(ix.pd_p[pc], Dp, c * 4, hipMemcpyDeviceToDevice, st);
+      ViewRun<T> none{nullptr, nullptr, nullptr}, Zi{piv[pc], ix.pi_p[pc], ix.pi_ids[pc]};
+      launch_run_merge<T, true>(ctx, none, 0, nullptr, nullptr, 0, Iv, Ip, m, (const uint64_t*)ix.ids, Zi);
+      if (finish()) return soft(0);
+      ix.npd = c; ix.npi = m;
+    } else {
+      // 2. which deleted keys are pending inserted keys (they cancel), which are keys of main (they join pd)? two ordered selects over the sorted run
+      T* sel_v = kv[cur ^ 1]; uint32_t* sel_p = kp[cur ^ 1];              // the sort's other buffer: [0, c) keys of main, [c, 2c) pending inserted keys
+      unsigned long long hc[2] = {0, 0};
+      if (c) {
+        SelGeom g = sel_geom<1>(c);
+        for (uint32_t want = 0; want < 2; want++) {
+          PredInPending<T> PP{Dv, Dp, (const T*)piv[pc], (const uint32_t*)ix.pi_p[pc], (uint32_t)ix.npi, want};
+          EmitKeys<T> EK{Dv, Dp, sel_v + (want ? c : 0), sel_p + (want ? c : 0)};
+          FinishCount FC{&ctx->ds->view_tmp[want]};
+          hipLaunchKernelGGL((k_sel_count<PredInPending<T>>), dim3(g.blocks), dim3(SEL_THREADS), 0, st, PP, c, g.tiles_per_block, ctx->block_counts);
+          hipLaunchKernelGGL((k_sel_write<PredInPending<T>, EmitKeys<T>, FinishCount>), dim3(g.blocks), dim3(SEL_THREADS), 0, st, PP, EK, FC, c, g.tiles_per_block, ctx->block_counts);
+        }
+        if (hipMemcpyAsync(hc, ctx->ds->view_tmp, sizeof(hc), hipMemcpyDeviceToHost, st) != hipSuccess || hipStreamSynchronize(st) != hipSuccess) return soft(0);
+        if (hc[0] + hc[1] != c) return soft(0);
+      }
+      const uint64_t cX = hc[0], cI = hc[1];
+      // pi' = pi - (deleted keys that were pending inserts) + inserted keys;  pd' = pd + (deleted keys of main)
+      ViewRun<T> Xi{piv[pc], ix.pi_p[pc], ix.pi_ids[pc]}, Zi{piv[pn], ix.pi_p[pn], ix.pi_ids[pn]};
+      launch_run_merge<T, true>(ctx, Xi, ix.npi, (const T*)(sel_v + c), (const uint32_t*)(sel_p + c), cI, Iv, Ip, m, (const uint64_t*)ix.ids, Zi);
+      ViewRun<T> Xd{pdv[pc], ix.pd_p[pc], nullptr}, Zd{pdv[pn], ix.pd_p[pn], nullptr};
+      if (ix.npd == 0) { (void)hipMemcpyAsync(pdv[pn], sel_v, cX * sizeof(T), hipMemcpyDeviceToDevice, st); (void)hipMemcpyAsync(ix.pd_p[pn], sel_p, cX * 4, hipMemcpyDeviceToDevice, st); }
+      else launch_run_merge<T, false>(ctx, Xd, ix.npd, nullptr, nullptr, 0, (const T*)sel_v, (const uint32_t*)sel_p, cX, nullptr, Zd);
+      if (finish()) return soft(0);
+      ix.pcur = pn; ix.npd += cX; ix.npi = ix.npi - cI + m;
+    }
+    if (ix.npd + ix.npi > thr) {       // 3. the pending patch has grown: main is rewritten, the patch is empty again
+      const int q = ix.pcur;
+      if (ix.npd > nx || !rewrite_main(static_cast<const T*>(ix.pd_v[q]), ix.pd_p[q], ix.npd, static_cast<const T*>(ix.pi_v[q]), ix.pi_p[q], ix.npi)) { ix.npd = ix.npi = 0; return soft(0); }
+      ix.npd = ix.npi = 0;
+    }
+  }
+  ix.ord_patches++; ix.ord_patched_keys += ktot;
   ix.last_patch_us = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count();
   return 0;
 }
@@ -1175,6 +1299,7 @@ bool ensure_ordered_view(bmx_ctx* ctx, Index* ix) {
   if (ix->stale_content != ix->content) { ix->stale_content = ix->content; ix->stale_queries = 0; }   // the count starts with every change of the columns
   if (++ix->stale_queries < after) return false;
   const auto t_sort = std::chrono::steady_clock::now();
+  ix->npd = ix->npi = 0;                          // a fresh sort of the columns: whatever patch was pending is in them
   const uint64_t n = ix->n;
   const size_t vb = ix->fits32 ? sizeof(int32_t) : sizeof(int64_t);
   auto give_up = [&]() { (void)hipGetLastError(); free_ordered_view(*ix); ix->stale_queries = 0; return false; };
@@ -1224,27 +1349,45 @@ bool ensure_ordered_view(bmx_ctx* ctx, Index* ix) {
   return true;
 }
 // the query itself: two searches + one contiguous copy; lo/hi are already clamped like the scans' (tombstones sort in front of every legal value)
-template <bool POS, class OutT>
-void launch_ordered(bmx_ctx* ctx, const Index* ix, int64_t lo, int64_t hi, OutT* d_out, uint64_t d_cap, unsigned long long* d_n, const PredFilter* filter = nullptr) {
+template <bool POS, class OutT, class T>
+void launch_ordered_t(bmx_ctx* ctx, const Index* ix, T l, T h, OutT* d_out, uint64_t d_cap, unsigned long long* d_n, const PredFilter* filter) {
   unsigned long long* ab = ctx->ds->ord_ab;
-  if (filter && !d_n) d_n = &ctx->ds->n_out;       // (the filter appends through a counter even when nobody asked for the count)
-  if (ix->ord_fits32) {     // the view was sorted from the 4-byte column: bounds clamped into int32 like the scans' (an empty range stays empty)
-    int64_t l = std::max<int64_t>(lo, (int64_t)INT32_MIN + 1), h = std::min<int64_t>(hi, INT32_MAX);
-    if (lo > INT32_MAX || hi < INT32_MIN) { l = 1; h = 0; }
-    hipLaunchKernelGGL((k_ordered_bounds<int32_t>), dim3(1), dim3(128), 0, ctx->stream, static_cast<const int32_t*>(ix->s_val), ix->ord_n, (int32_t)l, (int32_t)h, ab, d_n, filter ? 1u : 0u);
-  } else hipLaunchKernelGGL((k_ordered_bounds<int64_t>), dim3(1), dim3(128), 0, ctx->stream, static_cast<const int64_t*>(ix->s_val), ix->ord_n, lo, hi, ab, d_n, filter ? 1u : 0u);
+  const T* sv = static_cast<const T*>(ix->s_val);
+  const bool pending = ix->npd + ix->npi > 0;           // the logical view = main - pd + pi (patch_view_t)
+  const int q = ix->pcur;
+  const T* dv = static_cast<const T*>(ix->pd_v[q]); const T* iv = static_cast<const T*>(ix->pi_v[q]);
+  if (pending) hipLaunchKernelGGL((k_ordered_bounds_p<T>), dim3(1), dim3(384), 0, ctx->stream, sv, ix->ord_n, dv, ix->npd, iv, ix->npi, l, h, ab, d_n, filter ? 1u : 0u);
+  else hipLaunchKernelGGL((k_ordered_bounds<T>), dim3(1), dim3(128), 0, ctx->stream, sv, ix->ord_n, l, h, ab, d_n, filter ? 1u : 0u);
   if (filter) {             // every candidate of the run is looked at whatever the caller can take: the count is the number of survivors
     if constexpr (!POS) {
-      const uint32_t fb = (uint32_t)std::min<uint64_t>((ix->ord_n + 2047) / 2048, 4096);
-      hipLaunchKernelGGL((k_ordered_filter<PredFilter>), dim3(fb), dim3(256), 0, ctx->stream, (const uint64_t*)ix->s_ids, (const unsigned long long*)ab, *filter, d_out, d_out ? d_cap : 0, d_n);
+      const uint32_t fb = (uint32_t)std::min<uint64_t>((ix->ord_n + ix->npi + 2047) / 2048, 4096);
+      if (pending) hipLaunchKernelGGL((k_ordered_filter_p<T, PredFilter>), dim3(fb), dim3(256), 0, ctx->stream, sv, (const uint32_t*)ix->s_pos, (const uint64_t*)ix->s_ids, dv, (const uint32_t*)ix->pd_p[q],
+                                      (const uint64_t*)ix->pi_ids[q], (const unsigned long long*)ab, *filter, d_out, d_out ? d_cap : 0, d_n);
+      else hipLaunchKernelGGL((k_ordered_filter<PredFilter>), dim3(fb), dim3(256), 0, ctx->stream, (const uint64_t*)ix->s_ids, (const unsigned long long*)ab, *filter, d_out, d_out ? d_cap : 0, d_n);
     }
     return;
   }
   if (!d_out || !d_cap) return;
   // the match count is the device's: a grid for the most the caller can take, whose workgroups beyond the matches leave at once
-  const uint32_t blocks = (uint32_t)std::min<uint64_t>((std::min<uint64_t>(d_cap, ix->ord_n) + 2047) / 2048, 8192);
-  if constexpr (POS) hipLaunchKernelGGL((k_ordered_copy<uint32_t>), dim3(blocks), dim3(256), 0, ctx->stream, (const uint32_t*)ix->s_pos, (const unsigned long long*)ab, d_out, d_cap);
-  else hipLaunchKernelGGL((k_ordered_copy<uint64_t>), dim3(blocks), dim3(256), 0, ctx->stream, (const uint64_t*)ix->s_ids, (const unsigned long long*)ab, d_out, d_cap);
+  const uint32_t blocks = (uint32_t)std::min<uint64_t>((std::min<uint64_t>(d_cap, ix->ord_n + ix->npi) + 2047) / 2048, 8192);
+  if (pending) {
+    if constexpr (POS) hipLaunchKernelGGL((k_ordered_copy_p<T, uint32_t>), dim3(blocks), dim3(256), 0, ctx->stream, sv, (const uint32_t*)ix->s_pos, (const uint32_t*)ix->s_pos, dv, (const uint32_t*)ix->pd_p[q],
+                                          (const uint32_t*)ix->pi_p[q], (const unsigned long long*)ab, d_out, d_cap);
+    else hipLaunchKernelGGL((k_ordered_copy_p<T, uint64_t>), dim3(blocks), dim3(256), 0, ctx->stream, sv, (const uint32_t*)ix->s_pos, (const uint64_t*)ix->s_ids, dv, (const uint32_t*)ix->pd_p[q],
+                            (const uint64_t*)ix->pi_ids[q], (const unsigned long long*)ab, d_out, d_cap);
+  } else {
+    if constexpr (POS) hipLaunchKernelGGL((k_ordered_copy<uint32_t>), dim3(blocks), dim3(256), 0, ctx->stream, (const uint32_t*)ix->s_pos, (const unsigned long long*)ab, d_out, d_cap);
+    else hipLaunchKernelGGL((k_ordered_copy<uint64_t>), dim3(blocks), dim3(256), 0, ctx->stream, (const uint64_t*)ix->s_ids, (const unsigned long long*)ab, d_out, d_cap);
+  }
+}
+template <bool POS, class OutT>
+void launch_ordered(bmx_ctx* ctx, const Index* ix, int64_t lo, int64_t hi, OutT* d_out, uint64_t d_cap, unsigned long long* d_n, const PredFilter* filter = nullptr) {
+  if (filter && !d_n) d_n = &ctx->ds->n_out;       // (the filter appends through a counter even when nobody asked for the count)
+  if (ix->ord_fits32) {     // the view was sorted from the 4-byte column: bounds clamped into int32 like the scans' (an empty range stays empty)
+    int64_t l = std::max<int64_t>(lo, (int64_t)INT32_MIN + 1), h = std::min<int64_t>(hi, INT32_MAX);
+    if (lo > INT32_MAX || hi < INT32_MIN) { l = 1; h = 0; }
+    launch_ordered_t<POS, OutT, int32_t>(ctx, ix, (int32_t)l, (int32_t)h, d_out, d_cap, d_n, filter);
+  } else launch_ordered_t<POS, OutT, int64_t>(ctx, ix, lo, hi, d_out, d_cap, d_n, filter);
 }
 
 template <bool POS, class Pred>
@@ -1492,6 +1635,7 @@ int bmx_create_ex(int device, uint64_t capacity_rows, uint32_t max_load_pct, uin
   ctx->fixed_capacity = (flags & BMX_CTX_FIXED_CAPACITY) != 0;
   ctx->defer_enabled = !launches_are_serialized();
   { const char* vp = std::getenv("BMX_VIEW_PATCH"); if (vp && vp[0] == '0' && !vp[1]) ctx->view_patching = false; }
+  { const char* vp = std::getenv("BMX_VIEW_PENDING"); if (vp && vp[0] == '0' && !vp[1]) ctx->view_pending = false; }
   { const char* kw = std::getenv("BMX_K1_WAVES"); if (kw && kw[0] >= '3' && kw[0] <= '8' && kw[0] != '7' && !kw[1]) ctx->k1_waves = kw[0] - '0'; }
   CR(hipMemsetAsync(ctx->ds, 0, sizeof(DevScalars), ctx->stream));
   hipLaunchKernelGGL(k_init_slots, dim3(2048), dim3(256), 0, ctx->stream, ctx->slots, nslots);
@@ -1834,7 +1978,7 @@ int bmx_index_ordered_info(bmx_ctx* ctx, uint32_t field, uint32_t* after_queries
   return BMX_OK;
 }
 
-int bmx_index_ordered_stats(bmx_ctx* ctx, uint32_t field, uint64_t* sorts, uint64_t* patches, uint64_t* keys_patched, double* last_sort_us, double* last_patch_us) {
+int bmx_index_ordered_stats(bmx_ctx* ctx, uint32_t field, uint64_t* sorts, uint64_t* patches, uint64_t* keys_patched, double* last_sort_us, double* last_patch_us, uint64_t* rewrites, uint64_t* pending_keys) {
   if (!ctx) return fail(nullptr, BMX_ERR_INVALID, "null context");
   Index* ix = find_index(ctx, field);
   if (!ix) return fail(ctx, BMX_ERR_INVALID, "bmx_index_ordered_stats: no index on this field");
@@ -1843,6 +1987,8 @@ int bmx_index_ordered_stats(bmx_ctx* ctx, uint32_t field, uint64_t* sorts, uint6
   if (keys_patched) *keys_patched = ix->ord_patched_keys;
   if (last_sort_us) *last_sort_us = ix->last_sort_us;
   if (last_patch_us) *last_patch_us = ix->last_patch_us;
+  if (rewrites) *rewrites = ix->ord_merges;
+  if (pending_keys) *pending_keys = ix->npd + ix->npi;
   return BMX_OK;
 }
 

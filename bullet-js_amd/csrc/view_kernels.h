@@ -266,7 +266,7 @@ __device__ __forceinline__ int64_t rdlane(int64_t v, uint32_t l) {
 // Earlier forms, same box class: one key per lane with two LDS window searches per key 931 us; lanes WALKING from the chunk's rank to their own (dependent LDS
 // reads, the wave waits for its slowest lane) 847 us + 270 us for the keys of Y placed by workgroups of their own at the end of the grid.
 // *err is set when the tile's deleted keys were not all found among its keys (the view and the index columns have drifted apart: the caller sorts from scratch).
-template <class T>
+template <class T, bool HAS_IDS = true>
 __global__ __launch_bounds__(256) void k_view_merge(ViewRun<T> X, uint32_t nx, const T* __restrict__ dv, const uint32_t* __restrict__ dp, const T* __restrict__ yv, const uint32_t* __restrict__ yp,
                                                     const uint64_t* __restrict__ ix_ids, ViewRun<T> Z, const uint32_t* __restrict__ d0s, const uint32_t* __restrict__ y0s, uint32_t* __restrict__ err) {
   typedef T tvec __attribute__((ext_vector_type(4)));
@@ -289,10 +289,10 @@ __global__ __launch_bounds__(256) void k_view_merge(ViewRun<T> X, uint32_t nx, c
     const uint32_t e = lo + it * 1024u + w * CH + lane * 4u;        // this lane's group [e, e + 4)
     if (e + 4u <= hi) {
       xv[it] = __builtin_nontemporal_load(reinterpret_cast<const tvec*>(X.v + e)); xp[it] = __builtin_nontemporal_load(reinterpret_cast<const uvec*>(X.p + e));
-      xa[it] = __builtin_nontemporal_load(reinterpret_cast<const lvec*>(X.ids + e)); xb[it] = __builtin_nontemporal_load(reinterpret_cast<const lvec*>(X.ids + e + 2));
+      if (HAS_IDS) { xa[it] = __builtin_nontemporal_load(reinterpret_cast<const lvec*>(X.ids + e)); xb[it] = __builtin_nontemporal_load(reinterpret_cast<const lvec*>(X.ids + e + 2)); }
     } else {
 #pragma unroll
-      for (uint32_t k = 0; k < 4; k++) { const bool ok = e + k < hi; xv[it][k] = ok ? X.v[e + k] : (T)0; xp[it][k] = ok ? X.p[e + k] : 0u; const unsigned long long id = ok ? X.ids[e + k] : 0ull; if (k < 2) xa[it][k] = id; else xb[it][k - 2] = id; }
+      for (uint32_t k = 0; k < 4; k++) { const bool ok = e + k < hi; xv[it][k] = ok ? X.v[e + k] : (T)0; xp[it][k] = ok ? X.p[e + k] : 0u; const unsigned long long id = (HAS_IDS && ok) ? X.ids[e + k] : 0ull; if (k < 2) xa[it][k] = id; else xb[it][k - 2] = id; }
     }
   }
   const uint32_t d0 = d0s[t], d1 = d0s[t + 1], y0 = y0s[t], y1 = y0s[t + 1];
@@ -302,8 +302,8 @@ __global__ __launch_bounds__(256) void k_view_merge(ViewRun<T> X, uint32_t nx, c
     for (uint32_t it = 0; it < IT; it++) {
       const uint32_t e = lo + it * 1024u + w * CH + lane * 4u;
       const uint64_t o = (uint64_t)e - d0 + y0;
-      if (e + 4u <= hi) { st_vec(Z.v + o, xv[it]); st_vec(Z.p + o, xp[it]); st_vec(Z.ids + o, xa[it]); st_vec(Z.ids + o + 2, xb[it]); }
-      else for (uint32_t k = 0; k < 4 && e + k < hi; k++) { Z.v[o + k] = xv[it][k]; Z.p[o + k] = xp[it][k]; Z.ids[o + k] = k < 2 ? xa[it][k] : xb[it][k - 2]; }
+      if (e + 4u <= hi) { st_vec(Z.v + o, xv[it]); st_vec(Z.p + o, xp[it]); if (HAS_IDS) { st_vec(Z.ids + o, xa[it]); st_vec(Z.ids + o + 2, xb[it]); } }
+      else for (uint32_t k = 0; k < 4 && e + k < hi; k++) { Z.v[o + k] = xv[it][k]; Z.p[o + k] = xp[it][k]; if (HAS_IDS) Z.ids[o + k] = k < 2 ? xa[it][k] : xb[it][k - 2]; }
     }
     return;
   }
@@ -333,46 +333,52 @@ __global__ __launch_bounds__(256) void k_view_merge(ViewRun<T> X, uint32_t nx, c
     const uint32_t ra = rB[c], rb = rB[c + 1], ya = yB[c], yb = yB[c + 1];
     const uint32_t nD = rb - ra, nY = yb - ya;                          // (wave-uniform) this chunk's deleted / inserted keys
     uint32_t r[4], y[4]; bool gone[4];
-#pragma unroll
-    for (uint32_t k = 0; k < 4; k++) { r[k] = ra; y[k] = ya; gone[k] = false; }
-    if (nD <= 64u && nY <= 64u) {
-      // the chunk's entries, one per lane, then broadcast one by one: every lane counts how many sort in front of each of its keys
+    // (1) the ranks of the group's FIRST key: the chunk's entries, 64 at a time one per lane, broadcast one by one (readlane: no memory, no divergence) and compared
+    // with ONE key per lane. (The first form compared every entry with all four keys: ~35 vector instructions per entry and wave, and a rewrite of main with a
+    // patch of 7.5 % of the rows took 1.5 ms against 0.75 at 3 %.)
+    const T k0v = xv[it][0]; const uint32_t k0p = xp[it][0];
+    uint32_t r0 = ra, y0r = ya;
+    for (uint32_t b0 = 0; b0 < nD; b0 += 64u) {
       T ev = (T)0; uint32_t ep = 0;
-      if (lane < nD) { ev = dwv[ra + lane]; ep = dwp[ra + lane]; }
-      for (uint32_t j = 0; j < nD; j++) {
-        const T jv = rdlane(ev, j); const uint32_t jp = rdlane(ep, j);
+      if (b0 + lane < nD) { ev = dwv[ra + b0 + lane]; ep = dwp[ra + b0 + lane]; }
+      const uint32_t cnt = nD - b0 < 64u ? nD - b0 : 64u;
+      for (uint32_t j = 0; j < cnt; j++) { const T jv = rdlane(ev, j); const uint32_t jp = rdlane(ep, j); r0 += vk_less<T>(jv, jp, k0v, k0p) ? 1u : 0u; }
+    }
+    for (uint32_t b0 = 0; b0 < nY; b0 += 64u) {
+      T ev = (T)0; uint32_t ep = 0;
+      if (b0 + lane < nY) { ev = ywv[ya + b0 + lane]; ep = ywp[ya + b0 + lane]; }
+      const uint32_t cnt = nY - b0 < 64u ? nY - b0 : 64u;
+      for (uint32_t j = 0; j < cnt; j++) { const T jv = rdlane(ev, j); const uint32_t jp = rdlane(ep, j); y0r += vk_less<T>(jv, jp, k0v, k0p) ? 1u : 0u; }
+    }
+    if (e >= hi) { r0 = rb; y0r = yb; }                                  // behind the tile's end: what the last real group sees behind itself
+    // (2) the next group's ranks = the ranks just behind this group: the entries in [r0, rn) / [y0r, ynx) are the ones that touch THIS group's keys
+    uint32_t rn = (uint32_t)__shfl_down((int)r0, 1), ynx = (uint32_t)__shfl_down((int)y0r, 1);
+    if (lane == 63u) { rn = rb; ynx = yb; }
 #pragma unroll
-        for (uint32_t k = 0; k < 4; k++) { const T kv = xv[it][k]; const uint32_t kp = xp[it][k]; r[k] += vk_less<T>(jv, jp, kv, kp) ? 1u : 0u; gone[k] = gone[k] || (jv == kv && jp == kp); }
-      }
-      if (lane < nY) { ev = ywv[ya + lane]; ep = ywp[ya + lane]; }
-      for (uint32_t j = 0; j < nY; j++) {
-        const T jv = rdlane(ev, j); const uint32_t jp = rdlane(ep, j);
-#pragma unroll
-        for (uint32_t k = 0; k < 4; k++) y[k] += vk_less<T>(jv, jp, xv[it][k], xp[it][k]) ? 1u : 0u;
-      }
-    } else {
-      // a chunk crowded with entries (a skewed patch): every key searches the chunk's stretch of the windows
+    for (uint32_t k = 0; k < 4; k++) { r[k] = r0; y[k] = y0r; gone[k] = false; }
+    if (rn != r0 || ynx != y0r) {                                         // (per lane; most groups skip this) a walk over the few entries inside the group
+      uint32_t rk = r0, yk = y0r;
 #pragma unroll
       for (uint32_t k = 0; k < 4; k++) {
         const T kv = xv[it][k]; const uint32_t kp = xp[it][k];
-        r[k] = (uint32_t)vk_bound<T>(dwv, dwp, ra, rb, kv, kp); gone[k] = r[k] < rb && dwv[r[k]] == kv && dwp[r[k]] == kp;
-        y[k] = (uint32_t)vk_bound<T>(ywv, ywp, ya, yb, kv, kp);
+        while (rk < rn && vk_less<T>(dwv[rk], dwp[rk], kv, kp)) rk++;
+        gone[k] = rk < rn && dwv[rk] == kv && dwp[rk] == kp;
+        while (yk < ynx && vk_less<T>(ywv[yk], ywp[yk], kv, kp)) yk++;
+        r[k] = rk; y[k] = yk;
       }
     }
 #pragma unroll
-    for (uint32_t k = 0; k < 4; k++) if (e + k >= hi) { r[k] = rb; y[k] = yb; gone[k] = false; }     // behind the tile's end: what the last real key sees behind itself
+    for (uint32_t k = 0; k < 4; k++) if (e + k >= hi) { r[k] = rb; y[k] = yb; gone[k] = false; }     // keys behind the tile's end inside a group that straddles it
     // the inserted keys BEHIND key k (in front of the next key of X): ranks [y[k], yn[k])
-    uint32_t ynx = (uint32_t)__shfl_down((int)y[0], 1);
-    if (lane == 63u) ynx = yb;
     const uint32_t yn[4] = {y[1], y[2], y[3], ynx};
     const uint64_t ob = (uint64_t)y0 - d0;                               // output index of key i = i + ob - r + y
     const bool clean = !gone[0] && !gone[1] && !gone[2] && !gone[3] && r[3] == r[0] && y[3] == y[0] && e + 4u <= hi;
     if (e < hi) {
-      if (clean) { const uint64_t o = e + ob - r[0] + y[0]; st_vec(Z.v + o, xv[it]); st_vec(Z.p + o, xp[it]); st_vec(Z.ids + o, xa[it]); st_vec(Z.ids + o + 2, xb[it]); }
+      if (clean) { const uint64_t o = e + ob - r[0] + y[0]; st_vec(Z.v + o, xv[it]); st_vec(Z.p + o, xp[it]); if (HAS_IDS) { st_vec(Z.ids + o, xa[it]); st_vec(Z.ids + o + 2, xb[it]); } }
       else {
 #pragma unroll
         for (uint32_t k = 0; k < 4; k++) {
-          if (e + k < hi && !gone[k]) { const uint64_t o = (uint64_t)(e + k) + ob - r[k] + y[k]; Z.v[o] = xv[it][k]; Z.p[o] = xp[it][k]; Z.ids[o] = k < 2 ? xa[it][k] : xb[it][k - 2]; }
+          if (e + k < hi && !gone[k]) { const uint64_t o = (uint64_t)(e + k) + ob - r[k] + y[k]; Z.v[o] = xv[it][k]; Z.p[o] = xp[it][k]; if (HAS_IDS) Z.ids[o] = k < 2 ? xa[it][k] : xb[it][k - 2]; }
           gone_cnt += gone[k] ? 1u : 0u;
         }
       }
@@ -382,12 +388,12 @@ __global__ __launch_bounds__(256) void k_view_merge(ViewRun<T> X, uint32_t nx, c
         for (uint32_t j = y[k]; j < yn[k]; j++) {                          // (rare: 1 % of the keys have one behind them)
           const uint64_t o = (uint64_t)(e + k + 1u) + ob - (r[k] + (gone[k] ? 1u : 0u)) + j;
           const uint32_t jp = ywp[j];
-          Z.v[o] = ywv[j]; Z.p[o] = jp; Z.ids[o] = ix_ids[jp];
+          Z.v[o] = ywv[j]; Z.p[o] = jp; if (HAS_IDS) Z.ids[o] = ix_ids[jp];
         }
       }
       if (e == lo) for (uint32_t j = 0; j < y[0]; j++) {                 // tile 0 only: inserted keys in front of the view's first key
         const uint32_t jp = ywp[j];
-        Z.v[j] = ywv[j]; Z.p[j] = jp; Z.ids[j] = ix_ids[jp];
+        Z.v[j] = ywv[j]; Z.p[j] = jp; if (HAS_IDS) Z.ids[j] = ix_ids[jp];
       }
     }
   }
@@ -396,6 +402,94 @@ __global__ __launch_bounds__(256) void k_view_merge(ViewRun<T> X, uint32_t nx, c
   if (lane == 0 && gone_cnt) atomicAdd(&n_gone, gone_cnt);
   __syncthreads();
   if (threadIdx.x == 0 && n_gone != nd) *err = 1u;
+}
+
+
+// ---- the view with a PENDING patch (DESIGN section 4 "kept current"): the logical view = main - PD + PI, PD = sorted keys of main that are gone, PI = sorted keys (+ ids)
+// that are new; the physical merge above runs when the patch has grown, not on every refresh. ----
+// ids of the inserted keys (the patch keeps them so that a query copies one run)
+__global__ __launch_bounds__(256) void k_view_gather_ids(const uint32_t* __restrict__ pos, uint32_t n, const uint64_t* __restrict__ ix_ids, uint64_t* __restrict__ out) {
+  for (uint32_t i = blockIdx.x * 256u + threadIdx.x; i < n; i += gridDim.x * 256u) out[i] = ix_ids[pos[i]];
+}
+// Is deleted key i (sorted run D) one of the pending inserted keys? The change run's deleted keys are keys of the LOGICAL view: each is either a live key of main or a
+// pending inserted key — the second kind cancels its insert, the first kind joins the pending deleted keys. PredInPending(want = 1 / 0) selects one kind (select.h).
+template <class T>
+struct PredInPending {
+  static constexpr int E = 1;
+  const T* dv; const uint32_t* dp; const T* iv; const uint32_t* ip; uint32_t ni; uint32_t want;
+  __device__ uint32_t mask(uint64_t first, uint64_t n) const {
+    if (first >= n) return 0u;
+    const T kv = dv[first]; const uint32_t kp = dp[first];
+    const uint32_t at = (uint32_t)vk_bound<T>(iv, ip, 0, ni, kv, kp);
+    const uint32_t in = (at < ni && iv[at] == kv && ip[at] == kp) ? 1u : 0u;
+    return in == want ? 1u : 0u;
+  }
+};
+template <class T>
+struct EmitKeys { const T* dv; const uint32_t* dp; T* ov; uint32_t* op; __device__ void operator()(uint64_t rank, uint64_t i) const { ov[rank] = dv[i]; op[rank] = dp[i]; } };
+
+// bounds of a value range in all three sorted runs: ab[0,1] main, ab[2,3] pending deleted, ab[4,5] pending inserted; *n_out = matches of the logical view. Six waves.
+template <class T>
+__global__ __launch_bounds__(384) void k_ordered_bounds_p(const T* __restrict__ v, uint64_t n, const T* __restrict__ dv, uint64_t nd, const T* __restrict__ iv, uint64_t ni, T lo, T hi,
+                                                          unsigned long long* __restrict__ ab, unsigned long long* __restrict__ n_out, uint32_t zero_count) {
+  __shared__ unsigned long long sh[6];
+  const uint32_t w = threadIdx.x >> 6;
+  uint64_t r = 0;
+  if (lo <= hi) {
+    const T* a = w < 2 ? v : (w < 4 ? dv : iv); const uint64_t m = w < 2 ? n : (w < 4 ? nd : ni);
+    r = (w & 1u) == 0 ? ordered_bound<T, false>(a, m, lo) : ordered_bound<T, true>(a, m, hi);
+  }
+  if ((threadIdx.x & 63u) == 0) sh[w] = r;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    for (int k = 0; k < 6; k += 2) { const unsigned long long x = sh[k], y = sh[k + 1] < sh[k] ? sh[k] : sh[k + 1]; ab[k] = x; ab[k + 1] = y; }
+    if (n_out) *n_out = zero_count ? 0ull : (ab[1] - ab[0]) - (ab[3] - ab[2]) + (ab[5] - ab[4]);
+  }
+}
+// The matches of the logical view: main's run [a, b) without the pending deleted keys (each key of the run looks itself up in ITS stretch [da, db) of PD: the deleted
+// keys of a value range are exactly the deleted keys of that range's run), in order, then the pending inserted keys' run. out[k] for k < cap.
+template <class T, class OutT>
+__global__ __launch_bounds__(256) void k_ordered_copy_p(const T* __restrict__ v, const uint32_t* __restrict__ p, const OutT* __restrict__ src, const T* __restrict__ dv, const uint32_t* __restrict__ dp,
+                                                        const OutT* __restrict__ isrc, const unsigned long long* __restrict__ ab, OutT* __restrict__ out, uint64_t cap) {
+  const uint64_t a = ab[0], m = ab[1] - a, da = ab[2], db = ab[3], ia = ab[4], mi = ab[5] - ia;
+  const uint64_t kept = m - (db - da);
+  for (uint64_t i = (uint64_t)blockIdx.x * 256u + threadIdx.x; i < m + mi; i += (uint64_t)gridDim.x * 256u) {
+    if (i < m) {
+      const T kv = v[a + i]; const uint32_t kp = p[a + i];
+      const uint64_t r = da == db ? da : vk_bound<T>(dv, dp, da, db, kv, kp);
+      if (r < db && dv[r] == kv && dp[r] == kp) continue;
+      const uint64_t o = i - (r - da);
+      if (o < cap) out[o] = src[a + i];
+    } else {
+      const uint64_t o = kept + (i - m);
+      if (o < cap) out[o] = isrc[ia + (i - m)];
+    }
+  }
+}
+// declarative filter over the logical view's run: candidates = main's run minus the pending deleted keys, plus the pending inserted keys' run (k_ordered_filter's form)
+template <class T, class PF>
+__global__ __launch_bounds__(256) void k_ordered_filter_p(const T* __restrict__ v, const uint32_t* __restrict__ p, const uint64_t* __restrict__ s_ids, const T* __restrict__ dv, const uint32_t* __restrict__ dp,
+                                                          const uint64_t* __restrict__ i_ids, const unsigned long long* __restrict__ ab, PF P, uint64_t* __restrict__ out, uint64_t cap,
+                                                          unsigned long long* __restrict__ n_out) {
+  const uint64_t a = ab[0], m = ab[1] - a, da = ab[2], db = ab[3], ia = ab[4], mi = ab[5] - ia;
+  const uint64_t tot = m + mi;
+  const uint64_t rounds = (tot + (uint64_t)gridDim.x * 256u - 1) / ((uint64_t)gridDim.x * 256u);
+  for (uint64_t rd = 0; rd < rounds; rd++) {          // (uniform trip count per wave: the ballot below wants every lane there)
+    const uint64_t i = (rd * gridDim.x + blockIdx.x) * 256u + threadIdx.x;
+    uint64_t id = 0; bool ok = false;
+    if (i < m) {
+      const T kv = v[a + i]; const uint32_t kp = p[a + i];
+      const uint64_t r = da == db ? da : vk_bound<T>(dv, dp, da, db, kv, kp);
+      if (!(r < db && dv[r] == kv && dp[r] == kp)) { id = s_ids[a + i]; ok = P.rest(id); }
+    } else if (i < tot) { id = i_ids[ia + (i - m)]; ok = P.rest(id); }
+    const unsigned long long bal = __ballot(ok);
+    if (bal) {
+      unsigned long long base = 0;
+      if ((threadIdx.x & 63u) == 0) base = atomicAdd(n_out, (unsigned long long)__popcll(bal));
+      base = __shfl(base, 0);
+      if (ok) { const uint64_t pos = base + (uint64_t)__popcll(bal & ((1ull << (threadIdx.x & 63u)) - 1ull)); if (out && pos < cap) out[pos] = id; }
+    }
+  }
 }
 
 }  // namespace bmx

@@ -394,6 +394,12 @@ napi_value IndexOrderedInfo(napi_env env, napi_callback_info info) {
   if (rc) return throw_bmx(env, h->ctx, rc);
   napi_value out; NAPI_OK(napi_create_object(env, &out));
   set_num(env, out, "afterQueries", after); set_num(env, out, "valid", valid); set_num(env, out, "sorts", (double)sorts);
+  // round 5 (ABI 4): what kept the view current — patches from the change log instead of sorts (bmx_index_ordered_stats)
+  uint64_t s2 = 0, patches = 0, keys = 0, rewrites = 0, pending = 0; double sort_us = 0, patch_us = 0;
+  if (bmx_index_ordered_stats(h->ctx, f, &s2, &patches, &keys, &sort_us, &patch_us, &rewrites, &pending) == BMX_OK) {
+    set_num(env, out, "patches", (double)patches); set_num(env, out, "keysPatched", (double)keys); set_num(env, out, "lastSortUs", sort_us); set_num(env, out, "lastPatchUs", patch_us);
+    set_num(env, out, "rewrites", (double)rewrites); set_num(env, out, "pendingKeys", (double)pending);
+  }
   return out;
 }
 napi_value IndexDrop(napi_env env, napi_callback_info info) {

@@ -323,7 +323,8 @@ int bmx_index_refresh_counts(bmx_ctx* ctx, uint64_t* full_builds, uint64_t* incr
                                                * never more than twice the cheapest schedule, whatever comes next): ~70 queries on 10^8 int32 rows, ~25 on 10^7 */
 int bmx_index_set_ordered(bmx_ctx* ctx, uint32_t field, uint32_t after_queries);
 int bmx_index_ordered_info(bmx_ctx* ctx, uint32_t field, uint32_t* after_queries, int* valid_now, uint64_t* sorts);
-int bmx_index_ordered_stats(bmx_ctx* ctx, uint32_t field, uint64_t* sorts, uint64_t* patches, uint64_t* keys_patched, double* last_sort_us, double* last_patch_us);
+int bmx_index_ordered_stats(bmx_ctx* ctx, uint32_t field, uint64_t* sorts, uint64_t* patches, uint64_t* keys_patched, double* last_sort_us, double* last_patch_us,
+                            uint64_t* rewrites, uint64_t* pending_keys);
 int bmx_scan_range(bmx_ctx* ctx, uint32_t field, int64_t lo, int64_t hi, uint64_t* out_ids, uint64_t cap,
                    uint64_t* n_out, int mem);
 int bmx_scan_equals(bmx_ctx* ctx, uint32_t field, int64_t value, uint64_t* out_ids, uint64_t cap, uint64_t* n_out,

@@ -154,7 +154,7 @@ def test_a_current_view_stays_current_under_interleaved_merges_and_queries(wide)
     tombstones on the indexed field interleaved with queries — every query is answered from the view (ids, positions, counts equal numpy over the
     model), NOTHING is ever sorted again, every refresh that changed something patched the view once. Rows changed twice between two queries, rows
     changed back to the value they had, duplicate keys inside a batch, revived tombstones, appended rows that sort in front of / behind everything."""
-    R = 600_000
+    R = 2_400_000                    # ord_n / 16 = 150k keys: a round's change run (~90k keys) first joins the view's PENDING patch, the next one makes main be rewritten
     sh = 34 if wide else 0
     rng = np.random.default_rng(21 + wide)
     ids = streams.splitmix64_np(np.arange(1, R + 1, dtype=np.uint64))
@@ -168,6 +168,7 @@ def test_a_current_view_stays_current_under_interleaved_merges_and_queries(wide)
         _q(e, F, ids, vals, 3 << sh, 9 << sh)
         assert e.index_ordered_info(F) == (1, True, 1)
         patches = 0
+        seen_pending = seen_rewrite = 0
         for rnd in range(8):
             n_now = len(ids)
             snap = vals.copy()
@@ -208,6 +209,7 @@ def test_a_current_view_stays_current_under_interleaved_merges_and_queries(wide)
             patches += 1
             st = e.index_ordered_stats(F)
             assert e.index_ordered_info(F) == (1, True, 1) and st["sorts"] == 1 and st["patches"] == patches, (rnd, st)
+            seen_pending += st["pending_keys"] > 0; seen_rewrite = st["rewrites"]
             top = int(vals.max())
             for lo, hi in [(0, 0), (0, 499 << sh), (-(1 << 50), 1 << 50), ((-5 - rnd) << sh, (-5 - rnd) << sh), (top, top), (250 << sh, 251 << sh), (7 << sh, 6 << sh)]:
                 _check(e, F, ids, vals, lo, hi, alive)
@@ -217,12 +219,47 @@ def test_a_current_view_stays_current_under_interleaved_merges_and_queries(wide)
             _merge(e, F, ids[k3], 1, (vals[k3] + (1 << sh)))
             _check(e, F, ids, vals, 100 << sh, 130 << sh, alive)
             assert e.index_ordered_stats(F)["patches"] == patches
-        # the view equals what a fresh sort of the same columns gives: drop it, sort again, compare a whole-range position listing
+        assert seen_pending >= 2 and seen_rewrite >= 2, (seen_pending, seen_rewrite)         # both states of the view were queried: a pending patch beside main, and main rewritten
+        # the view equals what a fresh sort of the same columns gives: drop it, sort again, compare a whole-range position listing (element for element when the
+        # patched view is one run; as a set while it answers from main + a pending patch: survivors of main first, then the inserted keys)
+        one_run = e.index_ordered_stats(F)["pending_keys"] == 0
         pos_patched = e.scan_range_pos(F, -(1 << 50), 1 << 50)
         e.index_set_ordered(F, 0); e.index_set_ordered(F, 1)
         pos_sorted = e.scan_range_pos(F, -(1 << 50), 1 << 50)
         assert e.index_ordered_stats(F)["sorts"] == 2 and e.index_ordered_info(F)[1]       # (a new view: sorted from the columns as they are now)
-        assert np.array_equal(pos_patched, pos_sorted)
+        assert np.array_equal(pos_patched, pos_sorted) if one_run else np.array_equal(np.sort(pos_patched), np.sort(pos_sorted))
+
+
+def test_every_patch_rewrites_main_when_the_pending_patch_is_switched_off(monkeypatch):
+    """BMX_VIEW_PENDING=0 (A/B switch, read at create): every refresh merges its change run into the view's main run at once; after every round the patched view
+    lists its positions in exactly the order a fresh sort gives (the streaming merge kernel, element for element)"""
+    monkeypatch.setenv("BMX_VIEW_PENDING", "0")
+    R = 1_500_000
+    rng = np.random.default_rng(77)
+    ids = streams.splitmix64_np(np.arange(1, R + 1, dtype=np.uint64))
+    vals = rng.integers(0, 2000, R).astype(np.int64)
+    with bmx.Engine(3 * R) as e:
+        monkeypatch.delenv("BMX_VIEW_PENDING")
+        e.load_rows(ids, np.full(R, FA, np.uint32), np.full(R, 5, np.int64), vals)
+        e.index_build(FA)
+        e.index_set_ordered(FA, 1)
+        assert e.scan_count(FA, 0, 10) == int((vals <= 10).sum())
+        for rnd in range(4):
+            k = rng.choice(len(ids), 20_000 * (rnd + 1), replace=False)
+            nv = rng.integers(0, 2000, len(k)).astype(np.int64)
+            new_ids = streams.splitmix64_np(np.arange(70_000_000 + rnd * 5000, 70_000_000 + rnd * 5000 + 3000, dtype=np.uint64))
+            new_vals = rng.integers(0, 2000, 3000).astype(np.int64)
+            _merge(e, FA, ids[k], 100 + rnd, nv); _merge(e, FA, new_ids, 5, new_vals)
+            vals[k] = nv; ids = np.concatenate([ids, new_ids]); vals = np.concatenate([vals, new_vals])
+            got = e.scan_range_pos(FA, -(1 << 40), 1 << 40).astype(np.int64)
+            st = e.index_ordered_stats(FA)
+            assert st["sorts"] == 1 and st["patches"] == rnd + 1 and st["rewrites"] == rnd + 1 and st["pending_keys"] == 0, st
+            # the whole view, in order: every row once, keys (value, position) strictly ascending — what a fresh sort of the columns gives, element for element
+            col = e.index_ids(FA)
+            order = np.argsort(ids); v_of = vals[order][np.searchsorted(ids[order], col[got])]
+            assert len(got) == len(ids) and np.array_equal(np.sort(col[got]), ids[order])
+            dv, dp = np.diff(v_of), np.diff(got)
+            assert np.all((dv > 0) | ((dv == 0) & (dp > 0))), rnd
 
 
 def test_patch_of_a_large_view_with_a_skewed_change_run():

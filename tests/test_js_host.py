@@ -28,7 +28,7 @@ def test_addon_builds_and_refuses_without_gpu():
     g.build()
     addon = os.path.join(ROOT, "bullet-js_amd", "bmx.node")
     assert os.path.exists(addon)
-    code = ("const b=require(%r); if (b.abiVersion()!==3) process.exit(2);"
+    code = ("const b=require(%r); if (b.abiVersion()!==4) process.exit(2);"
             "const need=['create','destroy','mergeBatch','mergeBatchAsync','reserve','loadRows','getRows','rowCount','dumpRows','indexBuild','indexDrop','indexSize','scanRange','scanCount','scanFilter','info'];"
             "for (const k of need) if (typeof b[k]!=='function') { console.log('missing',k); process.exit(3); } console.log('addon ok');" % addon)
     out = subprocess.run([NODE, "-e", code], capture_output=True, text=True, timeout=60)
