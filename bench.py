@@ -429,19 +429,39 @@ def scan_bench(bmx, dev, R, reps=20, wide=False):
         torch.cuda.synchronize()
         e.merge_batch_dev(D_PER_STEP, *cols, bmx.INSERT_REFERENCE, applied=None, n_applied=n_out)
         e.scan_range_dev(fa, 42 << sh, 42 << sh, out_ids, R, n_out); e.sync()
-        cols = delta_batch(7, R + D_PER_STEP)
-        torch.cuda.synchronize()
-        s0 = e.index_ordered_stats(fa)
-        e.merge_batch_dev(D_PER_STEP, *cols, bmx.INSERT_REFERENCE, applied=None, n_applied=n_out)
-        e.sync()
-        t0 = time.perf_counter()
-        e.scan_range_dev(fa, 42 << sh, 42 << sh, out_ids, R, n_out); e.sync()
-        ov["first_equals_after_a_1M_delta_merge_us"] = round((time.perf_counter() - t0) * 1e6, 1)
-        m_view = int(n_out.item()); sum_view = int(out_ids[:m_view].sum().item())
+        hb = bmx.HostBuffer((1 << 18) * 8); host_ids = hb.array(np.uint64, 1 << 18); host_ids[:] = 0      # the caller's answer buffer (page-locked: what a host that cares uses)
+        # FOUR timed cycles: the pending patch grows over them (empty -> ~6 % of the rows) and the last makes a rewrite of main due, so every state of the scheme is timed.
+        # Each is a HOST-mode equals, ids in host memory when it returns: what the JS host calls. The refresh, the patch and the answer are in front of the return; a rewrite
+        # of the view's main run that the patch made due is enqueued BEHIND the answer and not waited for (a device-mode call followed by bmx_sync would wait for it).
+        cycles = []
+        s_first = e.index_ordered_stats(fa)
+        for cyc in range(4):
+            cols = delta_batch(7 + cyc, R + (1 + cyc) * D_PER_STEP)
+            torch.cuda.synchronize()
+            s0 = e.index_ordered_stats(fa)
+            e.merge_batch_dev(D_PER_STEP, *cols, bmx.INSERT_REFERENCE, applied=None, n_applied=n_out)
+            e.sync()
+            t0 = time.perf_counter()
+            got_ids = e.scan_range(fa, 42 << sh, 42 << sh, out=host_ids)
+            first_us = (time.perf_counter() - t0) * 1e6
+            m_view = len(got_ids)
+            with np.errstate(over="ignore"):
+                sum_view = int(got_ids.view(np.int64).sum(dtype=np.int64))
+            t0 = time.perf_counter(); e.sync()
+            behind_us = (time.perf_counter() - t0) * 1e6       # (a rewrite of main running behind the answer, when this patch made one due)
+            s1 = e.index_ordered_stats(fa)
+            cycles.append({"first_equals_us": round(first_us, 1), "work_behind_the_answer_us": round(behind_us, 1), "patch_us": round(s1["last_patch_us"], 1),
+                           "patch_keys": s1["keys_patched"] - s0["keys_patched"], "pending_keys_after": s1["pending_keys"], "matches": m_view})
         s1 = e.index_ordered_stats(fa)
-        ov["view_kept_current_by"] = "patch" if s1["patches"] > s0["patches"] and s1["sorts"] == s0["sorts"] and e.index_ordered_info(fa)[1] else ("sort" if s1["sorts"] > s0["sorts"] else "column scan (view stale)")
-        ov["patch_us"] = round(s1["last_patch_us"], 1); ov["patch_keys"] = s1["keys_patched"] - s0["keys_patched"]
-        ov["pending_keys_after"] = s1["pending_keys"]; ov["main_rewritten_in_this_patch"] = s1["rewrites"] - s0["rewrites"]
+        ov["cycles"] = cycles
+        firsts = sorted(c["first_equals_us"] for c in cycles)
+        ov["first_equals_after_a_1M_delta_merge_us"] = firsts[-1]                     # the WORST of the four states (the figure the line carries)
+        ov["first_equals_after_a_1M_delta_merge_us_best"] = firsts[0]
+        ov["work_behind_that_answer_us"] = max(c["work_behind_the_answer_us"] for c in cycles)
+        ov["main_rewrites_in_the_cycles"] = s1["rewrites"] - s_first["rewrites"]
+        ov["view_kept_current_by"] = ("patch" if s1["patches"] - s_first["patches"] == 4 and s1["sorts"] == s_first["sorts"] and e.index_ordered_info(fa)[1]
+                                      else ("sort" if s1["sorts"] > s_first["sorts"] else "column scan (view stale)"))
+        ov["patch_us"] = cycles[-1]["patch_us"]; ov["patch_keys"] = cycles[-1]["patch_keys"]; ov["pending_keys_after"] = s1["pending_keys"]
         e.sync(); e.timer_start()
         for _ in range(reps):
             e.scan_range_dev(fa, 42 << sh, 42 << sh, out_ids, R, n_out)
@@ -458,7 +478,7 @@ def scan_bench(bmx, dev, R, reps=20, wide=False):
         del out_pos, id_col
         # index maintenance WITHOUT a view: another 1M-delta merge on the indexed field (90 % updates of existing nodes, 10 % new nodes), then the first scan — which brings
         # the index up to date from the merge's change log instead of rebuilding it from the table (include/bmx.h "Maintenance")
-        cols = delta_batch(8, R + 2 * D_PER_STEP)
+        cols = delta_batch(12, R + 5 * D_PER_STEP)
         full0, inc0 = e.index_refresh_counts()
         torch.cuda.synchronize()                    # the batch columns were produced on torch's stream
         e.merge_batch_dev(D_PER_STEP, *cols, bmx.INSERT_REFERENCE, applied=None, n_applied=n_out)
@@ -545,7 +565,7 @@ def compact_line(out, detail_path=None):
                 one["view_equals_us"] = (ov.get("equals_0.1pct") or {}).get("us")
                 one["view_range10_ids_us"] = (ov.get("range_10pct") or {}).get("us")
                 one["view_sort_ms"] = ov.get("sort_ms")
-                for k, short in (("first_equals_after_a_1M_delta_merge_us", "view_first_equals_after_merge_us"), ("next_equals_us", "view_next_equals_us"), ("view_kept_current_by", "view_kept_current_by")):
+                for k, short in (("first_equals_after_a_1M_delta_merge_us", "view_first_equals_after_merge_us_worst_of_4"), ("first_equals_after_a_1M_delta_merge_us_best", "view_first_equals_after_merge_us_best_of_4"), ("next_equals_us", "view_next_equals_us"), ("view_kept_current_by", "view_kept_current_by")):
                     if k in ov:
                         one[short] = ov[k]
             fs = e.get("first_scan_after_a_1M_delta_merge") or {}

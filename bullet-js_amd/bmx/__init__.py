@@ -389,7 +389,14 @@ class Engine:
         self._chk(self.L.bmx_index_ordered_stats(self.h, int(field), C.byref(a), C.byref(b), C.byref(c), C.byref(d), C.byref(e), C.byref(f), C.byref(g)))
         return {"sorts": a.value, "patches": b.value, "keys_patched": c.value, "last_sort_us": d.value, "last_patch_us": e.value, "rewrites": f.value, "pending_keys": g.value}
 
-    def scan_range(self, field, lo, hi, cap=None):
+    def scan_range(self, field, lo, hi, cap=None, out=None):
+        """ids of the rows whose value is in [lo, hi]. `out`: a caller's uint64 array the ids are written into (a view of it is returned, no copy) —
+        one taken from a HostBuffer comes back at the link's rate."""
+        if out is not None:
+            cap = len(out) if cap is None else min(cap, len(out))
+            m = C.c_uint64()
+            self._chk(self.L.bmx_scan_range(self.h, int(field), int(lo), int(hi), _ptr(out), cap, C.cast(C.byref(m), C.c_void_p), MEM_HOST))
+            return out[:min(m.value, cap)]
         cap = self.index_size(field) if cap is None else cap
         out = np.zeros(max(cap, 1), np.uint64)
         m = C.c_uint64()

@@ -79,7 +79,10 @@ struct Index {
   // runs; the streaming merge into main runs when they have grown past ord_n / 16 keys. Two sets: a merge writes the other one.
   void* pd_v[2] = {nullptr, nullptr}; uint32_t* pd_p[2] = {nullptr, nullptr};
   void* pi_v[2] = {nullptr, nullptr}; uint32_t* pi_p[2] = {nullptr, nullptr}; uint64_t* pi_ids[2] = {nullptr, nullptr};
-  uint64_t npd = 0, npi = 0, pend_cap = 0; int pcur = 0;
+  uint64_t npd = 0, npi = 0, pend_cap = 0; int pcur = 0 /* the current set of pd */, icur = 0 /* the current set of pi */;
+  // the rewrite of main (main - pd + pi -> the second set of columns) runs BEHIND the answer of the query that found it due: in flight until its event has completed
+  // and its error word has been looked at; until then (main, pd, pi) go on answering
+  bool rewrite_due = false, rewrite_inflight = false; uint64_t rewrite_nz = 0;
 };
 void free_pending(Index& ix) {
   for (int i = 0; i < 2; i++) {
@@ -87,7 +90,7 @@ void free_pending(Index& ix) {
     if (ix.pi_v[i]) (void)hipFree(ix.pi_v[i]); if (ix.pi_p[i]) (void)hipFree(ix.pi_p[i]); if (ix.pi_ids[i]) (void)hipFree(ix.pi_ids[i]);
     ix.pd_v[i] = nullptr; ix.pd_p[i] = nullptr; ix.pi_v[i] = nullptr; ix.pi_p[i] = nullptr; ix.pi_ids[i] = nullptr;
   }
-  ix.npd = ix.npi = 0; ix.pend_cap = 0; ix.pcur = 0;
+  ix.npd = ix.npi = 0; ix.pend_cap = 0; ix.pcur = 0; ix.icur = 0; ix.rewrite_due = false; ix.rewrite_inflight = false;
 }
 void free_ordered_view(Index& ix) {
   free_pending(ix);
@@ -193,6 +196,8 @@ struct bmx_ctx {
   void* vk_v[2] = {nullptr, nullptr}; uint32_t* vk_p[2] = {nullptr, nullptr}; uint64_t vk_cap = 0;
   void* vk_sv = nullptr; uint32_t* vk_sp = nullptr; uint32_t* vk_d0 = nullptr; uint32_t* vk_y0 = nullptr; uint64_t vk_tiles_cap = 0;   // per tile of the view: its first key (the sample), deleted indices / inserted keys in front of it
   bool view_patching = true;          // BMX_VIEW_PATCH=0 in the environment: a change makes the view stale as in round 4 (A/B switch)
+  volatile unsigned long long* hres = nullptr;                            // mapped page-locked result words (HRES_*): counts the host waits for arrive without a download
+  uint32_t* view_err_host = nullptr; hipEvent_t view_ev = nullptr;      // a background rewrite's error word (page-locked host memory) and completion event
   bool view_pending = true;           // BMX_VIEW_PENDING=0: every patch rewrites the view's main run at once (no pending patch; A/B switch)
   // bmx_merge_notify: words (possibly in other GPUs' memory) that every merge's last workgroup sets to the number of merges finished since
   SeqPtrs notify{}; uint32_t n_notify = 0; uint64_t notify_seq = 0;
@@ -800,6 +805,17 @@ constexpr uint64_t SMALL_HOST_N = 32768;
 constexpr int SMALL_PATH_UNAVAILABLE = 1;
 constexpr size_t SMALL_IN_BYTES = SMALL_HOST_N * 28, SMALL_OUT_APPLIED = 0, SMALL_OUT_FLAGS = SMALL_HOST_N * 4, SMALL_OUT_TAIL = SMALL_HOST_N * 5,
                  SMALL_OUT_BYTES = SMALL_OUT_TAIL + sizeof(SmallOut);
+// result words in mapped host memory: a kernel's last workgroup (or one copy) writes them, the host reads them after the synchronisation it needs anyway
+constexpr int HRES_TOTALS = 0 /* 2 per maintained index */, HRES_RUN = PART_MAX_SHARDS /* one per index */, HRES_ERR = HRES_RUN + PART_MAX_SHARDS / 2, HRES_SPLIT = HRES_ERR + 1 /* 2 */,
+              HRES_SCAN_N = HRES_SPLIT + 2, HRES_WORDS = HRES_SCAN_N + 1;
+bool ensure_hres(bmx_ctx* ctx) {
+  if (ctx->hres) return true;
+  void* p = nullptr;
+  if (hipHostMalloc(&p, HRES_WORDS * sizeof(unsigned long long), hipHostMallocMapped) != hipSuccess) { (void)hipGetLastError(); return false; }
+  std::memset(p, 0, HRES_WORDS * sizeof(unsigned long long));
+  ctx->hres = static_cast<volatile unsigned long long*>(p);
+  return true;
+}
 bool ensure_pinned(bmx_ctx* ctx) {   // the two mapped host buffers of the small-call paths (merge, point reads, scans); false = fall back to copies
   if (ctx->pin_in) return true;
   { const char* t = std::getenv("BMX_TEST_FAIL_PINNED"); if (t && t[0] == '1') return false; }   // test hook: as if the page-locked allocation had failed
@@ -988,7 +1004,7 @@ template <class T>
 int ensure_pending(bmx_ctx* ctx, Index& ix, uint64_t need) {
   if (need <= ix.pend_cap) return BMX_OK;
   HIPCHK(hipStreamSynchronize(ctx->stream));
-  const uint64_t cap = need + need / 2 + (1u << 16);
+  const uint64_t cap = need + need / 8 + (1u << 16);
   void* nv[2][2] = {{nullptr, nullptr}, {nullptr, nullptr}}; uint32_t* np[2][2] = {{nullptr, nullptr}, {nullptr, nullptr}}; uint64_t* ni[2] = {nullptr, nullptr};
   bool ok = true;
   for (int i = 0; i < 2 && ok; i++)
@@ -999,14 +1015,14 @@ int ensure_pending(bmx_ctx* ctx, Index& ix, uint64_t need) {
     for (int i = 0; i < 2; i++) { for (int k = 0; k < 2; k++) { if (nv[k][i]) (void)hipFree(nv[k][i]); if (np[k][i]) (void)hipFree(np[k][i]); } if (ni[i]) (void)hipFree(ni[i]); }
     return fail(ctx, BMX_ERR_NOMEM, "view patch: out of device memory");
   }
-  const int c = ix.pcur;
+  const int c = ix.pcur, ci = ix.icur;
   if (ix.npd) { HIPCHK(hipMemcpy(nv[0][c], ix.pd_v[c], ix.npd * sizeof(T), hipMemcpyDeviceToDevice)); HIPCHK(hipMemcpy(np[0][c], ix.pd_p[c], ix.npd * 4, hipMemcpyDeviceToDevice)); }
-  if (ix.npi) { HIPCHK(hipMemcpy(nv[1][c], ix.pi_v[c], ix.npi * sizeof(T), hipMemcpyDeviceToDevice)); HIPCHK(hipMemcpy(np[1][c], ix.pi_p[c], ix.npi * 4, hipMemcpyDeviceToDevice));
-                HIPCHK(hipMemcpy(ni[c], ix.pi_ids[c], ix.npi * 8, hipMemcpyDeviceToDevice)); }
-  const uint64_t kd = ix.npd, ki = ix.npi;
+  if (ix.npi) { HIPCHK(hipMemcpy(nv[1][ci], ix.pi_v[ci], ix.npi * sizeof(T), hipMemcpyDeviceToDevice)); HIPCHK(hipMemcpy(np[1][ci], ix.pi_p[ci], ix.npi * 4, hipMemcpyDeviceToDevice));
+                HIPCHK(hipMemcpy(ni[ci], ix.pi_ids[ci], ix.npi * 8, hipMemcpyDeviceToDevice)); }
+  const uint64_t kd = ix.npd, ki = ix.npi; const bool due = ix.rewrite_due;
   free_pending(ix);
   for (int i = 0; i < 2; i++) { ix.pd_v[i] = nv[0][i]; ix.pd_p[i] = np[0][i]; ix.pi_v[i] = nv[1][i]; ix.pi_p[i] = np[1][i]; ix.pi_ids[i] = ni[i]; }
-  ix.npd = kd; ix.npi = ki; ix.pend_cap = cap; ix.pcur = c;
+  ix.npd = kd; ix.npi = ki; ix.pend_cap = cap; ix.pcur = c; ix.icur = ci; ix.rewrite_due = due;
   return BMX_OK;
 }
 // the second set of the view's columns, for `nz` rows
@@ -1026,6 +1042,50 @@ bool ensure_view_spare(bmx_ctx* ctx, Index& ix, uint64_t nz) {
   ix.ord_cap2 = cap;
   return true;
 }
+// ---- the rewrite of a view's main run, behind the answer ----
+// finish_rewrite: a rewrite in flight whose event has completed (wait = true: wait for it) is looked at: error word 0 -> the second set of columns becomes main and the
+// pending patch is empty; otherwise main and the patch stay what they are (they were never touched).
+template <class T>
+void finish_rewrite(bmx_ctx* ctx, Index& ix, bool wait) {
+  if (!ix.rewrite_inflight) return;
+  if (wait) (void)hipEventSynchronize(ctx->view_ev);
+  else if (hipEventQuery(ctx->view_ev) != hipSuccess) { (void)hipGetLastError(); return; }
+  ix.rewrite_inflight = false;
+  if (*ctx->view_err_host == 0) {
+    std::swap(ix.s_val, ix.s_val2); std::swap(ix.s_pos, ix.s_pos2); std::swap(ix.s_ids, ix.s_ids2); std::swap(ix.ord_cap, ix.ord_cap2);
+    ix.ord_n = ix.rewrite_nz; ix.npd = ix.npi = 0; ix.ord_merges++;
+  }
+}
+// start_rewrite: enqueue main - pd + pi -> the second set of columns, then the copy of the error word and the event. Nothing waits.
+template <class T>
+void start_rewrite(bmx_ctx* ctx, Index& ix) {
+  ix.rewrite_due = false;
+  if (ix.rewrite_inflight || ix.npd + ix.npi == 0 || ix.npd > ix.ord_n) return;
+  if (!ctx->view_err_host && hipHostMalloc(reinterpret_cast<void**>(&ctx->view_err_host), sizeof(uint32_t), hipHostMallocDefault) != hipSuccess) { (void)hipGetLastError(); ctx->view_err_host = nullptr; return; }
+  if (!ctx->view_ev && hipEventCreateWithFlags(&ctx->view_ev, hipEventDisableTiming) != hipSuccess) { (void)hipGetLastError(); ctx->view_ev = nullptr; return; }
+  for (auto& o : ctx->indexes) if (o.rewrite_inflight) return;                 // one at a time: they share the error word and the event
+  const uint64_t nz = ix.ord_n - ix.npd + ix.npi;
+  const uint32_t ntiles = (uint32_t)((ix.ord_n + VIEW_TILE - 1) / VIEW_TILE);
+  if (ntiles + 1 > ctx->vk_tiles_cap || !ensure_view_spare<T>(ctx, ix, nz)) return;
+  const int q = ix.pcur, qi = ix.icur;
+  (void)hipMemsetAsync(&ctx->ds->view_err, 0, sizeof(uint32_t), ctx->stream);
+  ViewRun<T> X{static_cast<T*>(ix.s_val), ix.s_pos, ix.s_ids}, Z{static_cast<T*>(ix.s_val2), ix.s_pos2, ix.s_ids2};
+  launch_run_merge<T, true>(ctx, X, ix.ord_n, static_cast<const T*>(ix.pd_v[q]), ix.pd_p[q], ix.npd, static_cast<const T*>(ix.pi_v[qi]), ix.pi_p[qi], ix.npi, (const uint64_t*)ix.ids, Z);
+  *ctx->view_err_host = 1u;                                                       // (overwritten by the copy below: an event that somehow completed without it reads as a failure)
+  if (hipMemcpyAsync(ctx->view_err_host, &ctx->ds->view_err, sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream) != hipSuccess || hipEventRecord(ctx->view_ev, ctx->stream) != hipSuccess) {
+    (void)hipGetLastError(); (void)hipStreamSynchronize(ctx->stream); return;    // nothing was swapped: main and the patch go on answering
+  }
+  ix.rewrite_inflight = true; ix.rewrite_nz = nz;
+}
+void view_after_query(bmx_ctx* ctx, Index* ix) {         // behind the answer of an ordered query
+  if (!ix->rewrite_due) return;
+  if (ix->ord_fits32) start_rewrite<int32_t>(ctx, *ix); else start_rewrite<int64_t>(ctx, *ix);
+}
+void view_before_use(bmx_ctx* ctx, Index* ix, bool wait) {   // in front of anything that reads or changes the view
+  if (!ix->rewrite_inflight) return;
+  if (ix->ord_fits32) finish_rewrite<int32_t>(ctx, *ix, wait); else finish_rewrite<int64_t>(ctx, *ix, wait);
+}
+
 // Patch the view of `ix` with the change run k_ix_update captured (c changed rows: ix.cl2_pos / ix.cl2_old) and the rows appended at positions [n0, n0 + added).
 // 0 = the (logical) view equals a fresh sort of the columns again; 1 = it could not be patched (no memory, or a deleted key was not where it should be): the caller
 // leaves it stale and the next queries scan / re-sort as ever. Synchronous at its end (one or two words come back).
@@ -1037,12 +1097,13 @@ bool ensure_view_spare(bmx_ctx* ctx, Index& ix, uint64_t nz) {
 template <class T>
 int patch_view_t(bmx_ctx* ctx, Index& ix, uint64_t c, uint64_t n0, uint64_t added) {
   const auto t0 = std::chrono::steady_clock::now();
+  finish_rewrite<T>(ctx, ix, /*wait=*/true);            // a rewrite still in flight is looked at first: the change run's keys are keys of the view as it is NOW
   const uint64_t m = c + added, ktot = c + m, nx = ix.ord_n;
   if (nx + m >= 0xFFFFFFFFull || ktot >= 0xFFFFFFFFull) return 1;
   auto soft = [&](int) { g_err.clear(); ctx->err.clear(); (void)hipGetLastError(); return 1; };
   const uint64_t thr = std::max<uint64_t>(nx / 16, 1u << 16);
   const uint32_t ntiles_main = (uint32_t)((nx + VIEW_TILE - 1) / VIEW_TILE);
-  if (ensure_view_scratch(ctx, ktot, std::max<uint64_t>(ntiles_main, (ix.npi + ix.npd + VIEW_TILE) / VIEW_TILE + 2))) return soft(0);
+  if (!ensure_hres(ctx) || ensure_view_scratch(ctx, ktot, std::max<uint64_t>(ntiles_main, (ix.npi + ix.npd + VIEW_TILE) / VIEW_TILE + 2))) return soft(0);
   hipStream_t st = ctx->stream;
   T* kv[2] = {static_cast<T*>(ctx->vk_v[0]), static_cast<T*>(ctx->vk_v[1])};
   uint32_t* kp[2] = {ctx->vk_p[0], ctx->vk_p[1]};
@@ -1064,11 +1125,11 @@ int patch_view_t(bmx_ctx* ctx, Index& ix, uint64_t c, uint64_t n0, uint64_t adde
   (void)hipMemsetAsync(&ctx->ds->view_err, 0, sizeof(uint32_t), st);
   ViewRun<T> X{static_cast<T*>(ix.s_val), ix.s_pos, ix.s_ids};
   auto finish = [&]() -> int {       // the error word comes back; 0 = everything enqueued above did what it should
-    uint32_t err = 0;
     hipError_t e = hipGetLastError();
-    if (e == hipSuccess) e = hipMemcpyAsync(&err, &ctx->ds->view_err, sizeof(err), hipMemcpyDeviceToHost, st);
+    ctx->hres[HRES_ERR] = 1;
+    if (e == hipSuccess) e = hipMemcpyAsync(const_cast<unsigned long long*>(&ctx->hres[HRES_ERR]), &ctx->ds->view_err, sizeof(uint32_t), hipMemcpyDeviceToHost, st);
     if (e == hipSuccess) e = hipStreamSynchronize(st);
-    return (e != hipSuccess || err) ? 1 : 0;
+    return (e != hipSuccess || (uint32_t)ctx->hres[HRES_ERR]) ? 1 : 0;
   };
   auto rewrite_main = [&](const T* dv, const uint32_t* dp, uint64_t nd, const T* yv, const uint32_t* yp, uint64_t ny) -> bool {   // step 3
     const uint64_t nz = nx - nd + ny;
@@ -1086,46 +1147,66 @@ int patch_view_t(bmx_ctx* ctx, Index& ix, uint64_t c, uint64_t n0, uint64_t adde
     if (have) return soft(0);
     if (c > nx || !rewrite_main(Dv, Dp, c, Iv, Ip, m)) return soft(0);
   } else {
-    if (ensure_pending<T>(ctx, ix, std::max<uint64_t>(ix.npd + c, ix.npi + m))) return soft(0);
-    const int pc = ix.pcur, pn = pc ^ 1;
+    // room for the patch at its largest (a rewrite falls due beyond thr keys; the run that crosses the line is still taken in), allocated once: a growing
+    // buffer would put its reallocation in front of some query's answer
+    if (ensure_pending<T>(ctx, ix, std::max<uint64_t>(std::max<uint64_t>(ix.npd + c, ix.npi + m), thr + 2 * std::max<uint64_t>(c, m)))) return soft(0);
     T* pdv[2] = {static_cast<T*>(ix.pd_v[0]), static_cast<T*>(ix.pd_v[1])}; T* piv[2] = {static_cast<T*>(ix.pi_v[0]), static_cast<T*>(ix.pi_v[1])};
+    auto merge2 = [&](bool ids, ViewRun<T> A, uint64_t la, const T* bv, const uint32_t* bp, uint64_t lb, ViewRun<T> Z) {
+      if (la + lb == 0) return;
+      const uint32_t g = (uint32_t)((la + lb + VIEW_PASS_KEYS - 1) / VIEW_PASS_KEYS);
+      if (ids) hipLaunchKernelGGL((k_view_merge2<T, true>), dim3(g), dim3(256), 0, st, A, (uint32_t)la, bv, bp, (uint32_t)lb, (const uint64_t*)ix.ids, Z);
+      else hipLaunchKernelGGL((k_view_merge2<T, false>), dim3(g), dim3(256), 0, st, A, (uint32_t)la, bv, bp, (uint32_t)lb, (const uint64_t*)nullptr, Z);
+    };
     if (!have) {
-      (void)hipMemcpyAsync(pdv[pc], Dv, c * sizeof(T), hipMemcpyDeviceToDevice, st); (void)hipMemcpyAsync(ix.pd_p[pc], Dp, c * 4, hipMemcpyDeviceToDevice, st);
-      ViewRun<T> none{nullptr, nullptr, nullptr}, Zi{piv[pc], ix.pi_p[pc], ix.pi_ids[pc]};
-      launch_run_merge<T, true>(ctx, none, 0, nullptr, nullptr, 0, Iv, Ip, m, (const uint64_t*)ix.ids, Zi);
+      const int dc = ix.pcur, ic = ix.icur;
+      (void)hipMemcpyAsync(pdv[dc], Dv, c * sizeof(T), hipMemcpyDeviceToDevice, st); (void)hipMemcpyAsync(ix.pd_p[dc], Dp, c * 4, hipMemcpyDeviceToDevice, st);
+      ViewRun<T> none{nullptr, nullptr, nullptr}, Zi{piv[ic], ix.pi_p[ic], ix.pi_ids[ic]};
+      merge2(true, none, 0, Iv, Ip, m, Zi);                             // (the inserted keys with their ids)
       if (finish()) return soft(0);
       ix.npd = c; ix.npi = m;
     } else {
-      // 2. which deleted keys are pending inserted keys (they cancel), which are keys of main (they join pd)? two ordered selects over the sorted run
-      T* sel_v = kv[cur ^ 1]; uint32_t* sel_p = kp[cur ^ 1];              // the sort's other buffer: [0, c) keys of main, [c, 2c) pending inserted keys
+      // 2. which deleted keys are pending inserted keys (they cancel), which are keys of main (they join pd)? one flag per key, two ordered selects by flag
+      T* sel_v = kv[cur ^ 1]; uint32_t* sel_p = kp[cur ^ 1];              // the sort's other buffer: [0, c) keys of main, [c, 2c) pending inserted keys, behind them the flags
+      uint8_t* flag = reinterpret_cast<uint8_t*>(sel_v + 2 * c);
+      const int dc = ix.pcur, ic = ix.icur;
       unsigned long long hc[2] = {0, 0};
       if (c) {
+        ctx->hres[HRES_SPLIT] = ctx->hres[HRES_SPLIT + 1] = ~0ull;
+        hipLaunchKernelGGL((k_view_flag_in<T>), dim3((uint32_t)((c + 255) / 256)), dim3(256), 0, st, Dv, Dp, (uint32_t)c, (const T*)piv[ic], (const uint32_t*)ix.pi_p[ic], (uint32_t)ix.npi, flag);
         SelGeom g = sel_geom<1>(c);
         for (uint32_t want = 0; want < 2; want++) {
-          PredInPending<T> PP{Dv, Dp, (const T*)piv[pc], (const uint32_t*)ix.pi_p[pc], (uint32_t)ix.npi, want};
+          PredFlag PF{flag, want};
           EmitKeys<T> EK{Dv, Dp, sel_v + (want ? c : 0), sel_p + (want ? c : 0)};
-          FinishCount FC{&ctx->ds->view_tmp[want]};
-          hipLaunchKernelGGL((k_sel_count<PredInPending<T>>), dim3(g.blocks), dim3(SEL_THREADS), 0, st, PP, c, g.tiles_per_block, ctx->block_counts);
-          hipLaunchKernelGGL((k_sel_write<PredInPending<T>, EmitKeys<T>, FinishCount>), dim3(g.blocks), dim3(SEL_THREADS), 0, st, PP, EK, FC, c, g.tiles_per_block, ctx->block_counts);
+          FinishCount FC{const_cast<unsigned long long*>(&ctx->hres[HRES_SPLIT + want])};
+          hipLaunchKernelGGL((k_sel_count<PredFlag>), dim3(g.blocks), dim3(SEL_THREADS), 0, st, PF, c, g.tiles_per_block, ctx->block_counts);
+          hipLaunchKernelGGL((k_sel_write<PredFlag, EmitKeys<T>, FinishCount>), dim3(g.blocks), dim3(SEL_THREADS), 0, st, PF, EK, FC, c, g.tiles_per_block, ctx->block_counts);
         }
-        if (hipMemcpyAsync(hc, ctx->ds->view_tmp, sizeof(hc), hipMemcpyDeviceToHost, st) != hipSuccess || hipStreamSynchronize(st) != hipSuccess) return soft(0);
-        if (hc[0] + hc[1] != c) return soft(0);
+        if (hipStreamSynchronize(st) != hipSuccess) return soft(0);
+        hc[0] = ctx->hres[HRES_SPLIT]; hc[1] = ctx->hres[HRES_SPLIT + 1];
+        if (hc[0] + hc[1] != c || hc[1] > ix.npi) return soft(0);
       }
       const uint64_t cX = hc[0], cI = hc[1];
-      // pi' = pi - (deleted keys that were pending inserts) + inserted keys;  pd' = pd + (deleted keys of main)
-      ViewRun<T> Xi{piv[pc], ix.pi_p[pc], ix.pi_ids[pc]}, Zi{piv[pn], ix.pi_p[pn], ix.pi_ids[pn]};
-      launch_run_merge<T, true>(ctx, Xi, ix.npi, (const T*)(sel_v + c), (const uint32_t*)(sel_p + c), cI, Iv, Ip, m, (const uint64_t*)ix.ids, Zi);
-      ViewRun<T> Xd{pdv[pc], ix.pd_p[pc], nullptr}, Zd{pdv[pn], ix.pd_p[pn], nullptr};
-      if (ix.npd == 0) { (void)hipMemcpyAsync(pdv[pn], sel_v, cX * sizeof(T), hipMemcpyDeviceToDevice, st); (void)hipMemcpyAsync(ix.pd_p[pn], sel_p, cX * 4, hipMemcpyDeviceToDevice, st); }
-      else launch_run_merge<T, false>(ctx, Xd, ix.npd, nullptr, nullptr, 0, (const T*)sel_v, (const uint32_t*)sel_p, cX, nullptr, Zd);
+      // pi' = pi - (deleted keys that were pending inserts) + inserted keys;  pd' = pd + (deleted keys of main): balanced two-run merges (k_view_merge2)
+      int ia = ic; uint64_t na = ix.npi;
+      if (cI) {                                                           // the cancelled inserts leave pi: an ordered select into the other set
+        PredNotIn<T> PN{(const T*)piv[ic], (const uint32_t*)ix.pi_p[ic], (const T*)(sel_v + c), (const uint32_t*)(sel_p + c), (uint32_t)cI};
+        EmitRun<T> ER{(const T*)piv[ic], (const uint32_t*)ix.pi_p[ic], (const uint64_t*)ix.pi_ids[ic], piv[ic ^ 1], ix.pi_p[ic ^ 1], ix.pi_ids[ic ^ 1]};
+        FinishCount FC{&ctx->ds->view_tmp[0]};
+        SelGeom g = sel_geom<1>(ix.npi);
+        hipLaunchKernelGGL((k_sel_count<PredNotIn<T>>), dim3(g.blocks), dim3(SEL_THREADS), 0, st, PN, ix.npi, g.tiles_per_block, ctx->block_counts);
+        hipLaunchKernelGGL((k_sel_write<PredNotIn<T>, EmitRun<T>, FinishCount>), dim3(g.blocks), dim3(SEL_THREADS), 0, st, PN, ER, FC, ix.npi, g.tiles_per_block, ctx->block_counts);
+        ia = ic ^ 1; na = ix.npi - cI;
+      }
+      ViewRun<T> Ai{piv[ia], ix.pi_p[ia], ix.pi_ids[ia]}, Zi{piv[ia ^ 1], ix.pi_p[ia ^ 1], ix.pi_ids[ia ^ 1]};
+      if (m) merge2(true, Ai, na, Iv, Ip, m, Zi);
+      ViewRun<T> Ad{pdv[dc], ix.pd_p[dc], nullptr}, Zd{pdv[dc ^ 1], ix.pd_p[dc ^ 1], nullptr};
+      if (cX) merge2(false, Ad, ix.npd, (const T*)sel_v, (const uint32_t*)sel_p, cX, Zd);
       if (finish()) return soft(0);
-      ix.pcur = pn; ix.npd += cX; ix.npi = ix.npi - cI + m;
+      ix.icur = m ? ia ^ 1 : ia; if (cX) ix.pcur = dc ^ 1;
+      ix.npd += cX; ix.npi = na + m;
     }
-    if (ix.npd + ix.npi > thr) {       // 3. the pending patch has grown: main is rewritten, the patch is empty again
-      const int q = ix.pcur;
-      if (ix.npd > nx || !rewrite_main(static_cast<const T*>(ix.pd_v[q]), ix.pd_p[q], ix.npd, static_cast<const T*>(ix.pi_v[q]), ix.pi_p[q], ix.npi)) { ix.npd = ix.npi = 0; return soft(0); }
-      ix.npd = ix.npi = 0;
-    }
+    // 3. the pending patch has grown: main will be rewritten BEHIND the answer of the query that brought this refresh about (view_after_query), not in front of it
+    if (ix.npd + ix.npi > thr) ix.rewrite_due = true;
   }
   ix.ord_patches++; ix.ord_patched_keys += ktot;
   ix.last_patch_us = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count();
@@ -1144,7 +1225,8 @@ int refresh_from_log(bmx_ctx* ctx) {
   // results of index k live in its own scratch words: part_totals[] is free between partitions (k < PART_MAX_SHARDS indexes are maintained)
   if (ctx->indexes.size() > IX_MAINTAINED_MAX) return fail(ctx, BMX_ERR_INTERNAL, "index maintenance with more indexes than result words");
   if (ub) {
-    HIPCHK(hipMemsetAsync(ctx->ds->view_cl_n, 0, sizeof(ctx->ds->view_cl_n), ctx->stream));
+    if (!ensure_hres(ctx)) return fail(ctx, BMX_ERR_NOMEM, "index maintenance: no page-locked memory for the result words");
+    for (size_t k = 0; k < ctx->indexes.size(); k++) ctx->hres[HRES_RUN + k] = ~0ull;
     for (size_t k = 0; k < ctx->indexes.size(); k++) {
       Index& ix = ctx->indexes[k];
       // the view is current and can stay so: capture the change run (needs room for one entry per log entry)
@@ -1185,17 +1267,20 @@ int refresh_from_log(bmx_ctx* ctx) {
         SelGeom gc = sel_geom<PredChanged::E>(ub);
         hipLaunchKernelGGL((k_sel_count<PredChanged>), dim3(gc.blocks), dim3(SEL_THREADS), 0, ctx->stream, PC, ub, gc.tiles_per_block, ctx->block_counts);
         EmitChanged EC{ix.cl_pos, ix.cl_old, ix.cl2_pos, ix.cl2_old};
-        FinishCount FC{&ctx->ds->view_cl_n[k]};
+        FinishCount FC{const_cast<unsigned long long*>(&ctx->hres[HRES_RUN + k])};
         hipLaunchKernelGGL((k_sel_write<PredChanged, EmitChanged, FinishCount>), dim3(gc.blocks), dim3(SEL_THREADS), 0, ctx->stream, PC, EC, FC, ub, gc.tiles_per_block, ctx->block_counts);
         LAUNCHCHK("k_sel_write(change run)");
       }
     }
-    for (size_t k = 0; k < ctx->indexes.size(); k++) {
-      HIPCHK(hipMemcpyAsync(&res[k].added, &ctx->ds->part_totals[2 * k], sizeof(unsigned long long), hipMemcpyDeviceToHost, ctx->stream));
-      HIPCHK(hipMemcpyAsync(&res[k].wide, &ctx->ds->part_totals[2 * k + 1], 2 * sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
-      if (capture[k]) HIPCHK(hipMemcpyAsync(&res[k].run, &ctx->ds->view_cl_n[k], sizeof(unsigned long long), hipMemcpyDeviceToHost, ctx->stream));
-    }
+    // one copy of the indexes' (added, wide | changed) words into the mapped result words; the change runs' lengths were written there by their selects
+    HIPCHK(hipMemcpyAsync(const_cast<unsigned long long*>(&ctx->hres[HRES_TOTALS]), ctx->ds->part_totals, 2 * ctx->indexes.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost, ctx->stream));
     HIPCHK(hipStreamSynchronize(ctx->stream));
+    for (size_t k = 0; k < ctx->indexes.size(); k++) {
+      res[k].added = ctx->hres[HRES_TOTALS + 2 * k];
+      const unsigned long long wc = ctx->hres[HRES_TOTALS + 2 * k + 1];
+      res[k].wide = (uint32_t)wc; res[k].changed = (uint32_t)(wc >> 32);
+      res[k].run = capture[k] ? ctx->hres[HRES_RUN + k] : 0;
+    }
   }
   int rc = reset_chg_log(ctx);
   if (rc) return rc;
@@ -1287,7 +1372,8 @@ constexpr uint32_t SCAN_NTX_DEFAULT = 0;      // EmitIds::ntx (profiles/r05_scan
 // (no memory: the index goes on without it). Synchronous where it sorts.
 bool ensure_ordered_view(bmx_ctx* ctx, Index* ix) {
   if (!ix->ordered_after || ix->n == 0 || ix->n > 0xFFFFFFFFull) return false;
-  if (ix->ord_content == ix->content && ix->s_val) return true;
+  if (ix->ord_content == ix->content && ix->s_val) { view_before_use(ctx, ix, /*wait=*/false); return true; }   // (a finished rewrite becomes main; an unfinished one changes nothing)
+  view_before_use(ctx, ix, /*wait=*/true);
   uint32_t after = ix->ordered_after;
   if (after == BMX_INDEX_ORDERED_AUTO) {
     // rent or buy: sort once the scans answered since the change have cost what a sort costs — then whatever the caller does next, at most twice
@@ -1354,15 +1440,15 @@ void launch_ordered_t(bmx_ctx* ctx, const Index* ix, T l, T h, OutT* d_out, uint
   unsigned long long* ab = ctx->ds->ord_ab;
   const T* sv = static_cast<const T*>(ix->s_val);
   const bool pending = ix->npd + ix->npi > 0;           // the logical view = main - pd + pi (patch_view_t)
-  const int q = ix->pcur;
-  const T* dv = static_cast<const T*>(ix->pd_v[q]); const T* iv = static_cast<const T*>(ix->pi_v[q]);
+  const int q = ix->pcur, qi = ix->icur;
+  const T* dv = static_cast<const T*>(ix->pd_v[q]); const T* iv = static_cast<const T*>(ix->pi_v[qi]);
   if (pending) hipLaunchKernelGGL((k_ordered_bounds_p<T>), dim3(1), dim3(384), 0, ctx->stream, sv, ix->ord_n, dv, ix->npd, iv, ix->npi, l, h, ab, d_n, filter ? 1u : 0u);
   else hipLaunchKernelGGL((k_ordered_bounds<T>), dim3(1), dim3(128), 0, ctx->stream, sv, ix->ord_n, l, h, ab, d_n, filter ? 1u : 0u);
   if (filter) {             // every candidate of the run is looked at whatever the caller can take: the count is the number of survivors
     if constexpr (!POS) {
       const uint32_t fb = (uint32_t)std::min<uint64_t>((ix->ord_n + ix->npi + 2047) / 2048, 4096);
       if (pending) hipLaunchKernelGGL((k_ordered_filter_p<T, PredFilter>), dim3(fb), dim3(256), 0, ctx->stream, sv, (const uint32_t*)ix->s_pos, (const uint64_t*)ix->s_ids, dv, (const uint32_t*)ix->pd_p[q],
-                                      (const uint64_t*)ix->pi_ids[q], (const unsigned long long*)ab, *filter, d_out, d_out ? d_cap : 0, d_n);
+                                      (const uint64_t*)ix->pi_ids[qi], (const unsigned long long*)ab, *filter, d_out, d_out ? d_cap : 0, d_n);
       else hipLaunchKernelGGL((k_ordered_filter<PredFilter>), dim3(fb), dim3(256), 0, ctx->stream, (const uint64_t*)ix->s_ids, (const unsigned long long*)ab, *filter, d_out, d_out ? d_cap : 0, d_n);
     }
     return;
@@ -1372,9 +1458,9 @@ void launch_ordered_t(bmx_ctx* ctx, const Index* ix, T l, T h, OutT* d_out, uint
   const uint32_t blocks = (uint32_t)std::min<uint64_t>((std::min<uint64_t>(d_cap, ix->ord_n + ix->npi) + 2047) / 2048, 8192);
   if (pending) {
     if constexpr (POS) hipLaunchKernelGGL((k_ordered_copy_p<T, uint32_t>), dim3(blocks), dim3(256), 0, ctx->stream, sv, (const uint32_t*)ix->s_pos, (const uint32_t*)ix->s_pos, dv, (const uint32_t*)ix->pd_p[q],
-                                          (const uint32_t*)ix->pi_p[q], (const unsigned long long*)ab, d_out, d_cap);
+                                          (const uint32_t*)ix->pi_p[qi], (const unsigned long long*)ab, d_out, d_cap);
     else hipLaunchKernelGGL((k_ordered_copy_p<T, uint64_t>), dim3(blocks), dim3(256), 0, ctx->stream, sv, (const uint32_t*)ix->s_pos, (const uint64_t*)ix->s_ids, dv, (const uint32_t*)ix->pd_p[q],
-                            (const uint64_t*)ix->pi_ids[q], (const unsigned long long*)ab, d_out, d_cap);
+                            (const uint64_t*)ix->pi_ids[qi], (const unsigned long long*)ab, d_out, d_cap);
   } else {
     if constexpr (POS) hipLaunchKernelGGL((k_ordered_copy<uint32_t>), dim3(blocks), dim3(256), 0, ctx->stream, (const uint32_t*)ix->s_pos, (const unsigned long long*)ab, d_out, d_cap);
     else hipLaunchKernelGGL((k_ordered_copy<uint64_t>), dim3(blocks), dim3(256), 0, ctx->stream, (const uint64_t*)ix->s_ids, (const unsigned long long*)ab, d_out, d_cap);
@@ -1411,7 +1497,9 @@ int run_scan_t(bmx_ctx* ctx, const Pred& P, const Index* ix, void* out_v, uint64
     }
   }
   if ((rc = ensure_scan_scratch(ctx, std::max<uint64_t>(ix->n, 1)))) return rc;
-  unsigned long long* d_n = host ? (pinned ? reinterpret_cast<unsigned long long*>(ctx->pin_out + SCAN_PIN_IDS * 8) : &ctx->ds->n_out) : reinterpret_cast<unsigned long long*>(n_out);
+  const bool hres_n = host && !pinned && !ctx->scan_defer && !(ordered && std::is_same<Pred, PredFilter>::value) /* (that one counts with atomics) */ && ensure_hres(ctx);       // the count of a larger host-mode answer: a mapped result word
+  unsigned long long* d_n = host ? (pinned ? reinterpret_cast<unsigned long long*>(ctx->pin_out + SCAN_PIN_IDS * 8) : hres_n ? const_cast<unsigned long long*>(&ctx->hres[HRES_SCAN_N]) : &ctx->ds->n_out)
+                                 : reinterpret_cast<unsigned long long*>(n_out);
   const uint32_t nb = (uint32_t)((std::max<uint64_t>(ix->n, 1) + SCAN_BLOCK_ELEMS - 1) / SCAN_BLOCK_ELEMS);
   hipEvent_t* se = (ctx->prof_on && ctx->scan_prof_n < PROF_MAX_CALLS && !ctx->scan_ev.empty()) ? &ctx->scan_ev[3 * ctx->scan_prof_n] : nullptr;
   if (se) HIPCHK(hipEventRecord(se[0], ctx->stream));
@@ -1459,8 +1547,9 @@ int run_scan_t(bmx_ctx* ctx, const Pred& P, const Index* ix, void* out_v, uint64
   }
   if (host) {
     unsigned long long m = 0;
-    HIPCHK(hipMemcpyAsync(&m, &ctx->ds->n_out, sizeof(m), hipMemcpyDeviceToHost, ctx->stream));
+    if (!hres_n) HIPCHK(hipMemcpyAsync(&m, &ctx->ds->n_out, sizeof(m), hipMemcpyDeviceToHost, ctx->stream));
     HIPCHK(hipStreamSynchronize(ctx->stream));
+    if (hres_n) m = ctx->hres[HRES_SCAN_N];
     if (out_ids && m) HIPCHK(hipMemcpy(out_ids, ctx->scan_out, std::min<uint64_t>(m, d_cap) * sizeof(OutT), hipMemcpyDeviceToHost));
     if (n_out) *n_out = m;
   }
@@ -1496,10 +1585,14 @@ int scan_range_impl_t(bmx_ctx* ctx, uint32_t field, int64_t lo, int64_t hi, void
     int64_t l = std::max<int64_t>(lo, (int64_t)INT32_MIN + 1), h = std::min<int64_t>(hi, INT32_MAX);
     if (lo > INT32_MAX || hi < INT32_MIN) { l = 1; h = 0; }
     PredRange32 P{ix->v32, (int32_t)l, (int32_t)h, ix->n * sizeof(int32_t) > SCAN_NT_BYTES};
-    return run_scan_t<POS>(ctx, P, ix, out, cap, n_out, mem, ordered, l, h);
+    const int src = run_scan_t<POS>(ctx, P, ix, out, cap, n_out, mem, ordered, l, h);
+    if (ordered && !src) view_after_query(ctx, ix);
+    return src;
   }
   PredRange64 P{ix->v64, std::max<int64_t>(lo, -VAL_MAX), hi, ix->n * sizeof(int64_t) > SCAN_NT_BYTES};    // values live in +-(2^53-1): the clamp changes no answer and keeps tombstones (INT64_MIN) out
-  return run_scan_t<POS>(ctx, P, ix, out, cap, n_out, mem, ordered, P.lo, P.hi);
+  const int src = run_scan_t<POS>(ctx, P, ix, out, cap, n_out, mem, ordered, P.lo, P.hi);
+  if (ordered && !src) view_after_query(ctx, ix);
+  return src;
 }
 int scan_range_impl(bmx_ctx* ctx, uint32_t field, int64_t lo, int64_t hi, uint64_t* out_ids, uint64_t cap, uint64_t* n_out, int mem) {
   return scan_range_impl_t<false>(ctx, field, lo, hi, out_ids, cap, n_out, mem);
@@ -1669,6 +1762,8 @@ void bmx_destroy(bmx_ctx* ctx) {
   dev_free(ctx->slot_pos); dev_free(ctx->chg);
   for (int i = 0; i < 2; i++) { if (ctx->vk_v[i]) (void)hipFree(ctx->vk_v[i]); dev_free(ctx->vk_p[i]); }
   if (ctx->vk_sv) (void)hipFree(ctx->vk_sv); dev_free(ctx->vk_sp); dev_free(ctx->vk_d0); dev_free(ctx->vk_y0);
+  if (ctx->hres) (void)hipHostFree(const_cast<unsigned long long*>(ctx->hres));
+  if (ctx->view_err_host) (void)hipHostFree(ctx->view_err_host); if (ctx->view_ev) (void)hipEventDestroy(ctx->view_ev);
   if (ctx->host_rows) { (void)hipHostFree(ctx->host_rows); ctx->host_rows = nullptr; }
   if (ctx->stg_tails) { (void)hipHostFree(ctx->stg_tails); ctx->stg_tails = nullptr; ctx->stg[0].tail = ctx->stg[1].tail = nullptr; }
   if (ctx->pin_in) { (void)hipHostFree(ctx->pin_in); ctx->pin_in = nullptr; }
@@ -2037,7 +2132,11 @@ int bmx_scan_filter(bmx_ctx* ctx, uint32_t nterms, const bmx_term* terms, uint64
   P.v = ix->v64; P.ids = ix->ids; P.slots = ctx->slots; P.nslots = ctx->nslots; P.nterms = nterms;
   for (uint32_t k = 0; k < nterms; k++) { P.t[k] = terms[k]; P.t[k].lo = std::max<int64_t>(terms[k].lo, -VAL_MAX); }   // tombstones (INT64_MIN) match no term
   // with a value-ordered view of the first term's index: its run is the candidate list, the other terms are probed for those ids only (no order)
-  if ((n_out || out_ids) && ensure_ordered_view(ctx, ix)) return run_scan_t<false>(ctx, P, ix, out_ids, cap, n_out, mem, true, P.t[0].lo, P.t[0].hi);
+  if ((n_out || out_ids) && ensure_ordered_view(ctx, ix)) {
+    const int src = run_scan_t<false>(ctx, P, ix, out_ids, cap, n_out, mem, true, P.t[0].lo, P.t[0].hi);
+    if (!src) view_after_query(ctx, ix);
+    return src;
+  }
   return run_scan(ctx, P, ix, out_ids, cap, n_out, mem);
 }
 

@@ -405,6 +405,97 @@ __global__ __launch_bounds__(256) void k_view_merge(ViewRun<T> X, uint32_t nx, c
 }
 
 
+// ---- merging two sorted runs of similar size (the pending patch's runs with a refresh's change run): merge path over the OUTPUT, like a pass of the sort ----
+// keys of run A that the merged sequence holds in front of diagonal d (ties: A first). Whole wave, same arguments.
+template <class T>
+__device__ __forceinline__ uint32_t merge_path_wave2(const T* __restrict__ av, const uint32_t* __restrict__ ap, uint32_t la, const T* __restrict__ bv, const uint32_t* __restrict__ bp, uint32_t lb, uint32_t d) {
+  const uint32_t lane = threadIdx.x & 63u;
+  uint32_t Lo = d > lb ? d - lb : 0u, Hi = d < la ? d : la;
+  while (Hi - Lo > 63u) {
+    const uint32_t step = (Hi - Lo + 63u) / 64u;
+    const uint32_t i = Lo + lane * step;
+    bool pr = false;
+    if (i < Hi) pr = !vk_less<T>(bv[d - 1u - i], bp[d - 1u - i], av[i], ap[i]);
+    const uint32_t tcount = (uint32_t)__popcll(__ballot(pr));
+    const uint32_t nLo = tcount ? Lo + (tcount - 1u) * step + 1u : Lo;
+    const uint32_t nHi = Lo + tcount * step < Hi ? Lo + tcount * step : Hi;
+    Lo = nLo; Hi = tcount == 0 ? Lo : nHi;
+  }
+  bool pr = false;
+  const uint32_t i = Lo + lane;
+  if (i < Hi) pr = !vk_less<T>(bv[d - 1u - i], bp[d - 1u - i], av[i], ap[i]);
+  return Lo + (uint32_t)__popcll(__ballot(pr));
+}
+// Z = A merged with B (both sorted, keys unique across them). IDS: the ids of A's keys travel with them, those of B's keys are gathered from the index's id column.
+// A workgroup owns 1024 consecutive keys of Z; a thread merges four of them (k_view_merge_pass's form, two source arrays).
+template <class T, bool IDS>
+__global__ __launch_bounds__(256) void k_view_merge2(ViewRun<T> A, uint32_t la, const T* __restrict__ bv, const uint32_t* __restrict__ bp, uint32_t lb, const uint64_t* __restrict__ ix_ids, ViewRun<T> Z) {
+  __shared__ uint32_t cut[2];
+  __shared__ T sv[VIEW_PASS_KEYS];
+  __shared__ uint32_t sp[VIEW_PASS_KEYS];
+  const uint32_t len = la + lb;
+  const uint32_t o0 = blockIdx.x * VIEW_PASS_KEYS;
+  if (o0 >= len) return;
+  const uint32_t o1 = o0 + VIEW_PASS_KEYS < len ? o0 + VIEW_PASS_KEYS : len;
+  const uint32_t w = threadIdx.x >> 6;
+  if (w < 2) {
+    const uint32_t d = w == 0 ? o0 : o1;
+    const uint32_t i = lb == 0 ? d : (la == 0 ? 0u : merge_path_wave2<T>(A.v, A.p, la, bv, bp, lb, d));
+    if ((threadIdx.x & 63u) == 0) cut[w] = i;
+  }
+  __syncthreads();
+  const uint32_t i0 = cut[0], i1 = cut[1], j0 = o0 - i0, j1 = o1 - i1;
+  const uint32_t na = i1 - i0, nb = j1 - j0;
+  for (uint32_t k = threadIdx.x; k < na + nb; k += 256u) {
+    if (k < na) { sv[k] = A.v[i0 + k]; sp[k] = A.p[i0 + k]; } else { sv[k] = bv[j0 + (k - na)]; sp[k] = bp[j0 + (k - na)]; }
+  }
+  __syncthreads();
+  const uint32_t tot = na + nb, dd = threadIdx.x * 4u;
+  if (dd >= tot) return;
+  uint32_t lo = dd > nb ? dd - nb : 0u, hi = dd < na ? dd : na;
+  while (lo < hi) {
+    const uint32_t mid = lo + ((hi - lo) >> 1);
+    const uint32_t bj = na + (dd - 1u - mid);
+    if (!vk_less<T>(sv[bj], sp[bj], sv[mid], sp[mid])) lo = mid + 1u; else hi = mid;
+  }
+  uint32_t ia = lo, ib = na + (dd - lo);
+#pragma unroll
+  for (uint32_t k = 0; k < 4; k++) {
+    if (dd + k >= tot) break;
+    const bool hasA = ia < na, hasB = ib < tot;
+    const T av = hasA ? sv[ia] : (T)0, bvv = hasB ? sv[ib] : (T)0; const uint32_t ap = hasA ? sp[ia] : 0u, bpp = hasB ? sp[ib] : 0u;
+    const bool takeA = hasA && (!hasB || !vk_less<T>(bvv, bpp, av, ap));
+    const uint32_t o = o0 + dd + k;
+    Z.v[o] = takeA ? av : bvv; Z.p[o] = takeA ? ap : bpp;
+    if (IDS) Z.ids[o] = takeA ? A.ids[i0 + ia] : ix_ids[bpp];
+    ia += takeA ? 1u : 0u; ib += takeA ? 0u : 1u;
+  }
+}
+// flag[i] = 1 when sorted key i of D is one of the sorted keys of I (one binary search per key, once: the two selects that split D read the flags)
+template <class T>
+__global__ __launch_bounds__(256) void k_view_flag_in(const T* __restrict__ dv, const uint32_t* __restrict__ dp, uint32_t nd, const T* __restrict__ iv, const uint32_t* __restrict__ ip, uint32_t ni, uint8_t* __restrict__ flag) {
+  const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+  if (i >= nd) return;
+  const T kv = dv[i]; const uint32_t kp = dp[i];
+  const uint32_t at = (uint32_t)vk_bound<T>(iv, ip, 0, ni, kv, kp);
+  flag[i] = (at < ni && iv[at] == kv && ip[at] == kp) ? 1u : 0u;
+}
+struct PredFlag { static constexpr int E = 1; const uint8_t* flag; uint32_t want; __device__ uint32_t mask(uint64_t first, uint64_t n) const { return first < n && flag[first] == want ? 1u : 0u; } };
+// keys of run X (with ids) that are NOT among the sorted keys K (the cancelled inserts): the select that takes them out of the pending run
+template <class T>
+struct PredNotIn {
+  static constexpr int E = 1;
+  const T* xv; const uint32_t* xp; const T* kv; const uint32_t* kp; uint32_t nk;
+  __device__ uint32_t mask(uint64_t first, uint64_t n) const {
+    if (first >= n) return 0u;
+    const T v = xv[first]; const uint32_t p = xp[first];
+    const uint32_t at = (uint32_t)vk_bound<T>(kv, kp, 0, nk, v, p);
+    return (at < nk && kv[at] == v && kp[at] == p) ? 0u : 1u;
+  }
+};
+template <class T>
+struct EmitRun { const T* xv; const uint32_t* xp; const uint64_t* xi; T* ov; uint32_t* op; uint64_t* oi; __device__ void operator()(uint64_t rank, uint64_t i) const { ov[rank] = xv[i]; op[rank] = xp[i]; oi[rank] = xi[i]; } };
+
 // ---- the view with a PENDING patch (DESIGN section 4 "kept current"): the logical view = main - PD + PI, PD = sorted keys of main that are gone, PI = sorted keys (+ ids)
 // that are new; the physical merge above runs when the patch has grown, not on every refresh. ----
 // ids of the inserted keys (the patch keeps them so that a query copies one run)

@@ -1,6 +1,6 @@
 #!/bin/bash
-OUT=gpurun_out/r05/m; mkdir -p $OUT
-timeout -k 10 300 ./bench_micro/view_merge_micro 100000000 > $OUT/view_merge_micro.log 2>&1; cat $OUT/view_merge_micro.log
+OUT=gpurun_out/r05/o; mkdir -p $OUT
+
 timeout -k 10 500 python -m pytest tests/test_gpu_ordered_view.py tests/test_gpu_index_maintenance.py -m gpu -q -x > $OUT/pytest_sel.log 2>&1; rc=$?; tail -6 $OUT/pytest_sel.log; echo "pytest rc=$rc"
 [ $rc -eq 124 ] && exit 124
 [ $rc -ne 0 ] && exit $rc
@@ -13,7 +13,7 @@ for cfg in "10000000 int32" "100000000 int32" "100000000 wide"; do set -- $cfg
 import csv,sys
 for r in csv.DictReader(open(sys.argv[1])):
     n=r['Name']
-    if any(k in n for k in ('k_view','k_ix_update','PredLogCreated','PredChanged')):
+    if any(k in n for k in ('k_view','k_ix_update','PredLogCreated','PredChanged','PredFlag','PredNotIn')):
         print("  %-44s calls %3s avg %9.1f us" % (n.split('(')[0].replace('void bmx::','')[:44], r['Calls'], float(r['AverageNs'])/1e3))
 PY
   if [ $r -eq 124 ]; then exit 124; fi
