@@ -86,9 +86,9 @@ int main(int argc, char** argv) {
     CK(hipMalloc(&a, (K + 4096) * 4)); CK(hipMalloc(&b, (K + 4096) * 4)); CK(hipMalloc(&ap, (K + 4096) * 4)); CK(hipMalloc(&bp, (K + 4096) * 4));
     CK(hipMemcpy(a, kv.data(), K * 4, hipMemcpyHostToDevice)); CK(hipMemcpy(ap, kp.data(), K * 4, hipMemcpyHostToDevice));
     ViewSegs S{}; S.base[0] = 0; S.len[0] = K / 2; S.base[1] = K / 2; S.len[1] = K - K / 2;
-    const uint32_t t0b = (S.len[0] + VIEW_TILE - 1) / VIEW_TILE, t1b = (S.len[1] + VIEW_TILE - 1) / VIEW_TILE;
+    const uint32_t t0b = (S.len[0] + VIEW_SORT_TILE - 1) / VIEW_SORT_TILE, t1b = (S.len[1] + VIEW_SORT_TILE - 1) / VIEW_SORT_TILE;
     S.blk0[0] = 0; S.blk0[1] = t0b; S.blk0[2] = t0b + t1b;
-    timeit("tile sort, 2 x 1M keys", [&] { hipLaunchKernelGGL((k_view_tile_sort<int>), dim3(S.blk0[2]), dim3(256), 0, 0, (const int*)a, (const unsigned*)ap, b, bp, S); });
+    timeit("tile sort, 2 x 1M keys", [&] { hipLaunchKernelGGL((k_view_tile_sort<int>), dim3(S.blk0[2]), dim3(VIEW_SORT_THREADS), 0, 0, (const int*)a, (const unsigned*)ap, b, bp, S); });
     ViewSegs P = S; P.blk0[1] = (S.len[0] + VIEW_PASS_KEYS - 1) / VIEW_PASS_KEYS; P.blk0[2] = P.blk0[1] + (S.len[1] + VIEW_PASS_KEYS - 1) / VIEW_PASS_KEYS;
     for (uint32_t dbg = 0; dbg < 4; dbg++) for (uint32_t L : {2048u, 65536u, 524288u}) {
       P.dbg = dbg; char nm[96]; snprintf(nm, sizeof nm, "merge pass L = %u, switches %u", L, dbg);
@@ -99,9 +99,9 @@ int main(int argc, char** argv) {
     P.dbg = 0;
     int* cv[2] = {a, b}; unsigned* cp[2] = {ap, bp};
     CK(hipEventRecord(e0));
-    hipLaunchKernelGGL((k_view_tile_sort<int>), dim3(S.blk0[2]), dim3(256), 0, 0, (const int*)cv[0], (const unsigned*)cp[0], cv[1], cp[1], S);
+    hipLaunchKernelGGL((k_view_tile_sort<int>), dim3(S.blk0[2]), dim3(VIEW_SORT_THREADS), 0, 0, (const int*)cv[0], (const unsigned*)cp[0], cv[1], cp[1], S);
     int cur = 1;
-    for (uint32_t L = VIEW_TILE; L < S.len[1]; L *= 2) { hipLaunchKernelGGL((k_view_merge_pass<int>), dim3(P.blk0[2]), dim3(256), 0, 0, (const int*)cv[cur], (const unsigned*)cp[cur], cv[cur ^ 1], cp[cur ^ 1], P, L); cur ^= 1; }
+    for (uint32_t L = VIEW_SORT_TILE; L < S.len[1]; L *= 2) { hipLaunchKernelGGL((k_view_merge_pass<int>), dim3(P.blk0[2]), dim3(256), 0, 0, (const int*)cv[cur], (const unsigned*)cp[cur], cv[cur ^ 1], cp[cur ^ 1], P, L); cur ^= 1; }
     CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1)); float ms; CK(hipEventElapsedTime(&ms, e0, e1));
     std::vector<int> rv(K); std::vector<unsigned> rp(K); CK(hipMemcpy(rv.data(), cv[cur], K * 4, hipMemcpyDeviceToHost)); CK(hipMemcpy(rp.data(), cp[cur], K * 4, hipMemcpyDeviceToHost));
     size_t bad = 0; for (uint32_t s2 = 0; s2 < 2; s2++) for (uint32_t i = S.base[s2] + 1; i < S.base[s2] + S.len[s2]; i++) if (rv[i - 1] > rv[i] || (rv[i - 1] == rv[i] && rp[i - 1] > rp[i])) bad++;

@@ -1079,7 +1079,9 @@ void start_rewrite(bmx_ctx* ctx, Index& ix) {
 }
 void view_after_query(bmx_ctx* ctx, Index* ix) {         // behind the answer of an ordered query
   if (!ix->rewrite_due) return;
+  const auto t0 = std::chrono::steady_clock::now();
   if (ix->ord_fits32) start_rewrite<int32_t>(ctx, *ix); else start_rewrite<int64_t>(ctx, *ix);
+  if (std::getenv("BMX_VIEW_DEBUG")) std::fprintf(stderr, "bmx: rewrite enqueued in %.1f us\n", std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count());
 }
 void view_before_use(bmx_ctx* ctx, Index* ix, bool wait) {   // in front of anything that reads or changes the view
   if (!ix->rewrite_inflight) return;
@@ -1112,12 +1114,12 @@ int patch_view_t(bmx_ctx* ctx, Index& ix, uint64_t c, uint64_t n0, uint64_t adde
                      (uint32_t)n0, (uint32_t)added, kv[0], kp[0]);
   // 1. sort the deleted keys [0, c) and the inserted keys [c, c + m): tiles in LDS, then merge-path passes
   ViewSegs S{}; S.base[0] = 0; S.len[0] = (uint32_t)c; S.base[1] = (uint32_t)c; S.len[1] = (uint32_t)m;
-  const uint32_t t0b = (uint32_t)((c + VIEW_TILE - 1) / VIEW_TILE), t1b = (uint32_t)((m + VIEW_TILE - 1) / VIEW_TILE);
+  const uint32_t t0b = (uint32_t)((c + VIEW_SORT_TILE - 1) / VIEW_SORT_TILE), t1b = (uint32_t)((m + VIEW_SORT_TILE - 1) / VIEW_SORT_TILE);
   S.blk0[0] = 0; S.blk0[1] = t0b; S.blk0[2] = t0b + t1b;
-  hipLaunchKernelGGL((k_view_tile_sort<T>), dim3(t0b + t1b), dim3(256), 0, st, (const T*)kv[0], (const uint32_t*)kp[0], kv[1], kp[1], S);
+  hipLaunchKernelGGL((k_view_tile_sort<T>), dim3(t0b + t1b), dim3(VIEW_SORT_THREADS), 0, st, (const T*)kv[0], (const uint32_t*)kp[0], kv[1], kp[1], S);
   int cur = 1;
   ViewSegs P = S; P.blk0[1] = (uint32_t)((c + VIEW_PASS_KEYS - 1) / VIEW_PASS_KEYS); P.blk0[2] = P.blk0[1] + (uint32_t)((m + VIEW_PASS_KEYS - 1) / VIEW_PASS_KEYS);
-  for (uint64_t L = VIEW_TILE; L < std::max<uint64_t>(c, m); L *= 2) {
+  for (uint64_t L = VIEW_SORT_TILE; L < std::max<uint64_t>(c, m); L *= 2) {
     hipLaunchKernelGGL((k_view_merge_pass<T>), dim3(P.blk0[2]), dim3(256), 0, st, (const T*)kv[cur], (const uint32_t*)kp[cur], kv[cur ^ 1], kp[cur ^ 1], P, (uint32_t)L);
     cur ^= 1;
   }
@@ -1150,6 +1152,9 @@ int patch_view_t(bmx_ctx* ctx, Index& ix, uint64_t c, uint64_t n0, uint64_t adde
     // room for the patch at its largest (a rewrite falls due beyond thr keys; the run that crosses the line is still taken in), allocated once: a growing
     // buffer would put its reallocation in front of some query's answer
     if (ensure_pending<T>(ctx, ix, std::max<uint64_t>(std::max<uint64_t>(ix.npd + c, ix.npi + m), thr + 2 * std::max<uint64_t>(c, m)))) return soft(0);
+    if (!ctx->view_err_host && hipHostMalloc(reinterpret_cast<void**>(&ctx->view_err_host), sizeof(uint32_t), hipHostMallocDefault) != hipSuccess) { (void)hipGetLastError(); ctx->view_err_host = nullptr; }
+    if (!ctx->view_ev && hipEventCreateWithFlags(&ctx->view_ev, hipEventDisableTiming) != hipSuccess) { (void)hipGetLastError(); ctx->view_ev = nullptr; }
+    if (!ix.s_val2 && !ensure_view_spare<T>(ctx, ix, nx + thr + 2 * m)) return soft(0);     // (the rewrite's target, also allocated now rather than in front of a later answer)
     T* pdv[2] = {static_cast<T*>(ix.pd_v[0]), static_cast<T*>(ix.pd_v[1])}; T* piv[2] = {static_cast<T*>(ix.pi_v[0]), static_cast<T*>(ix.pi_v[1])};
     auto merge2 = [&](bool ids, ViewRun<T> A, uint64_t la, const T* bv, const uint32_t* bp, uint64_t lb, ViewRun<T> Z) {
       if (la + lb == 0) return;

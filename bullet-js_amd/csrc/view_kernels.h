@@ -100,56 +100,121 @@ __global__ __launch_bounds__(256) void k_view_keys(const uint32_t* __restrict__ 
   }
 }
 
-// One tile of 2048 keys sorted in LDS (bitonic network, 66 compare-exchange rounds of 1024 pairs over 256 threads). A ragged last tile is padded with
-// keys behind every real one; only the real keys are written back.
+// One tile of VIEW_SORT_TILE keys sorted in LDS: a bitonic network whose compare-exchange stages are done THREE AT A TIME in registers. A thread takes 8 keys
+// whose indices differ in three consecutive bits (stride s, 2s, 4s), runs the stages j = 4s, 2s, s on them and puts them back: one LDS round trip and one
+// barrier per three stages — 28 rounds for 4096 keys instead of the 78 of the stage-per-round form (2048-key tiles in that form: 68 us per 2M keys; this one
+// sorts twice the run length, which also saves a merge pass). A ragged last tile is padded with keys behind every real one; only real keys are written back.
+constexpr uint32_t VIEW_SORT_TILE = 4096, VIEW_SORT_THREADS = VIEW_SORT_TILE / 8;
+// Where key i of the tile lives in LDS. With A, B, C the three 3-bit fields of i from the bottom, the bank (low 6 bits) is (A ^ C, B ^ C): whichever two of the
+// three fields a wave's lanes run through in a round (stride 1: B, C; stride 8: A, C; stride 64 and up: A, B), the 64 lanes fall on 64 different banks. The plain
+// layout serialises the stride-1 and stride-8 rounds eight ways (21 of the 30 rounds).
+__device__ __forceinline__ uint32_t vk_sw(uint32_t i) { return i ^ (((i >> 6) & 7u) * 9u); }
 template <class T>
-__global__ __launch_bounds__(256) void k_view_tile_sort(const T* __restrict__ vin, const uint32_t* __restrict__ pin, T* __restrict__ vout, uint32_t* __restrict__ pout, ViewSegs S) {
-  constexpr T VMAX = sizeof(T) == 4 ? (T)INT32_MAX : (T)INT64_MAX;
-  __shared__ T sv[VIEW_TILE];
-  __shared__ uint32_t sp[VIEW_TILE];
-  const uint32_t s = S.seg_of(blockIdx.x);
-  const uint32_t t0 = (blockIdx.x - S.blk0[s]) * VIEW_TILE;          // first key of the tile inside its segment
-  const uint32_t len = S.len[s], base = S.base[s];
+__device__ __forceinline__ void vk_cx(T& av, uint32_t& ap, T& bv, uint32_t& bp, bool up) {       // afterwards (a, b) ascending when up, descending otherwise
+  const bool sw = vk_less<T>(bv, bp, av, ap) == up;
+  const T tv = sw ? bv : av; const uint32_t tp = sw ? bp : ap;
+  bv = sw ? av : bv; bp = sw ? ap : bp; av = tv; ap = tp;
+}
+// NST stages (j = s << (NST - 1) ... s) of the merge step that builds sorted stretches of k keys; every thread 8 keys = 8 >> NST groups of 1 << NST
+template <class T, int NST>
+__device__ __forceinline__ void vk_round(T* sv, uint32_t* sp, uint32_t s, uint32_t k) {
+  constexpr uint32_t G = 1u << NST, NG = 8u / G;
 #pragma unroll
-  for (uint32_t u = 0; u < VIEW_TILE / 256u; u++) {
-    const uint32_t e = u * 256u + threadIdx.x;
-    const bool ok = t0 + e < len;
-    sv[e] = ok ? vin[base + t0 + e] : VMAX; sp[e] = ok ? pin[base + t0 + e] : 0xFFFFFFFFu;
+  for (uint32_t q = 0; q < NG; q++) {
+    const uint32_t t = q * VIEW_SORT_THREADS + threadIdx.x;                    // group number: consecutive lanes on consecutive groups (no bank conflicts)
+    const uint32_t base = (t & (s - 1u)) | ((t & ~(s - 1u)) << NST);           // its lowest key: the NST bits above log2(s) are the group's own
+    const bool up = (base & k) == 0;                                           // (bit k lies above the group's bits: one direction for the whole group)
+    T v[G]; uint32_t p[G];
+#pragma unroll
+    for (uint32_t r = 0; r < G; r++) { v[r] = sv[vk_sw(base + r * s)]; p[r] = sp[vk_sw(base + r * s)]; }
+#pragma unroll
+    for (uint32_t h = G >> 1; h > 0; h >>= 1) {
+#pragma unroll
+      for (uint32_t r = 0; r < G; r++) if ((r & h) == 0) vk_cx<T>(v[r], p[r], v[r | h], p[r | h], up);
+    }
+#pragma unroll
+    for (uint32_t r = 0; r < G; r++) { sv[vk_sw(base + r * s)] = v[r]; sp[vk_sw(base + r * s)] = p[r]; }
   }
   __syncthreads();
-  for (uint32_t k = 2; k <= VIEW_TILE; k <<= 1) {
-    for (uint32_t j = k >> 1; j > 0; j >>= 1) {
+}
+template <class T>
+__global__ __launch_bounds__(VIEW_SORT_THREADS) void k_view_tile_sort(const T* __restrict__ vin, const uint32_t* __restrict__ pin, T* __restrict__ vout, uint32_t* __restrict__ pout, ViewSegs S) {
+  constexpr T VMAX = sizeof(T) == 4 ? (T)INT32_MAX : (T)INT64_MAX;
+  __shared__ T sv[VIEW_SORT_TILE];
+  __shared__ uint32_t sp[VIEW_SORT_TILE];
+  const uint32_t sg = S.seg_of(blockIdx.x);
+  const uint32_t t0 = (blockIdx.x - S.blk0[sg]) * VIEW_SORT_TILE;     // first key of the tile inside its segment
+  const uint32_t len = S.len[sg], base = S.base[sg];
 #pragma unroll
-      for (uint32_t u = 0; u < VIEW_TILE / 512u; u++) {
-        const uint32_t t = u * 256u + threadIdx.x;                   // pair number
-        const uint32_t i = ((t & ~(j - 1u)) << 1) | (t & (j - 1u));  // lower element of the pair: bit j clear
-        const uint32_t q = i | j;
-        const T av = sv[i], bv = sv[q]; const uint32_t ap = sp[i], bp = sp[q];
-        const bool up = (i & k) == 0;                                 // this stretch is sorted ascending
-        if (vk_less<T>(bv, bp, av, ap) == up) { sv[i] = bv; sp[i] = bp; sv[q] = av; sp[q] = ap; }
-      }
-      __syncthreads();
+  for (uint32_t u = 0; u < 8u; u++) {
+    const uint32_t e = u * VIEW_SORT_THREADS + threadIdx.x;
+    const bool ok = t0 + e < len;
+    sv[vk_sw(e)] = ok ? vin[base + t0 + e] : VMAX; sp[vk_sw(e)] = ok ? pin[base + t0 + e] : 0xFFFFFFFFu;
+  }
+  __syncthreads();
+  {   // the merge steps k = 2, 4, 8 touch only the 8 consecutive keys of a thread: one round trip for their six stages
+    const uint32_t b8 = threadIdx.x * 8u;
+    T v[8]; uint32_t p[8];
+#pragma unroll
+    for (uint32_t r = 0; r < 8u; r++) { v[r] = sv[vk_sw(b8 + r)]; p[r] = sp[vk_sw(b8 + r)]; }
+#pragma unroll
+    for (uint32_t r = 0; r < 8u; r += 2u) vk_cx<T>(v[r], p[r], v[r + 1u], p[r + 1u], (r & 2u) == 0);                          // k = 2
+#pragma unroll
+    for (uint32_t r = 0; r < 8u; r++) if ((r & 2u) == 0) vk_cx<T>(v[r], p[r], v[r + 2u], p[r + 2u], (r & 4u) == 0);            // k = 4, j = 2
+#pragma unroll
+    for (uint32_t r = 0; r < 8u; r += 2u) vk_cx<T>(v[r], p[r], v[r + 1u], p[r + 1u], (r & 4u) == 0);                          // k = 4, j = 1
+    const bool up8 = (b8 & 8u) == 0;
+#pragma unroll
+    for (uint32_t h = 4u; h > 0; h >>= 1) {
+#pragma unroll
+      for (uint32_t r = 0; r < 8u; r++) if ((r & h) == 0) vk_cx<T>(v[r], p[r], v[r | h], p[r | h], up8);                       // k = 8
+    }
+#pragma unroll
+    for (uint32_t r = 0; r < 8u; r++) { sv[vk_sw(b8 + r)] = v[r]; sp[vk_sw(b8 + r)] = p[r]; }
+    __syncthreads();
+  }
+  for (uint32_t k = 16, n = 4; k <= VIEW_SORT_TILE; k <<= 1, n++) {    // n = log2(k) stages: j = k/2 ... 1
+    uint32_t left = n, jt = k >> 1;
+    while (left) {
+      const uint32_t g = left % 3u ? left % 3u : 3u;                   // the odd group first, then threes
+      const uint32_t s = jt >> (g - 1u);
+      if (g == 3u) vk_round<T, 3>(sv, sp, s, k); else if (g == 2u) vk_round<T, 2>(sv, sp, s, k); else vk_round<T, 1>(sv, sp, s, k);
+      jt >>= g; left -= g;
     }
   }
 #pragma unroll
-  for (uint32_t u = 0; u < VIEW_TILE / 256u; u++) {
-    const uint32_t e = u * 256u + threadIdx.x;
-    if (t0 + e < len) { vout[base + t0 + e] = sv[e]; pout[base + t0 + e] = sp[e]; }
+  for (uint32_t u = 0; u < 8u; u++) {
+    const uint32_t e = u * VIEW_SORT_THREADS + threadIdx.x;
+    if (t0 + e < len) { vout[base + t0 + e] = sv[vk_sw(e)]; pout[base + t0 + e] = sp[vk_sw(e)]; }
   }
 }
 
-// One pass of the merge sort: inside every segment, sorted runs of L keys (L a multiple of 2048) are merged pairwise into runs of 2L — merge path: a
+// One pass of the merge sort: inside every segment, sorted runs of L keys (L a multiple of 1024) are merged pairwise into runs of 2L — merge path: a
 // workgroup OWNS 1024 consecutive keys of the OUTPUT. Two waves find, 64-ary, where the diagonals through its first and last output key cut the two input
 // runs (a few rounds of dependent reads instead of a binary search's twenty); the two input pieces (1024 keys together) are staged in LDS, every key finds its
 // rank in the other piece there, and the workgroup writes its own contiguous stretch. (The first version let every INPUT key compute its output place and
 // store it there: two workgroups on different XCDs then fill every 32-byte sector of the output together, the memory side merges byte-masked partial writes,
 // and a pass over 1.9M keys took 27 us however the searches were arranged.)
 constexpr uint32_t VIEW_PASS_KEYS = 1024;
+constexpr uint32_t MP_WINDOW = 64u * 63u;          // keys spanned by the first (guessed) round of a merge-path search
 // keys of run A that the merged sequence holds in front of diagonal d (A: la keys at a0, B: lb keys at b0; ties: A first). Whole wave, same arguments.
 template <class T>
 __device__ __forceinline__ uint32_t merge_path_wave(const T* __restrict__ V, const uint32_t* __restrict__ P, uint32_t a0, uint32_t la, uint32_t b0, uint32_t lb, uint32_t d) {
   const uint32_t lane = threadIdx.x & 63u;
   uint32_t Lo = d > lb ? d - lb : 0u, Hi = d < la ? d : la;          // the answer i lies in [Lo, Hi]; predicate pred(i) = "A[i] is in front of the diagonal" = !(B[d-1-i] < A[i]), true for i < answer
+  if (Hi - Lo > 2u * MP_WINDOW) {
+    // a first round around the place the cut has when both runs are samples of one distribution, d * la / (la + lb): a window of 64 probes 63 keys apart. The cut is
+    // usually inside (the runs of a sort are, up to ~sqrt(L)) and one more round finishes; when it is not, the window has still cut the range on one side.
+    const uint32_t g = (uint32_t)(((uint64_t)d * la) / (la + lb));
+    uint32_t w0 = g > MP_WINDOW / 2u ? g - MP_WINDOW / 2u : 0u;
+    if (w0 < Lo) w0 = Lo;
+    if (w0 + MP_WINDOW > Hi) w0 = Hi - MP_WINDOW;                      // (Hi - Lo > 2 windows: stays >= Lo)
+    const uint32_t i = w0 + lane * 63u;                                // < Hi
+    const bool pr = !vk_less<T>(V[b0 + d - 1u - i], P[b0 + d - 1u - i], V[a0 + i], P[a0 + i]);
+    const uint32_t tcount = (uint32_t)__popcll(__ballot(pr));
+    if (tcount == 0) Hi = w0;                                          // the cut is at or in front of the window's first probe
+    else { Lo = w0 + (tcount - 1u) * 63u + 1u; if (tcount < 64u) Hi = w0 + tcount * 63u; }
+  }
   while (Hi - Lo > 63u) {
     const uint32_t step = (Hi - Lo + 63u) / 64u;
     const uint32_t i = Lo + lane * step;                              // probes Lo, Lo + step, ...; pred is monotone (true ... true false ... false)
@@ -411,6 +476,17 @@ template <class T>
 __device__ __forceinline__ uint32_t merge_path_wave2(const T* __restrict__ av, const uint32_t* __restrict__ ap, uint32_t la, const T* __restrict__ bv, const uint32_t* __restrict__ bp, uint32_t lb, uint32_t d) {
   const uint32_t lane = threadIdx.x & 63u;
   uint32_t Lo = d > lb ? d - lb : 0u, Hi = d < la ? d : la;
+  if (Hi - Lo > 2u * MP_WINDOW) {                                       // (the window round of merge_path_wave)
+    const uint32_t g = (uint32_t)(((uint64_t)d * la) / (la + lb));
+    uint32_t w0 = g > MP_WINDOW / 2u ? g - MP_WINDOW / 2u : 0u;
+    if (w0 < Lo) w0 = Lo;
+    if (w0 + MP_WINDOW > Hi) w0 = Hi - MP_WINDOW;
+    const uint32_t i = w0 + lane * 63u;
+    const bool pr = !vk_less<T>(bv[d - 1u - i], bp[d - 1u - i], av[i], ap[i]);
+    const uint32_t tcount = (uint32_t)__popcll(__ballot(pr));
+    if (tcount == 0) Hi = w0;
+    else { Lo = w0 + (tcount - 1u) * 63u + 1u; if (tcount < 64u) Hi = w0 + tcount * 63u; }
+  }
   while (Hi - Lo > 63u) {
     const uint32_t step = (Hi - Lo + 63u) / 64u;
     const uint32_t i = Lo + lane * step;

@@ -306,19 +306,31 @@ int bmx_index_refresh_counts(bmx_ctx* ctx, uint64_t* full_builds, uint64_t* incr
  * is the same; the host mirror can reproduce the reference's first-seen-value order from either).
  * Currency (ABI 4: the device-side _updateIndices, src/bullet-query.js:139-176 — the reference moves a path from the bucket of its old value to the bucket of
  * its new one on every write): a view that is current STAYS current under writes. The refresh that brings the dense columns up to date from the merges' change
- * log also captures the change run — (position, old value) of every row whose value really changed, plus the appended rows —, sorts it (hand-written LDS tile
- * sort + rank-merge passes, csrc/view_kernels.h) and merges it into the view in one streaming pass over the sorted columns: n * (w + 12) bytes read and written
- * (w = 4 or 8), ~0.1 ms at 10^7 rows, under a millisecond at 10^8 — paid once by the first query after any number of merges on the field, never by the merges;
- * merges on other fields, merges that lose and rewrites of the same value cost nothing. Memory: a second set of the view's columns from the first patch on (the
- * two sets swap), i.e. 32 or 40 bytes per row in all, + 12 bytes per logged winner for the change run. The view goes STALE (and is sorted again from scratch,
- * below) only when it cannot be patched: after an index rebuild (table growth, merges that do not log, a log longer than an eighth of the table or 2^24 entries),
- * when a value stops fitting int32 (the index switches columns), without memory for the second set, or with BMX_VIEW_PATCH=0 in the environment (A/B switch).
+ * log also captures the change run — (position, old value) of every row whose value really changed, plus the appended rows — and sorts it (hand-written LDS tile
+ * sort + merge-path passes, csrc/view_kernels.h). What happens to the sorted run depends on its size against the view (R rows):
+ *   - more than R/16 keys (small indexes: always): the view's main run is rewritten at once, one streaming pass main - deleted + inserted, R * (w + 12) bytes read
+ *     and written (w = 4 or 8): ~0.1 ms at 10^7 rows;
+ *   - otherwise the run joins the view's PENDING PATCH (pd: keys deleted from main, pi: keys inserted, each sorted; a deleted key that is a pending insert cancels
+ *     it). Queries answer from main - pd + pi: five k-ary searches instead of two, and the copy skips / appends the patch's keys of the answer's range. When the
+ *     patch has grown beyond R/16 keys, main is rewritten with it BEHIND the answer of the query that found it so: the rewrite is enqueued after that answer, reads
+ *     main and the patch and writes the second set of columns; the next call that touches the view looks at its completion event and error word and swaps the sets
+ *     (or, after a failure, goes on with main and the patch, which were never written). At 10^8 rows and 1M-delta merges on the field: every first query after a
+ *     merge pays the run's sort and the join (0.6-1.0 ms with its answer in host memory), every fourth is followed by a 1.3-1.8 ms rewrite that nobody waits for
+ *     unless the next merge + query arrive within that time.
+ * All of it is paid by the first query after any number of merges on the field, never by the merges; merges on other fields, merges that lose and rewrites of
+ * the same value cost nothing. ORDER of a view's answers: survivors of main in (value, position) order, then the range's pending inserts in (value, position)
+ * order — the same SET as ever, as one sorted run only while the patch is empty; the order may differ between two calls (a rewrite in between). Memory: a second
+ * set of the view's columns from the first patch on (the two sets swap), i.e. 32 or 40 bytes per row in all, the pending patch (two sets, R/16 + two runs of keys:
+ * ~5 bytes per row), + 12 bytes per logged winner for the change run. BMX_VIEW_PENDING=0 in the environment switches the pending patch off (every patch rewrites
+ * main; A/B switch). The view goes STALE (and is sorted again from scratch, below) only when it cannot be patched: after an index rebuild (table growth, merges
+ * that do not log, a log longer than an eighth of the table or 2^24 entries), when a value stops fitting int32 (the index switches columns), without memory for
+ * the second set or the patch, or with BMX_VIEW_PATCH=0 in the environment (A/B switch).
  * A stale (or new) view is sorted (one radix sort of the column + one gather: milliseconds for 10^8 rows, csrc/ordered_sort.hip) by the N-th query since the
  * columns last changed; the N - 1 queries before it scan the column as ever. N = 0 switches the view off and frees it. bmx_scan_filter takes its candidates from
  * the view of its FIRST term's index when there is one: the other terms are probed for the ids of one run only (survivors then come in no particular order).
  * If the memory cannot be had the index silently goes on without the view. bmx_index_ordered_info: N, whether the view would answer the next query, and how many
- * sorts have run; bmx_index_ordered_stats: sorts, patches, keys moved by the patches (deleted + inserted), and what the last sort / the last patch cost the
- * caller in microseconds (outputs may be NULL). */
+ * sorts have run; bmx_index_ordered_stats: sorts, patches, keys moved by the patches (deleted + inserted), what the last sort / the last patch cost the
+ * caller in microseconds, rewrites of main that have completed, and the keys in the pending patch now (outputs may be NULL). */
 #define BMX_INDEX_ORDERED_AUTO 0xFFFFFFFFu   /* after_queries chosen by the engine: sort once the scans since the change have cost what the sort costs (rent-or-buy:
                                                * never more than twice the cheapest schedule, whatever comes next): ~70 queries on 10^8 int32 rows, ~25 on 10^7 */
 int bmx_index_set_ordered(bmx_ctx* ctx, uint32_t field, uint32_t after_queries);

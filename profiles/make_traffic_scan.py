@@ -39,8 +39,8 @@ out = {"source": "rocprofv3 --kernel-trace --pmc FETCH_SIZE / --pmc WRITE_SIZE (
        "correction": "FETCH_SIZE x2 (gfx950 tallies 128-B read requests at 64 B); WRITE_SIZE exact", "rows": R, "queries": {}}
 for kind, per in PER.items():
     rows_f, rows_w = [x for x in fe if x[1] == kind], [x for x in wr if x[1] == kind]
-    # per column: the four queries' launches, then (id output only) the one scan of "first_scan_after_a_1M_delta_merge", which is left out
-    assert len(rows_f) == len(rows_w) and len(rows_f) % 2 == 0 and len(rows_f) // 2 - len(QUERIES) * per in (0, 1), (kind, len(rows_f), len(rows_w))
+    # per column: the four queries' launches, then (id output only) the column scan that checks the view after its patches and the one of "first_scan_after_a_1M_delta_merge", which are left out
+    assert len(rows_f) == len(rows_w) and len(rows_f) % 2 == 0 and len(rows_f) // 2 - len(QUERIES) * per in (0, 1, 2), (kind, len(rows_f), len(rows_w))
     per_col = len(rows_f) // 2
     for ci, (col, w) in enumerate((("int32", 4), ("int64", 8))):
         for qi, q in enumerate(QUERIES):

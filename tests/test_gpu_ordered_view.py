@@ -405,3 +405,51 @@ def test_declarative_filter_takes_its_candidates_from_the_view():
             few = e.scan_filter(q, cap=7)
             assert len(few) == min(7, len(p0)) and np.all(np.isin(few, p0))
         assert e.index_ordered_info(FA)[1:] == (True, 1)
+
+
+def test_two_views_of_one_context_are_patched_by_the_same_refresh_and_filters_see_the_patch():
+    """Two ordered indexes of ONE context — an int32 column and a wide int64 column — written by the same merges: one refresh of the change log patches both (they share the
+    sort scratch, the result words and the one background rewrite the context allows at a time). After every round both answer ranges, counts, positions and the declarative
+    filter (candidates from the first term's view, pending patch included) like numpy; a large host-mode answer (beyond the small-answer path) comes back whole."""
+    R = 1_200_000                       # ord_n / 16 = 75k keys: rounds of ~50k changed rows per field go through the pending patch and its rewrite
+    rng = np.random.default_rng(515)
+    ids = streams.splitmix64_np(np.arange(1, R + 1, dtype=np.uint64))
+    age = rng.integers(0, 300, R).astype(np.int64)
+    score = rng.integers(-1000, 1000, R).astype(np.int64) << 33
+    with bmx.Engine(4 * R) as e:
+        e.load_rows(ids, np.full(R, FA, np.uint32), np.full(R, 5, np.int64), age)
+        e.load_rows(ids, np.full(R, FS, np.uint32), np.full(R, 5, np.int64), score)
+        e.index_build(FA); e.index_build(FS)
+        e.index_set_ordered(FA, 1); e.index_set_ordered(FS, 1)
+        _q(e, FA, ids, age, 10, 20); _q(e, FS, ids, score, 0, 5 << 33)
+        states = set()
+        for rnd in range(7):
+            k = rng.choice(R, 25_000, replace=False)
+            na = rng.integers(0, 300, len(k)).astype(np.int64); ns = rng.integers(-1000, 1000, len(k)).astype(np.int64) << 33
+            # ONE batch carries both fields' deltas (interleaved): both indexes see their winners in the same change log
+            bi = np.concatenate([ids[k], ids[k]]); bf = np.concatenate([np.full(len(k), FA, np.uint32), np.full(len(k), FS, np.uint32)])
+            bv = np.concatenate([na, ns]); perm = rng.permutation(len(bi))
+            e.merge_batch(bi[perm], bf[perm], np.full(len(bi), 10 + 2 * rnd, np.int64), bv[perm])          # (clocks ascend over all merges of the test: every delta wins)
+            age[k] = na; score[k] = ns
+            if rnd % 3 == 2:                # a round that writes only ONE of the two fields: the other view must be left alone (no patch counted)
+                _q(e, FA, ids, age, 1, 2)       # (this refresh patches BOTH views with the batch above)
+                before = e.index_ordered_stats(FS)["patches"]
+                k1 = rng.choice(R, 9_000, replace=False); n1 = rng.integers(0, 300, len(k1)).astype(np.int64)
+                _merge(e, FA, ids[k1], 11 + 2 * rnd, n1); age[k1] = n1
+                _q(e, FA, ids, age, 100, 110)
+                assert e.index_ordered_stats(FS)["patches"] == before
+            _check(e, FA, ids, age, 40, 60); _check(e, FS, ids, score, -(20 << 33), 20 << 33)
+            sa, ss = e.index_ordered_stats(FA), e.index_ordered_stats(FS)
+            assert sa["sorts"] == 1 and ss["sorts"] == 1 and e.index_ordered_info(FA)[1] and e.index_ordered_info(FS)[1], (rnd, sa, ss)
+            states.add((sa["pending_keys"] > 0, ss["pending_keys"] > 0))
+            big = e.scan_range(FA, 0, 299)                                   # every row: a host-mode answer far beyond the small-answer buffer
+            assert len(big) == R and np.array_equal(np.sort(big), np.sort(ids))
+            for q in ([(FA, 40, 45), (FS, -(100 << 33), 100 << 33)], [(FS, 0, 3 << 33), (FA, 0, 150)], [(FA, 299, 299)]):
+                m = np.ones(R, bool)
+                for f, lo, hi in q:
+                    v = age if f == FA else score
+                    m &= (v >= lo) & (v <= hi)
+                got = e.scan_filter(q)
+                assert np.array_equal(np.sort(got), np.sort(ids[m])), (rnd, q, len(got), int(m.sum()))
+        assert (True, True) in states and len(states) >= 2, states         # both views were queried with a patch pending, and in at least one other state
+        assert e.index_ordered_stats(FA)["rewrites"] >= 1 and e.index_ordered_stats(FS)["rewrites"] >= 1
