@@ -198,6 +198,7 @@ struct bmx_ctx {
   bool view_patching = true;          // BMX_VIEW_PATCH=0 in the environment: a change makes the view stale as in round 4 (A/B switch)
   volatile unsigned long long* hres = nullptr;                            // mapped page-locked result words (HRES_*): counts the host waits for arrive without a download
   uint32_t* view_err_host = nullptr; hipEvent_t view_ev = nullptr;      // a background rewrite's error word (page-locked host memory) and completion event
+  bool view_own_sort = false;         // BMX_VIEW_SORT=own: a new view is sorted by the patch path's own kernels (tile sort + merge passes) instead of rocPRIM's radix sort (A/B switch)
   bool view_pending = true;           // BMX_VIEW_PENDING=0: every patch rewrites the view's main run at once (no pending patch; A/B switch)
   // bmx_merge_notify: words (possibly in other GPUs' memory) that every merge's last workgroup sets to the number of merges finished since
   SeqPtrs notify{}; uint32_t n_notify = 0; uint64_t notify_seq = 0;
@@ -1401,6 +1402,40 @@ bool ensure_ordered_view(bmx_ctx* ctx, Index* ix) {
         hipMalloc(reinterpret_cast<void**>(&ix->s_ids), cap * sizeof(uint64_t)) != hipSuccess) return give_up();
     ix->ord_cap = cap; ix->ord_fits32 = ix->fits32;
   }
+  if (ctx->view_own_sort && n && n < 0xFFFFFFFFull) {
+    // A/B arm: the whole column through the patch path's sort — (value, position) keys, 4096-key tiles in LDS, then log2(n / 4096) merge-path passes between
+    // the view's columns and a scratch pair; a tombstone is the column type's minimum and sorts in front like every other value
+    void* tv = nullptr; uint32_t* tp = nullptr;
+    if (hipMalloc(&tv, n * vb) != hipSuccess || hipMalloc(reinterpret_cast<void**>(&tp), n * sizeof(uint32_t)) != hipSuccess) { (void)hipGetLastError(); if (tv) (void)hipFree(tv); return give_up(); }
+    const uint32_t gbo = (uint32_t)std::min<uint64_t>((n + 255) / 256, 8192);
+    unsigned passes = 0; for (uint64_t L = VIEW_SORT_TILE; L < n; L *= 2) passes++;
+    auto run = [&](auto tag) {
+      using T = decltype(tag);
+      const T* col = sizeof(T) == 4 ? reinterpret_cast<const T*>(ix->v32) : reinterpret_cast<const T*>(ix->v64);
+      T* bufv[2] = {static_cast<T*>(ix->s_val), static_cast<T*>(tv)}; uint32_t* bufp[2] = {ix->s_pos, tp};
+      int cur = passes & 1;                                             // the tile sort writes into the buffer from which `passes` swaps end in the view's columns
+      uint32_t* iota = bufp[cur ^ 1];                                   // (the other position buffer is free until the first pass writes it)
+      hipLaunchKernelGGL(k_iota_u32, dim3(gbo), dim3(256), 0, ctx->stream, iota, n);
+      ViewSegs S{}; S.base[0] = 0; S.len[0] = (uint32_t)n; S.base[1] = (uint32_t)n; S.len[1] = 0;
+      const uint32_t tiles = (uint32_t)((n + VIEW_SORT_TILE - 1) / VIEW_SORT_TILE);
+      S.blk0[0] = 0; S.blk0[1] = tiles; S.blk0[2] = tiles;
+      hipLaunchKernelGGL((k_view_tile_sort<T>), dim3(tiles), dim3(VIEW_SORT_THREADS), 0, ctx->stream, col, (const uint32_t*)iota, bufv[cur], bufp[cur], S);
+      ViewSegs P = S; P.blk0[1] = (uint32_t)((n + VIEW_PASS_KEYS - 1) / VIEW_PASS_KEYS); P.blk0[2] = P.blk0[1];
+      for (uint64_t L = VIEW_SORT_TILE; L < n; L *= 2) {
+        hipLaunchKernelGGL((k_view_merge_pass<T>), dim3(P.blk0[2]), dim3(256), 0, ctx->stream, (const T*)bufv[cur], (const uint32_t*)bufp[cur], bufv[cur ^ 1], bufp[cur ^ 1], P, (uint32_t)L);
+        cur ^= 1;
+      }
+    };
+    if (ix->fits32) run(int32_t{}); else run(int64_t{});
+    hipLaunchKernelGGL(k_view_gather_ids, dim3(gbo), dim3(256), 0, ctx->stream, (const uint32_t*)ix->s_pos, (uint32_t)n, (const uint64_t*)ix->ids, ix->s_ids);
+    hipError_t eo = hipGetLastError();
+    if (eo == hipSuccess) eo = hipStreamSynchronize(ctx->stream);
+    (void)hipFree(tv); (void)hipFree(tp);
+    if (eo != hipSuccess) return give_up();
+    ix->ord_n = n; ix->ord_content = ix->content; ix->stale_queries = 0; ix->ord_sorts++;
+    ix->last_sort_us = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t_sort).count();
+    return true;
+  }
   // the column's value range decides how many bits the sort has to look at (csrc/ordered_sort.hip: keys rebased to min = 1, tombstones = 0)
   const uint32_t gb = (uint32_t)std::min<uint64_t>((n + 255) / 256, 8192);
   long long mm[2] = {INT64_MAX, INT64_MIN};
@@ -1733,6 +1768,7 @@ int bmx_create_ex(int device, uint64_t capacity_rows, uint32_t max_load_pct, uin
   ctx->fixed_capacity = (flags & BMX_CTX_FIXED_CAPACITY) != 0;
   ctx->defer_enabled = !launches_are_serialized();
   { const char* vp = std::getenv("BMX_VIEW_PATCH"); if (vp && vp[0] == '0' && !vp[1]) ctx->view_patching = false; }
+  { const char* vs = std::getenv("BMX_VIEW_SORT"); if (vs && std::strcmp(vs, "own") == 0) ctx->view_own_sort = true; }
   { const char* vp = std::getenv("BMX_VIEW_PENDING"); if (vp && vp[0] == '0' && !vp[1]) ctx->view_pending = false; }
   { const char* kw = std::getenv("BMX_K1_WAVES"); if (kw && kw[0] >= '3' && kw[0] <= '8' && kw[0] != '7' && !kw[1]) ctx->k1_waves = kw[0] - '0'; }
   CR(hipMemsetAsync(ctx->ds, 0, sizeof(DevScalars), ctx->stream));

@@ -1,18 +1,15 @@
 #!/bin/bash
-# round 5: (7) id-output memory policies A/B, (3) sharded one-rank rehearsal A/B (wait folded into the scatter / deferral variants), (6) placement counters
-OUT=gpurun_out/r05/j; mkdir -p $OUT
-timeout -k 10 300 python bench_micro/scan_nt_emit_ab.py 100000000 > $OUT/scan_nt_emit_ab.log 2>&1; r=$?; grep -v amdgpu.ids $OUT/scan_nt_emit_ab.log; [ $r -eq 124 ] && exit 124
-for rep in 1 2; do for cfg in "1 0" "0 0" "1 1" "1 2" "0 1"; do set -- $cfg
-  BMX_PART_WAIT_FOLD=$1 BMX_SHARDED_DEFER=$2 timeout -k 10 200 python bench.py --force-sharded --no-cpu-baseline > $OUT/sh_fold$1_defer$2_$rep.json 2> $OUT/sh_fold$1_defer$2_$rep.err; r=$?
-  echo "fold=$1 defer=$2 rep=$rep rc=$r $(python -c "import json; j=json.load(open('$OUT/sh_fold$1_defer$2_$rep.json')); print('us/step %.2f' % (j['ms_per_step']*1e3), j['roofline']['kernel_ms'], j['verified'])" 2>&1 | tail -1)"
-  [ $r -eq 124 ] && exit 124
-done; done
-cd /tmp && export TMPDIR=/tmp
-pass() { name=$1; shift; BMX_TABLE_PLACEMENT_TRIES=8 BMX_PLACEMENT_DEBUG=1 timeout -k 10 200 rocprofv3 --kernel-trace --pmc "$@" --output-format csv -d $GRAFT_REPO_ROOT/$OUT/pc_$name -- python3 $GRAFT_REPO_ROOT/bench_micro/placement_counters.py > $GRAFT_REPO_ROOT/$OUT/pc_$name.log 2>&1; r=$?
-  echo "pmc pass $name rc=$r"; grep "bmx placement\|placement:" $GRAFT_REPO_ROOT/$OUT/pc_$name.log | tail -9; if [ $r -eq 124 ]; then exit 124; fi; }
-pass utcl1 TCP_UTCL1_REQUEST_sum TCP_UTCL1_TRANSLATION_MISS_sum TCP_UTCL1_TRANSLATION_HIT_sum
-pass ea TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_LEVEL_sum TCC_EA0_RDREQ_DRAM_sum
-pass stall TCC_EA0_RDREQ_DRAM_CREDIT_STALL_sum TCC_TAG_STALL_sum TCC_EA0_WRREQ_sum
-pass chan TCC_EA0_RDREQ
-find $GRAFT_REPO_ROOT/$OUT -name "*.csv" | head -20
+OUT=gpurun_out/r05/t; mkdir -p $OUT
+timeout -k 10 400 python -m pytest tests/test_gpu_ordered_view.py -m gpu -q -x > $OUT/pytest_sel.log 2>&1; rc=$?; tail -6 $OUT/pytest_sel.log; echo "pytest rc=$rc"
+[ $rc -eq 124 ] && exit 124
+[ $rc -ne 0 ] && exit $rc
+# A/B of the first sort of a view: rocPRIM's radix sort (default) against the patch path's own kernels over the whole column
+for arm in library own; do
+  if [ $arm = own ]; then export BMX_VIEW_SORT=own; else unset BMX_VIEW_SORT; fi
+  for cfg in "10000000 int32" "100000000 int32" "100000000 wide"; do set -- $cfg
+    timeout -k 10 300 python3 bench_micro/view_patch.py $1 $2 1 > $OUT/sort_${arm}_$1_$2.log 2>&1; r=$?
+    echo "$arm: $(grep 'first sort' $OUT/sort_${arm}_$1_$2.log)"
+    if [ $r -eq 124 ]; then exit 124; fi
+  done
+done
 exit 0

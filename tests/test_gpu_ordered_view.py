@@ -453,3 +453,38 @@ def test_two_views_of_one_context_are_patched_by_the_same_refresh_and_filters_se
                 assert np.array_equal(np.sort(got), np.sort(ids[m])), (rnd, q, len(got), int(m.sum()))
         assert (True, True) in states and len(states) >= 2, states         # both views were queried with a patch pending, and in at least one other state
         assert e.index_ordered_stats(FA)["rewrites"] >= 1 and e.index_ordered_stats(FS)["rewrites"] >= 1
+
+
+@pytest.mark.parametrize("wide", [False, True])
+def test_a_view_sorted_by_the_patch_paths_own_kernels_equals_the_library_sorted_one(monkeypatch, wide):
+    """BMX_VIEW_SORT=own (A/B switch, read at create): a new view is sorted by k_view_tile_sort + k_view_merge_pass over the whole column instead of rocPRIM's radix
+    sort. Both arms list the positions in exactly (value, position) order of their own columns, element for element — tombstones in front, a ragged last tile, more rows than one pass covers."""
+    sh = 35 if wide else 0
+    R = 1_300_077
+    rng = np.random.default_rng(8 + wide)
+    ids = streams.splitmix64_np(np.arange(1, R + 1, dtype=np.uint64))
+    vals = (rng.integers(-700, 700, R).astype(np.int64)) << sh
+    dead = rng.choice(R, 3000, replace=False)
+    F = FS if wide else FA
+    listings = []
+    for arm in ("own", "library"):
+        if arm == "own":
+            monkeypatch.setenv("BMX_VIEW_SORT", "own")
+        else:
+            monkeypatch.delenv("BMX_VIEW_SORT", raising=False)
+        with bmx.Engine(2 * R) as e:
+            e.load_rows(ids, np.full(R, F, np.uint32), np.full(R, 5, np.int64), vals)
+            e.put_rows(ids[dead], np.full(len(dead), F, np.uint32), np.full(len(dead), 9, np.int64), np.full(len(dead), VAL_DELETED, np.int64))
+            e.index_build(F); e.index_set_ordered(F, 1)
+            alive = np.ones(R, bool); alive[dead] = False
+            _check(e, F, ids, vals, -(3 << sh), 4 << sh, alive)
+            assert e.index_ordered_info(F)[1:] == (True, 1)
+            got = e.scan_range_pos(F, -(1 << 60), 1 << 60).astype(np.int64)
+            col = e.index_ids(F)
+            order = np.argsort(ids); v_at = vals[order][np.searchsorted(ids[order], col)]        # value of the row at every index position
+            live = np.flatnonzero(np.isin(col, ids[alive]))
+            want = live[np.lexsort((live, v_at[live]))]                                           # (value, position) ascending
+            bad = np.flatnonzero(got != want) if len(got) == len(want) else np.array([-1])
+            assert len(bad) == 0, (arm, len(got), len(want), bad[:5], got[bad[:5]] if bad[0] >= 0 else None, want[bad[:5]] if bad[0] >= 0 else None)
+            listings.append(len(got))           # (two engines may number their index positions differently: each arm is held against its own columns)
+    assert listings[0] == listings[1] == R - len(dead)
