@@ -1,12 +1,12 @@
 #!/bin/bash
-OUT=gpurun_out/r05/o; mkdir -p $OUT
+OUT=gpurun_out/r05/w; mkdir -p $OUT
 
-timeout -k 10 500 python -m pytest tests/test_gpu_ordered_view.py tests/test_gpu_index_maintenance.py -m gpu -q -x > $OUT/pytest_sel.log 2>&1; rc=$?; tail -6 $OUT/pytest_sel.log; echo "pytest rc=$rc"
+rc=0
 [ $rc -eq 124 ] && exit 124
 [ $rc -ne 0 ] && exit $rc
 cd /tmp && export TMPDIR=/tmp
 for cfg in "10000000 int32" "100000000 int32" "100000000 wide"; do set -- $cfg
-  timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $GRAFT_REPO_ROOT/$OUT/vp_$1_$2 -- python3 $GRAFT_REPO_ROOT/bench_micro/view_patch.py $1 $2 8 > $GRAFT_REPO_ROOT/$OUT/vp_$1_$2.log 2>&1; r=$?
+  timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $GRAFT_REPO_ROOT/$OUT/vp_$1_$2 -- python3 $GRAFT_REPO_ROOT/bench_micro/view_patch.py $1 $2 9 > $GRAFT_REPO_ROOT/$OUT/vp_$1_$2.log 2>&1; r=$?
   grep -v "amdgpu.ids\|^E2026\|^W2026" $GRAFT_REPO_ROOT/$OUT/vp_$1_$2.log | tail -5
   f=$(find $GRAFT_REPO_ROOT/$OUT/vp_$1_$2 -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && cp $f $GRAFT_REPO_ROOT/$OUT/vp_$1_$2_kernel_stats.csv
   python3 - $GRAFT_REPO_ROOT/$OUT/vp_$1_$2_kernel_stats.csv <<'PY'
