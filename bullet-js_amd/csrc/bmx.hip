@@ -79,6 +79,7 @@ struct Index {
   // runs; the streaming merge into main runs when they have grown past ord_n / 16 keys. Two sets: a merge writes the other one.
   void* pd_v[2] = {nullptr, nullptr}; uint32_t* pd_p[2] = {nullptr, nullptr};
   void* pi_v[2] = {nullptr, nullptr}; uint32_t* pi_p[2] = {nullptr, nullptr}; uint64_t* pi_ids[2] = {nullptr, nullptr};
+  uint8_t* pi_dead = nullptr;          // one byte per key of pi: set for the inserts a refresh's deleted keys cancel (scratch of the join)
   uint64_t npd = 0, npi = 0, pend_cap = 0; int pcur = 0 /* the current set of pd */, icur = 0 /* the current set of pi */;
   // the rewrite of main (main - pd + pi -> the second set of columns) runs BEHIND the answer of the query that found it due: in flight until its event has completed
   // and its error word has been looked at; until then (main, pd, pi) go on answering
@@ -90,6 +91,8 @@ void free_pending(Index& ix) {
     if (ix.pi_v[i]) (void)hipFree(ix.pi_v[i]); if (ix.pi_p[i]) (void)hipFree(ix.pi_p[i]); if (ix.pi_ids[i]) (void)hipFree(ix.pi_ids[i]);
     ix.pd_v[i] = nullptr; ix.pd_p[i] = nullptr; ix.pi_v[i] = nullptr; ix.pi_p[i] = nullptr; ix.pi_ids[i] = nullptr;
   }
+  if (ix.pi_dead) (void)hipFree(ix.pi_dead);
+  ix.pi_dead = nullptr;
   ix.npd = ix.npi = 0; ix.pend_cap = 0; ix.pcur = 0; ix.icur = 0; ix.rewrite_due = false; ix.rewrite_inflight = false;
 }
 void free_ordered_view(Index& ix) {
@@ -1007,13 +1010,15 @@ int ensure_pending(bmx_ctx* ctx, Index& ix, uint64_t need) {
   HIPCHK(hipStreamSynchronize(ctx->stream));
   const uint64_t cap = need + need / 8 + (1u << 16);
   void* nv[2][2] = {{nullptr, nullptr}, {nullptr, nullptr}}; uint32_t* np[2][2] = {{nullptr, nullptr}, {nullptr, nullptr}}; uint64_t* ni[2] = {nullptr, nullptr};
-  bool ok = true;
+  uint8_t* nd = nullptr;
+  bool ok = hipMalloc(reinterpret_cast<void**>(&nd), cap) == hipSuccess;
   for (int i = 0; i < 2 && ok; i++)
     ok = hipMalloc(&nv[0][i], cap * sizeof(T)) == hipSuccess && hipMalloc(reinterpret_cast<void**>(&np[0][i]), cap * 4) == hipSuccess && hipMalloc(&nv[1][i], cap * sizeof(T)) == hipSuccess &&
          hipMalloc(reinterpret_cast<void**>(&np[1][i]), cap * 4) == hipSuccess && hipMalloc(reinterpret_cast<void**>(&ni[i]), cap * 8) == hipSuccess;
   if (!ok) {
     (void)hipGetLastError();
     for (int i = 0; i < 2; i++) { for (int k = 0; k < 2; k++) { if (nv[k][i]) (void)hipFree(nv[k][i]); if (np[k][i]) (void)hipFree(np[k][i]); } if (ni[i]) (void)hipFree(ni[i]); }
+    if (nd) (void)hipFree(nd);
     return fail(ctx, BMX_ERR_NOMEM, "view patch: out of device memory");
   }
   const int c = ix.pcur, ci = ix.icur;
@@ -1023,6 +1028,7 @@ int ensure_pending(bmx_ctx* ctx, Index& ix, uint64_t need) {
   const uint64_t kd = ix.npd, ki = ix.npi; const bool due = ix.rewrite_due;
   free_pending(ix);
   for (int i = 0; i < 2; i++) { ix.pd_v[i] = nv[0][i]; ix.pd_p[i] = np[0][i]; ix.pi_v[i] = nv[1][i]; ix.pi_p[i] = np[1][i]; ix.pi_ids[i] = ni[i]; }
+  ix.pi_dead = nd;
   ix.npd = kd; ix.npi = ki; ix.pend_cap = cap; ix.pcur = c; ix.icur = ci; ix.rewrite_due = due;
   return BMX_OK;
 }
@@ -1178,7 +1184,8 @@ int patch_view_t(bmx_ctx* ctx, Index& ix, uint64_t c, uint64_t n0, uint64_t adde
       unsigned long long hc[2] = {0, 0};
       if (c) {
         ctx->hres[HRES_SPLIT] = ctx->hres[HRES_SPLIT + 1] = ~0ull;
-        hipLaunchKernelGGL((k_view_flag_in<T>), dim3((uint32_t)((c + 255) / 256)), dim3(256), 0, st, Dv, Dp, (uint32_t)c, (const T*)piv[ic], (const uint32_t*)ix.pi_p[ic], (uint32_t)ix.npi, flag);
+        (void)hipMemsetAsync(ix.pi_dead, 0, ix.npi, st);
+        hipLaunchKernelGGL((k_view_flag_in<T>), dim3((uint32_t)((c + 255) / 256)), dim3(256), 0, st, Dv, Dp, (uint32_t)c, (const T*)piv[ic], (const uint32_t*)ix.pi_p[ic], (uint32_t)ix.npi, flag, ix.pi_dead);
         SelGeom g = sel_geom<1>(c);
         for (uint32_t want = 0; want < 2; want++) {
           PredFlag PF{flag, want};
@@ -1195,12 +1202,12 @@ int patch_view_t(bmx_ctx* ctx, Index& ix, uint64_t c, uint64_t n0, uint64_t adde
       // pi' = pi - (deleted keys that were pending inserts) + inserted keys;  pd' = pd + (deleted keys of main): balanced two-run merges (k_view_merge2)
       int ia = ic; uint64_t na = ix.npi;
       if (cI) {                                                           // the cancelled inserts leave pi: an ordered select into the other set
-        PredNotIn<T> PN{(const T*)piv[ic], (const uint32_t*)ix.pi_p[ic], (const T*)(sel_v + c), (const uint32_t*)(sel_p + c), (uint32_t)cI};
+        PredFlag PN{(const uint8_t*)ix.pi_dead, 0u};                           // (k_view_flag_in marked them while it looked the deleted keys up)
         EmitRun<T> ER{(const T*)piv[ic], (const uint32_t*)ix.pi_p[ic], (const uint64_t*)ix.pi_ids[ic], piv[ic ^ 1], ix.pi_p[ic ^ 1], ix.pi_ids[ic ^ 1]};
         FinishCount FC{&ctx->ds->view_tmp[0]};
         SelGeom g = sel_geom<1>(ix.npi);
-        hipLaunchKernelGGL((k_sel_count<PredNotIn<T>>), dim3(g.blocks), dim3(SEL_THREADS), 0, st, PN, ix.npi, g.tiles_per_block, ctx->block_counts);
-        hipLaunchKernelGGL((k_sel_write<PredNotIn<T>, EmitRun<T>, FinishCount>), dim3(g.blocks), dim3(SEL_THREADS), 0, st, PN, ER, FC, ix.npi, g.tiles_per_block, ctx->block_counts);
+        hipLaunchKernelGGL((k_sel_count<PredFlag>), dim3(g.blocks), dim3(SEL_THREADS), 0, st, PN, ix.npi, g.tiles_per_block, ctx->block_counts);
+        hipLaunchKernelGGL((k_sel_write<PredFlag, EmitRun<T>, FinishCount>), dim3(g.blocks), dim3(SEL_THREADS), 0, st, PN, ER, FC, ix.npi, g.tiles_per_block, ctx->block_counts);
         ia = ic ^ 1; na = ix.npi - cI;
       }
       ViewRun<T> Ai{piv[ia], ix.pi_p[ia], ix.pi_ids[ia]}, Zi{piv[ia ^ 1], ix.pi_p[ia ^ 1], ix.pi_ids[ia ^ 1]};

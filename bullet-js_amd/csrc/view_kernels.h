@@ -547,28 +547,20 @@ __global__ __launch_bounds__(256) void k_view_merge2(ViewRun<T> A, uint32_t la, 
     ia += takeA ? 1u : 0u; ib += takeA ? 0u : 1u;
   }
 }
-// flag[i] = 1 when sorted key i of D is one of the sorted keys of I (one binary search per key, once: the two selects that split D read the flags)
+// flag[i] = 1 when sorted key i of D is one of the sorted keys of I (one binary search per key, once: the two selects that split D read the flags), and
+// dead[j] = 1 for the key j of I it is (zeroed by the caller)
 template <class T>
-__global__ __launch_bounds__(256) void k_view_flag_in(const T* __restrict__ dv, const uint32_t* __restrict__ dp, uint32_t nd, const T* __restrict__ iv, const uint32_t* __restrict__ ip, uint32_t ni, uint8_t* __restrict__ flag) {
+__global__ __launch_bounds__(256) void k_view_flag_in(const T* __restrict__ dv, const uint32_t* __restrict__ dp, uint32_t nd, const T* __restrict__ iv, const uint32_t* __restrict__ ip, uint32_t ni, uint8_t* __restrict__ flag,
+                                                      uint8_t* __restrict__ dead) {
   const uint32_t i = blockIdx.x * 256u + threadIdx.x;
   if (i >= nd) return;
   const T kv = dv[i]; const uint32_t kp = dp[i];
   const uint32_t at = (uint32_t)vk_bound<T>(iv, ip, 0, ni, kv, kp);
-  flag[i] = (at < ni && iv[at] == kv && ip[at] == kp) ? 1u : 0u;
+  const bool hit = at < ni && iv[at] == kv && ip[at] == kp;
+  flag[i] = hit ? 1u : 0u;
+  if (hit) dead[at] = 1u;                    // the insert it cancels (keys are unique: one writer per byte); the select that takes them out of I reads these
 }
 struct PredFlag { static constexpr int E = 1; const uint8_t* flag; uint32_t want; __device__ uint32_t mask(uint64_t first, uint64_t n) const { return first < n && flag[first] == want ? 1u : 0u; } };
-// keys of run X (with ids) that are NOT among the sorted keys K (the cancelled inserts): the select that takes them out of the pending run
-template <class T>
-struct PredNotIn {
-  static constexpr int E = 1;
-  const T* xv; const uint32_t* xp; const T* kv; const uint32_t* kp; uint32_t nk;
-  __device__ uint32_t mask(uint64_t first, uint64_t n) const {
-    if (first >= n) return 0u;
-    const T v = xv[first]; const uint32_t p = xp[first];
-    const uint32_t at = (uint32_t)vk_bound<T>(kv, kp, 0, nk, v, p);
-    return (at < nk && kv[at] == v && kp[at] == p) ? 0u : 1u;
-  }
-};
 template <class T>
 struct EmitRun { const T* xv; const uint32_t* xp; const uint64_t* xi; T* ov; uint32_t* op; uint64_t* oi; __device__ void operator()(uint64_t rank, uint64_t i) const { ov[rank] = xv[i]; op[rank] = xp[i]; oi[rank] = xi[i]; } };
 
