@@ -201,6 +201,7 @@ struct bmx_ctx {
   bool view_patching = true;          // BMX_VIEW_PATCH=0 in the environment: a change makes the view stale as in round 4 (A/B switch)
   volatile unsigned long long* hres = nullptr;                            // mapped page-locked result words (HRES_*): counts the host waits for arrive without a download
   uint32_t* view_err_host = nullptr; hipEvent_t view_ev = nullptr;      // a background rewrite's error word (page-locked host memory) and completion event
+  int view_test_fail = 0;             // BMX_TEST_VIEW_FAIL (test hook): 1 = every patch reports failure (the view goes stale), 2 = every background rewrite reports failure (main + patch go on answering)
   bool view_own_sort = false;         // BMX_VIEW_SORT=own: a new view is sorted by the patch path's own kernels (tile sort + merge passes) instead of rocPRIM's radix sort (A/B switch)
   bool view_pending = true;           // BMX_VIEW_PENDING=0: every patch rewrites the view's main run at once (no pending patch; A/B switch)
   // bmx_merge_notify: words (possibly in other GPUs' memory) that every merge's last workgroup sets to the number of merges finished since
@@ -1058,7 +1059,7 @@ void finish_rewrite(bmx_ctx* ctx, Index& ix, bool wait) {
   if (wait) (void)hipEventSynchronize(ctx->view_ev);
   else if (hipEventQuery(ctx->view_ev) != hipSuccess) { (void)hipGetLastError(); return; }
   ix.rewrite_inflight = false;
-  if (*ctx->view_err_host == 0) {
+  if (*ctx->view_err_host == 0 && ctx->view_test_fail != 2) {
     std::swap(ix.s_val, ix.s_val2); std::swap(ix.s_pos, ix.s_pos2); std::swap(ix.s_ids, ix.s_ids2); std::swap(ix.ord_cap, ix.ord_cap2);
     ix.ord_n = ix.rewrite_nz; ix.npd = ix.npi = 0; ix.ord_merges++;
   }
@@ -1106,6 +1107,7 @@ void view_before_use(bmx_ctx* ctx, Index* ix, bool wait) {   // in front of anyt
 template <class T>
 int patch_view_t(bmx_ctx* ctx, Index& ix, uint64_t c, uint64_t n0, uint64_t added) {
   const auto t0 = std::chrono::steady_clock::now();
+  if (ctx->view_test_fail == 1) return 1;
   finish_rewrite<T>(ctx, ix, /*wait=*/true);            // a rewrite still in flight is looked at first: the change run's keys are keys of the view as it is NOW
   const uint64_t m = c + added, ktot = c + m, nx = ix.ord_n;
   if (nx + m >= 0xFFFFFFFFull || ktot >= 0xFFFFFFFFull) return 1;
@@ -1775,6 +1777,7 @@ int bmx_create_ex(int device, uint64_t capacity_rows, uint32_t max_load_pct, uin
   ctx->fixed_capacity = (flags & BMX_CTX_FIXED_CAPACITY) != 0;
   ctx->defer_enabled = !launches_are_serialized();
   { const char* vp = std::getenv("BMX_VIEW_PATCH"); if (vp && vp[0] == '0' && !vp[1]) ctx->view_patching = false; }
+  { const char* vf = std::getenv("BMX_TEST_VIEW_FAIL"); if (vf && (vf[0] == '1' || vf[0] == '2') && !vf[1]) ctx->view_test_fail = vf[0] - '0'; }
   { const char* vs = std::getenv("BMX_VIEW_SORT"); if (vs && std::strcmp(vs, "own") == 0) ctx->view_own_sort = true; }
   { const char* vp = std::getenv("BMX_VIEW_PENDING"); if (vp && vp[0] == '0' && !vp[1]) ctx->view_pending = false; }
   { const char* kw = std::getenv("BMX_K1_WAVES"); if (kw && kw[0] >= '3' && kw[0] <= '8' && kw[0] != '7' && !kw[1]) ctx->k1_waves = kw[0] - '0'; }

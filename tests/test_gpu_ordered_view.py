@@ -488,3 +488,39 @@ def test_a_view_sorted_by_the_patch_paths_own_kernels_equals_the_library_sorted_
             assert len(bad) == 0, (arm, len(got), len(want), bad[:5], got[bad[:5]] if bad[0] >= 0 else None, want[bad[:5]] if bad[0] >= 0 else None)
             listings.append(len(got))           # (two engines may number their index positions differently: each arm is held against its own columns)
     assert listings[0] == listings[1] == R - len(dead)
+
+
+@pytest.mark.parametrize("mode", ["1", "2"])
+def test_failures_of_the_patch_and_of_the_background_rewrite_cost_time_never_answers(monkeypatch, mode):
+    """BMX_TEST_VIEW_FAIL (test hook, read at create). 1: every patch reports failure — the view goes stale, the queries scan the column, the N-th re-sorts, exactly round 4's
+    behaviour. 2: every background rewrite of main reports failure — main and the pending patch were never written and go on answering, the patch keeps growing past its
+    threshold (its buffers grow with it), every later patch tries again. Answers equal numpy throughout."""
+    monkeypatch.setenv("BMX_TEST_VIEW_FAIL", mode)
+    R = 1_000_000                       # ord_n / 16 = 62.5k keys
+    rng = np.random.default_rng(40 + int(mode))
+    ids = streams.splitmix64_np(np.arange(1, R + 1, dtype=np.uint64))
+    vals = rng.integers(0, 400, R).astype(np.int64)
+    with bmx.Engine(3 * R) as e:
+        monkeypatch.delenv("BMX_TEST_VIEW_FAIL")
+        e.load_rows(ids, np.full(R, FA, np.uint32), np.full(R, 5, np.int64), vals)
+        e.index_build(FA); e.index_set_ordered(FA, 2)
+        _q(e, FA, ids, vals, 5, 9); _q(e, FA, ids, vals, 5, 9)                 # the second query sorts (N = 2)
+        assert e.index_ordered_info(FA) == (2, True, 1)
+        pend = []
+        for rnd in range(7):
+            k = rng.choice(R, 30_000, replace=False)
+            nv = rng.integers(0, 400, len(k)).astype(np.int64)
+            _merge(e, FA, ids[k], 10 + rnd, nv); vals[k] = nv
+            _check(e, FA, ids, vals, 100, 140)
+            st = e.index_ordered_stats(FA)
+            if mode == "1":
+                assert st["patches"] == 0 and not e.index_ordered_info(FA)[1] or st["sorts"] >= 2, (rnd, st)     # stale until the second query since the change sorts again
+                _q(e, FA, ids, vals, 0, 399)
+            else:
+                assert st["sorts"] == 1 and st["patches"] == rnd + 1 and st["rewrites"] == 0 and e.index_ordered_info(FA)[1], (rnd, st)
+                pend.append(st["pending_keys"])
+            _check(e, FA, ids, vals, 0, 0); _check(e, FA, ids, vals, 399, 399)
+        if mode == "1":
+            assert e.index_ordered_stats(FA)["sorts"] >= 4
+        else:
+            assert pend == sorted(pend) and pend[-1] > 3 * (R // 16), pend          # nothing was ever folded into main: the patch only grows, well past its threshold
