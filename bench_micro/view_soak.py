@@ -67,5 +67,6 @@ with bmx.Engine(capacity_rows=4 * R, device=0) as e:
         if rnd % 25 == 0:
             print("round %d ok: %d rows, %s, %.0f s" % (rnd, len(ids), e.index_ordered_stats(F), time.time() - t_start), flush=True)
     st = e.index_ordered_stats(F)
+    print("index refreshes (full rebuilds, from the change log):", e.index_refresh_counts())
     print("SOAK OK: %d rounds, %d rows at the end, domain %d%s, seed %d: %s" % (ROUNDS, len(ids), DOM, " (wide)" if wide else "", seed, st))
     assert st["sorts"] <= 2, st

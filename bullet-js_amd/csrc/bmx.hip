@@ -1111,10 +1111,13 @@ int patch_view_t(bmx_ctx* ctx, Index& ix, uint64_t c, uint64_t n0, uint64_t adde
   finish_rewrite<T>(ctx, ix, /*wait=*/true);            // a rewrite still in flight is looked at first: the change run's keys are keys of the view as it is NOW
   const uint64_t m = c + added, ktot = c + m, nx = ix.ord_n;
   if (nx + m >= 0xFFFFFFFFull || ktot >= 0xFFFFFFFFull) return 1;
-  auto soft = [&](int) { g_err.clear(); ctx->err.clear(); (void)hipGetLastError(); return 1; };
+  auto soft = [&](int line) {
+    if (std::getenv("BMX_VIEW_DEBUG")) std::fprintf(stderr, "bmx: view patch of field %u gave up (bmx.hip:%d): %s\n", ix.field, line, ctx->err.c_str());
+    g_err.clear(); ctx->err.clear(); (void)hipGetLastError(); return 1;
+  };
   const uint64_t thr = std::max<uint64_t>(nx / 16, 1u << 16);
   const uint32_t ntiles_main = (uint32_t)((nx + VIEW_TILE - 1) / VIEW_TILE);
-  if (!ensure_hres(ctx) || ensure_view_scratch(ctx, ktot, std::max<uint64_t>(ntiles_main, (ix.npi + ix.npd + VIEW_TILE) / VIEW_TILE + 2))) return soft(0);
+  if (!ensure_hres(ctx) || ensure_view_scratch(ctx, ktot, std::max<uint64_t>(ntiles_main, (ix.npi + ix.npd + VIEW_TILE) / VIEW_TILE + 2))) return soft(__LINE__);
   hipStream_t st = ctx->stream;
   T* kv[2] = {static_cast<T*>(ctx->vk_v[0]), static_cast<T*>(ctx->vk_v[1])};
   uint32_t* kp[2] = {ctx->vk_p[0], ctx->vk_p[1]};
@@ -1155,15 +1158,15 @@ int patch_view_t(bmx_ctx* ctx, Index& ix, uint64_t c, uint64_t n0, uint64_t adde
   const bool have = ix.npd + ix.npi > 0;
   if (!ctx->view_pending || (!have && ktot > thr)) {
     // the run alone is worth a rewrite of main (small indexes: always), or the pending patch is switched off (BMX_VIEW_PENDING=0)
-    if (have) return soft(0);
-    if (c > nx || !rewrite_main(Dv, Dp, c, Iv, Ip, m)) return soft(0);
+    if (have) return soft(__LINE__);
+    if (c > nx || !rewrite_main(Dv, Dp, c, Iv, Ip, m)) return soft(__LINE__);
   } else {
     // room for the patch at its largest (a rewrite falls due beyond thr keys; the run that crosses the line is still taken in), allocated once: a growing
     // buffer would put its reallocation in front of some query's answer
-    if (ensure_pending<T>(ctx, ix, std::max<uint64_t>(std::max<uint64_t>(ix.npd + c, ix.npi + m), thr + 2 * std::max<uint64_t>(c, m)))) return soft(0);
+    if (ensure_pending<T>(ctx, ix, std::max<uint64_t>(std::max<uint64_t>(ix.npd + c, ix.npi + m), thr + 2 * std::max<uint64_t>(c, m)))) return soft(__LINE__);
     if (!ctx->view_err_host && hipHostMalloc(reinterpret_cast<void**>(&ctx->view_err_host), sizeof(uint32_t), hipHostMallocDefault) != hipSuccess) { (void)hipGetLastError(); ctx->view_err_host = nullptr; }
     if (!ctx->view_ev && hipEventCreateWithFlags(&ctx->view_ev, hipEventDisableTiming) != hipSuccess) { (void)hipGetLastError(); ctx->view_ev = nullptr; }
-    if (!ix.s_val2 && !ensure_view_spare<T>(ctx, ix, nx + thr + 2 * m)) return soft(0);     // (the rewrite's target, also allocated now rather than in front of a later answer)
+    if (!ix.s_val2 && !ensure_view_spare<T>(ctx, ix, nx + thr + 2 * m)) return soft(__LINE__);     // (the rewrite's target, also allocated now rather than in front of a later answer)
     T* pdv[2] = {static_cast<T*>(ix.pd_v[0]), static_cast<T*>(ix.pd_v[1])}; T* piv[2] = {static_cast<T*>(ix.pi_v[0]), static_cast<T*>(ix.pi_v[1])};
     auto merge2 = [&](bool ids, ViewRun<T> A, uint64_t la, const T* bv, const uint32_t* bp, uint64_t lb, ViewRun<T> Z) {
       if (la + lb == 0) return;
@@ -1176,7 +1179,7 @@ int patch_view_t(bmx_ctx* ctx, Index& ix, uint64_t c, uint64_t n0, uint64_t adde
       (void)hipMemcpyAsync(pdv[dc], Dv, c * sizeof(T), hipMemcpyDeviceToDevice, st); (void)hipMemcpyAsync(ix.pd_p[dc], Dp, c * 4, hipMemcpyDeviceToDevice, st);
       ViewRun<T> none{nullptr, nullptr, nullptr}, Zi{piv[ic], ix.pi_p[ic], ix.pi_ids[ic]};
       merge2(true, none, 0, Iv, Ip, m, Zi);                             // (the inserted keys with their ids)
-      if (finish()) return soft(0);
+      if (finish()) return soft(__LINE__);
       ix.npd = c; ix.npi = m;
     } else {
       // 2. which deleted keys are pending inserted keys (they cancel), which are keys of main (they join pd)? one flag per key, two ordered selects by flag
@@ -1196,9 +1199,9 @@ int patch_view_t(bmx_ctx* ctx, Index& ix, uint64_t c, uint64_t n0, uint64_t adde
           hipLaunchKernelGGL((k_sel_count<PredFlag>), dim3(g.blocks), dim3(SEL_THREADS), 0, st, PF, c, g.tiles_per_block, ctx->block_counts);
           hipLaunchKernelGGL((k_sel_write<PredFlag, EmitKeys<T>, FinishCount>), dim3(g.blocks), dim3(SEL_THREADS), 0, st, PF, EK, FC, c, g.tiles_per_block, ctx->block_counts);
         }
-        if (hipStreamSynchronize(st) != hipSuccess) return soft(0);
+        if (hipStreamSynchronize(st) != hipSuccess) return soft(__LINE__);
         hc[0] = ctx->hres[HRES_SPLIT]; hc[1] = ctx->hres[HRES_SPLIT + 1];
-        if (hc[0] + hc[1] != c || hc[1] > ix.npi) return soft(0);
+        if (hc[0] + hc[1] != c || hc[1] > ix.npi) return soft(__LINE__);
       }
       const uint64_t cX = hc[0], cI = hc[1];
       // pi' = pi - (deleted keys that were pending inserts) + inserted keys;  pd' = pd + (deleted keys of main): balanced two-run merges (k_view_merge2)
@@ -1216,7 +1219,7 @@ int patch_view_t(bmx_ctx* ctx, Index& ix, uint64_t c, uint64_t n0, uint64_t adde
       if (m) merge2(true, Ai, na, Iv, Ip, m, Zi);
       ViewRun<T> Ad{pdv[dc], ix.pd_p[dc], nullptr}, Zd{pdv[dc ^ 1], ix.pd_p[dc ^ 1], nullptr};
       if (cX) merge2(false, Ad, ix.npd, (const T*)sel_v, (const uint32_t*)sel_p, cX, Zd);
-      if (finish()) return soft(0);
+      if (finish()) return soft(__LINE__);
       ix.icur = m ? ia ^ 1 : ia; if (cX) ix.pcur = dc ^ 1;
       ix.npd += cX; ix.npi = na + m;
     }
