@@ -6,6 +6,7 @@ sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "bullet-js_amd")
 import numpy as np, torch, bmx
 from bmx import synth
 R = int(sys.argv[1]) if len(sys.argv) > 1 else 100_000_000
+ARMS = tuple(sys.argv[2].split(",")) if len(sys.argv) > 2 else ("0", "1", "2", "3")       # bit 2 (4): streamed blocks keep 16 loads per lane in flight instead of 8
 dev = torch.device("cuda", 0)
 fa = synth.fnv1a32("n:age")
 with bmx.Engine(capacity_rows=R + 1024, device=0) as e:
@@ -18,10 +19,10 @@ with bmx.Engine(capacity_rows=R + 1024, device=0) as e:
     e.index_build(fa)
     out_ids = torch.zeros(R, dtype=torch.int64, device=dev); n_out = torch.zeros(1, dtype=torch.int64, device=dev)
     torch.cuda.synchronize()
-    for name, lo, hi in [("1%", 100, 109), ("10%", 100, 199), ("50%", 0, 499)]:
+    for name, lo, hi in [("1%", 100, 109), ("10%", 100, 199), ("30%", 0, 299), ("50%", 0, 499), ("100%", 0, 999)]:
         res, chk = {}, set()
         for rnd in range(3):
-            for arm in ("0", "1", "2", "3"):
+            for arm in ARMS:
                 os.environ["BMX_SCAN_NT"] = arm
                 for _ in range(3): e.scan_range_dev(fa, lo, hi, out_ids, R, n_out)
                 e.sync(); e.timer_start()
@@ -29,4 +30,4 @@ with bmx.Engine(capacity_rows=R + 1024, device=0) as e:
                 res.setdefault(arm, []).append(e.timer_stop() / 10 * 1e3)
                 chk.add(int(out_ids[:int(n_out.item())].sum().item()))
         assert len(chk) == 1
-        print("%s rows, %s: " % (R, name) + " | ".join("nt=%s %s" % (a, " ".join("%.1f" % x for x in res[a])) for a in ("0", "1", "2", "3")), flush=True)
+        print("%s rows, %s: " % (R, name) + " | ".join("nt=%s %s" % (a, " ".join("%.1f" % x for x in res[a])) for a in ARMS), flush=True)

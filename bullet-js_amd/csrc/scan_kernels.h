@@ -271,6 +271,7 @@ struct EmitIds {  // index position -> node id (bounded by cap)
   uint32_t stream_min = SCAN_STREAM_MIN;       // matches per 8192-row block from which the block streams (a launch argument so that one process can A/B it)
   uint32_t ntx = 0;                            // round 5 A/B (BMX_SCAN_NT): bit 0 = the gathered ids are loaded nontemporally too, bit 1 = the output is stored nontemporally
   __device__ __forceinline__ uint32_t stream_from() const { return stream_min; }
+  __device__ __forceinline__ bool deep() const { return (ntx & 4u) != 0; }      // (uniform) streamed blocks keep 16 loads per lane in flight instead of 8
   __device__ __forceinline__ void st1(uint64_t pos, uint64_t id) const { if (ntx & 2u) __builtin_nontemporal_store((unsigned long long)id, reinterpret_cast<unsigned long long*>(out + pos)); else out[pos] = id; }
   __device__ void operator()(uint64_t pos, uint64_t i) const {
     if (out && pos < cap) st1(pos, (nt && (ntx & 1u)) ? (uint64_t)__builtin_nontemporal_load(reinterpret_cast<const unsigned long long*>(ids + i)) : ids[i]);
@@ -296,6 +297,7 @@ struct EmitPos {  // index position itself (u32, bounded by cap): no read of the
   uint32_t* out; uint64_t cap;
   __device__ void operator()(uint64_t pos, uint64_t i) const { if (out && pos < cap) out[pos] = (uint32_t)i; }
   __device__ __forceinline__ uint32_t stream_from() const { return 0xFFFFFFFFu; }
+  __device__ __forceinline__ bool deep() const { return false; }
   __device__ __forceinline__ void load2(uint64_t, uint64_t&, uint64_t&) const {}
   __device__ __forceinline__ uint64_t load1(uint64_t) const { return 0; }
   __device__ __forceinline__ void put(uint64_t, uint64_t) const {}

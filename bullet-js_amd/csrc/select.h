@@ -135,13 +135,13 @@ constexpr uint32_t SCAN_STREAM_MIN = 2400;
 // them come from the lanes that own them (readlane: no barrier); a lane's rank = that base + the set bits below its two. `r` = exclusive
 // rank of the thread's own word inside the block, `pos0` = rank of the block's first match in the whole answer. Every 512 rows the wave's matches,
 // packed in rank order in ITS 4 KB of LDS (`stg`; nobody else touches it: wave-level ordering only), go out as 16-byte stores.
-template <class Emit>
+template <int U, class Emit>
 __device__ __forceinline__ void scan_emit_stream_block(const Emit& Em, uint32_t mk, uint32_t r, uint64_t pos0, uint64_t block_row0, uint64_t n, uint64_t* stg) {
   const uint32_t lane = threadIdx.x & 63u, w = threadIdx.x >> 6;
   const uint64_t row_w = block_row0 + (uint64_t)w * 2048u + 2u * lane;
   const uint32_t sub = lane >> 4, sh = 2u * (lane & 15u);          // which of the step's four words holds this lane's two rows, and where
   const bool whole = block_row0 + SCAN_BLOCK_ELEMS <= n;             // (uniform) every row of the block exists: loads need no guard
-  constexpr int U = 8;                                                // eight 16-byte loads in flight per lane before the first is used
+  // U 16-byte loads in flight per lane before the first is used (8: round 4; 16: the wave's whole 2048 rows — A/B switch BMX_SCAN_NT bit 2)
   constexpr int F = 4;                                                // steps (of 128 rows) per flush of the wave's LDS
   const uint32_t r_end = (uint32_t)__builtin_amdgcn_readlane((int)r, 63) + (uint32_t)__popc((uint32_t)__builtin_amdgcn_readlane((int)mk, 63));   // rank behind the wave's last row
 #pragma unroll 1
@@ -276,7 +276,8 @@ __global__ __launch_bounds__(SEL_THREADS) void k_scan_emit(const uint32_t* __res
     uint32_t tot;
     uint32_t r = block_excl_scan((uint32_t)__popc(mk), tot, wsum);
     if (Emit::STREAMABLE && tot >= Em.stream_from()) {      // (uniform over the workgroup)
-      scan_emit_stream_block(Em, mk, r, running, (uint64_t)blk * SCAN_BLOCK_ELEMS, n, reinterpret_cast<uint64_t*>(lds_raw) + (threadIdx.x >> 6) * 512u);
+      if (Em.deep()) scan_emit_stream_block<16>(Em, mk, r, running, (uint64_t)blk * SCAN_BLOCK_ELEMS, n, reinterpret_cast<uint64_t*>(lds_raw) + (threadIdx.x >> 6) * 512u);
+      else scan_emit_stream_block<8>(Em, mk, r, running, (uint64_t)blk * SCAN_BLOCK_ELEMS, n, reinterpret_cast<uint64_t*>(lds_raw) + (threadIdx.x >> 6) * 512u);
       running += tot;
       continue;
     }
