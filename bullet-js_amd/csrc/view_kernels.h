@@ -5,10 +5,15 @@
 // (scan_kernels.h: the index columns sorted by (value, position)) used to be thrown away by any write to its field and sorted again from
 // scratch. Here the merges' change log is turned into a CHANGE RUN — for every index row whose value really changed: the key it had,
 // (old value, position), and the key it has now; for every appended row: its key — the run is sorted by these kernels (an LDS bitonic
-// sort of 2048-key tiles + rank-merge passes: the run is at most a few million keys and lives in L2 / the Infinity Cache) and merged into the
-// view in ONE streaming pass: every key of the old view that is not deleted moves to (its index - deleted keys in front of it + inserted
-// keys in front of it), every inserted key to (its index + surviving keys in front of it). No atomics, no ordering between workgroups:
-// every output element is computed and written by exactly one thread from ranks in sorted, read-only inputs.
+// sort of 4096-key tiles, three stages per LDS round trip, + merge-path passes: the run is at most a few million keys and lives in L2 / the
+// Infinity Cache). What happens to the sorted run (patch_view_t in bmx.hip):
+//   * small views, or a run larger than a sixteenth of the view: it is merged into the view in ONE streaming pass (k_view_merge): every key of the
+//     old view that is not deleted moves to (its index - deleted keys in front of it + inserted keys in front of it), every inserted key to
+//     (its index + surviving keys in front of it);
+//   * large views: it joins the view's PENDING patch (deleted keys PD, inserted keys PI; k_view_flag_in, the flag selects, k_view_merge2), queries
+//     answer from main - PD + PI (k_ordered_bounds_p / k_ordered_copy_p / k_ordered_filter_p), and the streaming pass runs behind an answer once
+//     the patch has grown.
+// No atomics, no ordering between workgroups: every output element is computed and written by exactly one thread from ranks in sorted, read-only inputs.
 //
 // Keys are (value, position) pairs compared lexicographically; a position occurs at most once among the live keys, so keys are unique.
 // Bytes per patched view of n rows, c changed and a appended rows: n * (w + 12) read + (n + a) * (w + 12) written (w = 4 or 8: the value
@@ -570,20 +575,7 @@ struct EmitRun { const T* xv; const uint32_t* xp; const uint64_t* xi; T* ov; uin
 __global__ __launch_bounds__(256) void k_view_gather_ids(const uint32_t* __restrict__ pos, uint32_t n, const uint64_t* __restrict__ ix_ids, uint64_t* __restrict__ out) {
   for (uint32_t i = blockIdx.x * 256u + threadIdx.x; i < n; i += gridDim.x * 256u) out[i] = ix_ids[pos[i]];
 }
-// Is deleted key i (sorted run D) one of the pending inserted keys? The change run's deleted keys are keys of the LOGICAL view: each is either a live key of main or a
-// pending inserted key — the second kind cancels its insert, the first kind joins the pending deleted keys. PredInPending(want = 1 / 0) selects one kind (select.h).
-template <class T>
-struct PredInPending {
-  static constexpr int E = 1;
-  const T* dv; const uint32_t* dp; const T* iv; const uint32_t* ip; uint32_t ni; uint32_t want;
-  __device__ uint32_t mask(uint64_t first, uint64_t n) const {
-    if (first >= n) return 0u;
-    const T kv = dv[first]; const uint32_t kp = dp[first];
-    const uint32_t at = (uint32_t)vk_bound<T>(iv, ip, 0, ni, kv, kp);
-    const uint32_t in = (at < ni && iv[at] == kv && ip[at] == kp) ? 1u : 0u;
-    return in == want ? 1u : 0u;
-  }
-};
+// the deleted keys of a refresh's run split by k_view_flag_in's flags: EmitKeys copies one kind (select.h)
 template <class T>
 struct EmitKeys { const T* dv; const uint32_t* dp; T* ov; uint32_t* op; __device__ void operator()(uint64_t rank, uint64_t i) const { ov[rank] = dv[i]; op[rank] = dp[i]; } };
 

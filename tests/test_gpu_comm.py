@@ -124,7 +124,8 @@ def test_shards_grow_and_keep_indexes_fresh():
 @pytest.mark.parametrize("N", [1, 3])
 def test_value_ordered_views_on_every_shard(N):
     """bmx_comm_index_set_ordered: every shard answers from its own sorted copy of the index; the union equals the oracle's scan before and after merges
-    that change the field (the queries right after a merge scan the columns, the later ones sort again)."""
+    that change the field (round 4: the queries right after a merge scanned the columns and a later one sorted again; since round 5 every shard patches its view from
+    its own change log)."""
     o = Oracle()
     with bmx.Comm([0] * N, capacity_rows_per_shard=200_000) as c:
         f0 = int(synth.field_hash(0))
