@@ -1102,8 +1102,9 @@ void view_before_use(bmx_ctx* ctx, Index* ix, bool wait) {   // in front of anyt
 //   1. the run's deleted keys (old value, position) and inserted keys (value, position) are sorted;
 //   2. they join the view's PENDING patch (pd, pi): a deleted key that is a pending inserted key cancels it, the others are deleted keys of main; the inserted keys are
 //      merged into pi. All on runs of a few million keys: L2 / Infinity-Cache traffic;
-//   3. once the pending patch holds more than ord_n / 16 keys (or at once, when the run alone does), main is rewritten: one streaming pass, main - pd + pi.
-// A 1M-delta merge into a 10^8-row index: steps 1-2 on every refresh, step 3 on every third or fourth.
+//   3. once the pending patch holds more than ord_n / 16 keys, main is rewritten BEHIND the answer of the query that brought the refresh about: one streaming pass,
+//      main - pd + pi (start_rewrite / finish_rewrite). Only a run of more than ord_n / 4 keys is merged into main at once, in front of the answer.
+// A 1M-delta merge into a 10^8-row index: steps 1-2 on every refresh, step 3 behind every fourth; into a 10^7-row index: step 3 behind every answer.
 template <class T>
 int patch_view_t(bmx_ctx* ctx, Index& ix, uint64_t c, uint64_t n0, uint64_t added) {
   const auto t0 = std::chrono::steady_clock::now();
@@ -1115,7 +1116,8 @@ int patch_view_t(bmx_ctx* ctx, Index& ix, uint64_t c, uint64_t n0, uint64_t adde
     if (std::getenv("BMX_VIEW_DEBUG")) std::fprintf(stderr, "bmx: view patch of field %u gave up (bmx.hip:%d): %s\n", ix.field, line, ctx->err.c_str());
     g_err.clear(); ctx->err.clear(); (void)hipGetLastError(); return 1;
   };
-  const uint64_t thr = std::max<uint64_t>(nx / 16, 1u << 16);
+  const uint64_t thr = std::max<uint64_t>(nx / 16, 1u << 16);                 // a pending patch beyond this many keys makes a rewrite of main due (behind the answer)
+  const uint64_t thr_direct = std::max<uint64_t>(nx / 4, 1u << 16);          // a run beyond this many keys is merged into main at once, in front of the answer
   const uint32_t ntiles_main = (uint32_t)((nx + VIEW_TILE - 1) / VIEW_TILE);
   if (!ensure_hres(ctx) || ensure_view_scratch(ctx, ktot, std::max<uint64_t>(ntiles_main, (ix.npi + ix.npd + VIEW_TILE) / VIEW_TILE + 2))) return soft(__LINE__);
   hipStream_t st = ctx->stream;
@@ -1156,8 +1158,9 @@ int patch_view_t(bmx_ctx* ctx, Index& ix, uint64_t c, uint64_t n0, uint64_t adde
     return true;
   };
   const bool have = ix.npd + ix.npi > 0;
-  if (!ctx->view_pending || (!have && ktot > thr)) {
-    // the run alone is worth a rewrite of main (small indexes: always), or the pending patch is switched off (BMX_VIEW_PENDING=0)
+  if (!ctx->view_pending || (!have && ktot > thr_direct)) {
+    // the run is a large part of the view (joining it to a patch would cost what the rewrite costs), or the pending patch is switched off (BMX_VIEW_PENDING=0).
+    // A run between thr and thr_direct keys joins the (empty) patch and makes the rewrite due at once: the same work, but BEHIND the answer
     if (have) return soft(__LINE__);
     if (c > nx || !rewrite_main(Dv, Dp, c, Iv, Ip, m)) return soft(__LINE__);
   } else {

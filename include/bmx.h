@@ -308,13 +308,14 @@ int bmx_index_refresh_counts(bmx_ctx* ctx, uint64_t* full_builds, uint64_t* incr
  * its new one on every write): a view that is current STAYS current under writes. The refresh that brings the dense columns up to date from the merges' change
  * log also captures the change run — (position, old value) of every row whose value really changed, plus the appended rows — and sorts it (hand-written LDS tile
  * sort + merge-path passes, csrc/view_kernels.h). What happens to the sorted run depends on its size against the view (R rows):
- *   - more than R/16 keys (small indexes: always): the view's main run is rewritten at once, one streaming pass main - deleted + inserted, R * (w + 12) bytes read
- *     and written (w = 4 or 8): ~0.1 ms at 10^7 rows;
+ *   - more than R/4 keys: the view's main run is rewritten at once, in front of the answer: one streaming pass main - deleted + inserted, R * (w + 12) bytes
+ *     read and written (w = 4 or 8);
  *   - otherwise the run joins the view's PENDING PATCH (pd: keys deleted from main, pi: keys inserted, each sorted; a deleted key that is a pending insert cancels
  *     it). Queries answer from main - pd + pi: five k-ary searches instead of two, and the copy skips / appends the patch's keys of the answer's range. When the
  *     patch has grown beyond R/16 keys, main is rewritten with it BEHIND the answer of the query that found it so: the rewrite is enqueued after that answer, reads
  *     main and the patch and writes the second set of columns; the next call that touches the view looks at its completion event and error word and swaps the sets
- *     (or, after a failure, goes on with main and the patch, which were never written). At 10^8 rows and 1M-delta merges on the field: every first query after a
+ *     (or, after a failure, goes on with main and the patch, which were never written). A run of R/16 ... R/4 keys makes the rewrite due at once: the same
+ *     work as a rewrite in front of the answer, but behind it (10^7 rows, 1M-delta merges: every answer is followed by a 0.23-ms rewrite). At 10^8 rows and 1M-delta merges on the field: every first query after a
  *     merge pays the run's sort and the join (0.55-0.81 ms with its answer in host memory), every fourth is followed by a 1.3-1.8 ms rewrite that nobody waits for
  *     unless the next merge + query arrive within that time.
  * All of it is paid by the first query after any number of merges on the field, never by the merges; merges on other fields, merges that lose and rewrites of
