@@ -1238,6 +1238,10 @@ int patch_view_t(bmx_ctx* ctx, Index& ix, uint64_t c, uint64_t n0, uint64_t adde
 // appended in log order, then every logged row of the field gets its current value. One host sync at the end (appended counts, wide flags).
 // An index whose value-ordered view is current goes on being current: the refresh captures the change run and the view is patched with it.
 int refresh_from_log(bmx_ctx* ctx) {
+  const bool dbg_t = std::getenv("BMX_VIEW_DEBUG") != nullptr;
+  const auto dbg_t0 = std::chrono::steady_clock::now();
+  auto dbg_us = [&]() { return std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - dbg_t0).count(); };
+  double dbg_sync = 0;
   const unsigned long long* n_dev = &ctx->ds->chg_n[ctx->chg_par];
   const uint64_t ub = ctx->chg_ub;
   struct Res { unsigned long long added; uint32_t wide; uint32_t changed; unsigned long long run; };     // (wide, changed: the two halves of one result word)
@@ -1296,6 +1300,7 @@ int refresh_from_log(bmx_ctx* ctx) {
     // one copy of the indexes' (added, wide | changed) words into the mapped result words; the change runs' lengths were written there by their selects
     HIPCHK(hipMemcpyAsync(const_cast<unsigned long long*>(&ctx->hres[HRES_TOTALS]), ctx->ds->part_totals, 2 * ctx->indexes.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost, ctx->stream));
     HIPCHK(hipStreamSynchronize(ctx->stream));
+    dbg_sync = dbg_us();
     for (size_t k = 0; k < ctx->indexes.size(); k++) {
       res[k].added = ctx->hres[HRES_TOTALS + 2 * k];
       const unsigned long long wc = ctx->hres[HRES_TOTALS + 2 * k + 1];
@@ -1326,6 +1331,7 @@ int refresh_from_log(bmx_ctx* ctx) {
     ix.version = ctx->version;
   }
   ctx->ix_incremental++;
+  if (dbg_t) std::fprintf(stderr, "bmx: refresh from the log: columns up to date after %.1f us, patches done after %.1f us\n", dbg_sync, dbg_us());
   return BMX_OK;
 }
 
