@@ -1549,12 +1549,19 @@ int run_scan_t(bmx_ctx* ctx, const Pred& P, const Index* ix, void* out_v, uint64
   constexpr uint64_t SCAN_PIN_IDS = 16384;
   static_assert(SCAN_PIN_IDS * 8 + 8 <= SMALL_OUT_BYTES, "pinned scan answer fits the small-call buffer");
   const bool pinned = host && !ctx->scan_defer && (!out_ids || std::min<uint64_t>(cap, ix->n) <= SCAN_PIN_IDS) && ensure_pinned(ctx);
+  bool direct_host = false;
   if (host && out_ids) {
     d_cap = std::min<uint64_t>(cap, ix->n);
     if (pinned) d_out = reinterpret_cast<OutT*>(ctx->pin_out);
     else {
-      if ((rc = ensure_scan_out(ctx, std::max<uint64_t>(d_cap, 1)))) return rc;
-      d_out = reinterpret_cast<OutT*>(ctx->scan_out);
+      // a caller's buffer in page-locked memory (bmx_host_alloc, hipHostMalloc, a registered range) is written by the kernels themselves: no staging copy behind the answer
+      hipPointerAttribute_t at{};
+      if (!ctx->scan_defer && hipPointerGetAttributes(&at, out_ids) == hipSuccess && at.type == hipMemoryTypeHost && at.devicePointer) { d_out = static_cast<OutT*>(at.devicePointer); direct_host = true; }
+      else {
+        (void)hipGetLastError();
+        if ((rc = ensure_scan_out(ctx, std::max<uint64_t>(d_cap, 1)))) return rc;
+        d_out = reinterpret_cast<OutT*>(ctx->scan_out);
+      }
     }
   }
   if ((rc = ensure_scan_scratch(ctx, std::max<uint64_t>(ix->n, 1)))) return rc;
@@ -1611,7 +1618,7 @@ int run_scan_t(bmx_ctx* ctx, const Pred& P, const Index* ix, void* out_v, uint64
     if (!hres_n) HIPCHK(hipMemcpyAsync(&m, &ctx->ds->n_out, sizeof(m), hipMemcpyDeviceToHost, ctx->stream));
     HIPCHK(hipStreamSynchronize(ctx->stream));
     if (hres_n) m = ctx->hres[HRES_SCAN_N];
-    if (out_ids && m) HIPCHK(hipMemcpy(out_ids, ctx->scan_out, std::min<uint64_t>(m, d_cap) * sizeof(OutT), hipMemcpyDeviceToHost));
+    if (out_ids && m && !direct_host) HIPCHK(hipMemcpy(out_ids, ctx->scan_out, std::min<uint64_t>(m, d_cap) * sizeof(OutT), hipMemcpyDeviceToHost));
     if (n_out) *n_out = m;
   }
   return BMX_OK;

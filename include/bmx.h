@@ -213,7 +213,8 @@ int bmx_merge_submit(bmx_ctx* ctx, uint64_t n, const uint64_t* id, const uint32_
 int bmx_merge_collect(bmx_ctx* ctx, uint64_t ticket, uint32_t* applied_idx, uint64_t* n_applied, uint8_t* flags, bmx_merge_stats* stats);
 /* Page-locked host memory for the arrays handed to BMX_MEM_HOST calls (inputs and outputs): copies to and from it run at the link's rate and
  * without the runtime's own staging, where pageable memory costs an extra pass (a 1M-delta host batch: 0.76 ms against 1.2 ms on MI355X, and
- * ~17 ms the first time a fresh pageable array is seen). Usable with every context of the process, on any device. Nothing requires it:
+ * ~17 ms the first time a fresh pageable array is seen). A BMX_MEM_HOST scan whose out buffer lies in such memory (or in any page-locked range the runtime
+ * knows) has its answer written there by the kernels themselves — no staging copy behind the answer. Usable with every context of the process, on any device. Nothing requires it:
  * any host pointer is accepted everywhere. (The reference has no counterpart: its batches are JS objects, src/bullet-network-sync.js:551-569.) */
 int bmx_host_alloc(uint64_t bytes, void** host_ptr);
 int bmx_host_free(void* host_ptr);

@@ -524,3 +524,31 @@ def test_failures_of_the_patch_and_of_the_background_rewrite_cost_time_never_ans
             assert e.index_ordered_stats(FA)["sorts"] >= 4
         else:
             assert pend == sorted(pend) and pend[-1] > 3 * (R // 16), pend          # nothing was ever folded into main: the patch only grows, well past its threshold
+
+
+def test_host_mode_answers_written_straight_into_a_page_locked_caller_buffer():
+    """A host-mode scan whose out buffer lives in page-locked memory (bmx_host_alloc) is written by the kernels themselves, no staging copy: column scan and view, answers
+    beyond the small-answer path, a cap smaller than the answer, and the same calls into ordinary (pageable) arrays."""
+    R = 600_000
+    rng = np.random.default_rng(3)
+    ids = streams.splitmix64_np(np.arange(1, R + 1, dtype=np.uint64))
+    vals = rng.integers(0, 50, R).astype(np.int64)
+    hb = bmx.HostBuffer(R * 8)
+    with bmx.Engine(2 * R) as e:
+        e.load_rows(ids, np.full(R, FA, np.uint32), np.full(R, 5, np.int64), vals)
+        e.index_build(FA)
+        for ordered in (0, 1):
+            e.index_set_ordered(FA, ordered)
+            for lo, hi in [(0, 49), (10, 19), (7, 7), (60, 70)]:
+                want = np.sort(ids[(vals >= lo) & (vals <= hi)])
+                pinned = hb.array(np.uint64, R); pinned[:] = 0
+                got = e.scan_range(FA, lo, hi, out=pinned)
+                assert len(got) == len(want) and np.array_equal(np.sort(got), want), (ordered, lo, hi)
+                plain = np.zeros(R, np.uint64)
+                got2 = e.scan_range(FA, lo, hi, out=plain)
+                assert np.array_equal(np.sort(got2), want)
+            small = hb.array(np.uint64, 20_000); small[:] = 0                     # room for fewer ids than match: the first 20000 of the answer, the count says how many there are
+            got = e.scan_range(FA, 0, 49, out=small)
+            assert len(got) == 20_000 and np.all(np.isin(got, ids)) and len(np.unique(got)) == 20_000
+            assert e.scan_count(FA, 0, 49) == R
+    hb.close()
