@@ -1182,7 +1182,7 @@ int patch_view_t(bmx_ctx* ctx, Index& ix, uint64_t c, uint64_t n0, uint64_t adde
       (void)hipMemcpyAsync(pdv[dc], Dv, c * sizeof(T), hipMemcpyDeviceToDevice, st); (void)hipMemcpyAsync(ix.pd_p[dc], Dp, c * 4, hipMemcpyDeviceToDevice, st);
       ViewRun<T> none{nullptr, nullptr, nullptr}, Zi{piv[ic], ix.pi_p[ic], ix.pi_ids[ic]};
       merge2(true, none, 0, Iv, Ip, m, Zi);                             // (the inserted keys with their ids)
-      if (finish()) return soft(__LINE__);
+      if (hipGetLastError() != hipSuccess) return soft(__LINE__);       // (nothing here raises the error word, and everything that reads the patch is behind it on this stream: no synchronisation)
       ix.npd = c; ix.npi = m;
     } else {
       // 2. which deleted keys are pending inserted keys (they cancel), which are keys of main (they join pd)? one flag per key, two ordered selects by flag
@@ -1222,7 +1222,7 @@ int patch_view_t(bmx_ctx* ctx, Index& ix, uint64_t c, uint64_t n0, uint64_t adde
       if (m) merge2(true, Ai, na, Iv, Ip, m, Zi);
       ViewRun<T> Ad{pdv[dc], ix.pd_p[dc], nullptr}, Zd{pdv[dc ^ 1], ix.pd_p[dc ^ 1], nullptr};
       if (cX) merge2(false, Ad, ix.npd, (const T*)sel_v, (const uint32_t*)sel_p, cX, Zd);
-      if (finish()) return soft(__LINE__);
+      if (hipGetLastError() != hipSuccess) return soft(__LINE__);       // (nothing here raises the error word, and everything that reads the patch is behind it on this stream: no synchronisation)
       ix.icur = m ? ia ^ 1 : ia; if (cX) ix.pcur = dc ^ 1;
       ix.npd += cX; ix.npi = na + m;
     }

@@ -332,7 +332,8 @@ int bmx_index_refresh_counts(bmx_ctx* ctx, uint64_t* full_builds, uint64_t* incr
  * the view of its FIRST term's index when there is one: the other terms are probed for the ids of one run only (survivors then come in no particular order).
  * If the memory cannot be had the index silently goes on without the view. bmx_index_ordered_info: N, whether the view would answer the next query, and how many
  * sorts have run; bmx_index_ordered_stats: sorts, patches, keys moved by the patches (deleted + inserted), what the last sort / the last patch cost the
- * caller in microseconds, rewrites of main that have completed, and the keys in the pending patch now (outputs may be NULL). */
+ * caller in microseconds (the patch: the host's time in it — a run that joins the pending patch is not waited for, the query behind it on the stream is), rewrites of
+ * main that have completed, and the keys in the pending patch now (outputs may be NULL). */
 #define BMX_INDEX_ORDERED_AUTO 0xFFFFFFFFu   /* after_queries chosen by the engine: sort once the scans since the change have cost what the sort costs (rent-or-buy:
                                                * never more than twice the cheapest schedule, whatever comes next): ~70 queries on 10^8 int32 rows, ~25 on 10^7 */
 int bmx_index_set_ordered(bmx_ctx* ctx, uint32_t field, uint32_t after_queries);
