@@ -317,7 +317,7 @@ int bmx_index_refresh_counts(bmx_ctx* ctx, uint64_t* full_builds, uint64_t* incr
  *     main and the patch and writes the second set of columns; the next call that touches the view looks at its completion event and error word and swaps the sets
  *     (or, after a failure, goes on with main and the patch, which were never written). A run of R/16 ... R/4 keys makes the rewrite due at once: the same
  *     work as a rewrite in front of the answer, but behind it (10^7 rows, 1M-delta merges: every answer is followed by a 0.23-ms rewrite). At 10^8 rows and 1M-delta merges on the field: every first query after a
- *     merge pays the run's sort and the join (0.56-0.84 ms with its answer in host memory), every fourth is followed by a 1.3-1.8 ms rewrite that nobody waits for
+ *     merge pays the run's sort and the join (0.53-0.81 ms with its answer in host memory), every fourth is followed by a 1.3-1.8 ms rewrite that nobody waits for
  *     unless the next merge + query arrive within that time.
  * All of it is paid by the first query after any number of merges on the field, never by the merges; merges on other fields, merges that lose and rewrites of
  * the same value cost nothing. ORDER of a view's answers: survivors of main in (value, position) order, then the range's pending inserts in (value, position)
